@@ -1,0 +1,179 @@
+/* openrec_hip.h -- C ABI of the MI355X-native OpenRec training hot path.
+ *
+ * The reference (ylongqi/openrec, /root/reference) has NO FFI boundary: the
+ * path is reached through Python classes on top of TensorFlow.  This header is
+ * the boundary a maintainer would bind instead (ctypes stub in INTEGRATION.md);
+ * every entry point cites the reference interface it replaces (paths relative
+ * to /root/reference).
+ *
+ * Conventions
+ *   - every function returns int: 0 = ORX_OK, < 0 = error; the message is
+ *     available from orx_last_error() (thread local).  Nothing aborts, no C++
+ *     exception crosses the boundary.
+ *   - handles (orx_ctx / orx_table / orx_opt) are opaque and owned by the
+ *     library; pointer arguments are caller-owned and only need to stay valid
+ *     for the duration of the call.
+ *   - tables are fp32, row-major [rows, dim], resident in HBM for their whole
+ *     life (Keras Embedding weight layout, latent_factor.py:12-15).
+ *   - ids are int32 (openrec/tf2/data/dataset.py:113-115).  With
+ *     ORX_IDS_DEVICE the id pointers are device pointers, otherwise host.
+ *   - calls on one context are serialized on that context's HIP stream; a
+ *     context is not thread-safe, distinct contexts are independent.
+ *   - there is no CPU fallback: every call fails with ORX_ERR_HIP if no
+ *     gfx950 device is usable.
+ */
+#ifndef OPENREC_HIP_H
+#define OPENREC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orx_ctx orx_ctx;
+typedef struct orx_table orx_table;
+typedef struct orx_opt orx_opt;
+
+enum orx_status {
+    ORX_OK = 0,
+    ORX_ERR_ARG = -1,    /* bad argument / handle / shape                      */
+    ORX_ERR_HIP = -2,    /* HIP runtime error (message has hipGetErrorString)  */
+    ORX_ERR_OOM = -3,    /* device allocation failed                           */
+    ORX_ERR_INDEX = -4,  /* id out of range (TF CPU gather raises, bpr.py:23)  */
+    ORX_ERR_STATE = -5   /* call sequence error                                */
+};
+
+/* tensorflow.keras.optimizers.* used by tf2_examples/bpr_citeulike.py:31 */
+enum orx_opt_kind { ORX_SGD = 0, ORX_ADAGRAD = 1, ORX_ADAM = 2 };
+
+/* pairwise recommenders: recommenders/bpr.py:5, recommenders/ucml.py:5 */
+enum orx_pair_model { ORX_BPR = 0, ORX_UCML = 1 };
+/* pointwise recommenders: recommenders/gmf.py:5, recommenders/wrmf.py:5 */
+enum orx_point_model { ORX_GMF = 0, ORX_WRMF = 1 };
+
+enum orx_flags {
+    ORX_IDS_DEVICE = 1,   /* id / label pointers are device pointers            */
+    ORX_HOGWILD = 2,      /* skip duplicate handling: one in-place racy pass
+                             (NOT reference semantics; speed comparisons only)  */
+    ORX_NO_L2 = 4         /* objective = loss only (tape over `loss` alone)
+                             instead of the example's (loss, l2_loss) tuple     */
+};
+
+/* kernels whose device time can be sampled with orx_prof_* */
+enum orx_kernel_id {
+    ORX_K_COUNT = 0,      /* per-row reference counting (duplicate detection)   */
+    ORX_K_FUSED = 1,      /* fused gather-score-loss-grad-update (dominant)     */
+    ORX_K_DUP = 2,        /* duplicate-row finalize + loss reduce               */
+    ORX_K_SWEEP = 3,      /* Adam dense-decay sweep                             */
+    ORX_K_CENSOR = 4,
+    ORX_K_POINT = 5,      /* fused pointwise (GMF/WRMF) step                    */
+    ORX_K_NUM = 6
+};
+
+int orx_version(void);
+const char* orx_last_error(void);
+
+/* ---- context ----------------------------------------------------------
+ * device: HIP ordinal.  stream: an existing hipStream_t to enqueue on (e.g.
+ * torch's current stream) or NULL to create a private one. */
+int orx_ctx_create(int device, void* stream, orx_ctx** out);
+int orx_ctx_destroy(orx_ctx* ctx);
+int orx_synchronize(orx_ctx* ctx);
+/* raises the sticky "id out of range" condition recorded by the kernels
+ * (returns ORX_ERR_INDEX once, then clears it).  Synchronizes. */
+int orx_check_index_error(orx_ctx* ctx);
+
+/* ---- tables: replace LatentFactor.__init__/variables (latent_factor.py:6-15)
+ * orx_table_wrap adopts caller-owned device memory (e.g. a torch tensor). */
+int orx_table_create(orx_ctx* ctx, int64_t rows, int32_t dim, orx_table** out);
+int orx_table_wrap(orx_ctx* ctx, void* device_ptr, int64_t rows, int32_t dim, orx_table** out);
+int orx_table_destroy(orx_table* t);
+int64_t orx_table_rows(const orx_table* t);
+int32_t orx_table_dim(const orx_table* t);
+void* orx_table_device_ptr(const orx_table* t);
+/* Keras 'uniform' initializer = U(-0.05, 0.05) / 'zeros' (latent_factor.py:8-11) */
+int orx_table_init_uniform(orx_table* t, float lo, float hi, uint64_t seed);
+int orx_table_fill(orx_table* t, float value);
+/* checkpoint / parity access: rows [row0, row0+nrows) <-> host fp32 */
+int orx_table_read(orx_table* t, int64_t row0, int64_t nrows, float* host_dst);
+int orx_table_write(orx_table* t, int64_t row0, int64_t nrows, const float* host_src);
+/* LatentFactor.__call__ = Embedding gather (bpr.py:23-27): out[k,:] = W[ids[k],:].
+ * ids/out are host unless ORX_IDS_DEVICE (then both are device pointers). */
+int orx_table_gather(orx_table* t, const int32_t* ids, int64_t n, float* out, int flags);
+/* LatentFactor.censor (latent_factor.py:17-23): for each DISTINCT id,
+ * W[i] <- W[i] / max(||W[i]||_2, min_norm). */
+int orx_table_censor(orx_table* t, const int32_t* ids, int64_t n, float min_norm, int flags);
+
+/* ---- optimizers: replace optimizers.{SGD,Adagrad,Adam}.apply_gradients
+ * (tf2_examples/bpr_citeulike.py:31,38) with TF-2.0 sparse-apply semantics.
+ *   SGD:     p0..p2 unused
+ *   ADAGRAD: p0 = initial_accumulator_value, p1 = epsilon
+ *   ADAM:    p0 = beta_1, p1 = beta_2, p2 = epsilon   (dense-decay sparse apply) */
+int orx_opt_create(orx_ctx* ctx, int kind, float lr, float p0, float p1, float p2, orx_opt** out);
+int orx_opt_destroy(orx_opt* opt);
+int orx_opt_set_lr(orx_opt* opt, float lr);
+/* read/write an optimizer slot of a table (checkpointing, parity):
+ * slot 0 = Adagrad accumulator / Adam m, slot 1 = Adam v. */
+int orx_opt_slot_read(orx_opt* opt, orx_table* t, int slot, int64_t row0, int64_t nrows, float* host_dst);
+int orx_opt_slot_write(orx_opt* opt, orx_table* t, int slot, int64_t row0, int64_t nrows, const float* host_src);
+
+/* ---- the hot path ------------------------------------------------------
+ * K consecutive train steps of BPR.call / UCML.call + tape.gradient((loss,
+ * l2_loss)) + optimizer.apply_gradients  (bpr.py:21-37, ucml.py:21-42,
+ * pairwise_log_loss.py:15-34, tf2_examples/bpr_citeulike.py:33-39).
+ *   user/item/bias : tables [NU,D], [NI,D], [NI,1]
+ *   uid/pid/nid    : int32, step s uses elements [s*id_stride, s*id_stride+B)
+ *   margin         : UCML margin (ucml.py:7); ignored for BPR
+ *   loss_out/l2_out: host float[K] or NULL (NULL = fully asynchronous call)
+ * Gradients of every step are taken on the pre-step tables (snapshot
+ * semantics), duplicates handled as TF does (SGD accumulates every
+ * occurrence; Adagrad/Adam sum duplicates first). */
+int orx_pairwise_step(orx_ctx* ctx, int model, orx_opt* opt,
+                      orx_table* user, orx_table* item, orx_table* bias,
+                      const int32_t* uid, const int32_t* pid, const int32_t* nid,
+                      int64_t K, int64_t B, int64_t id_stride, float margin, int flags,
+                      float* loss_out, float* l2_out);
+
+/* Forward only: (loss, l2_loss) of one batch without touching the tables
+ * (BPR.call / UCML.call outside a tape). */
+int orx_pairwise_loss(orx_ctx* ctx, int model,
+                      orx_table* user, orx_table* item, orx_table* bias,
+                      const int32_t* uid, const int32_t* pid, const int32_t* nid,
+                      int64_t B, float margin, int flags, float* loss_out, float* l2_out);
+
+/* K train steps of GMF.call / WRMF.call (gmf.py:22-34, wrmf.py:21-34,
+ * pointwise_mse_loss.py:18-31).  w: GMF's Dense(1, use_bias=False) kernel as a
+ * [D,1] table (NULL for WRMF).  a, b: WRMF confidence weights (wrmf.py:7). */
+int orx_pointwise_step(orx_ctx* ctx, int model, orx_opt* opt,
+                       orx_table* user, orx_table* item, orx_table* bias, orx_table* w,
+                       const int32_t* uid, const int32_t* iid, const float* label,
+                       int64_t K, int64_t B, int64_t id_stride, float a, float b, int flags,
+                       float* loss_out, float* l2_out);
+
+/* ---- sharded building blocks (row-wise sharded tables, one rank per GPU;
+ * the exchange itself is RCCL all-to-all driven by the host, see
+ * openrec_amd/sharded.py).  All pointers are DEVICE pointers.
+ *   gather_rows : out[k, 0:D] = W[ids[k]], out[k, D] = bias[ids[k]] (bias may be NULL)
+ *   pair_grads  : per-occurrence gradients of J from already gathered rows
+ *   apply_rows  : optimizer sparse apply of per-occurrence gradient rows
+ */
+int orx_gather_rows(orx_ctx* ctx, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
+                    float* out, int64_t out_stride);
+int orx_pair_grads(orx_ctx* ctx, int model, int32_t D,
+                   const float* u_rows, const float* p_rows, const float* n_rows, int64_t row_stride,
+                   int64_t B, int64_t B_global, float margin, int flags,
+                   float* gu, float* gp, float* gn, int64_t g_stride, double* loss_l2_accum);
+int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias,
+                   const int32_t* ids, int64_t n, const float* grads, int64_t g_stride);
+
+/* ---- device-time sampling of the kernels (HIP events on the ctx stream) --- */
+int orx_prof_enable(orx_ctx* ctx, int on);
+int orx_prof_reset(orx_ctx* ctx);
+/* total device milliseconds and launch count recorded for kernel `kid` */
+int orx_prof_get(orx_ctx* ctx, int kid, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENREC_HIP_H */

@@ -1,0 +1,103 @@
+"""ctypes binding of include/openrec_hip.h (libopenrec_hip.so, built in-tree by
+openrec_amd.build).  There is no CPU fallback: if the library cannot be loaded
+the import fails loudly, and every call fails if no HIP device is usable."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_lib", "libopenrec_hip.so")
+
+ORX_OK, ORX_ERR_ARG, ORX_ERR_HIP, ORX_ERR_OOM, ORX_ERR_INDEX, ORX_ERR_STATE = 0, -1, -2, -3, -4, -5
+ORX_SGD, ORX_ADAGRAD, ORX_ADAM = 0, 1, 2
+ORX_BPR, ORX_UCML = 0, 1
+ORX_GMF, ORX_WRMF = 0, 1
+ORX_IDS_DEVICE, ORX_HOGWILD, ORX_NO_L2 = 1, 2, 4
+ORX_K_COUNT, ORX_K_FUSED, ORX_K_DUP, ORX_K_SWEEP, ORX_K_CENSOR, ORX_K_POINT, ORX_K_NUM = 0, 1, 2, 3, 4, 5, 6
+KERNEL_NAMES = {ORX_K_COUNT: "count", ORX_K_FUSED: "fused", ORX_K_DUP: "dup", ORX_K_SWEEP: "adam_sweep",
+                ORX_K_CENSOR: "censor", ORX_K_POINT: "pointwise"}
+
+_p = c_void_p
+_pp = POINTER(c_void_p)
+_ip = c_void_p      # int32* (host numpy .ctypes.data or device pointer)
+_fp = c_void_p      # float*
+
+# name -> (restype, argtypes); must list EVERY symbol declared in include/openrec_hip.h
+SIGNATURES = {
+    "orx_version": (c_int, []),
+    "orx_last_error": (c_char_p, []),
+    "orx_ctx_create": (c_int, [c_int, _p, _pp]),
+    "orx_ctx_destroy": (c_int, [_p]),
+    "orx_synchronize": (c_int, [_p]),
+    "orx_check_index_error": (c_int, [_p]),
+    "orx_table_create": (c_int, [_p, c_int64, c_int32, _pp]),
+    "orx_table_wrap": (c_int, [_p, _p, c_int64, c_int32, _pp]),
+    "orx_table_destroy": (c_int, [_p]),
+    "orx_table_rows": (c_int64, [_p]),
+    "orx_table_dim": (c_int32, [_p]),
+    "orx_table_device_ptr": (c_void_p, [_p]),
+    "orx_table_init_uniform": (c_int, [_p, c_float, c_float, c_uint64]),
+    "orx_table_fill": (c_int, [_p, c_float]),
+    "orx_table_read": (c_int, [_p, c_int64, c_int64, _fp]),
+    "orx_table_write": (c_int, [_p, c_int64, c_int64, _fp]),
+    "orx_table_gather": (c_int, [_p, _ip, c_int64, _fp, c_int]),
+    "orx_table_censor": (c_int, [_p, _ip, c_int64, c_float, c_int]),
+    "orx_opt_create": (c_int, [_p, c_int, c_float, c_float, c_float, c_float, _pp]),
+    "orx_opt_destroy": (c_int, [_p]),
+    "orx_opt_set_lr": (c_int, [_p, c_float]),
+    "orx_opt_slot_read": (c_int, [_p, _p, c_int, c_int64, c_int64, _fp]),
+    "orx_opt_slot_write": (c_int, [_p, _p, c_int, c_int64, c_int64, _fp]),
+    "orx_pairwise_step": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, _ip, _ip, c_int64, c_int64, c_int64,
+                                  c_float, c_int, _fp, _fp]),
+    "orx_pairwise_loss": (c_int, [_p, c_int, _p, _p, _p, _ip, _ip, _ip, c_int64, c_float, c_int, _fp, _fp]),
+    "orx_pointwise_step": (c_int, [_p, c_int, _p, _p, _p, _p, _p, _ip, _ip, _fp, c_int64, c_int64, c_int64,
+                                   c_float, c_float, c_int, _fp, _fp]),
+    "orx_gather_rows": (c_int, [_p, _p, _p, _ip, c_int64, _fp, c_int64]),
+    "orx_pair_grads": (c_int, [_p, c_int, c_int32, _fp, _fp, _fp, c_int64, c_int64, c_int64, c_float, c_int,
+                               _fp, _fp, _fp, c_int64, _p]),
+    "orx_apply_rows": (c_int, [_p, _p, _p, _p, _ip, c_int64, _fp, c_int64]),
+    "orx_prof_enable": (c_int, [_p, c_int]),
+    "orx_prof_reset": (c_int, [_p]),
+    "orx_prof_get": (c_int, [_p, c_int, POINTER(c_double), POINTER(c_int64)]),
+}
+
+_lib = None
+
+
+class OrxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[orx {code}] {msg}")
+        self.code = code
+
+
+def load():
+    """Load the shared library and attach signatures (no HIP call is made)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m openrec_amd.build` "
+            "(hipcc, gfx950).  openrec_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == ORX_OK:
+        return
+    msg = load().orx_last_error().decode("utf-8", "replace")
+    if rc == ORX_ERR_INDEX:
+        raise IndexError(msg)          # the reference's CPU gather raises on an out-of-range id
+    if rc == ORX_ERR_OOM:
+        raise MemoryError(msg)
+    if rc == ORX_ERR_ARG:
+        raise ValueError(msg)
+    raise OrxError(rc, msg)

@@ -1,0 +1,489 @@
+// C-ABI entry points (include/openrec_hip.h): contexts, tables, optimizers and
+// the host-side sequencing of the train-step kernels.  No torch, no CPU
+// fallback: every entry point needs a usable HIP device.
+#include <cmath>
+#include <cstring>
+
+#include "orx_internal.h"
+
+// ----------------------------------------------------------------- errors ---
+static thread_local char g_err[1024] = "";
+
+void orx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* orx_last_error(void) { return g_err; }
+extern "C" int orx_version(void) { return 100; }
+
+// ---------------------------------------------------------------- helpers ---
+int orx_ensure(void** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *p != nullptr) return ORX_OK;
+    if (*p) { ORX_HIP(hipFree(*p)); *p = nullptr; *cap = 0; }
+    size_t want = bytes < 4096 ? 4096 : bytes;
+    ORX_HIP(hipMalloc(p, want));
+    *cap = want;
+    return ORX_OK;
+}
+
+#define ENSURE(ptr, cap, bytes)                                                        \
+    do {                                                                               \
+        int _rc = orx_ensure((void**)&(ptr), &(cap), (bytes));                         \
+        if (_rc != ORX_OK) return _rc;                                                 \
+    } while (0)
+
+#define CHECK(call)                                                                    \
+    do {                                                                               \
+        int _rc = (call);                                                              \
+        if (_rc != ORX_OK) return _rc;                                                 \
+    } while (0)
+
+void orx_prof_begin(orx_ctx* ctx, int kid) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+    hipEventRecord(e0, ctx->stream);
+    ctx->prof_slot[kid].ev.push_back(e0);
+    ctx->prof_slot[kid].ev.push_back(e1);
+}
+
+void orx_prof_end(orx_ctx* ctx, int kid) {
+    auto& ev = ctx->prof_slot[kid].ev;
+    if (ev.size() >= 2) hipEventRecord(ev.back(), ctx->stream);
+}
+
+static int prof_collect(orx_ctx* ctx) {
+    for (int k = 0; k < ORX_K_NUM; ++k) {
+        auto& s = ctx->prof_slot[k];
+        for (size_t i = 0; i + 1 < s.ev.size(); i += 2) {
+            float ms = 0.f;
+            ORX_HIP(hipEventSynchronize(s.ev[i + 1]));
+            ORX_HIP(hipEventElapsedTime(&ms, s.ev[i], s.ev[i + 1]));
+            s.total_ms += ms;
+            s.launches += 1;
+            hipEventDestroy(s.ev[i]);
+            hipEventDestroy(s.ev[i + 1]);
+        }
+        s.ev.clear();
+    }
+    return ORX_OK;
+}
+
+// ---------------------------------------------------------------- context ---
+extern "C" int orx_ctx_create(int device, void* stream, orx_ctx** out) {
+    ORX_ARG(out != nullptr, "orx_ctx_create: out is NULL");
+    int ndev = 0;
+    ORX_HIP(hipGetDeviceCount(&ndev));
+    ORX_ARG(device >= 0 && device < ndev, "orx_ctx_create: device %d out of range (%d devices)", device, ndev);
+    ORX_HIP(hipSetDevice(device));
+    orx_ctx* c = new orx_ctx();
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { ORX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    ORX_HIP(hipMalloc((void**)&c->d_err, sizeof(int)));
+    ORX_HIP(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    hipDeviceProp_t prop;
+    ORX_HIP(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount;
+    *out = c;
+    return ORX_OK;
+}
+
+extern "C" int orx_ctx_destroy(orx_ctx* c) {
+    if (!c) return ORX_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dupmask);
+    hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return ORX_OK;
+}
+
+extern "C" int orx_synchronize(orx_ctx* c) {
+    ORX_ARG(c, "orx_synchronize: NULL context");
+    ORX_HIP(hipStreamSynchronize(c->stream));
+    return ORX_OK;
+}
+
+extern "C" int orx_check_index_error(orx_ctx* c) {
+    ORX_ARG(c, "orx_check_index_error: NULL context");
+    int flag = 0;
+    ORX_HIP(hipMemcpyAsync(&flag, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    ORX_HIP(hipStreamSynchronize(c->stream));
+    if (flag) {
+        ORX_HIP(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+        orx_set_error("id out of range: an index in the batch is < 0 or >= the table's row count");
+        return ORX_ERR_INDEX;
+    }
+    return ORX_OK;
+}
+
+// ----------------------------------------------------------------- tables ---
+static int table_new(orx_ctx* ctx, void* ptr, int64_t rows, int32_t dim, orx_table** out) {
+    ORX_ARG(ctx && out, "table: NULL context/out");
+    ORX_ARG(rows > 0 && dim > 0, "table: rows (%lld) and dim (%d) must be positive", (long long)rows, dim);
+    ORX_ARG(rows <= 0x7fffffffLL, "table: rows must fit int32 ids");
+    ORX_HIP(hipSetDevice(ctx->device));
+    orx_table* t = new orx_table();
+    t->ctx = ctx; t->rows = rows; t->dim = dim;
+    if (ptr) { t->w = (float*)ptr; t->owned = false; }
+    else {
+        hipError_t e = hipMalloc((void**)&t->w, (size_t)rows * dim * sizeof(float));
+        if (e != hipSuccess) {
+            delete t;
+            orx_set_error("table: hipMalloc of %lld x %d fp32 failed: %s", (long long)rows, dim, hipGetErrorString(e));
+            return ORX_ERR_OOM;
+        }
+    }
+    *out = t;
+    return ORX_OK;
+}
+
+extern "C" int orx_table_create(orx_ctx* ctx, int64_t rows, int32_t dim, orx_table** out) {
+    return table_new(ctx, nullptr, rows, dim, out);
+}
+
+extern "C" int orx_table_wrap(orx_ctx* ctx, void* device_ptr, int64_t rows, int32_t dim, orx_table** out) {
+    ORX_ARG(device_ptr, "orx_table_wrap: NULL device pointer");
+    return table_new(ctx, device_ptr, rows, dim, out);
+}
+
+extern "C" int orx_table_destroy(orx_table* t) {
+    if (!t) return ORX_OK;
+    hipSetDevice(t->ctx->device);
+    hipStreamSynchronize(t->ctx->stream);
+    if (t->owned) hipFree(t->w);
+    hipFree(t->cnt);
+    hipFree(t->gsum);
+    delete t;
+    return ORX_OK;
+}
+
+extern "C" int64_t orx_table_rows(const orx_table* t) { return t ? t->rows : -1; }
+extern "C" int32_t orx_table_dim(const orx_table* t) { return t ? t->dim : -1; }
+extern "C" void* orx_table_device_ptr(const orx_table* t) { return t ? (void*)t->w : nullptr; }
+
+int orx_table_scratch(orx_table* t) {
+    if (t->cnt && t->gsum) return ORX_OK;
+    ORX_HIP(hipSetDevice(t->ctx->device));
+    if (!t->cnt) {
+        ORX_HIP(hipMalloc((void**)&t->cnt, (size_t)t->rows * sizeof(int)));
+        ORX_HIP(hipMemsetAsync(t->cnt, 0, (size_t)t->rows * sizeof(int), t->ctx->stream));
+    }
+    if (!t->gsum) {
+        ORX_HIP(hipMalloc((void**)&t->gsum, (size_t)t->rows * t->dim * sizeof(float)));
+        ORX_HIP(hipMemsetAsync(t->gsum, 0, (size_t)t->rows * t->dim * sizeof(float), t->ctx->stream));
+    }
+    return ORX_OK;
+}
+
+extern "C" int orx_table_init_uniform(orx_table* t, float lo, float hi, uint64_t seed) {
+    ORX_ARG(t, "orx_table_init_uniform: NULL table");
+    ORX_HIP(hipSetDevice(t->ctx->device));
+    return orx_launch_init_uniform(t->ctx, t->w, t->rows * t->dim, lo, hi, seed);
+}
+
+extern "C" int orx_table_fill(orx_table* t, float value) {
+    ORX_ARG(t, "orx_table_fill: NULL table");
+    ORX_HIP(hipSetDevice(t->ctx->device));
+    return orx_launch_fill(t->ctx, t->w, t->rows * t->dim, value);
+}
+
+static int rows_copy(orx_ctx* ctx, float* dev, int64_t rows, int32_t dim, int64_t row0, int64_t nrows,
+                     float* host, bool to_host) {
+    ORX_ARG(host || nrows == 0, "table copy: NULL host buffer");
+    ORX_ARG(row0 >= 0 && nrows >= 0 && row0 + nrows <= rows, "table copy: rows [%lld, %lld) outside [0, %lld)",
+            (long long)row0, (long long)(row0 + nrows), (long long)rows);
+    if (nrows == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)nrows * dim * sizeof(float);
+    float* d = dev + (size_t)row0 * dim;
+    if (to_host) ORX_HIP(hipMemcpyAsync(host, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    else ORX_HIP(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ORX_HIP(hipStreamSynchronize(ctx->stream));
+    return ORX_OK;
+}
+
+extern "C" int orx_table_read(orx_table* t, int64_t row0, int64_t nrows, float* host_dst) {
+    ORX_ARG(t, "orx_table_read: NULL table");
+    return rows_copy(t->ctx, t->w, t->rows, t->dim, row0, nrows, host_dst, true);
+}
+
+extern "C" int orx_table_write(orx_table* t, int64_t row0, int64_t nrows, const float* host_src) {
+    ORX_ARG(t, "orx_table_write: NULL table");
+    return rows_copy(t->ctx, t->w, t->rows, t->dim, row0, nrows, (float*)host_src, false);
+}
+
+// upload host ids into the context's staging buffer at element offset `off`
+static int stage_ids(orx_ctx* c, const int32_t* host, int64_t n, int64_t off) {
+    ORX_HIP(hipMemcpyAsync(c->d_ids + off, host, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    return ORX_OK;
+}
+
+extern "C" int orx_table_gather(orx_table* t, const int32_t* ids, int64_t n, float* out, int flags) {
+    ORX_ARG(t && (n == 0 || (ids && out)), "orx_table_gather: NULL argument");
+    if (n == 0) return ORX_OK;
+    orx_ctx* c = t->ctx;
+    ORX_HIP(hipSetDevice(c->device));
+    if (flags & ORX_IDS_DEVICE) {
+        CHECK(orx_launch_gather(c, t->w, nullptr, t->rows, t->dim, ids, n, out, t->dim, c->d_err));
+        return ORX_OK;
+    }
+    ENSURE(c->d_ids, c->d_ids_cap, (size_t)n * sizeof(int32_t));
+    ENSURE(c->d_tmp, c->d_tmp_cap, (size_t)n * t->dim * sizeof(float));
+    CHECK(stage_ids(c, ids, n, 0));
+    CHECK(orx_launch_gather(c, t->w, nullptr, t->rows, t->dim, c->d_ids, n, c->d_tmp, t->dim, c->d_err));
+    ORX_HIP(hipMemcpyAsync(out, c->d_tmp, (size_t)n * t->dim * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return orx_check_index_error(c);
+}
+
+extern "C" int orx_table_censor(orx_table* t, const int32_t* ids, int64_t n, float min_norm, int flags) {
+    ORX_ARG(t && (n == 0 || ids), "orx_table_censor: NULL argument");
+    if (n == 0) return ORX_OK;
+    orx_ctx* c = t->ctx;
+    ORX_HIP(hipSetDevice(c->device));
+    CHECK(orx_table_scratch(t));
+    const int32_t* d = ids;
+    if (!(flags & ORX_IDS_DEVICE)) {
+        ENSURE(c->d_ids, c->d_ids_cap, (size_t)n * sizeof(int32_t));
+        CHECK(stage_ids(c, ids, n, 0));
+        d = c->d_ids;
+    }
+    CHECK(orx_launch_censor(c, t->w, t->cnt, t->rows, t->dim, d, n, min_norm, c->d_err));
+    if (!(flags & ORX_IDS_DEVICE)) return orx_check_index_error(c);
+    return ORX_OK;
+}
+
+// ------------------------------------------------------------- optimizers ---
+extern "C" int orx_opt_create(orx_ctx* ctx, int kind, float lr, float p0, float p1, float p2, orx_opt** out) {
+    ORX_ARG(ctx && out, "orx_opt_create: NULL context/out");
+    ORX_ARG(kind == ORX_SGD || kind == ORX_ADAGRAD || kind == ORX_ADAM, "orx_opt_create: unknown optimizer kind %d", kind);
+    orx_opt* o = new orx_opt();
+    o->ctx = ctx; o->kind = kind; o->lr = lr; o->p0 = p0; o->p1 = p1; o->p2 = p2;
+    *out = o;
+    return ORX_OK;
+}
+
+extern "C" int orx_opt_destroy(orx_opt* o) {
+    if (!o) return ORX_OK;
+    hipSetDevice(o->ctx->device);
+    hipStreamSynchronize(o->ctx->stream);
+    for (auto& kv : o->slots) { hipFree(kv.second.s0); hipFree(kv.second.s1); }
+    delete o;
+    return ORX_OK;
+}
+
+extern "C" int orx_opt_set_lr(orx_opt* o, float lr) {
+    ORX_ARG(o, "orx_opt_set_lr: NULL optimizer");
+    o->lr = lr;
+    return ORX_OK;
+}
+
+int orx_opt_slots(orx_opt* o, orx_table* t, OptSlots* out) {
+    auto it = o->slots.find(t);
+    if (it != o->slots.end()) { *out = it->second; return ORX_OK; }
+    OptSlots s;
+    const size_t n = (size_t)t->rows * t->dim;
+    ORX_HIP(hipSetDevice(o->ctx->device));
+    if (o->kind == ORX_ADAGRAD) {
+        ORX_HIP(hipMalloc((void**)&s.s0, n * sizeof(float)));
+        CHECK(orx_launch_fill(o->ctx, s.s0, (int64_t)n, o->p0));      // initial_accumulator_value
+    } else if (o->kind == ORX_ADAM) {
+        ORX_HIP(hipMalloc((void**)&s.s0, n * sizeof(float)));
+        ORX_HIP(hipMalloc((void**)&s.s1, n * sizeof(float)));
+        ORX_HIP(hipMemsetAsync(s.s0, 0, n * sizeof(float), o->ctx->stream));
+        ORX_HIP(hipMemsetAsync(s.s1, 0, n * sizeof(float), o->ctx->stream));
+    }
+    o->slots[t] = s;
+    *out = s;
+    return ORX_OK;
+}
+
+static int slot_ptr(orx_opt* o, orx_table* t, int slot, float** p) {
+    ORX_ARG(o && t, "optimizer slot: NULL argument");
+    OptSlots s;
+    CHECK(orx_opt_slots(o, t, &s));
+    *p = slot == 0 ? s.s0 : (slot == 1 ? s.s1 : nullptr);
+    ORX_ARG(*p, "optimizer slot %d does not exist for optimizer kind %d", slot, o->kind);
+    return ORX_OK;
+}
+
+extern "C" int orx_opt_slot_read(orx_opt* o, orx_table* t, int slot, int64_t row0, int64_t nrows, float* host_dst) {
+    float* p = nullptr;
+    CHECK(slot_ptr(o, t, slot, &p));
+    return rows_copy(t->ctx, p, t->rows, t->dim, row0, nrows, host_dst, true);
+}
+
+extern "C" int orx_opt_slot_write(orx_opt* o, orx_table* t, int slot, int64_t row0, int64_t nrows, const float* host_src) {
+    float* p = nullptr;
+    CHECK(slot_ptr(o, t, slot, &p));
+    return rows_copy(t->ctx, p, t->rows, t->dim, row0, nrows, (float*)host_src, false);
+}
+
+// ------------------------------------------------------------ the hot path ---
+static int check_pair_tables(orx_table* U, orx_table* V, orx_table* b) {
+    ORX_ARG(U && V && b, "pairwise: NULL table");
+    ORX_ARG(U->ctx == V->ctx && V->ctx == b->ctx, "pairwise: tables belong to different contexts");
+    ORX_ARG(U->dim == V->dim, "pairwise: user dim %d != item dim %d (every model multiplies them element-wise)", U->dim, V->dim);
+    ORX_ARG(b->dim == 1 && b->rows == V->rows, "pairwise: item_bias must be [%lld, 1]", (long long)V->rows);
+    return ORX_OK;
+}
+
+// stage ids of K steps; returns device pointers + stride
+static int stage_triplets(orx_ctx* c, const int32_t* uid, const int32_t* pid, const int32_t* nid,
+                          int64_t K, int64_t B, int64_t id_stride, int flags,
+                          const int32_t** du, const int32_t** dp, const int32_t** dn, int64_t* dstride) {
+    if (flags & ORX_IDS_DEVICE) { *du = uid; *dp = pid; *dn = nid; *dstride = id_stride; return ORX_OK; }
+    const int64_t n = K * B;
+    ENSURE(c->d_ids, c->d_ids_cap, (size_t)3 * n * sizeof(int32_t));
+    if (id_stride == B || K == 1) {
+        CHECK(stage_ids(c, uid, n, 0));
+        CHECK(stage_ids(c, pid, n, n));
+        CHECK(stage_ids(c, nid, n, 2 * n));
+    } else {
+        for (int64_t s = 0; s < K; ++s) {
+            CHECK(stage_ids(c, uid + s * id_stride, B, s * B));
+            CHECK(stage_ids(c, pid + s * id_stride, B, n + s * B));
+            CHECK(stage_ids(c, nid + s * id_stride, B, 2 * n + s * B));
+        }
+    }
+    *du = c->d_ids; *dp = c->d_ids + n; *dn = c->d_ids + 2 * n; *dstride = B;
+    return ORX_OK;
+}
+
+static int fetch_losses(orx_ctx* c, int64_t K, float* loss_out, float* l2_out) {
+    if (!loss_out && !l2_out) return ORX_OK;
+    std::vector<double> h((size_t)2 * K);
+    ORX_HIP(hipMemcpyAsync(h.data(), c->d_loss, sizeof(double) * 2 * K, hipMemcpyDeviceToHost, c->stream));
+    ORX_HIP(hipStreamSynchronize(c->stream));
+    for (int64_t s = 0; s < K; ++s) {
+        if (loss_out) loss_out[s] = (float)h[2 * s];
+        if (l2_out) l2_out[s] = (float)h[2 * s + 1];
+    }
+    return ORX_OK;
+}
+
+extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
+                                 orx_table* U, orx_table* V, orx_table* b,
+                                 const int32_t* uid, const int32_t* pid, const int32_t* nid,
+                                 int64_t K, int64_t B, int64_t id_stride, float margin, int flags,
+                                 float* loss_out, float* l2_out) {
+    ORX_ARG(c && opt, "orx_pairwise_step: NULL context/optimizer");
+    ORX_ARG(model == ORX_BPR || model == ORX_UCML, "orx_pairwise_step: unknown model %d", model);
+    CHECK(check_pair_tables(U, V, b));
+    ORX_ARG(U->ctx == c && opt->ctx == c, "orx_pairwise_step: objects belong to a different context");
+    ORX_ARG(K >= 0 && B >= 0, "orx_pairwise_step: negative K or B");
+    ORX_ARG(K == 0 || B == 0 || (uid && pid && nid), "orx_pairwise_step: NULL id pointer");
+    if (K == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(c->device));
+    if (B == 0) {           // empty batch: reduce_mean of nothing is NaN in TF; tables untouched
+        for (int64_t s = 0; s < K; ++s) { if (loss_out) loss_out[s] = model == ORX_BPR ? NAN : 0.f; if (l2_out) l2_out[s] = 0.f; }
+        return ORX_OK;
+    }
+    const int32_t *du, *dp, *dn; int64_t ds;
+    CHECK(stage_triplets(c, uid, pid, nid, K, B, id_stride, flags, &du, &dp, &dn, &ds));
+
+    const bool hogwild = (flags & ORX_HOGWILD) != 0;
+    const int mode = opt->kind == ORX_ADAM ? MODE_ACCUM : (hogwild ? MODE_HOGWILD : MODE_EXACT);
+    if (mode != MODE_HOGWILD) { CHECK(orx_table_scratch(U)); CHECK(orx_table_scratch(V)); CHECK(orx_table_scratch(b)); }
+    OptSlots sU, sV, sb;
+    CHECK(orx_opt_slots(opt, U, &sU)); CHECK(orx_opt_slots(opt, V, &sV)); CHECK(orx_opt_slots(opt, b, &sb));
+
+    const int nw = orx_fused_nwaves(U->dim, B);
+    ENSURE(c->d_partial, c->d_partial_cap, (size_t)nw * 2 * sizeof(float));
+    ENSURE(c->d_dupmask, c->d_dupmask_cap, (size_t)B);
+    ENSURE(c->d_loss, c->d_loss_cap, (size_t)K * 2 * sizeof(double));
+
+    PairArgs a;
+    memset(&a, 0, sizeof(a));
+    a.U = U->w; a.V = V->w; a.b = b->w;
+    a.gU = U->gsum; a.gV = V->gsum; a.gb = b->gsum;
+    a.cntU = U->cnt; a.cntV = V->cnt;
+    a.aU = sU.s0; a.aV = sV.s0; a.ab = sb.s0;
+    a.B = B; a.NU = U->rows; a.NI = V->rows; a.D = U->dim;
+    a.lr = opt->lr;
+    a.eps = opt->kind == ORX_ADAGRAD ? opt->p1 : 0.f;
+    a.margin = margin;
+    a.invB = 1.0f / (float)B;
+    a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f;
+    a.dupmask = c->d_dupmask; a.partial = c->d_partial; a.err = c->d_err; a.nwaves = nw;
+
+    for (int64_t s = 0; s < K; ++s) {
+        a.uid = du + s * ds; a.pid = dp + s * ds; a.nid = dn + s * ds;
+        a.loss_out = c->d_loss + 2 * s;
+        if (mode == MODE_EXACT) {
+            CHECK(orx_launch_count(c, a));
+            CHECK(orx_launch_fused(c, model, opt->kind, mode, a, nullptr));
+            CHECK(orx_launch_dup(c, opt->kind, a));
+        } else if (mode == MODE_HOGWILD) {
+            CHECK(orx_launch_fused(c, model, opt->kind, mode, a, nullptr));
+            CHECK(orx_launch_dup(c, -1, a));
+        } else {   // Adam: accumulate summed gradients, then the dense-decay sweep of TF 2.0
+            CHECK(orx_launch_fused(c, model, opt->kind, mode, a, nullptr));
+            CHECK(orx_launch_dup(c, -1, a));
+            opt->t += 1;
+            const double b1 = opt->p0, b2 = opt->p1;
+            const float lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, (double)opt->t)) / (1.0 - std::pow(b1, (double)opt->t)));
+            CHECK(orx_launch_adam_sweep(c, U->w, sU.s0, sU.s1, U->gsum, U->rows * U->dim, lr_t, opt->p0, opt->p1, opt->p2));
+            CHECK(orx_launch_adam_sweep(c, V->w, sV.s0, sV.s1, V->gsum, V->rows * V->dim, lr_t, opt->p0, opt->p1, opt->p2));
+            CHECK(orx_launch_adam_sweep(c, b->w, sb.s0, sb.s1, b->gsum, b->rows, lr_t, opt->p0, opt->p1, opt->p2));
+        }
+    }
+    CHECK(fetch_losses(c, K, loss_out, l2_out));
+    if (!(flags & ORX_IDS_DEVICE)) return orx_check_index_error(c);
+    return ORX_OK;
+}
+
+extern "C" int orx_pairwise_loss(orx_ctx* c, int model, orx_table* U, orx_table* V, orx_table* b,
+                                 const int32_t* uid, const int32_t* pid, const int32_t* nid,
+                                 int64_t B, float margin, int flags, float* loss_out, float* l2_out) {
+    ORX_ARG(c, "orx_pairwise_loss: NULL context");
+    ORX_ARG(model == ORX_BPR || model == ORX_UCML, "orx_pairwise_loss: unknown model %d", model);
+    CHECK(check_pair_tables(U, V, b));
+    ORX_ARG(B > 0 && uid && pid && nid, "orx_pairwise_loss: empty batch or NULL ids");
+    ORX_HIP(hipSetDevice(c->device));
+    const int32_t *du, *dp, *dn; int64_t ds;
+    CHECK(stage_triplets(c, uid, pid, nid, 1, B, B, flags, &du, &dp, &dn, &ds));
+    const int nw = orx_fused_nwaves(U->dim, B);
+    ENSURE(c->d_partial, c->d_partial_cap, (size_t)nw * 2 * sizeof(float));
+    ENSURE(c->d_loss, c->d_loss_cap, 2 * sizeof(double));
+    PairArgs a;
+    memset(&a, 0, sizeof(a));
+    a.U = U->w; a.V = V->w; a.b = b->w;
+    a.B = B; a.NU = U->rows; a.NI = V->rows; a.D = U->dim;
+    a.margin = margin; a.invB = 1.0f / (float)B; a.l2w = 1.f;
+    a.partial = c->d_partial; a.err = c->d_err; a.nwaves = nw;
+    a.uid = du; a.pid = dp; a.nid = dn; a.loss_out = c->d_loss;
+    CHECK(orx_launch_fused(c, model, ORX_SGD, MODE_LOSS, a, nullptr));
+    CHECK(orx_launch_dup(c, -1, a));
+    CHECK(fetch_losses(c, 1, loss_out, l2_out));
+    return orx_check_index_error(c);
+}
+
+// ---------------------------------------------------------------- profiling ---
+extern "C" int orx_prof_enable(orx_ctx* c, int on) {
+    ORX_ARG(c, "orx_prof_enable: NULL context");
+    c->prof = on != 0;
+    return ORX_OK;
+}
+
+extern "C" int orx_prof_reset(orx_ctx* c) {
+    ORX_ARG(c, "orx_prof_reset: NULL context");
+    ORX_HIP(hipStreamSynchronize(c->stream));
+    CHECK(prof_collect(c));
+    for (int k = 0; k < ORX_K_NUM; ++k) { c->prof_slot[k].total_ms = 0.0; c->prof_slot[k].launches = 0; }
+    return ORX_OK;
+}
+
+extern "C" int orx_prof_get(orx_ctx* c, int kid, double* total_ms, int64_t* launches) {
+    ORX_ARG(c && kid >= 0 && kid < ORX_K_NUM, "orx_prof_get: bad argument");
+    ORX_HIP(hipStreamSynchronize(c->stream));
+    CHECK(prof_collect(c));
+    if (total_ms) *total_ms = c->prof_slot[kid].total_ms;
+    if (launches) *launches = c->prof_slot[kid].launches;
+    return ORX_OK;
+}

@@ -1,0 +1,159 @@
+// Table utility kernels: initializers, Embedding gather (LatentFactor.__call__),
+// LatentFactor.censor, and the Adam dense-decay sweep.  gfx950.
+#include "orx_internal.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// ----------------------------------------------------------- initializers ---
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// Keras 'uniform' initializer (latent_factor.py:8-11): counter-based, so the
+// value of element i depends only on (seed, i) -- identical for any launch shape.
+__global__ void init_uniform_kernel(float* w, int64_t n, float lo, float hi, uint64_t seed) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t r = splitmix64(seed * 0xD1342543DE82EF95ull + (uint64_t)i);
+        const float u = (float)(r >> 40) * (1.0f / 16777216.0f);       // [0,1), 24 bits
+        w[i] = lo + (hi - lo) * u;
+    }
+}
+
+__global__ void fill_kernel(float* w, int64_t n, float v) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) w[i] = v;
+}
+
+static inline unsigned grid_for(int64_t n, int per_block) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g > 256 * 32) g = 256 * 32;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+int orx_launch_init_uniform(orx_ctx* ctx, float* w, int64_t n, float lo, float hi, uint64_t seed) {
+    hipLaunchKernelGGL(init_uniform_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, w, n, lo, hi, seed);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_launch_fill(orx_ctx* ctx, float* w, int64_t n, float v) {
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, w, n, v);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// ------------------------------------------------------------------ gather ---
+// out[k, 0:dim] = W[ids[k], :]; out[k, dim] = bias[ids[k]] when bias != NULL.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                     int64_t rows, int dim, const int32_t* __restrict__ ids,
+                                                     int64_t n, float* __restrict__ out, int64_t out_stride, int* err) {
+    const int per_row = VEC4 ? dim / 4 : dim;
+    const int64_t total = n * per_row;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t k = i / per_row;
+        const int e = (int)(i - k * per_row);
+        const int r = ids[k];
+        if ((uint32_t)r >= (uint64_t)rows) { *err = 1; continue; }
+        if (VEC4) {
+            *reinterpret_cast<f4*>(out + k * out_stride + 4 * e) = *reinterpret_cast<const f4*>(w + (size_t)r * dim + 4 * e);
+        } else {
+            out[k * out_stride + e] = w[(size_t)r * dim + e];
+        }
+        if (bias != nullptr && e == 0) out[k * out_stride + dim] = bias[r];
+    }
+}
+
+int orx_launch_gather(orx_ctx* ctx, const float* w, const float* bias, int64_t rows, int dim,
+                      const int32_t* ids, int64_t n, float* out, int64_t out_stride, int* err) {
+    if (n == 0) return ORX_OK;
+    const bool vec = (dim % 4 == 0) && (out_stride % 4 == 0) && (((uintptr_t)out) % 16 == 0);
+    if (vec) {
+        hipLaunchKernelGGL((gather_kernel<true>), dim3(grid_for(n * (dim / 4), 256)), dim3(256), 0, ctx->stream,
+                           w, bias, rows, dim, ids, n, out, out_stride, err);
+    } else {
+        hipLaunchKernelGGL((gather_kernel<false>), dim3(grid_for(n * dim, 256)), dim3(256), 0, ctx->stream,
+                           w, bias, rows, dim, ids, n, out, out_stride, err);
+    }
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// ------------------------------------------------------------------ censor ---
+// LatentFactor.censor (latent_factor.py:17-23).  tf.unique makes the update
+// once per DISTINCT id; here cnt[] elects exactly one reference per row.
+__global__ __launch_bounds__(256) void censor_count_kernel(int* cnt, int64_t rows, const int32_t* ids, int64_t n, int* err) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = ids[i];
+    if ((uint32_t)r >= (uint64_t)rows) { *err = 1; return; }
+    atomicAdd(cnt + r, 1);
+}
+
+__device__ __forceinline__ float wave_sum_f(float x) {
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void censor_apply_kernel(float* w, int* cnt, int64_t rows, int dim,
+                                                           const int32_t* ids, int64_t n, float min_norm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += stride) {
+        const int r = ids[i];
+        if ((uint32_t)r >= (uint64_t)rows) continue;
+        int old = 0;
+        if (lane == 0) old = atomicSub(cnt + r, 1);
+        old = __shfl(old, 0);
+        if (old != 1) continue;                              // not the elected reference of this row
+        float* row = w + (size_t)r * dim;
+        float s = 0.0f;
+        for (int e = lane; e < dim; e += 64) s += row[e] * row[e];
+        const float den = fmaxf(sqrtf(wave_sum_f(s)), min_norm);   // tf.norm, maximum(norm, 0.1)
+        for (int e = lane; e < dim; e += 64) row[e] = row[e] / den;
+    }
+}
+
+int orx_launch_censor(orx_ctx* ctx, float* w, int* cnt, int64_t rows, int dim, const int32_t* ids,
+                      int64_t n, float min_norm, int* err) {
+    if (n == 0) return ORX_OK;
+    ProfScope ps(ctx, ORX_K_CENSOR);
+    hipLaunchKernelGGL(censor_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cnt, rows, ids, n, err);
+    hipLaunchKernelGGL(censor_apply_kernel, dim3(grid_for(n, 4)), dim3(256), 0, ctx->stream, w, cnt, rows, dim, ids, n, min_norm);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// -------------------------------------------------------------- Adam sweep ---
+// keras.optimizers.Adam._resource_apply_sparse (TF 2.0.x): m and v decay over
+// the WHOLE table, the summed sparse gradient is added on its rows, and the
+// update var -= lr_t * m / (sqrt(v) + eps) also covers the whole table.
+// gsum holds the per-row summed gradient of this step (zero elsewhere) and is
+// re-zeroed here.
+__global__ __launch_bounds__(256) void adam_sweep_kernel(float* w, float* m, float* v, float* gsum, int64_t n,
+                                                         float lr_t, float b1, float b2, float eps) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float g = gsum[i];
+        if (g != 0.0f) gsum[i] = 0.0f;
+        const float mi = b1 * m[i] + (1.0f - b1) * g;
+        const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        w[i] = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+int orx_launch_adam_sweep(orx_ctx* ctx, float* w, float* m, float* v, float* gsum, int64_t n,
+                          float lr_t, float b1, float b2, float eps) {
+    ProfScope ps(ctx, ORX_K_SWEEP);
+    hipLaunchKernelGGL(adam_sweep_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, w, m, v, gsum, n, lr_t, b1, b2, eps);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}

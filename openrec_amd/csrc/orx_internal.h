@@ -1,0 +1,134 @@
+// Internal declarations shared by the translation units of libopenrec_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/openrec_hip.h"
+
+// ---------------------------------------------------------------- errors ---
+void orx_set_error(const char* fmt, ...);
+
+#define ORX_HIP(expr)                                                                  \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            orx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                          __FILE__, __LINE__);                                         \
+            return _e == hipErrorOutOfMemory ? ORX_ERR_OOM : ORX_ERR_HIP;              \
+        }                                                                              \
+    } while (0)
+
+#define ORX_ARG(cond, ...)                                                             \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            orx_set_error(__VA_ARGS__);                                                \
+            return ORX_ERR_ARG;                                                        \
+        }                                                                              \
+    } while (0)
+
+// --------------------------------------------------------------- objects ---
+struct ProfSlot {
+    std::vector<hipEvent_t> ev;   // pairs (start, stop) awaiting collection
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct orx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int* d_err = nullptr;             // sticky device-side "id out of range" flag
+    // staging buffers (grown on demand)
+    int32_t* d_ids = nullptr;  size_t d_ids_cap = 0;       // host-id upload
+    float* d_lab = nullptr;    size_t d_lab_cap = 0;
+    unsigned char* d_dupmask = nullptr; size_t d_dupmask_cap = 0;
+    float* d_partial = nullptr; size_t d_partial_cap = 0;   // per-wave loss partials
+    double* d_loss = nullptr;  size_t d_loss_cap = 0;       // [K][2] step results
+    float* d_tmp = nullptr;    size_t d_tmp_cap = 0;        // misc fp32 scratch
+    bool prof = false;
+    ProfSlot prof_slot[ORX_K_NUM];
+    int num_cu = 256;
+};
+
+struct orx_table {
+    orx_ctx* ctx = nullptr;
+    float* w = nullptr;               // [rows, dim]
+    int64_t rows = 0;
+    int32_t dim = 0;
+    bool owned = true;
+    // per-step scratch, allocated on first use by a train step
+    int* cnt = nullptr;               // [rows] reference counts (all-zero between steps)
+    float* gsum = nullptr;            // [rows, dim] duplicate-row gradient sums (all-zero between steps)
+};
+
+struct OptSlots {
+    float* s0 = nullptr;              // Adagrad acc / Adam m
+    float* s1 = nullptr;              // Adam v
+};
+
+struct orx_opt {
+    orx_ctx* ctx = nullptr;
+    int kind = ORX_SGD;
+    float lr = 0.01f, p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    int64_t t = 0;                    // Adam step counter
+    std::map<orx_table*, OptSlots> slots;
+};
+
+// ------------------------------------------------------- helpers (api.hip) ---
+int orx_ensure(void** p, size_t* cap, size_t bytes);           // grow a device buffer
+int orx_table_scratch(orx_table* t);                            // allocate cnt/gsum
+int orx_opt_slots(orx_opt* opt, orx_table* t, OptSlots* out);   // allocate optimizer slots
+void orx_prof_begin(orx_ctx* ctx, int kid);
+void orx_prof_end(orx_ctx* ctx, int kid);
+
+struct ProfScope {
+    orx_ctx* c; int k;
+    ProfScope(orx_ctx* c_, int k_) : c(c_), k(k_) { if (c->prof) orx_prof_begin(c, k); }
+    ~ProfScope() { if (c->prof) orx_prof_end(c, k); }
+};
+
+// ------------------------------------------------ kernel launch parameters ---
+struct PairArgs {
+    // tables
+    float* U; float* V; float* b;
+    float* gU; float* gV; float* gb;          // duplicate gradient sums (gb: [NI])
+    int* cntU; int* cntV;
+    float* aU; float* aV; float* ab;          // Adagrad accumulators (ab: [NI])
+    const int32_t* uid; const int32_t* pid; const int32_t* nid;
+    int64_t B; int64_t NU; int64_t NI;
+    int D;
+    float lr; float eps; float margin; float invB; float l2w;
+    unsigned char* dupmask;                   // [B]  bit0 user, bit1 pos item, bit2 neg item
+    float* partial;                           // [nwaves][2] loss / l2 partials
+    double* loss_out;                         // [2] for this step
+    int* err;
+    int nwaves;
+};
+
+// launchers implemented in kernels_pairwise.hip
+int orx_launch_count(orx_ctx* ctx, const PairArgs& a);
+int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairArgs& a, int* nwaves_out);
+int orx_launch_dup(orx_ctx* ctx, int optkind, const PairArgs& a);
+int orx_fused_nwaves(int D, int64_t B);
+
+// fused-kernel modes
+enum { MODE_EXACT = 0,     // unique rows in place, duplicate rows -> gsum (needs counts)
+       MODE_HOGWILD = 1,   // everything in place, no counts
+       MODE_ACCUM = 2,     // everything -> gsum (Adam: dense sweep follows)
+       MODE_LOSS = 3 };    // forward only
+
+// kernels_misc.hip
+int orx_launch_init_uniform(orx_ctx* ctx, float* w, int64_t n, float lo, float hi, uint64_t seed);
+int orx_launch_fill(orx_ctx* ctx, float* w, int64_t n, float v);
+int orx_launch_gather(orx_ctx* ctx, const float* w, const float* bias, int64_t rows, int dim,
+                      const int32_t* ids, int64_t n, float* out, int64_t out_stride, int* err);
+int orx_launch_censor(orx_ctx* ctx, float* w, int* cnt, int64_t rows, int dim, const int32_t* ids,
+                      int64_t n, float min_norm, int* err);
+int orx_launch_adam_sweep(orx_ctx* ctx, float* w, float* m, float* v, float* gsum, int64_t n,
+                          float lr_t, float b1, float b2, float eps);

@@ -1,0 +1,217 @@
+"""Thin object layer over the C ABI: Context (device + stream), Table (fp32
+[rows, dim] in HBM), Optimizer (Keras sparse-apply rules), and the fused train
+steps.  Host-side plumbing only; all arithmetic runs in libopenrec_hip.so."""
+from __future__ import annotations
+
+import ctypes
+import weakref
+from ctypes import byref, c_double, c_int64, c_void_p
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check
+
+_default_ctx = None
+
+
+def _is_device_tensor(x):
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+class DevicePtr:
+    """A raw device pointer + element count (ids already resident in HBM)."""
+
+    def __init__(self, ptr, n, keepalive=None):
+        self.ptr, self.n, self.keepalive = int(ptr), int(n), keepalive
+
+
+def _ids_arg(x):
+    """-> (pointer, n, on_device, keepalive)"""
+    if isinstance(x, DevicePtr):
+        return x.ptr, x.n, True, x
+    if _is_device_tensor(x):
+        assert str(x.dtype).endswith("int32"), "device ids must be int32"
+        assert x.is_contiguous()
+        return x.data_ptr(), x.numel(), True, x
+    if hasattr(x, "numpy") and not isinstance(x, np.ndarray):      # lazy / cpu tensors
+        x = x.numpy()
+    a = np.ascontiguousarray(x, dtype=np.int32).reshape(-1)       # tf.cast(ids, int32) in Embedding.call
+    return a.ctypes.data, a.size, False, a
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self._lib = _ffi.load()
+        h = c_void_p()
+        check(self._lib.orx_ctx_create(int(device), c_void_p(stream) if stream else None, byref(h)))
+        self._h = h
+        self.device = int(device)
+        self._fin = weakref.finalize(self, self._lib.orx_ctx_destroy, h)
+
+    def synchronize(self):
+        check(self._lib.orx_synchronize(self._h))
+
+    def check_index_error(self):
+        check(self._lib.orx_check_index_error(self._h))
+
+    # ---- kernel-time sampling ------------------------------------------
+    def prof_enable(self, on=True):
+        check(self._lib.orx_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        check(self._lib.orx_prof_reset(self._h))
+
+    def prof_get(self):
+        out = {}
+        for kid, name in _ffi.KERNEL_NAMES.items():
+            ms, n = c_double(), c_int64()
+            check(self._lib.orx_prof_get(self._h, kid, byref(ms), byref(n)))
+            out[name] = dict(total_ms=ms.value, launches=n.value)
+        return out
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class Table:
+    """fp32 [rows, dim] embedding table resident in HBM."""
+
+    def __init__(self, rows, dim, ctx=None, device_ptr=None, keepalive=None):
+        self.ctx = ctx or default_context()
+        self._lib = self.ctx._lib
+        h = c_void_p()
+        if device_ptr is None:
+            check(self._lib.orx_table_create(self.ctx._h, int(rows), int(dim), byref(h)))
+        else:
+            check(self._lib.orx_table_wrap(self.ctx._h, c_void_p(int(device_ptr)), int(rows), int(dim), byref(h)))
+        self._h = h
+        self.rows, self.dim = int(rows), int(dim)
+        self._keepalive = (keepalive, self.ctx)
+        self._fin = weakref.finalize(self, self._lib.orx_table_destroy, h)
+
+    @property
+    def shape(self):
+        return (self.rows, self.dim)
+
+    @property
+    def device_ptr(self):
+        return self._lib.orx_table_device_ptr(self._h)
+
+    def init_uniform(self, lo=-0.05, hi=0.05, seed=0):
+        check(self._lib.orx_table_init_uniform(self._h, lo, hi, int(seed) & (2 ** 64 - 1)))
+        return self
+
+    def fill(self, v):
+        check(self._lib.orx_table_fill(self._h, float(v)))
+        return self
+
+    def read(self, row0=0, nrows=None):
+        nrows = self.rows - row0 if nrows is None else nrows
+        out = np.empty((nrows, self.dim), np.float32)
+        check(self._lib.orx_table_read(self._h, int(row0), int(nrows), out.ctypes.data))
+        return out
+
+    def numpy(self):
+        return self.read()
+
+    def write(self, values, row0=0):
+        a = np.ascontiguousarray(values, np.float32).reshape(-1, self.dim)
+        check(self._lib.orx_table_write(self._h, int(row0), a.shape[0], a.ctypes.data))
+        return self
+
+    def gather(self, ids):
+        ptr, n, dev, keep = _ids_arg(ids)
+        if dev:
+            raise ValueError("Table.gather returns host rows; pass host ids (use gather_rows for device buffers)")
+        out = np.empty((n, self.dim), np.float32)
+        check(self._lib.orx_table_gather(self._h, ptr, n, out.ctypes.data, 0))
+        return out
+
+    def censor(self, ids, min_norm=0.1):
+        ptr, n, dev, keep = _ids_arg(ids)
+        check(self._lib.orx_table_censor(self._h, ptr, n, float(min_norm), _ffi.ORX_IDS_DEVICE if dev else 0))
+
+
+class Optimizer:
+    KINDS = {"sgd": _ffi.ORX_SGD, "adagrad": _ffi.ORX_ADAGRAD, "adam": _ffi.ORX_ADAM}
+
+    def __init__(self, kind, lr, p0=0.0, p1=0.0, p2=0.0, ctx=None):
+        self.ctx = ctx or default_context()
+        self._lib = self.ctx._lib
+        self.kind = kind
+        h = c_void_p()
+        check(self._lib.orx_opt_create(self.ctx._h, self.KINDS[kind], lr, p0, p1, p2, byref(h)))
+        self._h = h
+        self._tables = []          # keep tables alive while the optimizer holds slots for them
+        self._fin = weakref.finalize(self, self._lib.orx_opt_destroy, h)
+
+    @classmethod
+    def sgd(cls, lr=0.01, ctx=None):
+        return cls("sgd", lr, ctx=ctx)
+
+    @classmethod
+    def adagrad(cls, lr=0.001, initial_accumulator_value=0.1, epsilon=1e-7, ctx=None):
+        return cls("adagrad", lr, initial_accumulator_value, epsilon, ctx=ctx)
+
+    @classmethod
+    def adam(cls, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, ctx=None):
+        return cls("adam", lr, beta_1, beta_2, epsilon, ctx=ctx)
+
+    def set_lr(self, lr):
+        check(self._lib.orx_opt_set_lr(self._h, lr))
+
+    def slot(self, table, slot=0):
+        out = np.empty((table.rows, table.dim), np.float32)
+        check(self._lib.orx_opt_slot_read(self._h, table._h, slot, 0, table.rows, out.ctypes.data))
+        return out
+
+    def set_slot(self, table, values, slot=0):
+        a = np.ascontiguousarray(values, np.float32).reshape(table.rows, table.dim)
+        check(self._lib.orx_opt_slot_write(self._h, table._h, slot, 0, table.rows, a.ctypes.data))
+
+
+def pairwise_step(model, opt, user, item, bias, uid, pid, nid, K=1, B=None, id_stride=None,
+                  margin=0.5, hogwild=False, no_l2=False, want_loss=True):
+    """K fused train steps.  Returns (loss[K], l2[K]) as numpy float32 when
+    want_loss, else None (fully asynchronous)."""
+    lib = user.ctx._lib
+    pu, nu, du, k0 = _ids_arg(uid)
+    pp, npn, dp, k1 = _ids_arg(pid)
+    pn, nn, dn, k2 = _ids_arg(nid)
+    assert du == dp == dn, "ids must be all host or all device"
+    assert nu == npn == nn, "id arrays differ in length"
+    if B is None:
+        B = nu // K
+    if id_stride is None:
+        id_stride = B
+    flags = (_ffi.ORX_IDS_DEVICE if du else 0) | (_ffi.ORX_HOGWILD if hogwild else 0) | (_ffi.ORX_NO_L2 if no_l2 else 0)
+    mid = {"bpr": _ffi.ORX_BPR, "ucml": _ffi.ORX_UCML}[model]
+    if want_loss:
+        loss = np.empty(K, np.float32)
+        l2 = np.empty(K, np.float32)
+        lp, l2p = loss.ctypes.data, l2.ctypes.data
+    else:
+        loss = l2 = None
+        lp = l2p = None
+    check(lib.orx_pairwise_step(user.ctx._h, mid, opt._h, user._h, item._h, bias._h, pu, pp, pn,
+                                int(K), int(B), int(id_stride), float(margin), flags, lp, l2p))
+    opt._tables = list({id(t): t for t in (opt._tables + [user, item, bias])}.values())
+    return (loss, l2) if want_loss else None
+
+
+def pairwise_loss(model, user, item, bias, uid, pid, nid, margin=0.5):
+    lib = user.ctx._lib
+    pu, nu, du, k0 = _ids_arg(uid)
+    pp, _, dp, k1 = _ids_arg(pid)
+    pn, _, dn, k2 = _ids_arg(nid)
+    mid = {"bpr": _ffi.ORX_BPR, "ucml": _ffi.ORX_UCML}[model]
+    loss = np.empty(1, np.float32)
+    l2 = np.empty(1, np.float32)
+    check(lib.orx_pairwise_loss(user.ctx._h, mid, user._h, item._h, bias._h, pu, pp, pn, nu, float(margin),
+                                _ffi.ORX_IDS_DEVICE if du else 0, loss.ctypes.data, l2.ctypes.data))
+    return float(loss[0]), float(l2[0])
