@@ -62,13 +62,14 @@ enum orx_flags {
 
 /* kernels whose device time can be sampled with orx_prof_* */
 enum orx_kernel_id {
-    ORX_K_COUNT = 0,      /* per-row reference counting (duplicate detection)   */
+    ORX_K_DEDUP = 0,      /* duplicate-reference detection on the id arrays     */
     ORX_K_FUSED = 1,      /* fused gather-score-loss-grad-update (dominant)     */
-    ORX_K_DUP = 2,        /* duplicate-row finalize + loss reduce               */
+    ORX_K_REDUCE = 2,     /* per-step loss reduction (once per call)            */
     ORX_K_SWEEP = 3,      /* Adam dense-decay sweep                             */
     ORX_K_CENSOR = 4,
     ORX_K_POINT = 5,      /* fused pointwise (GMF/WRMF) step                    */
-    ORX_K_NUM = 6
+    ORX_K_DUPAPPLY = 6,   /* optimizer apply of the duplicate rows of a step    */
+    ORX_K_NUM = 7
 };
 
 int orx_version(void);

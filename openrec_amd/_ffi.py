@@ -15,9 +15,9 @@ ORX_SGD, ORX_ADAGRAD, ORX_ADAM = 0, 1, 2
 ORX_BPR, ORX_UCML = 0, 1
 ORX_GMF, ORX_WRMF = 0, 1
 ORX_IDS_DEVICE, ORX_HOGWILD, ORX_NO_L2 = 1, 2, 4
-ORX_K_COUNT, ORX_K_FUSED, ORX_K_DUP, ORX_K_SWEEP, ORX_K_CENSOR, ORX_K_POINT, ORX_K_NUM = 0, 1, 2, 3, 4, 5, 6
-KERNEL_NAMES = {ORX_K_COUNT: "count", ORX_K_FUSED: "fused", ORX_K_DUP: "dup", ORX_K_SWEEP: "adam_sweep",
-                ORX_K_CENSOR: "censor", ORX_K_POINT: "pointwise"}
+ORX_K_DEDUP, ORX_K_FUSED, ORX_K_REDUCE, ORX_K_SWEEP, ORX_K_CENSOR, ORX_K_POINT, ORX_K_DUPAPPLY, ORX_K_NUM = 0, 1, 2, 3, 4, 5, 6, 7
+KERNEL_NAMES = {ORX_K_DEDUP: "dedup", ORX_K_FUSED: "fused", ORX_K_REDUCE: "loss_reduce", ORX_K_SWEEP: "adam_sweep",
+                ORX_K_CENSOR: "censor", ORX_K_POINT: "pointwise", ORX_K_DUPAPPLY: "dup_apply"}
 
 _p = c_void_p
 _pp = POINTER(c_void_p)

@@ -96,8 +96,8 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dupmask);
-    hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
+    hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_dlist);
+    hipFree(c->d_dcount); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return ORX_OK;
@@ -157,7 +157,6 @@ extern "C" int orx_table_destroy(orx_table* t) {
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
     if (t->owned) hipFree(t->w);
-    hipFree(t->cnt);
     hipFree(t->gsum);
     delete t;
     return ORX_OK;
@@ -168,13 +167,9 @@ extern "C" int32_t orx_table_dim(const orx_table* t) { return t ? t->dim : -1; }
 extern "C" void* orx_table_device_ptr(const orx_table* t) { return t ? (void*)t->w : nullptr; }
 
 int orx_table_scratch(orx_table* t) {
-    if (t->cnt && t->gsum) return ORX_OK;
+    if (t->gsum) return ORX_OK;
     ORX_HIP(hipSetDevice(t->ctx->device));
-    if (!t->cnt) {
-        ORX_HIP(hipMalloc((void**)&t->cnt, (size_t)t->rows * sizeof(int)));
-        ORX_HIP(hipMemsetAsync(t->cnt, 0, (size_t)t->rows * sizeof(int), t->ctx->stream));
-    }
-    if (!t->gsum) {
+    {
         ORX_HIP(hipMalloc((void**)&t->gsum, (size_t)t->rows * t->dim * sizeof(float)));
         ORX_HIP(hipMemsetAsync(t->gsum, 0, (size_t)t->rows * t->dim * sizeof(float), t->ctx->stream));
     }
@@ -241,19 +236,30 @@ extern "C" int orx_table_gather(orx_table* t, const int32_t* ids, int64_t n, flo
     return orx_check_index_error(c);
 }
 
+// censor: dflag[i] = 0 for exactly one reference of every distinct row, 1 for the others
+static int dedup_single(orx_ctx* c, const int32_t* d_ids, int64_t n, int64_t rows) {
+    ENSURE(c->d_dflag, c->d_dflag_cap, (size_t)n);
+    DedupArgs d;
+    memset(&d, 0, sizeof(d));
+    d.uid = d_ids; d.pid = d_ids; d.nid = d_ids; d.id_stride = n;
+    d.dflag = c->d_dflag; d.flag_stride = n;
+    d.B = n; d.NU = rows; d.NI = 0; d.nbu = orx_dedup_buckets(rows); d.nbi = 0; d.first_only = 1;
+    return orx_launch_dedup(c, d, 1);
+}
+
 extern "C" int orx_table_censor(orx_table* t, const int32_t* ids, int64_t n, float min_norm, int flags) {
     ORX_ARG(t && (n == 0 || ids), "orx_table_censor: NULL argument");
     if (n == 0) return ORX_OK;
     orx_ctx* c = t->ctx;
     ORX_HIP(hipSetDevice(c->device));
-    CHECK(orx_table_scratch(t));
     const int32_t* d = ids;
     if (!(flags & ORX_IDS_DEVICE)) {
         ENSURE(c->d_ids, c->d_ids_cap, (size_t)n * sizeof(int32_t));
         CHECK(stage_ids(c, ids, n, 0));
         d = c->d_ids;
     }
-    CHECK(orx_launch_censor(c, t->w, t->cnt, t->rows, t->dim, d, n, min_norm, c->d_err));
+    CHECK(dedup_single(c, d, n, t->rows));
+    CHECK(orx_launch_censor(c, t->w, c->d_dflag, t->rows, t->dim, d, n, min_norm, c->d_err));
     if (!(flags & ORX_IDS_DEVICE)) return orx_check_index_error(c);
     return ORX_OK;
 }
@@ -394,15 +400,23 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     CHECK(orx_opt_slots(opt, U, &sU)); CHECK(orx_opt_slots(opt, V, &sV)); CHECK(orx_opt_slots(opt, b, &sb));
 
     const int nw = orx_fused_nwaves(U->dim, B);
-    ENSURE(c->d_partial, c->d_partial_cap, (size_t)nw * 2 * sizeof(float));
-    ENSURE(c->d_dupmask, c->d_dupmask_cap, (size_t)B);
+    // steps are processed in chunks so that the per-step scratch stays bounded
+    int64_t chunk = (int64_t)((256ull << 20) / ((size_t)3 * B * sizeof(int32_t)));
+    if (chunk < 1) chunk = 1;
+    if (chunk > K) chunk = K;
+    ENSURE(c->d_partial, c->d_partial_cap, (size_t)chunk * nw * 2 * sizeof(float));
     ENSURE(c->d_loss, c->d_loss_cap, (size_t)K * 2 * sizeof(double));
+    const int64_t list_stride = 2 * B;          // distinct duplicated rows <= B/2 (users) + B (items)
+    if (mode == MODE_EXACT) {
+        ENSURE(c->d_dflag, c->d_dflag_cap, (size_t)chunk * 3 * B);
+        ENSURE(c->d_dlist, c->d_dlist_cap, (size_t)chunk * list_stride * sizeof(uint32_t));
+        ENSURE(c->d_dcount, c->d_dcount_cap, (size_t)chunk * sizeof(int));
+    }
 
     PairArgs a;
     memset(&a, 0, sizeof(a));
     a.U = U->w; a.V = V->w; a.b = b->w;
     a.gU = U->gsum; a.gV = V->gsum; a.gb = b->gsum;
-    a.cntU = U->cnt; a.cntV = V->cnt;
     a.aU = sU.s0; a.aV = sV.s0; a.ab = sb.s0;
     a.B = B; a.NU = U->rows; a.NI = V->rows; a.D = U->dim;
     a.lr = opt->lr;
@@ -410,28 +424,42 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     a.margin = margin;
     a.invB = 1.0f / (float)B;
     a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f;
-    a.dupmask = c->d_dupmask; a.partial = c->d_partial; a.err = c->d_err; a.nwaves = nw;
+    a.err = c->d_err;
 
-    for (int64_t s = 0; s < K; ++s) {
-        a.uid = du + s * ds; a.pid = dp + s * ds; a.nid = dn + s * ds;
-        a.loss_out = c->d_loss + 2 * s;
+    for (int64_t s0 = 0; s0 < K; s0 += chunk) {
+        const int64_t kc = (K - s0 < chunk) ? (K - s0) : chunk;
         if (mode == MODE_EXACT) {
-            CHECK(orx_launch_count(c, a));
-            CHECK(orx_launch_fused(c, model, opt->kind, mode, a, nullptr));
-            CHECK(orx_launch_dup(c, opt->kind, a));
-        } else if (mode == MODE_HOGWILD) {
-            CHECK(orx_launch_fused(c, model, opt->kind, mode, a, nullptr));
-            CHECK(orx_launch_dup(c, -1, a));
-        } else {   // Adam: accumulate summed gradients, then the dense-decay sweep of TF 2.0
-            CHECK(orx_launch_fused(c, model, opt->kind, mode, a, nullptr));
-            CHECK(orx_launch_dup(c, -1, a));
-            opt->t += 1;
-            const double b1 = opt->p0, b2 = opt->p1;
-            const float lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, (double)opt->t)) / (1.0 - std::pow(b1, (double)opt->t)));
-            CHECK(orx_launch_adam_sweep(c, U->w, sU.s0, sU.s1, U->gsum, U->rows * U->dim, lr_t, opt->p0, opt->p1, opt->p2));
-            CHECK(orx_launch_adam_sweep(c, V->w, sV.s0, sV.s1, V->gsum, V->rows * V->dim, lr_t, opt->p0, opt->p1, opt->p2));
-            CHECK(orx_launch_adam_sweep(c, b->w, sb.s0, sb.s1, b->gsum, b->rows, lr_t, opt->p0, opt->p1, opt->p2));
+            // duplicate detection for every step of the chunk, on the id arrays alone
+            DedupArgs d;
+            memset(&d, 0, sizeof(d));
+            d.uid = du + s0 * ds; d.pid = dp + s0 * ds; d.nid = dn + s0 * ds; d.id_stride = ds;
+            d.dflag = c->d_dflag; d.dlist = c->d_dlist; d.dcount = c->d_dcount;
+            d.flag_stride = 3 * B; d.list_stride = list_stride;
+            d.B = B; d.NU = U->rows; d.NI = V->rows;
+            d.nbu = orx_dedup_buckets(U->rows); d.nbi = orx_dedup_buckets(V->rows);
+            ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));
+            CHECK(orx_launch_dedup(c, d, kc));
         }
+        for (int64_t i = 0; i < kc; ++i) {
+            const int64_t s = s0 + i;
+            a.uid = du + s * ds; a.pid = dp + s * ds; a.nid = dn + s * ds;
+            a.dflag = c->d_dflag + (size_t)i * 3 * B;
+            a.dlist = c->d_dlist + (size_t)i * list_stride; a.dcount = c->d_dcount + i;
+            a.partial = c->d_partial + (size_t)i * nw * 2;
+            CHECK(orx_launch_fused(c, model, opt->kind, mode, a));
+            if (mode == MODE_EXACT) CHECK(orx_launch_dup_apply(c, opt->kind, a));
+            if (mode == MODE_ACCUM) {   // Adam: dense-decay sweep of TF 2.0 over the whole tables
+                opt->t += 1;
+                const double b1 = opt->p0, b2 = opt->p1;
+                const float lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, (double)opt->t)) / (1.0 - std::pow(b1, (double)opt->t)));
+                CHECK(orx_launch_adam_sweep(c, U->w, sU.s0, sU.s1, U->gsum, U->rows * U->dim, lr_t, opt->p0, opt->p1, opt->p2));
+                CHECK(orx_launch_adam_sweep(c, V->w, sV.s0, sV.s1, V->gsum, V->rows * V->dim, lr_t, opt->p0, opt->p1, opt->p2));
+                CHECK(orx_launch_adam_sweep(c, b->w, sb.s0, sb.s1, b->gsum, b->rows, lr_t, opt->p0, opt->p1, opt->p2));
+            }
+        }
+        ReduceArgs r;
+        r.partial = c->d_partial; r.out = c->d_loss + 2 * s0; r.nwaves = nw;
+        CHECK(orx_launch_loss_reduce(c, r, kc));
     }
     CHECK(fetch_losses(c, K, loss_out, l2_out));
     if (!(flags & ORX_IDS_DEVICE)) return orx_check_index_error(c);
@@ -456,10 +484,12 @@ extern "C" int orx_pairwise_loss(orx_ctx* c, int model, orx_table* U, orx_table*
     a.U = U->w; a.V = V->w; a.b = b->w;
     a.B = B; a.NU = U->rows; a.NI = V->rows; a.D = U->dim;
     a.margin = margin; a.invB = 1.0f / (float)B; a.l2w = 1.f;
-    a.partial = c->d_partial; a.err = c->d_err; a.nwaves = nw;
-    a.uid = du; a.pid = dp; a.nid = dn; a.loss_out = c->d_loss;
-    CHECK(orx_launch_fused(c, model, ORX_SGD, MODE_LOSS, a, nullptr));
-    CHECK(orx_launch_dup(c, -1, a));
+    a.partial = c->d_partial; a.err = c->d_err;
+    a.uid = du; a.pid = dp; a.nid = dn;
+    CHECK(orx_launch_fused(c, model, ORX_SGD, MODE_LOSS, a));
+    ReduceArgs r;
+    r.partial = c->d_partial; r.out = c->d_loss; r.nwaves = nw;
+    CHECK(orx_launch_loss_reduce(c, r, 1));
     CHECK(fetch_losses(c, 1, loss_out, l2_out));
     return orx_check_index_error(c);
 }

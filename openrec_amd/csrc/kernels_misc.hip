@@ -87,31 +87,21 @@ int orx_launch_gather(orx_ctx* ctx, const float* w, const float* bias, int64_t r
 
 // ------------------------------------------------------------------ censor ---
 // LatentFactor.censor (latent_factor.py:17-23).  tf.unique makes the update
-// once per DISTINCT id; here cnt[] elects exactly one reference per row.
-__global__ __launch_bounds__(256) void censor_count_kernel(int* cnt, int64_t rows, const int32_t* ids, int64_t n, int* err) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int r = ids[i];
-    if ((uint32_t)r >= (uint64_t)rows) { *err = 1; return; }
-    atomicAdd(cnt + r, 1);
-}
-
+// once per DISTINCT id; the dedup kernel (kernels_pairwise.hip, first_only mode)
+// clears dflag for exactly one reference of every distinct row: that one applies.
 __device__ __forceinline__ float wave_sum_f(float x) {
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
     return x;
 }
 
-__global__ __launch_bounds__(256) void censor_apply_kernel(float* w, int* cnt, int64_t rows, int dim,
-                                                           const int32_t* ids, int64_t n, float min_norm) {
+__global__ __launch_bounds__(256) void censor_apply_kernel(float* w, const unsigned char* dflag, int64_t rows, int dim,
+                                                           const int32_t* ids, int64_t n, float min_norm, int* err) {
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * 4;
     for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += stride) {
         const int r = ids[i];
-        if ((uint32_t)r >= (uint64_t)rows) continue;
-        int old = 0;
-        if (lane == 0) old = atomicSub(cnt + r, 1);
-        old = __shfl(old, 0);
-        if (old != 1) continue;                              // not the elected reference of this row
+        if ((uint32_t)r >= (uint64_t)rows) { if (lane == 0) *err = 1; continue; }
+        if (dflag[i]) continue;                               // another reference of this row applies
         float* row = w + (size_t)r * dim;
         float s = 0.0f;
         for (int e = lane; e < dim; e += 64) s += row[e] * row[e];
@@ -120,12 +110,11 @@ __global__ __launch_bounds__(256) void censor_apply_kernel(float* w, int* cnt, i
     }
 }
 
-int orx_launch_censor(orx_ctx* ctx, float* w, int* cnt, int64_t rows, int dim, const int32_t* ids,
+int orx_launch_censor(orx_ctx* ctx, float* w, const unsigned char* dflag, int64_t rows, int dim, const int32_t* ids,
                       int64_t n, float min_norm, int* err) {
     if (n == 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_CENSOR);
-    hipLaunchKernelGGL(censor_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cnt, rows, ids, n, err);
-    hipLaunchKernelGGL(censor_apply_kernel, dim3(grid_for(n, 4)), dim3(256), 0, ctx->stream, w, cnt, rows, dim, ids, n, min_norm);
+    hipLaunchKernelGGL(censor_apply_kernel, dim3(grid_for(n, 4)), dim3(256), 0, ctx->stream, w, dflag, rows, dim, ids, n, min_norm, err);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

@@ -10,25 +10,33 @@
 //   GradientTape over (loss, l2_loss)        tf2_examples/bpr_citeulike.py:35-37
 //   Keras optimizer sparse apply             tf2_examples/bpr_citeulike.py:38
 //
-// Design:
-//   * HBM-bound: 3 random row reads + 3 random row writes per triplet, no reuse.
-//     A row of D fp32 is owned by LPR = D/4 adjacent lanes, one float4 each, so a
-//     D=64 row is one coalesced 256-B segment and a 64-lane wavefront carries
-//     64/LPR triplets; dot products reduce inside the lane group with DPP
-//     (quad_perm / row_half_mirror / row_mirror), never through LDS.
-//   * TF semantics need every gradient of a step to be taken on the PRE-step
-//     tables.  A one-pass in-place kernel violates that only for rows referenced
-//     more than once in the batch, so the step is three launches:
-//       count_kernel  : cnt[row] += 1 per reference            (4-B atomics)
-//       fused_kernel  : rows with cnt == 1 are updated in place (exact: nobody
-//                       else reads or writes them); references to rows with
-//                       cnt != 1 add their gradient to gsum[row] with fp32
-//                       atomics and leave the table row untouched
-//       dup_kernel    : per duplicate reference cnt[row] -= 1; the reference
-//                       that brings it to 0 applies the optimizer rule with the
-//                       summed gradient (TF dedup-sum semantics for Adagrad,
-//                       identical result for SGD) and re-zeroes gsum[row]
-//     cnt[] and gsum[] are all-zero again after every step.
+// Design (DESIGN.md has the measurements behind each choice):
+//   * The step is bound by the number of random memory transactions, not by
+//     flops: 3 row reads + 3 row writes per triplet with no reuse.  A row of D
+//     fp32 is owned by LPR = D/4 adjacent lanes (one float4 each): a D=64 row is
+//     one coalesced 256-B segment, a wavefront carries 64/LPR triplets, and the
+//     dot products reduce inside the lane group with DPP (quad_perm,
+//     row_half_mirror, row_mirror) -- no LDS, no barriers in the hot kernel.
+//   * TF takes every gradient of a step on the PRE-step tables.  A one-pass
+//     in-place kernel breaks that only for rows referenced more than once in the
+//     batch.  Per-row metadata in HBM would cost one extra random transaction
+//     per reference (measured: about as expensive as a row access), so duplicates
+//     are found WITHOUT touching HBM tables:
+//       dedup_kernel    : row-range buckets of 524288 rows; each workgroup keeps
+//                         two LDS bitmaps ("seen", "seen twice") for its range
+//                         while streaming the L2-resident id arrays: exact, no
+//                         hashing, no overflow.  It runs once for ALL K steps of
+//                         a call, before the first step.  Output per step: one
+//                         flag byte per reference and the list of duplicated rows.
+//       fused_kernel    : unique rows are read, scored and updated in place
+//                         (exact: nobody else reads or writes them).  A
+//                         duplicate reference adds its gradient to gsum[row]
+//                         with fire-and-forget fp32 atomics and leaves the row.
+//       dup_apply_kernel: for every duplicated row of the step, apply the
+//                         optimizer rule once with the summed gradient (TF's
+//                         dedup-sum semantics for Adagrad; identical for SGD)
+//                         and re-zero gsum[row].
+//     gsum[] is all-zero between steps.
 #include "orx_internal.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -67,6 +75,14 @@ __device__ __forceinline__ void atomic_add_f4(float* p, f4 v) {
     unsafeAtomicAdd(p + 2, v.z);
     unsafeAtomicAdd(p + 3, v.w);
 }
+
+// device-coherent load: bypasses the per-CU L1 and the non-coherent per-XCD L2,
+// i.e. observes fp32 atomics performed by any CU of the device.
+__device__ __forceinline__ float load_coherent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool id_ok(int id, int64_t rows) { return (uint32_t)id < (uint64_t)rows; }
 
 // ------------------------------------------------------------ score / loss ---
 // Returns the per-triplet loss term and the gradient coefficient `g`.
@@ -144,28 +160,105 @@ __device__ __forceinline__ void opt_apply1(float* w_ptr, float* a_ptr, float w_o
     }
 }
 
-// ------------------------------------------------------------ count kernel ---
-__global__ __launch_bounds__(256) void count_kernel(PairArgs a) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.B) return;
-    const int u = a.uid[t], p = a.pid[t], n = a.nid[t];
-    if ((uint32_t)u >= (uint64_t)a.NU || (uint32_t)p >= (uint64_t)a.NI || (uint32_t)n >= (uint64_t)a.NI) {
-        *a.err = 1;
-        return;
+// ------------------------------------------------------------ dedup kernel ---
+// One workgroup per (step, table, 524288-row range).  Exact duplicate detection
+// on the id arrays alone: two LDS bitmaps over the rows of the range; the ids of
+// the step are streamed twice from L2 (mark, then emit).  No HBM table is touched.
+constexpr int DD_WORDS = 16384;                 // 32-bit words per bitmap
+constexpr int DD_ROWS = DD_WORDS * 32;          // rows covered by one workgroup
+constexpr int DD_THREADS = 1024;
+constexpr int DD_LDS_BYTES = 2 * DD_WORDS * 4;  // 128 KiB
+
+__global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int dd_lds[];
+    unsigned int* seen = dd_lds;
+    unsigned int* dup = dd_lds + DD_WORDS;
+    __shared__ int list_base;
+    __shared__ int list_cnt;
+    const int per_step = a.nbu + a.nbi;
+    const int64_t s = blockIdx.x / per_step;
+    int bk = blockIdx.x % per_step;
+    const bool is_user = bk < a.nbu;
+    if (!is_user) bk -= a.nbu;
+    const int64_t r0 = (int64_t)bk * DD_ROWS;
+    const int64_t rows = is_user ? a.NU : a.NI;
+    const int64_t B = a.B;
+    const int32_t* idsA = (is_user ? a.uid : a.pid) + s * a.id_stride;
+    const int32_t* idsB = a.nid + s * a.id_stride;
+    const int64_t n = is_user ? B : 2 * B;
+    const int64_t ref0 = is_user ? 0 : B;
+    unsigned char* dflag = a.dflag + s * a.flag_stride;
+
+    for (int i = threadIdx.x; i < 2 * DD_WORDS; i += DD_THREADS) dd_lds[i] = 0u;
+    if (threadIdx.x == 0) list_cnt = 0;
+    __syncthreads();
+    for (int64_t j = threadIdx.x; j < n; j += DD_THREADS) {
+        const int id = j < B ? idsA[j] : idsB[j - B];
+        const int64_t l = (int64_t)id - r0;
+        if ((uint64_t)l < (uint64_t)DD_ROWS && id_ok(id, rows)) {
+            const unsigned int bit = 1u << (l & 31);
+            const unsigned int old = atomicOr(&seen[l >> 5], bit);
+            if (old & bit) atomicOr(&dup[l >> 5], bit);
+            if (a.first_only) dflag[ref0 + j] = (old & bit) ? 1 : 0;
+        }
     }
-    atomicAdd(a.cntU + u, 1);
-    atomicAdd(a.cntV + p, 1);
-    atomicAdd(a.cntV + n, 1);
+    if (a.first_only) return;
+    __syncthreads();
+    for (int64_t j = threadIdx.x; j < n; j += DD_THREADS) {
+        const int id = j < B ? idsA[j] : idsB[j - B];
+        const int64_t l = (int64_t)id - r0;
+        if ((uint64_t)l < (uint64_t)DD_ROWS && id_ok(id, rows))
+            dflag[ref0 + j] = (dup[l >> 5] >> (l & 31)) & 1u;
+    }
+    // append the duplicated rows of this range to the step's list
+    int mine = 0;
+    for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) mine += __popc(dup[w]);
+    int off = 0;
+    if (mine) off = atomicAdd(&list_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) list_base = list_cnt ? atomicAdd(a.dcount + s, list_cnt) : 0;
+    __syncthreads();
+    if (mine) {
+        uint32_t* out = a.dlist + s * a.list_stride + list_base + off;
+        const uint32_t tag = is_user ? 0u : 0x80000000u;
+        for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) {
+            unsigned int m = dup[w];
+            while (m) {
+                const int bpos = __ffs(m) - 1;
+                m &= m - 1;
+                *out++ = (uint32_t)(r0 + (int64_t)w * 32 + bpos) | tag;
+            }
+        }
+    }
+}
+
+int orx_dedup_buckets(int64_t rows) { return (int)((rows + DD_ROWS - 1) / DD_ROWS); }
+
+int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K) {
+    ProfScope ps(ctx, ORX_K_DEDUP);
+    const int64_t g = K * (a.nbu + a.nbi);
+    if (g == 0) return ORX_OK;
+    ORX_ARG(g < (1LL << 31), "dedup: grid too large (K=%lld, buckets=%d)", (long long)K, a.nbu + a.nbi);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ORX_HIP(hipFuncSetAttribute((const void*)dedup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DD_LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dedup_kernel, dim3((unsigned)g), dim3(DD_THREADS), DD_LDS_BYTES, ctx->stream, a);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
 }
 
 // -------------------------------------------------- loss partial reduction ---
-__device__ __forceinline__ void reduce_partials(const PairArgs& a) {
-    // one block: sum nwaves x {loss, l2} fp32 partials in fp64 -> loss_out[0..1]
+// One block per step: sum nwaves x {loss, l2} fp32 partials in fp64.
+__global__ __launch_bounds__(256) void loss_reduce_kernel(ReduceArgs a) {
     __shared__ double sh[2][4];
+    const float* part = a.partial + (size_t)blockIdx.x * a.nwaves * 2;
     double s0 = 0.0, s1 = 0.0;
     for (int i = threadIdx.x; i < a.nwaves; i += blockDim.x) {
-        s0 += (double)a.partial[2 * i];
-        s1 += (double)a.partial[2 * i + 1];
+        const float2 v = *reinterpret_cast<const float2*>(part + 2 * i);
+        s0 += (double)v.x;
+        s1 += (double)v.y;
     }
     for (int off = 32; off > 0; off >>= 1) {
         s0 += __shfl_xor(s0, off);
@@ -175,12 +268,17 @@ __device__ __forceinline__ void reduce_partials(const PairArgs& a) {
     if ((threadIdx.x & 63) == 0) { sh[0][w] = s0; sh[1][w] = s1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        a.loss_out[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-        a.loss_out[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        a.out[2 * blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        a.out[2 * blockIdx.x + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
     }
 }
 
-__global__ __launch_bounds__(256) void loss_reduce_kernel(PairArgs a) { reduce_partials(a); }
+int orx_launch_loss_reduce(orx_ctx* ctx, const ReduceArgs& a, int64_t K) {
+    ProfScope ps(ctx, ORX_K_REDUCE);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3((unsigned)K), dim3(256), 0, ctx->stream, a);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
 
 // ------------------------------------------------------------ fused kernel ---
 // LPR lanes own one row (D = 4*LPR).  MODE: see orx_internal.h.
@@ -197,12 +295,13 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
 
     for (int64_t t = wave_global * TPW + grp; t < a.B; t += stride) {
         const int u = a.uid[t], p = a.pid[t], n = a.nid[t];
-        if ((uint32_t)u >= (uint64_t)a.NU || (uint32_t)p >= (uint64_t)a.NI || (uint32_t)n >= (uint64_t)a.NI) {
-            if (sub == 0) { *a.err = 1; if (MODE == MODE_EXACT) a.dupmask[t] = 0; }
+        int du = 0, dp = 0, dn = 0;
+        if (MODE == MODE_EXACT) { du = a.dflag[t]; dp = a.dflag[a.B + t]; dn = a.dflag[2 * a.B + t]; }
+        if (MODE == MODE_ACCUM) { du = dp = dn = 1; }
+        if (!(id_ok(u, a.NU) && id_ok(p, a.NI) && id_ok(n, a.NI))) {
+            if (sub == 0) *a.err = 1;       // the reference's CPU gather raises; the triplet is skipped
             continue;
         }
-        int cu = 1, cp = 1, cn = 1;
-        if (MODE == MODE_EXACT) { cu = a.cntU[u]; cp = a.cntV[p]; cn = a.cntV[n]; }
         float* Up = a.U + (size_t)u * D + 4 * sub;
         float* Pp = a.V + (size_t)p * D + 4 * sub;
         float* Np = a.V + (size_t)n * D + 4 * sub;
@@ -221,50 +320,88 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
         f4 gu, gp, gn; float gbp, gbn;
         row_grads<MODEL>(ru, rp, rn, g, a.l2w, gu, gp, gn, gbp, gbn);
 
-        if (MODE == MODE_ACCUM) {
-            atomic_add_f4(a.gU + (size_t)u * D + 4 * sub, gu);
-            atomic_add_f4(a.gV + (size_t)p * D + 4 * sub, gp);
-            atomic_add_f4(a.gV + (size_t)n * D + 4 * sub, gn);
-            if (sub == 0) { unsafeAtomicAdd(a.gb + p, gbp); unsafeAtomicAdd(a.gb + n, gbn); }
-            continue;
-        }
-        // user row
-        if (cu == 1) {
-            opt_apply4<OPT>(Up, a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
-            if (MODE == MODE_EXACT && sub == 0) a.cntU[u] = 0;
-        } else {
-            atomic_add_f4(a.gU + (size_t)u * D + 4 * sub, gu);
-        }
-        // positive item row + bias
-        if (cp == 1) {
+        // unique row: in place.  duplicated row: gradient into gsum, row untouched.
+        if (du == 0) opt_apply4<OPT>(Up, a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
+        else atomic_add_f4(a.gU + (size_t)u * D + 4 * sub, gu);
+        if (dp == 0) {
             opt_apply4<OPT>(Pp, a.aV + (size_t)p * D + 4 * sub, rp, gp, a.lr, a.eps);
-            if (sub == 0) {
-                opt_apply1<OPT>(a.b + p, a.ab + p, bp, gbp, a.lr, a.eps);
-                if (MODE == MODE_EXACT) a.cntV[p] = 0;
-            }
+            if (sub == 0) opt_apply1<OPT>(a.b + p, a.ab + p, bp, gbp, a.lr, a.eps);
         } else {
             atomic_add_f4(a.gV + (size_t)p * D + 4 * sub, gp);
             if (sub == 0) unsafeAtomicAdd(a.gb + p, gbp);
         }
-        // negative item row + bias
-        if (cn == 1) {
+        if (dn == 0) {
             opt_apply4<OPT>(Np, a.aV + (size_t)n * D + 4 * sub, rn, gn, a.lr, a.eps);
-            if (sub == 0) {
-                opt_apply1<OPT>(a.b + n, a.ab + n, bn, gbn, a.lr, a.eps);
-                if (MODE == MODE_EXACT) a.cntV[n] = 0;
-            }
+            if (sub == 0) opt_apply1<OPT>(a.b + n, a.ab + n, bn, gbn, a.lr, a.eps);
         } else {
             atomic_add_f4(a.gV + (size_t)n * D + 4 * sub, gn);
             if (sub == 0) unsafeAtomicAdd(a.gb + n, gbn);
         }
-        if (MODE == MODE_EXACT && sub == 0)
-            a.dupmask[t] = (unsigned char)((cu != 1) | ((cp != 1) << 1) | ((cn != 1) << 2));
     }
     const float ls = wave_sum(loss_acc);
     const float sq = wave_sum(sq_acc);
     if (lane == 0) {
-        a.partial[2 * wave_global] = ls;
-        a.partial[2 * wave_global + 1] = 0.5f * sq;
+        float2 v; v.x = ls; v.y = 0.5f * sq;
+        *reinterpret_cast<float2*>(a.partial + 2 * wave_global) = v;
+    }
+}
+
+// dup_apply: one group of LPR lanes per duplicated row of the step.
+template <int LPR, int OPT>
+__global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
+    constexpr int TPW = 64 / LPR;
+    constexpr int D = 4 * LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    const int n = *a.dcount;
+    const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
+    for (int64_t e = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + grp; e < n; e += stride) {
+        const uint32_t ent = a.dlist[e];
+        const bool item = (ent >> 31) != 0;
+        const size_t row = ent & 0x7fffffffu;
+        float* W = item ? a.V : a.U;
+        float* G = item ? a.gV : a.gU;
+        float* A = item ? a.aV : a.aU;
+        float* gp = G + row * D + 4 * sub;
+        float* wp = W + row * D + 4 * sub;
+        const f4 g = *reinterpret_cast<const f4*>(gp);
+        const f4 w = *reinterpret_cast<const f4*>(wp);
+        f4 z; z.x = z.y = z.z = z.w = 0.0f;
+        *reinterpret_cast<f4*>(gp) = z;
+        opt_apply4<OPT>(wp, A + row * D + 4 * sub, w, g, a.lr, a.eps);
+        if (item && sub == 0) {
+            const float gb = a.gb[row];
+            a.gb[row] = 0.0f;
+            opt_apply1<OPT>(a.b + row, a.ab + row, a.b[row], gb, a.lr, a.eps);
+        }
+    }
+}
+
+template <int OPT>
+__global__ __launch_bounds__(256) void dup_apply_generic_kernel(PairArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int D = a.D;
+    const int n = *a.dcount;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += stride) {
+        const uint32_t ent = a.dlist[e];
+        const bool item = (ent >> 31) != 0;
+        const size_t row = ent & 0x7fffffffu;
+        float* W = item ? a.V : a.U;
+        float* G = item ? a.gV : a.gU;
+        float* A = item ? a.aV : a.aU;
+        for (int k = lane; k < D; k += 64) {
+            const size_t i = row * D + k;
+            const float g = G[i];
+            G[i] = 0.0f;
+            opt_apply1<OPT>(W + i, A + i, W[i], g, a.lr, a.eps);
+        }
+        if (item && lane == 0) {
+            const float gb = a.gb[row];
+            a.gb[row] = 0.0f;
+            opt_apply1<OPT>(a.b + row, a.ab + row, a.b[row], gb, a.lr, a.eps);
+        }
     }
 }
 
@@ -280,12 +417,13 @@ __global__ __launch_bounds__(256) void fused_generic_kernel(PairArgs a) {
     float loss_acc = 0.0f, sq_acc = 0.0f;
     for (int64_t t = wave_global; t < a.B; t += stride) {
         const int u = a.uid[t], p = a.pid[t], n = a.nid[t];
-        if ((uint32_t)u >= (uint64_t)a.NU || (uint32_t)p >= (uint64_t)a.NI || (uint32_t)n >= (uint64_t)a.NI) {
-            if (lane == 0) { *a.err = 1; if (MODE == MODE_EXACT) a.dupmask[t] = 0; }
+        int du = 0, dp = 0, dn = 0;
+        if (MODE == MODE_EXACT) { du = a.dflag[t]; dp = a.dflag[a.B + t]; dn = a.dflag[2 * a.B + t]; }
+        if (MODE == MODE_ACCUM) { du = dp = dn = 1; }
+        if (!(id_ok(u, a.NU) && id_ok(p, a.NI) && id_ok(n, a.NI))) {
+            if (lane == 0) *a.err = 1;
             continue;
         }
-        int cu = 1, cp = 1, cn = 1;
-        if (MODE == MODE_EXACT) { cu = a.cntU[u]; cp = a.cntV[p]; cn = a.cntV[n]; }
         float* Ur = a.U + (size_t)u * D;
         float* Pr = a.V + (size_t)p * D;
         float* Nr = a.V + (size_t)n * D;
@@ -302,7 +440,6 @@ __global__ __launch_bounds__(256) void fused_generic_kernel(PairArgs a) {
         score<MODEL>(red, bp, bn, a.invB, a.margin, term, g);
         if (lane == 0) loss_acc += term;
         if (MODE == MODE_LOSS) continue;
-        float gbp, gbn;
         for (int e = lane; e < D; e += 64) {
             const float x = Ur[e], y = Pr[e], z = Nr[e];
             float gu, gp, gn;
@@ -312,114 +449,27 @@ __global__ __launch_bounds__(256) void fused_generic_kernel(PairArgs a) {
                 const float a2 = 2.0f * g;
                 gu = -a2 * (y - z) + a.l2w * x; gp = -a2 * (x - y) + a.l2w * y; gn = a2 * (x - z) + a.l2w * z;
             }
-            if (MODE != MODE_ACCUM && cu == 1) opt_apply1<OPT>(Ur + e, a.aU + (size_t)u * D + e, x, gu, a.lr, a.eps);
+            if (du == 0) opt_apply1<OPT>(Ur + e, a.aU + (size_t)u * D + e, x, gu, a.lr, a.eps);
             else unsafeAtomicAdd(a.gU + (size_t)u * D + e, gu);
-            if (MODE != MODE_ACCUM && cp == 1) opt_apply1<OPT>(Pr + e, a.aV + (size_t)p * D + e, y, gp, a.lr, a.eps);
+            if (dp == 0) opt_apply1<OPT>(Pr + e, a.aV + (size_t)p * D + e, y, gp, a.lr, a.eps);
             else unsafeAtomicAdd(a.gV + (size_t)p * D + e, gp);
-            if (MODE != MODE_ACCUM && cn == 1) opt_apply1<OPT>(Nr + e, a.aV + (size_t)n * D + e, z, gn, a.lr, a.eps);
+            if (dn == 0) opt_apply1<OPT>(Nr + e, a.aV + (size_t)n * D + e, z, gn, a.lr, a.eps);
             else unsafeAtomicAdd(a.gV + (size_t)n * D + e, gn);
         }
-        if (MODEL == ORX_BPR) { gbp = g; gbn = -g; } else { gbp = -g; gbn = g; }
+        const float gbp = MODEL == ORX_BPR ? g : -g, gbn = -gbp;
         if (lane == 0) {
-            if (MODE != MODE_ACCUM && cp == 1) opt_apply1<OPT>(a.b + p, a.ab + p, bp, gbp, a.lr, a.eps);
+            if (dp == 0) opt_apply1<OPT>(a.b + p, a.ab + p, bp, gbp, a.lr, a.eps);
             else unsafeAtomicAdd(a.gb + p, gbp);
-            if (MODE != MODE_ACCUM && cn == 1) opt_apply1<OPT>(a.b + n, a.ab + n, bn, gbn, a.lr, a.eps);
+            if (dn == 0) opt_apply1<OPT>(a.b + n, a.ab + n, bn, gbn, a.lr, a.eps);
             else unsafeAtomicAdd(a.gb + n, gbn);
-            if (MODE == MODE_EXACT) {
-                if (cu == 1) a.cntU[u] = 0;
-                if (cp == 1) a.cntV[p] = 0;
-                if (cn == 1) a.cntV[n] = 0;
-                a.dupmask[t] = (unsigned char)((cu != 1) | ((cp != 1) << 1) | ((cn != 1) << 2));
-            }
         }
     }
     const float ls = wave_sum(loss_acc);
     const float sq = wave_sum(sq_acc);
     if (lane == 0) {
-        a.partial[2 * wave_global] = ls;
-        a.partial[2 * wave_global + 1] = 0.5f * sq;
+        float2 v; v.x = ls; v.y = 0.5f * sq;
+        *reinterpret_cast<float2*>(a.partial + 2 * wave_global) = v;
     }
-}
-
-// -------------------------------------------------------------- dup kernel ---
-// Finalize one duplicate reference: decrement the row's reference count; the
-// reference that reaches zero applies the optimizer with the summed gradient.
-template <int LPR, int OPT>
-__device__ __forceinline__ void finalize_row(float* W, float* G, int* cnt, float* A,
-                                             float* bW, float* bG, float* bA,
-                                             int row, int sub, int leader_lane, float lr, float eps) {
-    constexpr int D = 4 * LPR;
-    int old = 0;
-    if (sub == 0) old = atomicSub(cnt + row, 1);
-    old = __shfl(old, leader_lane);
-    if (old != 1) return;
-    float* gp = G + (size_t)row * D + 4 * sub;
-    float* wp = W + (size_t)row * D + 4 * sub;
-    const f4 g = *reinterpret_cast<const f4*>(gp);
-    const f4 w = *reinterpret_cast<const f4*>(wp);
-    f4 z; z.x = z.y = z.z = z.w = 0.0f;
-    *reinterpret_cast<f4*>(gp) = z;
-    opt_apply4<OPT>(wp, A + (size_t)row * D + 4 * sub, w, g, lr, eps);
-    if (bW != nullptr && sub == 0) {
-        const float gb = bG[row];
-        bG[row] = 0.0f;
-        opt_apply1<OPT>(bW + row, bA + row, bW[row], gb, lr, eps);
-    }
-}
-
-template <int LPR, int OPT>
-__global__ __launch_bounds__(256) void dup_kernel(PairArgs a) {
-    constexpr int TPW = 64 / LPR;
-    const int lane = threadIdx.x & 63;
-    const int sub = lane % LPR;
-    const int grp = lane / LPR;
-    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
-    for (int64_t t = wave_global * TPW + grp; t < a.B; t += stride) {
-        const int m = a.dupmask[t];
-        if (m == 0) continue;
-        const int lead = grp * LPR;
-        if (m & 1) finalize_row<LPR, OPT>(a.U, a.gU, a.cntU, a.aU, nullptr, nullptr, nullptr, a.uid[t], sub, lead, a.lr, a.eps);
-        if (m & 2) finalize_row<LPR, OPT>(a.V, a.gV, a.cntV, a.aV, a.b, a.gb, a.ab, a.pid[t], sub, lead, a.lr, a.eps);
-        if (m & 4) finalize_row<LPR, OPT>(a.V, a.gV, a.cntV, a.aV, a.b, a.gb, a.ab, a.nid[t], sub, lead, a.lr, a.eps);
-    }
-    if (blockIdx.x == 0) reduce_partials(a);
-}
-
-template <int OPT>
-__device__ __forceinline__ void finalize_row_generic(float* W, float* G, int* cnt, float* A,
-                                                     float* bW, float* bG, float* bA,
-                                                     int row, int lane, int D, float lr, float eps) {
-    int old = 0;
-    if (lane == 0) old = atomicSub(cnt + row, 1);
-    old = __shfl(old, 0);
-    if (old != 1) return;
-    for (int e = lane; e < D; e += 64) {
-        const size_t i = (size_t)row * D + e;
-        const float g = G[i];
-        G[i] = 0.0f;
-        opt_apply1<OPT>(W + i, A + i, W[i], g, lr, eps);
-    }
-    if (bW != nullptr && lane == 0) {
-        const float gb = bG[row];
-        bG[row] = 0.0f;
-        opt_apply1<OPT>(bW + row, bA + row, bW[row], gb, lr, eps);
-    }
-}
-
-template <int OPT>
-__global__ __launch_bounds__(256) void dup_generic_kernel(PairArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    for (int64_t t = wave_global; t < a.B; t += stride) {
-        const int m = a.dupmask[t];
-        if (m == 0) continue;
-        if (m & 1) finalize_row_generic<OPT>(a.U, a.gU, a.cntU, a.aU, nullptr, nullptr, nullptr, a.uid[t], lane, a.D, a.lr, a.eps);
-        if (m & 2) finalize_row_generic<OPT>(a.V, a.gV, a.cntV, a.aV, a.b, a.gb, a.ab, a.pid[t], lane, a.D, a.lr, a.eps);
-        if (m & 4) finalize_row_generic<OPT>(a.V, a.gV, a.cntV, a.aV, a.b, a.gb, a.ab, a.nid[t], lane, a.D, a.lr, a.eps);
-    }
-    if (blockIdx.x == 0) reduce_partials(a);
 }
 
 // ---------------------------------------------------------------- launchers ---
@@ -445,14 +495,6 @@ static inline int64_t fused_grid(int D, int64_t B) {
 }
 
 int orx_fused_nwaves(int D, int64_t B) { return (int)(fused_grid(D, B) * 4); }
-
-int orx_launch_count(orx_ctx* ctx, const PairArgs& a) {
-    ProfScope ps(ctx, ORX_K_COUNT);
-    const int64_t g = (a.B + 255) / 256;
-    hipLaunchKernelGGL(count_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
-    ORX_HIP(hipGetLastError());
-    return ORX_OK;
-}
 
 template <int LPR, int MODEL, int OPT>
 static void launch_fused_mode(int mode, dim3 g, hipStream_t s, const PairArgs& a) {
@@ -486,11 +528,10 @@ static void launch_fused_lpr(int lpr, int mode, dim3 g, hipStream_t s, const Pai
     }
 }
 
-int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairArgs& a, int* nwaves_out) {
+int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairArgs& a) {
     ProfScope ps(ctx, ORX_K_FUSED);
     const int lpr = lpr_for_dim(a.D);
     const dim3 g((unsigned)fused_grid(a.D, a.B));
-    if (nwaves_out) *nwaves_out = (int)g.x * 4;
     const int ok = (optkind == ORX_ADAGRAD) ? ORX_ADAGRAD : ORX_SGD;
     if (model == ORX_BPR) {
         if (ok == ORX_ADAGRAD) launch_fused_lpr<ORX_BPR, ORX_ADAGRAD>(lpr, mode, g, ctx->stream, a);
@@ -504,28 +545,27 @@ int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairA
 }
 
 template <int OPT>
-static void launch_dup_lpr(int lpr, dim3 g, hipStream_t s, const PairArgs& a) {
+static void launch_dup_apply_lpr(int lpr, dim3 g, hipStream_t s, const PairArgs& a) {
     switch (lpr) {
-        case 4: hipLaunchKernelGGL((dup_kernel<4, OPT>), g, dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((dup_kernel<8, OPT>), g, dim3(256), 0, s, a); break;
-        case 16: hipLaunchKernelGGL((dup_kernel<16, OPT>), g, dim3(256), 0, s, a); break;
-        case 32: hipLaunchKernelGGL((dup_kernel<32, OPT>), g, dim3(256), 0, s, a); break;
-        case 64: hipLaunchKernelGGL((dup_kernel<64, OPT>), g, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((dup_generic_kernel<OPT>), g, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((dup_apply_kernel<4, OPT>), g, dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((dup_apply_kernel<8, OPT>), g, dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((dup_apply_kernel<16, OPT>), g, dim3(256), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((dup_apply_kernel<32, OPT>), g, dim3(256), 0, s, a); break;
+        case 64: hipLaunchKernelGGL((dup_apply_kernel<64, OPT>), g, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((dup_apply_generic_kernel<OPT>), g, dim3(256), 0, s, a); break;
     }
 }
 
-// optkind < 0: only reduce the loss partials (modes without duplicate handling)
-int orx_launch_dup(orx_ctx* ctx, int optkind, const PairArgs& a) {
-    ProfScope ps(ctx, ORX_K_DUP);
-    if (optkind < 0) {
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
-    } else {
-        const int lpr = lpr_for_dim(a.D);
-        const dim3 g((unsigned)fused_grid(a.D, a.B));
-        if (optkind == ORX_ADAGRAD) launch_dup_lpr<ORX_ADAGRAD>(lpr, g, ctx->stream, a);
-        else launch_dup_lpr<ORX_SGD>(lpr, g, ctx->stream, a);
-    }
+// The number of duplicated rows lives in device memory: fixed grid, grid-stride loop.
+int orx_launch_dup_apply(orx_ctx* ctx, int optkind, const PairArgs& a) {
+    ProfScope ps(ctx, ORX_K_DUPAPPLY);
+    const int lpr = lpr_for_dim(a.D);
+    int64_t want = (a.B * 3 / 16) / (lpr ? 4 * (64 / lpr) : 4) + 1;     // ~ expected duplicates of a uniform batch
+    if (want > 2048) want = 2048;
+    if (want < 64) want = 64;
+    const dim3 g((unsigned)want);
+    if (optkind == ORX_ADAGRAD) launch_dup_apply_lpr<ORX_ADAGRAD>(lpr, g, ctx->stream, a);
+    else launch_dup_apply_lpr<ORX_SGD>(lpr, g, ctx->stream, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

@@ -47,8 +47,10 @@ struct orx_ctx {
     // staging buffers (grown on demand)
     int32_t* d_ids = nullptr;  size_t d_ids_cap = 0;       // host-id upload
     float* d_lab = nullptr;    size_t d_lab_cap = 0;
-    unsigned char* d_dupmask = nullptr; size_t d_dupmask_cap = 0;
-    float* d_partial = nullptr; size_t d_partial_cap = 0;   // per-wave loss partials
+    unsigned char* d_dflag = nullptr; size_t d_dflag_cap = 0;   // [K][3B] duplicate flags
+    uint32_t* d_dlist = nullptr; size_t d_dlist_cap = 0;         // [K][2B] duplicated rows
+    int* d_dcount = nullptr;   size_t d_dcount_cap = 0;          // [K]
+    float* d_partial = nullptr; size_t d_partial_cap = 0;   // [K][nwaves][2] loss partials
     double* d_loss = nullptr;  size_t d_loss_cap = 0;       // [K][2] step results
     float* d_tmp = nullptr;    size_t d_tmp_cap = 0;        // misc fp32 scratch
     bool prof = false;
@@ -63,7 +65,6 @@ struct orx_table {
     int32_t dim = 0;
     bool owned = true;
     // per-step scratch, allocated on first use by a train step
-    int* cnt = nullptr;               // [rows] reference counts (all-zero between steps)
     float* gsum = nullptr;            // [rows, dim] duplicate-row gradient sums (all-zero between steps)
 };
 
@@ -82,7 +83,7 @@ struct orx_opt {
 
 // ------------------------------------------------------- helpers (api.hip) ---
 int orx_ensure(void** p, size_t* cap, size_t bytes);           // grow a device buffer
-int orx_table_scratch(orx_table* t);                            // allocate cnt/gsum
+int orx_table_scratch(orx_table* t);                            // allocate gsum
 int orx_opt_slots(orx_opt* opt, orx_table* t, OptSlots* out);   // allocate optimizer slots
 void orx_prof_begin(orx_ctx* ctx, int kid);
 void orx_prof_end(orx_ctx* ctx, int kid);
@@ -94,32 +95,55 @@ struct ProfScope {
 };
 
 // ------------------------------------------------ kernel launch parameters ---
+// Duplicate detection output, per step (reference index r: user lookup k -> k,
+// pos-item lookup k -> B + k, neg-item lookup k -> 2B + k):
+//   dflag[r]   = 1 if the row of r is referenced more than once in the batch, else 0
+//   dlist[...] = the distinct duplicated rows of the step: row | (is_item << 31)
+//   dcount     = number of entries in dlist
 struct PairArgs {
-    // tables
     float* U; float* V; float* b;
-    float* gU; float* gV; float* gb;          // duplicate gradient sums (gb: [NI])
-    int* cntU; int* cntV;
-    float* aU; float* aV; float* ab;          // Adagrad accumulators (ab: [NI])
+    float* gU; float* gV; float* gb;          // duplicate-row gradient sums (zero between steps)
+    float* aU; float* aV; float* ab;          // Adagrad accumulators
     const int32_t* uid; const int32_t* pid; const int32_t* nid;
+    const unsigned char* dflag;               // [3B] (exact mode)
+    const uint32_t* dlist;                    // duplicated rows of this step
+    const int* dcount;
     int64_t B; int64_t NU; int64_t NI;
     int D;
     float lr; float eps; float margin; float invB; float l2w;
-    unsigned char* dupmask;                   // [B]  bit0 user, bit1 pos item, bit2 neg item
-    float* partial;                           // [nwaves][2] loss / l2 partials
-    double* loss_out;                         // [2] for this step
+    float* partial;                           // [nwaves][2] loss / l2 partials of this step
     int* err;
+};
+
+struct DedupArgs {
+    const int32_t* uid; const int32_t* pid; const int32_t* nid;   // step 0 of the chunk
+    int64_t id_stride;                        // elements between consecutive steps
+    unsigned char* dflag;                     // [K][flag_stride]
+    uint32_t* dlist;                          // [K][list_stride]
+    int* dcount;                              // [K], zeroed before the launch
+    int64_t flag_stride; int64_t list_stride;
+    int64_t B; int64_t NU; int64_t NI;
+    int nbu; int nbi;                         // row-range buckets per table
+    int first_only;                           // censor: dflag = 1 only on non-first references
+};
+
+struct ReduceArgs {
+    const float* partial;                     // [K][nwaves][2]
+    double* out;                              // [K][2]
     int nwaves;
 };
 
 // launchers implemented in kernels_pairwise.hip
-int orx_launch_count(orx_ctx* ctx, const PairArgs& a);
-int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairArgs& a, int* nwaves_out);
-int orx_launch_dup(orx_ctx* ctx, int optkind, const PairArgs& a);
+int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K);
+int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairArgs& a);
+int orx_launch_dup_apply(orx_ctx* ctx, int optkind, const PairArgs& a);
+int orx_launch_loss_reduce(orx_ctx* ctx, const ReduceArgs& a, int64_t K);
 int orx_fused_nwaves(int D, int64_t B);
+int orx_dedup_buckets(int64_t rows);
 
 // fused-kernel modes
-enum { MODE_EXACT = 0,     // unique rows in place, duplicate rows -> gsum (needs counts)
-       MODE_HOGWILD = 1,   // everything in place, no counts
+enum { MODE_EXACT = 0,     // unique rows in place; duplicate rows -> gsum, applied by dup_apply
+       MODE_HOGWILD = 1,   // everything in place, racy, no duplicate handling
        MODE_ACCUM = 2,     // everything -> gsum (Adam: dense sweep follows)
        MODE_LOSS = 3 };    // forward only
 
@@ -128,7 +152,7 @@ int orx_launch_init_uniform(orx_ctx* ctx, float* w, int64_t n, float lo, float h
 int orx_launch_fill(orx_ctx* ctx, float* w, int64_t n, float v);
 int orx_launch_gather(orx_ctx* ctx, const float* w, const float* bias, int64_t rows, int dim,
                       const int32_t* ids, int64_t n, float* out, int64_t out_stride, int* err);
-int orx_launch_censor(orx_ctx* ctx, float* w, int* cnt, int64_t rows, int dim, const int32_t* ids,
+int orx_launch_censor(orx_ctx* ctx, float* w, const unsigned char* dflag, int64_t rows, int dim, const int32_t* ids,
                       int64_t n, float min_norm, int* err);
 int orx_launch_adam_sweep(orx_ctx* ctx, float* w, float* m, float* v, float* gsum, int64_t n,
                           float lr_t, float b1, float b2, float eps);

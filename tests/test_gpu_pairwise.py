@@ -71,8 +71,9 @@ def _rand_case(seed, NU, NI, B, D, hot=True):
     pid = rng.integers(0, NI, B).astype(np.int32)
     nid = rng.integers(0, NI, B).astype(np.int32)
     if hot:
-        uid[: B // 8] = 3                        # one user in 1/8 of the batch
-        nid[B // 8: B // 8 + 17] = pid[B // 8: B // 8 + 17]      # p == n
+        uid[:16] = 3                             # a hot user (16x; lr * count stays < 1 so that
+        #                                          three steps do not amplify fp32 rounding)
+        nid[16:33] = pid[16:33]                  # p == n
         uid[-1], pid[-1], nid[-1] = NU - 1, NI - 1, 0            # boundary ids
     return U, V, b, uid, pid, nid
 
