@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BPR training triplets/s at dim=64 on a synthetic
+1M-user x 1M-item table (BASELINE.json configs[1]), MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one fused train step (forward on the pre-step tables, gradients of
+loss + l2_loss, exact TF sparse SGD apply) over one batch of 65536 triplets
+per GPU; ids are synthetic and already resident in HBM when the timed region
+starts.  N = 1: tables live on one GPU.  N > 1: tables are row-sharded across
+the N ranks (row r on rank r % N) and every step exchanges triplets, item rows
+and item-row gradients with RCCL all-to-all (openrec_amd/sharded.py);
+per-GPU batch is fixed => "scaling": "weak".
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def alg_bytes_per_triplet(dim, opt):
+    # SGD 24*D + 28, Adagrad 48*D + 44 bytes per triplet
+    return 24 * dim + 28 if opt == "sgd" else 48 * dim + 44
+
+
+def make_ids(torch, n_users, n_items, steps, batch, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    uid = torch.randint(0, n_users, (steps, batch), device=device, dtype=torch.int32, generator=g)
+    pid = torch.randint(0, n_items, (steps, batch), device=device, dtype=torch.int32, generator=g)
+    nid = torch.randint(0, n_items, (steps, batch), device=device, dtype=torch.int32, generator=g)
+    for _ in range(4):                      # resample negatives that collide with the positive
+        clash = nid == pid
+        if not bool(clash.any()):
+            break
+        fresh = torch.randint(0, n_items, (steps, batch), device=device, dtype=torch.int32, generator=g)
+        nid = torch.where(clash, fresh, nid)
+    return uid.contiguous(), pid.contiguous(), nid.contiguous()
+
+
+def cpu_baseline(args, budget_s=15.0, max_steps=2000):
+    """The C/OpenMP oracle port (oracle/orx_oracle.c) on the host cores: same
+    table shapes, same batch size, a bounded number of steps."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(0)
+    U = rng.uniform(-0.05, 0.05, (args.users, args.dim)).astype(np.float32)
+    V = rng.uniform(-0.05, 0.05, (args.items, args.dim)).astype(np.float32)
+    b = rng.uniform(-0.05, 0.05, (args.items, 1)).astype(np.float32)
+    cpu = c_oracle.PairwiseCPU(args.model, args.opt, U, V, b, lr=0.05)
+    ids = [(rng.integers(0, args.users, args.batch).astype(np.int32),
+            rng.integers(0, args.items, args.batch).astype(np.int32),
+            rng.integers(0, args.items, args.batch).astype(np.int32)) for _ in range(32)]
+    for s in range(2):
+        cpu.step(*ids[s])
+    t0 = time.perf_counter()
+    done = 0
+    while done < max_steps and time.perf_counter() - t0 < budget_s:      # bounded sample (~15 s)
+        cpu.step(*ids[done % len(ids)])
+        done += 1
+    dt = time.perf_counter() - t0
+    return dict(value=done * args.batch / dt, unit="triplets/s", cores=c_oracle.num_threads(), kind="port",
+                sample=f"{done} steps of {args.batch} triplets on {args.users}x{args.items}x{args.dim} tables, "
+                       f"oracle/orx_oracle.c (OpenMP), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", default="bpr", choices=["bpr", "ucml"])
+    ap.add_argument("--opt", default="sgd", choices=["sgd", "adagrad"])
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--users", type=int, default=1_000_000)
+    ap.add_argument("--items", type=int, default=1_000_000)
+    ap.add_argument("--batch", type=int, default=65536, help="triplets per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hogwild", action="store_true", help="racy non-reference mode (never the headline)")
+    args = ap.parse_args()
+
+    import torch
+    from openrec_amd import runtime as rt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    K, W = args.steps, args.warmup
+    lr = 0.05
+    if world == 1:
+        ctx = rt.Context(local_rank)
+        U = rt.Table(args.users, args.dim, ctx).init_uniform(seed=0)
+        V = rt.Table(args.items, args.dim, ctx).init_uniform(seed=1)
+        b = rt.Table(args.items, 1, ctx).init_uniform(seed=2)
+        opt = rt.Optimizer.sgd(lr, ctx=ctx) if args.opt == "sgd" else rt.Optimizer.adagrad(lr, ctx=ctx)
+        uid, pid, nid = make_ids(torch, args.users, args.items, K + W, args.batch, 1234, device)
+        torch.cuda.synchronize()
+
+        def run(first, count, want_loss=False):
+            return rt.pairwise_step(args.model, opt, U, V, b, uid[first:first + count], pid[first:first + count],
+                                    nid[first:first + count], K=count, B=args.batch, margin=0.5,
+                                    hogwild=args.hogwild, want_loss=want_loss)
+
+        if W:
+            run(0, W)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(W, K)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # kernel-level timing of the same K steps (HIP events on the library's stream)
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        losses = run(W, K, want_loss=True)
+        ctx.prof_enable(False)
+        prof = ctx.prof_get()
+        parallelism = "single-gpu"
+    else:
+        from openrec_amd import sharded
+        eng = sharded.ShardedPairwise(args.model, args.opt, args.users, args.items, args.dim, lr=lr,
+                                      rank=rank, world=world, device=device, seed=0)
+        uid, pid, nid = make_ids(torch, args.users, args.items, K + W, args.batch, 1234 + rank, device)
+        for s in range(W):
+            eng.step(uid[s], pid[s], nid[s])
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(W, W + K):
+            eng.step(uid[s], pid[s], nid[s])
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        prof = eng.prof()
+        losses = None
+        parallelism = f"row-sharded x{world}, all-to-all"
+
+    if rank == 0:
+        total = K * args.batch * world
+        bpt = alg_bytes_per_triplet(args.dim, args.opt)
+        out = {
+            "metric": "BPR training triplets/sec at dim=64, 1Mx1M table" if (args.model, args.dim) == ("bpr", 64)
+                      else f"{args.model.upper()} training triplets/sec at dim={args.dim}",
+            "value": total / dt, "unit": "triplets/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} dim={args.dim} {args.users}x{args.items} table, "
+                                   f"batch={args.batch} triplets/GPU, {args.opt} lr={lr}, objective loss+l2_loss, "
+                                   f"{'HOGWILD (non-reference)' if args.hogwild else 'exact TF duplicate semantics'}",
+                       "parallelism": parallelism},
+        }
+        fused = prof.get("fused", {})
+        if fused.get("launches"):
+            dur = fused["total_ms"] / fused["launches"] * 1e-3
+            achieved = args.batch * bpt / dur / 1e9
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "fused_hbm_traffic.json")
+            if world == 1 and os.path.exists(tfile):
+                try:
+                    traffic = json.load(open(tfile)).get(f"{args.model}_d{args.dim}_{args.opt}")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": "fused_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "bytes_per_triplet": bpt, "kernel_us": dur * 1e6,
+                               "other_kernels_us": {k: v["total_ms"] / v["launches"] * 1e3
+                                                    for k, v in prof.items() if v.get("launches") and k != "fused"}}
+        if losses is not None:
+            out["loss_first_last"] = [float(losses[0][0]), float(losses[0][-1])]
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:                      # the baseline must never hide the GPU number
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,15 +43,16 @@ int orx_ensure(void** p, size_t* cap, size_t bytes) {
 
 void orx_prof_begin(orx_ctx* ctx, int kid) {
     hipEvent_t e0, e1;
+    ctx->cur_e0 = ctx->cur_e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
-    hipEventRecord(e0, ctx->stream);
     ctx->prof_slot[kid].ev.push_back(e0);
     ctx->prof_slot[kid].ev.push_back(e1);
+    ctx->cur_e0 = e0; ctx->cur_e1 = e1;
 }
 
 void orx_prof_end(orx_ctx* ctx, int kid) {
-    auto& ev = ctx->prof_slot[kid].ev;
-    if (ev.size() >= 2) hipEventRecord(ev.back(), ctx->stream);
+    (void)kid;
+    ctx->cur_e0 = ctx->cur_e1 = nullptr;
 }
 
 static int prof_collect(orx_ctx* ctx) {

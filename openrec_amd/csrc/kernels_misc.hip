@@ -36,13 +36,13 @@ static inline unsigned grid_for(int64_t n, int per_block) {
 }
 
 int orx_launch_init_uniform(orx_ctx* ctx, float* w, int64_t n, float lo, float hi, uint64_t seed) {
-    hipLaunchKernelGGL(init_uniform_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, w, n, lo, hi, seed);
+    ORX_LAUNCH(ctx, init_uniform_kernel, dim3(grid_for(n, 256)), dim3(256), 0, w, n, lo, hi, seed);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
 
 int orx_launch_fill(orx_ctx* ctx, float* w, int64_t n, float v) {
-    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, w, n, v);
+    ORX_LAUNCH(ctx, fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, w, n, v);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -75,11 +75,9 @@ int orx_launch_gather(orx_ctx* ctx, const float* w, const float* bias, int64_t r
     if (n == 0) return ORX_OK;
     const bool vec = (dim % 4 == 0) && (out_stride % 4 == 0) && (((uintptr_t)out) % 16 == 0);
     if (vec) {
-        hipLaunchKernelGGL((gather_kernel<true>), dim3(grid_for(n * (dim / 4), 256)), dim3(256), 0, ctx->stream,
-                           w, bias, rows, dim, ids, n, out, out_stride, err);
+        ORX_LAUNCH(ctx, (gather_kernel<true>), dim3(grid_for(n * (dim / 4), 256)), dim3(256), 0, w, bias, rows, dim, ids, n, out, out_stride, err);
     } else {
-        hipLaunchKernelGGL((gather_kernel<false>), dim3(grid_for(n * dim, 256)), dim3(256), 0, ctx->stream,
-                           w, bias, rows, dim, ids, n, out, out_stride, err);
+        ORX_LAUNCH(ctx, (gather_kernel<false>), dim3(grid_for(n * dim, 256)), dim3(256), 0, w, bias, rows, dim, ids, n, out, out_stride, err);
     }
     ORX_HIP(hipGetLastError());
     return ORX_OK;
@@ -114,7 +112,7 @@ int orx_launch_censor(orx_ctx* ctx, float* w, const unsigned char* dflag, int64_
                       int64_t n, float min_norm, int* err) {
     if (n == 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_CENSOR);
-    hipLaunchKernelGGL(censor_apply_kernel, dim3(grid_for(n, 4)), dim3(256), 0, ctx->stream, w, dflag, rows, dim, ids, n, min_norm, err);
+    ORX_LAUNCH(ctx, censor_apply_kernel, dim3(grid_for(n, 4)), dim3(256), 0, w, dflag, rows, dim, ids, n, min_norm, err);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -142,7 +140,7 @@ __global__ __launch_bounds__(256) void adam_sweep_kernel(float* w, float* m, flo
 int orx_launch_adam_sweep(orx_ctx* ctx, float* w, float* m, float* v, float* gsum, int64_t n,
                           float lr_t, float b1, float b2, float eps) {
     ProfScope ps(ctx, ORX_K_SWEEP);
-    hipLaunchKernelGGL(adam_sweep_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, w, m, v, gsum, n, lr_t, b1, b2, eps);
+    ORX_LAUNCH(ctx, adam_sweep_kernel, dim3(grid_for(n, 256)), dim3(256), 0, w, m, v, gsum, n, lr_t, b1, b2, eps);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

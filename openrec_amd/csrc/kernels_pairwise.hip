@@ -244,7 +244,7 @@ int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K) {
         ORX_HIP(hipFuncSetAttribute((const void*)dedup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DD_LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(dedup_kernel, dim3((unsigned)g), dim3(DD_THREADS), DD_LDS_BYTES, ctx->stream, a);
+    ORX_LAUNCH(ctx, dedup_kernel, dim3((unsigned)g), dim3(DD_THREADS), DD_LDS_BYTES, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(ReduceArgs a) {
 
 int orx_launch_loss_reduce(orx_ctx* ctx, const ReduceArgs& a, int64_t K) {
     ProfScope ps(ctx, ORX_K_REDUCE);
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3((unsigned)K), dim3(256), 0, ctx->stream, a);
+    ORX_LAUNCH(ctx, loss_reduce_kernel, dim3((unsigned)K), dim3(256), 0, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -497,27 +497,27 @@ static inline int64_t fused_grid(int D, int64_t B) {
 int orx_fused_nwaves(int D, int64_t B) { return (int)(fused_grid(D, B) * 4); }
 
 template <int LPR, int MODEL, int OPT>
-static void launch_fused_mode(int mode, dim3 g, hipStream_t s, const PairArgs& a) {
+static void launch_fused_mode(int mode, dim3 g, orx_ctx* s, const PairArgs& a) {
     switch (mode) {
-        case MODE_EXACT: hipLaunchKernelGGL((fused_kernel<LPR, MODEL, OPT, MODE_EXACT>), g, dim3(256), 0, s, a); break;
-        case MODE_HOGWILD: hipLaunchKernelGGL((fused_kernel<LPR, MODEL, OPT, MODE_HOGWILD>), g, dim3(256), 0, s, a); break;
-        case MODE_ACCUM: hipLaunchKernelGGL((fused_kernel<LPR, MODEL, ORX_SGD, MODE_ACCUM>), g, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((fused_kernel<LPR, MODEL, ORX_SGD, MODE_LOSS>), g, dim3(256), 0, s, a); break;
+        case MODE_EXACT: ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, OPT, MODE_EXACT>), g, dim3(256), 0, a); break;
+        case MODE_HOGWILD: ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, OPT, MODE_HOGWILD>), g, dim3(256), 0, a); break;
+        case MODE_ACCUM: ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, ORX_SGD, MODE_ACCUM>), g, dim3(256), 0, a); break;
+        default: ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, ORX_SGD, MODE_LOSS>), g, dim3(256), 0, a); break;
     }
 }
 
 template <int MODEL, int OPT>
-static void launch_generic_mode(int mode, dim3 g, hipStream_t s, const PairArgs& a) {
+static void launch_generic_mode(int mode, dim3 g, orx_ctx* s, const PairArgs& a) {
     switch (mode) {
-        case MODE_EXACT: hipLaunchKernelGGL((fused_generic_kernel<MODEL, OPT, MODE_EXACT>), g, dim3(256), 0, s, a); break;
-        case MODE_HOGWILD: hipLaunchKernelGGL((fused_generic_kernel<MODEL, OPT, MODE_HOGWILD>), g, dim3(256), 0, s, a); break;
-        case MODE_ACCUM: hipLaunchKernelGGL((fused_generic_kernel<MODEL, ORX_SGD, MODE_ACCUM>), g, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((fused_generic_kernel<MODEL, ORX_SGD, MODE_LOSS>), g, dim3(256), 0, s, a); break;
+        case MODE_EXACT: ORX_LAUNCH(s, (fused_generic_kernel<MODEL, OPT, MODE_EXACT>), g, dim3(256), 0, a); break;
+        case MODE_HOGWILD: ORX_LAUNCH(s, (fused_generic_kernel<MODEL, OPT, MODE_HOGWILD>), g, dim3(256), 0, a); break;
+        case MODE_ACCUM: ORX_LAUNCH(s, (fused_generic_kernel<MODEL, ORX_SGD, MODE_ACCUM>), g, dim3(256), 0, a); break;
+        default: ORX_LAUNCH(s, (fused_generic_kernel<MODEL, ORX_SGD, MODE_LOSS>), g, dim3(256), 0, a); break;
     }
 }
 
 template <int MODEL, int OPT>
-static void launch_fused_lpr(int lpr, int mode, dim3 g, hipStream_t s, const PairArgs& a) {
+static void launch_fused_lpr(int lpr, int mode, dim3 g, orx_ctx* s, const PairArgs& a) {
     switch (lpr) {
         case 4: launch_fused_mode<4, MODEL, OPT>(mode, g, s, a); break;
         case 8: launch_fused_mode<8, MODEL, OPT>(mode, g, s, a); break;
@@ -534,25 +534,25 @@ int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairA
     const dim3 g((unsigned)fused_grid(a.D, a.B));
     const int ok = (optkind == ORX_ADAGRAD) ? ORX_ADAGRAD : ORX_SGD;
     if (model == ORX_BPR) {
-        if (ok == ORX_ADAGRAD) launch_fused_lpr<ORX_BPR, ORX_ADAGRAD>(lpr, mode, g, ctx->stream, a);
-        else launch_fused_lpr<ORX_BPR, ORX_SGD>(lpr, mode, g, ctx->stream, a);
+        if (ok == ORX_ADAGRAD) launch_fused_lpr<ORX_BPR, ORX_ADAGRAD>(lpr, mode, g, ctx, a);
+        else launch_fused_lpr<ORX_BPR, ORX_SGD>(lpr, mode, g, ctx, a);
     } else {
-        if (ok == ORX_ADAGRAD) launch_fused_lpr<ORX_UCML, ORX_ADAGRAD>(lpr, mode, g, ctx->stream, a);
-        else launch_fused_lpr<ORX_UCML, ORX_SGD>(lpr, mode, g, ctx->stream, a);
+        if (ok == ORX_ADAGRAD) launch_fused_lpr<ORX_UCML, ORX_ADAGRAD>(lpr, mode, g, ctx, a);
+        else launch_fused_lpr<ORX_UCML, ORX_SGD>(lpr, mode, g, ctx, a);
     }
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
 
 template <int OPT>
-static void launch_dup_apply_lpr(int lpr, dim3 g, hipStream_t s, const PairArgs& a) {
+static void launch_dup_apply_lpr(int lpr, dim3 g, orx_ctx* s, const PairArgs& a) {
     switch (lpr) {
-        case 4: hipLaunchKernelGGL((dup_apply_kernel<4, OPT>), g, dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((dup_apply_kernel<8, OPT>), g, dim3(256), 0, s, a); break;
-        case 16: hipLaunchKernelGGL((dup_apply_kernel<16, OPT>), g, dim3(256), 0, s, a); break;
-        case 32: hipLaunchKernelGGL((dup_apply_kernel<32, OPT>), g, dim3(256), 0, s, a); break;
-        case 64: hipLaunchKernelGGL((dup_apply_kernel<64, OPT>), g, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((dup_apply_generic_kernel<OPT>), g, dim3(256), 0, s, a); break;
+        case 4: ORX_LAUNCH(s, (dup_apply_kernel<4, OPT>), g, dim3(256), 0, a); break;
+        case 8: ORX_LAUNCH(s, (dup_apply_kernel<8, OPT>), g, dim3(256), 0, a); break;
+        case 16: ORX_LAUNCH(s, (dup_apply_kernel<16, OPT>), g, dim3(256), 0, a); break;
+        case 32: ORX_LAUNCH(s, (dup_apply_kernel<32, OPT>), g, dim3(256), 0, a); break;
+        case 64: ORX_LAUNCH(s, (dup_apply_kernel<64, OPT>), g, dim3(256), 0, a); break;
+        default: ORX_LAUNCH(s, (dup_apply_generic_kernel<OPT>), g, dim3(256), 0, a); break;
     }
 }
 
@@ -564,8 +564,8 @@ int orx_launch_dup_apply(orx_ctx* ctx, int optkind, const PairArgs& a) {
     if (want > 2048) want = 2048;
     if (want < 64) want = 64;
     const dim3 g((unsigned)want);
-    if (optkind == ORX_ADAGRAD) launch_dup_apply_lpr<ORX_ADAGRAD>(lpr, g, ctx->stream, a);
-    else launch_dup_apply_lpr<ORX_SGD>(lpr, g, ctx->stream, a);
+    if (optkind == ORX_ADAGRAD) launch_dup_apply_lpr<ORX_ADAGRAD>(lpr, g, ctx, a);
+    else launch_dup_apply_lpr<ORX_SGD>(lpr, g, ctx, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

@@ -1,6 +1,7 @@
 // Internal declarations shared by the translation units of libopenrec_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -55,6 +56,7 @@ struct orx_ctx {
     float* d_tmp = nullptr;    size_t d_tmp_cap = 0;        // misc fp32 scratch
     bool prof = false;
     ProfSlot prof_slot[ORX_K_NUM];
+    hipEvent_t cur_e0 = nullptr, cur_e1 = nullptr;   // events of the launch being profiled (or null)
     int num_cu = 256;
 };
 
@@ -88,11 +90,17 @@ int orx_opt_slots(orx_opt* opt, orx_table* t, OptSlots* out);   // allocate opti
 void orx_prof_begin(orx_ctx* ctx, int kid);
 void orx_prof_end(orx_ctx* ctx, int kid);
 
+// While a ProfScope is alive, ORX_LAUNCH attaches a (start, stop) event pair to
+// the kernel dispatch itself (hipExtLaunchKernelGGL), i.e. the events carry the
+// kernel's own begin/end timestamps -- the same quantity rocprofv3 reports.
 struct ProfScope {
     orx_ctx* c; int k;
     ProfScope(orx_ctx* c_, int k_) : c(c_), k(k_) { if (c->prof) orx_prof_begin(c, k); }
     ~ProfScope() { if (c->prof) orx_prof_end(c, k); }
 };
+
+#define ORX_LAUNCH(ctx, kernel, grid, block, shm, ...)                                 \
+    hipExtLaunchKernelGGL(kernel, grid, block, shm, (ctx)->stream, (ctx)->cur_e0, (ctx)->cur_e1, 0, __VA_ARGS__)
 
 // ------------------------------------------------ kernel launch parameters ---
 // Duplicate detection output, per step (reference index r: user lookup k -> k,

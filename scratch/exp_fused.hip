@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void fused(A a){
     if(F&2){cu=a.cU[u];cp=a.cV[p];cn=a.cV[n];}
     if(F&32){ cu+=a.c2U[u]>>30; cp+=a.c2V[p]>>30; cn+=a.c2V[n]>>30; }
     float*Up=a.U+(size_t)u*64+sub*4,*Pp=a.V+(size_t)p*64+sub*4,*Np=a.V+(size_t)n*64+sub*4;
-    f4 ru=*(f4*)Up, rp=*(f4*)Pp, rn=*(f4*)Np;
+    f4 ru,rp,rn;
+    if(F&256){ ru=__builtin_nontemporal_load((f4*)Up); rp=__builtin_nontemporal_load((f4*)Pp); rn=__builtin_nontemporal_load((f4*)Np);} else { ru=*(f4*)Up; rp=*(f4*)Pp; rn=*(f4*)Np; }
     float bp=0,bn=0; if(F&1){bp=a.b[p];bn=a.b[n];}
     if(F&8){ if(sub==0){ atomicAdd(a.c2U+a.uid2[t],1); atomicAdd(a.c2V+a.pid2[t],1); atomicAdd(a.c2V+a.nid2[t],1);} }
     if(F&16){ if(sub==0){ a.c2U[a.uid2[t]]=t; a.c2V[a.pid2[t]]=t|(1<<20); a.c2V[a.nid2[t]]=t|(2<<20);} }
@@ -35,9 +36,15 @@ __global__ __launch_bounds__(256) void fused(A a){
     float g;
     if(F&64){ float m=fmaxf(x,-30.f); float e=__expf(-fabsf(m)); lacc+= (sub==0)?(fmaxf(-m,0.f)+log1pf(e))*a.invB:0.f; float sig=(x>=0)?e/(1+e):1.f/(1+e); g=(x>=-30.f)?-sig*a.invB:0.f; sacc+=dot4(ru,ru)+dot4(rp,rp)+dot4(rn,rn);} else g=x*1e-6f;
     f4 gu=g*(rp-rn)+ru, gp=g*ru+rp, gn=-g*ru+rn;
+    if(F&128){
+      if(cu==1){ __builtin_nontemporal_store(ru-a.lr*gu,(f4*)Up); }
+      if(cp==1){ __builtin_nontemporal_store(rp-a.lr*gp,(f4*)Pp); if(sub==0){ if(F&1) a.b[p]=bp-a.lr*g; } }
+      if(cn==1){ __builtin_nontemporal_store(rn-a.lr*gn,(f4*)Np); if(sub==0){ if(F&1) a.b[n]=bn+a.lr*g; } }
+    } else {
     if(cu==1){ *(f4*)Up=ru-a.lr*gu; if((F&4)&&sub==0) a.cU[u]=0; }
     if(cp==1){ *(f4*)Pp=rp-a.lr*gp; if(sub==0){ if(F&1) a.b[p]=bp-a.lr*g; if(F&4) a.cV[p]=0; } }
     if(cn==1){ *(f4*)Np=rn-a.lr*gn; if(sub==0){ if(F&1) a.b[n]=bn+a.lr*g; if(F&4) a.cV[n]=0; } }
+    }
     if((F&2)&&sub==0) a.dm[t]=(cu!=1)|((cp!=1)<<1)|((cn!=1)<<2);
   }
   if(F&64){ for(int o=32;o>0;o>>=1){ lacc+=__shfl_xor(lacc,o); sacc+=__shfl_xor(sacc,o);} if(lane==0){a.part[2*gw]=lacc;a.part[2*gw+1]=sacc;} }
@@ -55,21 +62,13 @@ int main(){
   auto setids=[&](){ int s=step%K, s2=(step+1)%K; a.uid=ids+(size_t)s*B; a.pid=ids+(size_t)(K+s)*B; a.nid=ids+(size_t)(2*K+s)*B; a.uid2=ids+(size_t)s2*B; a.pid2=ids+(size_t)(K+s2)*B; a.nid2=ids+(size_t)(2*K+s2)*B; step++; };
   #define RUN(F,UN,name) { float ms=timeit([&]{ setids(); hipLaunchKernelGGL((fused<F,UN>),dim3(B/(16*UN)),dim3(256),0,0,a); },48); printf("%-46s UN=%d: %.1f us  (%.2f TB/s alg)\n",name,UN,ms*1e3,B*1564.0/ms/1e9); CK(hipMemcpy(a.cU,ones.data(),N*4,hipMemcpyHostToDevice)); CK(hipMemcpy(a.cV,ones.data(),N*4,hipMemcpyHostToDevice)); }
   RUN(0,1,"rows only")
-  RUN(0,2,"rows only")
-  RUN(0,4,"rows only")
-  RUN(64,1,"rows+loss math")
-  RUN(1,1,"rows+bias")
+  RUN(128,1,"rows only, nt stores")
+  RUN(256,1,"rows only, nt loads")
+  RUN(384,1,"rows only, nt loads+stores")
   RUN(65,1,"rows+bias+loss")
+  RUN(65+128,1,"rows+bias+loss, nt stores")
+  RUN(65+384,1,"rows+bias+loss, nt both")
+  // block-size / launch-bounds sensitivity is probed by UN
   RUN(65,2,"rows+bias+loss")
-  RUN(65,4,"rows+bias+loss")
-  RUN(67,1,"rows+bias+loss+cntread")
-  RUN(67,2,"rows+bias+loss+cntread")
-  RUN(71,1,"rows+bias+loss+cntread+reset")
-  RUN(71,2,"rows+bias+loss+cntread+reset")
-  RUN(79,1,"rows+bias+loss+cntread+reset+embedded atomics")
-  RUN(79,2,"rows+bias+loss+cntread+reset+embedded atomics")
-  RUN(83,1,"rows+bias+loss+tagread+tagstore(next)")
-  RUN(115,1,"rows+bias+loss+tagread+tagstore+tagB load")
-  RUN(115,2,"rows+bias+loss+tagread+tagstore+tagB load")
   return 0;
 }
