@@ -154,16 +154,23 @@ int orx_pointwise_step(orx_ctx* ctx, int model, orx_opt* opt,
 
 /* ---- sharded building blocks (row-wise sharded tables, one rank per GPU;
  * the exchange itself is RCCL all-to-all driven by the host, see
- * openrec_amd/sharded.py).  All pointers are DEVICE pointers.
+ * openrec_amd/sharded.py).  No reference equivalent (the reference is single
+ * process).  All pointers are DEVICE pointers; ids are LOCAL row ids, an id < 0
+ * marks a padding slot and is skipped.
  *   gather_rows : out[k, 0:D] = W[ids[k]], out[k, D] = bias[ids[k]] (bias may be NULL)
- *   pair_grads  : per-occurrence gradients of J from already gathered rows
+ *   pair_grads  : from gathered rows [T, row_stride] (bias at column D) compute the
+ *                 per-occurrence gradients of J (bias gradient at column D of gp/gn)
+ *                 and ADD this rank's (loss, l2_loss) contribution to loss_l2_accum[2];
+ *                 the loss mean is taken over B_global; triplet k is live iff
+ *                 valid == NULL or valid[k] >= 0
  *   apply_rows  : optimizer sparse apply of per-occurrence gradient rows
+ *                 (SGD: every occurrence accumulated; Adagrad: duplicates summed first)
  */
 int orx_gather_rows(orx_ctx* ctx, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
                     float* out, int64_t out_stride);
 int orx_pair_grads(orx_ctx* ctx, int model, int32_t D,
                    const float* u_rows, const float* p_rows, const float* n_rows, int64_t row_stride,
-                   int64_t B, int64_t B_global, float margin, int flags,
+                   const int32_t* valid, int64_t T, int64_t B_global, float margin, int flags,
                    float* gu, float* gp, float* gn, int64_t g_stride, double* loss_l2_accum);
 int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias,
                    const int32_t* ids, int64_t n, const float* grads, int64_t g_stride);

@@ -55,7 +55,7 @@ SIGNATURES = {
     "orx_pointwise_step": (c_int, [_p, c_int, _p, _p, _p, _p, _p, _ip, _ip, _fp, c_int64, c_int64, c_int64,
                                    c_float, c_float, c_int, _fp, _fp]),
     "orx_gather_rows": (c_int, [_p, _p, _p, _ip, c_int64, _fp, c_int64]),
-    "orx_pair_grads": (c_int, [_p, c_int, c_int32, _fp, _fp, _fp, c_int64, c_int64, c_int64, c_float, c_int,
+    "orx_pair_grads": (c_int, [_p, c_int, c_int32, _fp, _fp, _fp, c_int64, _ip, c_int64, c_int64, c_float, c_int,
                                _fp, _fp, _fp, c_int64, _p]),
     "orx_apply_rows": (c_int, [_p, _p, _p, _p, _ip, c_int64, _fp, c_int64]),
     "orx_prof_enable": (c_int, [_p, c_int]),

@@ -244,7 +244,7 @@ static int dedup_single(orx_ctx* c, const int32_t* d_ids, int64_t n, int64_t row
     memset(&d, 0, sizeof(d));
     d.uid = d_ids; d.pid = d_ids; d.nid = d_ids; d.id_stride = n;
     d.dflag = c->d_dflag; d.flag_stride = n;
-    d.B = n; d.NU = rows; d.NI = 0; d.nbu = orx_dedup_buckets(rows); d.nbi = 0; d.first_only = 1;
+    d.nU = n; d.nP = 0; d.nN = 0; d.NU = rows; d.NI = 0; d.nbu = orx_dedup_buckets(rows); d.nbi = 0; d.first_only = 1;
     return orx_launch_dedup(c, d, 1);
 }
 
@@ -436,7 +436,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             d.uid = du + s0 * ds; d.pid = dp + s0 * ds; d.nid = dn + s0 * ds; d.id_stride = ds;
             d.dflag = c->d_dflag; d.dlist = c->d_dlist; d.dcount = c->d_dcount;
             d.flag_stride = 3 * B; d.list_stride = list_stride;
-            d.B = B; d.NU = U->rows; d.NI = V->rows;
+            d.nU = B; d.nP = B; d.nN = B; d.NU = U->rows; d.NI = V->rows;
             d.nbu = orx_dedup_buckets(U->rows); d.nbi = orx_dedup_buckets(V->rows);
             ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));
             CHECK(orx_launch_dedup(c, d, kc));

@@ -52,7 +52,8 @@ int orx_launch_fill(orx_ctx* ctx, float* w, int64_t n, float v) {
 template <bool VEC4>
 __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                                      int64_t rows, int dim, const int32_t* __restrict__ ids,
-                                                     int64_t n, float* __restrict__ out, int64_t out_stride, int* err) {
+                                                     int64_t n, float* __restrict__ out, int64_t out_stride, int* err,
+                                                     int skip_negative) {
     const int per_row = VEC4 ? dim / 4 : dim;
     const int64_t total = n * per_row;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ w
         const int64_t k = i / per_row;
         const int e = (int)(i - k * per_row);
         const int r = ids[k];
+        if (skip_negative && r < 0) continue;                  // padding slot of the sharded exchange
         if ((uint32_t)r >= (uint64_t)rows) { *err = 1; continue; }
         if (VEC4) {
             *reinterpret_cast<f4*>(out + k * out_stride + 4 * e) = *reinterpret_cast<const f4*>(w + (size_t)r * dim + 4 * e);
@@ -71,13 +73,13 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ w
 }
 
 int orx_launch_gather(orx_ctx* ctx, const float* w, const float* bias, int64_t rows, int dim,
-                      const int32_t* ids, int64_t n, float* out, int64_t out_stride, int* err) {
+                      const int32_t* ids, int64_t n, float* out, int64_t out_stride, int* err, int skip_negative) {
     if (n == 0) return ORX_OK;
     const bool vec = (dim % 4 == 0) && (out_stride % 4 == 0) && (((uintptr_t)out) % 16 == 0);
     if (vec) {
-        ORX_LAUNCH(ctx, (gather_kernel<true>), dim3(grid_for(n * (dim / 4), 256)), dim3(256), 0, w, bias, rows, dim, ids, n, out, out_stride, err);
+        ORX_LAUNCH(ctx, (gather_kernel<true>), dim3(grid_for(n * (dim / 4), 256)), dim3(256), 0, w, bias, rows, dim, ids, n, out, out_stride, err, skip_negative);
     } else {
-        ORX_LAUNCH(ctx, (gather_kernel<false>), dim3(grid_for(n * dim, 256)), dim3(256), 0, w, bias, rows, dim, ids, n, out, out_stride, err);
+        ORX_LAUNCH(ctx, (gather_kernel<false>), dim3(grid_for(n * dim, 256)), dim3(256), 0, w, bias, rows, dim, ids, n, out, out_stride, err, skip_negative);
     }
     ORX_HIP(hipGetLastError());
     return ORX_OK;

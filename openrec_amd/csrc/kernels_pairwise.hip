@@ -39,126 +39,7 @@
 //     gsum[] is all-zero between steps.
 #include "orx_internal.h"
 
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-// ------------------------------------------------------------ lane helpers ---
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float x) {
-    return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
-}
-
-// sum over the LPR adjacent lanes that own one row; every lane gets the total
-template <int LPR>
-__device__ __forceinline__ float group_allreduce(float x) {
-    if (LPR >= 2) x += dpp_f<0xB1>(x);    // quad_perm [1,0,3,2]
-    if (LPR >= 4) x += dpp_f<0x4E>(x);    // quad_perm [2,3,0,1]
-    if (LPR >= 8) x += dpp_f<0x141>(x);   // row_half_mirror
-    if (LPR >= 16) x += dpp_f<0x140>(x);  // row_mirror
-    if (LPR >= 32) x += __shfl_xor(x, 16);
-    if (LPR >= 64) x += __shfl_xor(x, 32);
-    return x;
-}
-
-__device__ __forceinline__ float wave_sum(float x) {
-    x = group_allreduce<16>(x);
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 32);
-    return x;
-}
-
-__device__ __forceinline__ float dot4(f4 a, f4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-
-__device__ __forceinline__ void atomic_add_f4(float* p, f4 v) {
-    unsafeAtomicAdd(p + 0, v.x);
-    unsafeAtomicAdd(p + 1, v.y);
-    unsafeAtomicAdd(p + 2, v.z);
-    unsafeAtomicAdd(p + 3, v.w);
-}
-
-// device-coherent load: bypasses the per-CU L1 and the non-coherent per-XCD L2,
-// i.e. observes fp32 atomics performed by any CU of the device.
-__device__ __forceinline__ float load_coherent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ bool id_ok(int id, int64_t rows) { return (uint32_t)id < (uint64_t)rows; }
-
-// ------------------------------------------------------------ score / loss ---
-// Returns the per-triplet loss term and the gradient coefficient `g`.
-//   BPR : x = s+ - s-,  term = -log_sigmoid(max(x,-30))/B,  g = dJ/dx
-//   UCML: h = margin - diff, term = max(h,0), g = [h >= 0]
-template <int MODEL>
-__device__ __forceinline__ void score(float red, float bp, float bn, float invB, float margin,
-                                      float& term, float& g) {
-    if (MODEL == ORX_BPR) {
-        const float x = red + bp - bn;                       // pairwise_log_loss.py:19-30
-        const float m = fmaxf(x, -30.0f);                    // :32
-        const float e = __expf(-fabsf(m));
-        term = (fmaxf(-m, 0.0f) + log1pf(e)) * invB;         // -log_sigmoid(m) / B
-        const float sig = (x >= 0.0f) ? e / (1.0f + e) : 1.0f / (1.0f + e);   // sigmoid(-x)
-        g = (x >= -30.0f) ? -sig * invB : 0.0f;              // Maximum: gradient to arg 0 on >=
-    } else {
-        const float diff = red + bp - bn;                    // ucml.py:35-37, red = d(u,n) - d(u,p)
-        const float h = margin - diff;
-        term = fmaxf(h, 0.0f);                               // ucml.py:39 (sum)
-        g = (h >= 0.0f) ? 1.0f : 0.0f;
-    }
-}
-
-template <int MODEL>
-__device__ __forceinline__ float score_partial(f4 u, f4 p, f4 n) {
-    if (MODEL == ORX_BPR) {
-        return dot4(u, p - n);
-    } else {
-        const f4 a = u - p, c = u - n;
-        return dot4(c, c) - dot4(a, a);
-    }
-}
-
-// per-occurrence gradients of J = loss + l2w * l2_loss w.r.t. the gathered rows
-template <int MODEL>
-__device__ __forceinline__ void row_grads(f4 u, f4 p, f4 n, float g, float l2w, f4& gu, f4& gp, f4& gn,
-                                          float& gbp, float& gbn) {
-    if (MODEL == ORX_BPR) {
-        gu = g * (p - n) + l2w * u;
-        gp = g * u + l2w * p;
-        gn = -g * u + l2w * n;
-        gbp = g; gbn = -g;
-    } else {
-        const float a2 = 2.0f * g;
-        gu = -a2 * (p - n) + l2w * u;
-        gp = -a2 * (u - p) + l2w * p;
-        gn = a2 * (u - n) + l2w * n;
-        gbp = -g; gbn = g;
-    }
-}
-
-// ---------------------------------------------------------- optimizer rule ---
-template <int OPT>
-__device__ __forceinline__ void opt_apply4(float* w_ptr, float* a_ptr, f4 w_old, f4 grad, float lr, float eps) {
-    if (OPT == ORX_ADAGRAD) {
-        f4 acc = *reinterpret_cast<f4*>(a_ptr);
-        acc = acc + grad * grad;
-        *reinterpret_cast<f4*>(a_ptr) = acc;
-        f4 den;
-        den.x = sqrtf(acc.x) + eps; den.y = sqrtf(acc.y) + eps; den.z = sqrtf(acc.z) + eps; den.w = sqrtf(acc.w) + eps;
-        *reinterpret_cast<f4*>(w_ptr) = w_old - lr * grad / den;
-    } else {
-        *reinterpret_cast<f4*>(w_ptr) = w_old - lr * grad;
-    }
-}
-
-template <int OPT>
-__device__ __forceinline__ void opt_apply1(float* w_ptr, float* a_ptr, float w_old, float grad, float lr, float eps) {
-    if (OPT == ORX_ADAGRAD) {
-        const float acc = *a_ptr + grad * grad;
-        *a_ptr = acc;
-        *w_ptr = w_old - lr * grad / (sqrtf(acc) + eps);
-    } else {
-        *w_ptr = w_old - lr * grad;
-    }
-}
+#include "orx_device.h"
 
 // ------------------------------------------------------------ dedup kernel ---
 // One workgroup per (step, table, 524288-row range).  Exact duplicate detection
@@ -182,11 +63,11 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
     if (!is_user) bk -= a.nbu;
     const int64_t r0 = (int64_t)bk * DD_ROWS;
     const int64_t rows = is_user ? a.NU : a.NI;
-    const int64_t B = a.B;
+    const int64_t B = is_user ? a.nU : a.nP;                 // length of the first id segment
     const int32_t* idsA = (is_user ? a.uid : a.pid) + s * a.id_stride;
     const int32_t* idsB = a.nid + s * a.id_stride;
-    const int64_t n = is_user ? B : 2 * B;
-    const int64_t ref0 = is_user ? 0 : B;
+    const int64_t n = is_user ? a.nU : a.nP + a.nN;
+    const int64_t ref0 = is_user ? 0 : a.nU;
     unsigned char* dflag = a.dflag + s * a.flag_stride;
 
     for (int i = threadIdx.x; i < 2 * DD_WORDS; i += DD_THREADS) dd_lds[i] = 0u;
@@ -370,7 +251,7 @@ __global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
         f4 z; z.x = z.y = z.z = z.w = 0.0f;
         *reinterpret_cast<f4*>(gp) = z;
         opt_apply4<OPT>(wp, A + row * D + 4 * sub, w, g, a.lr, a.eps);
-        if (item && sub == 0) {
+        if (item && a.b != nullptr && sub == 0) {
             const float gb = a.gb[row];
             a.gb[row] = 0.0f;
             opt_apply1<OPT>(a.b + row, a.ab + row, a.b[row], gb, a.lr, a.eps);
@@ -397,7 +278,7 @@ __global__ __launch_bounds__(256) void dup_apply_generic_kernel(PairArgs a) {
             G[i] = 0.0f;
             opt_apply1<OPT>(W + i, A + i, W[i], g, a.lr, a.eps);
         }
-        if (item && lane == 0) {
+        if (item && a.b != nullptr && lane == 0) {
             const float gb = a.gb[row];
             a.gb[row] = 0.0f;
             opt_apply1<OPT>(a.b + row, a.ab + row, a.b[row], gb, a.lr, a.eps);

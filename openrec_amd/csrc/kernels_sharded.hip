@@ -1,0 +1,214 @@
+// Building blocks of the row-sharded multi-GPU step (one process per GPU; the
+// exchange between them is RCCL all-to-all driven from openrec_amd/sharded.py).
+// After the exchange every rank holds, per live triplet slot, the user row
+// (local shard) and the two item rows (received), all as dense [T, stride]
+// buffers with the bias at column D:
+//   pair_grads : score + loss + per-occurrence gradients (same math as the
+//                fused single-GPU kernel, kernels_pairwise.hip)
+//   apply_rows : optimizer sparse apply of per-occurrence gradient rows onto the
+//                local shard.  Reads (gather) and writes (apply) are separate
+//                phases here, so duplicates are no hazard for SGD: every
+//                occurrence is accumulated with fp32 atomics (TF scatter_add).
+//                Adagrad sums duplicates first (dedup flags + gsum + dup_apply).
+#include "orx_device.h"
+
+// ------------------------------------------------------------- pair_grads ---
+template <int LPR, int MODEL>
+__global__ __launch_bounds__(256) void pair_grads_kernel(GradArgs a) {
+    constexpr int TPW = 64 / LPR;
+    constexpr int D = 4 * LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
+    float loss_acc = 0.0f, sq_acc = 0.0f;
+    for (int64_t t = wave_global * TPW + grp; t < a.T; t += stride) {
+        if (a.valid != nullptr && a.valid[t] < 0) continue;
+        const f4 ru = *reinterpret_cast<const f4*>(a.u + t * a.row_stride + 4 * sub);
+        const f4 rp = *reinterpret_cast<const f4*>(a.p + t * a.row_stride + 4 * sub);
+        const f4 rn = *reinterpret_cast<const f4*>(a.n + t * a.row_stride + 4 * sub);
+        const float bp = a.p[t * a.row_stride + D], bn = a.n[t * a.row_stride + D];
+        const float red = group_allreduce<LPR>(score_partial<MODEL>(ru, rp, rn));
+        float term, g;
+        score<MODEL>(red, bp, bn, a.invB, a.margin, term, g);
+        sq_acc += dot4(ru, ru) + dot4(rp, rp) + dot4(rn, rn);
+        if (sub == 0) loss_acc += term;
+        f4 gu, gp, gn; float gbp, gbn;
+        row_grads<MODEL>(ru, rp, rn, g, a.l2w, gu, gp, gn, gbp, gbn);
+        *reinterpret_cast<f4*>(a.gu + t * a.g_stride + 4 * sub) = gu;
+        *reinterpret_cast<f4*>(a.gp + t * a.g_stride + 4 * sub) = gp;
+        *reinterpret_cast<f4*>(a.gn + t * a.g_stride + 4 * sub) = gn;
+        if (sub == 0) { a.gp[t * a.g_stride + D] = gbp; a.gn[t * a.g_stride + D] = gbn; }
+    }
+    const float ls = wave_sum(loss_acc);
+    const float sq = wave_sum(sq_acc);
+    if (lane == 0) {
+        float2 v; v.x = ls; v.y = 0.5f * sq;
+        *reinterpret_cast<float2*>(a.partial + 2 * wave_global) = v;
+    }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void pair_grads_generic_kernel(GradArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int D = a.D;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    float loss_acc = 0.0f, sq_acc = 0.0f;
+    for (int64_t t = wave_global; t < a.T; t += stride) {
+        if (a.valid != nullptr && a.valid[t] < 0) continue;
+        const float* u = a.u + t * a.row_stride;
+        const float* p = a.p + t * a.row_stride;
+        const float* n = a.n + t * a.row_stride;
+        float part = 0.0f;
+        for (int e = lane; e < D; e += 64) {
+            const float x = u[e], y = p[e], z = n[e];
+            if (MODEL == ORX_BPR) part += x * (y - z);
+            else part += (x - z) * (x - z) - (x - y) * (x - y);
+            sq_acc += x * x + y * y + z * z;
+        }
+        const float red = wave_sum(part);
+        float term, g;
+        score<MODEL>(red, p[D], n[D], a.invB, a.margin, term, g);
+        if (lane == 0) loss_acc += term;
+        for (int e = lane; e < D; e += 64) {
+            const float x = u[e], y = p[e], z = n[e];
+            float gu, gp, gn;
+            if (MODEL == ORX_BPR) {
+                gu = g * (y - z) + a.l2w * x; gp = g * x + a.l2w * y; gn = -g * x + a.l2w * z;
+            } else {
+                const float a2 = 2.0f * g;
+                gu = -a2 * (y - z) + a.l2w * x; gp = -a2 * (x - y) + a.l2w * y; gn = a2 * (x - z) + a.l2w * z;
+            }
+            a.gu[t * a.g_stride + e] = gu; a.gp[t * a.g_stride + e] = gp; a.gn[t * a.g_stride + e] = gn;
+        }
+        if (lane == 0) {
+            const float gbp = MODEL == ORX_BPR ? g : -g;
+            a.gp[t * a.g_stride + D] = gbp; a.gn[t * a.g_stride + D] = -gbp;
+        }
+    }
+    const float ls = wave_sum(loss_acc);
+    const float sq = wave_sum(sq_acc);
+    if (lane == 0) {
+        float2 v; v.x = ls; v.y = 0.5f * sq;
+        *reinterpret_cast<float2*>(a.partial + 2 * wave_global) = v;
+    }
+}
+
+static inline int lpr_for(int D, int64_t s1, int64_t s2) {
+    if (s1 % 4 || s2 % 4) return 0;
+    switch (D) { case 16: return 4; case 32: return 8; case 64: return 16; case 128: return 32; case 256: return 64; default: return 0; }
+}
+
+static inline unsigned grid_for_rows(int lpr, int64_t n) {
+    const int64_t per = lpr ? 4 * (64 / lpr) : 4;
+    int64_t g = (n + per - 1) / per;
+    if (g > 65536) g = 65536;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+int orx_launch_pair_grads(orx_ctx* ctx, int model, const GradArgs& a, int* nwaves) {
+    ProfScope ps(ctx, ORX_K_FUSED);
+    const int lpr = lpr_for(a.D, a.row_stride, a.g_stride);
+    const dim3 g(grid_for_rows(lpr, a.T));
+    if (nwaves) *nwaves = (int)g.x * 4;
+#define PG(L) (model == ORX_BPR ? (void)ORX_LAUNCH(ctx, (pair_grads_kernel<L, ORX_BPR>), g, dim3(256), 0, a) \
+                                : (void)ORX_LAUNCH(ctx, (pair_grads_kernel<L, ORX_UCML>), g, dim3(256), 0, a))
+    switch (lpr) {
+        case 4: PG(4); break;
+        case 8: PG(8); break;
+        case 16: PG(16); break;
+        case 32: PG(32); break;
+        case 64: PG(64); break;
+        default:
+            if (model == ORX_BPR) ORX_LAUNCH(ctx, (pair_grads_generic_kernel<ORX_BPR>), g, dim3(256), 0, a);
+            else ORX_LAUNCH(ctx, (pair_grads_generic_kernel<ORX_UCML>), g, dim3(256), 0, a);
+    }
+#undef PG
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// --------------------------------------------------------------- apply_rows ---
+// SGD: var.scatter_add(ids, -lr * grad), every occurrence accumulated.
+__global__ __launch_bounds__(256) void apply_rows_sgd_kernel(RowsArgs a) {
+    const int D = a.D;
+    const int64_t total = a.n * (D + 1);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t k = i / (D + 1);
+        const int e = (int)(i - k * (D + 1));
+        const int r = a.ids[k];
+        if (r < 0) continue;
+        if ((int64_t)r >= a.rows) { *a.err = 1; continue; }
+        const float g = a.grads[k * a.g_stride + e];
+        if (e < D) unsafeAtomicAdd(a.W + (size_t)r * D + e, -a.lr * g);
+        else if (a.bias != nullptr) unsafeAtomicAdd(a.bias + r, -a.lr * g);
+    }
+}
+
+// Adagrad: rows referenced once are updated in place, duplicated rows sum into
+// gsum first (dup_apply_kernel finishes them).  One wavefront per reference.
+__global__ __launch_bounds__(256) void apply_rows_adagrad_kernel(RowsArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int D = a.D;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < a.n; k += stride) {
+        const int r = a.ids[k];
+        if (r < 0) continue;
+        if ((int64_t)r >= a.rows) { if (lane == 0) *a.err = 1; continue; }
+        const bool dup = a.dflag[k] != 0;
+        const float* g = a.grads + k * a.g_stride;
+        for (int e = lane; e < D; e += 64) {
+            const size_t i = (size_t)r * D + e;
+            if (dup) unsafeAtomicAdd(a.G + i, g[e]);
+            else opt_apply1<ORX_ADAGRAD>(a.W + i, a.A + i, a.W[i], g[e], a.lr, a.eps);
+        }
+        if (a.bias != nullptr && lane == 0) {
+            if (dup) unsafeAtomicAdd(a.gb + r, g[D]);
+            else opt_apply1<ORX_ADAGRAD>(a.bias + r, a.ab + r, a.bias[r], g[D], a.lr, a.eps);
+        }
+    }
+}
+
+int orx_launch_apply_rows(orx_ctx* ctx, int optkind, bool use_dflag, const RowsArgs& a) {
+    ProfScope ps(ctx, ORX_K_DUPAPPLY);
+    if (a.n == 0) return ORX_OK;
+    if (optkind == ORX_SGD) {
+        int64_t g = (a.n * (a.D + 1) + 255) / 256;
+        if (g > 65536) g = 65536;
+        ORX_LAUNCH(ctx, apply_rows_sgd_kernel, dim3((unsigned)g), dim3(256), 0, a);
+    } else {
+        (void)use_dflag;
+        ORX_LAUNCH(ctx, apply_rows_adagrad_kernel, dim3(grid_for_rows(0, a.n)), dim3(256), 0, a);
+    }
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// ---------------------------------------------------------- loss accumulate ---
+__global__ __launch_bounds__(256) void loss_accumulate_kernel(const float* partial, int nwaves, double* accum) {
+    __shared__ double sh[2][4];
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < nwaves; i += blockDim.x) {
+        const float2 v = *reinterpret_cast<const float2*>(partial + 2 * i);
+        s0 += (double)v.x; s1 += (double)v.y;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = s0; sh[1][w] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        accum[0] += sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        accum[1] += sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    }
+}
+
+int orx_launch_loss_accumulate(orx_ctx* ctx, const float* partial, int nwaves, double* accum) {
+    ProfScope ps(ctx, ORX_K_REDUCE);
+    ORX_LAUNCH(ctx, loss_accumulate_kernel, dim3(1), dim3(256), 0, partial, nwaves, accum);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}

@@ -130,8 +130,10 @@ struct DedupArgs {
     uint32_t* dlist;                          // [K][list_stride]
     int* dcount;                              // [K], zeroed before the launch
     int64_t flag_stride; int64_t list_stride;
-    int64_t B; int64_t NU; int64_t NI;
-    int nbu; int nbi;                         // row-range buckets per table
+    // reference numbering: user refs [0, nU), then pid refs [nU, nU+nP), then nid refs [nU+nP, nU+nP+nN)
+    int64_t nU; int64_t nP; int64_t nN;
+    int64_t NU; int64_t NI;                   // table rows
+    int nbu; int nbi;                         // row-range buckets per table (0 = table not scanned)
     int first_only;                           // censor: dflag = 1 only on non-first references
 };
 
@@ -140,6 +142,31 @@ struct ReduceArgs {
     double* out;                              // [K][2]
     int nwaves;
 };
+
+struct RowsArgs {                              // sharded building blocks (kernels_sharded.hip)
+    float* W; float* bias;                    // table [rows, D], bias [rows] or NULL
+    float* G; float* gb;                      // gsum scratch
+    float* A; float* ab;                      // Adagrad accumulators
+    const int32_t* ids;                       // local row ids, < 0 = skip
+    const unsigned char* dflag;
+    const float* grads; int64_t g_stride;     // [n, g_stride]; bias gradient at column D
+    int64_t n; int64_t rows; int D;
+    float lr; float eps;
+    int* err;
+};
+
+struct GradArgs {
+    const float* u; const float* p; const float* n; int64_t row_stride;   // gathered rows, bias at column D
+    const int32_t* valid;                     // triplet k is live iff valid == NULL or valid[k] >= 0
+    float* gu; float* gp; float* gn; int64_t g_stride;
+    int64_t T; int D;
+    float invB; float margin; float l2w;
+    float* partial;
+};
+
+int orx_launch_pair_grads(orx_ctx* ctx, int model, const GradArgs& a, int* nwaves);
+int orx_launch_apply_rows(orx_ctx* ctx, int optkind, bool use_dflag, const RowsArgs& a);
+int orx_launch_loss_accumulate(orx_ctx* ctx, const float* partial, int nwaves, double* accum);
 
 // launchers implemented in kernels_pairwise.hip
 int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K);
@@ -159,7 +186,8 @@ enum { MODE_EXACT = 0,     // unique rows in place; duplicate rows -> gsum, appl
 int orx_launch_init_uniform(orx_ctx* ctx, float* w, int64_t n, float lo, float hi, uint64_t seed);
 int orx_launch_fill(orx_ctx* ctx, float* w, int64_t n, float v);
 int orx_launch_gather(orx_ctx* ctx, const float* w, const float* bias, int64_t rows, int dim,
-                      const int32_t* ids, int64_t n, float* out, int64_t out_stride, int* err);
+                      const int32_t* ids, int64_t n, float* out, int64_t out_stride, int* err,
+                      int skip_negative = 0);
 int orx_launch_censor(orx_ctx* ctx, float* w, const unsigned char* dflag, int64_t rows, int dim, const int32_t* ids,
                       int64_t n, float min_norm, int* err);
 int orx_launch_adam_sweep(orx_ctx* ctx, float* w, float* m, float* v, float* gsum, int64_t n,

@@ -1,0 +1,216 @@
+"""Row-sharded multi-GPU train step: one process per GPU,
+`torch.distributed` collectives (backend "nccl" = RCCL over xGMI on the GPU
+box, "gloo" in the CPU tests), compute in libopenrec_hip.so.
+
+Sharding: row r of every table lives on rank r % N at local index r // N.
+One step over the GLOBAL batch (all ranks' triplets; the loss mean runs over
+N*B) has exactly the single-GPU semantics:
+
+  1. route   every triplet goes to the owner of its user row      all_to_all  (12 B / triplet)
+  2. request the two item ids of each triplet go to their owners   all_to_all  (4 B / id)
+  3. rows    owners gather row + bias and send them back           all_to_all  ((D+4)*4 B / id)
+  4. local   gather user rows, score, loss, per-occurrence grads   (HIP: orx_gather_rows, orx_pair_grads)
+  5. users   apply user-row gradients on the local shard           (HIP: orx_apply_rows)
+  6. items   item-row gradients travel back along route 2          all_to_all  ((D+4)*4 B / id)
+             and are applied by the owners                         (HIP: orx_apply_rows)
+
+Reads (3) and writes (5, 6) are separate phases, so every gradient is taken on
+the pre-step tables and duplicates need no special care beyond the optimizer's
+own rule (SGD accumulates every occurrence, Adagrad sums duplicates first).
+All exchanges use fixed-capacity buckets (no host synchronization, no size
+exchange); `check()` reports a capacity overflow.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def owner_of(ids, world):
+    return ids % world
+
+
+def local_index(ids, world):
+    return torch.div(ids, world, rounding_mode="floor")
+
+
+def rows_on_rank(n_rows, rank, world):
+    return (n_rows - rank + world - 1) // world
+
+
+def bucket_slots(dest, world, cap):
+    """dest: int64 [n], owner rank of each element or -1 (dead element).
+    Returns (slot [n] int64 in [0, world*cap) or -1, overflow flag tensor).
+    Elements keep their relative order inside a bucket (stable)."""
+    n = dest.numel()
+    dev = dest.device
+    d = torch.where(dest >= 0, dest, torch.full_like(dest, world))
+    order = torch.argsort(d, stable=True)
+    ds = d[order]
+    counts = torch.bincount(ds, minlength=world + 1)
+    starts = torch.cumsum(counts, 0) - counts
+    pos = torch.arange(n, device=dev) - starts[ds]
+    ok = (ds < world) & (pos < cap)
+    slot_sorted = torch.where(ok, ds * cap + pos, torch.full_like(ds, -1))
+    slot = torch.empty_like(slot_sorted)
+    slot[order] = slot_sorted
+    overflow = (counts[:world] > cap).any()
+    return slot, overflow
+
+
+class HipBackend:
+    """Compute backend = the C ABI.  Buffers are torch tensors on the rank's GPU,
+    kernels run on torch's current stream so that they order with the collectives."""
+
+    def __init__(self, device, opt_kind, lr, opt_kw=None):
+        from . import runtime as rt, _ffi
+        self.rt, self._ffi = rt, _ffi
+        self.device = device
+        stream = torch.cuda.current_stream(device).cuda_stream
+        self.ctx = rt.Context(device.index if device.index is not None else 0, stream=stream)
+        kw = opt_kw or {}
+        if opt_kind == "sgd":
+            self.opt = rt.Optimizer.sgd(lr, ctx=self.ctx)
+        elif opt_kind == "adagrad":
+            self.opt = rt.Optimizer.adagrad(lr, kw.get("initial_accumulator_value", 0.1), kw.get("epsilon", 1e-7), ctx=self.ctx)
+        else:
+            raise ValueError("sharded tables support sgd and adagrad")
+        self.lib = self.ctx._lib
+
+    def make_table(self, rows, dim, seed):
+        return self.rt.Table(max(rows, 1), dim, self.ctx).init_uniform(seed=seed)
+
+    def gather_rows(self, table, bias, ids, out):
+        self._ffi.check(self.lib.orx_gather_rows(self.ctx._h, table._h, bias._h if bias is not None else None,
+                                                 ids.data_ptr(), ids.numel(), out.data_ptr(), out.shape[1]))
+
+    def pair_grads(self, model, dim, u, p, n, valid, b_global, margin, gu, gp, gn, accum):
+        mid = {"bpr": self._ffi.ORX_BPR, "ucml": self._ffi.ORX_UCML}[model]
+        self._ffi.check(self.lib.orx_pair_grads(self.ctx._h, mid, dim, u.data_ptr(), p.data_ptr(), n.data_ptr(),
+                                                u.shape[1], valid.data_ptr(), valid.numel(), b_global, margin, 0,
+                                                gu.data_ptr(), gp.data_ptr(), gn.data_ptr(), gu.shape[1],
+                                                accum.data_ptr()))
+
+    def apply_rows(self, table, bias, ids, grads):
+        self._ffi.check(self.lib.orx_apply_rows(self.ctx._h, self.opt._h, table._h,
+                                                bias._h if bias is not None else None,
+                                                ids.data_ptr(), ids.numel(), grads.data_ptr(), grads.shape[1]))
+
+    def check(self):
+        self.ctx.check_index_error()
+
+    def prof(self):
+        return self.ctx.prof_get()
+
+
+class ShardedPairwise:
+    def __init__(self, model, opt, n_users, n_items, dim, lr, rank, world, device, seed=0, margin=0.5,
+                 backend=None, slack=1.25, opt_kw=None, group=None):
+        assert model in ("bpr", "ucml")
+        self.model, self.dim, self.margin = model, dim, margin
+        self.rank, self.world, self.device, self.group = rank, world, device, group
+        self.n_users, self.n_items = n_users, n_items
+        self.be = backend if backend is not None else HipBackend(device, opt, lr, opt_kw)
+        self.U = self.be.make_table(rows_on_rank(n_users, rank, world), dim, seed * 3 + 0 + 1000 * rank)
+        self.V = self.be.make_table(rows_on_rank(n_items, rank, world), dim, seed * 3 + 1 + 1000 * rank)
+        self.b = self.be.make_table(rows_on_rank(n_items, rank, world), 1, seed * 3 + 2 + 1000 * rank)
+        self.slack = slack
+        self.DS = dim + 4                       # row + bias column, rows stay 16-B aligned
+        self.accum = torch.zeros(2, dtype=torch.float64, device=device)
+        self.overflow = torch.zeros((), dtype=torch.bool, device=device)
+        self._cap_for = {}
+
+    # capacity of one (source, destination) bucket for n elements spread over `world` ranks
+    def _cap(self, n):
+        if n not in self._cap_for:
+            mean = n / self.world
+            self._cap_for[n] = int(math.ceil(mean * self.slack + 6 * math.sqrt(mean) + 16))
+        return self._cap_for[n]
+
+    def _a2a(self, send):
+        recv = torch.empty_like(send)
+        if self.world == 1:
+            recv.copy_(send)
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)
+        return recv
+
+    def step(self, uid, pid, nid):
+        """uid/pid/nid: int32 [B] on self.device -- this rank's slice of the global batch."""
+        N, dev, DS, D = self.world, self.device, self.DS, self.dim
+        B = uid.numel()
+        b_global = B * N
+        # ---- 1. route triplets to the owner of the user row
+        cap1 = self._cap(B)
+        trip = torch.stack([uid, pid, nid], 1).to(torch.int32)
+        slot1, ov1 = bucket_slots(owner_of(uid.long(), N), N, cap1)
+        send1 = torch.full((N * cap1 + 1, 3), -1, dtype=torch.int32, device=dev)
+        send1.index_copy_(0, torch.where(slot1 >= 0, slot1, torch.full_like(slot1, N * cap1)), trip)
+        mine = self._a2a(send1[:N * cap1].contiguous())                  # [T, 3]
+        T = N * cap1
+        u_g, p_g, n_g = mine[:, 0].long(), mine[:, 1].long(), mine[:, 2].long()
+        live = u_g >= 0
+        u_loc = torch.where(live, local_index(u_g, N), torch.full_like(u_g, -1)).to(torch.int32).contiguous()
+        # ---- 2. request item rows from their owners
+        item_g = torch.cat([p_g, n_g])                                    # [2T]
+        live2 = torch.cat([live, live])
+        cap2 = self._cap(2 * T)
+        slot2, ov2 = bucket_slots(torch.where(live2, owner_of(item_g, N), torch.full_like(item_g, -1)), N, cap2)
+        trash2 = N * cap2
+        slot2s = torch.where(slot2 >= 0, slot2, torch.full_like(slot2, trash2))
+        send2 = torch.full((trash2 + 1,), -1, dtype=torch.int32, device=dev)
+        send2.index_copy_(0, slot2s, item_g.to(torch.int32))
+        req = self._a2a(send2[:trash2].contiguous()).long()               # ids requested from me
+        req_loc = torch.where(req >= 0, local_index(req, N), torch.full_like(req, -1)).to(torch.int32).contiguous()
+        # ---- 3. owners gather rows (+ bias at column D) and send them back
+        rows_out = torch.zeros((trash2, DS), dtype=torch.float32, device=dev)
+        self.be.gather_rows(self.V, self.b, req_loc, rows_out)
+        rows_in = torch.zeros((trash2 + 1, DS), dtype=torch.float32, device=dev)
+        rows_in[:trash2] = self._a2a(rows_out)
+        item_rows = rows_in.index_select(0, slot2s)                       # [2T, DS] in my reference order
+        p_rows, n_rows = item_rows[:T].contiguous(), item_rows[T:].contiguous()
+        # a triplet whose item request overflowed a bucket is dropped (and reported by check())
+        ok = live & (slot2[:T] >= 0) & (slot2[T:] >= 0)
+        valid = torch.where(ok, u_loc, torch.full_like(u_loc, -1)).contiguous()
+        # ---- 4. local rows, score, gradients
+        u_rows = torch.zeros((T, DS), dtype=torch.float32, device=dev)
+        self.be.gather_rows(self.U, None, valid, u_rows)
+        gu = torch.zeros((T, DS), dtype=torch.float32, device=dev)
+        gp = torch.zeros((T, DS), dtype=torch.float32, device=dev)
+        gn = torch.zeros((T, DS), dtype=torch.float32, device=dev)
+        self.be.pair_grads(self.model, D, u_rows, p_rows, n_rows, valid, b_global, self.margin, gu, gp, gn, self.accum)
+        # ---- 5. user rows are local
+        self.be.apply_rows(self.U, None, valid, gu)
+        # ---- 6. item-row gradients go back along route 2 and are applied by the owners
+        send_g = torch.zeros((trash2 + 1, DS), dtype=torch.float32, device=dev)
+        dead = ~torch.cat([ok, ok])
+        send_g.index_copy_(0, torch.where(dead, torch.full_like(slot2s, trash2), slot2s), torch.cat([gp, gn]))
+        g_in = self._a2a(send_g[:trash2].contiguous())
+        # a request whose triplet was dropped carries a zero gradient: harmless for SGD, and for
+        # Adagrad acc += 0, var -= 0
+        self.be.apply_rows(self.V, self.b, req_loc, g_in)
+        self.overflow |= ov1 | ov2
+        return None
+
+    # ---- results -----------------------------------------------------------
+    def loss_sums(self):
+        """(sum over steps of loss, sum of l2_loss) over the global batch so far."""
+        t = self.accum.clone()
+        if self.world > 1:
+            dist.all_reduce(t, group=self.group)
+        return float(t[0]), float(t[1])
+
+    def check(self):
+        """Raise if an id was out of range or an exchange bucket overflowed (synchronizes)."""
+        if hasattr(self.be, "check"):
+            self.be.check()
+        ov = self.overflow.clone().to(torch.int32)
+        if self.world > 1:
+            dist.all_reduce(ov, group=self.group)
+        if int(ov) != 0:
+            raise RuntimeError("sharded exchange: bucket capacity exceeded (raise `slack`)")
+
+    def prof(self):
+        return self.be.prof() if hasattr(self.be, "prof") else {}
