@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="triplets per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hogwild", action="store_true", help="racy non-reference mode (never the headline)")
+    ap.add_argument("--sharded", action="store_true", help="use the row-sharded engine even on one GPU (debug)")
     args = ap.parse_args()
 
     import torch
@@ -111,7 +112,7 @@ def main():
 
     K, W = args.steps, args.warmup
     lr = 0.05
-    if world == 1:
+    if world == 1 and not args.sharded:
         ctx = rt.Context(local_rank)
         U = rt.Table(args.users, args.dim, ctx).init_uniform(seed=0)
         V = rt.Table(args.items, args.dim, ctx).init_uniform(seed=1)
@@ -149,18 +150,22 @@ def main():
         for s in range(W):
             eng.step(uid[s], pid[s], nid[s])
         torch.cuda.synchronize()
-        dist.barrier()
+        if dist is not None:
+            dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for s in range(W, W + K):
             eng.step(uid[s], pid[s], nid[s])
         torch.cuda.synchronize()
-        dist.barrier()
+        if dist is not None:
+            dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        if dist is not None:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        eng.check()
         prof = eng.prof()
         losses = None
         parallelism = f"row-sharded x{world}, all-to-all"
@@ -197,7 +202,7 @@ def main():
                                                     for k, v in prof.items() if v.get("launches") and k != "fused"}}
         if losses is not None:
             out["loss_first_last"] = [float(losses[0][0]), float(losses[0][-1])]
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.sharded and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:                      # the baseline must never hide the GPU number

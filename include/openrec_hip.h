@@ -152,6 +152,18 @@ int orx_pointwise_step(orx_ctx* ctx, int model, orx_opt* opt,
                        int64_t K, int64_t B, int64_t id_stride, float a, float b, int flags,
                        float* loss_out, float* l2_out);
 
+/* Forward only for the pointwise models (GMF.call / WRMF.call outside a tape). */
+int orx_pointwise_loss(orx_ctx* ctx, int model,
+                       orx_table* user, orx_table* item, orx_table* bias, orx_table* w,
+                       const int32_t* uid, const int32_t* iid, const float* label,
+                       int64_t B, float a, float b, int flags, float* loss_out, float* l2_out);
+
+/* Recommender.inference (bpr.py:39-43, wrmf.py:36-40: kind 0 = U[uid] . V^T + b;
+ * ucml.py:50-53: kind 1 = -||U[uid] - V||^2 + b; gmf.py:36-41: kind 2 = sum_d w_d u_d v_d + b).
+ * uid: host int32[n]; out: host float[n * item_rows], row-major [n, item_rows]. */
+int orx_score_all_items(orx_ctx* ctx, int kind, orx_table* user, orx_table* item, orx_table* bias, orx_table* w,
+                        const int32_t* uid, int64_t n, float* out);
+
 /* ---- sharded building blocks (row-wise sharded tables, one rank per GPU;
  * the exchange itself is RCCL all-to-all driven by the host, see
  * openrec_amd/sharded.py).  No reference equivalent (the reference is single

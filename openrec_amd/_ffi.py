@@ -54,6 +54,8 @@ SIGNATURES = {
     "orx_pairwise_loss": (c_int, [_p, c_int, _p, _p, _p, _ip, _ip, _ip, c_int64, c_float, c_int, _fp, _fp]),
     "orx_pointwise_step": (c_int, [_p, c_int, _p, _p, _p, _p, _p, _ip, _ip, _fp, c_int64, c_int64, c_int64,
                                    c_float, c_float, c_int, _fp, _fp]),
+    "orx_pointwise_loss": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, _ip, _fp, c_int64, c_float, c_float, c_int, _fp, _fp]),
+    "orx_score_all_items": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, c_int64, _fp]),
     "orx_gather_rows": (c_int, [_p, _p, _p, _ip, c_int64, _fp, c_int64]),
     "orx_pair_grads": (c_int, [_p, c_int, c_int32, _fp, _fp, _fp, c_int64, _ip, c_int64, c_int64, c_float, c_int,
                                _fp, _fp, _fp, c_int64, _p]),

@@ -215,7 +215,7 @@ extern "C" int orx_table_write(orx_table* t, int64_t row0, int64_t nrows, const 
 }
 
 // upload host ids into the context's staging buffer at element offset `off`
-static int stage_ids(orx_ctx* c, const int32_t* host, int64_t n, int64_t off) {
+int stage_ids(orx_ctx* c, const int32_t* host, int64_t n, int64_t off) {
     ORX_HIP(hipMemcpyAsync(c->d_ids + off, host, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     return ORX_OK;
 }
@@ -362,7 +362,7 @@ static int stage_triplets(orx_ctx* c, const int32_t* uid, const int32_t* pid, co
     return ORX_OK;
 }
 
-static int fetch_losses(orx_ctx* c, int64_t K, float* loss_out, float* l2_out) {
+int fetch_losses(orx_ctx* c, int64_t K, float* loss_out, float* l2_out) {
     if (!loss_out && !l2_out) return ORX_OK;
     std::vector<double> h((size_t)2 * K);
     ORX_HIP(hipMemcpyAsync(h.data(), c->d_loss, sizeof(double) * 2 * K, hipMemcpyDeviceToHost, c->stream));

@@ -1,5 +1,6 @@
 // C-ABI entry points of the sharded building blocks (and, for now, the
 // not-yet-built pointwise step).
+#include <cmath>
 #include <cstring>
 
 #include "orx_internal.h"
@@ -15,11 +16,164 @@
         if (_rc != ORX_OK) return _rc;                                                 \
     } while (0)
 
-extern "C" int orx_pointwise_step(orx_ctx*, int, orx_opt*, orx_table*, orx_table*, orx_table*, orx_table*,
-                                  const int32_t*, const int32_t*, const float*, int64_t, int64_t, int64_t,
-                                  float, float, int, float*, float*) {
-    orx_set_error("orx_pointwise_step: not implemented yet");
-    return ORX_ERR_STATE;
+// ------------------------------------------------------------ pointwise step ---
+static int check_point_tables(int model, orx_table* U, orx_table* V, orx_table* b, orx_table* w) {
+    ORX_ARG(model == ORX_GMF || model == ORX_WRMF, "pointwise: unknown model %d", model);
+    ORX_ARG(U && V && b, "pointwise: NULL table");
+    ORX_ARG(U->dim == V->dim, "pointwise: user dim %d != item dim %d", U->dim, V->dim);
+    ORX_ARG(b->dim == 1 && b->rows == V->rows, "pointwise: item_bias must be [%lld, 1]", (long long)V->rows);
+    ORX_ARG(model != ORX_GMF || (w && w->rows == U->dim && w->dim == 1), "pointwise: GMF needs the Dense kernel w as a [D, 1] table");
+    return ORX_OK;
+}
+
+// stage (uid, iid, label) of K steps: ids into d_ids [2][K*B], labels into d_lab [K*B]
+static int stage_point(orx_ctx* c, const int32_t* uid, const int32_t* iid, const float* label,
+                       int64_t K, int64_t B, int64_t id_stride, int flags,
+                       const int32_t** du, const int32_t** di, const float** dl, int64_t* ds) {
+    if (flags & ORX_IDS_DEVICE) { *du = uid; *di = iid; *dl = label; *ds = id_stride; return ORX_OK; }
+    const int64_t n = K * B;
+    ENSURE(c->d_ids, c->d_ids_cap, (size_t)2 * n * sizeof(int32_t));
+    ENSURE(c->d_lab, c->d_lab_cap, (size_t)n * sizeof(float));
+    for (int64_t s = 0; s < K; ++s) {
+        CHECK(stage_ids(c, uid + s * id_stride, B, s * B));
+        CHECK(stage_ids(c, iid + s * id_stride, B, n + s * B));
+        ORX_HIP(hipMemcpyAsync(c->d_lab + s * B, label + s * id_stride, (size_t)B * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    *du = c->d_ids; *di = c->d_ids + n; *dl = c->d_lab; *ds = B;
+    return ORX_OK;
+}
+
+extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
+                                  orx_table* U, orx_table* V, orx_table* b, orx_table* w,
+                                  const int32_t* uid, const int32_t* iid, const float* label,
+                                  int64_t K, int64_t B, int64_t id_stride, float a_w, float b_w, int flags,
+                                  float* loss_out, float* l2_out) {
+    ORX_ARG(c && opt, "orx_pointwise_step: NULL context/optimizer");
+    CHECK(check_point_tables(model, U, V, b, w));
+    ORX_ARG(K >= 0 && B > 0, "orx_pointwise_step: K must be >= 0 and B > 0");
+    ORX_ARG(K == 0 || (uid && iid && label), "orx_pointwise_step: NULL id/label pointer");
+    if (K == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(c->device));
+    const int32_t *du, *di; const float* dl; int64_t ds;
+    CHECK(stage_point(c, uid, iid, label, K, B, id_stride, flags, &du, &di, &dl, &ds));
+    const bool hogwild = (flags & ORX_HOGWILD) != 0;
+    const int mode = opt->kind == ORX_ADAM ? MODE_ACCUM : (hogwild ? MODE_HOGWILD : MODE_EXACT);
+    CHECK(orx_table_scratch(U)); CHECK(orx_table_scratch(V)); CHECK(orx_table_scratch(b));
+    if (w) CHECK(orx_table_scratch(w));
+    OptSlots sU, sV, sb, sw;
+    CHECK(orx_opt_slots(opt, U, &sU)); CHECK(orx_opt_slots(opt, V, &sV)); CHECK(orx_opt_slots(opt, b, &sb));
+    if (w) CHECK(orx_opt_slots(opt, w, &sw));
+    const int D = U->dim;
+    const int nw = orx_point_nwaves(D, B);
+    const int nslot = nw + (model == ORX_GMF ? 1 : 0);      // + one slot for 0.5*||w||^2
+    ENSURE(c->d_partial, c->d_partial_cap, (size_t)K * nslot * 2 * sizeof(float));
+    ENSURE(c->d_loss, c->d_loss_cap, (size_t)K * 2 * sizeof(double));
+    if (model == ORX_GMF) ENSURE(c->d_wpart, c->d_wpart_cap, (size_t)nw * D * sizeof(float));
+    const int64_t list_stride = 2 * B;
+    if (mode == MODE_EXACT) {
+        ENSURE(c->d_dflag, c->d_dflag_cap, (size_t)K * 2 * B);
+        ENSURE(c->d_dlist, c->d_dlist_cap, (size_t)K * list_stride * sizeof(uint32_t));
+        ENSURE(c->d_dcount, c->d_dcount_cap, (size_t)K * sizeof(int));
+        DedupArgs d;
+        memset(&d, 0, sizeof(d));
+        d.uid = du; d.pid = di; d.nid = di; d.id_stride = ds;
+        d.dflag = c->d_dflag; d.dlist = c->d_dlist; d.dcount = c->d_dcount;
+        d.flag_stride = 2 * B; d.list_stride = list_stride;
+        d.nU = B; d.nP = B; d.nN = 0; d.NU = U->rows; d.NI = V->rows;
+        d.nbu = orx_dedup_buckets(U->rows); d.nbi = orx_dedup_buckets(V->rows);
+        ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)K * sizeof(int), c->stream));
+        CHECK(orx_launch_dedup(c, d, K));
+    }
+    PointArgs a;
+    memset(&a, 0, sizeof(a));
+    a.U = U->w; a.V = V->w; a.b = b->w; a.w = w ? w->w : nullptr;
+    a.gU = U->gsum; a.gV = V->gsum; a.gb = b->gsum;
+    a.aU = sU.s0; a.aV = sV.s0; a.ab = sb.s0;
+    a.B = B; a.NU = U->rows; a.NI = V->rows; a.D = D;
+    a.lr = opt->lr; a.eps = opt->kind == ORX_ADAGRAD ? opt->p1 : 0.f;
+    a.invB = 1.0f / (float)B; a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f; a.a_w = a_w; a.b_w = b_w;
+    a.wpartial = c->d_wpart; a.err = c->d_err;
+    PairArgs pa;                                 // view of the same tables for dup_apply_kernel
+    memset(&pa, 0, sizeof(pa));
+    pa.U = U->w; pa.V = V->w; pa.b = b->w; pa.gU = U->gsum; pa.gV = V->gsum; pa.gb = b->gsum;
+    pa.aU = sU.s0; pa.aV = sV.s0; pa.ab = sb.s0; pa.B = B; pa.D = D; pa.lr = a.lr; pa.eps = a.eps;
+    for (int64_t s = 0; s < K; ++s) {
+        a.uid = du + s * ds; a.iid = di + s * ds; a.label = dl + s * ds;
+        a.dflag = c->d_dflag + (size_t)s * 2 * B;
+        a.partial = c->d_partial + (size_t)s * nslot * 2;
+        CHECK(orx_launch_point_fused(c, model, opt->kind, mode, a));
+        if (mode == MODE_EXACT) {
+            pa.dlist = c->d_dlist + (size_t)s * list_stride; pa.dcount = c->d_dcount + s;
+            CHECK(orx_launch_dup_apply(c, opt->kind, pa));
+        }
+        float lr_t = 0.f;
+        if (mode == MODE_ACCUM) {
+            opt->t += 1;
+            const double b1 = opt->p0, b2 = opt->p1;
+            lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, (double)opt->t)) / (1.0 - std::pow(b1, (double)opt->t)));
+            CHECK(orx_launch_adam_sweep(c, U->w, sU.s0, sU.s1, U->gsum, U->rows * D, lr_t, opt->p0, opt->p1, opt->p2));
+            CHECK(orx_launch_adam_sweep(c, V->w, sV.s0, sV.s1, V->gsum, V->rows * D, lr_t, opt->p0, opt->p1, opt->p2));
+            CHECK(orx_launch_adam_sweep(c, b->w, sb.s0, sb.s1, b->gsum, b->rows, lr_t, opt->p0, opt->p1, opt->p2));
+        }
+        if (model == ORX_GMF) {                  // dense Dense(1) kernel: reduce partials, apply the dense rule
+            CHECK(orx_launch_dense_reduce(c, c->d_wpart, nw, D, w->w, a.l2w, w->gsum, a.partial + 2 * nw));
+            if (mode == MODE_ACCUM) CHECK(orx_launch_adam_sweep(c, w->w, sw.s0, sw.s1, w->gsum, D, lr_t, opt->p0, opt->p1, opt->p2));
+            else CHECK(orx_launch_dense_apply(c, w->w, sw.s0, w->gsum, D, opt->kind, opt->lr, a.eps));
+        }
+    }
+    ReduceArgs r;
+    r.partial = c->d_partial; r.out = c->d_loss; r.nwaves = nslot;
+    CHECK(orx_launch_loss_reduce(c, r, K));
+    CHECK(fetch_losses(c, K, loss_out, l2_out));
+    if (!(flags & ORX_IDS_DEVICE)) return orx_check_index_error(c);
+    return ORX_OK;
+}
+
+extern "C" int orx_pointwise_loss(orx_ctx* c, int model, orx_table* U, orx_table* V, orx_table* b, orx_table* w,
+                                  const int32_t* uid, const int32_t* iid, const float* label,
+                                  int64_t B, float a_w, float b_w, int flags, float* loss_out, float* l2_out) {
+    ORX_ARG(c, "orx_pointwise_loss: NULL context");
+    CHECK(check_point_tables(model, U, V, b, w));
+    ORX_ARG(B > 0 && uid && iid && label, "orx_pointwise_loss: empty batch or NULL pointer");
+    ORX_HIP(hipSetDevice(c->device));
+    const int32_t *du, *di; const float* dl; int64_t ds;
+    CHECK(stage_point(c, uid, iid, label, 1, B, B, flags, &du, &di, &dl, &ds));
+    const int D = U->dim;
+    const int nw = orx_point_nwaves(D, B);
+    const int nslot = nw + (model == ORX_GMF ? 1 : 0);
+    ENSURE(c->d_partial, c->d_partial_cap, (size_t)nslot * 2 * sizeof(float));
+    ENSURE(c->d_loss, c->d_loss_cap, 2 * sizeof(double));
+    PointArgs a;
+    memset(&a, 0, sizeof(a));
+    a.U = U->w; a.V = V->w; a.b = b->w; a.w = w ? w->w : nullptr;
+    a.B = B; a.NU = U->rows; a.NI = V->rows; a.D = D;
+    a.invB = 1.0f / (float)B; a.l2w = 1.f; a.a_w = a_w; a.b_w = b_w;
+    a.partial = c->d_partial; a.err = c->d_err;
+    a.uid = du; a.iid = di; a.label = dl;
+    CHECK(orx_launch_point_fused(c, model, ORX_SGD, MODE_LOSS, a));
+    if (model == ORX_GMF) CHECK(orx_launch_dense_reduce(c, nullptr, 0, D, w->w, 0.f, nullptr, c->d_partial + 2 * nw));
+    ReduceArgs r;
+    r.partial = c->d_partial; r.out = c->d_loss; r.nwaves = nslot;
+    CHECK(orx_launch_loss_reduce(c, r, 1));
+    CHECK(fetch_losses(c, 1, loss_out, l2_out));
+    return orx_check_index_error(c);
+}
+
+extern "C" int orx_score_all_items(orx_ctx* c, int kind, orx_table* U, orx_table* V, orx_table* b, orx_table* w,
+                                   const int32_t* uid, int64_t n, float* out) {
+    ORX_ARG(c && U && V && b && (n == 0 || (uid && out)), "orx_score_all_items: NULL argument");
+    ORX_ARG(kind >= 0 && kind <= 2, "orx_score_all_items: unknown kind %d", kind);
+    ORX_ARG(U->dim == V->dim && b->rows == V->rows && b->dim == 1, "orx_score_all_items: table shapes do not match");
+    ORX_ARG(kind != 2 || (w && w->rows == U->dim && w->dim == 1), "orx_score_all_items: GMF needs w [D, 1]");
+    ORX_ARG(U->dim <= 1024, "orx_score_all_items: dim too large for the LDS user tile");
+    if (n == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(c->device));
+    ENSURE(c->d_ids, c->d_ids_cap, (size_t)n * sizeof(int32_t));
+    ENSURE(c->d_tmp, c->d_tmp_cap, (size_t)n * V->rows * sizeof(float));
+    CHECK(stage_ids(c, uid, n, 0));
+    CHECK(orx_launch_score_all(c, U->w, V->w, b->w, w ? w->w : nullptr, c->d_ids, n, U->rows, V->rows, U->dim, kind, c->d_tmp));
+    ORX_HIP(hipMemcpyAsync(out, c->d_tmp, (size_t)n * V->rows * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return orx_check_index_error(c);
 }
 
 extern "C" int orx_gather_rows(orx_ctx* ctx, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,

@@ -1,0 +1,316 @@
+// Fused pointwise (GMF / WRMF) train step and the all-item scorer (inference).
+//
+//   GMF.call   recommenders/gmf.py:22-34   logit = Dense(1,no bias)(u*i) + b_i,
+//                                          mean BCE-with-logits, l2 over u, i and the kernel w
+//   WRMF.call  recommenders/wrmf.py:21-34 + modules/pointwise_mse_loss.py:18-31
+//                                          pred = u.i + b_i, sum of c*(y-pred)^2, c = (a-b)*y + b
+//   inference  bpr.py:39-43, wrmf.py:36-40 (dot), ucml.py:50-53 (-L2), gmf.py:36-41 (weighted dot)
+//
+// Same structure as kernels_pairwise.hip: LPR = D/4 lanes own one row, unique rows
+// are updated in place, duplicated rows (flags from dedup_kernel) accumulate into
+// gsum and are finished by dup_apply_kernel.  GMF's dense kernel gradient
+// (a [D] vector summed over the batch) leaves the fused kernel as one partial per
+// wavefront and is reduced + applied by dense_apply_kernel.
+#include "orx_device.h"
+
+// per-sample loss term and d(loss)/d(score)
+template <int MODEL>
+__device__ __forceinline__ void point_score(float s, float y, float invB, float a_w, float b_w, float& term, float& gs) {
+    if (MODEL == ORX_GMF) {
+        const float e = __expf(-fabsf(s));
+        term = (fmaxf(s, 0.0f) - s * y + log1pf(e)) * invB;            // BCE with logits, mean
+        const float sig = (s >= 0.0f) ? 1.0f / (1.0f + e) : e / (1.0f + e);
+        gs = (sig - y) * invB;
+    } else {
+        const float c = (a_w - b_w) * y + b_w;                         // pointwise_mse_loss.py:30
+        const float r = y - s;
+        term = c * r * r;                                              // :31 (sum)
+        gs = -2.0f * c * r;
+    }
+}
+
+template <int LPR, int MODEL, int OPT, int MODE>
+__global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
+    constexpr int TPW = 64 / LPR;
+    constexpr int D = 4 * LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
+    float loss_acc = 0.0f, sq_acc = 0.0f;
+    f4 wv; wv.x = wv.y = wv.z = wv.w = 1.0f;
+    if (MODEL == ORX_GMF) wv = *reinterpret_cast<const f4*>(a.w + 4 * sub);
+    f4 gw_acc; gw_acc.x = gw_acc.y = gw_acc.z = gw_acc.w = 0.0f;
+    for (int64_t t = wave_global * TPW + grp; t < a.B; t += stride) {
+        const int u = a.uid[t], i = a.iid[t];
+        const float y = a.label[t];
+        int du = 0, di = 0;
+        if (MODE == MODE_EXACT) { du = a.dflag[t]; di = a.dflag[a.B + t]; }
+        if (MODE == MODE_ACCUM) { du = di = 1; }
+        if (!(id_ok(u, a.NU) && id_ok(i, a.NI))) { if (sub == 0) *a.err = 1; continue; }
+        float* Up = a.U + (size_t)u * D + 4 * sub;
+        float* Ip = a.V + (size_t)i * D + 4 * sub;
+        const f4 ru = *reinterpret_cast<const f4*>(Up);
+        const f4 ri = *reinterpret_cast<const f4*>(Ip);
+        const float bi = a.b[i];
+        const f4 ui = ru * ri;
+        const float s = group_allreduce<LPR>(dot4(ui, wv)) + bi;
+        float term, gs;
+        point_score<MODEL>(s, y, a.invB, a.a_w, a.b_w, term, gs);
+        sq_acc += dot4(ru, ru) + dot4(ri, ri);
+        if (sub == 0) loss_acc += term;
+        if (MODE == MODE_LOSS) continue;
+        const f4 gu = gs * (ri * wv) + a.l2w * ru;
+        const f4 gi = gs * (ru * wv) + a.l2w * ri;
+        if (MODEL == ORX_GMF) gw_acc += gs * ui;
+        if (du == 0) opt_apply4<OPT>(Up, a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
+        else atomic_add_f4(a.gU + (size_t)u * D + 4 * sub, gu);
+        if (di == 0) {
+            opt_apply4<OPT>(Ip, a.aV + (size_t)i * D + 4 * sub, ri, gi, a.lr, a.eps);
+            if (sub == 0) opt_apply1<OPT>(a.b + i, a.ab + i, bi, gs, a.lr, a.eps);
+        } else {
+            atomic_add_f4(a.gV + (size_t)i * D + 4 * sub, gi);
+            if (sub == 0) unsafeAtomicAdd(a.gb + i, gs);
+        }
+    }
+    const float ls = wave_sum(loss_acc);
+    const float sq = wave_sum(sq_acc);
+    if (lane == 0) {
+        float2 v; v.x = ls; v.y = 0.5f * sq;
+        *reinterpret_cast<float2*>(a.partial + 2 * wave_global) = v;
+    }
+    if (MODEL == ORX_GMF && MODE != MODE_LOSS) {
+        // sum the lane groups of the wavefront (lanes with equal `sub`), one [D] partial per wave
+        for (int off = LPR; off < 64; off <<= 1) {
+            gw_acc.x += __shfl_xor(gw_acc.x, off); gw_acc.y += __shfl_xor(gw_acc.y, off);
+            gw_acc.z += __shfl_xor(gw_acc.z, off); gw_acc.w += __shfl_xor(gw_acc.w, off);
+        }
+        if (grp == 0) *reinterpret_cast<f4*>(a.wpartial + (size_t)wave_global * D + 4 * sub) = gw_acc;
+    }
+}
+
+// any D: one sample per wavefront, scalar elements
+template <int MODEL, int OPT, int MODE>
+__global__ __launch_bounds__(256) void point_generic_kernel(PointArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int D = a.D;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    float loss_acc = 0.0f, sq_acc = 0.0f;
+    float* wp = a.wpartial + (size_t)wave_global * D;
+    if (MODEL == ORX_GMF && MODE != MODE_LOSS) for (int e = lane; e < D; e += 64) wp[e] = 0.0f;
+    for (int64_t t = wave_global; t < a.B; t += stride) {
+        const int u = a.uid[t], i = a.iid[t];
+        const float y = a.label[t];
+        int du = 0, di = 0;
+        if (MODE == MODE_EXACT) { du = a.dflag[t]; di = a.dflag[a.B + t]; }
+        if (MODE == MODE_ACCUM) { du = di = 1; }
+        if (!(id_ok(u, a.NU) && id_ok(i, a.NI))) { if (lane == 0) *a.err = 1; continue; }
+        float* Ur = a.U + (size_t)u * D;
+        float* Ir = a.V + (size_t)i * D;
+        const float bi = a.b[i];
+        float part = 0.0f;
+        for (int e = lane; e < D; e += 64) {
+            const float x = Ur[e], z = Ir[e];
+            part += x * z * (MODEL == ORX_GMF ? a.w[e] : 1.0f);
+            sq_acc += x * x + z * z;
+        }
+        const float s = wave_sum(part) + bi;
+        float term, gs;
+        point_score<MODEL>(s, y, a.invB, a.a_w, a.b_w, term, gs);
+        if (lane == 0) loss_acc += term;
+        if (MODE == MODE_LOSS) continue;
+        for (int e = lane; e < D; e += 64) {
+            const float x = Ur[e], z = Ir[e];
+            const float we = MODEL == ORX_GMF ? a.w[e] : 1.0f;
+            const float gu = gs * z * we + a.l2w * x, gi = gs * x * we + a.l2w * z;
+            if (MODEL == ORX_GMF) wp[e] += gs * x * z;
+            if (du == 0) opt_apply1<OPT>(Ur + e, a.aU + (size_t)u * D + e, x, gu, a.lr, a.eps);
+            else unsafeAtomicAdd(a.gU + (size_t)u * D + e, gu);
+            if (di == 0) opt_apply1<OPT>(Ir + e, a.aV + (size_t)i * D + e, z, gi, a.lr, a.eps);
+            else unsafeAtomicAdd(a.gV + (size_t)i * D + e, gi);
+        }
+        if (lane == 0) {
+            if (di == 0) opt_apply1<OPT>(a.b + i, a.ab + i, bi, gs, a.lr, a.eps);
+            else unsafeAtomicAdd(a.gb + i, gs);
+        }
+    }
+    const float ls = wave_sum(loss_acc);
+    const float sq = wave_sum(sq_acc);
+    if (lane == 0) {
+        float2 v; v.x = ls; v.y = 0.5f * sq;
+        *reinterpret_cast<float2*>(a.partial + 2 * wave_global) = v;
+    }
+}
+
+// ------------------------------------------------------- dense kernel update ---
+// GMF's Dense(1, use_bias=False) kernel w[D]: gradient = sum of the per-wave
+// partials + l2w * w (gmf.py:31-32), then the optimizer's dense rule.
+__global__ __launch_bounds__(1024) void dense_reduce_kernel(const float* wpartial, int nwaves, int D, const float* w,
+                                                            float l2w, float* gout, float* l2slot) {
+    // blockDim = 1024 threads; column e is summed by threads e, e + ncol_threads, ...
+    __shared__ float sh[1024];
+    for (int e0 = 0; e0 < D; e0 += 64) {
+        const int e = e0 + (threadIdx.x & 63);
+        const int part = threadIdx.x >> 6;          // 16 row slices
+        float s = 0.0f;
+        if (e < D) for (int r = part; r < nwaves; r += 16) s += wpartial[(size_t)r * D + e];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (part == 0 && e < D && gout != nullptr) {
+            float t = 0.0f;
+            for (int k = 0; k < 16; ++k) t += sh[k * 64 + (threadIdx.x & 63)];
+            gout[e] = t + l2w * w[e];
+        }
+        __syncthreads();
+    }
+    if (l2slot != nullptr && threadIdx.x < 64) {       // 0.5*||w||^2 of the pre-step kernel joins l2_loss (gmf.py:31-32)
+        float s = 0.0f;
+        for (int e = threadIdx.x; e < D; e += 64) s += w[e] * w[e];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (threadIdx.x == 0) { l2slot[0] = 0.0f; l2slot[1] = 0.5f * s; }
+    }
+}
+
+__global__ __launch_bounds__(256) void dense_apply_kernel(float* w, float* acc, float* g, int n, int optkind, float lr, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    g[i] = 0.0f;
+    if (optkind == ORX_ADAGRAD) {
+        const float a2 = acc[i] + gi * gi;
+        acc[i] = a2;
+        w[i] = w[i] - lr * gi / (sqrtf(a2) + eps);
+    } else {
+        w[i] = w[i] - lr * gi;
+    }
+}
+
+// ------------------------------------------------------------- all-item scorer ---
+// out[q, j] = score(U[uid[q]], V[j]) + b[j]; block = 64 items x 16 users, the 16
+// user rows staged in LDS, every thread walks its own item row.
+// kind 0: dot, 1: -squared L2 distance, 2: GMF weighted dot
+__global__ __launch_bounds__(256) void score_all_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                        const float* __restrict__ b, const float* __restrict__ w,
+                                                        const int32_t* __restrict__ uid, int64_t nq, int64_t NU,
+                                                        int64_t NI, int D, int kind, float* __restrict__ out, int* err) {
+    extern __shared__ float urow[];                 // [16][D]
+    const int64_t q0 = (int64_t)blockIdx.y * 16;
+    const int64_t j = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int qs = threadIdx.x >> 6;                // this thread scores users qs, qs+4, qs+8, qs+12
+    for (int k = threadIdx.x; k < 16 * D; k += 256) {
+        const int64_t q = q0 + k / D;
+        float v = 0.0f;
+        if (q < nq) {
+            const int u = uid[q];
+            if ((uint32_t)u >= (uint64_t)NU) *err = 1; else v = U[(size_t)u * D + k % D];
+        }
+        urow[k] = v;
+    }
+    __syncthreads();
+    if (j >= NI) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* vr = V + (size_t)j * D;
+    for (int e = 0; e < D; ++e) {
+        const float v = vr[e];
+        const float we = kind == 2 ? w[e] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x = urow[(qs + 4 * k) * D + e];
+            if (kind == 1) { const float d = x - v; acc[k] -= d * d; }
+            else acc[k] += x * v * we;
+        }
+    }
+    const float bj = b[j];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t q = q0 + qs + 4 * k;
+        if (q < nq) out[q * NI + j] = acc[k] + bj;
+    }
+}
+
+// ---------------------------------------------------------------- launchers ---
+static inline int lpr_for_dim_p(int D) {
+    switch (D) { case 16: return 4; case 32: return 8; case 64: return 16; case 128: return 32; case 256: return 64; default: return 0; }
+}
+
+static inline int64_t point_grid(int D, int64_t B) {
+    const int lpr = lpr_for_dim_p(D);
+    const int64_t tpb = lpr ? 4 * (64 / lpr) : 4;
+    int64_t g = (B + tpb - 1) / tpb;
+    if (g > 16384) g = 16384;
+    if (g < 1) g = 1;
+    return g;
+}
+
+int orx_point_nwaves(int D, int64_t B) { return (int)(point_grid(D, B) * 4); }
+
+template <int LPR, int MODEL, int OPT>
+static void launch_point_mode(int mode, dim3 g, orx_ctx* c, const PointArgs& a) {
+    switch (mode) {
+        case MODE_EXACT: ORX_LAUNCH(c, (point_fused_kernel<LPR, MODEL, OPT, MODE_EXACT>), g, dim3(256), 0, a); break;
+        case MODE_HOGWILD: ORX_LAUNCH(c, (point_fused_kernel<LPR, MODEL, OPT, MODE_HOGWILD>), g, dim3(256), 0, a); break;
+        case MODE_ACCUM: ORX_LAUNCH(c, (point_fused_kernel<LPR, MODEL, ORX_SGD, MODE_ACCUM>), g, dim3(256), 0, a); break;
+        default: ORX_LAUNCH(c, (point_fused_kernel<LPR, MODEL, ORX_SGD, MODE_LOSS>), g, dim3(256), 0, a); break;
+    }
+}
+
+template <int MODEL, int OPT>
+static void launch_point_generic(int mode, dim3 g, orx_ctx* c, const PointArgs& a) {
+    switch (mode) {
+        case MODE_EXACT: ORX_LAUNCH(c, (point_generic_kernel<MODEL, OPT, MODE_EXACT>), g, dim3(256), 0, a); break;
+        case MODE_HOGWILD: ORX_LAUNCH(c, (point_generic_kernel<MODEL, OPT, MODE_HOGWILD>), g, dim3(256), 0, a); break;
+        case MODE_ACCUM: ORX_LAUNCH(c, (point_generic_kernel<MODEL, ORX_SGD, MODE_ACCUM>), g, dim3(256), 0, a); break;
+        default: ORX_LAUNCH(c, (point_generic_kernel<MODEL, ORX_SGD, MODE_LOSS>), g, dim3(256), 0, a); break;
+    }
+}
+
+template <int MODEL, int OPT>
+static void launch_point_lpr(int lpr, int mode, dim3 g, orx_ctx* c, const PointArgs& a) {
+    switch (lpr) {
+        case 4: launch_point_mode<4, MODEL, OPT>(mode, g, c, a); break;
+        case 8: launch_point_mode<8, MODEL, OPT>(mode, g, c, a); break;
+        case 16: launch_point_mode<16, MODEL, OPT>(mode, g, c, a); break;
+        case 32: launch_point_mode<32, MODEL, OPT>(mode, g, c, a); break;
+        case 64: launch_point_mode<64, MODEL, OPT>(mode, g, c, a); break;
+        default: launch_point_generic<MODEL, OPT>(mode, g, c, a); break;
+    }
+}
+
+int orx_launch_point_fused(orx_ctx* ctx, int model, int optkind, int mode, const PointArgs& a) {
+    ProfScope ps(ctx, ORX_K_POINT);
+    const int lpr = lpr_for_dim_p(a.D);
+    const dim3 g((unsigned)point_grid(a.D, a.B));
+    const bool ada = optkind == ORX_ADAGRAD;
+    if (model == ORX_GMF) {
+        if (ada) launch_point_lpr<ORX_GMF, ORX_ADAGRAD>(lpr, mode, g, ctx, a);
+        else launch_point_lpr<ORX_GMF, ORX_SGD>(lpr, mode, g, ctx, a);
+    } else {
+        if (ada) launch_point_lpr<ORX_WRMF, ORX_ADAGRAD>(lpr, mode, g, ctx, a);
+        else launch_point_lpr<ORX_WRMF, ORX_SGD>(lpr, mode, g, ctx, a);
+    }
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_launch_dense_reduce(orx_ctx* ctx, const float* wpartial, int nwaves, int D, const float* w, float l2w, float* gout,
+                            float* l2slot) {
+    ORX_LAUNCH(ctx, dense_reduce_kernel, dim3(1), dim3(1024), 0, wpartial, nwaves, D, w, l2w, gout, l2slot);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_launch_dense_apply(orx_ctx* ctx, float* w, float* acc, float* g, int n, int optkind, float lr, float eps) {
+    ORX_LAUNCH(ctx, dense_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, w, acc, g, n, optkind, lr, eps);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_launch_score_all(orx_ctx* ctx, const float* U, const float* V, const float* b, const float* w,
+                         const int32_t* uid, int64_t nq, int64_t NU, int64_t NI, int D, int kind, float* out) {
+    const dim3 g((unsigned)((NI + 63) / 64), (unsigned)((nq + 15) / 16));
+    ORX_LAUNCH(ctx, score_all_kernel, g, dim3(256), (size_t)16 * D * sizeof(float), U, V, b, w, uid, nq, NU, NI, D, kind, out, ctx->d_err);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}

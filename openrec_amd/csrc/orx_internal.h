@@ -54,6 +54,7 @@ struct orx_ctx {
     float* d_partial = nullptr; size_t d_partial_cap = 0;   // [K][nwaves][2] loss partials
     double* d_loss = nullptr;  size_t d_loss_cap = 0;       // [K][2] step results
     float* d_tmp = nullptr;    size_t d_tmp_cap = 0;        // misc fp32 scratch
+    float* d_wpart = nullptr;  size_t d_wpart_cap = 0;      // [nwaves][D] dense-kernel gradient partials
     bool prof = false;
     ProfSlot prof_slot[ORX_K_NUM];
     hipEvent_t cur_e0 = nullptr, cur_e1 = nullptr;   // events of the launch being profiled (or null)
@@ -87,6 +88,8 @@ struct orx_opt {
 int orx_ensure(void** p, size_t* cap, size_t bytes);           // grow a device buffer
 int orx_table_scratch(orx_table* t);                            // allocate gsum
 int orx_opt_slots(orx_opt* opt, orx_table* t, OptSlots* out);   // allocate optimizer slots
+int stage_ids(orx_ctx* c, const int32_t* host, int64_t n, int64_t off);   // H2D into ctx->d_ids
+int fetch_losses(orx_ctx* c, int64_t K, float* loss_out, float* l2_out);
 void orx_prof_begin(orx_ctx* ctx, int kid);
 void orx_prof_end(orx_ctx* ctx, int kid);
 
@@ -167,6 +170,29 @@ struct GradArgs {
 int orx_launch_pair_grads(orx_ctx* ctx, int model, const GradArgs& a, int* nwaves);
 int orx_launch_apply_rows(orx_ctx* ctx, int optkind, bool use_dflag, const RowsArgs& a);
 int orx_launch_loss_accumulate(orx_ctx* ctx, const float* partial, int nwaves, double* accum);
+
+// pointwise (GMF / WRMF) step, kernels_pointwise.hip
+struct PointArgs {
+    float* U; float* V; float* b; const float* w;
+    float* gU; float* gV; float* gb;
+    float* aU; float* aV; float* ab;
+    const int32_t* uid; const int32_t* iid; const float* label;
+    const unsigned char* dflag;               // [2B]: user refs then item refs
+    int64_t B; int64_t NU; int64_t NI;
+    int D;
+    float lr; float eps; float invB; float l2w; float a_w; float b_w;
+    float* partial;                           // [nwaves][2]
+    float* wpartial;                          // [nwaves][D] (GMF)
+    int* err;
+};
+
+int orx_launch_point_fused(orx_ctx* ctx, int model, int optkind, int mode, const PointArgs& a);
+int orx_launch_dense_reduce(orx_ctx* ctx, const float* wpartial, int nwaves, int D, const float* w, float l2w, float* gout,
+                            float* l2slot);
+int orx_launch_dense_apply(orx_ctx* ctx, float* w, float* acc, float* g, int n, int optkind, float lr, float eps);
+int orx_launch_score_all(orx_ctx* ctx, const float* U, const float* V, const float* b, const float* w,
+                         const int32_t* uid, int64_t nq, int64_t NU, int64_t NI, int D, int kind, float* out);
+int orx_point_nwaves(int D, int64_t B);
 
 // launchers implemented in kernels_pairwise.hip
 int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K);

@@ -215,3 +215,65 @@ def pairwise_loss(model, user, item, bias, uid, pid, nid, margin=0.5):
     check(lib.orx_pairwise_loss(user.ctx._h, mid, user._h, item._h, bias._h, pu, pp, pn, nu, float(margin),
                                 _ffi.ORX_IDS_DEVICE if du else 0, loss.ctypes.data, l2.ctypes.data))
     return float(loss[0]), float(l2[0])
+
+
+def _label_arg(x):
+    if _is_device_tensor(x):
+        assert str(x.dtype).endswith("float32") and x.is_contiguous()
+        return x.data_ptr(), x.numel(), True, x
+    if hasattr(x, "numpy") and not isinstance(x, np.ndarray):
+        x = x.numpy()
+    a = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    return a.ctypes.data, a.size, False, a
+
+
+_POINT = {"gmf": _ffi.ORX_GMF, "wrmf": _ffi.ORX_WRMF}
+
+
+def pointwise_step(model, opt, user, item, bias, w, uid, iid, label, K=1, B=None, id_stride=None,
+                   a=1.0, b_w=1.0, hogwild=False, no_l2=False, want_loss=True):
+    """K fused GMF / WRMF train steps (gmf.py:22-34, wrmf.py:21-34)."""
+    lib = user.ctx._lib
+    pu, nu, du, k0 = _ids_arg(uid)
+    pi, ni, di, k1 = _ids_arg(iid)
+    pl, nl, dl, k2 = _label_arg(label)
+    assert du == di == dl and nu == ni == nl
+    if B is None:
+        B = nu // K
+    if id_stride is None:
+        id_stride = B
+    flags = (_ffi.ORX_IDS_DEVICE if du else 0) | (_ffi.ORX_HOGWILD if hogwild else 0) | (_ffi.ORX_NO_L2 if no_l2 else 0)
+    loss = np.empty(K, np.float32) if want_loss else None
+    l2 = np.empty(K, np.float32) if want_loss else None
+    check(lib.orx_pointwise_step(user.ctx._h, _POINT[model], opt._h, user._h, item._h, bias._h,
+                                 w._h if w is not None else None, pu, pi, pl, int(K), int(B), int(id_stride),
+                                 float(a), float(b_w), flags,
+                                 loss.ctypes.data if want_loss else None, l2.ctypes.data if want_loss else None))
+    opt._tables = list({id(t): t for t in (opt._tables + [user, item, bias] + ([w] if w is not None else []))}.values())
+    return (loss, l2) if want_loss else None
+
+
+def pointwise_loss(model, user, item, bias, w, uid, iid, label, a=1.0, b_w=1.0):
+    lib = user.ctx._lib
+    pu, nu, du, k0 = _ids_arg(uid)
+    pi, _, di, k1 = _ids_arg(iid)
+    pl, _, dl, k2 = _label_arg(label)
+    loss = np.empty(1, np.float32)
+    l2 = np.empty(1, np.float32)
+    check(lib.orx_pointwise_loss(user.ctx._h, _POINT[model], user._h, item._h, bias._h,
+                                 w._h if w is not None else None, pu, pi, pl, nu, float(a), float(b_w),
+                                 _ffi.ORX_IDS_DEVICE if du else 0, loss.ctypes.data, l2.ctypes.data))
+    return float(loss[0]), float(l2[0])
+
+
+def score_all_items(kind, user, item, bias, uid, w=None):
+    """Recommender.inference: scores of the given users against ALL items -> [n, item_rows]."""
+    lib = user.ctx._lib
+    ptr, n, dev, keep = _ids_arg(uid)
+    if dev:
+        raise ValueError("score_all_items takes host ids")
+    out = np.empty((n, item.rows), np.float32)
+    k = {"dot": 0, "l2": 1, "gmf": 2}[kind]
+    check(lib.orx_score_all_items(user.ctx._h, k, user._h, item._h, bias._h, w._h if w is not None else None,
+                                  ptr, n, out.ctypes.data))
+    return out

@@ -1,0 +1,141 @@
+"""The handful of TensorFlow symbols that `tf2_examples/*.py` touch around the
+hot path, so that a script shaped like
+tf2_examples/bpr_citeulike.py runs with only its imports changed:
+
+    from openrec_amd.tf2.compat import tf, optimizers
+    from openrec_amd.tf2.recommenders import BPR
+
+`install()` additionally registers this module as `tensorflow` in sys.modules --
+only when no real TensorFlow is importable; it never shadows one."""
+from __future__ import annotations
+
+import sys
+import types
+
+import numpy as np
+
+from .. import runtime as rt
+from ._lazy import GradientTape, GradToken, LazyScalar
+
+
+def function(fn=None, **_):
+    """tf.function: the fused step is already one device call, nothing to trace."""
+    if fn is None:
+        return lambda f: f
+    return fn
+
+
+def constant(value, dtype=None):
+    return np.asarray(value, dtype=dtype)
+
+
+int32, float32, bool_ = np.int32, np.float32, np.bool_
+
+
+class _Optimizer:
+    """Keras optimizer facade; the device-side state lives in runtime.Optimizer."""
+    _kind = None
+
+    def __init__(self):
+        self._native = None
+
+    def _make(self, ctx):
+        raise NotImplementedError
+
+    def native(self, ctx=None):
+        if self._native is None:
+            self._native = self._make(ctx)
+        return self._native
+
+    def apply_gradients(self, grads_and_vars):
+        """Consumes the tokens of `GradientTape.gradient`: all tokens of one recorded
+        step trigger ONE fused forward+backward+update call."""
+        steps = []
+        for g, v in grads_and_vars:
+            if not isinstance(g, GradToken):
+                raise TypeError("apply_gradients expects gradients produced by openrec_amd's GradientTape")
+            if g.step not in [s for s, _ in steps]:
+                steps.append((g.step, g.no_l2))
+        for step, no_l2 in steps:
+            ctx = step.model.user_latent_factor.table.ctx
+            step.train(self.native(ctx), no_l2)
+
+
+class SGD(_Optimizer):
+    def __init__(self, learning_rate=0.01, momentum=0.0, **_):
+        super().__init__()
+        if momentum:
+            raise NotImplementedError("momentum SGD is not on the reference's hot path")
+        self.learning_rate = learning_rate
+
+    def _make(self, ctx):
+        return rt.Optimizer.sgd(self.learning_rate, ctx=ctx)
+
+
+class Adagrad(_Optimizer):
+    def __init__(self, learning_rate=0.001, initial_accumulator_value=0.1, epsilon=1e-7, **_):
+        super().__init__()
+        self.learning_rate, self.iav, self.epsilon = learning_rate, initial_accumulator_value, epsilon
+
+    def _make(self, ctx):
+        return rt.Optimizer.adagrad(self.learning_rate, self.iav, self.epsilon, ctx=ctx)
+
+
+class Adam(_Optimizer):
+    """keras.optimizers.Adam() as used by tf2_examples/bpr_citeulike.py:31 (TF-2.0
+    dense-decay sparse apply)."""
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, **_):
+        super().__init__()
+        self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
+
+    def _make(self, ctx):
+        return rt.Optimizer.adam(self.learning_rate, self.beta_1, self.beta_2, self.epsilon, ctx=ctx)
+
+
+class Mean:
+    """tf.keras.metrics.Mean; `update_state((loss, l2))` averages the two scalars
+    together, like the reference script does (bpr_citeulike.py:54)."""
+
+    def __init__(self):
+        self.reset_states()
+
+    def update_state(self, values):
+        for v in (values if isinstance(values, (tuple, list)) else [values]):
+            a = np.asarray(v.numpy() if hasattr(v, "numpy") else v, np.float64)
+            self._sum += float(a.sum())
+            self._n += a.size
+
+    def result(self):
+        return np.float32(self._sum / max(self._n, 1))
+
+    def reset_states(self):
+        self._sum, self._n = 0.0, 0
+
+
+optimizers = types.SimpleNamespace(SGD=SGD, Adagrad=Adagrad, Adam=Adam)
+keras = types.SimpleNamespace(optimizers=optimizers, metrics=types.SimpleNamespace(Mean=Mean))
+tf = types.SimpleNamespace(function=function, GradientTape=GradientTape, constant=constant, keras=keras,
+                           int32=int32, float32=float32, bool=bool_)
+
+
+def install():
+    """Make `import tensorflow as tf` / `from tensorflow.keras import optimizers`
+    resolve to this shim when (and only when) TensorFlow is absent."""
+    try:
+        import tensorflow  # noqa: F401
+        return False
+    except Exception:
+        pass
+    mod = types.ModuleType("tensorflow")
+    for k, v in vars(tf).items():
+        setattr(mod, k, v)
+    kmod = types.ModuleType("tensorflow.keras")
+    kmod.optimizers, kmod.metrics = optimizers, keras.metrics
+    omod = types.ModuleType("tensorflow.keras.optimizers")
+    omod.SGD, omod.Adagrad, omod.Adam = SGD, Adagrad, Adam
+    mod.keras = kmod
+    sys.modules["tensorflow"] = mod
+    sys.modules["tensorflow.keras"] = kmod
+    sys.modules["tensorflow.keras.optimizers"] = omod
+    return True

@@ -1,0 +1,98 @@
+"""The reference's Python surface on the GPU: a train step written exactly like
+tf2_examples/bpr_citeulike.py:33-39 (tape + apply_gradients) must give the
+oracle's result, executed as one fused device call."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def test_tape_style_train_step_bpr_adam_dim50():
+    from openrec_amd.tf2.compat import tf, optimizers
+    from openrec_amd.tf2.recommenders import BPR
+    from oracle import numpy_oracle as orc
+    total_users, total_items, dim_embed, batch_size = 555, 1698, 50, 1000     # CiteULike / 10, example dims
+    bpr_model = BPR(total_users=total_users, total_items=total_items, dim_user_embed=dim_embed, dim_item_embed=dim_embed)
+    optimizer = optimizers.Adam()
+
+    @tf.function
+    def train_step(user_id, p_item_id, n_item_id):
+        with tf.GradientTape() as tape:
+            loss_value = bpr_model(user_id, p_item_id, n_item_id)
+        gradients = tape.gradient(loss_value, bpr_model.trainable_variables)
+        optimizer.apply_gradients(zip(gradients, bpr_model.trainable_variables))
+        return loss_value
+
+    U, V, b = (v.numpy() for v in bpr_model.trainable_variables)
+    assert U.shape == (555, 50) and b.shape == (1698, 1) and np.abs(U).max() <= 0.05 and U.std() > 0.02
+    oo = orc.AdamTFSparse()
+    rng = np.random.default_rng(0)
+    average_loss = tf.keras.metrics.Mean()
+    for it in range(4):
+        batch = dict(user_id=rng.integers(0, total_users, batch_size).astype(np.int32),
+                     p_item_id=rng.integers(0, total_items, batch_size).astype(np.int32),
+                     n_item_id=rng.integers(0, total_items, batch_size).astype(np.int32))
+        loss = train_step(**batch)
+        average_loss.update_state(loss)
+        lr, l2r = orc.bpr_step(U, V, b, batch["user_id"], batch["p_item_id"], batch["n_item_id"], oo)
+        assert abs(float(loss[0]) - lr) <= TOL * abs(lr) and abs(float(loss[1]) - l2r) <= TOL * abs(l2r)
+    Ud, Vd, bd = (v.numpy() for v in bpr_model.trainable_variables)
+    assert rel_err(Ud, U) < 5e-5 and rel_err(Vd, V) < 5e-5 and rel_err(bd, b) < 5e-5
+    assert np.isfinite(average_loss.result())
+    # inference keeps returning [B, total_items]
+    pred = bpr_model.inference(np.arange(8, dtype=np.int32))
+    assert pred.shape == (8, total_items) and rel_err(pred, orc.bpr_inference(U, V, b, np.arange(8))) < 1e-4
+
+
+def test_forward_outside_tape_and_ucml_censor():
+    from openrec_amd.tf2.recommenders import UCML
+    from openrec_amd.tf2.compat import tf, optimizers
+    from oracle import numpy_oracle as orc
+    m = UCML(dim_user_embed=128, dim_item_embed=128, total_users=400, total_items=600, margin=0.5)
+    U, V, b = (v.numpy() for v in m.trainable_variables)
+    rng = np.random.default_rng(2)
+    u = rng.integers(0, 400, 512).astype(np.int32); p = rng.integers(0, 600, 512).astype(np.int32); n = rng.integers(0, 600, 512).astype(np.int32)
+    loss, l2 = m(u, p, n)                                   # no tape: forward only, tables untouched
+    lr, l2r, _ = orc.ucml_forward(U, V, b, u, p, n, 0.5)
+    assert abs(float(loss) - lr) <= TOL * abs(lr) and abs(float(l2) - l2r) <= TOL * abs(l2r)
+    assert np.array_equal(m.trainable_variables[0].numpy(), U)
+    opt = optimizers.SGD(learning_rate=0.05)
+    with tf.GradientTape() as tape:
+        out = m(u, p, n)
+    opt.apply_gradients(zip(tape.gradient(out, m.trainable_variables), m.trainable_variables))
+    m.censor_vec(u, p, n)
+    orc.ucml_step(U, V, b, u, p, n, orc.SGD(0.05), margin=0.5, do_censor=True)
+    Ud, Vd, bd = (v.numpy() for v in m.trainable_variables)
+    assert rel_err(Ud, U) < TOL and rel_err(Vd, V) < TOL and rel_err(bd, b) < TOL
+
+
+def test_gmf_wrmf_models():
+    from openrec_amd.tf2.recommenders import GMF, WRMF
+    from openrec_amd.tf2.compat import tf, optimizers
+    from oracle import numpy_oracle as orc
+    rng = np.random.default_rng(3)
+    u = rng.integers(0, 200, 300).astype(np.int32); i = rng.integers(0, 300, 300).astype(np.int32)
+    y = (rng.uniform(size=300) < 0.5).astype(np.float32)
+    g = GMF(dim_user_embed=64, dim_item_embed=64, total_users=200, total_items=300)
+    U, V, b, w = (v.numpy() for v in g.trainable_variables)
+    assert w.shape == (64, 1)
+    opt = optimizers.Adagrad(learning_rate=0.05)
+    with tf.GradientTape() as tape:
+        out = g(u, i, y)
+    opt.apply_gradients(zip(tape.gradient(out, g.trainable_variables), g.trainable_variables))
+    lr, l2r = orc.gmf_step(U, V, b, w, u, i, y, orc.Adagrad(0.05, 0.1, 1e-7))
+    assert abs(float(out[0]) - lr) <= TOL * abs(lr) and abs(float(out[1]) - l2r) <= TOL * abs(l2r)
+    for dv, ref in zip(g.trainable_variables, (U, V, b, w)):
+        assert rel_err(dv.numpy(), ref) < TOL
+    wm = WRMF(dim_user_embed=64, dim_item_embed=64, total_users=200, total_items=300, a=2.0, b=0.5)
+    U, V, b = (v.numpy() for v in wm.trainable_variables)
+    with tf.GradientTape() as tape:
+        out = wm(u, i, y)
+    optimizers.SGD(0.01).apply_gradients(zip(tape.gradient(out, wm.trainable_variables), wm.trainable_variables))
+    lr, l2r = orc.wrmf_step(U, V, b, u, i, y, orc.SGD(0.01), a=2.0, b_w=0.5)
+    assert abs(float(out[0]) - lr) <= TOL * abs(lr)
+    assert rel_err(wm.trainable_variables[1].numpy(), V) < TOL
+    assert wm.inference(u[:5]).shape == (5, 300)
