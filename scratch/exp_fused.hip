@@ -13,10 +13,10 @@ __device__ __forceinline__ float dot4(f4 a,f4 b){return a.x*b.x+a.y*b.y+a.z*b.z+
 struct A { float*U,*V,*b; int*cU,*cV; int*c2U,*c2V; const int*uid,*pid,*nid; const int*uid2,*pid2,*nid2; unsigned char* dm; float* part; int B; float lr, invB; };
 
 // flags: 1 bias, 2 cnt read, 4 cnt reset, 8 embedded atomics for next step, 16 tag store (plain) for next step, 32 extra tag load (pass B), 64 loss math
-template<int F, int UN>
-__global__ __launch_bounds__(256) void fused(A a){
+template<int F, int UN, int BS>
+__global__ __launch_bounds__(BS) void fused(A a){
   const int lane=threadIdx.x&63, sub=lane&15, grp=lane>>4;
-  const int64_t gw=(int64_t)blockIdx.x*4+(threadIdx.x>>6);
+  const int64_t gw=(int64_t)blockIdx.x*(BS/64)+(threadIdx.x>>6);
   float lacc=0, sacc=0;
   const int base=(int)gw*4*UN;
   #pragma unroll
@@ -60,15 +60,15 @@ int main(){
   CK(hipMalloc(&a.dm,B)); CK(hipMalloc(&a.part,65536*8)); a.B=B; a.lr=0.05f; a.invB=1.f/B;
   int step=0;
   auto setids=[&](){ int s=step%K, s2=(step+1)%K; a.uid=ids+(size_t)s*B; a.pid=ids+(size_t)(K+s)*B; a.nid=ids+(size_t)(2*K+s)*B; a.uid2=ids+(size_t)s2*B; a.pid2=ids+(size_t)(K+s2)*B; a.nid2=ids+(size_t)(2*K+s2)*B; step++; };
-  #define RUN(F,UN,name) { float ms=timeit([&]{ setids(); hipLaunchKernelGGL((fused<F,UN>),dim3(B/(16*UN)),dim3(256),0,0,a); },48); printf("%-46s UN=%d: %.1f us  (%.2f TB/s alg)\n",name,UN,ms*1e3,B*1564.0/ms/1e9); CK(hipMemcpy(a.cU,ones.data(),N*4,hipMemcpyHostToDevice)); CK(hipMemcpy(a.cV,ones.data(),N*4,hipMemcpyHostToDevice)); }
-  RUN(0,1,"rows only")
-  RUN(128,1,"rows only, nt stores")
-  RUN(256,1,"rows only, nt loads")
-  RUN(384,1,"rows only, nt loads+stores")
-  RUN(65,1,"rows+bias+loss")
-  RUN(65+128,1,"rows+bias+loss, nt stores")
-  RUN(65+384,1,"rows+bias+loss, nt both")
-  // block-size / launch-bounds sensitivity is probed by UN
-  RUN(65,2,"rows+bias+loss")
+  #define RUN(F,UN,name) { float ms=timeit([&]{ setids(); hipLaunchKernelGGL((fused<F,UN,256>),dim3(B/(16*UN)),dim3(256),0,0,a); },48); printf("%-46s UN=%d: %.1f us  (%.2f TB/s alg)\n",name,UN,ms*1e3,B*1564.0/ms/1e9); CK(hipMemcpy(a.cU,ones.data(),N*4,hipMemcpyHostToDevice)); CK(hipMemcpy(a.cV,ones.data(),N*4,hipMemcpyHostToDevice)); }
+  #define RUNB(F,BS,name) { float ms=timeit([&]{ setids(); hipLaunchKernelGGL((fused<F,1,BS>),dim3(B*16/BS),dim3(BS),0,0,a); },48); printf("%-30s BS=%d: %.1f us  (%.2f TB/s alg)\n",name,BS,ms*1e3,B*1564.0/ms/1e9); }
+  RUNB(65,64,"rows+bias+loss")
+  RUNB(65,128,"rows+bias+loss")
+  RUNB(65,256,"rows+bias+loss")
+  RUNB(65,512,"rows+bias+loss")
+  RUNB(65,1024,"rows+bias+loss")
+  RUNB(0,64,"rows only")
+  RUNB(0,256,"rows only")
+  RUNB(0,1024,"rows only")
   return 0;
 }
