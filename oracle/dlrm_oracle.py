@@ -1,0 +1,163 @@
+"""CPU oracle for the reference's DLRM train step (NumPy; TEST INFRASTRUCTURE ONLY).
+
+PARITY UNPINNED (no reference tests / golden vectors; TensorFlow absent) -- pinned
+against torch autograd fixtures (tests/golden/make_golden_dlrm.py).
+
+Restates (paths relative to /root/reference):
+  openrec/tf2/recommenders/dlrm.py:8-100          model wiring, loss, clipping
+  openrec/tf2/modules/multi_layer_perceptron.py:5-18   Dense stacks (hidden relu)
+  openrec/tf2/modules/second_order_feature_interaction.py:12-34
+  tf2_examples/dlrm_criteo.py:42-48               tape.gradient(loss) + apply_gradients
+
+`reference_compat=True` reproduces second_order_feature_interaction.py bit for
+bit, including its bug: line 21 keeps the LOWER triangle of
+Z Z^T, lines 23-27/32 select the strictly UPPER triangle, so every selected
+element is 0 (only the diagonal survives with self_interaction) and the
+embedding tables receive zero gradients.  `reference_compat=False` is the
+evidently intended strictly-lower-triangle pairwise dot product.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import numpy_oracle as orc
+
+KERAS_EPS = 1e-7
+
+
+def glorot(rng, fan_in, fan_out, dtype):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, (fan_in, fan_out)).astype(dtype)
+
+
+def interaction_pairs(F, self_interaction, reference_compat):
+    """Returns (I, J) index arrays of the selected (row, col) elements in
+    tf.boolean_mask (row-major) order, and whether off-diagonal values are live."""
+    if reference_compat:
+        mask = np.triu(np.ones((F, F), bool), k=0 if self_interaction else 1)
+    else:
+        mask = np.tril(np.ones((F, F), bool), k=0 if self_interaction else -1)
+    I, J = np.nonzero(mask)
+    return I, J
+
+
+class DLRMOracle:
+    def __init__(self, m_spa, ln_emb, ln_bot, ln_top, dense_dim, arch_interaction_itself=False,
+                 sigmoid_bot=False, sigmoid_top=True, loss_func="mse", loss_threshold=0.0,
+                 reference_compat=True, dtype=np.float32, seed=0):
+        rng = np.random.default_rng(seed)
+        self.dt = np.dtype(dtype)
+        self.m_spa, self.ln_emb = m_spa, list(ln_emb)
+        self.emb = [rng.uniform(-0.05, 0.05, (n, m_spa)).astype(dtype) for n in ln_emb]   # dlrm.py:32-33
+        self.bot, d = [], dense_dim
+        for u in ln_bot:
+            self.bot.append([glorot(rng, d, u, dtype), np.zeros(u, dtype)]); d = u
+        assert d == m_spa, "the bottom MLP must end at m_spa (its output is stacked with the embeddings)"
+        self.F = len(ln_emb) + 1
+        self.I, self.J = interaction_pairs(self.F, arch_interaction_itself, reference_compat)
+        self.compat = reference_compat
+        self.top, d = [], m_spa + len(self.I)
+        for u in ln_top:
+            self.top.append([glorot(rng, d, u, dtype), np.zeros(u, dtype)]); d = u
+        self.bot_act = ["relu"] * (len(ln_bot) - 1) + ["sigmoid" if sigmoid_bot else "relu"]   # dlrm.py:34-35
+        self.top_act = ["relu"] * (len(ln_top) - 1) + ["sigmoid" if sigmoid_top else "relu"]   # dlrm.py:36-37
+        self.loss_func, self.thr = loss_func, loss_threshold
+
+    # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _act(x, a):
+        if a == "relu":
+            return np.maximum(x, 0)
+        if a == "sigmoid":
+            return orc._sigmoid(x)
+        return x
+
+    def _mlp(self, x, layers, acts):
+        outs = [x]
+        for (W, b), a in zip(layers, acts):
+            x = self._act(x @ W + b, a)
+            outs.append(x)
+        return outs
+
+    def forward(self, dense, sparse):
+        dense = dense.astype(self.dt)
+        bot = self._mlp(dense, self.bot, self.bot_act)                                  # dlrm.py:87
+        vecs = [self.emb[f][sparse[:, f]] for f in range(len(self.emb))] + [bot[-1]]    # dlrm.py:83-85, :91
+        Z = np.stack(vecs, 1)                                                           # [B, F, d]
+        dots = np.einsum("bfd,bgd->bfg", Z, Z)
+        if self.compat:
+            dots = np.tril(dots)                                                        # interaction.py:21
+        inter = dots[:, self.I, self.J]
+        R = np.concatenate([bot[-1], inter], 1)                                         # dlrm.py:90-92
+        top = self._mlp(R, self.top, self.top_act)
+        p = top[-1]
+        clip_mask = np.ones_like(p)
+        if 0.0 < self.thr < 1.0:                                                        # dlrm.py:97-98
+            lo, hi = self.dt.type(self.thr), self.dt.type(1.0 - self.thr)
+            clip_mask = ((p >= lo) & (p <= hi)).astype(self.dt)
+            p = np.clip(p, lo, hi)
+        return dict(bot=bot, Z=Z, R=R, top=top, pred=p.reshape(-1), clip_mask=clip_mask.reshape(-1))
+
+    def inference(self, dense, sparse):
+        return self.forward(dense, sparse)["pred"]
+
+    # ----------------------------------------------------------- loss + backward
+    def loss_and_grads(self, dense, sparse, label):
+        c = self.forward(dense, sparse)
+        p, y = c["pred"], label.astype(self.dt)
+        B = p.shape[0]
+        if self.loss_func == "mse":                                                     # Keras MeanSquaredError
+            loss = ((y - p) ** 2).mean(dtype=self.dt)
+            dp = 2 * (p - y) / self.dt.type(B)
+        else:                                                                           # Keras BinaryCrossentropy
+            eps = self.dt.type(KERAS_EPS)
+            pc = np.clip(p, eps, 1 - eps)
+            loss = -(y * np.log(pc + eps) + (1 - y) * np.log(1 - pc + eps)).mean(dtype=self.dt)
+            inside = ((p >= eps) & (p <= 1 - eps)).astype(self.dt)
+            dp = -(y / (pc + eps) - (1 - y) / (1 - pc + eps)) * inside / self.dt.type(B)
+        dp = (dp * c["clip_mask"]).reshape(-1, 1)
+        g_top, dR = self._mlp_backward(c["top"], self.top, self.top_act, dp)
+        d = self.m_spa
+        dZ = np.zeros_like(c["Z"])
+        dZ[:, self.F - 1, :] += dR[:, :d]
+        G = dR[:, d:]                                                                   # [B, P]
+        Z = c["Z"]
+        for k, (i, j) in enumerate(zip(self.I, self.J)):
+            live = (i >= j) if self.compat else True        # compat: only the kept lower triangle carries values
+            if not live:
+                continue
+            g = G[:, k:k + 1]
+            if i == j:
+                dZ[:, i, :] += 2 * g * Z[:, i, :]
+            else:
+                dZ[:, i, :] += g * Z[:, j, :]
+                dZ[:, j, :] += g * Z[:, i, :]
+        g_bot, _ = self._mlp_backward(c["bot"], self.bot, self.bot_act, dZ[:, self.F - 1, :])
+        return loss, dict(emb=dZ[:, :self.F - 1, :], bot=g_bot, top=g_top)
+
+    def _mlp_backward(self, outs, layers, acts, dy):
+        grads = [None] * len(layers)
+        for l in range(len(layers) - 1, -1, -1):
+            y = outs[l + 1]
+            if acts[l] == "relu":
+                dz = dy * (y > 0)
+            elif acts[l] == "sigmoid":
+                dz = dy * y * (1 - y)
+            else:
+                dz = dy
+            grads[l] = (outs[l].T @ dz, dz.sum(0))
+            dy = dz @ layers[l][0].T
+        return grads, dy
+
+    # ------------------------------------------------------------------- step
+    def step(self, dense, sparse, label, opt):
+        loss, g = self.loss_and_grads(dense, sparse, label)
+        if hasattr(opt, "begin_step"):
+            opt.begin_step()
+        for f in range(len(self.emb)):
+            opt.apply(self.emb[f], sparse[:, f], g["emb"][:, f, :], key=("emb", f))
+        for name, layers, gl in (("bot", self.bot, g["bot"]), ("top", self.top, g["top"])):
+            for l, ((W, b), (gW, gb)) in enumerate(zip(layers, gl)):
+                opt.apply_dense(W, gW.astype(self.dt), key=(name, l, "W"))
+                opt.apply_dense(b, gb.astype(self.dt), key=(name, l, "b"))
+        return loss
