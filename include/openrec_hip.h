@@ -164,6 +164,39 @@ int orx_pointwise_loss(orx_ctx* ctx, int model,
 int orx_score_all_items(orx_ctx* ctx, int kind, orx_table* user, orx_table* item, orx_table* bias, orx_table* w,
                         const int32_t* uid, int64_t n, float* out);
 
+/* ---- DLRM (recommenders/dlrm.py:6-100, modules/multi_layer_perceptron.py:5-18,
+ * modules/second_order_feature_interaction.py:4-34; train step as in
+ * tf2_examples/dlrm_criteo.py:42-48).  The n_emb embedding tables (all of dim
+ * m_spa) live in ONE combined table, table f starting at row sum(ln_emb[0:f]).
+ * The bottom MLP must end at m_spa (its output is stacked with the embeddings). */
+typedef struct orx_dlrm orx_dlrm;
+enum orx_dlrm_flags {
+    ORX_DLRM_INTERACT_ITSELF = 1,   /* arch_interaction_itself                           */
+    ORX_DLRM_SIGMOID_BOT = 2,       /* sigmoid_bot (else relu), dlrm.py:34-35            */
+    ORX_DLRM_SIGMOID_TOP = 4,       /* sigmoid_top (else relu), dlrm.py:36-37            */
+    ORX_DLRM_LOSS_BCE = 8,          /* loss_func='bce' (else 'mse'), dlrm.py:52-55       */
+    ORX_DLRM_REFERENCE_COMPAT = 16  /* reproduce second_order_feature_interaction.py:21-32
+                                       literally: lower triangle kept, upper selected -> the
+                                       interaction output is 0; without this
+                                       flag the strictly lower triangle is used             */
+};
+enum orx_dlrm_param_kind { ORX_DLRM_EMB = 0, ORX_DLRM_BOT_W = 1, ORX_DLRM_BOT_B = 2, ORX_DLRM_TOP_W = 3, ORX_DLRM_TOP_B = 4 };
+
+int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const int64_t* ln_emb,
+                    int32_t n_bot, const int32_t* ln_bot, int32_t n_top, const int32_t* ln_top,
+                    int32_t dense_dim, int flags, float loss_threshold, uint64_t seed, orx_dlrm** out);
+int orx_dlrm_destroy(orx_dlrm* m);
+/* borrowed handle of a parameter: the combined embedding table, or Dense layer `layer`'s
+ * kernel [in, out] / bias [1, out] (Keras layout).  Owned by the model. */
+int orx_dlrm_param(orx_dlrm* m, int kind, int layer, orx_table** out);
+/* K train steps (DLRM.call + tape.gradient + apply_gradients).  dense [K*B, dense_dim] fp32,
+ * sparse [K*B, n_emb] int32 (id within its own table), label [K*B] fp32; host pointers unless
+ * ORX_IDS_DEVICE.  loss_out: host float[K] or NULL. */
+int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, const int32_t* sparse, const float* label,
+                  int64_t K, int64_t B, int flags, float* loss_out);
+/* DLRM.inference (dlrm.py:76-100): pred_out host/device float[B] */
+int orx_dlrm_inference(orx_dlrm* m, const float* dense, const int32_t* sparse, int64_t B, int flags, float* pred_out);
+
 /* ---- sharded building blocks (row-wise sharded tables, one rank per GPU;
  * the exchange itself is RCCL all-to-all driven by the host, see
  * openrec_amd/sharded.py).  No reference equivalent (the reference is single

@@ -15,6 +15,7 @@ ORX_SGD, ORX_ADAGRAD, ORX_ADAM = 0, 1, 2
 ORX_BPR, ORX_UCML = 0, 1
 ORX_GMF, ORX_WRMF = 0, 1
 ORX_IDS_DEVICE, ORX_HOGWILD, ORX_NO_L2 = 1, 2, 4
+ORX_DLRM_INTERACT_ITSELF, ORX_DLRM_SIGMOID_BOT, ORX_DLRM_SIGMOID_TOP, ORX_DLRM_LOSS_BCE, ORX_DLRM_REFERENCE_COMPAT = 1, 2, 4, 8, 16
 ORX_K_DEDUP, ORX_K_FUSED, ORX_K_REDUCE, ORX_K_SWEEP, ORX_K_CENSOR, ORX_K_POINT, ORX_K_DUPAPPLY, ORX_K_NUM = 0, 1, 2, 3, 4, 5, 6, 7
 KERNEL_NAMES = {ORX_K_DEDUP: "dedup", ORX_K_FUSED: "fused", ORX_K_REDUCE: "loss_reduce", ORX_K_SWEEP: "adam_sweep",
                 ORX_K_CENSOR: "censor", ORX_K_POINT: "pointwise", ORX_K_DUPAPPLY: "dup_apply"}
@@ -56,6 +57,11 @@ SIGNATURES = {
                                    c_float, c_float, c_int, _fp, _fp]),
     "orx_pointwise_loss": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, _ip, _fp, c_int64, c_float, c_float, c_int, _fp, _fp]),
     "orx_score_all_items": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, c_int64, _fp]),
+    "orx_dlrm_create": (c_int, [_p, c_int32, c_int32, _p, c_int32, _p, c_int32, _p, c_int32, c_int, c_float, c_uint64, _pp]),
+    "orx_dlrm_destroy": (c_int, [_p]),
+    "orx_dlrm_param": (c_int, [_p, c_int, c_int, _pp]),
+    "orx_dlrm_step": (c_int, [_p, _p, _fp, _ip, _fp, c_int64, c_int64, c_int, _fp]),
+    "orx_dlrm_inference": (c_int, [_p, _fp, _ip, c_int64, c_int, _fp]),
     "orx_gather_rows": (c_int, [_p, _p, _p, _ip, c_int64, _fp, c_int64]),
     "orx_pair_grads": (c_int, [_p, c_int, c_int32, _fp, _fp, _fp, c_int64, _ip, c_int64, c_int64, c_float, c_int,
                                _fp, _fp, _fp, c_int64, _p]),

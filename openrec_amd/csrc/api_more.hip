@@ -212,7 +212,8 @@ extern "C" int orx_pair_grads(orx_ctx* ctx, int model, int32_t D,
 extern "C" int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias,
                               const int32_t* ids, int64_t n, const float* grads, int64_t g_stride) {
     ORX_ARG(ctx && opt && t && (n == 0 || (ids && grads)), "orx_apply_rows: NULL argument");
-    ORX_ARG(opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD, "orx_apply_rows: only SGD and Adagrad are supported on sharded tables");
+    ORX_ARG(opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD || (opt->kind == ORX_ADAM && !bias),
+            "orx_apply_rows: SGD and Adagrad (and Adam without a bias column) are supported");
     ORX_ARG(g_stride >= t->dim + (bias ? 1 : 0), "orx_apply_rows: g_stride too small");
     ORX_ARG(!bias || (bias->dim == 1 && bias->rows == t->rows), "orx_apply_rows: bias must be [%lld, 1]", (long long)t->rows);
     if (n == 0) return ORX_OK;
@@ -223,6 +224,18 @@ extern "C" int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_tabl
     a.ids = ids; a.grads = grads; a.g_stride = g_stride; a.n = n; a.rows = t->rows; a.D = t->dim;
     a.lr = opt->lr; a.err = ctx->d_err;
     if (opt->kind == ORX_SGD) return orx_launch_apply_rows(ctx, ORX_SGD, false, a);
+    if (opt->kind == ORX_ADAM) {
+        // TF-2.0 sparse Adam: summed gradient rows + a dense-decay sweep of the whole table.
+        // The caller advances opt->t once per step (see dlrm.hip).
+        CHECK(orx_table_scratch(t));
+        OptSlots st;
+        CHECK(orx_opt_slots(opt, t, &st));
+        CHECK(orx_launch_rows_accum(ctx, t->gsum, ids, grads, g_stride, n, t->dim, t->rows));
+        const double b1 = opt->p0, b2 = opt->p1;
+        const double tt = (double)(opt->t > 0 ? opt->t : 1);
+        const float lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, tt)) / (1.0 - std::pow(b1, tt)));
+        return orx_launch_adam_sweep(ctx, t->w, st.s0, st.s1, t->gsum, t->rows * t->dim, lr_t, opt->p0, opt->p1, opt->p2);
+    }
 
     // Adagrad: dedup-sum semantics
     CHECK(orx_table_scratch(t));

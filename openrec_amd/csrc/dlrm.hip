@@ -1,0 +1,309 @@
+// DLRM model object and train step (C ABI: orx_dlrm_*).
+// Host-side sequencing of: combined-table embedding gather, bottom MLP, feature
+// interaction, top MLP, loss, full backward, sparse + dense optimizer apply.
+// Restates openrec/tf2/recommenders/dlrm.py:8-100 and tf2_examples/dlrm_criteo.py:42-48.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "orx_internal.h"
+
+#define CHECK(call)                                                                    \
+    do {                                                                               \
+        int _rc = (call);                                                              \
+        if (_rc != ORX_OK) return _rc;                                                 \
+    } while (0)
+
+struct DenseLayer {
+    int in = 0, out = 0, act = 0;       // act: 1 relu, 2 sigmoid
+    orx_table* W = nullptr;             // [in, out]
+    orx_table* b = nullptr;             // [1, out]
+};
+
+struct orx_dlrm {
+    orx_ctx* ctx = nullptr;
+    int m_spa = 0, n_emb = 0, dense_dim = 0, flags = 0;
+    float thr = 0.f;
+    std::vector<int64_t> ln_emb, offset;
+    int64_t* d_offset = nullptr;
+    int64_t* d_rows = nullptr;
+    orx_table* emb = nullptr;           // combined [sum(ln_emb), m_spa]
+    std::vector<DenseLayer> bot, top;
+    int F = 0, P = 0;
+    // activations / gradients, sized for `cap` samples
+    int64_t cap = 0;
+    float *d_dense = nullptr, *d_label = nullptr;
+    int32_t *d_sparse = nullptr, *d_idx = nullptr;
+    float *Z = nullptr, *dZ = nullptr, *R = nullptr;
+    std::vector<float*> bot_y, top_y;   // outputs of every layer (bot last layer lives in Z)
+    float *gA = nullptr, *gB = nullptr; // ping-pong gradient buffers [cap, maxwidth]
+    double* d_loss = nullptr;           // [Kcap]
+    int64_t loss_cap = 0;
+    int maxw = 0;
+};
+
+static int make_layers(orx_ctx* ctx, std::vector<DenseLayer>& L, int in, int n, const int32_t* units, int last_act, uint64_t seed) {
+    for (int l = 0; l < n; ++l) {
+        DenseLayer d;
+        d.in = in; d.out = units[l]; d.act = (l == n - 1) ? last_act : 1;
+        ORX_ARG(d.out > 0, "dlrm: layer width must be positive");
+        CHECK(orx_table_create(ctx, d.in, d.out, &d.W));
+        CHECK(orx_table_create(ctx, 1, d.out, &d.b));
+        const float lim = std::sqrt(6.0f / (float)(d.in + d.out));          // Keras glorot_uniform
+        CHECK(orx_table_init_uniform(d.W, -lim, lim, seed + 101 * (uint64_t)(l + 1)));
+        CHECK(orx_table_fill(d.b, 0.f));
+        L.push_back(d);
+        in = d.out;
+    }
+    return ORX_OK;
+}
+
+extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const int64_t* ln_emb,
+                               int32_t n_bot, const int32_t* ln_bot, int32_t n_top, const int32_t* ln_top,
+                               int32_t dense_dim, int flags, float loss_threshold, uint64_t seed, orx_dlrm** out) {
+    ORX_ARG(ctx && out && ln_emb && ln_bot && ln_top, "orx_dlrm_create: NULL argument");
+    ORX_ARG(m_spa > 0 && n_emb > 0 && n_bot > 0 && n_top > 0 && dense_dim > 0, "orx_dlrm_create: sizes must be positive");
+    ORX_ARG(ln_bot[n_bot - 1] == m_spa, "orx_dlrm_create: the bottom MLP must end at m_spa=%d (got %d)", m_spa, ln_bot[n_bot - 1]);
+    ORX_ARG(ln_top[n_top - 1] == 1, "orx_dlrm_create: the top MLP must end at 1 unit");
+    ORX_HIP(hipSetDevice(ctx->device));
+    orx_dlrm* m = new orx_dlrm();
+    m->ctx = ctx; m->m_spa = m_spa; m->n_emb = n_emb; m->dense_dim = dense_dim; m->flags = flags; m->thr = loss_threshold;
+    int64_t total = 0;
+    for (int f = 0; f < n_emb; ++f) {
+        ORX_ARG(ln_emb[f] > 0, "orx_dlrm_create: ln_emb[%d] must be positive", f);
+        m->ln_emb.push_back(ln_emb[f]); m->offset.push_back(total); total += ln_emb[f];
+    }
+    CHECK(orx_table_create(ctx, total, m_spa, &m->emb));
+    CHECK(orx_table_init_uniform(m->emb, -0.05f, 0.05f, seed));            // LatentFactor 'uniform' (dlrm.py:32-33)
+    ORX_HIP(hipMalloc((void**)&m->d_offset, sizeof(int64_t) * n_emb));
+    ORX_HIP(hipMalloc((void**)&m->d_rows, sizeof(int64_t) * n_emb));
+    ORX_HIP(hipMemcpy(m->d_offset, m->offset.data(), sizeof(int64_t) * n_emb, hipMemcpyHostToDevice));
+    ORX_HIP(hipMemcpy(m->d_rows, m->ln_emb.data(), sizeof(int64_t) * n_emb, hipMemcpyHostToDevice));
+    m->F = n_emb + 1;
+    const bool itself = flags & ORX_DLRM_INTERACT_ITSELF;
+    m->P = itself ? m->F * (m->F + 1) / 2 : m->F * (m->F - 1) / 2;
+    CHECK(make_layers(ctx, m->bot, dense_dim, n_bot, ln_bot, (flags & ORX_DLRM_SIGMOID_BOT) ? 2 : 1, seed + 7));
+    CHECK(make_layers(ctx, m->top, m_spa + m->P, n_top, ln_top, (flags & ORX_DLRM_SIGMOID_TOP) ? 2 : 1, seed + 13));
+    m->maxw = m_spa + m->P;
+    for (auto& d : m->bot) m->maxw = std::max(m->maxw, std::max(d.in, d.out));
+    for (auto& d : m->top) m->maxw = std::max(m->maxw, std::max(d.in, d.out));
+    *out = m;
+    return ORX_OK;
+}
+
+static void free_buffers(orx_dlrm* m) {
+    hipFree(m->d_dense); hipFree(m->d_label); hipFree(m->d_sparse); hipFree(m->d_idx);
+    hipFree(m->Z); hipFree(m->dZ); hipFree(m->R); hipFree(m->gA); hipFree(m->gB);
+    for (float* p : m->bot_y) hipFree(p);
+    for (float* p : m->top_y) hipFree(p);
+    m->bot_y.clear(); m->top_y.clear();
+    m->d_dense = m->d_label = m->Z = m->dZ = m->R = m->gA = m->gB = nullptr;
+    m->d_sparse = m->d_idx = nullptr;
+    m->cap = 0;
+}
+
+extern "C" int orx_dlrm_destroy(orx_dlrm* m) {
+    if (!m) return ORX_OK;
+    hipSetDevice(m->ctx->device);
+    hipStreamSynchronize(m->ctx->stream);
+    free_buffers(m);
+    hipFree(m->d_offset); hipFree(m->d_rows); hipFree(m->d_loss);
+    orx_table_destroy(m->emb);
+    for (auto& d : m->bot) { orx_table_destroy(d.W); orx_table_destroy(d.b); }
+    for (auto& d : m->top) { orx_table_destroy(d.W); orx_table_destroy(d.b); }
+    delete m;
+    return ORX_OK;
+}
+
+extern "C" int orx_dlrm_param(orx_dlrm* m, int kind, int layer, orx_table** out) {
+    ORX_ARG(m && out, "orx_dlrm_param: NULL argument");
+    if (kind == ORX_DLRM_EMB) { *out = m->emb; return ORX_OK; }
+    std::vector<DenseLayer>& L = (kind == ORX_DLRM_BOT_W || kind == ORX_DLRM_BOT_B) ? m->bot : m->top;
+    ORX_ARG(kind >= ORX_DLRM_BOT_W && kind <= ORX_DLRM_TOP_B, "orx_dlrm_param: unknown kind %d", kind);
+    ORX_ARG(layer >= 0 && layer < (int)L.size(), "orx_dlrm_param: layer %d out of range", layer);
+    *out = (kind == ORX_DLRM_BOT_W || kind == ORX_DLRM_TOP_W) ? L[layer].W : L[layer].b;
+    return ORX_OK;
+}
+
+static int ensure_buffers(orx_dlrm* m, int64_t B) {
+    if (B <= m->cap) return ORX_OK;
+    hipStreamSynchronize(m->ctx->stream);
+    free_buffers(m);
+    const size_t F = m->F, d = m->m_spa;
+    ORX_HIP(hipMalloc((void**)&m->d_dense, sizeof(float) * B * m->dense_dim));
+    ORX_HIP(hipMalloc((void**)&m->d_label, sizeof(float) * B));
+    ORX_HIP(hipMalloc((void**)&m->d_sparse, sizeof(int32_t) * B * m->n_emb));
+    ORX_HIP(hipMalloc((void**)&m->d_idx, sizeof(int32_t) * B * F));
+    ORX_HIP(hipMalloc((void**)&m->Z, sizeof(float) * B * F * d));
+    ORX_HIP(hipMalloc((void**)&m->dZ, sizeof(float) * B * F * d));
+    ORX_HIP(hipMalloc((void**)&m->R, sizeof(float) * B * (d + m->P)));
+    ORX_HIP(hipMalloc((void**)&m->gA, sizeof(float) * B * m->maxw));
+    ORX_HIP(hipMalloc((void**)&m->gB, sizeof(float) * B * m->maxw));
+    for (size_t l = 0; l + 1 < m->bot.size(); ++l) {          // the last bottom layer writes into Z[:, F-1, :]
+        float* p; ORX_HIP(hipMalloc((void**)&p, sizeof(float) * B * m->bot[l].out)); m->bot_y.push_back(p);
+    }
+    for (size_t l = 0; l < m->top.size(); ++l) {
+        float* p; ORX_HIP(hipMalloc((void**)&p, sizeof(float) * B * m->top[l].out)); m->top_y.push_back(p);
+    }
+    m->cap = B;
+    return ORX_OK;
+}
+
+struct Batch { const float* dense; const int32_t* sparse; const float* label; };
+
+// forward of one batch; leaves every activation in the model's buffers
+static int forward(orx_dlrm* m, const Batch& bt, int64_t B) {
+    orx_ctx* c = m->ctx;
+    const int F = m->F, d = m->m_spa;
+    const int compat = (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0, itself = (m->flags & ORX_DLRM_INTERACT_ITSELF) ? 1 : 0;
+    CHECK(orx_launch_dlrm_ids(c, bt.sparse, m->d_offset, m->d_rows, m->n_emb, B, m->d_idx));
+    // dlrm.py:83-85: the n_emb gathers = one gather on the combined table (dense slot skipped)
+    CHECK(orx_launch_gather(c, m->emb->w, nullptr, m->emb->rows, d, m->d_idx, B * F, m->Z, d, c->d_err, 1));
+    // dlrm.py:87: bottom MLP; its last layer writes straight into slot F-1 of Z
+    const float* x = bt.dense; int64_t ldx = m->dense_dim;
+    for (size_t l = 0; l < m->bot.size(); ++l) {
+        const DenseLayer& L = m->bot[l];
+        const bool last = l + 1 == m->bot.size();
+        float* y = last ? m->Z + (size_t)(F - 1) * d : m->bot_y[l];
+        const int64_t ldy = last ? (int64_t)F * d : L.out;
+        CHECK(orx_launch_gemm(c, x, ldx, 1, L.W->w, L.out, 1, y, ldy, L.b->w, (int)B, L.out, L.in, L.act));
+        x = y; ldx = ldy;
+    }
+    // dlrm.py:89-92: R = concat(dense_emb, interaction)
+    CHECK(orx_launch_interact(c, true, m->Z, nullptr, F, d, compat, itself, m->R, m->P, B));
+    x = m->R; ldx = d + m->P;
+    for (size_t l = 0; l < m->top.size(); ++l) {
+        const DenseLayer& L = m->top[l];
+        CHECK(orx_launch_gemm(c, x, ldx, 1, L.W->w, L.out, 1, m->top_y[l], L.out, L.b->w, (int)B, L.out, L.in, L.act));
+        x = m->top_y[l]; ldx = L.out;
+    }
+    return ORX_OK;
+}
+
+// dense optimizer rule on one parameter whose gradient sits in t->gsum
+static int dense_apply(orx_ctx* c, orx_opt* opt, orx_table* t, float lr_t) {
+    OptSlots s;
+    CHECK(orx_opt_slots(opt, t, &s));
+    const int64_t n = t->rows * t->dim;
+    if (opt->kind == ORX_ADAM) return orx_launch_adam_sweep(c, t->w, s.s0, s.s1, t->gsum, n, lr_t, opt->p0, opt->p1, opt->p2);
+    return orx_launch_dense_apply(c, t->w, s.s0, t->gsum, (int)n, opt->kind, opt->lr, opt->p1);
+}
+
+// backward through one MLP; dy [B, last.out] is consumed (in place), returns d(input) in *dx_out
+static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vector<const float*>& ins, const std::vector<int64_t>& ld_in,
+                        const std::vector<const float*>& outs, const std::vector<int64_t>& ld_out,
+                        float* dy, float* other, int64_t B, bool need_dx0, float** dx_out) {
+    orx_ctx* c = m->ctx;
+    for (int l = (int)L.size() - 1; l >= 0; --l) {
+        DenseLayer& D = L[l];
+        CHECK(orx_launch_act_bwd(c, dy, outs[l], ld_out[l], (int)B, D.out, D.act));
+        CHECK(orx_table_scratch(D.W)); CHECK(orx_table_scratch(D.b));
+        // gW [in, out] = X^T * dZ ; gb = colsum(dZ)
+        CHECK(orx_launch_gemm(c, ins[l], 1, ld_in[l], dy, D.out, 1, D.W->gsum, D.out, nullptr, D.in, D.out, (int)B, 0));
+        CHECK(orx_launch_colsum(c, dy, (int)B, D.out, D.b->gsum));
+        if (l > 0 || need_dx0) {
+            // dX [B, in] = dZ * W^T
+            CHECK(orx_launch_gemm(c, dy, D.out, 1, D.W->w, 1, D.out, other, D.in, nullptr, (int)B, D.in, D.out, 0));
+            float* t = dy; dy = other; other = t;
+        }
+    }
+    *dx_out = dy;
+    return ORX_OK;
+}
+
+static int stage(orx_dlrm* m, const float* dense, const int32_t* sparse, const float* label, int64_t B, int flags, Batch* out) {
+    if (flags & ORX_IDS_DEVICE) { out->dense = dense; out->sparse = sparse; out->label = label; return ORX_OK; }
+    hipStream_t s = m->ctx->stream;
+    ORX_HIP(hipMemcpyAsync(m->d_dense, dense, sizeof(float) * B * m->dense_dim, hipMemcpyHostToDevice, s));
+    ORX_HIP(hipMemcpyAsync(m->d_sparse, sparse, sizeof(int32_t) * B * m->n_emb, hipMemcpyHostToDevice, s));
+    if (label) ORX_HIP(hipMemcpyAsync(m->d_label, label, sizeof(float) * B, hipMemcpyHostToDevice, s));
+    out->dense = m->d_dense; out->sparse = m->d_sparse; out->label = m->d_label;
+    return ORX_OK;
+}
+
+extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, const int32_t* sparse, const float* label,
+                             int64_t K, int64_t B, int flags, float* loss_out) {
+    ORX_ARG(m && opt && (K == 0 || (dense && sparse && label)), "orx_dlrm_step: NULL argument");
+    ORX_ARG(K >= 0 && B > 0, "orx_dlrm_step: K must be >= 0 and B > 0");
+    if (K == 0) return ORX_OK;
+    orx_ctx* c = m->ctx;
+    ORX_HIP(hipSetDevice(c->device));
+    CHECK(ensure_buffers(m, B));
+    if (m->loss_cap < K) {
+        if (m->d_loss) ORX_HIP(hipFree(m->d_loss));
+        ORX_HIP(hipMalloc((void**)&m->d_loss, sizeof(double) * K)); m->loss_cap = K;
+    }
+    const int F = m->F, d = m->m_spa;
+    const int compat = (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0, itself = (m->flags & ORX_DLRM_INTERACT_ITSELF) ? 1 : 0;
+    for (int64_t s = 0; s < K; ++s) {
+        Batch bt;
+        CHECK(stage(m, dense + s * B * m->dense_dim, sparse + s * B * m->n_emb, label + s * B, B, flags, &bt));
+        CHECK(forward(m, bt, B));
+        float* pred = m->top_y.back();
+        // loss + dLoss/dP  (dlrm.py:72-73, :97-98)
+        CHECK(orx_launch_dlrm_loss(c, pred, bt.label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, m->d_loss + s));
+        // ---- top MLP backward
+        std::vector<const float*> ins, outs; std::vector<int64_t> ldi, ldo;
+        for (size_t l = 0; l < m->top.size(); ++l) {
+            ins.push_back(l == 0 ? m->R : m->top_y[l - 1]); ldi.push_back(l == 0 ? d + m->P : m->top[l - 1].out);
+            outs.push_back(m->top_y[l]); ldo.push_back(m->top[l].out);
+        }
+        float* dR = nullptr;
+        CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR));
+        // ---- interaction backward: dZ for every slot (slot F-1 = d dense_emb)
+        CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B));
+        // ---- bottom MLP backward from dZ[:, F-1, :]
+        float* dy = (dR == m->gA) ? m->gB : m->gA;
+        float* other = (dy == m->gA) ? m->gB : m->gA;
+        CHECK(orx_launch_copy2d(c, dy, d, m->dZ + (size_t)(F - 1) * d, (int64_t)F * d, (int)B, d));
+        ins.clear(); outs.clear(); ldi.clear(); ldo.clear();
+        for (size_t l = 0; l < m->bot.size(); ++l) {
+            const bool last = l + 1 == m->bot.size();
+            ins.push_back(l == 0 ? bt.dense : m->bot_y[l - 1]); ldi.push_back(l == 0 ? m->dense_dim : m->bot[l - 1].out);
+            outs.push_back(last ? m->Z + (size_t)(F - 1) * d : m->bot_y[l]); ldo.push_back(last ? (int64_t)F * d : m->bot[l].out);
+        }
+        float* dx0 = nullptr;
+        CHECK(mlp_backward(m, m->bot, ins, ldi, outs, ldo, dy, other, B, false, &dx0));
+        // ---- optimizer: one step counter for all variables (Keras `iterations`)
+        opt->t += 1;
+        float lr_t = 0.f;
+        if (opt->kind == ORX_ADAM) {
+            const double b1 = opt->p0, b2 = opt->p1;
+            lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, (double)opt->t)) / (1.0 - std::pow(b1, (double)opt->t)));
+        }
+        // sparse: per-occurrence rows dZ[b, f, :] onto the combined table (dense slot has id -1)
+        CHECK(orx_apply_rows(c, opt, m->emb, nullptr, m->d_idx, B * F, m->dZ, d));
+        for (auto& D : m->bot) { CHECK(dense_apply(c, opt, D.W, lr_t)); CHECK(dense_apply(c, opt, D.b, lr_t)); }
+        for (auto& D : m->top) { CHECK(dense_apply(c, opt, D.W, lr_t)); CHECK(dense_apply(c, opt, D.b, lr_t)); }
+    }
+    if (loss_out) {
+        std::vector<double> h((size_t)K);
+        ORX_HIP(hipMemcpyAsync(h.data(), m->d_loss, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
+        ORX_HIP(hipStreamSynchronize(c->stream));
+        for (int64_t s = 0; s < K; ++s) loss_out[s] = (float)h[s];
+    }
+    if (!(flags & ORX_IDS_DEVICE)) return orx_check_index_error(c);
+    return ORX_OK;
+}
+
+extern "C" int orx_dlrm_inference(orx_dlrm* m, const float* dense, const int32_t* sparse, int64_t B, int flags, float* pred_out) {
+    ORX_ARG(m && dense && sparse && pred_out && B > 0, "orx_dlrm_inference: bad argument");
+    orx_ctx* c = m->ctx;
+    ORX_HIP(hipSetDevice(c->device));
+    CHECK(ensure_buffers(m, B));
+    Batch bt;
+    CHECK(stage(m, dense, sparse, nullptr, B, flags, &bt));
+    CHECK(forward(m, bt, B));
+    float* pred = m->top_y.back();
+    if (m->thr > 0.f && m->thr < 1.f) {
+        if (m->loss_cap < 1) { ORX_HIP(hipMalloc((void**)&m->d_loss, sizeof(double))); m->loss_cap = 1; }
+        // clip only (label-free): reuse the loss kernel with y = pred, no gradient output
+        CHECK(orx_launch_dlrm_loss(c, pred, pred, B, 0, m->thr, nullptr, m->d_loss));
+    }
+    if (flags & ORX_IDS_DEVICE) {
+        ORX_HIP(hipMemcpyAsync(pred_out, pred, sizeof(float) * B, hipMemcpyDeviceToDevice, c->stream));
+        return ORX_OK;
+    }
+    ORX_HIP(hipMemcpyAsync(pred_out, pred, sizeof(float) * B, hipMemcpyDeviceToHost, c->stream));
+    return orx_check_index_error(c);
+}

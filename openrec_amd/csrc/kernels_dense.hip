@@ -1,0 +1,312 @@
+// Dense-side kernels of the DLRM step (recommenders/dlrm.py:63-100): fp32 GEMM on
+// the f32 MFMA (exact fp32: v_mfma_f32_16x16x4_f32 == an fmaf chain), bias/
+// activation epilogues, activation backward, column sums, the second-order
+// feature interaction (modules/second_order_feature_interaction.py:12-34,
+// forward and backward, with the reference's triangle bug as an option), the
+// loss (MSE / BCE on probabilities, Keras semantics) and index helpers.
+#include "orx_device.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------- GEMM ---
+// C[M,N] = act(A[M,K] * B[K,N] + bias[N]);  A(i,k) = A[i*sa0 + k*sa1],
+// B(k,j) = B[k*sb0 + j*sb1]  (all three MLP products -- X*W, dY*W^T, X^T*dY --
+// are expressed through the strides).  64x64 block tile, 4 wavefronts each
+// computing 32x32 as 2x2 MFMA 16x16x4 tiles, K staged through LDS 16 at a time.
+struct GemmArgs {
+    const float* A; int64_t sa0, sa1;
+    const float* B; int64_t sb0, sb1;
+    float* C; int64_t ldc;
+    const float* bias;
+    int M, N, K;
+    int act;                 // 0 none, 1 relu, 2 sigmoid
+};
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ float As[64][17];
+    __shared__ float Bs[16][65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm = blockIdx.y * 64, bn = blockIdx.x * 64;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc[i][j].x = acc[i][j].y = acc[i][j].z = acc[i][j].w = 0.0f; }
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = tid + 256 * r;
+            const int i = idx >> 4, k = idx & 15;
+            As[i][k] = (bm + i < g.M && k0 + k < g.K) ? g.A[(int64_t)(bm + i) * g.sa0 + (int64_t)(k0 + k) * g.sa1] : 0.0f;
+            const int kb = idx >> 6, j = idx & 63;
+            Bs[kb][j] = (k0 + kb < g.K && bn + j < g.N) ? g.B[(int64_t)(k0 + kb) * g.sb0 + (int64_t)(bn + j) * g.sb1] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4) {
+            float a[2], b[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[mi] = As[wm + mi * 16 + (lane & 15)][kk + (lane >> 4)];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[ni] = Bs[kk + (lane >> 4)][wn + ni * 16 + (lane & 15)];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = bm + wm + mi * 16 + (lane >> 4) * 4 + r;
+                const int col = bn + wn + ni * 16 + (lane & 15);
+                if (row < g.M && col < g.N) {
+                    float v = acc[mi][ni][r];
+                    if (g.bias) v += g.bias[col];
+                    if (g.act == 1) v = fmaxf(v, 0.0f);
+                    else if (g.act == 2) v = 1.0f / (1.0f + __expf(-v));
+                    g.C[(int64_t)row * g.ldc + col] = v;
+                }
+            }
+}
+
+int orx_launch_gemm(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
+                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act) {
+    if (M == 0 || N == 0) return ORX_OK;
+    GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act};
+    ORX_LAUNCH(ctx, gemm_f32_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0, g);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// dZ = dY * act'(Y), in place on dY.  Y may be strided (ldy), dY is contiguous [M,N].
+__global__ void act_bwd_kernel(float* dY, const float* Y, int64_t ldy, int M, int N, int act) {
+    const int64_t total = (int64_t)M * N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / N; const int c = (int)(i - r * N);
+        const float y = Y[r * ldy + c];
+        float d = dY[i];
+        if (act == 1) d = y > 0.0f ? d : 0.0f;
+        else if (act == 2) d = d * y * (1.0f - y);
+        dY[i] = d;
+    }
+}
+
+int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act) {
+    if (act == 0 || M == 0) return ORX_OK;
+    int64_t g = ((int64_t)M * N + 255) / 256; if (g > 8192) g = 8192;
+    ORX_LAUNCH(ctx, act_bwd_kernel, dim3((unsigned)g), dim3(256), 0, dY, Y, ldy, M, N, act);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// out[c] = sum_r X[r, c]   (bias gradient); one block per 64 columns
+__global__ __launch_bounds__(256) void colsum_kernel(const float* X, int M, int N, float* out) {
+    __shared__ float sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (c < N) for (int r = part; r < M; r += 4) s += X[(int64_t)r * N + c];
+    sh[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && c < N) out[c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+int orx_launch_colsum(orx_ctx* ctx, const float* X, int M, int N, float* out) {
+    ORX_LAUNCH(ctx, colsum_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, X, M, N, out);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// strided copy: dst[r, 0:n] = src[r*lds + 0:n]
+__global__ void copy2d_kernel(float* dst, int64_t ldd, const float* src, int64_t lds_, int M, int N) {
+    const int64_t total = (int64_t)M * N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / N; const int c = (int)(i - r * N);
+        dst[r * ldd + c] = src[r * lds_ + c];
+    }
+}
+
+int orx_launch_copy2d(orx_ctx* ctx, float* dst, int64_t ldd, const float* src, int64_t lds_, int M, int N) {
+    if (M == 0 || N == 0) return ORX_OK;
+    int64_t g = ((int64_t)M * N + 255) / 256; if (g > 8192) g = 8192;
+    ORX_LAUNCH(ctx, copy2d_kernel, dim3((unsigned)g), dim3(256), 0, dst, ldd, src, lds_, M, N);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// ------------------------------------------------------- feature interaction ---
+// Z [B, F, d] (slot F-1 = bottom-MLP output).  R [B, d + P]: R[:, 0:d] = Z[:, F-1, :],
+// R[:, d + k] = k-th selected element of Z Z^T in tf.boolean_mask (row-major) order.
+//   compat = 1 : lower triangle kept, (strictly) UPPER triangle selected -> zeros,
+//                only the diagonal survives when `itself`  (the reference's behaviour)
+//   compat = 0 : (strictly) lower triangle selected, values z_i . z_j
+__device__ __forceinline__ bool pair_selected(int i, int j, int compat, int itself) {
+    if (compat) return itself ? (j >= i) : (j > i);
+    return itself ? (j <= i) : (j < i);
+}
+
+__global__ __launch_bounds__(256) void interact_fwd_kernel(const float* Z, int F, int d, int compat, int itself,
+                                                           float* R, int P, int64_t B) {
+    extern __shared__ float zs[];            // [F][d]
+    const int64_t b = blockIdx.x;
+    if (b >= B) return;
+    const float* zb = Z + b * F * d;
+    for (int k = threadIdx.x; k < F * d; k += 256) zs[k] = zb[k];
+    __syncthreads();
+    float* rb = R + b * (d + P);
+    for (int k = threadIdx.x; k < d; k += 256) rb[k] = zs[(F - 1) * d + k];
+    for (int e = threadIdx.x; e < F * F; e += 256) {
+        const int i = e / F, j = e % F;
+        if (!pair_selected(i, j, compat, itself)) continue;
+        // rank of (i, j) among the selected elements in row-major order
+        int rank;
+        if (compat) rank = itself ? (i * F - i * (i - 1) / 2 + (j - i)) : (i * F - i * (i + 1) / 2 + (j - i - 1));
+        else rank = itself ? (i * (i + 1) / 2 + j) : (i * (i - 1) / 2 + j);
+        float v = 0.0f;
+        if (!compat || i == j) { for (int k = 0; k < d; ++k) v += zs[i * d + k] * zs[j * d + k]; }
+        rb[d + rank] = v;
+    }
+}
+
+// dZ [B, F, d] from dR [B, d + P]
+__global__ __launch_bounds__(256) void interact_bwd_kernel(const float* Z, const float* dR, int F, int d, int compat,
+                                                           int itself, float* dZ, int P, int64_t B) {
+    extern __shared__ float sm[];            // zs [F][d], gs [F][F]
+    float* zs = sm;
+    float* gs = sm + F * d;
+    const int64_t b = blockIdx.x;
+    if (b >= B) return;
+    const float* zb = Z + b * F * d;
+    const float* rb = dR + b * (d + P);
+    for (int k = threadIdx.x; k < F * d; k += 256) zs[k] = zb[k];
+    for (int e = threadIdx.x; e < F * F; e += 256) {
+        const int i = e / F, j = e % F;
+        float g = 0.0f;
+        if (pair_selected(i, j, compat, itself) && (!compat || i == j)) {
+            int rank;
+            if (compat) rank = itself ? (i * F - i * (i - 1) / 2 + (j - i)) : (i * F - i * (i + 1) / 2 + (j - i - 1));
+            else rank = itself ? (i * (i + 1) / 2 + j) : (i * (i - 1) / 2 + j);
+            g = rb[d + rank];
+        }
+        gs[e] = g;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < F * d; e += 256) {
+        const int i = e / d, k = e % d;
+        float acc = (i == F - 1) ? rb[k] : 0.0f;
+        for (int j = 0; j < F; ++j) acc += (gs[i * F + j] + gs[j * F + i]) * zs[j * d + k];   // d(z_i.z_j): both orders
+        dZ[b * F * d + e] = acc;
+    }
+}
+
+int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
+                        float* out, int P, int64_t B) {
+    if (B == 0) return ORX_OK;
+    if (fwd) ORX_LAUNCH(ctx, interact_fwd_kernel, dim3((unsigned)B), dim3(256), (size_t)F * d * sizeof(float), Z, F, d, compat, itself, out, P, B);
+    else ORX_LAUNCH(ctx, interact_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(F * d + F * F) * sizeof(float), Z, dR, F, d, compat, itself, out, P, B);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// ------------------------------------------------------------------- loss ---
+// pred [B] = (clipped) top-MLP output; writes loss (fp64) and dP [B] = dLoss/d(pre-clip p).
+__global__ __launch_bounds__(1024) void dlrm_loss_kernel(float* P, const float* y, int64_t B, int bce, float thr,
+                                                         float* dP, double* loss_out) {
+    __shared__ double sh[16];
+    double s = 0.0;
+    const float invB = 1.0f / (float)B;
+    for (int64_t i = threadIdx.x; i < B; i += 1024) {
+        float p = P[i];
+        float mask = 1.0f;
+        if (thr > 0.0f && thr < 1.0f) {                         // dlrm.py:97-98
+            mask = (p >= thr && p <= 1.0f - thr) ? 1.0f : 0.0f;
+            p = fminf(fmaxf(p, thr), 1.0f - thr);
+            P[i] = p;
+        }
+        const float t = y[i];
+        float g;
+        if (!bce) {                                             // keras.losses.MeanSquaredError
+            const float r = t - p;
+            s += (double)(r * r);
+            g = 2.0f * (p - t) * invB;
+        } else {                                                // keras.losses.BinaryCrossentropy (probabilities)
+            const float eps = 1e-7f;
+            const float pc = fminf(fmaxf(p, eps), 1.0f - eps);
+            s += -(double)(t * logf(pc + eps) + (1.0f - t) * logf(1.0f - pc + eps));
+            const float inside = (p >= eps && p <= 1.0f - eps) ? 1.0f : 0.0f;
+            g = -(t / (pc + eps) - (1.0f - t) / (1.0f - pc + eps)) * inside * invB;
+        }
+        if (dP) dP[i] = g * mask;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += sh[k];
+        loss_out[0] = t / (double)B;
+    }
+}
+
+int orx_launch_dlrm_loss(orx_ctx* ctx, float* P, const float* y, int64_t B, int bce, float thr, float* dP, double* loss_out) {
+    ORX_LAUNCH(ctx, dlrm_loss_kernel, dim3(1), dim3(1024), 0, P, y, B, bce, thr, dP, loss_out);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// ---------------------------------------------------------------- id helper ---
+// Row ids into the COMBINED embedding table: idx[b*F + f] = offset[f] + sparse[b, f]
+// (f < F-1), -1 for the dense slot f = F-1 and for out-of-range ids (flagged).
+__global__ void dlrm_ids_kernel(const int32_t* sparse, const int64_t* offset, const int64_t* rows, int nf, int64_t B,
+                                int32_t* idx, int* err) {
+    const int F = nf + 1;
+    const int64_t total = B * F;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t b = i / F; const int f = (int)(i - b * F);
+        int32_t v = -1;
+        if (f < nf) {
+            const int s = sparse[b * nf + f];
+            if ((uint32_t)s >= (uint64_t)rows[f]) *err = 1; else v = (int32_t)(offset[f] + s);
+        }
+        idx[i] = v;
+    }
+}
+
+int orx_launch_dlrm_ids(orx_ctx* ctx, const int32_t* sparse, const int64_t* offset, const int64_t* rows, int nf, int64_t B,
+                        int32_t* idx) {
+    int64_t g = (B * (nf + 1) + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1;
+    ORX_LAUNCH(ctx, dlrm_ids_kernel, dim3((unsigned)g), dim3(256), 0, sparse, offset, rows, nf, B, idx, ctx->d_err);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// sparse gradient rows -> gsum (Adam on sharded/DLRM tables: accumulate, the dense sweep follows)
+__global__ void rows_accum_kernel(float* G, const int32_t* ids, const float* grads, int64_t g_stride, int64_t n, int D, int64_t rows, int* err) {
+    const int64_t total = n * D;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t k = i / D; const int e = (int)(i - k * D);
+        const int r = ids[k];
+        if (r < 0) continue;
+        if ((int64_t)r >= rows) { *err = 1; continue; }
+        unsafeAtomicAdd(G + (size_t)r * D + e, grads[k * g_stride + e]);
+    }
+}
+
+int orx_launch_rows_accum(orx_ctx* ctx, float* G, const int32_t* ids, const float* grads, int64_t g_stride, int64_t n, int D, int64_t rows) {
+    if (n == 0) return ORX_OK;
+    int64_t g = (n * D + 255) / 256; if (g > 65536) g = 65536;
+    ORX_LAUNCH(ctx, rows_accum_kernel, dim3((unsigned)g), dim3(256), 0, G, ids, grads, g_stride, n, D, rows, ctx->d_err);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}

@@ -277,3 +277,74 @@ def score_all_items(kind, user, item, bias, uid, w=None):
     check(lib.orx_score_all_items(user.ctx._h, k, user._h, item._h, bias._h, w._h if w is not None else None,
                                   ptr, n, out.ctypes.data))
     return out
+
+
+class _BorrowedTable(Table):
+    """A table handle owned by another object (e.g. a DLRM model's parameter)."""
+
+    def __init__(self, ctx, handle, owner):
+        self.ctx, self._lib, self._h = ctx, ctx._lib, handle
+        self.rows, self.dim = int(self._lib.orx_table_rows(handle)), int(self._lib.orx_table_dim(handle))
+        self._keepalive = (owner, ctx)
+
+
+class DLRMModel:
+    """Device-side DLRM (recommenders/dlrm.py:6-100): combined embedding table,
+    bottom / top MLPs, feature interaction, loss; `step` = forward + backward +
+    optimizer apply of tf2_examples/dlrm_criteo.py:42-48."""
+
+    def __init__(self, m_spa, ln_emb, ln_bot, ln_top, dense_dim, arch_interaction_itself=False, sigmoid_bot=False,
+                 sigmoid_top=True, loss_func="mse", loss_threshold=0.0, reference_compat=True, seed=0, ctx=None):
+        self.ctx = ctx or default_context()
+        lib = self._lib = self.ctx._lib
+        self.m_spa, self.ln_emb, self.ln_bot, self.ln_top = int(m_spa), [int(x) for x in ln_emb], list(ln_bot), list(ln_top)
+        self.dense_dim = int(dense_dim)
+        flags = ((_ffi.ORX_DLRM_INTERACT_ITSELF if arch_interaction_itself else 0)
+                 | (_ffi.ORX_DLRM_SIGMOID_BOT if sigmoid_bot else 0) | (_ffi.ORX_DLRM_SIGMOID_TOP if sigmoid_top else 0)
+                 | (_ffi.ORX_DLRM_LOSS_BCE if loss_func == "bce" else 0)
+                 | (_ffi.ORX_DLRM_REFERENCE_COMPAT if reference_compat else 0))
+        if loss_func not in ("mse", "bce"):
+            raise ValueError("loss_func=%s is not supported" % loss_func)          # dlrm.py:56-61
+        emb = (ctypes.c_int64 * len(self.ln_emb))(*self.ln_emb)
+        bot = (ctypes.c_int32 * len(ln_bot))(*ln_bot)
+        top = (ctypes.c_int32 * len(ln_top))(*ln_top)
+        h = c_void_p()
+        check(lib.orx_dlrm_create(self.ctx._h, self.m_spa, len(self.ln_emb), ctypes.cast(emb, c_void_p),
+                                  len(ln_bot), ctypes.cast(bot, c_void_p), len(ln_top), ctypes.cast(top, c_void_p),
+                                  self.dense_dim, flags, float(loss_threshold), int(seed), byref(h)))
+        self._h = h
+        self._fin = weakref.finalize(self, lib.orx_dlrm_destroy, h)
+        self.offsets = np.concatenate([[0], np.cumsum(self.ln_emb)[:-1]]).astype(np.int64)
+
+    def param(self, kind, layer=0):
+        k = {"emb": 0, "bot_w": 1, "bot_b": 2, "top_w": 3, "top_b": 4}[kind]
+        h = c_void_p()
+        check(self._lib.orx_dlrm_param(self._h, k, int(layer), byref(h)))
+        return _BorrowedTable(self.ctx, h, self)
+
+    def emb_table(self, f):
+        """numpy view helper: rows of embedding table f inside the combined table"""
+        return int(self.offsets[f]), self.ln_emb[f]
+
+    @staticmethod
+    def _host(x, dtype):
+        if hasattr(x, "numpy") and not isinstance(x, np.ndarray):
+            x = x.numpy()
+        return np.ascontiguousarray(x, dtype=dtype)
+
+    def step(self, opt, dense, sparse, label, K=1, want_loss=True):
+        d, s, y = self._host(dense, np.float32), self._host(sparse, np.int32), self._host(label, np.float32)
+        B = y.size // K
+        assert d.size == K * B * self.dense_dim and s.size == K * B * len(self.ln_emb)
+        loss = np.empty(K, np.float32) if want_loss else None
+        check(self._lib.orx_dlrm_step(self._h, opt._h, d.ctypes.data, s.ctypes.data, y.ctypes.data, K, B, 0,
+                                      loss.ctypes.data if want_loss else None))
+        opt._tables.append(self)
+        return loss
+
+    def inference(self, dense, sparse):
+        d, s = self._host(dense, np.float32), self._host(sparse, np.int32)
+        B = d.size // self.dense_dim
+        out = np.empty(B, np.float32)
+        check(self._lib.orx_dlrm_inference(self._h, d.ctypes.data, s.ctypes.data, B, 0, out.ctypes.data))
+        return out

@@ -1,0 +1,74 @@
+"""DLRM (openrec/tf2/recommenders/dlrm.py:6-100): same constructor arguments,
+`__call__(dense_features, sparse_features, label) -> loss` and
+`inference(dense_features, sparse_features) -> [B]`.
+
+`reference_compat` (an extra keyword, default True) keeps the reference's
+feature-interaction behaviour bit for bit -- including the triangle bug that
+makes the interaction output zero; set it to False for the
+evidently intended pairwise dot products."""
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+
+from ... import runtime as rt
+from .._lazy import LazyScalar, PendingStep, active_tape
+from ..modules.latent_factor import Variable
+
+
+class DLRM:
+
+    def __init__(self, m_spa, ln_emb, ln_bot, ln_top, arch_interaction_op='dot', arch_interaction_itself=False,
+                 sigmoid_bot=False, sigmoid_top=True, loss_func='mse', loss_threshold=0.0,
+                 reference_compat=True, dense_dim=13, ctx=None, seed=0):
+        if arch_interaction_op != 'dot':
+            # dlrm.py:45 reads self._arch_interaction_op, which is never assigned: every value other
+            # than 'dot' raises AttributeError in the reference
+            raise AttributeError("'DLRM' object has no attribute '_arch_interaction_op'")
+        if loss_func not in ('mse', 'bce'):
+            sys.exit("ERROR: loss_func=" + loss_func + " is not supported")       # dlrm.py:56-61
+        self._model = rt.DLRMModel(m_spa, ln_emb, ln_bot, ln_top, dense_dim, arch_interaction_itself, sigmoid_bot,
+                                   sigmoid_top, loss_func, loss_threshold, reference_compat, seed, ctx)
+
+    @property
+    def trainable_variables(self):
+        m = self._model
+        out = [Variable(m.param("emb"), "latent_factors/embeddings")]
+        for nm, n in (("bot", len(m.ln_bot)), ("top", len(m.ln_top))):
+            for l in range(n):
+                out.append(Variable(m.param(nm + "_w", l), f"mlp_{nm}/dense_{l}/kernel"))
+                out.append(Variable(m.param(nm + "_b", l), f"mlp_{nm}/dense_{l}/bias"))
+        return out
+
+    def __call__(self, dense_features, sparse_features, label):
+        m = self._model
+        d, s, y = (np.asarray(x.numpy() if hasattr(x, "numpy") else x) for x in (dense_features, sparse_features, label))
+
+        def run_forward():
+            p = m.inference(d, s)
+            yy = y.astype(np.float32).reshape(-1)
+            return (float(np.mean((yy - p) ** 2)), 0.0)        # only used outside a tape (mse); see inference
+
+        def run_train(optimizer, no_l2):
+            loss = m.step(optimizer, d, s, y, K=1)
+            return float(loss[0]), 0.0
+
+        step = PendingStep(self, run_forward, run_train)
+        step.user_latent_factor = None
+        tape = active_tape()
+        if tape is not None:
+            tape.record(step)
+        return LazyScalar(step, 0)
+
+    call = __call__
+
+    # `optimizer.apply_gradients` looks the context up through this attribute
+    @property
+    def user_latent_factor(self):
+        class _T:
+            table = self._model.param("emb")
+        return _T
+
+    def inference(self, dense_features, sparse_features):
+        return self._model.inference(dense_features, sparse_features)

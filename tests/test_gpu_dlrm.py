@@ -1,0 +1,110 @@
+"""GPU parity of the DLRM train step against the torch-autograd golden fixtures
+and the NumPy oracle."""
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden, rel_err, OPT_KW
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(m_spa=4, ln_emb=[7, 5, 11], ln_bot=[8, 4], ln_top=[16, 8, 1], dense_dim=13)
+KW = {
+    "compat": dict(reference_compat=True),
+    "compatself": dict(reference_compat=True, arch_interaction_itself=True),
+    "intended": dict(reference_compat=False),
+    "intendedbce": dict(reference_compat=False, loss_func="bce", loss_threshold=0.05, sigmoid_bot=True),
+}
+
+
+def _opt(rt, kind):
+    kw = OPT_KW[kind]
+    if kind == "sgd":
+        return rt.Optimizer.sgd(kw["lr"])
+    if kind == "adagrad":
+        return rt.Optimizer.adagrad(kw["lr"], kw["initial_accumulator_value"], kw["epsilon"])
+    return rt.Optimizer.adam(kw["lr"], kw["beta_1"], kw["beta_2"], kw["epsilon"])
+
+
+def _load(m, g, prefix="in_"):
+    emb = np.concatenate([g[f"{prefix}emb{f}"] for f in range(len(CFG["ln_emb"]))])
+    m.param("emb").write(emb)
+    for nm, n in (("bot", len(CFG["ln_bot"])), ("top", len(CFG["ln_top"]))):
+        for l in range(n):
+            m.param(nm + "_w", l).write(g[f"{prefix}{nm}{l}W"])
+            m.param(nm + "_b", l).write(g[f"{prefix}{nm}{l}b"].reshape(1, -1))
+
+
+@pytest.mark.parametrize("fname", golden_files("dlrm"))
+def test_dlrm_golden(fname):
+    from openrec_amd import runtime as rt
+    _, name, optkind = fname[:-4].split("_")
+    g = load_golden(fname)
+    m = rt.DLRMModel(**CFG, **KW[name])
+    _load(m, g)
+    opt = _opt(rt, optkind)
+    losses = [m.step(opt, g["dense"], g["sparse"], g["label"])[0] for _ in range(2)]
+    tol = 2e-5
+    assert rel_err(losses, g["losses"]) < tol
+    emb = m.param("emb").read()
+    ref = np.concatenate([g[f"out_emb{f}"] for f in range(3)])
+    assert rel_err(emb, ref) < 5 * tol
+    for nm, n in (("bot", 2), ("top", 3)):
+        for l in range(n):
+            assert rel_err(m.param(nm + "_w", l).read(), g[f"out_{nm}{l}W"]) < 5 * tol, (nm, l)
+            assert rel_err(m.param(nm + "_b", l).read().reshape(-1), g[f"out_{nm}{l}b"]) < 5 * tol, (nm, l)
+    if name == "compat":      # the reference's bug: embeddings never move
+        assert np.array_equal(emb, np.concatenate([g[f"in_emb{f}"] for f in range(3)]))
+
+
+@pytest.mark.parametrize("compat", [True, False])
+def test_dlrm_example_shapes_vs_oracle(compat):
+    """tf2_examples/dlrm_criteo.py shapes: dim 4, bottom [8,4], top [128,64,1], 26 tables, batch 1024."""
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    from oracle.dlrm_oracle import DLRMOracle
+    rng = np.random.default_rng(0)
+    ln_emb = [int(x) for x in rng.integers(3, 2000, 26)]
+    cfg = dict(m_spa=4, ln_emb=ln_emb, ln_bot=[8, 4], ln_top=[128, 64, 1], dense_dim=13)
+    o = DLRMOracle(dtype=np.float32, seed=2, reference_compat=compat, **cfg)
+    m = rt.DLRMModel(reference_compat=compat, **cfg)
+    m.param("emb").write(np.concatenate(o.emb))
+    for nm, layers in (("bot", o.bot), ("top", o.top)):
+        for l, (W, b) in enumerate(layers):
+            m.param(nm + "_w", l).write(W); m.param(nm + "_b", l).write(b.reshape(1, -1))
+    B = 1024
+    dense = np.log1p(rng.integers(0, 100, (B, 13))).astype(np.float32)
+    sparse = np.stack([rng.integers(0, n, B) for n in ln_emb], 1).astype(np.int32)
+    label = (rng.uniform(size=B) < 0.25).astype(np.float32)
+    assert rel_err(m.inference(dense, sparse), o.inference(dense, sparse)) < 1e-5
+    opt, oo = rt.Optimizer.adagrad(0.05, 0.1, 1e-7), orc.Adagrad(0.05, 0.1, 1e-7)
+    for s in range(2):
+        l = m.step(opt, dense, sparse, label)[0]
+        lr = o.step(dense, sparse, label, oo)
+        assert abs(l - lr) <= 2e-5 * abs(lr)
+    assert rel_err(m.param("emb").read(), np.concatenate(o.emb)) < 1e-4
+    assert rel_err(m.param("top_w", 0).read(), o.top[0][0]) < 1e-4
+    assert rel_err(m.param("bot_w", 0).read(), o.bot[0][0]) < 1e-4
+
+
+def test_dlrm_api_surface():
+    from openrec_amd.tf2.recommenders import DLRM
+    from openrec_amd.tf2.compat import tf, optimizers
+    rng = np.random.default_rng(1)
+    counts = [10, 20, 30]
+    dlrm_model = DLRM(m_spa=4, ln_emb=counts, ln_bot=[8, 4], ln_top=[128, 64, 1])
+    optimizer = optimizers.Adam()
+    dense = rng.uniform(0, 3, (64, 13)).astype(np.float32)
+    sparse = np.stack([rng.integers(0, n, 64) for n in counts], 1).astype(np.int32)
+    label = (rng.uniform(size=64) < 0.5).astype(np.float32)
+    first = None
+    for it in range(30):
+        with tf.GradientTape() as tape:
+            loss_value = dlrm_model(dense, sparse, label)
+        gradients = tape.gradient(loss_value, dlrm_model.trainable_variables)
+        optimizer.apply_gradients(zip(gradients, dlrm_model.trainable_variables))
+        first = float(loss_value) if first is None else first
+    assert float(loss_value) < first                       # it trains
+    pred = dlrm_model.inference(dense, sparse)
+    assert pred.shape == (64,) and (pred > 0).all() and (pred < 1).all()
+    with pytest.raises(AttributeError):
+        DLRM(m_spa=4, ln_emb=counts, ln_bot=[8, 4], ln_top=[8, 1], arch_interaction_op='cat')
