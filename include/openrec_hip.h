@@ -220,6 +220,27 @@ int orx_pair_grads(orx_ctx* ctx, int model, int32_t D,
 int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias,
                    const int32_t* ids, int64_t n, const float* grads, int64_t g_stride);
 
+/* Device-side exchange plan of the sharded step (openrec_amd/sharded.py): fixed-capacity
+ * buckets, no host synchronization.  Row r of a table lives on rank r % world at local
+ * index r / world.  `overflow` is a device int set to 1 when a bucket was full.
+ *   shard_route   : triplets -> send[world*cap][3] (bucket = uid % world); fills unused slots with -1
+ *   shard_request : received triplets [T][3] (u < 0 = empty) -> item-id requests
+ *                   send_ids[world*cap] (bucket = id % world, -1 unused), slot[2T] (where the p / n
+ *                   request of triplet t went, -1 if none) and u_loc[T] (local user row or -1)
+ *   shard_localize: out[i] = ids[i] / world (or -1)
+ *   shard_grads   : user rows from the local shard + received item rows [world*cap][DS] ->
+ *                   gu[T][D] and the item-row gradients written in place into send_g at the slots
+ *                   of their requests; adds the (loss, l2_loss) contribution to loss_l2_accum[2] */
+int orx_shard_route(orx_ctx* ctx, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t B,
+                    int64_t users_global, int64_t items_global, int32_t world, int32_t cap,
+                    int32_t* send, int32_t* counters, int32_t* overflow);
+int orx_shard_request(orx_ctx* ctx, const int32_t* trip, int64_t T, int32_t world, int32_t cap,
+                      int32_t* send_ids, int32_t* slot, int32_t* u_loc, int32_t* counters, int32_t* overflow);
+int orx_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int32_t world, int32_t* out);
+int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const float* rows_in, const int32_t* u_loc,
+                    const int32_t* slot, int64_t T, int64_t row_stride, int64_t B_global, float margin, int flags,
+                    float* gu, float* send_g, double* loss_l2_accum);
+
 /* ---- device-time sampling of the kernels (HIP events on the ctx stream) --- */
 int orx_prof_enable(orx_ctx* ctx, int on);
 int orx_prof_reset(orx_ctx* ctx);

@@ -267,3 +267,61 @@ extern "C" int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_tabl
     pa.B = n; pa.D = t->dim; pa.lr = opt->lr; pa.eps = opt->p1;
     return orx_launch_dup_apply(ctx, ORX_ADAGRAD, pa);
 }
+
+// ------------------------------------------------- device-side exchange plan ---
+extern "C" int orx_shard_route(orx_ctx* ctx, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t B,
+                               int64_t users_global, int64_t items_global, int32_t world, int32_t cap,
+                               int32_t* send, int32_t* counters, int32_t* overflow) {
+    ORX_ARG(ctx && uid && pid && nid && send && counters && overflow, "orx_shard_route: NULL argument");
+    ORX_ARG(world >= 1 && world <= 64 && cap >= 1, "orx_shard_route: world must be in [1, 64] and cap positive");
+    ORX_HIP(hipSetDevice(ctx->device));
+    ORX_HIP(hipMemsetAsync(send, 0xFF, (size_t)world * cap * 3 * sizeof(int32_t), ctx->stream));
+    ORX_HIP(hipMemsetAsync(counters, 0, (size_t)world * sizeof(int32_t), ctx->stream));
+    RouteArgs a;
+    memset(&a, 0, sizeof(a));
+    a.uid = uid; a.pid = pid; a.nid = nid; a.B = B; a.world = world; a.cap = cap;
+    a.send = send; a.counters = counters; a.overflow = overflow; a.err = ctx->d_err;
+    a.NU = users_global; a.NI = items_global;
+    return orx_launch_shard_route(ctx, a);
+}
+
+extern "C" int orx_shard_request(orx_ctx* ctx, const int32_t* trip, int64_t T, int32_t world, int32_t cap,
+                                 int32_t* send_ids, int32_t* slot, int32_t* u_loc, int32_t* counters, int32_t* overflow) {
+    ORX_ARG(ctx && trip && send_ids && slot && u_loc && counters && overflow, "orx_shard_request: NULL argument");
+    ORX_ARG(world >= 1 && world <= 64 && cap >= 1, "orx_shard_request: world must be in [1, 64] and cap positive");
+    ORX_HIP(hipSetDevice(ctx->device));
+    ORX_HIP(hipMemsetAsync(send_ids, 0xFF, (size_t)world * cap * sizeof(int32_t), ctx->stream));
+    ORX_HIP(hipMemsetAsync(counters, 0, (size_t)world * sizeof(int32_t), ctx->stream));
+    RequestArgs a;
+    memset(&a, 0, sizeof(a));
+    a.trip = trip; a.T = T; a.world = world; a.cap = cap;
+    a.send_ids = send_ids; a.slot = slot; a.u_loc = u_loc; a.counters = counters; a.overflow = overflow;
+    return orx_launch_shard_request(ctx, a);
+}
+
+extern "C" int orx_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int32_t world, int32_t* out) {
+    ORX_ARG(ctx && (n == 0 || (ids && out)) && world >= 1, "orx_shard_localize: bad argument");
+    ORX_HIP(hipSetDevice(ctx->device));
+    return orx_launch_shard_localize(ctx, ids, n, world, out);
+}
+
+extern "C" int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const float* rows_in, const int32_t* u_loc,
+                               const int32_t* slot, int64_t T, int64_t row_stride, int64_t B_global, float margin, int flags,
+                               float* gu, float* send_g, double* loss_l2_accum) {
+    ORX_ARG(ctx && user && rows_in && u_loc && slot && gu && send_g, "orx_shard_grads: NULL argument");
+    ORX_ARG(model == ORX_BPR || model == ORX_UCML, "orx_shard_grads: unknown model %d", model);
+    ORX_ARG(row_stride > user->dim && B_global > 0, "orx_shard_grads: row_stride must leave room for the bias column");
+    if (T == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(ctx->device));
+    ShardGradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.U = user->w; a.rows_in = rows_in; a.u_loc = u_loc; a.slot = slot; a.gu = gu; a.send_g = send_g;
+    a.T = T; a.D = user->dim; a.DS = (int)row_stride;
+    a.invB = 1.0f / (float)B_global; a.margin = margin; a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f;
+    ENSURE(ctx->d_partial, ctx->d_partial_cap, (size_t)(T + 4) * 2 * sizeof(float));
+    a.partial = ctx->d_partial;
+    int nw = 0;
+    CHECK(orx_launch_shard_grads(ctx, model, a, &nw));
+    if (loss_l2_accum) CHECK(orx_launch_loss_accumulate(ctx, ctx->d_partial, nw, loss_l2_accum));
+    return ORX_OK;
+}

@@ -212,3 +212,152 @@ int orx_launch_loss_accumulate(orx_ctx* ctx, const float* partial, int nwaves, d
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
+
+// =====================================================================
+// Device-side exchange plan (no host synchronization, fixed-capacity buckets)
+// =====================================================================
+// Bucket assignment: every element picks its destination rank and takes the next
+// free slot of that destination's bucket.  Slots are claimed with one atomic per
+// (wavefront, destination): ballot + popcount, so the counters see <= world
+// atomics per wavefront.  The order inside a bucket is arbitrary (it only
+// changes fp32 summation order downstream).
+__device__ __forceinline__ int claim_slot(int dest, bool active, int world, int* counters) {
+    int slot = -1;
+    const int lane = threadIdx.x & 63;
+    for (int k = 0; k < world; ++k) {
+        const unsigned long long m = __ballot(active && dest == k);
+        if (m == 0ull) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(counters + k, __popcll(m));
+        base = __shfl(base, leader);
+        if (active && dest == k) slot = base + __popcll(m & ((1ull << lane) - 1ull));
+    }
+    return slot;
+}
+
+
+// 1. route each triplet to the owner of its user row (rank = uid % world)
+__global__ __launch_bounds__(256) void shard_route_kernel(RouteArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = t < a.B;
+    int u = 0, p = 0, n = 0;
+    if (active) {
+        u = a.uid[t]; p = a.pid[t]; n = a.nid[t];
+        if (!(id_ok(u, a.NU) && id_ok(p, a.NI) && id_ok(n, a.NI))) { *a.err = 1; active = false; }
+    }
+    const int dest = active ? u % a.world : 0;
+    const int slot = claim_slot(dest, active, a.world, a.counters);
+    if (!active) return;
+    if (slot >= a.cap) { *a.overflow = 1; return; }
+    int32_t* o = a.send + ((int64_t)dest * a.cap + slot) * 3;
+    o[0] = u; o[1] = p; o[2] = n;
+}
+
+
+// 2. request the two item rows of every live triplet from their owners (rank = id % world)
+__global__ __launch_bounds__(256) void shard_request_kernel(RequestArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inb = t < a.T;
+    int u = -1, p = 0, n = 0;
+    if (inb) { u = a.trip[3 * t]; p = a.trip[3 * t + 1]; n = a.trip[3 * t + 2]; }
+    const bool live = inb && u >= 0;
+    const int sp = claim_slot(live ? p % a.world : 0, live, a.world, a.counters);
+    const int sn = claim_slot(live ? n % a.world : 0, live, a.world, a.counters);
+    if (!inb) return;
+    int gp = -1, gn = -1;
+    if (live) {
+        if (sp < a.cap) { gp = (p % a.world) * a.cap + sp; a.send_ids[gp] = p; } else *a.overflow = 1;
+        if (sn < a.cap) { gn = (n % a.world) * a.cap + sn; a.send_ids[gn] = n; } else *a.overflow = 1;
+    }
+    a.slot[t] = gp; a.slot[a.T + t] = gn;
+    a.u_loc[t] = (live && gp >= 0 && gn >= 0) ? u / a.world : -1;
+}
+
+// local row ids of a received id list: id / world (or -1)
+__global__ void shard_localize_kernel(const int32_t* ids, int64_t n, int world, int32_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int v = ids[i]; out[i] = v >= 0 ? v / world : -1; }
+}
+
+
+// 4. per live triplet: user row straight from the local shard, item rows from the receive
+// buffer; gradients of the item rows go straight into the send buffer of the return trip.
+template <int LPR, int MODEL>
+__global__ __launch_bounds__(256) void shard_grads_kernel(ShardGradArgs a) {
+    constexpr int TPW = 64 / LPR;
+    constexpr int D = 4 * LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
+    float loss_acc = 0.0f, sq_acc = 0.0f;
+    for (int64_t t = wave_global * TPW + grp; t < a.T; t += stride) {
+        const int sp = a.slot[t], sn = a.slot[a.T + t];
+        const int ul = a.u_loc[t];
+        if (ul < 0) {                    // empty slot, or a triplet dropped by a bucket overflow:
+            f4 z; z.x = z.y = z.z = z.w = 0.0f;                     // its surviving request gets a zero gradient
+            if (sp >= 0) { *reinterpret_cast<f4*>(a.send_g + (int64_t)sp * a.DS + 4 * sub) = z; if (sub == 0) a.send_g[(int64_t)sp * a.DS + D] = 0.f; }
+            if (sn >= 0) { *reinterpret_cast<f4*>(a.send_g + (int64_t)sn * a.DS + 4 * sub) = z; if (sub == 0) a.send_g[(int64_t)sn * a.DS + D] = 0.f; }
+            continue;
+        }
+        const f4 ru = *reinterpret_cast<const f4*>(a.U + (size_t)ul * D + 4 * sub);
+        const f4 rp = *reinterpret_cast<const f4*>(a.rows_in + (int64_t)sp * a.DS + 4 * sub);
+        const f4 rn = *reinterpret_cast<const f4*>(a.rows_in + (int64_t)sn * a.DS + 4 * sub);
+        const float bp = a.rows_in[(int64_t)sp * a.DS + D], bn = a.rows_in[(int64_t)sn * a.DS + D];
+        const float red = group_allreduce<LPR>(score_partial<MODEL>(ru, rp, rn));
+        float term, g;
+        score<MODEL>(red, bp, bn, a.invB, a.margin, term, g);
+        sq_acc += dot4(ru, ru) + dot4(rp, rp) + dot4(rn, rn);
+        if (sub == 0) loss_acc += term;
+        f4 gu, gp, gn; float gbp, gbn;
+        row_grads<MODEL>(ru, rp, rn, g, a.l2w, gu, gp, gn, gbp, gbn);
+        *reinterpret_cast<f4*>(a.gu + t * D + 4 * sub) = gu;
+        *reinterpret_cast<f4*>(a.send_g + (int64_t)sp * a.DS + 4 * sub) = gp;
+        *reinterpret_cast<f4*>(a.send_g + (int64_t)sn * a.DS + 4 * sub) = gn;
+        if (sub == 0) { a.send_g[(int64_t)sp * a.DS + D] = gbp; a.send_g[(int64_t)sn * a.DS + D] = gbn; }
+    }
+    const float ls = wave_sum(loss_acc);
+    const float sq = wave_sum(sq_acc);
+    if (lane == 0) {
+        float2 v; v.x = ls; v.y = 0.5f * sq;
+        *reinterpret_cast<float2*>(a.partial + 2 * wave_global) = v;
+    }
+}
+
+int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a) {
+    if (a.B == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, shard_route_kernel, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, a);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_launch_shard_request(orx_ctx* ctx, const RequestArgs& a) {
+    if (a.T == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, shard_request_kernel, dim3((unsigned)((a.T + 255) / 256)), dim3(256), 0, a);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_launch_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int32_t* out) {
+    if (n == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, shard_localize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ids, n, world, out);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_launch_shard_grads(orx_ctx* ctx, int model, const ShardGradArgs& a, int* nwaves) {
+    ProfScope ps(ctx, ORX_K_FUSED);
+    int lpr = 0;
+    switch (a.D) { case 16: lpr = 4; break; case 32: lpr = 8; break; case 64: lpr = 16; break; case 128: lpr = 32; break; case 256: lpr = 64; break; }
+    ORX_ARG(lpr != 0 && a.DS % 4 == 0, "sharded fast path: dim must be 16/32/64/128/256 (got %d)", a.D);
+    const dim3 g(grid_for_rows(lpr, a.T));
+    if (nwaves) *nwaves = (int)g.x * 4;
+#define SG(L) (model == ORX_BPR ? (void)ORX_LAUNCH(ctx, (shard_grads_kernel<L, ORX_BPR>), g, dim3(256), 0, a) \
+                                : (void)ORX_LAUNCH(ctx, (shard_grads_kernel<L, ORX_UCML>), g, dim3(256), 0, a))
+    switch (lpr) { case 4: SG(4); break; case 8: SG(8); break; case 16: SG(16); break; case 32: SG(32); break; default: SG(64); break; }
+#undef SG
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}

@@ -231,3 +231,40 @@ int orx_launch_dlrm_loss(orx_ctx* ctx, float* P, const float* y, int64_t B, int 
 int orx_launch_dlrm_ids(orx_ctx* ctx, const int32_t* sparse, const int64_t* offset, const int64_t* rows, int nf, int64_t B,
                         int32_t* idx);
 int orx_launch_rows_accum(orx_ctx* ctx, float* G, const int32_t* ids, const float* grads, int64_t g_stride, int64_t n, int D, int64_t rows);
+
+// device-side exchange plan of the sharded step (kernels_sharded.hip)
+struct RouteArgs {
+    const int32_t* uid; const int32_t* pid; const int32_t* nid; int64_t B;
+    int world; int cap;
+    int32_t* send;           // [world*cap][3], pre-filled with -1
+    int* counters;           // [world], zeroed
+    int* overflow; int* err;
+    int64_t NU, NI;          // GLOBAL table rows (id validation)
+};
+
+struct RequestArgs {
+    const int32_t* trip;     // [T][3] received triplets, u < 0 = empty slot
+    int64_t T; int world; int cap;
+    int32_t* send_ids;       // [world*cap], pre-filled with -1
+    int32_t* slot;           // [2T]: slot of the p / n request of triplet t, -1 if none
+    int32_t* u_loc;          // [T]: local user row or -1
+    int* counters;           // [world], zeroed
+    int* overflow;
+};
+
+struct ShardGradArgs {
+    const float* U;          // local user shard [rows, D]
+    const float* rows_in;    // [world*cap2][DS] received item rows, bias at column D
+    const int32_t* u_loc;    // [T]
+    const int32_t* slot;     // [2T]
+    float* gu;               // [T][D]
+    float* send_g;           // [world*cap2][DS]
+    int64_t T; int D; int DS;
+    float invB; float margin; float l2w;
+    float* partial;
+};
+
+int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a);
+int orx_launch_shard_request(orx_ctx* ctx, const RequestArgs& a);
+int orx_launch_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int32_t* out);
+int orx_launch_shard_grads(orx_ctx* ctx, int model, const ShardGradArgs& a, int* nwaves);

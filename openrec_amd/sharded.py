@@ -98,6 +98,28 @@ class HipBackend:
                                                 bias._h if bias is not None else None,
                                                 ids.data_ptr(), ids.numel(), grads.data_ptr(), grads.shape[1]))
 
+    # ---- device-side exchange plan (fast path) ----------------------------
+    fast = True
+
+    def shard_route(self, uid, pid, nid, n_users, n_items, world, cap, send, counters, overflow):
+        self._ffi.check(self.lib.orx_shard_route(self.ctx._h, uid.data_ptr(), pid.data_ptr(), nid.data_ptr(), uid.numel(),
+                                                 n_users, n_items, world, cap, send.data_ptr(), counters.data_ptr(),
+                                                 overflow.data_ptr()))
+
+    def shard_request(self, trip, world, cap, send_ids, slot, u_loc, counters, overflow):
+        self._ffi.check(self.lib.orx_shard_request(self.ctx._h, trip.data_ptr(), trip.shape[0], world, cap,
+                                                   send_ids.data_ptr(), slot.data_ptr(), u_loc.data_ptr(),
+                                                   counters.data_ptr(), overflow.data_ptr()))
+
+    def shard_localize(self, ids, world, out):
+        self._ffi.check(self.lib.orx_shard_localize(self.ctx._h, ids.data_ptr(), ids.numel(), world, out.data_ptr()))
+
+    def shard_grads(self, model, user, rows_in, u_loc, slot, b_global, margin, gu, send_g, accum):
+        mid = {"bpr": self._ffi.ORX_BPR, "ucml": self._ffi.ORX_UCML}[model]
+        self._ffi.check(self.lib.orx_shard_grads(self.ctx._h, mid, user._h, rows_in.data_ptr(), u_loc.data_ptr(),
+                                                 slot.data_ptr(), u_loc.numel(), rows_in.shape[1], b_global, margin, 0,
+                                                 gu.data_ptr(), send_g.data_ptr(), accum.data_ptr()))
+
     def check(self):
         self.ctx.check_index_error()
 
@@ -107,7 +129,7 @@ class HipBackend:
 
 class ShardedPairwise:
     def __init__(self, model, opt, n_users, n_items, dim, lr, rank, world, device, seed=0, margin=0.5,
-                 backend=None, slack=1.25, opt_kw=None, group=None):
+                 backend=None, slack=1.05, opt_kw=None, group=None, a2a_fn=None, fast=None):
         assert model in ("bpr", "ucml")
         self.model, self.dim, self.margin = model, dim, margin
         self.rank, self.world, self.device, self.group = rank, world, device, group
@@ -121,6 +143,12 @@ class ShardedPairwise:
         self.accum = torch.zeros(2, dtype=torch.float64, device=device)
         self.overflow = torch.zeros((), dtype=torch.bool, device=device)
         self._cap_for = {}
+        self.a2a_fn = a2a_fn
+        # the device-side plan needs the HIP building blocks and a float4 row path
+        can_fast = getattr(self.be, "fast", False) and dim in (16, 32, 64, 128, 256)
+        self.fast = can_fast if fast is None else (fast and can_fast)
+        self._ovf = torch.zeros(1, dtype=torch.int32, device=device) if self.fast else None
+        self._bufs = {}
 
     # capacity of one (source, destination) bucket for n elements spread over `world` ranks
     def _cap(self, n):
@@ -129,16 +157,55 @@ class ShardedPairwise:
             self._cap_for[n] = int(math.ceil(mean * self.slack + 6 * math.sqrt(mean) + 16))
         return self._cap_for[n]
 
-    def _a2a(self, send):
-        recv = torch.empty_like(send)
+    def _a2a(self, send, recv=None):
+        if self.a2a_fn is not None:                       # injected exchange (single-process tests)
+            recv = torch.empty_like(send) if recv is None else recv
+            self.a2a_fn(recv, send)
+            return recv
         if self.world == 1:
-            recv.copy_(send)
-        else:
-            dist.all_to_all_single(recv, send, group=self.group)
+            return send                                   # a one-rank exchange is the identity
+        recv = torch.empty_like(send) if recv is None else recv
+        dist.all_to_all_single(recv, send, group=self.group)
         return recv
+
+    # ------------------------------------------------------------------ fast path
+    def _buffers(self, B):
+        if B not in self._bufs:
+            N, dev, DS, D = self.world, self.device, self.DS, self.dim
+            cap1 = self._cap(B); T = N * cap1
+            cap2 = self._cap(2 * T); M = N * cap2
+            i32 = dict(dtype=torch.int32, device=dev); f32 = dict(dtype=torch.float32, device=dev)
+            self._bufs[B] = dict(
+                cap1=cap1, T=T, cap2=cap2, M=M,
+                send1=torch.empty((T, 3), **i32), recv1=torch.empty((T, 3), **i32), cnt=torch.zeros(N, **i32),
+                send2=torch.empty(M, **i32), req=torch.empty(M, **i32), req_loc=torch.empty(M, **i32),
+                slot=torch.empty(2 * T, **i32), u_loc=torch.empty(T, **i32),
+                rows_out=torch.zeros((M, DS), **f32), rows_in=torch.empty((M, DS), **f32),
+                gu=torch.zeros((T, D), **f32), send_g=torch.zeros((M, DS), **f32), g_in=torch.empty((M, DS), **f32))
+        return self._bufs[B]
+
+    def _step_fast(self, uid, pid, nid):
+        be, N = self.be, self.world
+        B = uid.numel()
+        f = self._buffers(B)
+        be.shard_route(uid, pid, nid, self.n_users, self.n_items, N, f["cap1"], f["send1"], f["cnt"], self._ovf)
+        mine = self._a2a(f["send1"], f["recv1"])                                   # 1. triplets -> user owner
+        be.shard_request(mine, N, f["cap2"], f["send2"], f["slot"], f["u_loc"], f["cnt"], self._ovf)
+        req = self._a2a(f["send2"], f["req"])                                      # 2. item ids -> item owner
+        be.shard_localize(req, N, f["req_loc"])
+        be.gather_rows(self.V, self.b, f["req_loc"], f["rows_out"])
+        rows_in = self._a2a(f["rows_out"], f["rows_in"])                           # 3. item rows back
+        be.shard_grads(self.model, self.U, rows_in, f["u_loc"], f["slot"], B * N, self.margin, f["gu"], f["send_g"],
+                       self.accum)
+        be.apply_rows(self.U, None, f["u_loc"], f["gu"])                           # 5. user rows are local
+        g_in = self._a2a(f["send_g"], f["g_in"])                                   # 6. item-row gradients -> owners
+        be.apply_rows(self.V, self.b, f["req_loc"], g_in)
+        return None
 
     def step(self, uid, pid, nid):
         """uid/pid/nid: int32 [B] on self.device -- this rank's slice of the global batch."""
+        if self.fast:
+            return self._step_fast(uid, pid, nid)
         N, dev, DS, D = self.world, self.device, self.DS, self.dim
         B = uid.numel()
         b_global = B * N
@@ -207,6 +274,8 @@ class ShardedPairwise:
         if hasattr(self.be, "check"):
             self.be.check()
         ov = self.overflow.clone().to(torch.int32)
+        if self._ovf is not None:
+            ov = ov + self._ovf[0]
         if self.world > 1:
             dist.all_reduce(ov, group=self.group)
         if int(ov) != 0:

@@ -62,3 +62,78 @@ def test_gather_rows_skips_padding_and_is_bit_exact():
     m = ids >= 0
     assert np.array_equal(o[m, :64], W[ids[m]]) and np.array_equal(o[m, 64], bb[ids[m], 0])
     assert (o[~m] == 7.0).all() and (o[:, 65:] == 7.0).all()
+
+
+class _FakeCluster:
+    """All-to-all between `N` engines living in N threads of this process (one GPU):
+    exercises the device-side routing kernels with world > 1 without a second GPU."""
+
+    def __init__(self, N):
+        import threading
+        self.N, self.bar, self.slots = N, threading.Barrier(N), [None] * N
+
+    def a2a(self, rank):
+        import torch
+
+        def fn(recv, send):
+            torch.cuda.synchronize()
+            self.slots[rank] = send
+            self.bar.wait()
+            chunk = send.shape[0] // self.N
+            for src in range(self.N):
+                recv[src * chunk:(src + 1) * chunk] = self.slots[src][rank * chunk:(rank + 1) * chunk]
+            torch.cuda.synchronize()
+            self.bar.wait()
+        return fn
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("model,optk", [("bpr", "sgd"), ("bpr", "adagrad"), ("ucml", "sgd")])
+@pytest.mark.parametrize("fast", [True, False])
+def test_virtual_cluster_matches_oracle(world, model, optk, fast):
+    import threading
+    import torch
+    from openrec_amd import sharded
+    from oracle import numpy_oracle as orc
+    dev = torch.device("cuda", 0)
+    NU, NI, D, Bg = 1001, 1503, 64, 4096
+    U, V, b, u, p, n = _case(7, NU, NI, Bg, D)
+    cl = _FakeCluster(world)
+    engs, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            e = sharded.ShardedPairwise(model, optk, NU, NI, D, lr=0.05, rank=rank, world=world, device=dev,
+                                        slack=1.5, a2a_fn=cl.a2a(rank), fast=fast)
+            assert e.fast == fast
+            e.U.write(U[rank::world]); e.V.write(V[rank::world]); e.b.write(b[rank::world])
+            engs[rank] = e
+            per = Bg // world
+            for s in range(3):
+                uu, pp, nn = np.roll(u, s), np.roll(p, 5 * s), np.roll(n, 2 * s)
+                sl = slice(rank * per, (rank + 1) * per)
+                e.step(torch.from_numpy(uu[sl].copy()).to(dev), torch.from_numpy(pp[sl].copy()).to(dev),
+                       torch.from_numpy(nn[sl].copy()).to(dev))
+            torch.cuda.synchronize()
+        except Exception as ex:                         # pragma: no cover
+            errs.append(ex)
+            cl.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    o = orc.SGD(0.05) if optk == "sgd" else orc.Adagrad(0.05, 0.1, 1e-7)
+    tl = 0.0
+    for s in range(3):
+        uu, pp, nn = np.roll(u, s), np.roll(p, 5 * s), np.roll(n, 2 * s)
+        l, _ = (orc.bpr_step if model == "bpr" else (lambda *a: orc.ucml_step(*a, do_censor=False)))(U, V, b, uu, pp, nn, o)
+        tl += float(l)
+    got = 0.0
+    for r, e in enumerate(engs):
+        assert int(e._ovf[0]) == 0 if e._ovf is not None else True
+        assert not bool(e.overflow)
+        assert rel_err(e.U.read()[:len(U[r::world])], U[r::world]) < 2e-5
+        assert rel_err(e.V.read()[:len(V[r::world])], V[r::world]) < 2e-5
+        assert rel_err(e.b.read()[:len(b[r::world])], b[r::world]) < 2e-5
+        got += float(e.accum[0])
+    assert abs(got - tl) <= 1e-5 * abs(tl)
