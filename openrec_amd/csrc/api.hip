@@ -97,7 +97,7 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_dlist);
+    hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_ids2); hipFree(c->d_dlist);
     hipFree(c->d_dcount); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -408,8 +408,11 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     ENSURE(c->d_partial, c->d_partial_cap, (size_t)chunk * nw * 2 * sizeof(float));
     ENSURE(c->d_loss, c->d_loss_cap, (size_t)K * 2 * sizeof(double));
     const int64_t list_stride = 2 * B;          // distinct duplicated rows <= B/2 (users) + B (items)
+    // the three rewritten id arrays of a step are padded apart: with B a power of two their
+    // addresses would otherwise differ by exact multiples of 256 KiB (same cache set / HBM channel)
+    const int64_t Bp = ((B + 3) / 4) * 4 + 96;
     if (mode == MODE_EXACT) {
-        ENSURE(c->d_dflag, c->d_dflag_cap, (size_t)chunk * 3 * B);
+        ENSURE(c->d_ids2, c->d_ids2_cap, (size_t)chunk * 3 * Bp * sizeof(int32_t));
         ENSURE(c->d_dlist, c->d_dlist_cap, (size_t)chunk * list_stride * sizeof(uint32_t));
         ENSURE(c->d_dcount, c->d_dcount_cap, (size_t)chunk * sizeof(int));
     }
@@ -434,8 +437,8 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             DedupArgs d;
             memset(&d, 0, sizeof(d));
             d.uid = du + s0 * ds; d.pid = dp + s0 * ds; d.nid = dn + s0 * ds; d.id_stride = ds;
-            d.dflag = c->d_dflag; d.dlist = c->d_dlist; d.dcount = c->d_dcount;
-            d.flag_stride = 3 * B; d.list_stride = list_stride;
+            d.dflag = nullptr; d.ids_out = c->d_ids2; d.dlist = c->d_dlist; d.dcount = c->d_dcount;
+            d.flag_stride = 3 * Bp; d.role_stride = Bp; d.list_stride = list_stride;
             d.nU = B; d.nP = B; d.nN = B; d.NU = U->rows; d.NI = V->rows;
             d.nbu = orx_dedup_buckets(U->rows); d.nbi = orx_dedup_buckets(V->rows);
             ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));
@@ -443,8 +446,11 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
         }
         for (int64_t i = 0; i < kc; ++i) {
             const int64_t s = s0 + i;
-            a.uid = du + s * ds; a.pid = dp + s * ds; a.nid = dn + s * ds;
-            a.dflag = c->d_dflag + (size_t)i * 3 * B;
+            if (mode == MODE_EXACT) {       // ids rewritten by dedup (duplicate flag in bit 31)
+                a.uid = c->d_ids2 + (size_t)i * 3 * Bp; a.pid = a.uid + Bp; a.nid = a.uid + 2 * Bp;
+            } else {
+                a.uid = du + s * ds; a.pid = dp + s * ds; a.nid = dn + s * ds;
+            }
             a.dlist = c->d_dlist + (size_t)i * list_stride; a.dcount = c->d_dcount + i;
             a.partial = c->d_partial + (size_t)i * nw * 2;
             CHECK(orx_launch_fused(c, model, opt->kind, mode, a));

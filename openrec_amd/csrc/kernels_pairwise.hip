@@ -50,6 +50,21 @@ constexpr int DD_ROWS = DD_WORDS * 32;          // rows covered by one workgroup
 constexpr int DD_THREADS = 1024;
 constexpr int DD_LDS_BYTES = 2 * DD_WORDS * 4;  // 128 KiB
 
+// visit every reference j in [0, n) of a table's id stream (segment A of length nA, then
+// segment B); int4 loads when both segments are 16-byte aligned multiples of 4
+template <class F>
+__device__ __forceinline__ void for_each_ref(const int32_t* idsA, int64_t nA, const int32_t* idsB, int64_t n, bool vec, F f) {
+    if (vec) {
+        const int64_t n4 = n >> 2, nA4 = nA >> 2;
+        for (int64_t q = threadIdx.x; q < n4; q += DD_THREADS) {
+            const int4 v = q < nA4 ? reinterpret_cast<const int4*>(idsA)[q] : reinterpret_cast<const int4*>(idsB)[q - nA4];
+            f(4 * q + 0, v.x); f(4 * q + 1, v.y); f(4 * q + 2, v.z); f(4 * q + 3, v.w);
+        }
+    } else {
+        for (int64_t j = threadIdx.x; j < n; j += DD_THREADS) f(j, j < nA ? idsA[j] : idsB[j - nA]);
+    }
+}
+
 __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned int dd_lds[];
     unsigned int* seen = dd_lds;
@@ -63,18 +78,25 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
     if (!is_user) bk -= a.nbu;
     const int64_t r0 = (int64_t)bk * DD_ROWS;
     const int64_t rows = is_user ? a.NU : a.NI;
-    const int64_t B = is_user ? a.nU : a.nP;                 // length of the first id segment
+    const int64_t nA = is_user ? a.nU : a.nP;                // length of the first id segment
     const int32_t* idsA = (is_user ? a.uid : a.pid) + s * a.id_stride;
     const int32_t* idsB = a.nid + s * a.id_stride;
     const int64_t n = is_user ? a.nU : a.nP + a.nN;
     const int64_t ref0 = is_user ? 0 : a.nU;
-    unsigned char* dflag = a.dflag + s * a.flag_stride;
+    unsigned char* dflag = a.dflag ? a.dflag + s * a.flag_stride : nullptr;
+    int32_t* ids_out = a.ids_out ? a.ids_out + s * a.flag_stride : nullptr;
+    // position of reference j in ids_out: [role][role_stride] (role 0 user, 1 pos item, 2 neg item)
+    auto out_index = [&](int64_t j) -> int64_t {
+        if (a.role_stride == 0) return ref0 + j;
+        if (is_user) return j;
+        return j < nA ? a.role_stride + j : 2 * a.role_stride + (j - nA);
+    };
+    const bool vec = ((nA & 3) == 0) && ((n & 3) == 0) && ((((uintptr_t)idsA) | ((uintptr_t)idsB)) & 15) == 0;
 
     for (int i = threadIdx.x; i < 2 * DD_WORDS; i += DD_THREADS) dd_lds[i] = 0u;
     if (threadIdx.x == 0) list_cnt = 0;
     __syncthreads();
-    for (int64_t j = threadIdx.x; j < n; j += DD_THREADS) {
-        const int id = j < B ? idsA[j] : idsB[j - B];
+    for_each_ref(idsA, nA, idsB, n, vec, [&](int64_t j, int id) {
         const int64_t l = (int64_t)id - r0;
         if ((uint64_t)l < (uint64_t)DD_ROWS && id_ok(id, rows)) {
             const unsigned int bit = 1u << (l & 31);
@@ -82,15 +104,20 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
             if (old & bit) atomicOr(&dup[l >> 5], bit);
             if (a.first_only) dflag[ref0 + j] = (old & bit) ? 1 : 0;
         }
-    }
+    });
     if (a.first_only) return;
     __syncthreads();
-    for (int64_t j = threadIdx.x; j < n; j += DD_THREADS) {
-        const int id = j < B ? idsA[j] : idsB[j - B];
+    for_each_ref(idsA, nA, idsB, n, vec, [&](int64_t j, int id) {
         const int64_t l = (int64_t)id - r0;
-        if ((uint64_t)l < (uint64_t)DD_ROWS && id_ok(id, rows))
-            dflag[ref0 + j] = (dup[l >> 5] >> (l & 31)) & 1u;
-    }
+        const bool ok = id_ok(id, rows);
+        if ((uint64_t)l < (uint64_t)DD_ROWS && ok) {
+            const unsigned int d = (dup[l >> 5] >> (l & 31)) & 1u;
+            if (dflag) dflag[ref0 + j] = (unsigned char)d;
+            if (ids_out) ids_out[out_index(j)] = (int32_t)((uint32_t)id | (d << 31));
+        } else if (!ok && bk == 0 && ids_out) {
+            ids_out[out_index(j)] = 0x7fffffff;              // out-of-range id: can never be a valid row
+        }
+    });
     // append the duplicated rows of this range to the step's list
     int mine = 0;
     for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) mine += __popc(dup[w]);
@@ -175,11 +202,16 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     float loss_acc = 0.0f, sq_acc = 0.0f;
 
     for (int64_t t = wave_global * TPW + grp; t < a.B; t += stride) {
-        const int u = a.uid[t], p = a.pid[t], n = a.nid[t];
+        int u = a.uid[t], p = a.pid[t], n = a.nid[t];
         int du = 0, dp = 0, dn = 0;
-        if (MODE == MODE_EXACT) { du = a.dflag[t]; dp = a.dflag[a.B + t]; dn = a.dflag[2 * a.B + t]; }
+        if (MODE == MODE_EXACT) {       // ids rewritten by dedup_kernel: bit 31 = "row is referenced more than once"
+            du = (uint32_t)u >> 31; dp = (uint32_t)p >> 31; dn = (uint32_t)n >> 31;
+            u &= 0x7fffffff; p &= 0x7fffffff; n &= 0x7fffffff;
+        }
         if (MODE == MODE_ACCUM) { du = dp = dn = 1; }
-        if (!(id_ok(u, a.NU) && id_ok(p, a.NI) && id_ok(n, a.NI))) {
+        // bitwise &: all three id loads are issued together (a short-circuit && lets the compiler
+        // sink the loads behind each other: three dependent round trips)
+        if (!(id_ok(u, a.NU) & id_ok(p, a.NI) & id_ok(n, a.NI))) {
             if (sub == 0) *a.err = 1;       // the reference's CPU gather raises; the triplet is skipped
             continue;
         }
@@ -297,11 +329,16 @@ __global__ __launch_bounds__(256) void fused_generic_kernel(PairArgs a) {
     const int64_t stride = (int64_t)gridDim.x * 4;
     float loss_acc = 0.0f, sq_acc = 0.0f;
     for (int64_t t = wave_global; t < a.B; t += stride) {
-        const int u = a.uid[t], p = a.pid[t], n = a.nid[t];
+        int u = a.uid[t], p = a.pid[t], n = a.nid[t];
         int du = 0, dp = 0, dn = 0;
-        if (MODE == MODE_EXACT) { du = a.dflag[t]; dp = a.dflag[a.B + t]; dn = a.dflag[2 * a.B + t]; }
+        if (MODE == MODE_EXACT) {       // ids rewritten by dedup_kernel: bit 31 = "row is referenced more than once"
+            du = (uint32_t)u >> 31; dp = (uint32_t)p >> 31; dn = (uint32_t)n >> 31;
+            u &= 0x7fffffff; p &= 0x7fffffff; n &= 0x7fffffff;
+        }
         if (MODE == MODE_ACCUM) { du = dp = dn = 1; }
-        if (!(id_ok(u, a.NU) && id_ok(p, a.NI) && id_ok(n, a.NI))) {
+        // bitwise &: all three id loads are issued together (a short-circuit && lets the compiler
+        // sink the loads behind each other: three dependent round trips)
+        if (!(id_ok(u, a.NU) & id_ok(p, a.NI) & id_ok(n, a.NI))) {
             if (lane == 0) *a.err = 1;
             continue;
         }

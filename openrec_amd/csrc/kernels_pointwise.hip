@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
         int du = 0, di = 0;
         if (MODE == MODE_EXACT) { du = a.dflag[t]; di = a.dflag[a.B + t]; }
         if (MODE == MODE_ACCUM) { du = di = 1; }
-        if (!(id_ok(u, a.NU) && id_ok(i, a.NI))) { if (sub == 0) *a.err = 1; continue; }
+        if (!(id_ok(u, a.NU) & id_ok(i, a.NI))) { if (sub == 0) *a.err = 1; continue; }
         float* Up = a.U + (size_t)u * D + 4 * sub;
         float* Ip = a.V + (size_t)i * D + 4 * sub;
         const f4 ru = *reinterpret_cast<const f4*>(Up);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void point_generic_kernel(PointArgs a) {
         int du = 0, di = 0;
         if (MODE == MODE_EXACT) { du = a.dflag[t]; di = a.dflag[a.B + t]; }
         if (MODE == MODE_ACCUM) { du = di = 1; }
-        if (!(id_ok(u, a.NU) && id_ok(i, a.NI))) { if (lane == 0) *a.err = 1; continue; }
+        if (!(id_ok(u, a.NU) & id_ok(i, a.NI))) { if (lane == 0) *a.err = 1; continue; }
         float* Ur = a.U + (size_t)u * D;
         float* Ir = a.V + (size_t)i * D;
         const float bi = a.b[i];

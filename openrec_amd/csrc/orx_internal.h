@@ -48,7 +48,8 @@ struct orx_ctx {
     // staging buffers (grown on demand)
     int32_t* d_ids = nullptr;  size_t d_ids_cap = 0;       // host-id upload
     float* d_lab = nullptr;    size_t d_lab_cap = 0;
-    unsigned char* d_dflag = nullptr; size_t d_dflag_cap = 0;   // [K][3B] duplicate flags
+    unsigned char* d_dflag = nullptr; size_t d_dflag_cap = 0;   // [K][2B] duplicate flags (pointwise, censor)
+    int32_t* d_ids2 = nullptr; size_t d_ids2_cap = 0;            // [K][3B] ids with the duplicate flag in bit 31
     uint32_t* d_dlist = nullptr; size_t d_dlist_cap = 0;         // [K][2B] duplicated rows
     int* d_dcount = nullptr;   size_t d_dcount_cap = 0;          // [K]
     float* d_partial = nullptr; size_t d_partial_cap = 0;   // [K][nwaves][2] loss partials
@@ -108,7 +109,9 @@ struct ProfScope {
 // ------------------------------------------------ kernel launch parameters ---
 // Duplicate detection output, per step (reference index r: user lookup k -> k,
 // pos-item lookup k -> B + k, neg-item lookup k -> 2B + k):
-//   dflag[r]   = 1 if the row of r is referenced more than once in the batch, else 0
+//   ids_out[r] = id | (dup << 31): the id with "row referenced more than once in this batch" in bit 31
+//                (the pairwise fused kernel reads these instead of the caller's ids); dflag[r] = the same
+//                flag as a byte (pointwise / censor / apply_rows)
 //   dlist[...] = the distinct duplicated rows of the step: row | (is_item << 31)
 //   dcount     = number of entries in dlist
 struct PairArgs {
@@ -116,7 +119,6 @@ struct PairArgs {
     float* gU; float* gV; float* gb;          // duplicate-row gradient sums (zero between steps)
     float* aU; float* aV; float* ab;          // Adagrad accumulators
     const int32_t* uid; const int32_t* pid; const int32_t* nid;
-    const unsigned char* dflag;               // [3B] (exact mode)
     const uint32_t* dlist;                    // duplicated rows of this step
     const int* dcount;
     int64_t B; int64_t NU; int64_t NI;
@@ -129,7 +131,9 @@ struct PairArgs {
 struct DedupArgs {
     const int32_t* uid; const int32_t* pid; const int32_t* nid;   // step 0 of the chunk
     int64_t id_stride;                        // elements between consecutive steps
-    unsigned char* dflag;                     // [K][flag_stride]
+    unsigned char* dflag;                     // [K][flag_stride] or NULL
+    int32_t* ids_out;                         // [K][flag_stride] or NULL: id | (dup << 31); 0x7fffffff = invalid id
+    int64_t role_stride;                      // ids_out layout [3][role_stride] per step (0: compact reference order)
     uint32_t* dlist;                          // [K][list_stride]
     int* dcount;                              // [K], zeroed before the launch
     int64_t flag_stride; int64_t list_stride;

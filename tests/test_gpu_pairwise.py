@@ -136,8 +136,10 @@ def test_all_same_user_and_kats():
     U, V, b, uid, pid, nid = _rand_case(5, 10, 3000, B, D, hot=False)
     uid[:] = 4
     for optkind in ("sgd", "adagrad"):
-        U1, V1, b1 = U.copy(), V.copy(), b.copy()
-        tU, tV, tb = _tables(rt, U1, V1, b1)
+        # 1024 gradients are summed into one row in an arbitrary (atomic) order: compare with the
+        # fp64 oracle (truth) rather than with one particular fp32 summation order
+        U1, V1, b1 = U.astype(np.float64), V.astype(np.float64), b.astype(np.float64)
+        tU, tV, tb = _tables(rt, U, V, b)
         opt = _make_opt(rt, optkind)
         rt.pairwise_step("bpr", opt, tU, tV, tb, uid, pid, nid)
         orc.bpr_step(U1, V1, b1, uid, pid, nid, _oracle_opt(optkind))
