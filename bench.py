@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hogwild", action="store_true", help="racy non-reference mode (never the headline)")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded engine even on one GPU (debug)")
+    ap.add_argument("--censor", action="store_true",
+                    help="UCML: LatentFactor.censor of the touched rows after every step (ucml.py:44-48); "
+                         "steps are then issued one call at a time")
     args = ap.parse_args()
 
     import torch
@@ -122,6 +125,13 @@ def main():
         torch.cuda.synchronize()
 
         def run(first, count, want_loss=False):
+            if args.censor:                     # BASELINE configs[2]: censor after each step
+                out = None
+                for s in range(first, first + count):
+                    out = rt.pairwise_step(args.model, opt, U, V, b, uid[s], pid[s], nid[s], K=1, B=args.batch,
+                                           margin=0.5, hogwild=args.hogwild, want_loss=want_loss and s == first + count - 1)
+                    U.censor(uid[s]); V.censor(pid[s]); V.censor(nid[s])
+                return out
             return rt.pairwise_step(args.model, opt, U, V, b, uid[first:first + count], pid[first:first + count],
                                     nid[first:first + count], K=count, B=args.batch, margin=0.5,
                                     hogwild=args.hogwild, want_loss=want_loss)
@@ -181,7 +191,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.model} dim={args.dim} {args.users}x{args.items} table, "
                                    f"batch={args.batch} triplets/GPU, {args.opt} lr={lr}, objective loss+l2_loss, "
-                                   f"{'HOGWILD (non-reference)' if args.hogwild else 'exact TF duplicate semantics'}",
+                                   f"{'HOGWILD (non-reference)' if args.hogwild else 'exact TF duplicate semantics'}"
+                                   f"{', censor after each step' if args.censor else ''}",
                        "parallelism": parallelism},
         }
         fused = prof.get("fused", {})

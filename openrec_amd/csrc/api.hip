@@ -97,7 +97,7 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_ids2); hipFree(c->d_dlist);
+    hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_dlist);
     hipFree(c->d_dcount); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -159,6 +159,7 @@ extern "C" int orx_table_destroy(orx_table* t) {
     hipStreamSynchronize(t->ctx->stream);
     if (t->owned) hipFree(t->w);
     hipFree(t->gsum);
+    hipFree(t->gsum2);
     delete t;
     return ORX_OK;
 }
@@ -167,12 +168,16 @@ extern "C" int64_t orx_table_rows(const orx_table* t) { return t ? t->rows : -1;
 extern "C" int32_t orx_table_dim(const orx_table* t) { return t ? t->dim : -1; }
 extern "C" void* orx_table_device_ptr(const orx_table* t) { return t ? (void*)t->w : nullptr; }
 
-int orx_table_scratch(orx_table* t) {
-    if (t->gsum) return ORX_OK;
+int orx_table_scratch(orx_table* t, bool second) {
     ORX_HIP(hipSetDevice(t->ctx->device));
-    {
-        ORX_HIP(hipMalloc((void**)&t->gsum, (size_t)t->rows * t->dim * sizeof(float)));
-        ORX_HIP(hipMemsetAsync(t->gsum, 0, (size_t)t->rows * t->dim * sizeof(float), t->ctx->stream));
+    const size_t bytes = (size_t)t->rows * t->dim * sizeof(float);
+    if (!t->gsum) {
+        ORX_HIP(hipMalloc((void**)&t->gsum, bytes));
+        ORX_HIP(hipMemsetAsync(t->gsum, 0, bytes, t->ctx->stream));
+    }
+    if (second && !t->gsum2) {
+        ORX_HIP(hipMalloc((void**)&t->gsum2, bytes));
+        ORX_HIP(hipMemsetAsync(t->gsum2, 0, bytes, t->ctx->stream));
     }
     return ORX_OK;
 }
@@ -396,7 +401,12 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
 
     const bool hogwild = (flags & ORX_HOGWILD) != 0;
     const int mode = opt->kind == ORX_ADAM ? MODE_ACCUM : (hogwild ? MODE_HOGWILD : MODE_EXACT);
-    if (mode != MODE_HOGWILD) { CHECK(orx_table_scratch(U)); CHECK(orx_table_scratch(V)); CHECK(orx_table_scratch(b)); }
+    // rows referenced exactly twice get plain stores into two scratch rows; the role of a reference
+    // travels in bits 30:29 of its id, which needs tables below 2^29 rows
+    const bool role_bits = mode == MODE_EXACT && U->rows < (1LL << 29) && V->rows < (1LL << 29);
+    if (mode != MODE_HOGWILD) {
+        CHECK(orx_table_scratch(U, role_bits)); CHECK(orx_table_scratch(V, role_bits)); CHECK(orx_table_scratch(b, role_bits));
+    }
     OptSlots sU, sV, sb;
     CHECK(orx_opt_slots(opt, U, &sU)); CHECK(orx_opt_slots(opt, V, &sV)); CHECK(orx_opt_slots(opt, b, &sb));
 
@@ -413,6 +423,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     const int64_t Bp = ((B + 3) / 4) * 4 + 96;
     if (mode == MODE_EXACT) {
         ENSURE(c->d_ids2, c->d_ids2_cap, (size_t)chunk * 3 * Bp * sizeof(int32_t));
+        if (role_bits) ENSURE(c->d_roles, c->d_roles_cap, (size_t)chunk * 3 * Bp);
         ENSURE(c->d_dlist, c->d_dlist_cap, (size_t)chunk * list_stride * sizeof(uint32_t));
         ENSURE(c->d_dcount, c->d_dcount_cap, (size_t)chunk * sizeof(int));
     }
@@ -421,6 +432,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     memset(&a, 0, sizeof(a));
     a.U = U->w; a.V = V->w; a.b = b->w;
     a.gU = U->gsum; a.gV = V->gsum; a.gb = b->gsum;
+    if (role_bits) { a.gU2 = U->gsum2; a.gV2 = V->gsum2; a.gb2 = b->gsum2; a.role_bits = 1; }
     a.aU = sU.s0; a.aV = sV.s0; a.ab = sb.s0;
     a.B = B; a.NU = U->rows; a.NI = V->rows; a.D = U->dim;
     a.lr = opt->lr;
@@ -438,6 +450,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             memset(&d, 0, sizeof(d));
             d.uid = du + s0 * ds; d.pid = dp + s0 * ds; d.nid = dn + s0 * ds; d.id_stride = ds;
             d.dflag = nullptr; d.ids_out = c->d_ids2; d.dlist = c->d_dlist; d.dcount = c->d_dcount;
+            d.roles = role_bits ? c->d_roles : nullptr;
             d.flag_stride = 3 * Bp; d.role_stride = Bp; d.list_stride = list_stride;
             d.nU = B; d.nP = B; d.nN = B; d.NU = U->rows; d.NI = V->rows;
             d.nbu = orx_dedup_buckets(U->rows); d.nbi = orx_dedup_buckets(V->rows);

@@ -22,43 +22,60 @@
 //     batch.  Per-row metadata in HBM would cost one extra random transaction
 //     per reference (measured: about as expensive as a row access), so duplicates
 //     are found WITHOUT touching HBM tables:
-//       dedup_kernel    : row-range buckets of 524288 rows; each workgroup keeps
-//                         two LDS bitmaps ("seen", "seen twice") for its range
-//                         while streaming the L2-resident id arrays: exact, no
-//                         hashing, no overflow.  It runs once for ALL K steps of
-//                         a call, before the first step.  Output per step: one
-//                         flag byte per reference and the list of duplicated rows.
+//       dedup_kernel    : row-range buckets of 425984 rows; each workgroup keeps
+//                         three LDS bitmaps ("seen", "seen twice", "seen three
+//                         times", 156 KiB) for its range while streaming the
+//                         L2-resident id arrays: exact, no hashing, no overflow.
+//                         It runs once for ALL K steps of a call, before the
+//                         first step.  Output per step: the ids rewritten with
+//                         the duplicate flag in bit 31 and the reference's role
+//                         (first / second / any of >= 3) in bits 30:29, and the
+//                         list of duplicated rows.
 //       fused_kernel    : unique rows are read, scored and updated in place
 //                         (exact: nobody else reads or writes them).  A
-//                         duplicate reference adds its gradient to gsum[row]
-//                         with fire-and-forget fp32 atomics and leaves the row.
+//                         duplicated row is left untouched; a reference to it
+//                         deposits its gradient in scratch: rows referenced
+//                         exactly twice (the vast majority) get ONE PLAIN STORE
+//                         per reference into scratch row 1 / scratch row 2 (no
+//                         atomics, bitwise reproducible), rows referenced >= 3
+//                         times use fire-and-forget fp32 atomics into scratch row 1.
 //       dup_apply_kernel: for every duplicated row of the step, apply the
 //                         optimizer rule once with the summed gradient (TF's
 //                         dedup-sum semantics for Adagrad; identical for SGD)
-//                         and re-zero gsum[row].
-//     gsum[] is all-zero between steps.
+//                         and re-zero the scratch rows.
+//     The scratch tables are all-zero between steps.
 #include "orx_internal.h"
 
 #include "orx_device.h"
 
 // ------------------------------------------------------------ dedup kernel ---
-// One workgroup per (step, table, 524288-row range).  Exact duplicate detection
-// on the id arrays alone: two LDS bitmaps over the rows of the range; the ids of
+// One workgroup per (step, table, 425984-row range).  Exact duplicate detection
+// on the id arrays alone: three LDS bitmaps over the rows of the range; the ids of
 // the step are streamed twice from L2 (mark, then emit).  No HBM table is touched.
-constexpr int DD_WORDS = 16384;                 // 32-bit words per bitmap
-constexpr int DD_ROWS = DD_WORDS * 32;          // rows covered by one workgroup
+constexpr int DD_WORDS = 13312;                 // 32-bit words per bitmap
+constexpr int DD_ROWS = DD_WORDS * 32;          // rows covered by one workgroup (425984)
 constexpr int DD_THREADS = 1024;
-constexpr int DD_LDS_BYTES = 2 * DD_WORDS * 4;  // 128 KiB
+constexpr int DD_LDS_BYTES = 3 * DD_WORDS * 4;  // three bitmaps: seen / seen twice / seen three times (156 KiB of the 160 KiB LDS)
 
 // visit every reference j in [0, n) of a table's id stream (segment A of length nA, then
 // segment B); int4 loads when both segments are 16-byte aligned multiples of 4
 template <class F>
 __device__ __forceinline__ void for_each_ref(const int32_t* idsA, int64_t nA, const int32_t* idsB, int64_t n, bool vec, F f) {
     if (vec) {
+        // four independent 16-byte loads in flight per thread: the scan is latency-bound otherwise
         const int64_t n4 = n >> 2, nA4 = nA >> 2;
-        for (int64_t q = threadIdx.x; q < n4; q += DD_THREADS) {
-            const int4 v = q < nA4 ? reinterpret_cast<const int4*>(idsA)[q] : reinterpret_cast<const int4*>(idsB)[q - nA4];
-            f(4 * q + 0, v.x); f(4 * q + 1, v.y); f(4 * q + 2, v.z); f(4 * q + 3, v.w);
+        for (int64_t q0 = threadIdx.x; q0 < n4; q0 += 4 * DD_THREADS) {
+            int4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t q = q0 + (int64_t)k * DD_THREADS;
+                if (q < n4) v[k] = q < nA4 ? reinterpret_cast<const int4*>(idsA)[q] : reinterpret_cast<const int4*>(idsB)[q - nA4];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t q = q0 + (int64_t)k * DD_THREADS;
+                if (q < n4) { f(4 * q + 0, v[k].x); f(4 * q + 1, v[k].y); f(4 * q + 2, v[k].z); f(4 * q + 3, v[k].w); }
+            }
         }
     } else {
         for (int64_t j = threadIdx.x; j < n; j += DD_THREADS) f(j, j < nA ? idsA[j] : idsB[j - nA]);
@@ -69,6 +86,7 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned int dd_lds[];
     unsigned int* seen = dd_lds;
     unsigned int* dup = dd_lds + DD_WORDS;
+    unsigned int* tri = dd_lds + 2 * DD_WORDS;
     __shared__ int list_base;
     __shared__ int list_cnt;
     const int per_step = a.nbu + a.nbi;
@@ -85,6 +103,7 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
     const int64_t ref0 = is_user ? 0 : a.nU;
     unsigned char* dflag = a.dflag ? a.dflag + s * a.flag_stride : nullptr;
     int32_t* ids_out = a.ids_out ? a.ids_out + s * a.flag_stride : nullptr;
+    unsigned char* roles = a.roles ? a.roles + s * a.flag_stride : nullptr;
     // position of reference j in ids_out: [role][role_stride] (role 0 user, 1 pos item, 2 neg item)
     auto out_index = [&](int64_t j) -> int64_t {
         if (a.role_stride == 0) return ref0 + j;
@@ -93,7 +112,7 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
     };
     const bool vec = ((nA & 3) == 0) && ((n & 3) == 0) && ((((uintptr_t)idsA) | ((uintptr_t)idsB)) & 15) == 0;
 
-    for (int i = threadIdx.x; i < 2 * DD_WORDS; i += DD_THREADS) dd_lds[i] = 0u;
+    for (int i = threadIdx.x; i < 3 * DD_WORDS; i += DD_THREADS) dd_lds[i] = 0u;
     if (threadIdx.x == 0) list_cnt = 0;
     __syncthreads();
     for_each_ref(idsA, nA, idsB, n, vec, [&](int64_t j, int id) {
@@ -101,7 +120,13 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
         if ((uint64_t)l < (uint64_t)DD_ROWS && id_ok(id, rows)) {
             const unsigned int bit = 1u << (l & 31);
             const unsigned int old = atomicOr(&seen[l >> 5], bit);
-            if (old & bit) atomicOr(&dup[l >> 5], bit);
+            int role = 0;                                    // 0: first reference of the row, 1: second, 2: later
+            if (old & bit) {
+                const unsigned int old2 = atomicOr(&dup[l >> 5], bit);
+                role = 1;
+                if (old2 & bit) { atomicOr(&tri[l >> 5], bit); role = 2; }
+            }
+            if (roles) roles[out_index(j)] = (unsigned char)role;
             if (a.first_only) dflag[ref0 + j] = (old & bit) ? 1 : 0;
         }
     });
@@ -113,7 +138,16 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
         if ((uint64_t)l < (uint64_t)DD_ROWS && ok) {
             const unsigned int d = (dup[l >> 5] >> (l & 31)) & 1u;
             if (dflag) dflag[ref0 + j] = (unsigned char)d;
-            if (ids_out) ids_out[out_index(j)] = (int32_t)((uint32_t)id | (d << 31));
+            if (ids_out) {
+                uint32_t v = (uint32_t)id | (d << 31);
+                if (roles && d) {
+                    // rows with exactly two references: one plain store each into two scratch rows;
+                    // three or more: every reference uses atomics (role 2)
+                    const unsigned int t3 = (tri[l >> 5] >> (l & 31)) & 1u;
+                    v |= (t3 ? 2u : (uint32_t)roles[out_index(j)]) << 29;
+                }
+                ids_out[out_index(j)] = (int32_t)v;
+            }
         } else if (!ok && bk == 0 && ids_out) {
             ids_out[out_index(j)] = 0x7fffffff;              // out-of-range id: can never be a valid row
         }
@@ -159,8 +193,8 @@ int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K) {
 
 // -------------------------------------------------- loss partial reduction ---
 // One block per step: sum nwaves x {loss, l2} fp32 partials in fp64.
-__global__ __launch_bounds__(256) void loss_reduce_kernel(ReduceArgs a) {
-    __shared__ double sh[2][4];
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(ReduceArgs a) {
+    __shared__ double sh[2][16];
     const float* part = a.partial + (size_t)blockIdx.x * a.nwaves * 2;
     double s0 = 0.0, s1 = 0.0;
     for (int i = threadIdx.x; i < a.nwaves; i += blockDim.x) {
@@ -176,16 +210,34 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(ReduceArgs a) {
     if ((threadIdx.x & 63) == 0) { sh[0][w] = s0; sh[1][w] = s1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        a.out[2 * blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-        a.out[2 * blockIdx.x + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        double t0 = 0.0, t1 = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { t0 += sh[0][k]; t1 += sh[1][k]; }
+        a.out[2 * blockIdx.x] = t0;
+        a.out[2 * blockIdx.x + 1] = t1;
     }
 }
 
 int orx_launch_loss_reduce(orx_ctx* ctx, const ReduceArgs& a, int64_t K) {
     ProfScope ps(ctx, ORX_K_REDUCE);
-    ORX_LAUNCH(ctx, loss_reduce_kernel, dim3((unsigned)K), dim3(256), 0, a);
+    ORX_LAUNCH(ctx, loss_reduce_kernel, dim3((unsigned)K), dim3(1024), 0, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
+}
+
+// Gradient of a duplicated reference.  Rows referenced exactly twice in the batch get one PLAIN
+// store per reference, into scratch row 1 (role 0) or scratch row 2 (role 1): no atomics and a
+// summation that is bitwise reproducible.  Rows referenced three or more times (role 2) use
+// fp32 atomics into scratch row 1.  dup_apply_kernel adds the two scratch rows.
+__device__ __forceinline__ void dup_store4(float* G1, float* G2, size_t off, f4 g, int role) {
+    if (role == 0) *reinterpret_cast<f4*>(G1 + off) = g;
+    else if (role == 1) *reinterpret_cast<f4*>(G2 + off) = g;
+    else atomic_add_f4(G1 + off, g);
+}
+
+__device__ __forceinline__ void dup_store1(float* G1, float* G2, size_t off, float g, int role) {
+    if (role == 0) G1[off] = g;
+    else if (role == 1) G2[off] = g;
+    else unsafeAtomicAdd(G1 + off, g);
 }
 
 // ------------------------------------------------------------ fused kernel ---
@@ -204,9 +256,15 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     for (int64_t t = wave_global * TPW + grp; t < a.B; t += stride) {
         int u = a.uid[t], p = a.pid[t], n = a.nid[t];
         int du = 0, dp = 0, dn = 0;
+        int ku = 2, kp = 2, kn = 2;     // duplicate role: 0 / 1 = plain store into scratch row 1 / 2, 2 = atomics
         if (MODE == MODE_EXACT) {       // ids rewritten by dedup_kernel: bit 31 = "row is referenced more than once"
             du = (uint32_t)u >> 31; dp = (uint32_t)p >> 31; dn = (uint32_t)n >> 31;
-            u &= 0x7fffffff; p &= 0x7fffffff; n &= 0x7fffffff;
+            if (a.role_bits) {          // bits 30:29 = role of this reference among the row's references
+                ku = ((uint32_t)u >> 29) & 3; kp = ((uint32_t)p >> 29) & 3; kn = ((uint32_t)n >> 29) & 3;
+                u &= 0x1fffffff; p &= 0x1fffffff; n &= 0x1fffffff;
+            } else {
+                u &= 0x7fffffff; p &= 0x7fffffff; n &= 0x7fffffff;
+            }
         }
         if (MODE == MODE_ACCUM) { du = dp = dn = 1; }
         // bitwise &: all three id loads are issued together (a short-circuit && lets the compiler
@@ -235,20 +293,20 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
 
         // unique row: in place.  duplicated row: gradient into gsum, row untouched.
         if (du == 0) opt_apply4<OPT>(Up, a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
-        else atomic_add_f4(a.gU + (size_t)u * D + 4 * sub, gu);
+        else dup_store4(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku);
         if (dp == 0) {
             opt_apply4<OPT>(Pp, a.aV + (size_t)p * D + 4 * sub, rp, gp, a.lr, a.eps);
             if (sub == 0) opt_apply1<OPT>(a.b + p, a.ab + p, bp, gbp, a.lr, a.eps);
         } else {
-            atomic_add_f4(a.gV + (size_t)p * D + 4 * sub, gp);
-            if (sub == 0) unsafeAtomicAdd(a.gb + p, gbp);
+            dup_store4(a.gV, a.gV2, (size_t)p * D + 4 * sub, gp, kp);
+            if (sub == 0) dup_store1(a.gb, a.gb2, p, gbp, kp);
         }
         if (dn == 0) {
             opt_apply4<OPT>(Np, a.aV + (size_t)n * D + 4 * sub, rn, gn, a.lr, a.eps);
             if (sub == 0) opt_apply1<OPT>(a.b + n, a.ab + n, bn, gbn, a.lr, a.eps);
         } else {
-            atomic_add_f4(a.gV + (size_t)n * D + 4 * sub, gn);
-            if (sub == 0) unsafeAtomicAdd(a.gb + n, gbn);
+            dup_store4(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn);
+            if (sub == 0) dup_store1(a.gb, a.gb2, n, gbn, kn);
         }
     }
     const float ls = wave_sum(loss_acc);
@@ -276,16 +334,22 @@ __global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
         float* W = item ? a.V : a.U;
         float* G = item ? a.gV : a.gU;
         float* A = item ? a.aV : a.aU;
+        float* G2 = item ? a.gV2 : a.gU2;
         float* gp = G + row * D + 4 * sub;
         float* wp = W + row * D + 4 * sub;
-        const f4 g = *reinterpret_cast<const f4*>(gp);
+        f4 g = *reinterpret_cast<const f4*>(gp);
         const f4 w = *reinterpret_cast<const f4*>(wp);
         f4 z; z.x = z.y = z.z = z.w = 0.0f;
         *reinterpret_cast<f4*>(gp) = z;
+        if (G2 != nullptr) {
+            g = g + *reinterpret_cast<const f4*>(G2 + row * D + 4 * sub);
+            *reinterpret_cast<f4*>(G2 + row * D + 4 * sub) = z;
+        }
         opt_apply4<OPT>(wp, A + row * D + 4 * sub, w, g, a.lr, a.eps);
         if (item && a.b != nullptr && sub == 0) {
-            const float gb = a.gb[row];
+            float gb = a.gb[row];
             a.gb[row] = 0.0f;
+            if (a.gb2 != nullptr) { gb += a.gb2[row]; a.gb2[row] = 0.0f; }
             opt_apply1<OPT>(a.b + row, a.ab + row, a.b[row], gb, a.lr, a.eps);
         }
     }
@@ -304,15 +368,18 @@ __global__ __launch_bounds__(256) void dup_apply_generic_kernel(PairArgs a) {
         float* W = item ? a.V : a.U;
         float* G = item ? a.gV : a.gU;
         float* A = item ? a.aV : a.aU;
+        float* G2 = item ? a.gV2 : a.gU2;
         for (int k = lane; k < D; k += 64) {
             const size_t i = row * D + k;
-            const float g = G[i];
+            float g = G[i];
             G[i] = 0.0f;
+            if (G2 != nullptr) { g += G2[i]; G2[i] = 0.0f; }
             opt_apply1<OPT>(W + i, A + i, W[i], g, a.lr, a.eps);
         }
         if (item && a.b != nullptr && lane == 0) {
-            const float gb = a.gb[row];
+            float gb = a.gb[row];
             a.gb[row] = 0.0f;
+            if (a.gb2 != nullptr) { gb += a.gb2[row]; a.gb2[row] = 0.0f; }
             opt_apply1<OPT>(a.b + row, a.ab + row, a.b[row], gb, a.lr, a.eps);
         }
     }
@@ -331,9 +398,15 @@ __global__ __launch_bounds__(256) void fused_generic_kernel(PairArgs a) {
     for (int64_t t = wave_global; t < a.B; t += stride) {
         int u = a.uid[t], p = a.pid[t], n = a.nid[t];
         int du = 0, dp = 0, dn = 0;
+        int ku = 2, kp = 2, kn = 2;     // duplicate role: 0 / 1 = plain store into scratch row 1 / 2, 2 = atomics
         if (MODE == MODE_EXACT) {       // ids rewritten by dedup_kernel: bit 31 = "row is referenced more than once"
             du = (uint32_t)u >> 31; dp = (uint32_t)p >> 31; dn = (uint32_t)n >> 31;
-            u &= 0x7fffffff; p &= 0x7fffffff; n &= 0x7fffffff;
+            if (a.role_bits) {          // bits 30:29 = role of this reference among the row's references
+                ku = ((uint32_t)u >> 29) & 3; kp = ((uint32_t)p >> 29) & 3; kn = ((uint32_t)n >> 29) & 3;
+                u &= 0x1fffffff; p &= 0x1fffffff; n &= 0x1fffffff;
+            } else {
+                u &= 0x7fffffff; p &= 0x7fffffff; n &= 0x7fffffff;
+            }
         }
         if (MODE == MODE_ACCUM) { du = dp = dn = 1; }
         // bitwise &: all three id loads are issued together (a short-circuit && lets the compiler
@@ -368,18 +441,18 @@ __global__ __launch_bounds__(256) void fused_generic_kernel(PairArgs a) {
                 gu = -a2 * (y - z) + a.l2w * x; gp = -a2 * (x - y) + a.l2w * y; gn = a2 * (x - z) + a.l2w * z;
             }
             if (du == 0) opt_apply1<OPT>(Ur + e, a.aU + (size_t)u * D + e, x, gu, a.lr, a.eps);
-            else unsafeAtomicAdd(a.gU + (size_t)u * D + e, gu);
+            else dup_store1(a.gU, a.gU2, (size_t)u * D + e, gu, ku);
             if (dp == 0) opt_apply1<OPT>(Pr + e, a.aV + (size_t)p * D + e, y, gp, a.lr, a.eps);
-            else unsafeAtomicAdd(a.gV + (size_t)p * D + e, gp);
+            else dup_store1(a.gV, a.gV2, (size_t)p * D + e, gp, kp);
             if (dn == 0) opt_apply1<OPT>(Nr + e, a.aV + (size_t)n * D + e, z, gn, a.lr, a.eps);
-            else unsafeAtomicAdd(a.gV + (size_t)n * D + e, gn);
+            else dup_store1(a.gV, a.gV2, (size_t)n * D + e, gn, kn);
         }
         const float gbp = MODEL == ORX_BPR ? g : -g, gbn = -gbp;
         if (lane == 0) {
             if (dp == 0) opt_apply1<OPT>(a.b + p, a.ab + p, bp, gbp, a.lr, a.eps);
-            else unsafeAtomicAdd(a.gb + p, gbp);
+            else dup_store1(a.gb, a.gb2, p, gbp, kp);
             if (dn == 0) opt_apply1<OPT>(a.b + n, a.ab + n, bn, gbn, a.lr, a.eps);
-            else unsafeAtomicAdd(a.gb + n, gbn);
+            else dup_store1(a.gb, a.gb2, n, gbn, kn);
         }
     }
     const float ls = wave_sum(loss_acc);

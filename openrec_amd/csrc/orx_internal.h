@@ -50,6 +50,7 @@ struct orx_ctx {
     float* d_lab = nullptr;    size_t d_lab_cap = 0;
     unsigned char* d_dflag = nullptr; size_t d_dflag_cap = 0;   // [K][2B] duplicate flags (pointwise, censor)
     int32_t* d_ids2 = nullptr; size_t d_ids2_cap = 0;            // [K][3B] ids with the duplicate flag in bit 31
+    unsigned char* d_roles = nullptr; size_t d_roles_cap = 0;    // [K][3B] dedup scratch
     uint32_t* d_dlist = nullptr; size_t d_dlist_cap = 0;         // [K][2B] duplicated rows
     int* d_dcount = nullptr;   size_t d_dcount_cap = 0;          // [K]
     float* d_partial = nullptr; size_t d_partial_cap = 0;   // [K][nwaves][2] loss partials
@@ -70,6 +71,7 @@ struct orx_table {
     bool owned = true;
     // per-step scratch, allocated on first use by a train step
     float* gsum = nullptr;            // [rows, dim] duplicate-row gradient sums (all-zero between steps)
+    float* gsum2 = nullptr;           // second scratch rows of the pairwise step (rows referenced exactly twice)
 };
 
 struct OptSlots {
@@ -87,7 +89,7 @@ struct orx_opt {
 
 // ------------------------------------------------------- helpers (api.hip) ---
 int orx_ensure(void** p, size_t* cap, size_t bytes);           // grow a device buffer
-int orx_table_scratch(orx_table* t);                            // allocate gsum
+int orx_table_scratch(orx_table* t, bool second = false);       // allocate gsum (and gsum2)
 int orx_opt_slots(orx_opt* opt, orx_table* t, OptSlots* out);   // allocate optimizer slots
 int stage_ids(orx_ctx* c, const int32_t* host, int64_t n, int64_t off);   // H2D into ctx->d_ids
 int fetch_losses(orx_ctx* c, int64_t K, float* loss_out, float* l2_out);
@@ -117,8 +119,10 @@ struct ProfScope {
 struct PairArgs {
     float* U; float* V; float* b;
     float* gU; float* gV; float* gb;          // duplicate-row gradient sums (zero between steps)
+    float* gU2; float* gV2; float* gb2;       // second scratch rows (rows referenced exactly twice), may be NULL
     float* aU; float* aV; float* ab;          // Adagrad accumulators
     const int32_t* uid; const int32_t* pid; const int32_t* nid;
+    int role_bits;                            // ids carry the duplicate role in bits 30:29 (tables < 2^29 rows)
     const uint32_t* dlist;                    // duplicated rows of this step
     const int* dcount;
     int64_t B; int64_t NU; int64_t NI;
@@ -133,6 +137,7 @@ struct DedupArgs {
     int64_t id_stride;                        // elements between consecutive steps
     unsigned char* dflag;                     // [K][flag_stride] or NULL
     int32_t* ids_out;                         // [K][flag_stride] or NULL: id | (dup << 31); 0x7fffffff = invalid id
+    unsigned char* roles;                     // [K][flag_stride] scratch (pass 1 -> pass 2) or NULL: no role bits
     int64_t role_stride;                      // ids_out layout [3][role_stride] per step (0: compact reference order)
     uint32_t* dlist;                          // [K][list_stride]
     int* dcount;                              // [K], zeroed before the launch
