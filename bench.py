@@ -92,8 +92,7 @@ def main():
     ap.add_argument("--hogwild", action="store_true", help="racy non-reference mode (never the headline)")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded engine even on one GPU (debug)")
     ap.add_argument("--censor", action="store_true",
-                    help="UCML: LatentFactor.censor of the touched rows after every step (ucml.py:44-48); "
-                         "steps are then issued one call at a time")
+                    help="UCML: LatentFactor.censor of the touched rows after every step (ucml.py:44-48)")
     args = ap.parse_args()
 
     import torch
@@ -125,16 +124,9 @@ def main():
         torch.cuda.synchronize()
 
         def run(first, count, want_loss=False):
-            if args.censor:                     # BASELINE configs[2]: censor after each step
-                out = None
-                for s in range(first, first + count):
-                    out = rt.pairwise_step(args.model, opt, U, V, b, uid[s], pid[s], nid[s], K=1, B=args.batch,
-                                           margin=0.5, hogwild=args.hogwild, want_loss=want_loss and s == first + count - 1)
-                    U.censor(uid[s]); V.censor(pid[s]); V.censor(nid[s])
-                return out
             return rt.pairwise_step(args.model, opt, U, V, b, uid[first:first + count], pid[first:first + count],
                                     nid[first:first + count], K=count, B=args.batch, margin=0.5,
-                                    hogwild=args.hogwild, want_loss=want_loss)
+                                    hogwild=args.hogwild, want_loss=want_loss, censor=args.censor)
 
         if W:
             run(0, W)

@@ -56,8 +56,11 @@ enum orx_flags {
     ORX_IDS_DEVICE = 1,   /* id / label pointers are device pointers            */
     ORX_HOGWILD = 2,      /* skip duplicate handling: one in-place racy pass
                              (NOT reference semantics; speed comparisons only)  */
-    ORX_NO_L2 = 4         /* objective = loss only (tape over `loss` alone)
+    ORX_NO_L2 = 4,        /* objective = loss only (tape over `loss` alone)
                              instead of the example's (loss, l2_loss) tuple     */
+    ORX_CENSOR = 8        /* orx_pairwise_step: after every step, UCML.censor_vec
+                             (ucml.py:44-48) on that step's ids: users, then pos
+                             items, then neg items, min_norm 0.1                */
 };
 
 /* kernels whose device time can be sampled with orx_prof_* */

@@ -14,7 +14,7 @@ ORX_OK, ORX_ERR_ARG, ORX_ERR_HIP, ORX_ERR_OOM, ORX_ERR_INDEX, ORX_ERR_STATE = 0,
 ORX_SGD, ORX_ADAGRAD, ORX_ADAM = 0, 1, 2
 ORX_BPR, ORX_UCML = 0, 1
 ORX_GMF, ORX_WRMF = 0, 1
-ORX_IDS_DEVICE, ORX_HOGWILD, ORX_NO_L2 = 1, 2, 4
+ORX_IDS_DEVICE, ORX_HOGWILD, ORX_NO_L2, ORX_CENSOR = 1, 2, 4, 8
 ORX_DLRM_INTERACT_ITSELF, ORX_DLRM_SIGMOID_BOT, ORX_DLRM_SIGMOID_TOP, ORX_DLRM_LOSS_BCE, ORX_DLRM_REFERENCE_COMPAT = 1, 2, 4, 8, 16
 ORX_K_DEDUP, ORX_K_FUSED, ORX_K_REDUCE, ORX_K_SWEEP, ORX_K_CENSOR, ORX_K_POINT, ORX_K_DUPAPPLY, ORX_K_NUM = 0, 1, 2, 3, 4, 5, 6, 7
 KERNEL_NAMES = {ORX_K_DEDUP: "dedup", ORX_K_FUSED: "fused", ORX_K_REDUCE: "loss_reduce", ORX_K_SWEEP: "adam_sweep",

@@ -97,7 +97,7 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_dlist);
+    hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_cflag); hipFree(c->d_dlist);
     hipFree(c->d_dcount); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -457,6 +457,21 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));
             CHECK(orx_launch_dedup(c, d, kc));
         }
+        const bool censor = (flags & ORX_CENSOR) != 0;
+        if (censor) {
+            // one elected reference per distinct row of each of the three id lists, for every step of the chunk
+            ENSURE(c->d_cflag, c->d_cflag_cap, (size_t)3 * kc * B);
+            const int32_t* lists[3] = {du + s0 * ds, dp + s0 * ds, dn + s0 * ds};
+            const int64_t rows[3] = {U->rows, V->rows, V->rows};
+            for (int l = 0; l < 3; ++l) {
+                DedupArgs d;
+                memset(&d, 0, sizeof(d));
+                d.uid = lists[l]; d.pid = lists[l]; d.nid = lists[l]; d.id_stride = ds;
+                d.dflag = c->d_cflag + (size_t)l * kc * B; d.flag_stride = B;
+                d.nU = B; d.NU = rows[l]; d.nbu = orx_dedup_buckets(rows[l]); d.first_only = 1;
+                CHECK(orx_launch_dedup(c, d, kc));
+            }
+        }
         for (int64_t i = 0; i < kc; ++i) {
             const int64_t s = s0 + i;
             if (mode == MODE_EXACT) {       // ids rewritten by dedup (duplicate flag in bit 31)
@@ -475,6 +490,13 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
                 CHECK(orx_launch_adam_sweep(c, U->w, sU.s0, sU.s1, U->gsum, U->rows * U->dim, lr_t, opt->p0, opt->p1, opt->p2));
                 CHECK(orx_launch_adam_sweep(c, V->w, sV.s0, sV.s1, V->gsum, V->rows * V->dim, lr_t, opt->p0, opt->p1, opt->p2));
                 CHECK(orx_launch_adam_sweep(c, b->w, sb.s0, sb.s1, b->gsum, b->rows, lr_t, opt->p0, opt->p1, opt->p2));
+            }
+            if (censor) {                   // ucml.py:44-48: users and pos items (two tables), then neg items
+                const unsigned char* fu = c->d_cflag + (size_t)i * B;
+                const unsigned char* fp = c->d_cflag + (size_t)(kc + i) * B;
+                const unsigned char* fn = c->d_cflag + (size_t)(2 * kc + i) * B;
+                CHECK(orx_launch_censor2(c, U->w, fu, U->rows, du + s * ds, B, V->w, fp, V->rows, dp + s * ds, B, U->dim, 0.1f));
+                CHECK(orx_launch_censor2(c, V->w, fn, V->rows, dn + s * ds, B, nullptr, nullptr, 0, nullptr, 0, U->dim, 0.1f));
             }
         }
         ReduceArgs r;

@@ -94,15 +94,21 @@ __device__ __forceinline__ float wave_sum_f(float x) {
     return x;
 }
 
-__global__ __launch_bounds__(256) void censor_apply_kernel(float* w, const unsigned char* dflag, int64_t rows, int dim,
-                                                           const int32_t* ids, int64_t n, float min_norm, int* err) {
+struct CensorSeg { float* w; const unsigned char* dflag; const int32_t* ids; int64_t n; int64_t rows; };
+
+// One wavefront per id of segment A, then of segment B (two independent tables in one launch).
+__global__ __launch_bounds__(256) void censor_apply_kernel(CensorSeg A, CensorSeg B, int dim, float min_norm, int* err) {
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * 4;
-    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += stride) {
-        const int r = ids[i];
-        if ((uint32_t)r >= (uint64_t)rows) { if (lane == 0) *err = 1; continue; }
-        if (dflag[i]) continue;                               // another reference of this row applies
-        float* row = w + (size_t)r * dim;
+    const int64_t total = A.n + B.n;
+    for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < total; k += stride) {
+        const bool inA = k < A.n;
+        const CensorSeg& S = inA ? A : B;
+        const int64_t i = inA ? k : k - A.n;
+        const int r = S.ids[i] & 0x7fffffff;
+        if ((uint32_t)S.ids[i] >= (uint64_t)S.rows) { if (lane == 0) *err = 1; continue; }
+        if (S.dflag[i]) continue;                             // another reference of this row applies
+        float* row = S.w + (size_t)r * dim;
         float s = 0.0f;
         for (int e = lane; e < dim; e += 64) s += row[e] * row[e];
         const float den = fmaxf(sqrtf(wave_sum_f(s)), min_norm);   // tf.norm, maximum(norm, 0.1)
@@ -114,7 +120,19 @@ int orx_launch_censor(orx_ctx* ctx, float* w, const unsigned char* dflag, int64_
                       int64_t n, float min_norm, int* err) {
     if (n == 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_CENSOR);
-    ORX_LAUNCH(ctx, censor_apply_kernel, dim3(grid_for(n, 4)), dim3(256), 0, w, dflag, rows, dim, ids, n, min_norm, err);
+    CensorSeg A{w, dflag, ids, n, rows}, B{nullptr, nullptr, nullptr, 0, 0};
+    ORX_LAUNCH(ctx, censor_apply_kernel, dim3(grid_for(n, 4)), dim3(256), 0, A, B, dim, min_norm, err);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_launch_censor2(orx_ctx* ctx, float* wA, const unsigned char* fA, int64_t rowsA, const int32_t* idsA, int64_t nA,
+                       float* wB, const unsigned char* fB, int64_t rowsB, const int32_t* idsB, int64_t nB,
+                       int dim, float min_norm) {
+    if (nA + nB == 0) return ORX_OK;
+    ProfScope ps(ctx, ORX_K_CENSOR);
+    CensorSeg A{wA, fA, idsA, nA, rowsA}, B{wB, fB, idsB, nB, rowsB};
+    ORX_LAUNCH(ctx, censor_apply_kernel, dim3(grid_for(nA + nB, 4)), dim3(256), 0, A, B, dim, min_norm, ctx->d_err);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

@@ -51,6 +51,7 @@ struct orx_ctx {
     unsigned char* d_dflag = nullptr; size_t d_dflag_cap = 0;   // [K][2B] duplicate flags (pointwise, censor)
     int32_t* d_ids2 = nullptr; size_t d_ids2_cap = 0;            // [K][3B] ids with the duplicate flag in bit 31
     unsigned char* d_roles = nullptr; size_t d_roles_cap = 0;    // [K][3B] dedup scratch
+    unsigned char* d_cflag = nullptr; size_t d_cflag_cap = 0;    // [3][K][B] censor election flags
     uint32_t* d_dlist = nullptr; size_t d_dlist_cap = 0;         // [K][2B] duplicated rows
     int* d_dcount = nullptr;   size_t d_dcount_cap = 0;          // [K]
     float* d_partial = nullptr; size_t d_partial_cap = 0;   // [K][nwaves][2] loss partials
@@ -225,6 +226,9 @@ int orx_launch_gather(orx_ctx* ctx, const float* w, const float* bias, int64_t r
                       int skip_negative = 0);
 int orx_launch_censor(orx_ctx* ctx, float* w, const unsigned char* dflag, int64_t rows, int dim, const int32_t* ids,
                       int64_t n, float min_norm, int* err);
+int orx_launch_censor2(orx_ctx* ctx, float* wA, const unsigned char* fA, int64_t rowsA, const int32_t* idsA, int64_t nA,
+                       float* wB, const unsigned char* fB, int64_t rowsB, const int32_t* idsB, int64_t nB,
+                       int dim, float min_norm);
 int orx_launch_adam_sweep(orx_ctx* ctx, float* w, float* m, float* v, float* gsum, int64_t n,
                           float lr_t, float b1, float b2, float eps);
 

@@ -176,7 +176,7 @@ class Optimizer:
 
 
 def pairwise_step(model, opt, user, item, bias, uid, pid, nid, K=1, B=None, id_stride=None,
-                  margin=0.5, hogwild=False, no_l2=False, want_loss=True):
+                  margin=0.5, hogwild=False, no_l2=False, want_loss=True, censor=False):
     """K fused train steps.  Returns (loss[K], l2[K]) as numpy float32 when
     want_loss, else None (fully asynchronous)."""
     lib = user.ctx._lib
@@ -189,7 +189,8 @@ def pairwise_step(model, opt, user, item, bias, uid, pid, nid, K=1, B=None, id_s
         B = nu // K
     if id_stride is None:
         id_stride = B
-    flags = (_ffi.ORX_IDS_DEVICE if du else 0) | (_ffi.ORX_HOGWILD if hogwild else 0) | (_ffi.ORX_NO_L2 if no_l2 else 0)
+    flags = ((_ffi.ORX_IDS_DEVICE if du else 0) | (_ffi.ORX_HOGWILD if hogwild else 0)
+             | (_ffi.ORX_NO_L2 if no_l2 else 0) | (_ffi.ORX_CENSOR if censor else 0))
     mid = {"bpr": _ffi.ORX_BPR, "ucml": _ffi.ORX_UCML}[model]
     if want_loss:
         loss = np.empty(K, np.float32)

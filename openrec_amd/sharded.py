@@ -68,8 +68,12 @@ class HipBackend:
         from . import runtime as rt, _ffi
         self.rt, self._ffi = rt, _ffi
         self.device = device
-        stream = torch.cuda.current_stream(device).cuda_stream
-        self.ctx = rt.Context(device.index if device.index is not None else 0, stream=stream)
+        # A dedicated torch stream: the library enqueues its kernels on it and the step runs its
+        # torch ops / collectives under it, so kernels and RCCL exchanges are ordered by the stream.
+        # (torch's default stream has handle 0, which the C ABI reads as "create a private stream".)
+        self.stream = torch.cuda.Stream(device=device)
+        assert self.stream.cuda_stream != 0
+        self.ctx = rt.Context(device.index if device.index is not None else 0, stream=self.stream.cuda_stream)
         kw = opt_kw or {}
         if opt_kind == "sgd":
             self.opt = rt.Optimizer.sgd(lr, ctx=self.ctx)
@@ -119,6 +123,9 @@ class HipBackend:
         self._ffi.check(self.lib.orx_shard_grads(self.ctx._h, mid, user._h, rows_in.data_ptr(), u_loc.data_ptr(),
                                                  slot.data_ptr(), u_loc.numel(), rows_in.shape[1], b_global, margin, 0,
                                                  gu.data_ptr(), send_g.data_ptr(), accum.data_ptr()))
+
+    def stream_ctx(self):
+        return torch.cuda.stream(self.stream)
 
     def check(self):
         self.ctx.check_index_error()
@@ -204,6 +211,12 @@ class ShardedPairwise:
 
     def step(self, uid, pid, nid):
         """uid/pid/nid: int32 [B] on self.device -- this rank's slice of the global batch."""
+        if hasattr(self.be, "stream_ctx"):
+            with self.be.stream_ctx():
+                return self._step(uid, pid, nid)
+        return self._step(uid, pid, nid)
+
+    def _step(self, uid, pid, nid):
         if self.fast:
             return self._step_fast(uid, pid, nid)
         N, dev, DS, D = self.world, self.device, self.DS, self.dim
@@ -264,6 +277,8 @@ class ShardedPairwise:
     # ---- results -----------------------------------------------------------
     def loss_sums(self):
         """(sum over steps of loss, sum of l2_loss) over the global batch so far."""
+        if hasattr(self.be, "stream"):
+            self.be.stream.synchronize()
         t = self.accum.clone()
         if self.world > 1:
             dist.all_reduce(t, group=self.group)
@@ -271,6 +286,8 @@ class ShardedPairwise:
 
     def check(self):
         """Raise if an id was out of range or an exchange bucket overflowed (synchronizes)."""
+        if hasattr(self.be, "stream"):
+            self.be.stream.synchronize()
         if hasattr(self.be, "check"):
             self.be.check()
         ov = self.overflow.clone().to(torch.int32)

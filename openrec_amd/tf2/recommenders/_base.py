@@ -71,7 +71,7 @@ class PairwiseRecommender(Recommender):
 
     call = __call__
 
-    def train_steps(self, optimizer, user_id, p_item_id, n_item_id, K=None, want_loss=True):
+    def train_steps(self, optimizer, user_id, p_item_id, n_item_id, K=None, want_loss=True, censor=False):
         """Beyond the reference API: K consecutive fused steps in one device call
         (ids shaped [K, B]); the path `bench.py` measures."""
         U, V, b = self._tables()
@@ -80,4 +80,4 @@ class PairwiseRecommender(Recommender):
             K = uid.shape[0] if getattr(uid, "ndim", 1) == 2 else 1
         opt = optimizer.native(U.ctx) if hasattr(optimizer, "native") else optimizer
         return rt.pairwise_step(self._model, opt, U, V, b, uid, pid, nid, K=K, margin=self.margin,
-                                want_loss=want_loss)
+                                want_loss=want_loss, censor=censor)

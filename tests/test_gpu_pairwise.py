@@ -182,3 +182,25 @@ def test_loss_only_and_gather_and_censor():
     orc.censor(W, ids, 0.1)
     assert rel_err(tW.read(), W) < 1e-6
     assert np.array_equal(tW.read()[~np.isin(np.arange(500), ids)], W[~np.isin(np.arange(500), ids)])
+
+
+@pytest.mark.parametrize("D", [50, 128])
+def test_ucml_censor_inside_multi_step_call(D):
+    """ORX_CENSOR: UCML.censor_vec after every step of a K-step call (BASELINE configs[2])."""
+    rt = _rt()
+    from oracle import numpy_oracle as orc
+    K, B = 4, 1500
+    U, V, b, *_ = _rand_case(21, 900, 1100, B, D)
+    U *= 30; V *= 30                                   # norms around 1: the censor really rescales
+    rng = np.random.default_rng(5)
+    uid = rng.integers(0, 900, (K, B)).astype(np.int32); pid = rng.integers(0, 1100, (K, B)).astype(np.int32)
+    nid = rng.integers(0, 1100, (K, B)).astype(np.int32)
+    nid[:, :40] = pid[:, :40]                          # rows in both item lists are censored twice
+    tU, tV, tb = _tables(rt, U, V, b)
+    opt = rt.Optimizer.sgd(0.01)
+    loss, l2 = rt.pairwise_step("ucml", opt, tU, tV, tb, uid, pid, nid, K=K, B=B, margin=0.5, censor=True)
+    oo = orc.SGD(lr=0.01)
+    for s in range(K):
+        lr, _ = orc.ucml_step(U, V, b, uid[s], pid[s], nid[s], oo, margin=0.5, do_censor=True)
+        assert abs(loss[s] - lr) <= 2e-5 * abs(lr)
+    assert rel_err(tU.read(), U) < 2e-5 and rel_err(tV.read(), V) < 2e-5 and rel_err(tb.read(), b) < 2e-5
