@@ -128,6 +128,7 @@ def main():
                                     nid[first:first + count], K=count, B=args.batch, margin=0.5,
                                     hogwild=args.hogwild, want_loss=want_loss, censor=args.censor)
 
+        rt.pairwise_reserve(opt, U, V, b, max(K, W, 1), args.batch)     # allocations stay out of the timed region
         if W:
             run(0, W)
         ctx.synchronize()

@@ -139,6 +139,12 @@ int orx_pairwise_step(orx_ctx* ctx, int model, orx_opt* opt,
                       int64_t K, int64_t B, int64_t id_stride, float margin, int flags,
                       float* loss_out, float* l2_out);
 
+/* Pre-size every per-call scratch buffer for calls of up to K steps of B triplets on these tables
+ * (duplicate-detection outputs, rewritten ids, loss partials, scratch tables), so that a later
+ * orx_pairwise_step performs no device allocation.  Optional: buffers also grow on demand. */
+int orx_pairwise_reserve(orx_ctx* ctx, orx_opt* opt, orx_table* user, orx_table* item, orx_table* bias,
+                         int64_t K, int64_t B);
+
 /* Forward only: (loss, l2_loss) of one batch without touching the tables
  * (BPR.call / UCML.call outside a tape). */
 int orx_pairwise_loss(orx_ctx* ctx, int model,

@@ -52,6 +52,7 @@ SIGNATURES = {
     "orx_opt_slot_write": (c_int, [_p, _p, c_int, c_int64, c_int64, _fp]),
     "orx_pairwise_step": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, _ip, _ip, c_int64, c_int64, c_int64,
                                   c_float, c_int, _fp, _fp]),
+    "orx_pairwise_reserve": (c_int, [_p, _p, _p, _p, _p, c_int64, c_int64]),
     "orx_pairwise_loss": (c_int, [_p, c_int, _p, _p, _p, _ip, _ip, _ip, c_int64, c_float, c_int, _fp, _fp]),
     "orx_pointwise_step": (c_int, [_p, c_int, _p, _p, _p, _p, _p, _ip, _ip, _fp, c_int64, c_int64, c_int64,
                                    c_float, c_float, c_int, _fp, _fp]),

@@ -1,6 +1,7 @@
 // C-ABI entry points (include/openrec_hip.h): contexts, tables, optimizers and
 // the host-side sequencing of the train-step kernels.  No torch, no CPU
 // fallback: every entry point needs a usable HIP device.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -97,7 +98,7 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_cflag); hipFree(c->d_dlist);
+    hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_cflag); hipFree(c->d_dupbits); hipFree(c->d_dlist);
     hipFree(c->d_dcount); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -160,6 +161,7 @@ extern "C" int orx_table_destroy(orx_table* t) {
     if (t->owned) hipFree(t->w);
     hipFree(t->gsum);
     hipFree(t->gsum2);
+    hipFree(t->ready);
     delete t;
     return ORX_OK;
 }
@@ -178,6 +180,10 @@ int orx_table_scratch(orx_table* t, bool second) {
     if (second && !t->gsum2) {
         ORX_HIP(hipMalloc((void**)&t->gsum2, bytes));
         ORX_HIP(hipMemsetAsync(t->gsum2, 0, bytes, t->ctx->stream));
+    }
+    if (second && !t->ready) {
+        ORX_HIP(hipMalloc((void**)&t->ready, (size_t)t->rows * sizeof(int)));
+        ORX_HIP(hipMemsetAsync(t->ready, 0, (size_t)t->rows * sizeof(int), t->ctx->stream));
     }
     return ORX_OK;
 }
@@ -379,6 +385,34 @@ int fetch_losses(orx_ctx* c, int64_t K, float* loss_out, float* l2_out) {
     return ORX_OK;
 }
 
+struct PairPlan { int nw; int64_t chunk; int64_t list_stride; int64_t Bp; };
+
+// sizes every per-call buffer of the exact pairwise step (grow-only)
+static int pair_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t B, int mode, bool role_bits,
+                        bool inline_apply, int nb_total, PairPlan* plan) {
+    const int nw = orx_fused_nwaves(U->dim, B);
+    // steps are processed in chunks so that the per-step scratch stays bounded
+    int64_t chunk = (int64_t)((256ull << 20) / ((size_t)3 * B * sizeof(int32_t)));
+    if (chunk < 1) chunk = 1;
+    if (chunk > K) chunk = K;
+    ENSURE(c->d_partial, c->d_partial_cap, (size_t)chunk * nw * 2 * sizeof(float));
+    ENSURE(c->d_loss, c->d_loss_cap, (size_t)K * 2 * sizeof(double));
+    const int64_t list_stride = 2 * B;          // distinct duplicated rows <= B/2 (users) + B (items)
+    // the three rewritten id arrays of a step are padded apart: with B a power of two their
+    // addresses would otherwise differ by exact multiples of 256 KiB (same cache set / HBM channel)
+    const int64_t Bp = ((B + 3) / 4) * 4 + 96;
+    if (mode == MODE_EXACT) {
+        ENSURE(c->d_ids2, c->d_ids2_cap, (size_t)chunk * 3 * Bp * sizeof(int32_t));
+        if (role_bits) ENSURE(c->d_roles, c->d_roles_cap, (size_t)chunk * 3 * Bp);
+        if (inline_apply) ENSURE(c->d_dupbits, c->d_dupbits_cap, (size_t)chunk * nb_total * orx_dedup_words() * sizeof(unsigned int));
+        ENSURE(c->d_dlist, c->d_dlist_cap, (size_t)chunk * list_stride * sizeof(uint32_t));
+        ENSURE(c->d_dcount, c->d_dcount_cap, (size_t)chunk * sizeof(int));
+    }
+
+    plan->nw = nw; plan->chunk = chunk; plan->list_stride = list_stride; plan->Bp = Bp;
+    return ORX_OK;
+}
+
 extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
                                  orx_table* U, orx_table* V, orx_table* b,
                                  const int32_t* uid, const int32_t* pid, const int32_t* nid,
@@ -403,36 +437,27 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     const int mode = opt->kind == ORX_ADAM ? MODE_ACCUM : (hogwild ? MODE_HOGWILD : MODE_EXACT);
     // rows referenced exactly twice get plain stores into two scratch rows; the role of a reference
     // travels in bits 30:29 of its id, which needs tables below 2^29 rows
-    const bool role_bits = mode == MODE_EXACT && U->rows < (1LL << 29) && V->rows < (1LL << 29);
+    const bool role_bits = mode == MODE_EXACT && U->rows < (1LL << 28) && V->rows < (1LL << 28);
+    // the previous step's duplicated rows are applied by extra blocks of the next step's launch
+    // (no dup_apply launch, no kernel boundary) -- not with a censor pass between the steps
+    const bool inline_apply = role_bits && !(flags & ORX_CENSOR) && K > 1 && orx_fused_can_inline_apply(U->dim);
+    const int nb_total = orx_dedup_buckets(U->rows) + orx_dedup_buckets(V->rows);
     if (mode != MODE_HOGWILD) {
         CHECK(orx_table_scratch(U, role_bits)); CHECK(orx_table_scratch(V, role_bits)); CHECK(orx_table_scratch(b, role_bits));
     }
     OptSlots sU, sV, sb;
     CHECK(orx_opt_slots(opt, U, &sU)); CHECK(orx_opt_slots(opt, V, &sV)); CHECK(orx_opt_slots(opt, b, &sb));
 
-    const int nw = orx_fused_nwaves(U->dim, B);
-    // steps are processed in chunks so that the per-step scratch stays bounded
-    int64_t chunk = (int64_t)((256ull << 20) / ((size_t)3 * B * sizeof(int32_t)));
-    if (chunk < 1) chunk = 1;
-    if (chunk > K) chunk = K;
-    ENSURE(c->d_partial, c->d_partial_cap, (size_t)chunk * nw * 2 * sizeof(float));
-    ENSURE(c->d_loss, c->d_loss_cap, (size_t)K * 2 * sizeof(double));
-    const int64_t list_stride = 2 * B;          // distinct duplicated rows <= B/2 (users) + B (items)
-    // the three rewritten id arrays of a step are padded apart: with B a power of two their
-    // addresses would otherwise differ by exact multiples of 256 KiB (same cache set / HBM channel)
-    const int64_t Bp = ((B + 3) / 4) * 4 + 96;
-    if (mode == MODE_EXACT) {
-        ENSURE(c->d_ids2, c->d_ids2_cap, (size_t)chunk * 3 * Bp * sizeof(int32_t));
-        if (role_bits) ENSURE(c->d_roles, c->d_roles_cap, (size_t)chunk * 3 * Bp);
-        ENSURE(c->d_dlist, c->d_dlist_cap, (size_t)chunk * list_stride * sizeof(uint32_t));
-        ENSURE(c->d_dcount, c->d_dcount_cap, (size_t)chunk * sizeof(int));
-    }
+    PairPlan plan;
+    CHECK(pair_buffers(c, U, V, K, B, mode, role_bits, inline_apply, nb_total, &plan));
+    const int nw = plan.nw;
+    const int64_t chunk = plan.chunk, list_stride = plan.list_stride, Bp = plan.Bp;
 
     PairArgs a;
     memset(&a, 0, sizeof(a));
     a.U = U->w; a.V = V->w; a.b = b->w;
     a.gU = U->gsum; a.gV = V->gsum; a.gb = b->gsum;
-    if (role_bits) { a.gU2 = U->gsum2; a.gV2 = V->gsum2; a.gb2 = b->gsum2; a.role_bits = 1; }
+    if (role_bits) { a.gU2 = U->gsum2; a.gV2 = V->gsum2; a.gb2 = b->gsum2; a.role_bits = 1; a.readyU = U->ready; a.readyV = V->ready; }
     a.aU = sU.s0; a.aV = sV.s0; a.ab = sb.s0;
     a.B = B; a.NU = U->rows; a.NI = V->rows; a.D = U->dim;
     a.lr = opt->lr;
@@ -451,11 +476,13 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             d.uid = du + s0 * ds; d.pid = dp + s0 * ds; d.nid = dn + s0 * ds; d.id_stride = ds;
             d.dflag = nullptr; d.ids_out = c->d_ids2; d.dlist = c->d_dlist; d.dcount = c->d_dcount;
             d.roles = role_bits ? c->d_roles : nullptr;
+            d.dupbits = inline_apply ? c->d_dupbits : nullptr;
             d.flag_stride = 3 * Bp; d.role_stride = Bp; d.list_stride = list_stride;
             d.nU = B; d.nP = B; d.nN = B; d.NU = U->rows; d.NI = V->rows;
             d.nbu = orx_dedup_buckets(U->rows); d.nbi = orx_dedup_buckets(V->rows);
             ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));
             CHECK(orx_launch_dedup(c, d, kc));
+            if (inline_apply) CHECK(orx_launch_urgent(c, d, kc));
         }
         const bool censor = (flags & ORX_CENSOR) != 0;
         if (censor) {
@@ -481,8 +508,17 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             }
             a.dlist = c->d_dlist + (size_t)i * list_stride; a.dcount = c->d_dcount + i;
             a.partial = c->d_partial + (size_t)i * nw * 2;
+            if (inline_apply && i > 0) {    // this launch also applies the duplicated rows of step i-1
+                // one lane group per duplicated row in a single pass for the usual ~0.15*B duplicated rows
+                // (the count lives in device memory; surplus blocks exit, a larger count grid-strides)
+                a.n_apply_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(16, (B / 4) / (1024 / U->dim) + 1));
+                a.epoch = ++c->epoch;
+                a.prev_dlist = c->d_dlist + (size_t)(i - 1) * list_stride; a.prev_dcount = c->d_dcount + (i - 1);
+            } else {
+                a.n_apply_blocks = 0; a.prev_dlist = nullptr; a.prev_dcount = nullptr;
+            }
             CHECK(orx_launch_fused(c, model, opt->kind, mode, a));
-            if (mode == MODE_EXACT) CHECK(orx_launch_dup_apply(c, opt->kind, a));
+            if (mode == MODE_EXACT && (!inline_apply || i == kc - 1)) CHECK(orx_launch_dup_apply(c, opt->kind, a));
             if (mode == MODE_ACCUM) {   // Adam: dense-decay sweep of TF 2.0 over the whole tables
                 opt->t += 1;
                 const double b1 = opt->p0, b2 = opt->p1;
@@ -505,6 +541,24 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     }
     CHECK(fetch_losses(c, K, loss_out, l2_out));
     if (!(flags & ORX_IDS_DEVICE)) return orx_check_index_error(c);
+    return ORX_OK;
+}
+
+extern "C" int orx_pairwise_reserve(orx_ctx* c, orx_opt* opt, orx_table* U, orx_table* V, orx_table* b, int64_t K, int64_t B) {
+    ORX_ARG(c && opt, "orx_pairwise_reserve: NULL context/optimizer");
+    CHECK(check_pair_tables(U, V, b));
+    ORX_ARG(K > 0 && B > 0, "orx_pairwise_reserve: K and B must be positive");
+    ORX_HIP(hipSetDevice(c->device));
+    const int mode = opt->kind == ORX_ADAM ? MODE_ACCUM : MODE_EXACT;
+    const bool role_bits = mode == MODE_EXACT && U->rows < (1LL << 28) && V->rows < (1LL << 28);
+    const bool inline_apply = role_bits && K > 1 && orx_fused_can_inline_apply(U->dim);
+    const int nb_total = orx_dedup_buckets(U->rows) + orx_dedup_buckets(V->rows);
+    CHECK(orx_table_scratch(U, role_bits)); CHECK(orx_table_scratch(V, role_bits)); CHECK(orx_table_scratch(b, role_bits));
+    OptSlots s;
+    CHECK(orx_opt_slots(opt, U, &s)); CHECK(orx_opt_slots(opt, V, &s)); CHECK(orx_opt_slots(opt, b, &s));
+    PairPlan plan;
+    CHECK(pair_buffers(c, U, V, K, B, mode, role_bits, inline_apply, nb_total, &plan));
+    ORX_HIP(hipStreamSynchronize(c->stream));
     return ORX_OK;
 }
 

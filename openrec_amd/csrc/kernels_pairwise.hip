@@ -152,6 +152,10 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
             ids_out[out_index(j)] = 0x7fffffff;              // out-of-range id: can never be a valid row
         }
     });
+    if (a.dupbits != nullptr) {      // keep the "seen twice" bitmap of (step, range) for urgent_kernel
+        unsigned int* out = a.dupbits + ((size_t)s * per_step + (is_user ? bk : a.nbu + bk)) * DD_WORDS;
+        for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) out[w] = dup[w];
+    }
     // append the duplicated rows of this range to the step's list
     int mine = 0;
     for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) mine += __popc(dup[w]);
@@ -175,6 +179,7 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
 }
 
 int orx_dedup_buckets(int64_t rows) { return (int)((rows + DD_ROWS - 1) / DD_ROWS); }
+int orx_dedup_words(void) { return DD_WORDS; }
 
 int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K) {
     ProfScope ps(ctx, ORX_K_DEDUP);
@@ -187,6 +192,45 @@ int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K) {
         attr_set = true;
     }
     ORX_LAUNCH(ctx, dedup_kernel, dim3((unsigned)g), dim3(DD_THREADS), DD_LDS_BYTES, a);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// A reference of step s whose row was duplicated in step s-1 is "urgent": the row's update of step
+// s-1 is applied by the apply blocks of the SAME launch that processes step s (see fused_kernel),
+// so this reference has to wait for the row's ready flag.  Marks such references with bit 28.
+__global__ __launch_bounds__(DD_THREADS) void urgent_kernel(DedupArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int dd_lds[];
+    const int per_step = a.nbu + a.nbi;
+    const int64_t s = 1 + blockIdx.x / per_step;             // steps 1 .. K-1 of the chunk
+    int bk = blockIdx.x % per_step;
+    const unsigned int* prev = a.dupbits + ((size_t)(s - 1) * per_step + bk) * DD_WORDS;
+    const bool is_user = bk < a.nbu;
+    if (!is_user) bk -= a.nbu;
+    const int64_t r0 = (int64_t)bk * DD_ROWS;
+    const int64_t rows = is_user ? a.NU : a.NI;
+    const int64_t nA = is_user ? a.nU : a.nP;
+    const int32_t* idsA = (is_user ? a.uid : a.pid) + s * a.id_stride;
+    const int32_t* idsB = a.nid + s * a.id_stride;
+    const int64_t n = is_user ? a.nU : a.nP + a.nN;
+    int32_t* ids_out = a.ids_out + s * a.flag_stride;
+    const bool vec = ((nA & 3) == 0) && ((n & 3) == 0) && ((((uintptr_t)idsA) | ((uintptr_t)idsB)) & 15) == 0;
+    for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) dd_lds[w] = prev[w];
+    __syncthreads();
+    for_each_ref(idsA, nA, idsB, n, vec, [&](int64_t j, int id) {
+        const int64_t l = (int64_t)id - r0;
+        if ((uint64_t)l < (uint64_t)DD_ROWS && id_ok(id, rows) && ((dd_lds[l >> 5] >> (l & 31)) & 1u)) {
+            const int64_t idx = is_user ? j : (j < nA ? a.role_stride + j : 2 * a.role_stride + (j - nA));
+            ids_out[idx] |= (1 << 28);
+        }
+    });
+}
+
+int orx_launch_urgent(orx_ctx* ctx, const DedupArgs& a, int64_t K) {
+    ProfScope ps(ctx, ORX_K_DEDUP);
+    const int64_t g = (K - 1) * (a.nbu + a.nbi);
+    if (g <= 0) return ORX_OK;
+    ORX_LAUNCH(ctx, urgent_kernel, dim3((unsigned)g), dim3(DD_THREADS), DD_WORDS * 4, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -240,6 +284,79 @@ __device__ __forceinline__ void dup_store1(float* G1, float* G2, size_t off, flo
     else unsafeAtomicAdd(G1 + off, g);
 }
 
+// ---- in-launch application of the previous step's duplicated rows ------------------------
+// The first `n_apply_blocks` blocks of a fused launch of step s apply the summed gradients
+// that step s-1 left in the scratch rows (what dup_apply_kernel does as a launch of its own).
+// Hand-off to the references of step s that read such a row (marked "urgent" by
+// urgent_kernel), following the producer/consumer recipe of the CDNA guide:
+//   producer: row / accumulator / scratch-zero stores WRITE-THROUGH (agent-scope stores),
+//             s_waitcnt vmcnt(0), then ONE lane stores the row's ready flag (= epoch of this launch)
+//   consumer: one lane polls the flag with relaxed agent-scope loads, then an agent-scope acquire
+//             fence, then plain loads.
+// Apply blocks have the lowest block indices (dispatched first) and never wait, so a consumer
+// cannot starve them.
+__device__ __forceinline__ void store_wt(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_wt4(float* p, f4 v) {
+    // one 16-byte write-through (sc1) store; the caller drains it with s_waitcnt vmcnt(0)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+
+template <int OPT>
+__device__ __forceinline__ float opt_rule(float w, float g, float& acc, float lr, float eps) {
+    if (OPT == ORX_ADAGRAD) { acc = acc + g * g; return w - lr * g / (sqrtf(acc) + eps); }
+    return w - lr * g;
+}
+
+template <int LPR, int OPT>
+__device__ __forceinline__ void inline_apply(const PairArgs& a) {
+    constexpr int TPW = 64 / LPR;
+    constexpr int D = 4 * LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    const int n = *a.prev_dcount;
+    const int64_t stride = (int64_t)a.n_apply_blocks * 4 * TPW;
+    for (int64_t e = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + grp; e < n; e += stride) {
+        const uint32_t ent = a.prev_dlist[e];
+        const bool item = (ent >> 31) != 0;
+        const size_t row = ent & 0x7fffffffu;
+        float* W = item ? a.V : a.U;
+        float* A = item ? a.aV : a.aU;
+        float* g1 = (item ? a.gV : a.gU) + row * D + 4 * sub;
+        float* g2 = (item ? a.gV2 : a.gU2) + row * D + 4 * sub;
+        float* wp = W + row * D + 4 * sub;
+        const f4 g = *reinterpret_cast<const f4*>(g1) + *reinterpret_cast<const f4*>(g2);
+        const f4 w = *reinterpret_cast<const f4*>(wp);
+        f4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
+        if (OPT == ORX_ADAGRAD) acc = *reinterpret_cast<const f4*>(A + row * D + 4 * sub);
+        float ac[4] = {acc.x, acc.y, acc.z, acc.w};
+        f4 wn;
+        wn.x = opt_rule<OPT>(w.x, g.x, ac[0], a.lr, a.eps); wn.y = opt_rule<OPT>(w.y, g.y, ac[1], a.lr, a.eps);
+        wn.z = opt_rule<OPT>(w.z, g.z, ac[2], a.lr, a.eps); wn.w = opt_rule<OPT>(w.w, g.w, ac[3], a.lr, a.eps);
+        acc.x = ac[0]; acc.y = ac[1]; acc.z = ac[2]; acc.w = ac[3];
+        f4 z; z.x = z.y = z.z = z.w = 0.0f;
+        store_wt4(wp, wn);
+        store_wt4(g1, z);
+        store_wt4(g2, z);
+        if (OPT == ORX_ADAGRAD) store_wt4(A + row * D + 4 * sub, acc);
+        if (item && sub == 0) {
+            const float gb = a.gb[row] + a.gb2[row];
+            float ab = OPT == ORX_ADAGRAD ? a.ab[row] : 0.0f;
+            const float bn = opt_rule<OPT>(a.b[row], gb, ab, a.lr, a.eps);
+            store_wt(a.b + row, bn); store_wt(a.gb + row, 0.0f); store_wt(a.gb2 + row, 0.0f);
+            if (OPT == ORX_ADAGRAD) store_wt(a.ab + row, ab);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store of this wave has been written through
+        if (sub == 0) __hip_atomic_store((item ? a.readyV : a.readyU) + row, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__device__ __forceinline__ void wait_ready(const int* flag, int epoch) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(4);
+}
+
 // ------------------------------------------------------------ fused kernel ---
 // LPR lanes own one row (D = 4*LPR).  MODE: see orx_internal.h.
 template <int LPR, int MODEL, int OPT, int MODE>
@@ -249,19 +366,26 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
-    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
+    const int nab = MODE == MODE_EXACT ? a.n_apply_blocks : 0;
+    if (MODE == MODE_EXACT && (int)blockIdx.x < nab) {          // apply role (block-uniform)
+        inline_apply<LPR, OPT>(a);
+        return;
+    }
+    const int64_t wave_global = (int64_t)(blockIdx.x - nab) * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)(gridDim.x - nab) * 4 * TPW;
     float loss_acc = 0.0f, sq_acc = 0.0f;
 
     for (int64_t t = wave_global * TPW + grp; t < a.B; t += stride) {
         int u = a.uid[t], p = a.pid[t], n = a.nid[t];
         int du = 0, dp = 0, dn = 0;
         int ku = 2, kp = 2, kn = 2;     // duplicate role: 0 / 1 = plain store into scratch row 1 / 2, 2 = atomics
+        int urgent = 0;
         if (MODE == MODE_EXACT) {       // ids rewritten by dedup_kernel: bit 31 = "row is referenced more than once"
             du = (uint32_t)u >> 31; dp = (uint32_t)p >> 31; dn = (uint32_t)n >> 31;
-            if (a.role_bits) {          // bits 30:29 = role of this reference among the row's references
+            if (a.role_bits) {          // bits 30:29 = role among the row's references, bit 28 = urgent
                 ku = ((uint32_t)u >> 29) & 3; kp = ((uint32_t)p >> 29) & 3; kn = ((uint32_t)n >> 29) & 3;
-                u &= 0x1fffffff; p &= 0x1fffffff; n &= 0x1fffffff;
+                urgent = (((uint32_t)u >> 28) & 1) | (((uint32_t)p >> 27) & 2) | (((uint32_t)n >> 26) & 4);
+                u &= 0x0fffffff; p &= 0x0fffffff; n &= 0x0fffffff;
             } else {
                 u &= 0x7fffffff; p &= 0x7fffffff; n &= 0x7fffffff;
             }
@@ -272,6 +396,15 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
         if (!(id_ok(u, a.NU) & id_ok(p, a.NI) & id_ok(n, a.NI))) {
             if (sub == 0) *a.err = 1;       // the reference's CPU gather raises; the triplet is skipped
             continue;
+        }
+        if (MODE == MODE_EXACT && urgent) {
+            // a row of this triplet is being updated by an apply block of this launch
+            if (sub == 0) {
+                if (urgent & 1) wait_ready(a.readyU + u, a.epoch);
+                if (urgent & 2) wait_ready(a.readyV + p, a.epoch);
+                if (urgent & 4) wait_ready(a.readyV + n, a.epoch);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         float* Up = a.U + (size_t)u * D + 4 * sub;
         float* Pp = a.V + (size_t)p * D + 4 * sub;
@@ -519,10 +652,12 @@ static void launch_fused_lpr(int lpr, int mode, dim3 g, orx_ctx* s, const PairAr
     }
 }
 
+int orx_fused_can_inline_apply(int D) { return lpr_for_dim(D) != 0; }
+
 int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairArgs& a) {
     ProfScope ps(ctx, ORX_K_FUSED);
     const int lpr = lpr_for_dim(a.D);
-    const dim3 g((unsigned)fused_grid(a.D, a.B));
+    const dim3 g((unsigned)(fused_grid(a.D, a.B) + (mode == MODE_EXACT ? a.n_apply_blocks : 0)));
     const int ok = (optkind == ORX_ADAGRAD) ? ORX_ADAGRAD : ORX_SGD;
     if (model == ORX_BPR) {
         if (ok == ORX_ADAGRAD) launch_fused_lpr<ORX_BPR, ORX_ADAGRAD>(lpr, mode, g, ctx, a);

@@ -52,6 +52,8 @@ struct orx_ctx {
     int32_t* d_ids2 = nullptr; size_t d_ids2_cap = 0;            // [K][3B] ids with the duplicate flag in bit 31
     unsigned char* d_roles = nullptr; size_t d_roles_cap = 0;    // [K][3B] dedup scratch
     unsigned char* d_cflag = nullptr; size_t d_cflag_cap = 0;    // [3][K][B] censor election flags
+    unsigned int* d_dupbits = nullptr; size_t d_dupbits_cap = 0; // [K][buckets][words] duplicate bitmaps
+    int epoch = 0;                                               // launch epoch of the in-launch duplicate apply
     uint32_t* d_dlist = nullptr; size_t d_dlist_cap = 0;         // [K][2B] duplicated rows
     int* d_dcount = nullptr;   size_t d_dcount_cap = 0;          // [K]
     float* d_partial = nullptr; size_t d_partial_cap = 0;   // [K][nwaves][2] loss partials
@@ -73,6 +75,7 @@ struct orx_table {
     // per-step scratch, allocated on first use by a train step
     float* gsum = nullptr;            // [rows, dim] duplicate-row gradient sums (all-zero between steps)
     float* gsum2 = nullptr;           // second scratch rows of the pairwise step (rows referenced exactly twice)
+    int* ready = nullptr;             // [rows] ready flags of the in-launch duplicate apply
 };
 
 struct OptSlots {
@@ -123,7 +126,11 @@ struct PairArgs {
     float* gU2; float* gV2; float* gb2;       // second scratch rows (rows referenced exactly twice), may be NULL
     float* aU; float* aV; float* ab;          // Adagrad accumulators
     const int32_t* uid; const int32_t* pid; const int32_t* nid;
-    int role_bits;                            // ids carry the duplicate role in bits 30:29 (tables < 2^29 rows)
+    int role_bits;                            // ids carry role (bits 30:29) and urgent (bit 28): tables < 2^28 rows
+    // in-launch application of the PREVIOUS step's duplicated rows (n_apply_blocks == 0: off)
+    int n_apply_blocks; int epoch;
+    const uint32_t* prev_dlist; const int* prev_dcount;
+    int* readyU; int* readyV;                 // per-row ready flags (value = epoch of the launch that applied the row)
     const uint32_t* dlist;                    // duplicated rows of this step
     const int* dcount;
     int64_t B; int64_t NU; int64_t NI;
@@ -138,6 +145,7 @@ struct DedupArgs {
     int64_t id_stride;                        // elements between consecutive steps
     unsigned char* dflag;                     // [K][flag_stride] or NULL
     int32_t* ids_out;                         // [K][flag_stride] or NULL: id | (dup << 31); 0x7fffffff = invalid id
+    unsigned int* dupbits;                    // [K][nbu+nbi][DD_WORDS] "seen twice" bitmaps kept for urgent_kernel, or NULL
     unsigned char* roles;                     // [K][flag_stride] scratch (pass 1 -> pass 2) or NULL: no role bits
     int64_t role_stride;                      // ids_out layout [3][role_stride] per step (0: compact reference order)
     uint32_t* dlist;                          // [K][list_stride]
@@ -208,6 +216,9 @@ int orx_point_nwaves(int D, int64_t B);
 int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K);
 int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairArgs& a);
 int orx_launch_dup_apply(orx_ctx* ctx, int optkind, const PairArgs& a);
+int orx_launch_urgent(orx_ctx* ctx, const DedupArgs& a, int64_t K);
+int orx_fused_can_inline_apply(int D);
+int orx_dedup_words(void);
 int orx_launch_loss_reduce(orx_ctx* ctx, const ReduceArgs& a, int64_t K);
 int orx_fused_nwaves(int D, int64_t B);
 int orx_dedup_buckets(int64_t rows);

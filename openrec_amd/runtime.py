@@ -205,6 +205,12 @@ def pairwise_step(model, opt, user, item, bias, uid, pid, nid, K=1, B=None, id_s
     return (loss, l2) if want_loss else None
 
 
+def pairwise_reserve(opt, user, item, bias, K, B):
+    """Pre-size every per-call device buffer for calls of up to K steps of B triplets."""
+    check(user.ctx._lib.orx_pairwise_reserve(user.ctx._h, opt._h, user._h, item._h, bias._h, int(K), int(B)))
+    opt._tables = list({id(t): t for t in (opt._tables + [user, item, bias])}.values())
+
+
 def pairwise_loss(model, user, item, bias, uid, pid, nid, margin=0.5):
     lib = user.ctx._lib
     pu, nu, du, k0 = _ids_arg(uid)
