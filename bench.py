@@ -107,7 +107,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or (args.sharded and "RANK" in os.environ):     # torchrun with one rank: exercises the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
@@ -149,6 +149,7 @@ def main():
         from openrec_amd import sharded
         eng = sharded.ShardedPairwise(args.model, args.opt, args.users, args.items, args.dim, lr=lr,
                                       rank=rank, world=world, device=device, seed=0)
+        eng.force_collectives = dist is not None
         uid, pid, nid = make_ids(torch, args.users, args.items, K + W, args.batch, 1234 + rank, device)
         for s in range(W):
             eng.step(uid[s], pid[s], nid[s])
@@ -212,7 +213,7 @@ def main():
             except Exception as e:                      # the baseline must never hide the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -151,6 +151,7 @@ class ShardedPairwise:
         self.overflow = torch.zeros((), dtype=torch.bool, device=device)
         self._cap_for = {}
         self.a2a_fn = a2a_fn
+        self.force_collectives = False                    # world 1: still go through torch.distributed (smoke test)
         # the device-side plan needs the HIP building blocks and a float4 row path
         can_fast = getattr(self.be, "fast", False) and dim in (16, 32, 64, 128, 256)
         self.fast = can_fast if fast is None else (fast and can_fast)
@@ -169,7 +170,7 @@ class ShardedPairwise:
             recv = torch.empty_like(send) if recv is None else recv
             self.a2a_fn(recv, send)
             return recv
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return send                                   # a one-rank exchange is the identity
         recv = torch.empty_like(send) if recv is None else recv
         dist.all_to_all_single(recv, send, group=self.group)

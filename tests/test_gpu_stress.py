@@ -1,0 +1,32 @@
+"""Stress of the in-launch duplicate apply (apply blocks + ready-flag hand-off inside the fused
+launch): small tables make almost every row duplicated AND urgent in every step; many steps and
+several calls are compared step by step with the fp64 oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cfg", [(3000, 3000, 8192, 24, 64, "sgd"), (2000, 2500, 4096, 20, 128, "adagrad"),
+                                 (40000, 40000, 65536, 8, 32, "sgd")])
+def test_handoff_under_heavy_duplication(cfg):
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    NU, NI, B, K, D, optk = cfg
+    rng = np.random.default_rng(B)
+    U32 = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V32 = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b32 = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    U, V, b = U32.astype(np.float64), V32.astype(np.float64), b32.astype(np.float64)
+    uid = rng.integers(0, NU, (K, B)).astype(np.int32); pid = rng.integers(0, NI, (K, B)).astype(np.int32)
+    nid = rng.integers(0, NI, (K, B)).astype(np.int32)
+    lr = 0.02 / (B / min(NU, NI))                      # lr * multiplicity < 1: rounding is not amplified
+    tU = rt.Table(NU, D).write(U32); tV = rt.Table(NI, D).write(V32); tb = rt.Table(NI, 1).write(b32)
+    opt = rt.Optimizer.sgd(lr) if optk == "sgd" else rt.Optimizer.adagrad(lr, 0.1, 1e-7)
+    oo = orc.SGD(lr) if optk == "sgd" else orc.Adagrad(lr, 0.1, 1e-7)
+    for rep in range(2):                               # the call boundary is part of the protocol
+        loss, l2 = rt.pairwise_step("bpr", opt, tU, tV, tb, uid, pid, nid, K=K, B=B)
+        for s in range(K):
+            ref, _ = orc.bpr_step(U, V, b, uid[s], pid[s], nid[s], oo)
+            assert abs(loss[s] - ref) <= 2e-5 * abs(ref), (rep, s)
+        for dev, host in ((tU, U), (tV, V), (tb, b)):
+            assert np.abs(dev.read() - host).max() <= 5e-5 * np.abs(host).max(), rep
