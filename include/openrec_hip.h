@@ -173,6 +173,16 @@ int orx_pointwise_loss(orx_ctx* ctx, int model,
 int orx_score_all_items(orx_ctx* ctx, int kind, orx_table* user, orx_table* item, orx_table* bias, orx_table* w,
                         const int32_t* uid, int64_t n, float* out);
 
+/* Ranking metrics of the evaluation step (openrec/tf2/metrics/ranking_metrics.py:8-69; eval_step in
+ * tf2_examples/bpr_citeulike.py:41-46).  For each of n users: scores over ALL items (computed on the
+ * device like orx_score_all_items when pred == NULL, else taken from the host array pred[n*items]),
+ * pos_mask / excl_mask host uint8 [n*items]; at: host float[nat] cut-offs (nat <= 16).
+ * Outputs (host): auc[n], ndcg[n*nat], recall[n*nat]; any of them may be NULL. */
+int orx_rank_metrics(orx_ctx* ctx, int kind, orx_table* user, orx_table* item, orx_table* bias, orx_table* w,
+                     const int32_t* uid, const float* pred, const uint8_t* pos_mask, const uint8_t* excl_mask,
+                     int64_t n, int64_t items, const float* at, int32_t nat,
+                     float* auc, float* ndcg, float* recall);
+
 /* ---- DLRM (recommenders/dlrm.py:6-100, modules/multi_layer_perceptron.py:5-18,
  * modules/second_order_feature_interaction.py:4-34; train step as in
  * tf2_examples/dlrm_criteo.py:42-48).  The n_emb embedding tables (all of dim

@@ -325,3 +325,51 @@ extern "C" int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const f
     if (loss_l2_accum) CHECK(orx_launch_loss_accumulate(ctx, ctx->d_partial, nw, loss_l2_accum));
     return ORX_OK;
 }
+
+// ------------------------------------------------------------- ranking metrics ---
+extern "C" int orx_rank_metrics(orx_ctx* c, int kind, orx_table* U, orx_table* V, orx_table* b, orx_table* w,
+                                const int32_t* uid, const float* pred, const uint8_t* pos_mask, const uint8_t* excl_mask,
+                                int64_t n, int64_t items, const float* at, int32_t nat,
+                                float* auc, float* ndcg, float* recall) {
+    ORX_ARG(c && pos_mask && excl_mask && at, "orx_rank_metrics: NULL argument");
+    ORX_ARG(nat >= 1 && nat <= 16, "orx_rank_metrics: nat must be in [1, 16]");
+    ORX_ARG(pred || (U && V && b && uid), "orx_rank_metrics: need either pred or tables + user ids");
+    ORX_ARG(pred || V->rows == items, "orx_rank_metrics: items must equal the item table's rows");
+    if (n == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(c->device));
+    const size_t cells = (size_t)n * items;
+    // layout of d_tmp: pred [cells] | auc [n] | ndcg [n*nat] | recall [n*nat] | at [nat]
+    const size_t nf = cells + (size_t)n * (1 + 2 * nat) + nat;
+    ENSURE(c->d_tmp, c->d_tmp_cap, nf * sizeof(float));
+    ENSURE(c->d_dflag, c->d_dflag_cap, 2 * cells);
+    float* d_pred = c->d_tmp; float* d_auc = d_pred + cells; float* d_ndcg = d_auc + n; float* d_rec = d_ndcg + (size_t)n * nat;
+    float* d_at = d_rec + (size_t)n * nat;
+    unsigned char* d_pos = c->d_dflag; unsigned char* d_excl = d_pos + cells;
+    ORX_HIP(hipMemcpyAsync(d_pos, pos_mask, cells, hipMemcpyHostToDevice, c->stream));
+    ORX_HIP(hipMemcpyAsync(d_excl, excl_mask, cells, hipMemcpyHostToDevice, c->stream));
+    ORX_HIP(hipMemcpyAsync(d_at, at, sizeof(float) * nat, hipMemcpyHostToDevice, c->stream));
+    if (pred) {
+        ORX_HIP(hipMemcpyAsync(d_pred, pred, cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    } else {
+        ORX_ARG(kind >= 0 && kind <= 2 && U->dim == V->dim && U->dim <= 1024, "orx_rank_metrics: bad scorer arguments");
+        ENSURE(c->d_ids, c->d_ids_cap, (size_t)n * sizeof(int32_t));
+        CHECK(stage_ids(c, uid, n, 0));
+        CHECK(orx_launch_score_all(c, U->w, V->w, b->w, w ? w->w : nullptr, c->d_ids, n, U->rows, V->rows, U->dim, kind, d_pred));
+    }
+    EvalArgs a;
+    a.pred = d_pred; a.pos = d_pos; a.excl = d_excl; a.NI = items; a.at = d_at; a.nat = nat;
+    a.auc = d_auc; a.ndcg = d_ndcg; a.recall = d_rec; a.err = c->d_err;
+    CHECK(orx_launch_rank_metrics(c, a, n));
+    if (auc) ORX_HIP(hipMemcpyAsync(auc, d_auc, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    if (ndcg) ORX_HIP(hipMemcpyAsync(ndcg, d_ndcg, sizeof(float) * n * nat, hipMemcpyDeviceToHost, c->stream));
+    if (recall) ORX_HIP(hipMemcpyAsync(recall, d_rec, sizeof(float) * n * nat, hipMemcpyDeviceToHost, c->stream));
+    ORX_HIP(hipStreamSynchronize(c->stream));
+    int flag = 0;
+    ORX_HIP(hipMemcpy(&flag, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag == 2) {
+        ORX_HIP(hipMemset(c->d_err, 0, sizeof(int)));
+        orx_set_error("orx_rank_metrics: a user has more than 8192 positive items");
+        return ORX_ERR_ARG;
+    }
+    return orx_check_index_error(c);
+}

@@ -292,3 +292,15 @@ int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a);
 int orx_launch_shard_request(orx_ctx* ctx, const RequestArgs& a);
 int orx_launch_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int32_t* out);
 int orx_launch_shard_grads(orx_ctx* ctx, int model, const ShardGradArgs& a, int* nwaves);
+
+// kernels_eval.hip (ranking metrics of the evaluation step)
+struct EvalArgs {
+    const float* pred;            // [n, NI]
+    const unsigned char* pos;     // [n, NI]
+    const unsigned char* excl;    // [n, NI]
+    int64_t NI;
+    const float* at; int nat;     // cut-offs
+    float* auc; float* ndcg; float* recall;   // [n], [n, nat], [n, nat]
+    int* err;
+};
+int orx_launch_rank_metrics(orx_ctx* ctx, const EvalArgs& a, int64_t n);

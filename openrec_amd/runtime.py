@@ -355,3 +355,53 @@ class DLRMModel:
         out = np.empty(B, np.float32)
         check(self._lib.orx_dlrm_inference(self._h, d.ctypes.data, s.ctypes.data, B, 0, out.ctypes.data))
         return out
+
+
+def rank_metrics(pos_mask, excl_mask, at, pred=None, kind=None, user=None, item=None, bias=None, w=None, uid=None, ctx=None):
+    """AUC / NDCG@at / Recall@at per user (openrec/tf2/metrics/ranking_metrics.py).  Either `pred`
+    (host scores [n, items]) or the tables + user ids (scores computed on the device)."""
+    pos = np.ascontiguousarray(pos_mask, np.uint8)
+    excl = np.ascontiguousarray(excl_mask, np.uint8)
+    n, items = pos.shape
+    atv = np.ascontiguousarray(at, np.float32).reshape(-1)
+    c = ctx or (user.ctx if user is not None else default_context())
+    auc = np.empty(n, np.float32); ndcg = np.empty((n, atv.size), np.float32); rec = np.empty((n, atv.size), np.float32)
+    if pred is not None:
+        pr = np.ascontiguousarray(pred, np.float32)
+        assert pr.shape == (n, items)
+        check(c._lib.orx_rank_metrics(c._h, 0, None, None, None, None, None, pr.ctypes.data, pos.ctypes.data, excl.ctypes.data,
+                                      n, items, atv.ctypes.data, atv.size, auc.ctypes.data, ndcg.ctypes.data, rec.ctypes.data))
+    else:
+        ptr, nn, dev, keep = _ids_arg(uid)
+        assert nn == n and not dev
+        k = {"dot": 0, "l2": 1, "gmf": 2}[kind]
+        check(c._lib.orx_rank_metrics(c._h, k, user._h, item._h, bias._h, w._h if w is not None else None, ptr, None,
+                                      pos.ctypes.data, excl.ctypes.data, n, items, atv.ctypes.data, atv.size,
+                                      auc.ctypes.data, ndcg.ctypes.data, rec.ctypes.data))
+    return dict(auc=auc, ndcg=ndcg, recall=rec)
+
+
+def save_checkpoint(path, tables, opt=None):
+    """Tables (and the optimizer's slots for them) -> one .npz.  The tf2 reference has no
+    checkpointing (`save_interval` is unused, tf2_examples/bpr_citeulike.py:16); tf1 used
+    tf.train.Saver (tf1/recommenders/recommender.py:430-473).  `tables`: {name: Table}."""
+    out = {}
+    for name, t in tables.items():
+        out["table/" + name] = t.read()
+        if opt is not None and opt.kind in ("adagrad", "adam"):
+            out["slot0/" + name] = opt.slot(t, 0)
+            if opt.kind == "adam":
+                out["slot1/" + name] = opt.slot(t, 1)
+    if opt is not None:
+        out["opt/kind"] = np.array(opt.kind)
+    np.savez(path, **out)
+
+
+def load_checkpoint(path, tables, opt=None):
+    z = np.load(path)
+    for name, t in tables.items():
+        t.write(z["table/" + name])
+        if opt is not None and ("slot0/" + name) in z:
+            opt.set_slot(t, z["slot0/" + name], 0)
+            if ("slot1/" + name) in z:
+                opt.set_slot(t, z["slot1/" + name], 1)

@@ -41,6 +41,16 @@ class Recommender:
     def _tables(self):
         return self.user_latent_factor.table, self.item_latent_factor.table, self.item_bias.table
 
+    _score_kind = "dot"
+
+    def evaluate(self, user_id, pos_mask, excl_mask, at=(100,)):
+        """Beyond the reference API: `eval_step` of tf2_examples/bpr_citeulike.py:41-46 as one device call
+        (all-item scores + AUC / NDCG / Recall; the [B, n_items] score matrix never reaches the host)."""
+        U, V, b = self._tables()
+        w = self.mlp.layers[0].kernel if self._score_kind == "gmf" else None
+        return rt.rank_metrics(pos_mask, excl_mask, list(at), kind=self._score_kind, user=U, item=V, bias=b, w=w,
+                               uid=_ids(user_id))
+
     def _record(self, run_forward, run_train):
         step = PendingStep(self, run_forward, run_train)
         tape = active_tape()

@@ -6,6 +6,7 @@ from ... import runtime as rt
 
 
 class GMF(Recommender):
+    _score_kind = "gmf"
 
     def __init__(self, dim_user_embed, dim_item_embed, total_users, total_items, ctx=None):
         self._build_tables(dim_user_embed, dim_item_embed, total_users, total_items, ctx)

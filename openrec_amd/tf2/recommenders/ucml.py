@@ -6,6 +6,7 @@ from ... import runtime as rt
 
 class UCML(PairwiseRecommender):
     _model = "ucml"
+    _score_kind = "l2"
 
     def __init__(self, dim_user_embed, dim_item_embed, total_users, total_items, margin=0.5, ctx=None):
         self._build_tables(dim_user_embed, dim_item_embed, total_users, total_items, ctx)
