@@ -130,4 +130,4 @@ def test_checkpoint_roundtrip_resumes(tmp_path):
     # rows referenced >= 3 times in a batch are summed with atomics (order varies run to run): compare to 1e-6
     for x, y in ((U, U2), (V, V2), (b, b2)):
         assert np.abs(x.read() - y.read()).max() <= 1e-6 * np.abs(x.read()).max()
-    assert np.abs(opt.slot(V) - opt2.slot(V)).max() <= 1e-6 * np.abs(opt.slot(V)).max()
+    assert np.abs(opt.slot(V) - opt2.slot(V2)).max() <= 1e-6 * np.abs(opt.slot(V)).max()
