@@ -183,6 +183,22 @@ int orx_rank_metrics(orx_ctx* ctx, int kind, orx_table* user, orx_table* item, o
                      int64_t n, int64_t items, const float* at, int32_t nat,
                      float* auc, float* ndcg, float* recall);
 
+/* ---- on-device triplet sampler: the producer of the train step
+ * (openrec/tf2/data/dataset.py:7-16 _pairwise_generator; utils.py:82-87, 102-116).
+ * rec_user / rec_item: the n_records interaction records; csr_ptr[total_users + 1] / csr_items: the
+ * positives of every user, item ids sorted ascending inside a row (host arrays, copied to the device).
+ * orx_sampler_pairwise writes samples [first, first + n) of the stream `seed` to DEVICE arrays:
+ * every record is the positive exactly once per epoch of n_records samples (keyed permutation);
+ * negatives are uniform over the items that are not positives of the user.  Sample g depends only
+ * on (seed, g), never on the launch shape. */
+typedef struct orx_sampler orx_sampler;
+int orx_sampler_create(orx_ctx* ctx, const int32_t* rec_user, const int32_t* rec_item, int64_t n_records,
+                       const int64_t* csr_ptr, const int32_t* csr_items, int64_t total_users, int64_t total_items,
+                       orx_sampler** out);
+int orx_sampler_destroy(orx_sampler* s);
+int orx_sampler_pairwise(orx_sampler* s, uint64_t seed, int64_t first, int64_t n,
+                         int32_t* uid_dev, int32_t* pid_dev, int32_t* nid_dev);
+
 /* ---- DLRM (recommenders/dlrm.py:6-100, modules/multi_layer_perceptron.py:5-18,
  * modules/second_order_feature_interaction.py:4-34; train step as in
  * tf2_examples/dlrm_criteo.py:42-48).  The n_emb embedding tables (all of dim

@@ -59,6 +59,9 @@ SIGNATURES = {
     "orx_pointwise_loss": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, _ip, _fp, c_int64, c_float, c_float, c_int, _fp, _fp]),
     "orx_score_all_items": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, c_int64, _fp]),
     "orx_rank_metrics": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, _fp, _p, _p, c_int64, c_int64, _fp, c_int32, _fp, _fp, _fp]),
+    "orx_sampler_create": (c_int, [_p, _ip, _ip, c_int64, _p, _ip, c_int64, c_int64, _pp]),
+    "orx_sampler_destroy": (c_int, [_p]),
+    "orx_sampler_pairwise": (c_int, [_p, c_uint64, c_int64, c_int64, _ip, _ip, _ip]),
     "orx_dlrm_create": (c_int, [_p, c_int32, c_int32, _p, c_int32, _p, c_int32, _p, c_int32, c_int, c_float, c_uint64, _pp]),
     "orx_dlrm_destroy": (c_int, [_p]),
     "orx_dlrm_param": (c_int, [_p, c_int, c_int, _pp]),

@@ -373,3 +373,54 @@ extern "C" int orx_rank_metrics(orx_ctx* c, int kind, orx_table* U, orx_table* V
     }
     return orx_check_index_error(c);
 }
+
+// ------------------------------------------------------------- device sampler ---
+struct orx_sampler {
+    orx_ctx* ctx = nullptr;
+    int32_t *rec_user = nullptr, *rec_item = nullptr, *items = nullptr;
+    int64_t* ptr = nullptr;
+    int64_t R = 0, total_users = 0, total_items = 0;
+    int h = 1;
+};
+
+extern "C" int orx_sampler_create(orx_ctx* ctx, const int32_t* rec_user, const int32_t* rec_item, int64_t n_records,
+                                  const int64_t* csr_ptr, const int32_t* csr_items, int64_t total_users, int64_t total_items,
+                                  orx_sampler** out) {
+    ORX_ARG(ctx && rec_user && rec_item && csr_ptr && csr_items && out, "orx_sampler_create: NULL argument");
+    ORX_ARG(n_records > 0 && total_users > 0 && total_items > 0, "orx_sampler_create: sizes must be positive");
+    ORX_HIP(hipSetDevice(ctx->device));
+    orx_sampler* s = new orx_sampler();
+    s->ctx = ctx; s->R = n_records; s->total_users = total_users; s->total_items = total_items;
+    while ((1ll << (2 * s->h)) < n_records) s->h++;
+    const int64_t nnz = csr_ptr[total_users];
+    ORX_HIP(hipMalloc((void**)&s->rec_user, sizeof(int32_t) * n_records));
+    ORX_HIP(hipMalloc((void**)&s->rec_item, sizeof(int32_t) * n_records));
+    ORX_HIP(hipMalloc((void**)&s->ptr, sizeof(int64_t) * (total_users + 1)));
+    ORX_HIP(hipMalloc((void**)&s->items, sizeof(int32_t) * (nnz > 0 ? nnz : 1)));
+    ORX_HIP(hipMemcpy(s->rec_user, rec_user, sizeof(int32_t) * n_records, hipMemcpyHostToDevice));
+    ORX_HIP(hipMemcpy(s->rec_item, rec_item, sizeof(int32_t) * n_records, hipMemcpyHostToDevice));
+    ORX_HIP(hipMemcpy(s->ptr, csr_ptr, sizeof(int64_t) * (total_users + 1), hipMemcpyHostToDevice));
+    if (nnz > 0) ORX_HIP(hipMemcpy(s->items, csr_items, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+    *out = s;
+    return ORX_OK;
+}
+
+extern "C" int orx_sampler_destroy(orx_sampler* s) {
+    if (!s) return ORX_OK;
+    hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->stream);
+    hipFree(s->rec_user); hipFree(s->rec_item); hipFree(s->ptr); hipFree(s->items);
+    delete s;
+    return ORX_OK;
+}
+
+extern "C" int orx_sampler_pairwise(orx_sampler* s, uint64_t seed, int64_t first, int64_t n,
+                                    int32_t* uid_dev, int32_t* pid_dev, int32_t* nid_dev) {
+    ORX_ARG(s && uid_dev && pid_dev && nid_dev && first >= 0 && n >= 0, "orx_sampler_pairwise: bad argument");
+    ORX_HIP(hipSetDevice(s->ctx->device));
+    SamplerArgs a;
+    a.rec_user = s->rec_user; a.rec_item = s->rec_item; a.R = s->R; a.ptr = s->ptr; a.items = s->items;
+    a.total_items = s->total_items; a.seed = seed; a.first = first; a.n = n; a.h = s->h;
+    a.uid = uid_dev; a.pid = pid_dev; a.nid = nid_dev;
+    return orx_launch_sample_pairwise(s->ctx, a);
+}

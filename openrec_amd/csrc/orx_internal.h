@@ -304,3 +304,13 @@ struct EvalArgs {
     int* err;
 };
 int orx_launch_rank_metrics(orx_ctx* ctx, const EvalArgs& a, int64_t n);
+
+// kernels_sampler.hip (on-device triplet sampler)
+struct SamplerArgs {
+    const int32_t* rec_user; const int32_t* rec_item; int64_t R;      // interaction records
+    const int64_t* ptr; const int32_t* items;                          // CSR of positives (sorted per user)
+    int64_t total_items;
+    uint64_t seed; int64_t first; int64_t n; int h;
+    int32_t* uid; int32_t* pid; int32_t* nid;
+};
+int orx_launch_sample_pairwise(orx_ctx* ctx, const SamplerArgs& a);

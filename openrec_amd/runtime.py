@@ -405,3 +405,32 @@ def load_checkpoint(path, tables, opt=None):
             opt.set_slot(t, z["slot0/" + name], 0)
             if ("slot1/" + name) in z:
                 opt.set_slot(t, z["slot1/" + name], 1)
+
+
+class DeviceSampler:
+    """On-device pairwise sampler over an interaction set (see kernels_sampler.hip).  `raw_data`: the
+    structured array the reference's Dataset takes ('user_id', 'item_id')."""
+
+    def __init__(self, raw_data, total_users, total_items, ctx=None):
+        self.ctx = ctx or default_context()
+        lib = self._lib = self.ctx._lib
+        u = np.ascontiguousarray(raw_data["user_id"], np.int32)
+        i = np.ascontiguousarray(raw_data["item_id"], np.int32)
+        key = np.unique(u.astype(np.int64) * int(total_items) + i)            # sorted by (user, item), distinct
+        cu, ci = (key // int(total_items)).astype(np.int64), (key % int(total_items)).astype(np.int32)
+        ptr = np.zeros(int(total_users) + 1, np.int64)
+        np.add.at(ptr, cu + 1, 1)
+        ptr = np.ascontiguousarray(np.cumsum(ptr), np.int64)
+        ci = np.ascontiguousarray(ci)
+        h = c_void_p()
+        check(lib.orx_sampler_create(self.ctx._h, u.ctypes.data, i.ctypes.data, u.size, ptr.ctypes.data, ci.ctypes.data,
+                                     int(total_users), int(total_items), byref(h)))
+        self._h, self.n_records = h, int(u.size)
+        self._fin = weakref.finalize(self, lib.orx_sampler_destroy, h)
+
+    def pairwise(self, seed, first, n, uid, pid, nid):
+        """Fill the DEVICE int32 buffers uid / pid / nid (torch tensors or DevicePtr) with samples
+        [first, first + n) of stream `seed`."""
+        pu, nu, du, _ = _ids_arg(uid); pp, _, dp, _ = _ids_arg(pid); pn, _, dn, _ = _ids_arg(nid)
+        assert du and dp and dn and nu >= n, "the sampler writes device buffers"
+        check(self._lib.orx_sampler_pairwise(self._h, int(seed) & (2 ** 64 - 1), int(first), int(n), pu, pp, pn))
