@@ -37,10 +37,16 @@ def alg_bytes_per_triplet(dim, opt):
     return 24 * dim + 28 if opt == "sgd" else 48 * dim + 44
 
 
-def make_ids(torch, n_users, n_items, steps, batch, seed, device):
+def make_ids(torch, n_users, n_items, steps, batch, seed, device, zipf=0.0):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     uid = torch.randint(0, n_users, (steps, batch), device=device, dtype=torch.int32, generator=g)
+    if zipf > 0:        # secondary workload: item popularity ~ Zipf(alpha), exposes duplicate handling
+        w = 1.0 / torch.arange(1, n_items + 1, device=device, dtype=torch.float64) ** zipf
+        cdf = torch.cumsum(w / w.sum(), 0)
+        draw = lambda: torch.searchsorted(cdf, torch.rand((steps, batch), device=device, dtype=torch.float64, generator=g)).clamp_(max=n_items - 1).to(torch.int32)
+        pid, nid = draw(), draw()
+        return uid.contiguous(), pid.contiguous(), nid.contiguous()
     pid = torch.randint(0, n_items, (steps, batch), device=device, dtype=torch.int32, generator=g)
     nid = torch.randint(0, n_items, (steps, batch), device=device, dtype=torch.int32, generator=g)
     for _ in range(4):                      # resample negatives that collide with the positive
@@ -91,6 +97,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hogwild", action="store_true", help="racy non-reference mode (never the headline)")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded engine even on one GPU (debug)")
+    ap.add_argument("--zipf", type=float, default=0.0, help="item ids ~ Zipf(alpha) instead of uniform (secondary workload)")
     ap.add_argument("--censor", action="store_true",
                     help="UCML: LatentFactor.censor of the touched rows after every step (ucml.py:44-48)")
     args = ap.parse_args()
@@ -120,7 +127,7 @@ def main():
         V = rt.Table(args.items, args.dim, ctx).init_uniform(seed=1)
         b = rt.Table(args.items, 1, ctx).init_uniform(seed=2)
         opt = rt.Optimizer.sgd(lr, ctx=ctx) if args.opt == "sgd" else rt.Optimizer.adagrad(lr, ctx=ctx)
-        uid, pid, nid = make_ids(torch, args.users, args.items, K + W, args.batch, 1234, device)
+        uid, pid, nid = make_ids(torch, args.users, args.items, K + W, args.batch, 1234, device, args.zipf)
         torch.cuda.synchronize()
 
         def run(first, count, want_loss=False):
@@ -186,7 +193,8 @@ def main():
             "config": {"workload": f"{args.model} dim={args.dim} {args.users}x{args.items} table, "
                                    f"batch={args.batch} triplets/GPU, {args.opt} lr={lr}, objective loss+l2_loss, "
                                    f"{'HOGWILD (non-reference)' if args.hogwild else 'exact TF duplicate semantics'}"
-                                   f"{', censor after each step' if args.censor else ''}",
+                                   f"{', censor after each step' if args.censor else ''}"
+                                   f"{', items ~ Zipf(%g)' % args.zipf if args.zipf else ''}",
                        "parallelism": parallelism},
         }
         fused = prof.get("fused", {})
