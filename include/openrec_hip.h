@@ -210,6 +210,9 @@ enum orx_dlrm_flags {
     ORX_DLRM_SIGMOID_BOT = 2,       /* sigmoid_bot (else relu), dlrm.py:34-35            */
     ORX_DLRM_SIGMOID_TOP = 4,       /* sigmoid_top (else relu), dlrm.py:36-37            */
     ORX_DLRM_LOSS_BCE = 8,          /* loss_func='bce' (else 'mse'), dlrm.py:52-55       */
+    ORX_DLRM_FP16_MLP = 32,         /* performance mode: the MLP products run on fp16 MFMA
+                                       (operands rounded to fp16, fp32 accumulate / storage);
+                                       NOT within the 1e-5 parity tolerance                 */
     ORX_DLRM_REFERENCE_COMPAT = 16  /* reproduce second_order_feature_interaction.py:21-32
                                        literally: lower triangle kept, upper selected -> the
                                        interaction output is 0; without this

@@ -16,6 +16,7 @@ ORX_BPR, ORX_UCML = 0, 1
 ORX_GMF, ORX_WRMF = 0, 1
 ORX_IDS_DEVICE, ORX_HOGWILD, ORX_NO_L2, ORX_CENSOR = 1, 2, 4, 8
 ORX_DLRM_INTERACT_ITSELF, ORX_DLRM_SIGMOID_BOT, ORX_DLRM_SIGMOID_TOP, ORX_DLRM_LOSS_BCE, ORX_DLRM_REFERENCE_COMPAT = 1, 2, 4, 8, 16
+ORX_DLRM_FP16_MLP = 32
 ORX_K_DEDUP, ORX_K_FUSED, ORX_K_REDUCE, ORX_K_SWEEP, ORX_K_CENSOR, ORX_K_POINT, ORX_K_DUPAPPLY, ORX_K_NUM = 0, 1, 2, 3, 4, 5, 6, 7
 KERNEL_NAMES = {ORX_K_DEDUP: "dedup", ORX_K_FUSED: "fused", ORX_K_REDUCE: "loss_reduce", ORX_K_SWEEP: "adam_sweep",
                 ORX_K_CENSOR: "censor", ORX_K_POINT: "pointwise", ORX_K_DUPAPPLY: "dup_apply"}

@@ -30,6 +30,7 @@ struct orx_dlrm {
     orx_table* emb = nullptr;           // combined [sum(ln_emb), m_spa]
     std::vector<DenseLayer> bot, top;
     int F = 0, P = 0;
+    int ldR = 0;                        // row stride of R / dR: d + P rounded up to 4 floats (16-byte rows)
     // activations / gradients, sized for `cap` samples
     int64_t cap = 0;
     float *d_dense = nullptr, *d_label = nullptr;
@@ -84,7 +85,8 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
     m->P = itself ? m->F * (m->F + 1) / 2 : m->F * (m->F - 1) / 2;
     CHECK(make_layers(ctx, m->bot, dense_dim, n_bot, ln_bot, (flags & ORX_DLRM_SIGMOID_BOT) ? 2 : 1, seed + 7));
     CHECK(make_layers(ctx, m->top, m_spa + m->P, n_top, ln_top, (flags & ORX_DLRM_SIGMOID_TOP) ? 2 : 1, seed + 13));
-    m->maxw = m_spa + m->P;
+    m->ldR = (m_spa + m->P + 3) & ~3;
+    m->maxw = m->ldR;
     for (auto& d : m->bot) m->maxw = std::max(m->maxw, std::max(d.in, d.out));
     for (auto& d : m->top) m->maxw = std::max(m->maxw, std::max(d.in, d.out));
     *out = m;
@@ -136,7 +138,8 @@ static int ensure_buffers(orx_dlrm* m, int64_t B) {
     ORX_HIP(hipMalloc((void**)&m->d_idx, sizeof(int32_t) * B * F));
     ORX_HIP(hipMalloc((void**)&m->Z, sizeof(float) * B * F * d));
     ORX_HIP(hipMalloc((void**)&m->dZ, sizeof(float) * B * F * d));
-    ORX_HIP(hipMalloc((void**)&m->R, sizeof(float) * B * (d + m->P)));
+    ORX_HIP(hipMalloc((void**)&m->R, sizeof(float) * B * m->ldR));
+    ORX_HIP(hipMemsetAsync(m->R, 0, sizeof(float) * B * m->ldR, m->ctx->stream));
     ORX_HIP(hipMalloc((void**)&m->gA, sizeof(float) * B * m->maxw));
     ORX_HIP(hipMalloc((void**)&m->gB, sizeof(float) * B * m->maxw));
     for (size_t l = 0; l + 1 < m->bot.size(); ++l) {          // the last bottom layer writes into Z[:, F-1, :]
@@ -150,6 +153,13 @@ static int ensure_buffers(orx_dlrm* m, int64_t B) {
 }
 
 struct Batch { const float* dense; const int32_t* sparse; const float* label; };
+
+// MLP product: exact fp32 MFMA, or fp16 MFMA in the performance mode
+static int mlp_gemm(orx_dlrm* m, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
+                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act) {
+    if (m->flags & ORX_DLRM_FP16_MLP) return orx_launch_gemm_f16(m->ctx, A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act);
+    return orx_launch_gemm(m->ctx, A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act);
+}
 
 // forward of one batch; leaves every activation in the model's buffers
 static int forward(orx_dlrm* m, const Batch& bt, int64_t B) {
@@ -166,15 +176,15 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B) {
         const bool last = l + 1 == m->bot.size();
         float* y = last ? m->Z + (size_t)(F - 1) * d : m->bot_y[l];
         const int64_t ldy = last ? (int64_t)F * d : L.out;
-        CHECK(orx_launch_gemm(c, x, ldx, 1, L.W->w, L.out, 1, y, ldy, L.b->w, (int)B, L.out, L.in, L.act));
+        CHECK(mlp_gemm(m, x, ldx, 1, L.W->w, L.out, 1, y, ldy, L.b->w, (int)B, L.out, L.in, L.act));
         x = y; ldx = ldy;
     }
     // dlrm.py:89-92: R = concat(dense_emb, interaction)
-    CHECK(orx_launch_interact(c, true, m->Z, nullptr, F, d, compat, itself, m->R, m->P, B));
-    x = m->R; ldx = d + m->P;
+    CHECK(orx_launch_interact(c, true, m->Z, nullptr, F, d, compat, itself, m->R, m->P, B, m->ldR));
+    x = m->R; ldx = m->ldR;
     for (size_t l = 0; l < m->top.size(); ++l) {
         const DenseLayer& L = m->top[l];
-        CHECK(orx_launch_gemm(c, x, ldx, 1, L.W->w, L.out, 1, m->top_y[l], L.out, L.b->w, (int)B, L.out, L.in, L.act));
+        CHECK(mlp_gemm(m, x, ldx, 1, L.W->w, L.out, 1, m->top_y[l], L.out, L.b->w, (int)B, L.out, L.in, L.act));
         x = m->top_y[l]; ldx = L.out;
     }
     return ORX_OK;
@@ -199,11 +209,11 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
         CHECK(orx_launch_act_bwd(c, dy, outs[l], ld_out[l], (int)B, D.out, D.act));
         CHECK(orx_table_scratch(D.W)); CHECK(orx_table_scratch(D.b));
         // gW [in, out] = X^T * dZ ; gb = colsum(dZ)
-        CHECK(orx_launch_gemm(c, ins[l], 1, ld_in[l], dy, D.out, 1, D.W->gsum, D.out, nullptr, D.in, D.out, (int)B, 0));
+        CHECK(mlp_gemm(m, ins[l], 1, ld_in[l], dy, D.out, 1, D.W->gsum, D.out, nullptr, D.in, D.out, (int)B, 0));
         CHECK(orx_launch_colsum(c, dy, (int)B, D.out, D.b->gsum));
         if (l > 0 || need_dx0) {
             // dX [B, in] = dZ * W^T
-            CHECK(orx_launch_gemm(c, dy, D.out, 1, D.W->w, 1, D.out, other, D.in, nullptr, (int)B, D.in, D.out, 0));
+            CHECK(mlp_gemm(m, dy, D.out, 1, D.W->w, 1, D.out, other, ld_in[l], nullptr, (int)B, D.in, D.out, 0));
             float* t = dy; dy = other; other = t;
         }
     }
@@ -245,13 +255,13 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         // ---- top MLP backward
         std::vector<const float*> ins, outs; std::vector<int64_t> ldi, ldo;
         for (size_t l = 0; l < m->top.size(); ++l) {
-            ins.push_back(l == 0 ? m->R : m->top_y[l - 1]); ldi.push_back(l == 0 ? d + m->P : m->top[l - 1].out);
+            ins.push_back(l == 0 ? m->R : m->top_y[l - 1]); ldi.push_back(l == 0 ? m->ldR : m->top[l - 1].out);
             outs.push_back(m->top_y[l]); ldo.push_back(m->top[l].out);
         }
         float* dR = nullptr;
         CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR));
         // ---- interaction backward: dZ for every slot (slot F-1 = d dense_emb)
-        CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B));
+        CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B, m->ldR));
         // ---- bottom MLP backward from dZ[:, F-1, :]
         float* dy = (dR == m->gA) ? m->gB : m->gA;
         float* other = (dy == m->gA) ? m->gB : m->gA;

@@ -20,6 +20,7 @@ struct GemmArgs {
     const float* bias;
     int M, N, K;
     int act;                 // 0 none, 1 relu, 2 sigmoid
+    int kchunk;              // split-K (fp16 kernel): K range per blockIdx.z, partial tiles combine with atomics
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
@@ -76,10 +77,168 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             }
 }
 
+// ---- fp16 MFMA variant (performance mode of the DLRM MLPs) -------------------------------
+// Same contract as gemm_f32_kernel, but the operands are rounded to fp16 while they are staged
+// into LDS and multiplied with v_mfma_f32_16x16x32_f16 (fp32 accumulate, fp32 output).
+// 128x128 block tile, 4 wavefronts x (4x4 tiles of 16x16), K staged 32 at a time.  Both LDS
+// tiles are stored K-contiguous ([m][k] and [n][k]) so that every MFMA operand is one 16-byte
+// LDS read.  A_KC / B_NC tell which global dimension is contiguous so that the staging loads
+// coalesce in all three MLP products (X*W, dY*W^T, X^T*dY).
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+// 4 consecutive floats starting at p (element i valid iff i < nvalid); one 16-byte load when possible
+__device__ __forceinline__ f32x4 load4c(const float* p, int nvalid, bool vec_ok) {
+    f32x4 v; v.x = v.y = v.z = v.w = 0.0f;
+    if (nvalid >= 4 && vec_ok) return *reinterpret_cast<const f32x4*>(p);
+    if (nvalid > 0) v.x = p[0];
+    if (nvalid > 1) v.y = p[1];
+    if (nvalid > 2) v.z = p[2];
+    if (nvalid > 3) v.w = p[3];
+    return v;
+}
+
+// One 128 x 32 operand tile per block, 16 elements per thread, held in registers between the
+// global loads and the LDS stores (so the loads of tile t+1 fly while tile t is multiplied).
+//   KC (K contiguous in memory): thread = (row, 16 consecutive k)  -> two 16-byte LDS stores
+//   otherwise (row index contiguous): thread = 4 rows x 4 k         -> four 8-byte LDS stores
+template <bool KC>
+struct TileLoader {
+    f32x4 v[4];
+    __device__ __forceinline__ void load(const float* P, int64_t s_row, int64_t s_k, int row0, int nrows, int k0, int K, bool vec_ok) {
+        const int t = threadIdx.x;
+        if (KC) {
+            const int r = t >> 1, kb = (t & 1) * 16;
+            const bool rok = row0 + r < nrows;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + kb + 4 * q;
+                v[q] = load4c(P + (int64_t)(row0 + r) * s_row + k, rok ? K - k : 0, vec_ok);
+            }
+        } else {
+            const int rb = (t & 31) * 4, kb = (t >> 5) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + kb + q;
+                v[q] = load4c(P + (int64_t)k * s_k + (row0 + rb), k < K ? nrows - (row0 + rb) : 0, vec_ok);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(_Float16* T, int LD) const {
+        const int t = threadIdx.x;
+        if (KC) {
+            const int r = t >> 1, kb = (t & 1) * 16;
+            h8 lo, hi;
+            lo[0] = (_Float16)v[0].x; lo[1] = (_Float16)v[0].y; lo[2] = (_Float16)v[0].z; lo[3] = (_Float16)v[0].w;
+            lo[4] = (_Float16)v[1].x; lo[5] = (_Float16)v[1].y; lo[6] = (_Float16)v[1].z; lo[7] = (_Float16)v[1].w;
+            hi[0] = (_Float16)v[2].x; hi[1] = (_Float16)v[2].y; hi[2] = (_Float16)v[2].z; hi[3] = (_Float16)v[2].w;
+            hi[4] = (_Float16)v[3].x; hi[5] = (_Float16)v[3].y; hi[6] = (_Float16)v[3].z; hi[7] = (_Float16)v[3].w;
+            *reinterpret_cast<h8*>(T + r * LD + kb) = lo;
+            *reinterpret_cast<h8*>(T + r * LD + kb + 8) = hi;
+        } else {
+            const int rb = (t & 31) * 4, kb = (t >> 5) * 4;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                h4 w;
+                w[0] = (_Float16)v[0][m]; w[1] = (_Float16)v[1][m]; w[2] = (_Float16)v[2][m]; w[3] = (_Float16)v[3][m];
+                *reinterpret_cast<h4*>(T + (rb + m) * LD + kb) = w;
+            }
+        }
+    }
+};
+
+template <bool A_KC, bool B_NC>
+__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int vec_a, int vec_b) {
+    constexpr int BM = 128, BN = 128, BK = 32, LD = BK + 8;      // 80-byte rows: 16-B aligned, spread over banks
+    __shared__ __attribute__((aligned(16))) _Float16 As[BM * LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[BN * LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[i][j].x = acc[i][j].y = acc[i][j].z = acc[i][j].w = 0.0f; }
+    TileLoader<A_KC> la;       // A(i,k): rows = m
+    TileLoader<!B_NC> lb;      // B(k,j): rows = n; K contiguous iff NOT n-contiguous
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);                // kchunk is a multiple of BK
+    la.load(g.A, g.sa0, g.sa1, bm, g.M, kbeg, kend, vec_a != 0);
+    lb.load(g.B, g.sb1, g.sb0, bn, g.N, kbeg, kend, vec_b != 0);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        la.store(As, LD);
+        lb.store(Bs, LD);
+        __syncthreads();
+        if (k0 + BK < kend) {                                  // next tile's loads overlap the MFMAs below
+            la.load(g.A, g.sa0, g.sa1, bm, g.M, k0 + BK, kend, vec_a != 0);
+            lb.load(g.B, g.sb1, g.sb0, bn, g.N, k0 + BK, kend, vec_b != 0);
+        }
+        h8 a[4], b[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const h8*>(&As[(wm + mi * 16 + (lane & 15)) * LD + (lane >> 4) * 8]);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const h8*>(&Bs[(wn + ni * 16 + (lane & 15)) * LD + (lane >> 4) * 8]);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = bm + wm + mi * 16 + (lane >> 4) * 4 + r;
+                const int col = bn + wn + ni * 16 + (lane & 15);
+                if (row < g.M && col < g.N) {
+                    float v = acc[mi][ni][r];
+                    if (gridDim.z > 1) { unsafeAtomicAdd(g.C + (int64_t)row * g.ldc + col, v); continue; }
+                    if (g.bias) v += g.bias[col];
+                    if (g.act == 1) v = fmaxf(v, 0.0f);
+                    else if (g.act == 2) v = 1.0f / (1.0f + __expf(-v));
+                    g.C[(int64_t)row * g.ldc + col] = v;
+                }
+            }
+}
+
+int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
+                        float* C, int64_t ldc, const float* bias, int M, int N, int K, int act) {
+    if (M == 0 || N == 0) return ORX_OK;
+    GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0};
+    // split-K when the output has too few tiles to fill the chip (the X^T*dY weight-gradient products:
+    // small M x N, K = batch); partial tiles are combined with fp32 atomics into a zeroed output
+    const int tiles = ((N + 127) / 128) * ((M + 127) / 128);
+    int splits = 1;
+    if (bias == nullptr && act == 0 && ldc == N && tiles < 256 && K >= 1024) {
+        splits = (512 + tiles - 1) / tiles;
+        if (splits > K / 256) splits = K / 256;
+        if (splits < 1) splits = 1;
+    }
+    g.kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
+    splits = (K + g.kchunk - 1) / g.kchunk;
+    if (splits > 1) ORX_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * ldc, ctx->stream));
+    const dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)splits);
+    const bool akc = sa1 == 1, bnc = sb1 == 1;
+    ORX_ARG((akc || sa0 == 1) && (bnc || sb0 == 1), "gemm_f16: every operand needs one unit stride");
+    // 16-byte loads need an aligned base and a leading stride that keeps every row aligned
+    const int va = (((uintptr_t)A & 15) == 0) && ((akc ? sa0 : sa1) % 4 == 0);
+    const int vb = (((uintptr_t)B & 15) == 0) && ((bnc ? sb0 : sb1) % 4 == 0);
+    if (akc && bnc) ORX_LAUNCH(ctx, (gemm_f16_kernel<true, true>), grid, dim3(256), 0, g, va, vb);
+    else if (akc) ORX_LAUNCH(ctx, (gemm_f16_kernel<true, false>), grid, dim3(256), 0, g, va, vb);
+    else if (bnc) ORX_LAUNCH(ctx, (gemm_f16_kernel<false, true>), grid, dim3(256), 0, g, va, vb);
+    else ORX_LAUNCH(ctx, (gemm_f16_kernel<false, false>), grid, dim3(256), 0, g, va, vb);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
 int orx_launch_gemm(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
                     float* C, int64_t ldc, const float* bias, int M, int N, int K, int act) {
     if (M == 0 || N == 0) return ORX_OK;
-    GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act};
+    GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0};
     ORX_LAUNCH(ctx, gemm_f32_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0, g);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
@@ -107,20 +266,23 @@ int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int
     return ORX_OK;
 }
 
-// out[c] = sum_r X[r, c]   (bias gradient); one block per 64 columns
+// out[c] = sum_r X[r, c]   (bias gradient).  grid = (columns / 64, row slabs of 1024); the slabs
+// combine with one fp32 atomic per (slab, column) into the zeroed output.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* X, int M, int N, float* out) {
     __shared__ float sh[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * 1024, r1 = min(M, r0 + 1024);
     float s = 0.0f;
-    if (c < N) for (int r = part; r < M; r += 4) s += X[(int64_t)r * N + c];
+    if (c < N) for (int r = r0 + part; r < r1; r += 4) s += X[(int64_t)r * N + c];
     sh[part][threadIdx.x & 63] = s;
     __syncthreads();
-    if (part == 0 && c < N) out[c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    if (part == 0 && c < N) unsafeAtomicAdd(out + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 int orx_launch_colsum(orx_ctx* ctx, const float* X, int M, int N, float* out) {
-    ORX_LAUNCH(ctx, colsum_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, X, M, N, out);
+    ORX_HIP(hipMemsetAsync(out, 0, sizeof(float) * N, ctx->stream));
+    ORX_LAUNCH(ctx, colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 1023) / 1024)), dim3(256), 0, X, M, N, out);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -155,14 +317,14 @@ __device__ __forceinline__ bool pair_selected(int i, int j, int compat, int itse
 }
 
 __global__ __launch_bounds__(256) void interact_fwd_kernel(const float* Z, int F, int d, int compat, int itself,
-                                                           float* R, int P, int64_t B) {
+                                                           float* R, int P, int64_t B, int ldR) {
     extern __shared__ float zs[];            // [F][d]
     const int64_t b = blockIdx.x;
     if (b >= B) return;
     const float* zb = Z + b * F * d;
     for (int k = threadIdx.x; k < F * d; k += 256) zs[k] = zb[k];
     __syncthreads();
-    float* rb = R + b * (d + P);
+    float* rb = R + b * ldR;
     for (int k = threadIdx.x; k < d; k += 256) rb[k] = zs[(F - 1) * d + k];
     for (int e = threadIdx.x; e < F * F; e += 256) {
         const int i = e / F, j = e % F;
@@ -179,14 +341,14 @@ __global__ __launch_bounds__(256) void interact_fwd_kernel(const float* Z, int F
 
 // dZ [B, F, d] from dR [B, d + P]
 __global__ __launch_bounds__(256) void interact_bwd_kernel(const float* Z, const float* dR, int F, int d, int compat,
-                                                           int itself, float* dZ, int P, int64_t B) {
+                                                           int itself, float* dZ, int P, int64_t B, int ldR) {
     extern __shared__ float sm[];            // zs [F][d], gs [F][F]
     float* zs = sm;
     float* gs = sm + F * d;
     const int64_t b = blockIdx.x;
     if (b >= B) return;
     const float* zb = Z + b * F * d;
-    const float* rb = dR + b * (d + P);
+    const float* rb = dR + b * ldR;
     for (int k = threadIdx.x; k < F * d; k += 256) zs[k] = zb[k];
     for (int e = threadIdx.x; e < F * F; e += 256) {
         const int i = e / F, j = e % F;
@@ -209,10 +371,10 @@ __global__ __launch_bounds__(256) void interact_bwd_kernel(const float* Z, const
 }
 
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
-                        float* out, int P, int64_t B) {
+                        float* out, int P, int64_t B, int ldR) {
     if (B == 0) return ORX_OK;
-    if (fwd) ORX_LAUNCH(ctx, interact_fwd_kernel, dim3((unsigned)B), dim3(256), (size_t)F * d * sizeof(float), Z, F, d, compat, itself, out, P, B);
-    else ORX_LAUNCH(ctx, interact_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(F * d + F * F) * sizeof(float), Z, dR, F, d, compat, itself, out, P, B);
+    if (fwd) ORX_LAUNCH(ctx, interact_fwd_kernel, dim3((unsigned)B), dim3(256), (size_t)F * d * sizeof(float), Z, F, d, compat, itself, out, P, B, ldR);
+    else ORX_LAUNCH(ctx, interact_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(F * d + F * F) * sizeof(float), Z, dR, F, d, compat, itself, out, P, B, ldR);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

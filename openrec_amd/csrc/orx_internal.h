@@ -246,11 +246,13 @@ int orx_launch_adam_sweep(orx_ctx* ctx, float* w, float* m, float* v, float* gsu
 // kernels_dense.hip (DLRM dense side)
 int orx_launch_gemm(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
                     float* C, int64_t ldc, const float* bias, int M, int N, int K, int act);
+int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
+                        float* C, int64_t ldc, const float* bias, int M, int N, int K, int act);
 int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act);
 int orx_launch_colsum(orx_ctx* ctx, const float* X, int M, int N, float* out);
 int orx_launch_copy2d(orx_ctx* ctx, float* dst, int64_t ldd, const float* src, int64_t lds_, int M, int N);
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
-                        float* out, int P, int64_t B);
+                        float* out, int P, int64_t B, int ldR);
 int orx_launch_dlrm_loss(orx_ctx* ctx, float* P, const float* y, int64_t B, int bce, float thr, float* dP, double* loss_out);
 int orx_launch_dlrm_ids(orx_ctx* ctx, const int32_t* sparse, const int64_t* offset, const int64_t* rows, int nf, int64_t B,
                         int32_t* idx);

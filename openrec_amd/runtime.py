@@ -301,7 +301,8 @@ class DLRMModel:
     optimizer apply of tf2_examples/dlrm_criteo.py:42-48."""
 
     def __init__(self, m_spa, ln_emb, ln_bot, ln_top, dense_dim, arch_interaction_itself=False, sigmoid_bot=False,
-                 sigmoid_top=True, loss_func="mse", loss_threshold=0.0, reference_compat=True, seed=0, ctx=None):
+                 sigmoid_top=True, loss_func="mse", loss_threshold=0.0, reference_compat=True, seed=0, ctx=None,
+                 fp16_mlp=False):
         self.ctx = ctx or default_context()
         lib = self._lib = self.ctx._lib
         self.m_spa, self.ln_emb, self.ln_bot, self.ln_top = int(m_spa), [int(x) for x in ln_emb], list(ln_bot), list(ln_top)
@@ -309,7 +310,8 @@ class DLRMModel:
         flags = ((_ffi.ORX_DLRM_INTERACT_ITSELF if arch_interaction_itself else 0)
                  | (_ffi.ORX_DLRM_SIGMOID_BOT if sigmoid_bot else 0) | (_ffi.ORX_DLRM_SIGMOID_TOP if sigmoid_top else 0)
                  | (_ffi.ORX_DLRM_LOSS_BCE if loss_func == "bce" else 0)
-                 | (_ffi.ORX_DLRM_REFERENCE_COMPAT if reference_compat else 0))
+                 | (_ffi.ORX_DLRM_REFERENCE_COMPAT if reference_compat else 0)
+                 | (_ffi.ORX_DLRM_FP16_MLP if fp16_mlp else 0))
         if loss_func not in ("mse", "bce"):
             raise ValueError("loss_func=%s is not supported" % loss_func)          # dlrm.py:56-61
         emb = (ctypes.c_int64 * len(self.ln_emb))(*self.ln_emb)

@@ -108,3 +108,36 @@ def test_dlrm_api_surface():
     assert pred.shape == (64,) and (pred > 0).all() and (pred < 1).all()
     with pytest.raises(AttributeError):
         DLRM(m_spa=4, ln_emb=counts, ln_bot=[8, 4], ln_top=[8, 1], arch_interaction_op='cat')
+
+
+def test_dlrm_fp16_mlp_mode_tracks_the_fp32_oracle():
+    """ORX_DLRM_FP16_MLP: MLP products on fp16 MFMA (performance mode).  Not a parity mode -- the check
+    is that loss and every parameter UPDATE agree with the fp32 oracle to fp16 accuracy, which also
+    pins the MFMA fragment layouts of all three products (X*W, dY*W^T, X^T*dY) on asymmetric data."""
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    from oracle.dlrm_oracle import DLRMOracle
+    rng = np.random.default_rng(4)
+    ln_emb = [50, 300, 7, 1000]
+    cfg = dict(m_spa=32, ln_emb=ln_emb, ln_bot=[96, 32], ln_top=[200, 72, 1], dense_dim=13)
+    o = DLRMOracle(dtype=np.float32, seed=5, reference_compat=False, **cfg)
+    m = rt.DLRMModel(reference_compat=False, fp16_mlp=True, **cfg)
+    m.param("emb").write(np.concatenate(o.emb))
+    for nm, layers in (("bot", o.bot), ("top", o.top)):
+        for l, (W, b) in enumerate(layers):
+            b[:] = rng.normal(size=b.shape).astype(np.float32) * 0.1
+            m.param(nm + "_w", l).write(W); m.param(nm + "_b", l).write(b.reshape(1, -1))
+    B = 333
+    dense = np.log1p(rng.integers(0, 100, (B, 13))).astype(np.float32)
+    sparse = np.stack([rng.integers(0, n, B) for n in ln_emb], 1).astype(np.int32)
+    label = (rng.uniform(size=B) < 0.3).astype(np.float32)
+    before = {("top", 0): o.top[0][0].copy(), ("bot", 1): o.bot[1][0].copy(), "emb": np.concatenate(o.emb).copy()}
+    p16, p32 = m.inference(dense, sparse), o.inference(dense, sparse)
+    assert np.abs(p16 - p32).max() < 5e-3
+    l16 = m.step(rt.Optimizer.sgd(0.1), dense, sparse, label)[0]
+    l32 = o.step(dense, sparse, label, orc.SGD(0.1))
+    assert abs(l16 - l32) < 5e-3 * abs(l32)
+    for key, dev, ref in ((("top", 0), m.param("top_w", 0).read(), o.top[0][0]), (("bot", 1), m.param("bot_w", 1).read(), o.bot[1][0]),
+                          ("emb", m.param("emb").read(), np.concatenate(o.emb))):
+        du, dr = dev - before[key], ref - before[key]
+        assert np.abs(du - dr).max() < 0.03 * np.abs(dr).max() + 1e-7, key
