@@ -266,13 +266,13 @@ int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int
     return ORX_OK;
 }
 
-// out[c] = sum_r X[r, c]   (bias gradient).  grid = (columns / 64, row slabs of 1024); the slabs
+// out[c] = sum_r X[r, c]   (bias gradient).  grid = (columns / 64, row slabs of 256); the slabs
 // combine with one fp32 atomic per (slab, column) into the zeroed output.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* X, int M, int N, float* out) {
     __shared__ float sh[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * 1024, r1 = min(M, r0 + 1024);
+    const int r0 = blockIdx.y * 256, r1 = min(M, r0 + 256);
     float s = 0.0f;
     if (c < N) for (int r = r0 + part; r < r1; r += 4) s += X[(int64_t)r * N + c];
     sh[part][threadIdx.x & 63] = s;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* X, int M, int 
 
 int orx_launch_colsum(orx_ctx* ctx, const float* X, int M, int N, float* out) {
     ORX_HIP(hipMemsetAsync(out, 0, sizeof(float) * N, ctx->stream));
-    ORX_LAUNCH(ctx, colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 1023) / 1024)), dim3(256), 0, X, M, N, out);
+    ORX_LAUNCH(ctx, colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 255) / 256)), dim3(256), 0, X, M, N, out);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -318,14 +318,15 @@ __device__ __forceinline__ bool pair_selected(int i, int j, int compat, int itse
 
 __global__ __launch_bounds__(256) void interact_fwd_kernel(const float* Z, int F, int d, int compat, int itself,
                                                            float* R, int P, int64_t B, int ldR) {
-    extern __shared__ float zs[];            // [F][d]
+    extern __shared__ float zs[];            // [F][d + 1]: the +1 keeps rows i and j off the same LDS bank
+    const int zd = d + 1;
     const int64_t b = blockIdx.x;
     if (b >= B) return;
     const float* zb = Z + b * F * d;
-    for (int k = threadIdx.x; k < F * d; k += 256) zs[k] = zb[k];
+    for (int k = threadIdx.x; k < F * d; k += 256) zs[(k / d) * zd + k % d] = zb[k];
     __syncthreads();
     float* rb = R + b * ldR;
-    for (int k = threadIdx.x; k < d; k += 256) rb[k] = zs[(F - 1) * d + k];
+    for (int k = threadIdx.x; k < d; k += 256) rb[k] = zs[(F - 1) * zd + k];
     for (int e = threadIdx.x; e < F * F; e += 256) {
         const int i = e / F, j = e % F;
         if (!pair_selected(i, j, compat, itself)) continue;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256) void interact_fwd_kernel(const float* Z, int F
         if (compat) rank = itself ? (i * F - i * (i - 1) / 2 + (j - i)) : (i * F - i * (i + 1) / 2 + (j - i - 1));
         else rank = itself ? (i * (i + 1) / 2 + j) : (i * (i - 1) / 2 + j);
         float v = 0.0f;
-        if (!compat || i == j) { for (int k = 0; k < d; ++k) v += zs[i * d + k] * zs[j * d + k]; }
+        if (!compat || i == j) { for (int k = 0; k < d; ++k) v += zs[i * zd + k] * zs[j * zd + k]; }
         rb[d + rank] = v;
     }
 }
@@ -342,14 +343,15 @@ __global__ __launch_bounds__(256) void interact_fwd_kernel(const float* Z, int F
 // dZ [B, F, d] from dR [B, d + P]
 __global__ __launch_bounds__(256) void interact_bwd_kernel(const float* Z, const float* dR, int F, int d, int compat,
                                                            int itself, float* dZ, int P, int64_t B, int ldR) {
-    extern __shared__ float sm[];            // zs [F][d], gs [F][F]
+    extern __shared__ float sm[];            // zs [F][d + 1], gs [F][F]
+    const int zd = d + 1;
     float* zs = sm;
-    float* gs = sm + F * d;
+    float* gs = sm + F * zd;
     const int64_t b = blockIdx.x;
     if (b >= B) return;
     const float* zb = Z + b * F * d;
     const float* rb = dR + b * ldR;
-    for (int k = threadIdx.x; k < F * d; k += 256) zs[k] = zb[k];
+    for (int k = threadIdx.x; k < F * d; k += 256) zs[(k / d) * zd + k % d] = zb[k];
     for (int e = threadIdx.x; e < F * F; e += 256) {
         const int i = e / F, j = e % F;
         float g = 0.0f;
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void interact_bwd_kernel(const float* Z, const
     for (int e = threadIdx.x; e < F * d; e += 256) {
         const int i = e / d, k = e % d;
         float acc = (i == F - 1) ? rb[k] : 0.0f;
-        for (int j = 0; j < F; ++j) acc += (gs[i * F + j] + gs[j * F + i]) * zs[j * d + k];   // d(z_i.z_j): both orders
+        for (int j = 0; j < F; ++j) acc += (gs[i * F + j] + gs[j * F + i]) * zs[j * zd + k];  // d(z_i.z_j): both orders
         dZ[b * F * d + e] = acc;
     }
 }
@@ -373,8 +375,8 @@ __global__ __launch_bounds__(256) void interact_bwd_kernel(const float* Z, const
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
                         float* out, int P, int64_t B, int ldR) {
     if (B == 0) return ORX_OK;
-    if (fwd) ORX_LAUNCH(ctx, interact_fwd_kernel, dim3((unsigned)B), dim3(256), (size_t)F * d * sizeof(float), Z, F, d, compat, itself, out, P, B, ldR);
-    else ORX_LAUNCH(ctx, interact_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(F * d + F * F) * sizeof(float), Z, dR, F, d, compat, itself, out, P, B, ldR);
+    if (fwd) ORX_LAUNCH(ctx, interact_fwd_kernel, dim3((unsigned)B), dim3(256), (size_t)F * (d + 1) * sizeof(float), Z, F, d, compat, itself, out, P, B, ldR);
+    else ORX_LAUNCH(ctx, interact_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(F * (d + 1) + F * F) * sizeof(float), Z, dR, F, d, compat, itself, out, P, B, ldR);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
