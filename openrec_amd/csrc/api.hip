@@ -3,6 +3,7 @@
 // fallback: every entry point needs a usable HIP device.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "orx_internal.h"
@@ -437,10 +438,14 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     const int mode = opt->kind == ORX_ADAM ? MODE_ACCUM : (hogwild ? MODE_HOGWILD : MODE_EXACT);
     // rows referenced exactly twice get plain stores into two scratch rows; the role of a reference
     // travels in bits 30:29 of its id, which needs tables below 2^29 rows
-    const bool role_bits = mode == MODE_EXACT && U->rows < (1LL << 28) && V->rows < (1LL << 28);
+    // ORX_FORCE_FALLBACK (debug / tests): bit 0 = behave as if the tables had >= 2^28 rows (no role bits: every
+    // duplicate uses atomics, separate dup_apply launches), bit 1 = no in-launch apply
+    const char* fb_env = getenv("ORX_FORCE_FALLBACK");
+    const int fb = fb_env ? atoi(fb_env) : 0;
+    const bool role_bits = mode == MODE_EXACT && U->rows < (1LL << 28) && V->rows < (1LL << 28) && !(fb & 1);
     // the previous step's duplicated rows are applied by extra blocks of the next step's launch
     // (no dup_apply launch, no kernel boundary) -- not with a censor pass between the steps
-    const bool inline_apply = role_bits && !(flags & ORX_CENSOR) && K > 1 && orx_fused_can_inline_apply(U->dim);
+    const bool inline_apply = role_bits && !(flags & ORX_CENSOR) && K > 1 && orx_fused_can_inline_apply(U->dim) && !(fb & 2);
     const int nb_total = orx_dedup_buckets(U->rows) + orx_dedup_buckets(V->rows);
     if (mode != MODE_HOGWILD) {
         CHECK(orx_table_scratch(U, role_bits)); CHECK(orx_table_scratch(V, role_bits)); CHECK(orx_table_scratch(b, role_bits));

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include <cstdint>
 typedef float f4 __attribute__((ext_vector_type(4)));
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("ERR %s line %d\n",hipGetErrorString(e),__LINE__);exit(1);} }while(0)
@@ -50,13 +51,16 @@ __global__ __launch_bounds__(BS) void fused(A a){
   if(F&64){ for(int o=32;o>0;o>>=1){ lacc+=__shfl_xor(lacc,o); sacc+=__shfl_xor(sacc,o);} if(lane==0){a.part[2*gw]=lacc;a.part[2*gw+1]=sacc;} }
 }
 template<class Fn> float timeit(Fn f,int reps){ hipEvent_t a,b; CK(hipEventCreate(&a));CK(hipEventCreate(&b)); for(int i=0;i<3;i++) f(); CK(hipDeviceSynchronize()); CK(hipEventRecord(a)); for(int i=0;i<reps;i++) f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms,a,b)); return ms/reps; }
-int main(){
+int main(int argc,char**argv){ bool do_sort = argc>1;
   const int N=1000000,B=65536,K=16; A a;
   CK(hipMalloc(&a.U,(size_t)N*256)); CK(hipMalloc(&a.V,(size_t)N*256)); CK(hipMalloc(&a.b,N*4));
   CK(hipMemset(a.U,0,(size_t)N*256)); CK(hipMemset(a.V,0,(size_t)N*256)); CK(hipMemset(a.b,0,N*4));
   CK(hipMalloc(&a.cU,N*4)); CK(hipMalloc(&a.cV,N*4)); CK(hipMalloc(&a.c2U,N*4)); CK(hipMalloc(&a.c2V,N*4));
   std::vector<int> ones(N,1); CK(hipMemcpy(a.cU,ones.data(),N*4,hipMemcpyHostToDevice)); CK(hipMemcpy(a.cV,ones.data(),N*4,hipMemcpyHostToDevice)); CK(hipMemset(a.c2U,0,N*4)); CK(hipMemset(a.c2V,0,N*4));
-  int* ids; CK(hipMalloc(&ids,(size_t)3*K*B*4)); std::vector<int> h((size_t)3*K*B); srand(1); for(auto&x:h) x=(int)(((uint64_t)rand()*2147483647ull+rand())%N); CK(hipMemcpy(ids,h.data(),h.size()*4,hipMemcpyHostToDevice));
+  int* ids; CK(hipMalloc(&ids,(size_t)3*K*B*4)); std::vector<int> h((size_t)3*K*B); srand(1); for(auto&x:h) x=(int)(((uint64_t)rand()*2147483647ull+rand())%N); if(do_sort){
+    for(int s=0;s<K;s++){ std::vector<int> perm(B); for(int i=0;i<B;i++) perm[i]=i; int* u=&h[(size_t)s*B]; int* p=&h[(size_t)(K+s)*B]; int* n=&h[(size_t)(2*K+s)*B];
+      std::sort(perm.begin(),perm.end(),[&](int a,int b){return u[a]<u[b];}); std::vector<int> uu(B),pp(B),nn(B); for(int i=0;i<B;i++){uu[i]=u[perm[i]];pp[i]=p[perm[i]];nn[i]=n[perm[i]];} for(int i=0;i<B;i++){u[i]=uu[i];p[i]=pp[i];n[i]=nn[i];} } printf("triplets sorted by user id\n"); }
+  CK(hipMemcpy(ids,h.data(),h.size()*4,hipMemcpyHostToDevice));
   CK(hipMalloc(&a.dm,B)); CK(hipMalloc(&a.part,65536*8)); a.B=B; a.lr=0.05f; a.invB=1.f/B;
   int step=0;
   auto setids=[&](){ int s=step%K, s2=(step+1)%K; a.uid=ids+(size_t)s*B; a.pid=ids+(size_t)(K+s)*B; a.nid=ids+(size_t)(2*K+s)*B; a.uid2=ids+(size_t)s2*B; a.pid2=ids+(size_t)(K+s2)*B; a.nid2=ids+(size_t)(2*K+s2)*B; step++; };

@@ -30,3 +30,30 @@ def test_handoff_under_heavy_duplication(cfg):
             assert abs(loss[s] - ref) <= 2e-5 * abs(ref), (rep, s)
         for dev, host in ((tU, U), (tV, V), (tb, b)):
             assert np.abs(dev.read() - host).max() <= 5e-5 * np.abs(host).max(), rep
+
+
+@pytest.mark.parametrize("fallback", ["1", "2"])
+def test_fallback_paths_give_the_same_result(fallback, monkeypatch):
+    """The paths taken by tables of >= 2^28 rows (no role bits: atomics + dup_apply launches) and
+    without the in-launch apply are forced through ORX_FORCE_FALLBACK and checked like the main path."""
+    monkeypatch.setenv("ORX_FORCE_FALLBACK", fallback)
+    test_handoff_under_heavy_duplication((3000, 3000, 8192, 12, 64, "sgd"))
+    test_handoff_under_heavy_duplication((2000, 2500, 4096, 10, 128, "adagrad"))
+
+
+def test_batch_larger_than_the_grid_cap():
+    """B = 1.2 M triplets: the fused grid is capped at 65536 blocks, so lane groups grid-stride."""
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    NU, NI, B, D = 400000, 500000, 1_200_003, 16
+    rng = np.random.default_rng(0)
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    uid = rng.integers(0, NU, (2, B)).astype(np.int32); pid = rng.integers(0, NI, (2, B)).astype(np.int32); nid = rng.integers(0, NI, (2, B)).astype(np.int32)
+    tU = rt.Table(NU, D).write(U); tV = rt.Table(NI, D).write(V); tb = rt.Table(NI, 1).write(b)
+    loss, l2 = rt.pairwise_step("bpr", rt.Optimizer.sgd(0.05), tU, tV, tb, uid, pid, nid, K=2, B=B)
+    oo = orc.SGD(0.05)
+    for s in range(2):
+        ref, l2r = orc.bpr_step(U, V, b, uid[s], pid[s], nid[s], oo)
+        assert abs(loss[s] - ref) <= 1e-5 * abs(ref) and abs(l2[s] - l2r) <= 1e-5 * abs(l2r)
+    assert np.abs(tU.read() - U).max() <= 1e-5 * np.abs(U).max() and np.abs(tV.read() - V).max() <= 1e-5 * np.abs(V).max()
