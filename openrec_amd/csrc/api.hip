@@ -163,6 +163,7 @@ extern "C" int orx_table_destroy(orx_table* t) {
     hipFree(t->gsum);
     hipFree(t->gsum2);
     hipFree(t->ready);
+    hipFree(t->side);
     delete t;
     return ORX_OK;
 }
@@ -186,6 +187,14 @@ int orx_table_scratch(orx_table* t, bool second) {
         ORX_HIP(hipMalloc((void**)&t->ready, (size_t)t->rows * sizeof(int)));
         ORX_HIP(hipMemsetAsync(t->ready, 0, (size_t)t->rows * sizeof(int), t->ctx->stream));
     }
+    return ORX_OK;
+}
+
+int orx_table_side(orx_table* t) {
+    if (t->side) return ORX_OK;
+    ORX_HIP(hipSetDevice(t->ctx->device));
+    ORX_HIP(hipMalloc((void**)&t->side, (size_t)t->rows * 2 * sizeof(int)));
+    ORX_HIP(hipMemsetAsync(t->side, 0, (size_t)t->rows * 2 * sizeof(int), t->ctx->stream));
     return ORX_OK;
 }
 
@@ -443,9 +452,14 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     const char* fb_env = getenv("ORX_FORCE_FALLBACK");
     const int fb = fb_env ? atoi(fb_env) : 0;
     const bool role_bits = mode == MODE_EXACT && U->rows < (1LL << 28) && V->rows < (1LL << 28) && !(fb & 1);
+    // censor_vec after every step (ucml.py:44-48): fused into the row write-back for the float4 dims in
+    // exact mode (fb bit 2 forces the separate passes); separate passes otherwise
+    const bool want_censor = (flags & ORX_CENSOR) != 0;
+    const bool fused_censor = want_censor && mode == MODE_EXACT && orx_fused_can_inline_apply(U->dim) && !(fb & 4);
+    const bool censor = want_censor && !fused_censor;
     // the previous step's duplicated rows are applied by extra blocks of the next step's launch
-    // (no dup_apply launch, no kernel boundary) -- not with a censor pass between the steps
-    const bool inline_apply = role_bits && !(flags & ORX_CENSOR) && K > 1 && orx_fused_can_inline_apply(U->dim) && !(fb & 2);
+    // (no dup_apply launch, no kernel boundary) -- not with a separate censor pass between the steps
+    const bool inline_apply = role_bits && !censor && K > 1 && orx_fused_can_inline_apply(U->dim) && !(fb & 2);
     const int nb_total = orx_dedup_buckets(U->rows) + orx_dedup_buckets(V->rows);
     if (mode != MODE_HOGWILD) {
         CHECK(orx_table_scratch(U, role_bits)); CHECK(orx_table_scratch(V, role_bits)); CHECK(orx_table_scratch(b, role_bits));
@@ -471,6 +485,16 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     a.invB = 1.0f / (float)B;
     a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f;
     a.err = c->d_err;
+    // epochs are consumed one per step; on wrap-around every table clears its epoch-tagged arrays
+    if ((int64_t)c->epoch + K + 16 > 0x7fffffff) { c->epoch = 0; c->epoch_gen += 1; }
+    for (orx_table* t : {U, V}) {
+        if (t->tag_gen != c->epoch_gen) {
+            if (t->ready) ORX_HIP(hipMemsetAsync(t->ready, 0, (size_t)t->rows * sizeof(int), c->stream));
+            if (t->side) ORX_HIP(hipMemsetAsync(t->side, 0, (size_t)t->rows * 2 * sizeof(int), c->stream));
+            t->tag_gen = c->epoch_gen;
+        }
+    }
+    if (fused_censor) { CHECK(orx_table_side(V)); a.censor = 1; a.min_norm = 0.1f; a.sideV = V->side; }
 
     for (int64_t s0 = 0; s0 < K; s0 += chunk) {
         const int64_t kc = (K - s0 < chunk) ? (K - s0) : chunk;
@@ -489,7 +513,6 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             CHECK(orx_launch_dedup(c, d, kc));
             if (inline_apply) CHECK(orx_launch_urgent(c, d, kc));
         }
-        const bool censor = (flags & ORX_CENSOR) != 0;
         if (censor) {
             // one elected reference per distinct row of each of the three id lists, for every step of the chunk
             ENSURE(c->d_cflag, c->d_cflag_cap, (size_t)3 * kc * B);
@@ -513,11 +536,11 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             }
             a.dlist = c->d_dlist + (size_t)i * list_stride; a.dcount = c->d_dcount + i;
             a.partial = c->d_partial + (size_t)i * nw * 2;
+            a.epoch = ++c->epoch;           // one epoch per step: ready flags and censor side marks are tagged with it
             if (inline_apply && i > 0) {    // this launch also applies the duplicated rows of step i-1
                 // one lane group per duplicated row in a single pass for the usual ~0.15*B duplicated rows
                 // (the count lives in device memory; surplus blocks exit, a larger count grid-strides)
                 a.n_apply_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(16, (B / 4) / (1024 / U->dim) + 1));
-                a.epoch = ++c->epoch;
                 a.prev_dlist = c->d_dlist + (size_t)(i - 1) * list_stride; a.prev_dcount = c->d_dcount + (i - 1);
             } else {
                 a.n_apply_blocks = 0; a.prev_dlist = nullptr; a.prev_dcount = nullptr;

@@ -299,8 +299,11 @@ __device__ __forceinline__ void store_wt(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void store_wt4(float* p, f4 v) {
-    // one 16-byte write-through (sc1) store; the caller drains it with s_waitcnt vmcnt(0)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    // one 16-byte write-through (sc1) store; the caller drains it with s_waitcnt vmcnt(0).
+    // The s_nop covers the hardware hazard "VALU write of the data VGPRs right after a >64-bit VMEM
+    // store" (2 wait states): the compiler's hazard recognizer does not look inside inline asm, and
+    // without it a following v_mov into the same registers corrupted the stored row.
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 
 template <int OPT>
@@ -309,7 +312,22 @@ __device__ __forceinline__ float opt_rule(float w, float g, float& acc, float lr
     return w - lr * g;
 }
 
-template <int LPR, int OPT>
+// LatentFactor.censor (latent_factor.py:17-23) of a row held by LPR lanes: row / max(||row||, min_norm)
+template <int LPR>
+__device__ __forceinline__ f4 censor4(f4 w, float min_norm) {
+    const float m = fmaxf(sqrtf(group_allreduce<LPR>(dot4(w, w))), min_norm);
+    f4 r; r.x = w.x / m; r.y = w.y / m; r.z = w.z / m; r.w = w.w / m;
+    return r;
+}
+
+// was this item row referenced as a positive AND as a negative in the step of epoch `ep`?
+// (censor_vec censors the row once per id list, ucml.py:46-48)
+__device__ __forceinline__ bool censored_twice(const PairArgs& a, size_t row, int ep) {
+    const int2 m = *reinterpret_cast<const int2*>(a.sideV + 2 * row);
+    return m.x == ep && m.y == ep;
+}
+
+template <int LPR, int OPT, bool CENSOR>
 __device__ __forceinline__ void inline_apply(const PairArgs& a) {
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
@@ -336,6 +354,10 @@ __device__ __forceinline__ void inline_apply(const PairArgs& a) {
         wn.x = opt_rule<OPT>(w.x, g.x, ac[0], a.lr, a.eps); wn.y = opt_rule<OPT>(w.y, g.y, ac[1], a.lr, a.eps);
         wn.z = opt_rule<OPT>(w.z, g.z, ac[2], a.lr, a.eps); wn.w = opt_rule<OPT>(w.w, g.w, ac[3], a.lr, a.eps);
         acc.x = ac[0]; acc.y = ac[1]; acc.z = ac[2]; acc.w = ac[3];
+        if (CENSOR) {                   // the rows of step s-1 are censored where they are applied
+            wn = censor4<LPR>(wn, a.min_norm);
+            if (item && censored_twice(a, row, a.epoch - 1)) wn = censor4<LPR>(wn, a.min_norm);
+        }
         f4 z; z.x = z.y = z.z = z.w = 0.0f;
         store_wt4(wp, wn);
         store_wt4(g1, z);
@@ -359,7 +381,7 @@ __device__ __forceinline__ void wait_ready(const int* flag, int epoch) {
 
 // ------------------------------------------------------------ fused kernel ---
 // LPR lanes own one row (D = 4*LPR).  MODE: see orx_internal.h.
-template <int LPR, int MODEL, int OPT, int MODE>
+template <int LPR, int MODEL, int OPT, int MODE, bool CENSOR = false>
 __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
@@ -368,7 +390,7 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     const int grp = lane / LPR;
     const int nab = MODE == MODE_EXACT ? a.n_apply_blocks : 0;
     if (MODE == MODE_EXACT && (int)blockIdx.x < nab) {          // apply role (block-uniform)
-        inline_apply<LPR, OPT>(a);
+        inline_apply<LPR, OPT, CENSOR>(a);
         return;
     }
     const int64_t wave_global = (int64_t)(blockIdx.x - nab) * 4 + (threadIdx.x >> 6);
@@ -425,6 +447,32 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
         row_grads<MODEL>(ru, rp, rn, g, a.l2w, gu, gp, gn, gbp, gbn);
 
         // unique row: in place.  duplicated row: gradient into gsum, row untouched.
+        if (CENSOR) {
+            // censor_vec fused into the write-back: a row referenced once is censored once, here;
+            // duplicated rows are censored by the kernel that applies their summed gradient
+            f4 wu = ru, wp = rp, wn = rn;
+            if (du == 0) wu = opt_new4<OPT>(a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
+            else dup_store4(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku);
+            if (dp == 0) {
+                wp = opt_new4<OPT>(a.aV + (size_t)p * D + 4 * sub, rp, gp, a.lr, a.eps);
+                if (sub == 0) opt_apply1<OPT>(a.b + p, a.ab + p, bp, gbp, a.lr, a.eps);
+            } else {
+                dup_store4(a.gV, a.gV2, (size_t)p * D + 4 * sub, gp, kp);
+                if (sub == 0) { dup_store1(a.gb, a.gb2, p, gbp, kp); a.sideV[2 * (size_t)p] = a.epoch; }
+            }
+            if (dn == 0) {
+                wn = opt_new4<OPT>(a.aV + (size_t)n * D + 4 * sub, rn, gn, a.lr, a.eps);
+                if (sub == 0) opt_apply1<OPT>(a.b + n, a.ab + n, bn, gbn, a.lr, a.eps);
+            } else {
+                dup_store4(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn);
+                if (sub == 0) { dup_store1(a.gb, a.gb2, n, gbn, kn); a.sideV[2 * (size_t)n + 1] = a.epoch; }
+            }
+            wu = censor4<LPR>(wu, a.min_norm); wp = censor4<LPR>(wp, a.min_norm); wn = censor4<LPR>(wn, a.min_norm);
+            if (du == 0) *reinterpret_cast<f4*>(Up) = wu;
+            if (dp == 0) *reinterpret_cast<f4*>(Pp) = wp;
+            if (dn == 0) *reinterpret_cast<f4*>(Np) = wn;
+            continue;
+        }
         if (du == 0) opt_apply4<OPT>(Up, a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
         else dup_store4(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku);
         if (dp == 0) {
@@ -478,7 +526,13 @@ __global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
             g = g + *reinterpret_cast<const f4*>(G2 + row * D + 4 * sub);
             *reinterpret_cast<f4*>(G2 + row * D + 4 * sub) = z;
         }
-        opt_apply4<OPT>(wp, A + row * D + 4 * sub, w, g, a.lr, a.eps);
+        if (a.censor) {
+            f4 wn = censor4<LPR>(opt_new4<OPT>(A + row * D + 4 * sub, w, g, a.lr, a.eps), a.min_norm);
+            if (item && censored_twice(a, row, a.epoch)) wn = censor4<LPR>(wn, a.min_norm);
+            *reinterpret_cast<f4*>(wp) = wn;
+        } else {
+            opt_apply4<OPT>(wp, A + row * D + 4 * sub, w, g, a.lr, a.eps);
+        }
         if (item && a.b != nullptr && sub == 0) {
             float gb = a.gb[row];
             a.gb[row] = 0.0f;
@@ -623,7 +677,10 @@ int orx_fused_nwaves(int D, int64_t B) { return (int)(fused_grid(D, B) * 4); }
 template <int LPR, int MODEL, int OPT>
 static void launch_fused_mode(int mode, dim3 g, orx_ctx* s, const PairArgs& a) {
     switch (mode) {
-        case MODE_EXACT: ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, OPT, MODE_EXACT>), g, dim3(256), 0, a); break;
+        case MODE_EXACT:
+            if (a.censor) ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, OPT, MODE_EXACT, true>), g, dim3(256), 0, a);
+            else ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, OPT, MODE_EXACT>), g, dim3(256), 0, a);
+            break;
         case MODE_HOGWILD: ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, OPT, MODE_HOGWILD>), g, dim3(256), 0, a); break;
         case MODE_ACCUM: ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, ORX_SGD, MODE_ACCUM>), g, dim3(256), 0, a); break;
         default: ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, ORX_SGD, MODE_LOSS>), g, dim3(256), 0, a); break;

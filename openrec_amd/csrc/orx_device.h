@@ -112,6 +112,20 @@ __device__ __forceinline__ void opt_apply4(float* w_ptr, float* a_ptr, f4 w_old,
     }
 }
 
+// the updated row is returned instead of stored (the caller post-processes it); accumulator stored
+template <int OPT>
+__device__ __forceinline__ f4 opt_new4(float* a_ptr, f4 w_old, f4 grad, float lr, float eps) {
+    if (OPT == ORX_ADAGRAD) {
+        f4 acc = *reinterpret_cast<f4*>(a_ptr);
+        acc = acc + grad * grad;
+        *reinterpret_cast<f4*>(a_ptr) = acc;
+        f4 den;
+        den.x = sqrtf(acc.x) + eps; den.y = sqrtf(acc.y) + eps; den.z = sqrtf(acc.z) + eps; den.w = sqrtf(acc.w) + eps;
+        return w_old - lr * grad / den;
+    }
+    return w_old - lr * grad;
+}
+
 template <int OPT>
 __device__ __forceinline__ void opt_apply1(float* w_ptr, float* a_ptr, float w_old, float grad, float lr, float eps) {
     if (OPT == ORX_ADAGRAD) {

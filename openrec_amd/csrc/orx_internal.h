@@ -53,7 +53,8 @@ struct orx_ctx {
     unsigned char* d_roles = nullptr; size_t d_roles_cap = 0;    // [K][3B] dedup scratch
     unsigned char* d_cflag = nullptr; size_t d_cflag_cap = 0;    // [3][K][B] censor election flags
     unsigned int* d_dupbits = nullptr; size_t d_dupbits_cap = 0; // [K][buckets][words] duplicate bitmaps
-    int epoch = 0;                                               // launch epoch of the in-launch duplicate apply
+    int epoch = 0;                                               // step epoch: tags ready flags and censor side marks
+    int epoch_gen = 0;                                           // bumped when `epoch` wraps (tables then clear their tags)
     uint32_t* d_dlist = nullptr; size_t d_dlist_cap = 0;         // [K][2B] duplicated rows
     int* d_dcount = nullptr;   size_t d_dcount_cap = 0;          // [K]
     float* d_partial = nullptr; size_t d_partial_cap = 0;   // [K][nwaves][2] loss partials
@@ -76,6 +77,8 @@ struct orx_table {
     float* gsum = nullptr;            // [rows, dim] duplicate-row gradient sums (all-zero between steps)
     float* gsum2 = nullptr;           // second scratch rows of the pairwise step (rows referenced exactly twice)
     int* ready = nullptr;             // [rows] ready flags of the in-launch duplicate apply
+    int tag_gen = 0;                  // ctx->epoch_gen the ready / side tags belong to
+    int* side = nullptr;              // [rows][2] fused censor: last epoch with a duplicated pos / neg reference
 };
 
 struct OptSlots {
@@ -94,6 +97,7 @@ struct orx_opt {
 // ------------------------------------------------------- helpers (api.hip) ---
 int orx_ensure(void** p, size_t* cap, size_t bytes);           // grow a device buffer
 int orx_table_scratch(orx_table* t, bool second = false);       // allocate gsum (and gsum2)
+int orx_table_side(orx_table* t);                               // allocate the fused-censor side marks
 int orx_opt_slots(orx_opt* opt, orx_table* t, OptSlots* out);   // allocate optimizer slots
 int stage_ids(orx_ctx* c, const int32_t* host, int64_t n, int64_t off);   // H2D into ctx->d_ids
 int fetch_losses(orx_ctx* c, int64_t K, float* loss_out, float* l2_out);
@@ -130,6 +134,8 @@ struct PairArgs {
     // in-launch application of the PREVIOUS step's duplicated rows (n_apply_blocks == 0: off)
     int n_apply_blocks; int epoch;
     const uint32_t* prev_dlist; const int* prev_dcount;
+    int censor; float min_norm;               // censor_vec fused into the row write-back (fast dims, exact mode)
+    int* sideV;                               // [NI][2] epoch of the last step that referenced the item as a duplicated pos / neg
     int* readyU; int* readyV;                 // per-row ready flags (value = epoch of the launch that applied the row)
     const uint32_t* dlist;                    // duplicated rows of this step
     const int* dcount;

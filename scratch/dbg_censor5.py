@@ -1,0 +1,22 @@
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from openrec_amd import runtime as rt
+from oracle import numpy_oracle as orc
+D = 64; B = 1500
+for K in (2, 3, 4):
+  for scale in (1, 30):
+    for fb in ("0", "2"):
+        os.environ["ORX_FORCE_FALLBACK"] = fb
+        rng = np.random.default_rng(21)
+        U = rng.uniform(-.05, .05, (900, D)).astype(np.float32) * scale; V = rng.uniform(-.05, .05, (1100, D)).astype(np.float32) * scale
+        b = rng.uniform(-.05, .05, (1100, 1)).astype(np.float32)
+        rng = np.random.default_rng(5)
+        uid = rng.integers(0, 900, (K, B)).astype(np.int32); pid = rng.integers(0, 1100, (K, B)).astype(np.int32)
+        nid = rng.integers(0, 1100, (K, B)).astype(np.int32)
+        tU = rt.Table(900, D).write(U); tV = rt.Table(1100, D).write(V); tb = rt.Table(1100, 1).write(b)
+        loss, l2 = rt.pairwise_step("ucml", rt.Optimizer.sgd(0.01), tU, tV, tb, uid, pid, nid, K=K, B=B, margin=0.5, censor=False)
+        oo = orc.SGD(lr=0.01)
+        for s in range(K):
+            orc.ucml_step(U, V, b, uid[s], pid[s], nid[s], oo, margin=0.5, do_censor=False)
+        print("K", K, "scale", scale, "fb", fb, "err", np.abs(tU.read() - U).max() / np.abs(U).max(), np.abs(tV.read() - V).max() / np.abs(V).max())

@@ -204,3 +204,30 @@ def test_ucml_censor_inside_multi_step_call(D):
         lr, _ = orc.ucml_step(U, V, b, uid[s], pid[s], nid[s], oo, margin=0.5, do_censor=True)
         assert abs(loss[s] - lr) <= 2e-5 * abs(lr)
     assert rel_err(tU.read(), U) < 2e-5 and rel_err(tV.read(), V) < 2e-5 and rel_err(tb.read(), b) < 2e-5
+
+
+@pytest.mark.parametrize("D,optname,fallback", [(64, "sgd", "0"), (128, "sgd", "0"), (16, "adagrad", "0"), (128, "adagrad", "0"),
+                                                (64, "sgd", "1"), (64, "sgd", "2"), (128, "adagrad", "4"), (256, "sgd", "0")])
+def test_fused_censor_matches_censor_vec(D, optname, fallback, monkeypatch):
+    """censor_vec fused into the write-back (rows referenced once) and into the duplicate apply (ucml.py:44-48,
+    latent_factor.py:17-23): heavy duplication, rows shorter than min_norm (scaled x10 per censor), items
+    referenced as positive and negative in the same step (censored twice).  fallback 4 = the separate passes."""
+    monkeypatch.setenv("ORX_FORCE_FALLBACK", fallback)
+    rt = _rt()
+    from oracle import numpy_oracle as orc
+    K, B, NU, NI = 6, 3000, 700, 900
+    U, V, b, *_ = _rand_case(33, NU, NI, B, D)
+    U *= 20; V *= 20
+    V[::3] *= 1e-3; U[::5] *= 1e-3                     # norms far below 0.1: one censor = x10, two = x100
+    rng = np.random.default_rng(9)
+    uid = rng.integers(0, NU, (K, B)).astype(np.int32); pid = rng.integers(0, NI, (K, B)).astype(np.int32)
+    nid = rng.integers(0, NI, (K, B)).astype(np.int32)
+    nid[:, :30] = pid[:, :30]
+    tU, tV, tb = _tables(rt, U, V, b)
+    opt = rt.Optimizer.sgd(0.01) if optname == "sgd" else rt.Optimizer.adagrad(0.01)
+    oo = orc.SGD(lr=0.01) if optname == "sgd" else orc.Adagrad(lr=0.01)
+    loss, l2 = rt.pairwise_step("ucml", opt, tU, tV, tb, uid, pid, nid, K=K, B=B, margin=0.5, censor=True)
+    for s in range(K):
+        lr, l2r = orc.ucml_step(U, V, b, uid[s], pid[s], nid[s], oo, margin=0.5, do_censor=True)
+        assert abs(loss[s] - lr) <= 2e-5 * abs(lr) and abs(l2[s] - l2r) <= 2e-5 * abs(l2r)
+    assert rel_err(tU.read(), U) < 2e-5 and rel_err(tV.read(), V) < 2e-5 and rel_err(tb.read(), b) < 2e-5
