@@ -100,7 +100,7 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipStreamSynchronize(c->stream);
     prof_collect(c);
     hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_cflag); hipFree(c->d_dupbits); hipFree(c->d_dlist);
-    hipFree(c->d_dcount); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
+    hipFree(c->d_dcount); hipFree(c->d_refinfo); hipFree(c->d_tricnt); hipFree(c->d_segstart); hipFree(c->d_alloc); hipFree(c->d_dseg); hipFree(c->d_dcnt); hipFree(c->d_chunks); hipFree(c->d_stage); hipFree(c->d_stageb); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return ORX_OK;
@@ -395,14 +395,16 @@ int fetch_losses(orx_ctx* c, int64_t K, float* loss_out, float* l2_out) {
     return ORX_OK;
 }
 
-struct PairPlan { int nw; int64_t chunk; int64_t list_stride; int64_t Bp; };
+struct PairPlan { int nw; int64_t chunk; int64_t list_stride; int64_t Bp; int64_t chunk_stride; };
 
 // sizes every per-call buffer of the exact pairwise step (grow-only)
 static int pair_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t B, int mode, bool role_bits,
-                        bool inline_apply, int nb_total, PairPlan* plan) {
+                        bool inline_apply, bool staging, int nb_total, PairPlan* plan) {
     const int nw = orx_fused_nwaves(U->dim, B);
-    // steps are processed in chunks so that the per-step scratch stays bounded
+    // steps are processed in chunks so that the per-step scratch stays bounded (~80 B per triplet and
+    // step with a staging plan, ~25 B without)
     int64_t chunk = (int64_t)((256ull << 20) / ((size_t)3 * B * sizeof(int32_t)));
+    if (staging && chunk > 256) chunk = 256;
     if (chunk < 1) chunk = 1;
     if (chunk > K) chunk = K;
     ENSURE(c->d_partial, c->d_partial_cap, (size_t)chunk * nw * 2 * sizeof(float));
@@ -418,6 +420,19 @@ static int pair_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64
         ENSURE(c->d_dlist, c->d_dlist_cap, (size_t)chunk * list_stride * sizeof(uint32_t));
         ENSURE(c->d_dcount, c->d_dcount_cap, (size_t)chunk * sizeof(int));
     }
+    const int64_t chunk_stride = 3 * B / 32 + 16;   // sum over long rows of ceil(cnt / 64) < 3B/64 + 3B/65
+    if (staging) {
+        ENSURE(c->d_refinfo, c->d_refinfo_cap, (size_t)chunk * 3 * Bp * sizeof(int2));
+        ENSURE(c->d_tricnt, c->d_tricnt_cap, (size_t)chunk * B * sizeof(int));
+        ENSURE(c->d_segstart, c->d_segstart_cap, (size_t)chunk * B * sizeof(int));
+        ENSURE(c->d_alloc, c->d_alloc_cap, (size_t)chunk * 4 * sizeof(int));
+        ENSURE(c->d_dseg, c->d_dseg_cap, (size_t)chunk * list_stride * sizeof(int));
+        ENSURE(c->d_dcnt, c->d_dcnt_cap, (size_t)chunk * list_stride * sizeof(int));
+        ENSURE(c->d_chunks, c->d_chunks_cap, (size_t)chunk * chunk_stride * sizeof(int4));
+        ENSURE(c->d_stage, c->d_stage_cap, (size_t)2 * 3 * B * U->dim * sizeof(float));
+        ENSURE(c->d_stageb, c->d_stageb_cap, (size_t)2 * 3 * B * sizeof(float));
+    }
+    plan->chunk_stride = chunk_stride;
 
     plan->nw = nw; plan->chunk = chunk; plan->list_stride = list_stride; plan->Bp = Bp;
     return ORX_OK;
@@ -460,6 +475,8 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     // the previous step's duplicated rows are applied by extra blocks of the next step's launch
     // (no dup_apply launch, no kernel boundary) -- not with a separate censor pass between the steps
     const bool inline_apply = role_bits && !censor && K > 1 && orx_fused_can_inline_apply(U->dim) && !(fb & 2);
+    // rows referenced >= 3 times in a step: private staging slots instead of atomics (fb bit 3: atomics)
+    const bool staging = role_bits && orx_fused_can_inline_apply(U->dim) && !(fb & 8);
     const int nb_total = orx_dedup_buckets(U->rows) + orx_dedup_buckets(V->rows);
     if (mode != MODE_HOGWILD) {
         CHECK(orx_table_scratch(U, role_bits)); CHECK(orx_table_scratch(V, role_bits)); CHECK(orx_table_scratch(b, role_bits));
@@ -468,7 +485,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     CHECK(orx_opt_slots(opt, U, &sU)); CHECK(orx_opt_slots(opt, V, &sV)); CHECK(orx_opt_slots(opt, b, &sb));
 
     PairPlan plan;
-    CHECK(pair_buffers(c, U, V, K, B, mode, role_bits, inline_apply, nb_total, &plan));
+    CHECK(pair_buffers(c, U, V, K, B, mode, role_bits, inline_apply, staging, nb_total, &plan));
     const int nw = plan.nw;
     const int64_t chunk = plan.chunk, list_stride = plan.list_stride, Bp = plan.Bp;
 
@@ -498,6 +515,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
 
     for (int64_t s0 = 0; s0 < K; s0 += chunk) {
         const int64_t kc = (K - s0 < chunk) ? (K - s0) : chunk;
+        bool hot = false, use_stage = false, dense_dups = false;
         if (mode == MODE_EXACT) {
             // duplicate detection for every step of the chunk, on the id arrays alone
             DedupArgs d;
@@ -510,9 +528,44 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             d.nU = B; d.nP = B; d.nN = B; d.NU = U->rows; d.NI = V->rows;
             d.nbu = orx_dedup_buckets(U->rows); d.nbi = orx_dedup_buckets(V->rows);
             ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));
+            if (staging) {
+                d.refinfo = c->d_refinfo; d.tricnt = c->d_tricnt; d.segstart = c->d_segstart; d.alloc = c->d_alloc;
+                d.dseg = c->d_dseg; d.dcnt = c->d_dcnt; d.chunks = c->d_chunks;
+                d.tri_stride = B; d.chunk_stride = plan.chunk_stride;
+                ORX_HIP(hipMemsetAsync(c->d_tricnt, 0, (size_t)kc * B * sizeof(int), c->stream));
+                ORX_HIP(hipMemsetAsync(c->d_alloc, 0, (size_t)kc * 4 * sizeof(int), c->stream));
+            }
             CHECK(orx_launch_dedup(c, d, kc));
-            if (inline_apply) CHECK(orx_launch_urgent(c, d, kc));
+            if (inline_apply) {
+                // The in-launch apply hides the duplicate apply behind the next step while few references have
+                // to wait for it (the headline: ~0.16 B duplicated rows per step, 34 vs 39 us).  With many
+                // duplicated rows most references of the next step wait and the launch serializes (100k x 100k
+                // tables: 148 vs 56 us per step; break-even measured at ~0.19 B, 800k x 800k tables), so from
+                // B/5 duplicated rows on the apply is its own launch.
+                std::vector<int> dc((size_t)kc);
+                ORX_HIP(hipMemcpyAsync(dc.data(), c->d_dcount, dc.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                ORX_HIP(hipStreamSynchronize(c->stream));
+                int max_dup = 0;
+                for (int64_t i = 0; i < kc; ++i) max_dup = std::max(max_dup, dc[i]);
+                const char* thr = getenv("ORX_INLINE_DUP_DIV");        // debug: threshold = B / value
+                dense_dups = (int64_t)max_dup * (thr ? atoi(thr) : 5) > B;
+            }
+            if (staging) {
+                // long segments (a row referenced > 64 times in one step) need hot_reduce_kernel between the
+                // fused launch and the apply: one small read-back per chunk of steps decides
+                std::vector<int> al((size_t)kc * 4);
+                ORX_HIP(hipMemcpyAsync(al.data(), c->d_alloc, al.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                ORX_HIP(hipStreamSynchronize(c->stream));
+                hot = false;
+                int max_staged = 0;
+                for (int64_t i = 0; i < kc; ++i) { hot = hot || al[4 * i + 2] > 0; max_staged = std::max(max_staged, al[4 * i + 1]); }
+                // dedup_kernel plans staging only for row ranges where atomics would pile up; without any plan in
+                // the chunk the kernels without the segment bookkeeping are launched
+                use_stage = max_staged > 0;
+            }
+            if (inline_apply && !hot && !dense_dups) CHECK(orx_launch_urgent(c, d, kc));
         }
+        const bool inl = inline_apply && !hot && !dense_dups;
         if (censor) {
             // one elected reference per distinct row of each of the three id lists, for every step of the chunk
             ENSURE(c->d_cflag, c->d_cflag_cap, (size_t)3 * kc * B);
@@ -537,7 +590,19 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             a.dlist = c->d_dlist + (size_t)i * list_stride; a.dcount = c->d_dcount + i;
             a.partial = c->d_partial + (size_t)i * nw * 2;
             a.epoch = ++c->epoch;           // one epoch per step: ready flags and censor side marks are tagged with it
-            if (inline_apply && i > 0) {    // this launch also applies the duplicated rows of step i-1
+            if (use_stage) {
+                const size_t par = (size_t)(i & 1), ppar = par ^ 1;
+                a.refinfo = c->d_refinfo + (size_t)i * 3 * Bp; a.segstart = c->d_segstart + (size_t)i * B;
+                a.stage = c->d_stage + par * 3 * B * U->dim; a.stageb = c->d_stageb + par * 3 * B;
+                a.dseg = c->d_dseg + (size_t)i * list_stride; a.dcnt = c->d_dcnt + (size_t)i * list_stride;
+                a.chunks = c->d_chunks + (size_t)i * plan.chunk_stride; a.nchunk = c->d_alloc + 4 * i + 2;
+                a.prev_stage = c->d_stage + ppar * 3 * B * U->dim; a.prev_stageb = c->d_stageb + ppar * 3 * B;
+                a.prev_dseg = i > 0 ? c->d_dseg + (size_t)(i - 1) * list_stride : nullptr;
+                a.prev_dcnt = i > 0 ? c->d_dcnt + (size_t)(i - 1) * list_stride : nullptr;
+            } else {
+                a.stage = nullptr; a.stageb = nullptr; a.dcnt = nullptr; a.dseg = nullptr; a.prev_dcnt = nullptr; a.prev_dseg = nullptr;
+            }
+            if (inl && i > 0) {    // this launch also applies the duplicated rows of step i-1
                 // one lane group per duplicated row in a single pass for the usual ~0.15*B duplicated rows
                 // (the count lives in device memory; surplus blocks exit, a larger count grid-strides)
                 a.n_apply_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(16, (B / 4) / (1024 / U->dim) + 1));
@@ -546,7 +611,8 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
                 a.n_apply_blocks = 0; a.prev_dlist = nullptr; a.prev_dcount = nullptr;
             }
             CHECK(orx_launch_fused(c, model, opt->kind, mode, a));
-            if (mode == MODE_EXACT && (!inline_apply || i == kc - 1)) CHECK(orx_launch_dup_apply(c, opt->kind, a));
+            if (hot) CHECK(orx_launch_hot_reduce(c, a));
+            if (mode == MODE_EXACT && (!inl || i == kc - 1)) CHECK(orx_launch_dup_apply(c, opt->kind, a));
             if (mode == MODE_ACCUM) {   // Adam: dense-decay sweep of TF 2.0 over the whole tables
                 opt->t += 1;
                 const double b1 = opt->p0, b2 = opt->p1;
@@ -580,12 +646,13 @@ extern "C" int orx_pairwise_reserve(orx_ctx* c, orx_opt* opt, orx_table* U, orx_
     const int mode = opt->kind == ORX_ADAM ? MODE_ACCUM : MODE_EXACT;
     const bool role_bits = mode == MODE_EXACT && U->rows < (1LL << 28) && V->rows < (1LL << 28);
     const bool inline_apply = role_bits && K > 1 && orx_fused_can_inline_apply(U->dim);
+    const bool staging = role_bits && orx_fused_can_inline_apply(U->dim);
     const int nb_total = orx_dedup_buckets(U->rows) + orx_dedup_buckets(V->rows);
     CHECK(orx_table_scratch(U, role_bits)); CHECK(orx_table_scratch(V, role_bits)); CHECK(orx_table_scratch(b, role_bits));
     OptSlots s;
     CHECK(orx_opt_slots(opt, U, &s)); CHECK(orx_opt_slots(opt, V, &s)); CHECK(orx_opt_slots(opt, b, &s));
     PairPlan plan;
-    CHECK(pair_buffers(c, U, V, K, B, mode, role_bits, inline_apply, nb_total, &plan));
+    CHECK(pair_buffers(c, U, V, K, B, mode, role_bits, inline_apply, staging, nb_total, &plan));
     ORX_HIP(hipStreamSynchronize(c->stream));
     return ORX_OK;
 }

@@ -82,6 +82,43 @@ __device__ __forceinline__ void for_each_ref(const int32_t* idsA, int64_t nA, co
     }
 }
 
+// exclusive prefix sum of one int per thread over the DD_THREADS-thread workgroup; `total` = sum
+__device__ __forceinline__ int block_scan_excl(int v, int* wave_tot, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < DD_THREADS / 64; ++k) {
+        const int t = wave_tot[k];
+        if (k < wave) before += t;
+        all += t;
+    }
+    __syncthreads();            // wave_tot may be reused
+    total = all;
+    return before + incl - v;
+}
+
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---- staging ------------------------------------------------------------------------------
+// Rows referenced >= 3 times in a step ("tri" rows: hot items of a skewed id distribution) do not
+// take atomics: every such reference gets a private slot in a staging buffer, the slots of a row
+// are contiguous, and whoever applies the row sums its segment.  The plan is made here, on the
+// id arrays alone:
+//   dense numbering of the bucket's tri rows (popcount prefix over the tri bitmap, kept where the
+//   "seen" bitmap lived), a per-step allocator hands the bucket a range of dense numbers;
+//   in pass 2 every tri reference takes rank = atomicAdd(count[dense], 1) and records
+//   (dense, rank); after the pass the counts are final: a second scan gives every row its
+//   segment start.  A reference's slot = segstart[dense] + rank (computed by the fused kernel).
+// The duplicate list carries (segment start, count) per row; segments longer than
+// ORX_STAGE_CHUNK are also cut into pieces for hot_reduce_kernel.
 __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned int dd_lds[];
     unsigned int* seen = dd_lds;
@@ -89,6 +126,8 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
     unsigned int* tri = dd_lds + 2 * DD_WORDS;
     __shared__ int list_base;
     __shared__ int list_cnt;
+    __shared__ int wave_tot[DD_THREADS / 64];
+    __shared__ int sh_dense, sh_seg, sh_late;
     const int per_step = a.nbu + a.nbi;
     const int64_t s = blockIdx.x / per_step;
     int bk = blockIdx.x % per_step;
@@ -113,8 +152,9 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
     const bool vec = ((nA & 3) == 0) && ((n & 3) == 0) && ((((uintptr_t)idsA) | ((uintptr_t)idsB)) & 15) == 0;
 
     for (int i = threadIdx.x; i < 3 * DD_WORDS; i += DD_THREADS) dd_lds[i] = 0u;
-    if (threadIdx.x == 0) list_cnt = 0;
+    if (threadIdx.x == 0) { list_cnt = 0; sh_late = 0; }
     __syncthreads();
+    int late = 0;                                            // third-or-later references seen by this thread
     for_each_ref(idsA, nA, idsB, n, vec, [&](int64_t j, int id) {
         const int64_t l = (int64_t)id - r0;
         if ((uint64_t)l < (uint64_t)DD_ROWS && id_ok(id, rows)) {
@@ -124,14 +164,37 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
             if (old & bit) {
                 const unsigned int old2 = atomicOr(&dup[l >> 5], bit);
                 role = 1;
-                if (old2 & bit) { atomicOr(&tri[l >> 5], bit); role = 2; }
+                if (old2 & bit) { atomicOr(&tri[l >> 5], bit); role = 2; ++late; }
             }
             if (roles) roles[out_index(j)] = (unsigned char)role;
             if (a.first_only) dflag[ref0 + j] = (old & bit) ? 1 : 0;
         }
     });
+    if (a.refinfo != nullptr && late) atomicAdd(&sh_late, late);
     if (a.first_only) return;
     __syncthreads();
+    // staging plan, part 1: dense numbers for the tri rows of this range
+    int* prefix = reinterpret_cast<int*>(seen);             // "seen" is dead after pass 1
+    int ntri = 0;                                            // tri rows of the range (workgroup-uniform)
+    int dense0 = 0;
+    int2* refinfo = nullptr; int* tricnt = nullptr; int* segstart = nullptr;
+    // the plan pays for itself only where atomics would pile up: ranges with at least max(64, n/512)
+    // third-or-later references (uniform ids over a large table stay below: ~110 per range at the
+    // headline sizes); elsewhere role-2 references keep atomics, marked by refinfo = (-1, 0)
+    const bool plan = a.refinfo != nullptr && sh_late >= (n / 512 > 64 ? n / 512 : 64);
+    if (a.refinfo != nullptr) refinfo = a.refinfo + s * a.flag_stride;
+    if (plan) {
+        tricnt = a.tricnt + s * a.tri_stride; segstart = a.segstart + s * a.tri_stride;
+        int mine3 = 0;
+        for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) mine3 += __popc(tri[w]);
+        int run = block_scan_excl(mine3, wave_tot, ntri);
+        if (ntri) {
+            if (threadIdx.x == 0) sh_dense = atomicAdd(a.alloc + 4 * s, ntri);
+            for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) { prefix[w] = run; run += __popc(tri[w]); }
+            __syncthreads();
+            dense0 = sh_dense;
+        }
+    }
     for_each_ref(idsA, nA, idsB, n, vec, [&](int64_t j, int id) {
         const int64_t l = (int64_t)id - r0;
         const bool ok = id_ok(id, rows);
@@ -143,8 +206,15 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
                 if (roles && d) {
                     // rows with exactly two references: one plain store each into two scratch rows;
                     // three or more: every reference uses atomics (role 2)
-                    const unsigned int t3 = (tri[l >> 5] >> (l & 31)) & 1u;
+                    const unsigned int tw = tri[l >> 5];
+                    const unsigned int t3 = (tw >> (l & 31)) & 1u;
                     v |= (t3 ? 2u : (uint32_t)roles[out_index(j)]) << 29;
+                    if (t3 && ntri) {
+                        const int dense = dense0 + prefix[l >> 5] + __popc(tw & ((1u << (l & 31)) - 1u));
+                        refinfo[out_index(j)] = make_int2(dense, atomicAdd(tricnt + dense, 1));
+                    } else if (t3 && refinfo != nullptr) {
+                        refinfo[out_index(j)] = make_int2(-1, 0);
+                    }
                 }
                 ids_out[out_index(j)] = (int32_t)v;
             }
@@ -156,6 +226,51 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
         unsigned int* out = a.dupbits + ((size_t)s * per_step + (is_user ? bk : a.nbu + bk)) * DD_WORDS;
         for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) out[w] = dup[w];
     }
+    // staging plan, part 2: the counts are final -> segment start of every tri row.  A thread's tri rows
+    // are numbered q = 0, 1, ... in (word, bit) order; count and segment start of the first TQ stay in
+    // registers for the list emission below (one global round trip instead of three).
+    constexpr int TQ = 6;
+    int qcnt[TQ], qseg[TQ];
+    // constant-index access only (a dynamically indexed local array would live in scratch memory)
+    auto qput = [](int (&arr)[TQ], int q, int v) {
+#pragma unroll
+        for (int i = 0; i < TQ; ++i) if (q == i) arr[i] = v;
+    };
+    auto qget = [](const int (&arr)[TQ], int q) {
+        int v = 0;
+#pragma unroll
+        for (int i = 0; i < TQ; ++i) if (q == i) v = arr[i];
+        return v;
+    };
+    if (ntri) {
+        // counts of this range are only ever touched by this workgroup (atomics and agent-scope loads at
+        // the same L2): the barrier orders them, no fence (an agent-scope release writes back the whole L2)
+        __syncthreads();
+        int csum = 0, q = 0;
+        for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) {
+            const int c = __popc(tri[w]);
+            for (int k = 0; k < c; ++k, ++q) {
+                const int v = ld_agent(tricnt + dense0 + prefix[w] + k);
+                qput(qcnt, q, v);
+                csum += v;
+            }
+        }
+        int total_refs;
+        int run = block_scan_excl(csum, wave_tot, total_refs);
+        if (threadIdx.x == 0) sh_seg = atomicAdd(a.alloc + 4 * s + 1, total_refs);
+        __syncthreads();
+        run += sh_seg;
+        q = 0;
+        for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) {
+            const int c = __popc(tri[w]);
+            for (int k = 0; k < c; ++k, ++q) {
+                const int dense = dense0 + prefix[w] + k;
+                segstart[dense] = run;
+                qput(qseg, q, run);
+                run += q < TQ ? qget(qcnt, q) : ld_agent(tricnt + dense);
+            }
+        }
+    }
     // append the duplicated rows of this range to the step's list
     int mine = 0;
     for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) mine += __popc(dup[w]);
@@ -165,14 +280,40 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
     if (threadIdx.x == 0) list_base = list_cnt ? atomicAdd(a.dcount + s, list_cnt) : 0;
     __syncthreads();
     if (mine) {
-        uint32_t* out = a.dlist + s * a.list_stride + list_base + off;
+        int64_t e = s * a.list_stride + list_base + off;
         const uint32_t tag = is_user ? 0u : 0x80000000u;
+        int q = 0;
         for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) {
             unsigned int m = dup[w];
+            const unsigned int tw = tri[w];
             while (m) {
                 const int bpos = __ffs(m) - 1;
                 m &= m - 1;
-                *out++ = (uint32_t)(r0 + (int64_t)w * 32 + bpos) | tag;
+                const uint32_t ent = (uint32_t)(r0 + (int64_t)w * 32 + bpos) | tag;
+                a.dlist[e] = ent;
+                if (a.dcnt != nullptr) {
+                    int c = 0, sg = 0;
+                    if (ntri && ((tw >> bpos) & 1u)) {      // this thread wrote segstart[dense] itself (same word)
+                        if (q < TQ) { c = qget(qcnt, q); sg = qget(qseg, q); }
+                        else {
+                            const int dense = dense0 + prefix[w] + __popc(tw & ((1u << bpos) - 1u));
+                            c = ld_agent(tricnt + dense);
+                            sg = segstart[dense];
+                        }
+                        ++q;
+                        if (c > ORX_STAGE_CHUNK) {          // long segment: pieces for hot_reduce_kernel
+                            const int pieces = (c + ORX_STAGE_CHUNK - 1) / ORX_STAGE_CHUNK;
+                            int4* ck = a.chunks + s * a.chunk_stride + atomicAdd(a.alloc + 4 * s + 2, pieces);
+                            for (int k = 0; k < pieces; ++k) {
+                                const int len = c - k * ORX_STAGE_CHUNK < ORX_STAGE_CHUNK ? c - k * ORX_STAGE_CHUNK : ORX_STAGE_CHUNK;
+                                ck[k] = make_int4((int)ent, sg + k * ORX_STAGE_CHUNK, len, 0);
+                            }
+                            c = -c;
+                        }
+                    }
+                    a.dseg[e] = sg; a.dcnt[e] = c;
+                }
+                ++e;
             }
         }
     }
@@ -284,6 +425,42 @@ __device__ __forceinline__ void dup_store1(float* G1, float* G2, size_t off, flo
     else unsafeAtomicAdd(G1 + off, g);
 }
 
+// with a staging plan (slot >= 0) a role-2 reference owns one staging slot: plain store, no atomics
+__device__ __forceinline__ void dup_store4s(float* G1, float* G2, size_t off, f4 g, int role, float* stage, int slot, int D, int sub) {
+    if (role == 2 && slot >= 0) *reinterpret_cast<f4*>(stage + (size_t)slot * D + 4 * sub) = g;
+    else dup_store4(G1, G2, off, g, role);
+}
+
+__device__ __forceinline__ void dup_store1s(float* G1, float* G2, size_t off, float g, int role, float* stageb, int slot) {
+    if (role == 2 && slot >= 0) stageb[slot] = g;
+    else dup_store1(G1, G2, off, g, role);
+}
+
+// sum of a staging segment, one float4 column slice per lane (LPR lanes per row)
+template <int D>
+__device__ __forceinline__ f4 segment_sum4(const float* stage, int seg, int cnt, int sub) {
+    const float* p = stage + (size_t)seg * D + 4 * sub;
+    f4 s0, s1; s0.x = s0.y = s0.z = s0.w = 0.0f; s1 = s0;
+    int k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+        const f4 a0 = *reinterpret_cast<const f4*>(p + (size_t)(k + 0) * D);
+        const f4 a1 = *reinterpret_cast<const f4*>(p + (size_t)(k + 1) * D);
+        const f4 a2 = *reinterpret_cast<const f4*>(p + (size_t)(k + 2) * D);
+        const f4 a3 = *reinterpret_cast<const f4*>(p + (size_t)(k + 3) * D);
+        s0 = s0 + (a0 + a1); s1 = s1 + (a2 + a3);
+    }
+    for (; k < cnt; ++k) s0 = s0 + *reinterpret_cast<const f4*>(p + (size_t)k * D);
+    return s0 + s1;
+}
+
+// sum of the staged bias gradients of a segment, spread over the LPR lanes of the row's group
+template <int LPR>
+__device__ __forceinline__ float segment_sum1(const float* stageb, int seg, int cnt, int sub) {
+    float s = 0.0f;
+    for (int k = sub; k < cnt; k += LPR) s += stageb[seg + k];
+    return group_allreduce<LPR>(s);
+}
+
 // ---- in-launch application of the previous step's duplicated rows ------------------------
 // The first `n_apply_blocks` blocks of a fused launch of step s apply the summed gradients
 // that step s-1 left in the scratch rows (what dup_apply_kernel does as a launch of its own).
@@ -327,7 +504,7 @@ __device__ __forceinline__ bool censored_twice(const PairArgs& a, size_t row, in
     return m.x == ep && m.y == ep;
 }
 
-template <int LPR, int OPT, bool CENSOR>
+template <int LPR, int OPT, bool CENSOR, bool STAGED>
 __device__ __forceinline__ void inline_apply(const PairArgs& a) {
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
@@ -345,7 +522,12 @@ __device__ __forceinline__ void inline_apply(const PairArgs& a) {
         float* g1 = (item ? a.gV : a.gU) + row * D + 4 * sub;
         float* g2 = (item ? a.gV2 : a.gU2) + row * D + 4 * sub;
         float* wp = W + row * D + 4 * sub;
-        const f4 g = *reinterpret_cast<const f4*>(g1) + *reinterpret_cast<const f4*>(g2);
+        // staged row (>= 3 references): sum its segment; the scratch rows were not used
+        const int scnt = STAGED ? a.prev_dcnt[e] : 0;
+        const int sseg = STAGED && scnt > 0 ? a.prev_dseg[e] : 0;
+        f4 g;
+        if (STAGED && scnt > 0) g = segment_sum4<D>(a.prev_stage, sseg, scnt, sub);
+        else g = *reinterpret_cast<const f4*>(g1) + *reinterpret_cast<const f4*>(g2);
         const f4 w = *reinterpret_cast<const f4*>(wp);
         f4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
         if (OPT == ORX_ADAGRAD) acc = *reinterpret_cast<const f4*>(A + row * D + 4 * sub);
@@ -360,14 +542,16 @@ __device__ __forceinline__ void inline_apply(const PairArgs& a) {
         }
         f4 z; z.x = z.y = z.z = z.w = 0.0f;
         store_wt4(wp, wn);
-        store_wt4(g1, z);
-        store_wt4(g2, z);
+        if (!STAGED || scnt <= 0) { store_wt4(g1, z); store_wt4(g2, z); }
         if (OPT == ORX_ADAGRAD) store_wt4(A + row * D + 4 * sub, acc);
+        float gbs = 0.0f;
+        if (STAGED && scnt > 0 && item) gbs = segment_sum1<LPR>(a.prev_stageb, sseg, scnt, sub);
         if (item && sub == 0) {
-            const float gb = a.gb[row] + a.gb2[row];
+            const float gb = STAGED && scnt > 0 ? gbs : a.gb[row] + a.gb2[row];
             float ab = OPT == ORX_ADAGRAD ? a.ab[row] : 0.0f;
             const float bn = opt_rule<OPT>(a.b[row], gb, ab, a.lr, a.eps);
-            store_wt(a.b + row, bn); store_wt(a.gb + row, 0.0f); store_wt(a.gb2 + row, 0.0f);
+            store_wt(a.b + row, bn);
+            if (!STAGED || scnt <= 0) { store_wt(a.gb + row, 0.0f); store_wt(a.gb2 + row, 0.0f); }
             if (OPT == ORX_ADAGRAD) store_wt(a.ab + row, ab);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store of this wave has been written through
@@ -381,7 +565,7 @@ __device__ __forceinline__ void wait_ready(const int* flag, int epoch) {
 
 // ------------------------------------------------------------ fused kernel ---
 // LPR lanes own one row (D = 4*LPR).  MODE: see orx_internal.h.
-template <int LPR, int MODEL, int OPT, int MODE, bool CENSOR = false>
+template <int LPR, int MODEL, int OPT, int MODE, bool CENSOR = false, bool STAGED = false>
 __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
@@ -390,7 +574,7 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     const int grp = lane / LPR;
     const int nab = MODE == MODE_EXACT ? a.n_apply_blocks : 0;
     if (MODE == MODE_EXACT && (int)blockIdx.x < nab) {          // apply role (block-uniform)
-        inline_apply<LPR, OPT, CENSOR>(a);
+        inline_apply<LPR, OPT, CENSOR, STAGED>(a);
         return;
     }
     const int64_t wave_global = (int64_t)(blockIdx.x - nab) * 4 + (threadIdx.x >> 6);
@@ -419,6 +603,14 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             if (sub == 0) *a.err = 1;       // the reference's CPU gather raises; the triplet is skipped
             continue;
         }
+        // staged references (role 2 with a staging plan): slot = segment start of the row + rank of the
+        // reference, looked up only where such a reference deposits its gradient
+        const int64_t Bp = a.pid - a.uid;           // the three id arrays of a step are Bp apart
+        auto slot_of = [&](int64_t ref) -> int {
+            if (!STAGED) return -1;
+            const int2 ri = a.refinfo[ref];
+            return ri.x < 0 ? -1 : a.segstart[ri.x] + ri.y;      // (-1, 0): the row's range made no plan -> atomics
+        };
         if (MODE == MODE_EXACT && urgent) {
             // a row of this triplet is being updated by an apply block of this launch
             if (sub == 0) {
@@ -452,20 +644,22 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             // duplicated rows are censored by the kernel that applies their summed gradient
             f4 wu = ru, wp = rp, wn = rn;
             if (du == 0) wu = opt_new4<OPT>(a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
-            else dup_store4(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku);
+            else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t) : -1, D, sub);
             if (dp == 0) {
                 wp = opt_new4<OPT>(a.aV + (size_t)p * D + 4 * sub, rp, gp, a.lr, a.eps);
                 if (sub == 0) opt_apply1<OPT>(a.b + p, a.ab + p, bp, gbp, a.lr, a.eps);
             } else {
-                dup_store4(a.gV, a.gV2, (size_t)p * D + 4 * sub, gp, kp);
-                if (sub == 0) { dup_store1(a.gb, a.gb2, p, gbp, kp); a.sideV[2 * (size_t)p] = a.epoch; }
+                const int sp = kp == 2 ? slot_of(Bp + t) : -1;
+                dup_store4s(a.gV, a.gV2, (size_t)p * D + 4 * sub, gp, kp, a.stage, sp, D, sub);
+                if (sub == 0) { dup_store1s(a.gb, a.gb2, p, gbp, kp, a.stageb, sp); a.sideV[2 * (size_t)p] = a.epoch; }
             }
             if (dn == 0) {
                 wn = opt_new4<OPT>(a.aV + (size_t)n * D + 4 * sub, rn, gn, a.lr, a.eps);
                 if (sub == 0) opt_apply1<OPT>(a.b + n, a.ab + n, bn, gbn, a.lr, a.eps);
             } else {
-                dup_store4(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn);
-                if (sub == 0) { dup_store1(a.gb, a.gb2, n, gbn, kn); a.sideV[2 * (size_t)n + 1] = a.epoch; }
+                const int sn = kn == 2 ? slot_of(2 * Bp + t) : -1;
+                dup_store4s(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn, a.stage, sn, D, sub);
+                if (sub == 0) { dup_store1s(a.gb, a.gb2, n, gbn, kn, a.stageb, sn); a.sideV[2 * (size_t)n + 1] = a.epoch; }
             }
             wu = censor4<LPR>(wu, a.min_norm); wp = censor4<LPR>(wp, a.min_norm); wn = censor4<LPR>(wn, a.min_norm);
             if (du == 0) *reinterpret_cast<f4*>(Up) = wu;
@@ -474,20 +668,22 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             continue;
         }
         if (du == 0) opt_apply4<OPT>(Up, a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
-        else dup_store4(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku);
+        else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t) : -1, D, sub);
         if (dp == 0) {
             opt_apply4<OPT>(Pp, a.aV + (size_t)p * D + 4 * sub, rp, gp, a.lr, a.eps);
             if (sub == 0) opt_apply1<OPT>(a.b + p, a.ab + p, bp, gbp, a.lr, a.eps);
         } else {
-            dup_store4(a.gV, a.gV2, (size_t)p * D + 4 * sub, gp, kp);
-            if (sub == 0) dup_store1(a.gb, a.gb2, p, gbp, kp);
+            const int sp = kp == 2 ? slot_of(Bp + t) : -1;
+            dup_store4s(a.gV, a.gV2, (size_t)p * D + 4 * sub, gp, kp, a.stage, sp, D, sub);
+            if (sub == 0) dup_store1s(a.gb, a.gb2, p, gbp, kp, a.stageb, sp);
         }
         if (dn == 0) {
             opt_apply4<OPT>(Np, a.aV + (size_t)n * D + 4 * sub, rn, gn, a.lr, a.eps);
             if (sub == 0) opt_apply1<OPT>(a.b + n, a.ab + n, bn, gbn, a.lr, a.eps);
         } else {
-            dup_store4(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn);
-            if (sub == 0) dup_store1(a.gb, a.gb2, n, gbn, kn);
+            const int sn = kn == 2 ? slot_of(2 * Bp + t) : -1;
+            dup_store4s(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn, a.stage, sn, D, sub);
+            if (sub == 0) dup_store1s(a.gb, a.gb2, n, gbn, kn, a.stageb, sn);
         }
     }
     const float ls = wave_sum(loss_acc);
@@ -518,13 +714,22 @@ __global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
         float* G2 = item ? a.gV2 : a.gU2;
         float* gp = G + row * D + 4 * sub;
         float* wp = W + row * D + 4 * sub;
-        f4 g = *reinterpret_cast<const f4*>(gp);
+        // staged row: 0 < scnt <= ORX_STAGE_CHUNK: sum the segment here; scnt < 0: hot_reduce_kernel has
+        // summed the (long) segment into the scratch row; scnt == 0: two-reference row, scratch rows
+        const int scnt = a.dcnt != nullptr ? a.dcnt[e] : 0;
+        const int sseg = scnt > 0 ? a.dseg[e] : 0;
         const f4 w = *reinterpret_cast<const f4*>(wp);
         f4 z; z.x = z.y = z.z = z.w = 0.0f;
-        *reinterpret_cast<f4*>(gp) = z;
-        if (G2 != nullptr) {
-            g = g + *reinterpret_cast<const f4*>(G2 + row * D + 4 * sub);
-            *reinterpret_cast<f4*>(G2 + row * D + 4 * sub) = z;
+        f4 g;
+        if (scnt > 0) {
+            g = segment_sum4<D>(a.stage, sseg, scnt, sub);
+        } else {
+            g = *reinterpret_cast<const f4*>(gp);
+            *reinterpret_cast<f4*>(gp) = z;
+            if (G2 != nullptr && scnt == 0) {
+                g = g + *reinterpret_cast<const f4*>(G2 + row * D + 4 * sub);
+                *reinterpret_cast<f4*>(G2 + row * D + 4 * sub) = z;
+            }
         }
         if (a.censor) {
             f4 wn = censor4<LPR>(opt_new4<OPT>(A + row * D + 4 * sub, w, g, a.lr, a.eps), a.min_norm);
@@ -533,11 +738,40 @@ __global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
         } else {
             opt_apply4<OPT>(wp, A + row * D + 4 * sub, w, g, a.lr, a.eps);
         }
+        float gbs = 0.0f;
+        if (scnt > 0 && item && a.b != nullptr) gbs = segment_sum1<LPR>(a.stageb, sseg, scnt, sub);
         if (item && a.b != nullptr && sub == 0) {
-            float gb = a.gb[row];
-            a.gb[row] = 0.0f;
-            if (a.gb2 != nullptr) { gb += a.gb2[row]; a.gb2[row] = 0.0f; }
+            float gb = gbs;
+            if (scnt <= 0) {
+                gb = a.gb[row];
+                a.gb[row] = 0.0f;
+                if (a.gb2 != nullptr && scnt == 0) { gb += a.gb2[row]; a.gb2[row] = 0.0f; }
+            }
             opt_apply1<OPT>(a.b + row, a.ab + row, a.b[row], gb, a.lr, a.eps);
+        }
+    }
+}
+
+// hot_reduce: one group of LPR lanes per <= ORX_STAGE_CHUNK-reference piece of a long staging segment;
+// the piece sums go into the row's scratch row with (few) atomics, dup_apply_kernel applies the row.
+template <int LPR>
+__global__ __launch_bounds__(256) void hot_reduce_kernel(PairArgs a) {
+    constexpr int TPW = 64 / LPR;
+    constexpr int D = 4 * LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    const int n = *a.nchunk;
+    const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
+    for (int64_t c = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + grp; c < n; c += stride) {
+        const int4 ck = a.chunks[c];
+        const bool item = ((uint32_t)ck.x >> 31) != 0;
+        const size_t row = (uint32_t)ck.x & 0x7fffffffu;
+        const f4 g = segment_sum4<D>(a.stage, ck.y, ck.z, sub);
+        atomic_add_f4((item ? a.gV : a.gU) + row * D + 4 * sub, g);
+        if (item && a.b != nullptr) {
+            const float gb = segment_sum1<LPR>(a.stageb, ck.y, ck.z, sub);
+            if (sub == 0) unsafeAtomicAdd(a.gb + row, gb);
         }
     }
 }
@@ -678,7 +912,9 @@ template <int LPR, int MODEL, int OPT>
 static void launch_fused_mode(int mode, dim3 g, orx_ctx* s, const PairArgs& a) {
     switch (mode) {
         case MODE_EXACT:
-            if (a.censor) ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, OPT, MODE_EXACT, true>), g, dim3(256), 0, a);
+            if (a.censor && a.stage) ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, OPT, MODE_EXACT, true, true>), g, dim3(256), 0, a);
+            else if (a.censor) ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, OPT, MODE_EXACT, true, false>), g, dim3(256), 0, a);
+            else if (a.stage) ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, OPT, MODE_EXACT, false, true>), g, dim3(256), 0, a);
             else ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, OPT, MODE_EXACT>), g, dim3(256), 0, a);
             break;
         case MODE_HOGWILD: ORX_LAUNCH(s, (fused_kernel<LPR, MODEL, OPT, MODE_HOGWILD>), g, dim3(256), 0, a); break;
@@ -737,6 +973,22 @@ static void launch_dup_apply_lpr(int lpr, dim3 g, orx_ctx* s, const PairArgs& a)
         case 64: ORX_LAUNCH(s, (dup_apply_kernel<64, OPT>), g, dim3(256), 0, a); break;
         default: ORX_LAUNCH(s, (dup_apply_generic_kernel<OPT>), g, dim3(256), 0, a); break;
     }
+}
+
+int orx_launch_hot_reduce(orx_ctx* ctx, const PairArgs& a) {
+    ProfScope ps(ctx, ORX_K_DUPAPPLY);
+    const int lpr = lpr_for_dim(a.D);
+    const dim3 g(1024);
+    switch (lpr) {
+        case 4: ORX_LAUNCH(ctx, (hot_reduce_kernel<4>), g, dim3(256), 0, a); break;
+        case 8: ORX_LAUNCH(ctx, (hot_reduce_kernel<8>), g, dim3(256), 0, a); break;
+        case 16: ORX_LAUNCH(ctx, (hot_reduce_kernel<16>), g, dim3(256), 0, a); break;
+        case 32: ORX_LAUNCH(ctx, (hot_reduce_kernel<32>), g, dim3(256), 0, a); break;
+        case 64: ORX_LAUNCH(ctx, (hot_reduce_kernel<64>), g, dim3(256), 0, a); break;
+        default: orx_set_error("hot_reduce: no staging for dim %d", a.D); return ORX_ERR_ARG;
+    }
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
 }
 
 // The number of duplicated rows lives in device memory: fixed grid, grid-stride loop.

@@ -55,6 +55,16 @@ struct orx_ctx {
     unsigned int* d_dupbits = nullptr; size_t d_dupbits_cap = 0; // [K][buckets][words] duplicate bitmaps
     int epoch = 0;                                               // step epoch: tags ready flags and censor side marks
     int epoch_gen = 0;                                           // bumped when `epoch` wraps (tables then clear their tags)
+    // staging plan of rows referenced >= 3 times in a step (see kernels_pairwise.hip, "staging")
+    int2* d_refinfo = nullptr; size_t d_refinfo_cap = 0;         // [K][3Bp] (dense row, rank) of role-2 references
+    int* d_tricnt = nullptr;   size_t d_tricnt_cap = 0;          // [K][B] references per dense row
+    int* d_segstart = nullptr; size_t d_segstart_cap = 0;        // [K][B] first staging slot per dense row
+    int* d_alloc = nullptr;    size_t d_alloc_cap = 0;           // [K][4] allocators: dense rows, staging slots, chunks
+    int* d_dseg = nullptr;     size_t d_dseg_cap = 0;            // [K][2B] parallel to dlist: staging segment start
+    int* d_dcnt = nullptr;     size_t d_dcnt_cap = 0;            // [K][2B] parallel to dlist: segment length (0: two-reference row, <0: long)
+    int4* d_chunks = nullptr;  size_t d_chunks_cap = 0;          // [K][chunk_stride] 64-reference pieces of long segments
+    float* d_stage = nullptr;  size_t d_stage_cap = 0;           // [2][3B][D] staged gradients (double-buffered by step parity)
+    float* d_stageb = nullptr; size_t d_stageb_cap = 0;          // [2][3B] staged bias gradients
     uint32_t* d_dlist = nullptr; size_t d_dlist_cap = 0;         // [K][2B] duplicated rows
     int* d_dcount = nullptr;   size_t d_dcount_cap = 0;          // [K]
     float* d_partial = nullptr; size_t d_partial_cap = 0;   // [K][nwaves][2] loss partials
@@ -139,6 +149,12 @@ struct PairArgs {
     int* readyU; int* readyV;                 // per-row ready flags (value = epoch of the launch that applied the row)
     const uint32_t* dlist;                    // duplicated rows of this step
     const int* dcount;
+    // staging of rows referenced >= 3 times (NULL stage: such references use atomics into gsum)
+    const int2* refinfo; const int* segstart;         // this step
+    float* stage; float* stageb;                      // this step's staging buffers
+    const int* dseg; const int* dcnt;                 // parallel to dlist
+    const float* prev_stage; const float* prev_stageb; const int* prev_dseg; const int* prev_dcnt;   // step s-1 (in-launch apply)
+    const int4* chunks; const int* nchunk;            // long segments of this step (hot_reduce_kernel)
     int64_t B; int64_t NU; int64_t NI;
     int D;
     float lr; float eps; float margin; float invB; float l2w;
@@ -162,7 +178,15 @@ struct DedupArgs {
     int64_t NU; int64_t NI;                   // table rows
     int nbu; int nbi;                         // row-range buckets per table (0 = table not scanned)
     int first_only;                           // censor: dflag = 1 only on non-first references
+    // staging plan (all NULL: rows referenced >= 3 times keep role 2 = atomics)
+    int2* refinfo;                            // [K][flag_stride]
+    int* tricnt; int* segstart;               // [K][tri_stride], tricnt zeroed before the launch
+    int* alloc;                               // [K][4], zeroed before the launch
+    int* dseg; int* dcnt;                     // [K][list_stride]
+    int4* chunks;                             // [K][chunk_stride]
+    int64_t tri_stride; int64_t chunk_stride;
 };
+constexpr int ORX_STAGE_CHUNK = 64;           // references per piece of a long staging segment
 
 struct ReduceArgs {
     const float* partial;                     // [K][nwaves][2]
@@ -221,6 +245,7 @@ int orx_point_nwaves(int D, int64_t B);
 // launchers implemented in kernels_pairwise.hip
 int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K);
 int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairArgs& a);
+int orx_launch_hot_reduce(orx_ctx* ctx, const PairArgs& a);
 int orx_launch_dup_apply(orx_ctx* ctx, int optkind, const PairArgs& a);
 int orx_launch_urgent(orx_ctx* ctx, const DedupArgs& a, int64_t K);
 int orx_fused_can_inline_apply(int D);

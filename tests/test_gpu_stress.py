@@ -32,10 +32,11 @@ def test_handoff_under_heavy_duplication(cfg):
             assert np.abs(dev.read() - host).max() <= 5e-5 * np.abs(host).max(), rep
 
 
-@pytest.mark.parametrize("fallback", ["1", "2"])
+@pytest.mark.parametrize("fallback", ["1", "2", "8"])
 def test_fallback_paths_give_the_same_result(fallback, monkeypatch):
-    """The paths taken by tables of >= 2^28 rows (no role bits: atomics + dup_apply launches) and
-    without the in-launch apply are forced through ORX_FORCE_FALLBACK and checked like the main path."""
+    """The paths taken by tables of >= 2^28 rows (no role bits: atomics + dup_apply launches), without the
+    in-launch apply (2) and without the staging plan (8: rows referenced >= 3 times use atomics) are forced
+    through ORX_FORCE_FALLBACK and checked like the main path."""
     monkeypatch.setenv("ORX_FORCE_FALLBACK", fallback)
     test_handoff_under_heavy_duplication((3000, 3000, 8192, 12, 64, "sgd"))
     test_handoff_under_heavy_duplication((2000, 2500, 4096, 10, 128, "adagrad"))
@@ -57,3 +58,38 @@ def test_batch_larger_than_the_grid_cap():
         ref, l2r = orc.bpr_step(U, V, b, uid[s], pid[s], nid[s], oo)
         assert abs(loss[s] - ref) <= 1e-5 * abs(ref) and abs(l2[s] - l2r) <= 1e-5 * abs(l2r)
     assert np.abs(tU.read() - U).max() <= 1e-5 * np.abs(U).max() and np.abs(tV.read() - V).max() <= 1e-5 * np.abs(V).max()
+
+
+@pytest.mark.parametrize("model,D,optname,K", [("bpr", 64, "sgd", 5), ("ucml", 128, "sgd", 3), ("bpr", 16, "adagrad", 4),
+                                               ("bpr", 64, "sgd", 1)])
+def test_skewed_items_use_staging_and_hot_reduce(model, D, optname, K):
+    """Items ~ Zipf(1.05): the hottest row takes ~10 % of the 2B item references of a step (hundreds of
+    references -> long staging segments, hot_reduce_kernel), a long tail of rows takes 3..64 (segments summed
+    by the apply).  The oracle runs in float64 here: a row that sums ~1000 gradients has no unique fp32
+    answer (sequential fp32 summation alone is off by ~1e-4 of the largest term), so both the fp32 oracle
+    and the kernels are only comparable to the exact sum."""
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    NU, NI, B = 20000, 6000, 8192
+    rng = np.random.default_rng(11)
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    w = 1.0 / np.arange(1, NI + 1) ** 1.05
+    cdf = np.cumsum(w / w.sum())
+    perm = rng.permutation(NI)                                   # hot rows scattered over the table
+    draw = lambda: perm[np.minimum(np.searchsorted(cdf, rng.random((K, B))), NI - 1)].astype(np.int32)
+    uid = rng.integers(0, NU, (K, B)).astype(np.int32); pid = draw(); nid = draw()
+    uid[:, :300] = 7                                             # one hot user as well (a long user segment)
+    assert np.bincount(pid[0], minlength=NI).max() > 300
+    tU = rt.Table(NU, D).write(U); tV = rt.Table(NI, D).write(V); tb = rt.Table(NI, 1).write(b)
+    U, V, b = U.astype(np.float64), V.astype(np.float64), b.astype(np.float64)
+    lr = 0.002
+    opt = rt.Optimizer.sgd(lr) if optname == "sgd" else rt.Optimizer.adagrad(lr)
+    oo = orc.SGD(lr) if optname == "sgd" else orc.Adagrad(lr)
+    loss, l2 = rt.pairwise_step(model, opt, tU, tV, tb, uid, pid, nid, K=K, B=B)
+    step = orc.bpr_step if model == "bpr" else (lambda *a: orc.ucml_step(*a, margin=0.5, do_censor=False))
+    for s in range(K):
+        ref, l2r = step(U, V, b, uid[s], pid[s], nid[s], oo)
+        assert abs(loss[s] - ref) <= 2e-5 * abs(ref) and abs(l2[s] - l2r) <= 2e-5 * abs(l2r), (s, loss[s], ref)
+    for got, want in ((tU.read(), U), (tV.read(), V), (tb.read(), b)):
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
