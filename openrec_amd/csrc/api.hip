@@ -100,7 +100,7 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipStreamSynchronize(c->stream);
     prof_collect(c);
     hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_cflag); hipFree(c->d_dupbits); hipFree(c->d_dlist);
-    hipFree(c->d_dcount); hipFree(c->d_refinfo); hipFree(c->d_tricnt); hipFree(c->d_segstart); hipFree(c->d_alloc); hipFree(c->d_dseg); hipFree(c->d_dcnt); hipFree(c->d_chunks); hipFree(c->d_stage); hipFree(c->d_stageb); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
+    hipFree(c->d_dcount); hipFree(c->d_refinfo); hipFree(c->d_tricnt); hipFree(c->d_segstart); hipFree(c->d_alloc); hipFree(c->d_dseg); hipFree(c->d_dcnt); hipFree(c->d_chunks); hipFree(c->d_part); hipFree(c->d_partb); hipFree(c->d_stage); hipFree(c->d_stageb); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return ORX_OK;
@@ -395,7 +395,7 @@ int fetch_losses(orx_ctx* c, int64_t K, float* loss_out, float* l2_out) {
     return ORX_OK;
 }
 
-struct PairPlan { int nw; int64_t chunk; int64_t list_stride; int64_t Bp; int64_t chunk_stride; };
+struct PairPlan { int nw; int64_t chunk; int64_t list_stride; int64_t Bp; int64_t item_stride; int tree_off[3]; };
 
 // sizes every per-call buffer of the exact pairwise step (grow-only)
 static int pair_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t B, int mode, bool role_bits,
@@ -420,19 +420,24 @@ static int pair_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64
         ENSURE(c->d_dlist, c->d_dlist_cap, (size_t)chunk * list_stride * sizeof(uint32_t));
         ENSURE(c->d_dcount, c->d_dcount_cap, (size_t)chunk * sizeof(int));
     }
-    const int64_t chunk_stride = 3 * B / 32 + 16;   // sum over long rows of ceil(cnt / 64) < 3B/64 + 3B/65
+    // reduction tree over segments longer than ORX_SEG_DIRECT: level 1 has < 3B/64 + 3B/17 work items (one per
+    // started 64 references of a long row), level 2 < level 1 / 64 + 3B/1024, level 3 the rest
+    const int64_t cap1 = 3 * B / 64 + 3 * B / 17 + 64, cap2 = cap1 / 64 + 3 * B / 1024 + 64, cap3 = cap2 / 64 + 64;
+    const int64_t item_stride = cap1 + cap2 + cap3;
     if (staging) {
         ENSURE(c->d_refinfo, c->d_refinfo_cap, (size_t)chunk * 3 * Bp * sizeof(int2));
         ENSURE(c->d_tricnt, c->d_tricnt_cap, (size_t)chunk * B * sizeof(int));
         ENSURE(c->d_segstart, c->d_segstart_cap, (size_t)chunk * B * sizeof(int));
-        ENSURE(c->d_alloc, c->d_alloc_cap, (size_t)chunk * 4 * sizeof(int));
+        ENSURE(c->d_alloc, c->d_alloc_cap, (size_t)chunk * 8 * sizeof(int));
         ENSURE(c->d_dseg, c->d_dseg_cap, (size_t)chunk * list_stride * sizeof(int));
         ENSURE(c->d_dcnt, c->d_dcnt_cap, (size_t)chunk * list_stride * sizeof(int));
-        ENSURE(c->d_chunks, c->d_chunks_cap, (size_t)chunk * chunk_stride * sizeof(int4));
+        ENSURE(c->d_chunks, c->d_chunks_cap, (size_t)chunk * item_stride * sizeof(int4));
+        ENSURE(c->d_part, c->d_part_cap, (size_t)item_stride * U->dim * sizeof(float));
+        ENSURE(c->d_partb, c->d_partb_cap, (size_t)item_stride * sizeof(float));
         ENSURE(c->d_stage, c->d_stage_cap, (size_t)2 * 3 * B * U->dim * sizeof(float));
         ENSURE(c->d_stageb, c->d_stageb_cap, (size_t)2 * 3 * B * sizeof(float));
     }
-    plan->chunk_stride = chunk_stride;
+    plan->item_stride = item_stride; plan->tree_off[0] = 0; plan->tree_off[1] = (int)cap1; plan->tree_off[2] = (int)(cap1 + cap2);
 
     plan->nw = nw; plan->chunk = chunk; plan->list_stride = list_stride; plan->Bp = Bp;
     return ORX_OK;
@@ -516,6 +521,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     for (int64_t s0 = 0; s0 < K; s0 += chunk) {
         const int64_t kc = (K - s0 < chunk) ? (K - s0) : chunk;
         bool hot = false, use_stage = false, dense_dups = false;
+        int tree_levels = 0;
         if (mode == MODE_EXACT) {
             // duplicate detection for every step of the chunk, on the id arrays alone
             DedupArgs d;
@@ -530,10 +536,11 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));
             if (staging) {
                 d.refinfo = c->d_refinfo; d.tricnt = c->d_tricnt; d.segstart = c->d_segstart; d.alloc = c->d_alloc;
-                d.dseg = c->d_dseg; d.dcnt = c->d_dcnt; d.chunks = c->d_chunks;
-                d.tri_stride = B; d.chunk_stride = plan.chunk_stride;
+                d.dseg = c->d_dseg; d.dcnt = c->d_dcnt; d.items = c->d_chunks;
+                d.tri_stride = B; d.item_stride = plan.item_stride;
+                for (int l = 0; l < 3; ++l) d.tree_off[l] = plan.tree_off[l];
                 ORX_HIP(hipMemsetAsync(c->d_tricnt, 0, (size_t)kc * B * sizeof(int), c->stream));
-                ORX_HIP(hipMemsetAsync(c->d_alloc, 0, (size_t)kc * 4 * sizeof(int), c->stream));
+                ORX_HIP(hipMemsetAsync(c->d_alloc, 0, (size_t)kc * 8 * sizeof(int), c->stream));
             }
             CHECK(orx_launch_dedup(c, d, kc));
             if (inline_apply) {
@@ -551,14 +558,18 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
                 dense_dups = (int64_t)max_dup * (thr ? atoi(thr) : 5) > B;
             }
             if (staging) {
-                // long segments (a row referenced > 64 times in one step) need hot_reduce_kernel between the
+                // long segments (a row referenced > 16 times in one step) need the hot_reduce_kernel levels between the
                 // fused launch and the apply: one small read-back per chunk of steps decides
-                std::vector<int> al((size_t)kc * 4);
+                std::vector<int> al((size_t)kc * 8);
                 ORX_HIP(hipMemcpyAsync(al.data(), c->d_alloc, al.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 ORX_HIP(hipStreamSynchronize(c->stream));
-                hot = false;
+                hot = false; tree_levels = 0;
                 int max_staged = 0;
-                for (int64_t i = 0; i < kc; ++i) { hot = hot || al[4 * i + 2] > 0; max_staged = std::max(max_staged, al[4 * i + 1]); }
+                for (int64_t i = 0; i < kc; ++i) {
+                    for (int l = 0; l < 3; ++l) if (al[8 * i + 2 + l] > 0) tree_levels = std::max(tree_levels, l + 1);
+                    max_staged = std::max(max_staged, al[8 * i + 1]);
+                }
+                hot = tree_levels > 0;
                 // dedup_kernel plans staging only for row ranges where atomics would pile up; without any plan in
                 // the chunk the kernels without the segment bookkeeping are launched
                 use_stage = max_staged > 0;
@@ -595,7 +606,9 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
                 a.refinfo = c->d_refinfo + (size_t)i * 3 * Bp; a.segstart = c->d_segstart + (size_t)i * B;
                 a.stage = c->d_stage + par * 3 * B * U->dim; a.stageb = c->d_stageb + par * 3 * B;
                 a.dseg = c->d_dseg + (size_t)i * list_stride; a.dcnt = c->d_dcnt + (size_t)i * list_stride;
-                a.chunks = c->d_chunks + (size_t)i * plan.chunk_stride; a.nchunk = c->d_alloc + 4 * i + 2;
+                a.items = c->d_chunks + (size_t)i * plan.item_stride; a.nitems = c->d_alloc + 8 * i + 2;
+                a.part = c->d_part; a.partb = c->d_partb;
+                for (int l = 0; l < 3; ++l) a.tree_off[l] = plan.tree_off[l];
                 a.prev_stage = c->d_stage + ppar * 3 * B * U->dim; a.prev_stageb = c->d_stageb + ppar * 3 * B;
                 a.prev_dseg = i > 0 ? c->d_dseg + (size_t)(i - 1) * list_stride : nullptr;
                 a.prev_dcnt = i > 0 ? c->d_dcnt + (size_t)(i - 1) * list_stride : nullptr;
@@ -611,7 +624,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
                 a.n_apply_blocks = 0; a.prev_dlist = nullptr; a.prev_dcount = nullptr;
             }
             CHECK(orx_launch_fused(c, model, opt->kind, mode, a));
-            if (hot) CHECK(orx_launch_hot_reduce(c, a));
+            for (int l = 0; l < tree_levels; ++l) CHECK(orx_launch_hot_reduce(c, a, l));
             if (mode == MODE_EXACT && (!inl || i == kc - 1)) CHECK(orx_launch_dup_apply(c, opt->kind, a));
             if (mode == MODE_ACCUM) {   // Adam: dense-decay sweep of TF 2.0 over the whole tables
                 opt->t += 1;

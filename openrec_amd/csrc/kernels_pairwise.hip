@@ -117,8 +117,11 @@ __device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load
 //   in pass 2 every tri reference takes rank = atomicAdd(count[dense], 1) and records
 //   (dense, rank); after the pass the counts are final: a second scan gives every row its
 //   segment start.  A reference's slot = segstart[dense] + rank (computed by the fused kernel).
-// The duplicate list carries (segment start, count) per row; segments longer than
-// ORX_STAGE_CHUNK are also cut into pieces for hot_reduce_kernel.
+// The duplicate list carries (segment start, count) per row.  A segment longer than ORX_SEG_DIRECT
+// is reduced by a tree of 64-to-1 partial sums before the apply (hot_reduce_kernel, up to three
+// levels, plain stores only: same-address fp32 atomics cost ~100 ns each on this part, so even
+// 200 of them on a hot row would dominate the step); its list entry then points at the last
+// level's partial sums (count stored negative).
 __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned int dd_lds[];
     unsigned int* seen = dd_lds;
@@ -175,6 +178,11 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
     __syncthreads();
     // staging plan, part 1: dense numbers for the tri rows of this range
     int* prefix = reinterpret_cast<int*>(seen);             // "seen" is dead after pass 1
+    // up to DD_WORDS/2 tri rows: 16-bit prefixes in the first half of that space, the rows' reference
+    // counters in the second half (LDS atomics instead of global ones: a hot row takes thousands)
+    unsigned short* prefix16 = reinterpret_cast<unsigned short*>(seen);
+    int* lcnt = reinterpret_cast<int*>(seen) + DD_WORDS / 2;
+    bool lds_cnt = false;
     int ntri = 0;                                            // tri rows of the range (workgroup-uniform)
     int dense0 = 0;
     int2* refinfo = nullptr; int* tricnt = nullptr; int* segstart = nullptr;
@@ -189,8 +197,14 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
         for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) mine3 += __popc(tri[w]);
         int run = block_scan_excl(mine3, wave_tot, ntri);
         if (ntri) {
-            if (threadIdx.x == 0) sh_dense = atomicAdd(a.alloc + 4 * s, ntri);
-            for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) { prefix[w] = run; run += __popc(tri[w]); }
+            if (threadIdx.x == 0) sh_dense = atomicAdd(a.alloc + 8 * s, ntri);
+            lds_cnt = ntri <= DD_WORDS / 2;
+            if (lds_cnt) {
+                for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) { prefix16[w] = (unsigned short)run; run += __popc(tri[w]); }
+                for (int i = threadIdx.x; i < ntri; i += DD_THREADS) lcnt[i] = 0;
+            } else {
+                for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) { prefix[w] = run; run += __popc(tri[w]); }
+            }
             __syncthreads();
             dense0 = sh_dense;
         }
@@ -210,8 +224,8 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
                     const unsigned int t3 = (tw >> (l & 31)) & 1u;
                     v |= (t3 ? 2u : (uint32_t)roles[out_index(j)]) << 29;
                     if (t3 && ntri) {
-                        const int dense = dense0 + prefix[l >> 5] + __popc(tw & ((1u << (l & 31)) - 1u));
-                        refinfo[out_index(j)] = make_int2(dense, atomicAdd(tricnt + dense, 1));
+                        const int d = (lds_cnt ? (int)prefix16[l >> 5] : prefix[l >> 5]) + __popc(tw & ((1u << (l & 31)) - 1u));
+                        refinfo[out_index(j)] = make_int2(dense0 + d, lds_cnt ? atomicAdd(lcnt + d, 1) : atomicAdd(tricnt + dense0 + d, 1));
                     } else if (t3 && refinfo != nullptr) {
                         refinfo[out_index(j)] = make_int2(-1, 0);
                     }
@@ -249,25 +263,26 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
         int csum = 0, q = 0;
         for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) {
             const int c = __popc(tri[w]);
+            const int d0 = lds_cnt ? (int)prefix16[w] : prefix[w];
             for (int k = 0; k < c; ++k, ++q) {
-                const int v = ld_agent(tricnt + dense0 + prefix[w] + k);
+                const int v = lds_cnt ? lcnt[d0 + k] : ld_agent(tricnt + dense0 + d0 + k);
                 qput(qcnt, q, v);
                 csum += v;
             }
         }
         int total_refs;
         int run = block_scan_excl(csum, wave_tot, total_refs);
-        if (threadIdx.x == 0) sh_seg = atomicAdd(a.alloc + 4 * s + 1, total_refs);
+        if (threadIdx.x == 0) sh_seg = atomicAdd(a.alloc + 8 * s + 1, total_refs);
         __syncthreads();
         run += sh_seg;
         q = 0;
         for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) {
             const int c = __popc(tri[w]);
+            const int d0 = lds_cnt ? (int)prefix16[w] : prefix[w];
             for (int k = 0; k < c; ++k, ++q) {
-                const int dense = dense0 + prefix[w] + k;
-                segstart[dense] = run;
+                segstart[dense0 + d0 + k] = run;
                 qput(qseg, q, run);
-                run += q < TQ ? qget(qcnt, q) : ld_agent(tricnt + dense);
+                run += q < TQ ? qget(qcnt, q) : (lds_cnt ? lcnt[d0 + k] : ld_agent(tricnt + dense0 + d0 + k));
             }
         }
     }
@@ -296,19 +311,24 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
                     if (ntri && ((tw >> bpos) & 1u)) {      // this thread wrote segstart[dense] itself (same word)
                         if (q < TQ) { c = qget(qcnt, q); sg = qget(qseg, q); }
                         else {
-                            const int dense = dense0 + prefix[w] + __popc(tw & ((1u << bpos) - 1u));
-                            c = ld_agent(tricnt + dense);
-                            sg = segstart[dense];
+                            const int d = (lds_cnt ? (int)prefix16[w] : prefix[w]) + __popc(tw & ((1u << bpos) - 1u));
+                            c = lds_cnt ? lcnt[d] : ld_agent(tricnt + dense0 + d);
+                            sg = segstart[dense0 + d];
                         }
                         ++q;
-                        if (c > ORX_STAGE_CHUNK) {          // long segment: pieces for hot_reduce_kernel
-                            const int pieces = (c + ORX_STAGE_CHUNK - 1) / ORX_STAGE_CHUNK;
-                            int4* ck = a.chunks + s * a.chunk_stride + atomicAdd(a.alloc + 4 * s + 2, pieces);
-                            for (int k = 0; k < pieces; ++k) {
-                                const int len = c - k * ORX_STAGE_CHUNK < ORX_STAGE_CHUNK ? c - k * ORX_STAGE_CHUNK : ORX_STAGE_CHUNK;
-                                ck[k] = make_int4((int)ent, sg + k * ORX_STAGE_CHUNK, len, 0);
-                            }
-                            c = -c;
+                        if (c > ORX_SEG_DIRECT) {           // long segment: reduction tree
+                            int4* items = a.items + s * a.item_stride;
+                            int src = sg, len = c, level = 0;
+                            do {
+                                const int pieces = (len + ORX_PIECE - 1) / ORX_PIECE;
+                                const int b0 = a.tree_off[level] + atomicAdd(a.alloc + 8 * s + 2 + level, pieces);
+                                for (int k = 0; k < pieces; ++k) {
+                                    const int rem = len - k * ORX_PIECE;
+                                    items[b0 + k] = make_int4(src + k * ORX_PIECE, rem < ORX_PIECE ? rem : ORX_PIECE, b0 + k, 0);
+                                }
+                                src = b0; len = pieces; ++level;
+                            } while (len > ORX_SEG_DIRECT && level < 3);
+                            sg = src; c = -len;
                         }
                     }
                     a.dseg[e] = sg; a.dcnt[e] = c;
@@ -714,19 +734,21 @@ __global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
         float* G2 = item ? a.gV2 : a.gU2;
         float* gp = G + row * D + 4 * sub;
         float* wp = W + row * D + 4 * sub;
-        // staged row: 0 < scnt <= ORX_STAGE_CHUNK: sum the segment here; scnt < 0: hot_reduce_kernel has
-        // summed the (long) segment into the scratch row; scnt == 0: two-reference row, scratch rows
+        // staged row: scnt > 0: sum its staging segment here; scnt < 0: hot_reduce_kernel has reduced the
+        // (long) segment to -scnt partial sums; scnt == 0: two-reference row, scratch rows
         const int scnt = a.dcnt != nullptr ? a.dcnt[e] : 0;
-        const int sseg = scnt > 0 ? a.dseg[e] : 0;
+        const int sseg = scnt != 0 ? a.dseg[e] : 0;
         const f4 w = *reinterpret_cast<const f4*>(wp);
         f4 z; z.x = z.y = z.z = z.w = 0.0f;
         f4 g;
         if (scnt > 0) {
             g = segment_sum4<D>(a.stage, sseg, scnt, sub);
+        } else if (scnt < 0) {
+            g = segment_sum4<D>(a.part, sseg, -scnt, sub);
         } else {
             g = *reinterpret_cast<const f4*>(gp);
             *reinterpret_cast<f4*>(gp) = z;
-            if (G2 != nullptr && scnt == 0) {
+            if (G2 != nullptr) {
                 g = g + *reinterpret_cast<const f4*>(G2 + row * D + 4 * sub);
                 *reinterpret_cast<f4*>(G2 + row * D + 4 * sub) = z;
             }
@@ -739,39 +761,58 @@ __global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
             opt_apply4<OPT>(wp, A + row * D + 4 * sub, w, g, a.lr, a.eps);
         }
         float gbs = 0.0f;
-        if (scnt > 0 && item && a.b != nullptr) gbs = segment_sum1<LPR>(a.stageb, sseg, scnt, sub);
+        if (scnt != 0 && item && a.b != nullptr)
+            gbs = scnt > 0 ? segment_sum1<LPR>(a.stageb, sseg, scnt, sub) : segment_sum1<LPR>(a.partb, sseg, -scnt, sub);
         if (item && a.b != nullptr && sub == 0) {
             float gb = gbs;
-            if (scnt <= 0) {
+            if (scnt == 0) {
                 gb = a.gb[row];
                 a.gb[row] = 0.0f;
-                if (a.gb2 != nullptr && scnt == 0) { gb += a.gb2[row]; a.gb2[row] = 0.0f; }
+                if (a.gb2 != nullptr) { gb += a.gb2[row]; a.gb2[row] = 0.0f; }
             }
             opt_apply1<OPT>(a.b + row, a.ab + row, a.b[row], gb, a.lr, a.eps);
         }
     }
 }
 
-// hot_reduce: one group of LPR lanes per <= ORX_STAGE_CHUNK-reference piece of a long staging segment;
-// the piece sums go into the row's scratch row with (few) atomics, dup_apply_kernel applies the row.
+// hot_reduce: one level of the reduction tree over long staging segments.  One wavefront per work
+// item (src, len <= ORX_PIECE, dst): its 64/LPR lane groups each sum every (64/LPR)-th vector, the
+// groups combine by cross-lane shuffles and group 0 stores the partial sum.  Level 1 reads the
+// staged gradients, levels 2 and 3 the partial sums of the level below.  No atomics.
 template <int LPR>
-__global__ __launch_bounds__(256) void hot_reduce_kernel(PairArgs a) {
+__global__ __launch_bounds__(256) void hot_reduce_kernel(PairArgs a, int level) {
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
-    const int n = *a.nchunk;
-    const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
-    for (int64_t c = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + grp; c < n; c += stride) {
-        const int4 ck = a.chunks[c];
-        const bool item = ((uint32_t)ck.x >> 31) != 0;
-        const size_t row = (uint32_t)ck.x & 0x7fffffffu;
-        const f4 g = segment_sum4<D>(a.stage, ck.y, ck.z, sub);
-        atomic_add_f4((item ? a.gV : a.gU) + row * D + 4 * sub, g);
-        if (item && a.b != nullptr) {
-            const float gb = segment_sum1<LPR>(a.stageb, ck.y, ck.z, sub);
-            if (sub == 0) unsafeAtomicAdd(a.gb + row, gb);
+    const int n = a.nitems[level];
+    const int4* items = a.items + a.tree_off[level];
+    const float* src = level == 0 ? a.stage : a.part;
+    const float* srcb = level == 0 ? a.stageb : a.partb;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); c < n; c += stride) {
+        const int4 it = items[c];
+        const float* p = src + (size_t)it.x * D + 4 * sub;
+        f4 s0, s1; s0.x = s0.y = s0.z = s0.w = 0.0f; s1 = s0;
+        int k = grp;
+        for (; k + 3 * TPW < it.y; k += 4 * TPW) {
+            const f4 a0 = *reinterpret_cast<const f4*>(p + (size_t)(k + 0 * TPW) * D);
+            const f4 a1 = *reinterpret_cast<const f4*>(p + (size_t)(k + 1 * TPW) * D);
+            const f4 a2 = *reinterpret_cast<const f4*>(p + (size_t)(k + 2 * TPW) * D);
+            const f4 a3 = *reinterpret_cast<const f4*>(p + (size_t)(k + 3 * TPW) * D);
+            s0 = s0 + (a0 + a1); s1 = s1 + (a2 + a3);
+        }
+        for (; k < it.y; k += TPW) s0 = s0 + *reinterpret_cast<const f4*>(p + (size_t)k * D);
+        f4 g = s0 + s1;
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+            g.x += __shfl_xor(g.x, off); g.y += __shfl_xor(g.y, off); g.z += __shfl_xor(g.z, off); g.w += __shfl_xor(g.w, off);
+        }
+        if (grp == 0) *reinterpret_cast<f4*>(a.part + (size_t)it.z * D + 4 * sub) = g;
+        if (a.b != nullptr) {
+            const float gb = wave_sum(lane < it.y ? srcb[it.x + lane] : 0.0f);
+            if (lane == 0) a.partb[it.z] = gb;
         }
     }
 }
@@ -975,16 +1016,16 @@ static void launch_dup_apply_lpr(int lpr, dim3 g, orx_ctx* s, const PairArgs& a)
     }
 }
 
-int orx_launch_hot_reduce(orx_ctx* ctx, const PairArgs& a) {
+int orx_launch_hot_reduce(orx_ctx* ctx, const PairArgs& a, int level) {
     ProfScope ps(ctx, ORX_K_DUPAPPLY);
     const int lpr = lpr_for_dim(a.D);
-    const dim3 g(1024);
+    const dim3 g(level == 0 ? 2048 : 256);
     switch (lpr) {
-        case 4: ORX_LAUNCH(ctx, (hot_reduce_kernel<4>), g, dim3(256), 0, a); break;
-        case 8: ORX_LAUNCH(ctx, (hot_reduce_kernel<8>), g, dim3(256), 0, a); break;
-        case 16: ORX_LAUNCH(ctx, (hot_reduce_kernel<16>), g, dim3(256), 0, a); break;
-        case 32: ORX_LAUNCH(ctx, (hot_reduce_kernel<32>), g, dim3(256), 0, a); break;
-        case 64: ORX_LAUNCH(ctx, (hot_reduce_kernel<64>), g, dim3(256), 0, a); break;
+        case 4: ORX_LAUNCH(ctx, (hot_reduce_kernel<4>), g, dim3(256), 0, a, level); break;
+        case 8: ORX_LAUNCH(ctx, (hot_reduce_kernel<8>), g, dim3(256), 0, a, level); break;
+        case 16: ORX_LAUNCH(ctx, (hot_reduce_kernel<16>), g, dim3(256), 0, a, level); break;
+        case 32: ORX_LAUNCH(ctx, (hot_reduce_kernel<32>), g, dim3(256), 0, a, level); break;
+        case 64: ORX_LAUNCH(ctx, (hot_reduce_kernel<64>), g, dim3(256), 0, a, level); break;
         default: orx_set_error("hot_reduce: no staging for dim %d", a.D); return ORX_ERR_ARG;
     }
     ORX_HIP(hipGetLastError());

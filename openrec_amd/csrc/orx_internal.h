@@ -59,10 +59,12 @@ struct orx_ctx {
     int2* d_refinfo = nullptr; size_t d_refinfo_cap = 0;         // [K][3Bp] (dense row, rank) of role-2 references
     int* d_tricnt = nullptr;   size_t d_tricnt_cap = 0;          // [K][B] references per dense row
     int* d_segstart = nullptr; size_t d_segstart_cap = 0;        // [K][B] first staging slot per dense row
-    int* d_alloc = nullptr;    size_t d_alloc_cap = 0;           // [K][4] allocators: dense rows, staging slots, chunks
+    int* d_alloc = nullptr;    size_t d_alloc_cap = 0;           // [K][8] allocators: dense rows, staging slots, tree items per level
     int* d_dseg = nullptr;     size_t d_dseg_cap = 0;            // [K][2B] parallel to dlist: staging segment start
     int* d_dcnt = nullptr;     size_t d_dcnt_cap = 0;            // [K][2B] parallel to dlist: segment length (0: two-reference row, <0: long)
-    int4* d_chunks = nullptr;  size_t d_chunks_cap = 0;          // [K][chunk_stride] 64-reference pieces of long segments
+    int4* d_chunks = nullptr;  size_t d_chunks_cap = 0;          // [K][item_stride] work items of the reduction tree over long segments
+    float* d_part = nullptr;   size_t d_part_cap = 0;            // [item_stride][D] partial sums of the tree (one step at a time)
+    float* d_partb = nullptr;  size_t d_partb_cap = 0;           // [item_stride] the same for the bias gradients
     float* d_stage = nullptr;  size_t d_stage_cap = 0;           // [2][3B][D] staged gradients (double-buffered by step parity)
     float* d_stageb = nullptr; size_t d_stageb_cap = 0;          // [2][3B] staged bias gradients
     uint32_t* d_dlist = nullptr; size_t d_dlist_cap = 0;         // [K][2B] duplicated rows
@@ -154,7 +156,9 @@ struct PairArgs {
     float* stage; float* stageb;                      // this step's staging buffers
     const int* dseg; const int* dcnt;                 // parallel to dlist
     const float* prev_stage; const float* prev_stageb; const int* prev_dseg; const int* prev_dcnt;   // step s-1 (in-launch apply)
-    const int4* chunks; const int* nchunk;            // long segments of this step (hot_reduce_kernel)
+    const int4* items; const int* nitems;             // reduction tree over this step's long segments (hot_reduce_kernel):
+    float* part; float* partb;                        //   items of level l at items + tree_off[l], count nitems[l]; partial sums
+    int tree_off[3];
     int64_t B; int64_t NU; int64_t NI;
     int D;
     float lr; float eps; float margin; float invB; float l2w;
@@ -181,12 +185,14 @@ struct DedupArgs {
     // staging plan (all NULL: rows referenced >= 3 times keep role 2 = atomics)
     int2* refinfo;                            // [K][flag_stride]
     int* tricnt; int* segstart;               // [K][tri_stride], tricnt zeroed before the launch
-    int* alloc;                               // [K][4], zeroed before the launch
+    int* alloc;                               // [K][8], zeroed before the launch: 0 dense rows, 1 staging slots, 2.. tree items of level 1, 2, 3
     int* dseg; int* dcnt;                     // [K][list_stride]
-    int4* chunks;                             // [K][chunk_stride]
-    int64_t tri_stride; int64_t chunk_stride;
+    int4* items;                              // [K][item_stride] tree work items (src, len, dst, -), level l at offset tree_off[l]
+    int64_t tri_stride; int64_t item_stride;
+    int tree_off[3];
 };
-constexpr int ORX_STAGE_CHUNK = 64;           // references per piece of a long staging segment
+constexpr int ORX_SEG_DIRECT = 16;            // the apply sums up to this many staged gradients / partial sums of a row itself
+constexpr int ORX_PIECE = 64;                 // longer segments: a tree of 64-to-1 partial sums (hot_reduce_kernel, one wavefront per piece)
 
 struct ReduceArgs {
     const float* partial;                     // [K][nwaves][2]
@@ -245,7 +251,7 @@ int orx_point_nwaves(int D, int64_t B);
 // launchers implemented in kernels_pairwise.hip
 int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K);
 int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairArgs& a);
-int orx_launch_hot_reduce(orx_ctx* ctx, const PairArgs& a);
+int orx_launch_hot_reduce(orx_ctx* ctx, const PairArgs& a, int level);
 int orx_launch_dup_apply(orx_ctx* ctx, int optkind, const PairArgs& a);
 int orx_launch_urgent(orx_ctx* ctx, const DedupArgs& a, int64_t K);
 int orx_fused_can_inline_apply(int D);
