@@ -32,8 +32,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
-def alg_bytes_per_triplet(dim, opt):
-    # SGD 24*D + 28, Adagrad 48*D + 44 bytes per triplet
+def alg_bytes_per_triplet(dim, opt, model="bpr"):
+    # SGD 24*D + 28, Adagrad 48*D + 44 bytes per triplet; GMF / WRMF 16*D + 20 per (user, item, label)
+    if model in ("gmf", "wrmf"):
+        return 16 * dim + 20 if opt == "sgd" else 32 * dim + 28
     return 24 * dim + 28 if opt == "sgd" else 48 * dim + 44
 
 
@@ -88,7 +90,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--model", default="bpr", choices=["bpr", "ucml"])
+    ap.add_argument("--model", default="bpr", choices=["bpr", "ucml", "gmf", "wrmf"],
+                    help="gmf / wrmf: the pointwise step over B (user, item, label) samples (secondary workloads)")
     ap.add_argument("--opt", default="sgd", choices=["sgd", "adagrad"])
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--users", type=int, default=1_000_000)
@@ -129,13 +132,25 @@ def main():
         opt = rt.Optimizer.sgd(lr, ctx=ctx) if args.opt == "sgd" else rt.Optimizer.adagrad(lr, ctx=ctx)
         uid, pid, nid = make_ids(torch, args.users, args.items, K + W, args.batch, 1234, device, args.zipf)
         torch.cuda.synchronize()
+        pointwise = args.model in ("gmf", "wrmf")
+        if pointwise:
+            g = torch.Generator(device=device); g.manual_seed(7)
+            label = (torch.rand((K + W, args.batch), device=device, generator=g) < 0.5).to(torch.float32).contiguous()
+            wk = rt.Table(args.dim, 1, ctx).init_uniform(seed=3) if args.model == "gmf" else None
 
         def run(first, count, want_loss=False):
+            if pointwise:
+                return rt.pointwise_step(args.model, opt, U, V, b, wk, uid[first:first + count], pid[first:first + count],
+                                         label[first:first + count], K=count, B=args.batch, hogwild=args.hogwild,
+                                         want_loss=want_loss)
             return rt.pairwise_step(args.model, opt, U, V, b, uid[first:first + count], pid[first:first + count],
                                     nid[first:first + count], K=count, B=args.batch, margin=0.5,
                                     hogwild=args.hogwild, want_loss=want_loss, censor=args.censor)
 
-        rt.pairwise_reserve(opt, U, V, b, max(K, W, 1), args.batch)     # allocations stay out of the timed region
+        if pointwise:
+            run(0, max(K, W, 1))                                          # sizes every grow-only buffer
+        else:
+            rt.pairwise_reserve(opt, U, V, b, max(K, W, 1), args.batch)   # allocations stay out of the timed region
         if W:
             run(0, W)
         ctx.synchronize()
@@ -183,11 +198,12 @@ def main():
 
     if rank == 0:
         total = K * args.batch * world
-        bpt = alg_bytes_per_triplet(args.dim, args.opt)
+        bpt = alg_bytes_per_triplet(args.dim, args.opt, args.model)
+        unit = "samples/s" if args.model in ("gmf", "wrmf") else "triplets/s"
         out = {
             "metric": "BPR training triplets/sec at dim=64, 1Mx1M table" if (args.model, args.dim) == ("bpr", 64)
-                      else f"{args.model.upper()} training triplets/sec at dim={args.dim}",
-            "value": total / dt, "unit": "triplets/s", "n_gpus": world, "steps": K, "warmup": W,
+                      else f"{args.model.upper()} training {unit[:-2]}/sec at dim={args.dim}",
+            "value": total / dt, "unit": unit, "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.model} dim={args.dim} {args.users}x{args.items} table, "
@@ -197,7 +213,7 @@ def main():
                                    f"{', items ~ Zipf(%g)' % args.zipf if args.zipf else ''}",
                        "parallelism": parallelism},
         }
-        fused = prof.get("fused", {})
+        fused = prof.get("pointwise" if args.model in ("gmf", "wrmf") else "fused", {})
         if fused.get("launches"):
             dur = fused["total_ms"] / fused["launches"] * 1e-3
             achieved = args.batch * bpt / dur / 1e9
@@ -208,11 +224,11 @@ def main():
                     traffic = json.load(open(tfile)).get(f"{args.model}_d{args.dim}_{args.opt}")
                 except Exception:
                     traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": "fused_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            out["roofline"] = {"bound": "hbm", "kernel": "point_fused_kernel" if args.model in ("gmf", "wrmf") else "fused_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "bytes_per_triplet": bpt, "kernel_us": dur * 1e6,
                                "other_kernels_us": {k: v["total_ms"] / v["launches"] * 1e3
-                                                    for k, v in prof.items() if v.get("launches") and k != "fused"}}
+                                                    for k, v in prof.items() if v.get("launches") and k not in ("fused", "pointwise")}}
         if losses is not None:
             out["loss_first_last"] = [float(losses[0][0]), float(losses[0][-1])]
         if world == 1 and not args.sharded and not args.no_cpu_baseline:

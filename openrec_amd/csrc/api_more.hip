@@ -68,7 +68,7 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     const int nslot = nw + (model == ORX_GMF ? 1 : 0);      // + one slot for 0.5*||w||^2
     ENSURE(c->d_partial, c->d_partial_cap, (size_t)K * nslot * 2 * sizeof(float));
     ENSURE(c->d_loss, c->d_loss_cap, (size_t)K * 2 * sizeof(double));
-    if (model == ORX_GMF) ENSURE(c->d_wpart, c->d_wpart_cap, (size_t)nw * D * sizeof(float));
+    if (model == ORX_GMF) ENSURE(c->d_wpart, c->d_wpart_cap, (size_t)(nw + 256) * D * sizeof(float));   // + stage-1 rows of dense_reduce
     const int64_t list_stride = 2 * B;
     if (mode == MODE_EXACT) {
         ENSURE(c->d_dflag, c->d_dflag_cap, (size_t)K * 2 * B);
@@ -116,9 +116,12 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
             CHECK(orx_launch_adam_sweep(c, b->w, sb.s0, sb.s1, b->gsum, b->rows, lr_t, opt->p0, opt->p1, opt->p2));
         }
         if (model == ORX_GMF) {                  // dense Dense(1) kernel: reduce partials, apply the dense rule
-            CHECK(orx_launch_dense_reduce(c, c->d_wpart, nw, D, w->w, a.l2w, w->gsum, a.partial + 2 * nw));
-            if (mode == MODE_ACCUM) CHECK(orx_launch_adam_sweep(c, w->w, sw.s0, sw.s1, w->gsum, D, lr_t, opt->p0, opt->p1, opt->p2));
-            else CHECK(orx_launch_dense_apply(c, w->w, sw.s0, w->gsum, D, opt->kind, opt->lr, a.eps));
+            if (mode == MODE_ACCUM) {
+                CHECK(orx_launch_dense_reduce(c, c->d_wpart, nw, D, w->w, a.l2w, w->gsum, a.partial + 2 * nw, nullptr, -1, 0.f, 0.f));
+                CHECK(orx_launch_adam_sweep(c, w->w, sw.s0, sw.s1, w->gsum, D, lr_t, opt->p0, opt->p1, opt->p2));
+            } else {        // reduce + dense SGD / Adagrad rule in one launch
+                CHECK(orx_launch_dense_reduce(c, c->d_wpart, nw, D, w->w, a.l2w, nullptr, a.partial + 2 * nw, sw.s0, opt->kind, opt->lr, a.eps));
+            }
         }
     }
     ReduceArgs r;
@@ -151,7 +154,7 @@ extern "C" int orx_pointwise_loss(orx_ctx* c, int model, orx_table* U, orx_table
     a.partial = c->d_partial; a.err = c->d_err;
     a.uid = du; a.iid = di; a.label = dl;
     CHECK(orx_launch_point_fused(c, model, ORX_SGD, MODE_LOSS, a));
-    if (model == ORX_GMF) CHECK(orx_launch_dense_reduce(c, nullptr, 0, D, w->w, 0.f, nullptr, c->d_partial + 2 * nw));
+    if (model == ORX_GMF) CHECK(orx_launch_dense_reduce(c, nullptr, 0, D, w->w, 0.f, nullptr, c->d_partial + 2 * nw, nullptr, -1, 0.f, 0.f));
     ReduceArgs r;
     r.partial = c->d_partial; r.out = c->d_loss; r.nwaves = nslot;
     CHECK(orx_launch_loss_reduce(c, r, 1));

@@ -241,8 +241,8 @@ struct PointArgs {
 };
 
 int orx_launch_point_fused(orx_ctx* ctx, int model, int optkind, int mode, const PointArgs& a);
-int orx_launch_dense_reduce(orx_ctx* ctx, const float* wpartial, int nwaves, int D, const float* w, float l2w, float* gout,
-                            float* l2slot);
+int orx_launch_dense_reduce(orx_ctx* ctx, const float* wpartial, int nwaves, int D, float* w, float l2w, float* gout,
+                            float* l2slot, float* acc, int optkind /* -1: gradient to gout only */, float lr, float eps);
 int orx_launch_dense_apply(orx_ctx* ctx, float* w, float* acc, float* g, int n, int optkind, float lr, float eps);
 int orx_launch_score_all(orx_ctx* ctx, const float* U, const float* V, const float* b, const float* w,
                          const int32_t* uid, int64_t nq, int64_t NU, int64_t NI, int D, int kind, float* out);
