@@ -213,10 +213,12 @@ enum orx_dlrm_flags {
     ORX_DLRM_FP16_MLP = 32,         /* performance mode: the MLP products run on fp16 MFMA
                                        (operands rounded to fp16, fp32 accumulate / storage);
                                        NOT within the 1e-5 parity tolerance                 */
-    ORX_DLRM_REFERENCE_COMPAT = 16  /* reproduce second_order_feature_interaction.py:21-32
+    ORX_DLRM_REFERENCE_COMPAT = 16, /* reproduce second_order_feature_interaction.py:21-32
                                        literally: lower triangle kept, upper selected -> the
                                        interaction output is 0; without this
                                        flag the strictly lower triangle is used             */
+    ORX_DLRM_NO_EMB = 64            /* the model owns no embedding table: the rows come from
+                                       outside (row-sharded tables, orx_dlrm_grads)         */
 };
 enum orx_dlrm_param_kind { ORX_DLRM_EMB = 0, ORX_DLRM_BOT_W = 1, ORX_DLRM_BOT_B = 2, ORX_DLRM_TOP_W = 3, ORX_DLRM_TOP_B = 4 };
 
@@ -234,6 +236,22 @@ int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, const int32_t* 
                   int64_t K, int64_t B, int flags, float* loss_out);
 /* DLRM.inference (dlrm.py:76-100): pred_out host/device float[B] */
 int orx_dlrm_inference(orx_dlrm* m, const float* dense, const int32_t* sparse, int64_t B, int flags, float* pred_out);
+/* Hybrid-parallel train step (embedding tables row-sharded across ranks, MLPs data-parallel;
+ * no reference equivalent).  All pointers are DEVICE pointers.
+ *   orx_dlrm_grads       : forward + backward of this rank's B samples with the embedding rows
+ *                          handed in (emb_rows [B, n_emb, m_spa], already exchanged); the loss
+ *                          mean runs over global_B samples.  Writes d loss / d emb_rows to
+ *                          emb_grads [B, n_emb, m_spa], leaves the dense gradients inside the
+ *                          model and adds this rank's part of the loss to loss_accum[0] (double).
+ *   orx_dlrm_dense_count : number of fp32 dense parameters (all kernels and biases)
+ *   orx_dlrm_dense_pack  : copy the dense gradients into flat[count] (for ONE all-reduce)
+ *   orx_dlrm_dense_apply : optimizer step of every dense parameter with the gradients in
+ *                          flat[count] (after the all-reduce); advances the step counter. */
+int orx_dlrm_grads(orx_dlrm* m, const float* dense, const float* emb_rows, const float* label, int64_t B,
+                   int64_t global_B, float* emb_grads, double* loss_accum);
+int orx_dlrm_dense_count(orx_dlrm* m, int64_t* count);
+int orx_dlrm_dense_pack(orx_dlrm* m, float* flat);
+int orx_dlrm_dense_apply(orx_dlrm* m, orx_opt* opt, const float* flat);
 
 /* ---- sharded building blocks (row-wise sharded tables, one rank per GPU;
  * the exchange itself is RCCL all-to-all driven by the host, see

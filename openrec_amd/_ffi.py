@@ -17,6 +17,7 @@ ORX_GMF, ORX_WRMF = 0, 1
 ORX_IDS_DEVICE, ORX_HOGWILD, ORX_NO_L2, ORX_CENSOR = 1, 2, 4, 8
 ORX_DLRM_INTERACT_ITSELF, ORX_DLRM_SIGMOID_BOT, ORX_DLRM_SIGMOID_TOP, ORX_DLRM_LOSS_BCE, ORX_DLRM_REFERENCE_COMPAT = 1, 2, 4, 8, 16
 ORX_DLRM_FP16_MLP = 32
+ORX_DLRM_NO_EMB = 64
 ORX_K_DEDUP, ORX_K_FUSED, ORX_K_REDUCE, ORX_K_SWEEP, ORX_K_CENSOR, ORX_K_POINT, ORX_K_DUPAPPLY, ORX_K_NUM = 0, 1, 2, 3, 4, 5, 6, 7
 KERNEL_NAMES = {ORX_K_DEDUP: "dedup", ORX_K_FUSED: "fused", ORX_K_REDUCE: "loss_reduce", ORX_K_SWEEP: "adam_sweep",
                 ORX_K_CENSOR: "censor", ORX_K_POINT: "pointwise", ORX_K_DUPAPPLY: "dup_apply"}
@@ -68,6 +69,10 @@ SIGNATURES = {
     "orx_dlrm_param": (c_int, [_p, c_int, c_int, _pp]),
     "orx_dlrm_step": (c_int, [_p, _p, _fp, _ip, _fp, c_int64, c_int64, c_int, _fp]),
     "orx_dlrm_inference": (c_int, [_p, _fp, _ip, c_int64, c_int, _fp]),
+    "orx_dlrm_grads": (c_int, [_p, _p, _p, _p, c_int64, c_int64, _p, _p]),
+    "orx_dlrm_dense_count": (c_int, [_p, POINTER(c_int64)]),
+    "orx_dlrm_dense_pack": (c_int, [_p, _p]),
+    "orx_dlrm_dense_apply": (c_int, [_p, _p, _p]),
     "orx_gather_rows": (c_int, [_p, _p, _p, _ip, c_int64, _fp, c_int64]),
     "orx_pair_grads": (c_int, [_p, c_int, c_int32, _fp, _fp, _fp, c_int64, _ip, c_int64, c_int64, c_float, c_int,
                                _fp, _fp, _fp, c_int64, _p]),

@@ -74,8 +74,10 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
         ORX_ARG(ln_emb[f] > 0, "orx_dlrm_create: ln_emb[%d] must be positive", f);
         m->ln_emb.push_back(ln_emb[f]); m->offset.push_back(total); total += ln_emb[f];
     }
-    CHECK(orx_table_create(ctx, total, m_spa, &m->emb));
-    CHECK(orx_table_init_uniform(m->emb, -0.05f, 0.05f, seed));            // LatentFactor 'uniform' (dlrm.py:32-33)
+    if (!(flags & ORX_DLRM_NO_EMB)) {
+        CHECK(orx_table_create(ctx, total, m_spa, &m->emb));
+        CHECK(orx_table_init_uniform(m->emb, -0.05f, 0.05f, seed));        // LatentFactor 'uniform' (dlrm.py:32-33)
+    }
     ORX_HIP(hipMalloc((void**)&m->d_offset, sizeof(int64_t) * n_emb));
     ORX_HIP(hipMalloc((void**)&m->d_rows, sizeof(int64_t) * n_emb));
     ORX_HIP(hipMemcpy(m->d_offset, m->offset.data(), sizeof(int64_t) * n_emb, hipMemcpyHostToDevice));
@@ -119,7 +121,10 @@ extern "C" int orx_dlrm_destroy(orx_dlrm* m) {
 
 extern "C" int orx_dlrm_param(orx_dlrm* m, int kind, int layer, orx_table** out) {
     ORX_ARG(m && out, "orx_dlrm_param: NULL argument");
-    if (kind == ORX_DLRM_EMB) { *out = m->emb; return ORX_OK; }
+    if (kind == ORX_DLRM_EMB) {
+        ORX_ARG(m->emb, "orx_dlrm_param: the model was created with ORX_DLRM_NO_EMB");
+        *out = m->emb; return ORX_OK;
+    }
     std::vector<DenseLayer>& L = (kind == ORX_DLRM_BOT_W || kind == ORX_DLRM_BOT_B) ? m->bot : m->top;
     ORX_ARG(kind >= ORX_DLRM_BOT_W && kind <= ORX_DLRM_TOP_B, "orx_dlrm_param: unknown kind %d", kind);
     ORX_ARG(layer >= 0 && layer < (int)L.size(), "orx_dlrm_param: layer %d out of range", layer);
@@ -161,14 +166,20 @@ static int mlp_gemm(orx_dlrm* m, const float* A, int64_t sa0, int64_t sa1, const
     return orx_launch_gemm(m->ctx, A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act);
 }
 
-// forward of one batch; leaves every activation in the model's buffers
-static int forward(orx_dlrm* m, const Batch& bt, int64_t B) {
+// forward of one batch; leaves every activation in the model's buffers.  emb_rows != NULL: the
+// embedding rows [B, n_emb, d] are handed in (hybrid-parallel step) instead of gathered here.
+static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_rows = nullptr) {
     orx_ctx* c = m->ctx;
     const int F = m->F, d = m->m_spa;
     const int compat = (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0, itself = (m->flags & ORX_DLRM_INTERACT_ITSELF) ? 1 : 0;
-    CHECK(orx_launch_dlrm_ids(c, bt.sparse, m->d_offset, m->d_rows, m->n_emb, B, m->d_idx));
-    // dlrm.py:83-85: the n_emb gathers = one gather on the combined table (dense slot skipped)
-    CHECK(orx_launch_gather(c, m->emb->w, nullptr, m->emb->rows, d, m->d_idx, B * F, m->Z, d, c->d_err, 1));
+    if (emb_rows != nullptr) {
+        CHECK(orx_launch_copy2d(c, m->Z, (int64_t)F * d, emb_rows, (int64_t)m->n_emb * d, (int)B, m->n_emb * d));
+    } else {
+        ORX_ARG(m->emb, "dlrm: the model was created with ORX_DLRM_NO_EMB (use orx_dlrm_grads)");
+        CHECK(orx_launch_dlrm_ids(c, bt.sparse, m->d_offset, m->d_rows, m->n_emb, B, m->d_idx));
+        // dlrm.py:83-85: the n_emb gathers = one gather on the combined table (dense slot skipped)
+        CHECK(orx_launch_gather(c, m->emb->w, nullptr, m->emb->rows, d, m->d_idx, B * F, m->Z, d, c->d_err, 1));
+    }
     // dlrm.py:87: bottom MLP; its last layer writes straight into slot F-1 of Z
     const float* x = bt.dense; int64_t ldx = m->dense_dim;
     for (size_t l = 0; l < m->bot.size(); ++l) {
@@ -221,6 +232,39 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
     return ORX_OK;
 }
 
+// backward of the batch whose activations `forward` left behind; m->gA holds dLoss/dPred.
+// Leaves dZ [B, F, d] (slot F-1 = d dense_emb) and every dense gradient in its table's gsum.
+static int backward(orx_dlrm* m, const Batch& bt, int64_t B) {
+    orx_ctx* c = m->ctx;
+    const int F = m->F, d = m->m_spa;
+    const int compat = (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0, itself = (m->flags & ORX_DLRM_INTERACT_ITSELF) ? 1 : 0;
+    {
+    // ---- top MLP backward
+    std::vector<const float*> ins, outs; std::vector<int64_t> ldi, ldo;
+    for (size_t l = 0; l < m->top.size(); ++l) {
+        ins.push_back(l == 0 ? m->R : m->top_y[l - 1]); ldi.push_back(l == 0 ? m->ldR : m->top[l - 1].out);
+        outs.push_back(m->top_y[l]); ldo.push_back(m->top[l].out);
+    }
+    float* dR = nullptr;
+    CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR));
+    // ---- interaction backward: dZ for every slot (slot F-1 = d dense_emb)
+    CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B, m->ldR));
+    // ---- bottom MLP backward from dZ[:, F-1, :]
+    float* dy = (dR == m->gA) ? m->gB : m->gA;
+    float* other = (dy == m->gA) ? m->gB : m->gA;
+    CHECK(orx_launch_copy2d(c, dy, d, m->dZ + (size_t)(F - 1) * d, (int64_t)F * d, (int)B, d));
+    ins.clear(); outs.clear(); ldi.clear(); ldo.clear();
+    for (size_t l = 0; l < m->bot.size(); ++l) {
+        const bool last = l + 1 == m->bot.size();
+        ins.push_back(l == 0 ? bt.dense : m->bot_y[l - 1]); ldi.push_back(l == 0 ? m->dense_dim : m->bot[l - 1].out);
+        outs.push_back(last ? m->Z + (size_t)(F - 1) * d : m->bot_y[l]); ldo.push_back(last ? (int64_t)F * d : m->bot[l].out);
+    }
+    float* dx0 = nullptr;
+    CHECK(mlp_backward(m, m->bot, ins, ldi, outs, ldo, dy, other, B, false, &dx0));
+    }
+    return ORX_OK;
+}
+
 static int stage(orx_dlrm* m, const float* dense, const int32_t* sparse, const float* label, int64_t B, int flags, Batch* out) {
     if (flags & ORX_IDS_DEVICE) { out->dense = dense; out->sparse = sparse; out->label = label; return ORX_OK; }
     hipStream_t s = m->ctx->stream;
@@ -252,28 +296,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         float* pred = m->top_y.back();
         // loss + dLoss/dP  (dlrm.py:72-73, :97-98)
         CHECK(orx_launch_dlrm_loss(c, pred, bt.label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, m->d_loss + s));
-        // ---- top MLP backward
-        std::vector<const float*> ins, outs; std::vector<int64_t> ldi, ldo;
-        for (size_t l = 0; l < m->top.size(); ++l) {
-            ins.push_back(l == 0 ? m->R : m->top_y[l - 1]); ldi.push_back(l == 0 ? m->ldR : m->top[l - 1].out);
-            outs.push_back(m->top_y[l]); ldo.push_back(m->top[l].out);
-        }
-        float* dR = nullptr;
-        CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR));
-        // ---- interaction backward: dZ for every slot (slot F-1 = d dense_emb)
-        CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B, m->ldR));
-        // ---- bottom MLP backward from dZ[:, F-1, :]
-        float* dy = (dR == m->gA) ? m->gB : m->gA;
-        float* other = (dy == m->gA) ? m->gB : m->gA;
-        CHECK(orx_launch_copy2d(c, dy, d, m->dZ + (size_t)(F - 1) * d, (int64_t)F * d, (int)B, d));
-        ins.clear(); outs.clear(); ldi.clear(); ldo.clear();
-        for (size_t l = 0; l < m->bot.size(); ++l) {
-            const bool last = l + 1 == m->bot.size();
-            ins.push_back(l == 0 ? bt.dense : m->bot_y[l - 1]); ldi.push_back(l == 0 ? m->dense_dim : m->bot[l - 1].out);
-            outs.push_back(last ? m->Z + (size_t)(F - 1) * d : m->bot_y[l]); ldo.push_back(last ? (int64_t)F * d : m->bot[l].out);
-        }
-        float* dx0 = nullptr;
-        CHECK(mlp_backward(m, m->bot, ins, ldi, outs, ldo, dy, other, B, false, &dx0));
+        CHECK(backward(m, bt, B));
         // ---- optimizer: one step counter for all variables (Keras `iterations`)
         opt->t += 1;
         float lr_t = 0.f;
@@ -316,4 +339,69 @@ extern "C" int orx_dlrm_inference(orx_dlrm* m, const float* dense, const int32_t
     }
     ORX_HIP(hipMemcpyAsync(pred_out, pred, sizeof(float) * B, hipMemcpyDeviceToHost, c->stream));
     return orx_check_index_error(c);
+}
+
+// ------------------------------------------------- hybrid-parallel building blocks ---
+static void dense_params(orx_dlrm* m, std::vector<orx_table*>& out) {
+    for (auto& D : m->bot) { out.push_back(D.W); out.push_back(D.b); }
+    for (auto& D : m->top) { out.push_back(D.W); out.push_back(D.b); }
+}
+
+extern "C" int orx_dlrm_grads(orx_dlrm* m, const float* dense, const float* emb_rows, const float* label, int64_t B,
+                              int64_t global_B, float* emb_grads, double* loss_accum) {
+    ORX_ARG(m && dense && emb_rows && label && emb_grads && loss_accum, "orx_dlrm_grads: NULL argument");
+    ORX_ARG(B > 0 && global_B >= B, "orx_dlrm_grads: need 0 < B <= global_B");
+    orx_ctx* c = m->ctx;
+    ORX_HIP(hipSetDevice(c->device));
+    CHECK(ensure_buffers(m, B));
+    Batch bt; bt.dense = dense; bt.sparse = nullptr; bt.label = label;
+    CHECK(forward(m, bt, B, emb_rows));
+    CHECK(orx_launch_dlrm_loss(c, m->top_y.back(), label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, loss_accum,
+                               global_B, 1));
+    CHECK(backward(m, bt, B));
+    const int d = m->m_spa;
+    return orx_launch_copy2d(c, emb_grads, (int64_t)m->n_emb * d, m->dZ, (int64_t)m->F * d, (int)B, m->n_emb * d);
+}
+
+extern "C" int orx_dlrm_dense_count(orx_dlrm* m, int64_t* count) {
+    ORX_ARG(m && count, "orx_dlrm_dense_count: NULL argument");
+    std::vector<orx_table*> ps; dense_params(m, ps);
+    int64_t n = 0;
+    for (orx_table* t : ps) n += t->rows * t->dim;
+    *count = n;
+    return ORX_OK;
+}
+
+extern "C" int orx_dlrm_dense_pack(orx_dlrm* m, float* flat) {
+    ORX_ARG(m && flat, "orx_dlrm_dense_pack: NULL argument");
+    ORX_HIP(hipSetDevice(m->ctx->device));
+    std::vector<orx_table*> ps; dense_params(m, ps);
+    for (orx_table* t : ps) {
+        ORX_ARG(t->gsum, "orx_dlrm_dense_pack: no gradients yet (call orx_dlrm_grads first)");
+        const size_t n = (size_t)t->rows * t->dim;
+        ORX_HIP(hipMemcpyAsync(flat, t->gsum, n * sizeof(float), hipMemcpyDeviceToDevice, m->ctx->stream));
+        flat += n;
+    }
+    return ORX_OK;
+}
+
+extern "C" int orx_dlrm_dense_apply(orx_dlrm* m, orx_opt* opt, const float* flat) {
+    ORX_ARG(m && opt && flat, "orx_dlrm_dense_apply: NULL argument");
+    orx_ctx* c = m->ctx;
+    ORX_HIP(hipSetDevice(c->device));
+    std::vector<orx_table*> ps; dense_params(m, ps);
+    opt->t += 1;
+    float lr_t = 0.f;
+    if (opt->kind == ORX_ADAM) {
+        const double b1 = opt->p0, b2 = opt->p1;
+        lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, (double)opt->t)) / (1.0 - std::pow(b1, (double)opt->t)));
+    }
+    for (orx_table* t : ps) {
+        CHECK(orx_table_scratch(t));
+        const size_t n = (size_t)t->rows * t->dim;
+        ORX_HIP(hipMemcpyAsync(t->gsum, flat, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        flat += n;
+        CHECK(dense_apply(c, opt, t, lr_t));
+    }
+    return ORX_OK;
 }

@@ -383,11 +383,13 @@ int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR,
 
 // ------------------------------------------------------------------- loss ---
 // pred [B] = (clipped) top-MLP output; writes loss (fp64) and dP [B] = dLoss/d(pre-clip p).
+// n_mean: the batch the loss mean runs over (= B, or the global batch of a data-parallel step);
+// accumulate: add this launch's share to *loss_out instead of overwriting it
 __global__ __launch_bounds__(1024) void dlrm_loss_kernel(float* P, const float* y, int64_t B, int bce, float thr,
-                                                         float* dP, double* loss_out) {
+                                                         float* dP, double* loss_out, int64_t n_mean, int accumulate) {
     __shared__ double sh[16];
     double s = 0.0;
-    const float invB = 1.0f / (float)B;
+    const float invB = 1.0f / (float)n_mean;
     for (int64_t i = threadIdx.x; i < B; i += 1024) {
         float p = P[i];
         float mask = 1.0f;
@@ -417,12 +419,14 @@ __global__ __launch_bounds__(1024) void dlrm_loss_kernel(float* P, const float* 
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int k = 0; k < 16; ++k) t += sh[k];
-        loss_out[0] = t / (double)B;
+        if (accumulate) loss_out[0] += t / (double)n_mean;
+        else loss_out[0] = t / (double)n_mean;
     }
 }
 
-int orx_launch_dlrm_loss(orx_ctx* ctx, float* P, const float* y, int64_t B, int bce, float thr, float* dP, double* loss_out) {
-    ORX_LAUNCH(ctx, dlrm_loss_kernel, dim3(1), dim3(1024), 0, P, y, B, bce, thr, dP, loss_out);
+int orx_launch_dlrm_loss(orx_ctx* ctx, float* P, const float* y, int64_t B, int bce, float thr, float* dP, double* loss_out,
+                         int64_t n_mean, int accumulate) {
+    ORX_LAUNCH(ctx, dlrm_loss_kernel, dim3(1), dim3(1024), 0, P, y, B, bce, thr, dP, loss_out, n_mean > 0 ? n_mean : B, accumulate);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

@@ -290,7 +290,8 @@ int orx_launch_colsum(orx_ctx* ctx, const float* X, int M, int N, float* out);
 int orx_launch_copy2d(orx_ctx* ctx, float* dst, int64_t ldd, const float* src, int64_t lds_, int M, int N);
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
                         float* out, int P, int64_t B, int ldR);
-int orx_launch_dlrm_loss(orx_ctx* ctx, float* P, const float* y, int64_t B, int bce, float thr, float* dP, double* loss_out);
+int orx_launch_dlrm_loss(orx_ctx* ctx, float* P, const float* y, int64_t B, int bce, float thr, float* dP, double* loss_out,
+                         int64_t n_mean = 0, int accumulate = 0);
 int orx_launch_dlrm_ids(orx_ctx* ctx, const int32_t* sparse, const int64_t* offset, const int64_t* rows, int nf, int64_t B,
                         int32_t* idx);
 int orx_launch_rows_accum(orx_ctx* ctx, float* G, const int32_t* ids, const float* grads, int64_t g_stride, int64_t n, int D, int64_t rows);

@@ -302,7 +302,7 @@ class DLRMModel:
 
     def __init__(self, m_spa, ln_emb, ln_bot, ln_top, dense_dim, arch_interaction_itself=False, sigmoid_bot=False,
                  sigmoid_top=True, loss_func="mse", loss_threshold=0.0, reference_compat=True, seed=0, ctx=None,
-                 fp16_mlp=False):
+                 fp16_mlp=False, no_emb=False):
         self.ctx = ctx or default_context()
         lib = self._lib = self.ctx._lib
         self.m_spa, self.ln_emb, self.ln_bot, self.ln_top = int(m_spa), [int(x) for x in ln_emb], list(ln_bot), list(ln_top)
@@ -311,7 +311,7 @@ class DLRMModel:
                  | (_ffi.ORX_DLRM_SIGMOID_BOT if sigmoid_bot else 0) | (_ffi.ORX_DLRM_SIGMOID_TOP if sigmoid_top else 0)
                  | (_ffi.ORX_DLRM_LOSS_BCE if loss_func == "bce" else 0)
                  | (_ffi.ORX_DLRM_REFERENCE_COMPAT if reference_compat else 0)
-                 | (_ffi.ORX_DLRM_FP16_MLP if fp16_mlp else 0))
+                 | (_ffi.ORX_DLRM_FP16_MLP if fp16_mlp else 0) | (_ffi.ORX_DLRM_NO_EMB if no_emb else 0))
         if loss_func not in ("mse", "bce"):
             raise ValueError("loss_func=%s is not supported" % loss_func)          # dlrm.py:56-61
         emb = (ctypes.c_int64 * len(self.ln_emb))(*self.ln_emb)
@@ -350,6 +350,23 @@ class DLRMModel:
                                       loss.ctypes.data if want_loss else None))
         opt._tables.append(self)
         return loss
+
+    # ---- hybrid-parallel building blocks (device pointers; openrec_amd/sharded_dlrm.py) ----
+    def grads(self, dense_ptr, emb_rows_ptr, label_ptr, B, global_B, emb_grads_ptr, loss_accum_ptr):
+        check(self._lib.orx_dlrm_grads(self._h, dense_ptr, emb_rows_ptr, label_ptr, int(B), int(global_B),
+                                       emb_grads_ptr, loss_accum_ptr))
+
+    def dense_count(self):
+        n = ctypes.c_int64()
+        check(self._lib.orx_dlrm_dense_count(self._h, byref(n)))
+        return int(n.value)
+
+    def dense_pack(self, flat_ptr):
+        check(self._lib.orx_dlrm_dense_pack(self._h, flat_ptr))
+
+    def dense_apply(self, opt, flat_ptr):
+        check(self._lib.orx_dlrm_dense_apply(self._h, opt._h, flat_ptr))
+        opt._tables.append(self)
 
     def inference(self, dense, sparse):
         d, s = self._host(dense, np.float32), self._host(sparse, np.int32)

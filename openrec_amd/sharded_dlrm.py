@@ -1,0 +1,209 @@
+"""Hybrid-parallel DLRM train step: one process per GPU.
+
+* the 26 embedding tables = ONE combined table, row-sharded: combined row r lives
+  on rank r % N at local index r // N (model parallel);
+* bottom / top MLPs and the feature interaction are replicated, every rank runs
+  its own B samples (data parallel); the loss mean runs over the global batch N*B.
+
+One step (exactly the single-GPU semantics of orx_dlrm_step on the concatenated
+global batch; reference: recommenders/dlrm.py:63-74 + tf2_examples/dlrm_criteo.py:42-48):
+
+  1. request  combined row ids of the B*n_emb lookups -> their owners       all_to_all (4 B / id)
+  2. rows     owners gather the rows and send them back                     all_to_all (4*d B / id)
+  3. local    forward + backward with the received rows (orx_dlrm_grads)
+  4. dense    ONE all-reduce(sum) of the packed MLP gradients, then the dense optimizer rule
+              on every rank (identical replicas stay identical)
+  5. sparse   d loss / d row travels back along route 1                     all_to_all (4*d B / id)
+              and the owners apply it (orx_apply_rows: SGD accumulates every
+              occurrence, Adagrad / Adam sum duplicates first - as on one GPU)
+
+Exchanges use fixed-capacity buckets (no size exchange, no host sync);
+`check()` reports a capacity overflow.  Compute is libopenrec_hip.so through
+`HipDLRMBackend`; the tests inject an oracle-backed backend for the CPU (gloo) runs.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .sharded import bucket_slots, rows_on_rank
+
+
+class HipDLRMBackend:
+    """Compute backend = the C ABI on this rank's GPU.  Kernels run on a dedicated torch
+    stream under which the step also issues its torch ops and collectives."""
+
+    def __init__(self, device, cfg, opt_kind, lr, opt_kw=None, seed=0, fp16_mlp=False):
+        from . import runtime as rt, _ffi
+        self.rt, self._ffi, self.device = rt, _ffi, device
+        self.stream = torch.cuda.Stream(device=device)
+        assert self.stream.cuda_stream != 0         # handle 0 would mean "create a private stream" to the C ABI
+        self.ctx = rt.Context(device.index if device.index is not None else 0, stream=self.stream.cuda_stream)
+        kw = opt_kw or {}
+        if opt_kind == "sgd":
+            self.opt = rt.Optimizer.sgd(lr, ctx=self.ctx)
+        elif opt_kind == "adagrad":
+            self.opt = rt.Optimizer.adagrad(lr, kw.get("initial_accumulator_value", 0.1), kw.get("epsilon", 1e-7), ctx=self.ctx)
+        elif opt_kind == "adam":
+            self.opt = rt.Optimizer.adam(lr, kw.get("beta_1", 0.9), kw.get("beta_2", 0.999), kw.get("epsilon", 1e-7), ctx=self.ctx)
+        else:
+            raise ValueError("unknown optimizer %r" % opt_kind)
+        self.model = rt.DLRMModel(ctx=self.ctx, no_emb=True, seed=seed, fp16_mlp=fp16_mlp, **cfg)
+        self.lib = self.ctx._lib
+
+    def make_table(self, rows, dim, seed):
+        return self.rt.Table(max(rows, 1), dim, self.ctx).init_uniform(seed=seed)
+
+    def write_table(self, table, values):
+        table.write(np.ascontiguousarray(values, np.float32))
+
+    def read_table(self, table):
+        return table.read()
+
+    def gather_rows(self, table, ids, out):
+        self._ffi.check(self.lib.orx_gather_rows(self.ctx._h, table._h, None, ids.data_ptr(), ids.numel(),
+                                                 out.data_ptr(), out.shape[1]))
+
+    def apply_rows(self, table, ids, grads):
+        self._ffi.check(self.lib.orx_apply_rows(self.ctx._h, self.opt._h, table._h, None, ids.data_ptr(), ids.numel(),
+                                                grads.data_ptr(), grads.shape[1]))
+
+    def grads(self, dense, emb_rows, label, global_b, emb_grads, loss_accum):
+        self.model.grads(dense.data_ptr(), emb_rows.data_ptr(), label.data_ptr(), label.numel(), global_b,
+                         emb_grads.data_ptr(), loss_accum.data_ptr())
+
+    def dense_count(self):
+        return self.model.dense_count()
+
+    def dense_pack(self, flat):
+        self.model.dense_pack(flat.data_ptr())
+
+    def dense_apply(self, flat):
+        self.model.dense_apply(self.opt, flat.data_ptr())
+
+    def dense_param(self, kind, layer):
+        return self.model.param(kind, layer)
+
+    def stream_ctx(self):
+        return torch.cuda.stream(self.stream)
+
+    def check(self):
+        self.ctx.check_index_error()
+
+
+class ShardedDLRM:
+    def __init__(self, m_spa, ln_emb, ln_bot, ln_top, dense_dim, rank, world, device, opt="sgd", lr=0.01, opt_kw=None,
+                 seed=0, slack=1.25, backend=None, group=None, a2a_fn=None, allreduce_fn=None, fp16_mlp=False,
+                 **model_kw):
+        self.m_spa, self.ln_emb, self.n_emb = int(m_spa), [int(x) for x in ln_emb], len(ln_emb)
+        self.dense_dim, self.rank, self.world, self.device = int(dense_dim), rank, world, device
+        self.group, self.a2a_fn, self.allreduce_fn, self.slack = group, a2a_fn, allreduce_fn, slack
+        cfg = dict(m_spa=m_spa, ln_emb=ln_emb, ln_bot=ln_bot, ln_top=ln_top, dense_dim=dense_dim, **model_kw)
+        self.be = backend if backend is not None else HipDLRMBackend(device, cfg, opt, lr, opt_kw, seed, fp16_mlp)
+        self.total_rows = int(sum(self.ln_emb))
+        self.offsets = torch.tensor(np.concatenate([[0], np.cumsum(self.ln_emb)[:-1]]), dtype=torch.int64, device=device)
+        self.rows_t = torch.tensor(self.ln_emb, dtype=torch.int64, device=device)
+        self.local_rows = rows_on_rank(self.total_rows, rank, world)
+        self.emb = self.be.make_table(self.local_rows, self.m_spa, seed + 1000 + rank)
+        self.n_dense = self.be.dense_count()
+        self.flat = torch.zeros(self.n_dense, dtype=torch.float32, device=device)
+        self.loss_accum = torch.zeros(1, dtype=torch.float64, device=device)
+        self.overflow = torch.zeros((), dtype=torch.bool, device=device)
+        self.bad_id = torch.zeros((), dtype=torch.bool, device=device)
+
+    # ---- table access by GLOBAL combined row (tests, checkpoints) ----------
+    def load_embeddings(self, combined):
+        """combined: [sum(ln_emb), m_spa] array; this rank keeps rows rank, rank + N, ..."""
+        self.be.write_table(self.emb, np.asarray(combined)[self.rank::self.world])
+
+    def local_embeddings(self):
+        return self.be.read_table(self.emb)[:self.local_rows]
+
+    # ---- collectives ---------------------------------------------------------
+    def _a2a(self, x):
+        if self.a2a_fn is not None:            # tests: fn(recv, send), e.g. an in-process fake cluster
+            out = torch.empty_like(x)
+            self.a2a_fn(out, x)
+            return out
+        if self.world == 1:
+            return x
+        out = torch.empty_like(x)
+        dist.all_to_all_single(out, x, group=self.group)
+        return out
+
+    def _allreduce(self, x):
+        if self.allreduce_fn is not None:      # tests: in-place sum over the fake cluster
+            self.allreduce_fn(x)
+        elif self.world > 1:
+            dist.all_reduce(x, group=self.group)
+        return x
+
+    def step(self, dense, sparse, label):
+        """dense [B, dense_dim] fp32, sparse [B, n_emb] int (id within its own table), label [B] fp32 -
+        this rank's slice of the global batch, on self.device."""
+        if hasattr(self.be, "stream_ctx"):
+            with self.be.stream_ctx():
+                return self._step(dense, sparse, label)
+        return self._step(dense, sparse, label)
+
+    def _step(self, dense, sparse, label):
+        N, dev, d, nf = self.world, self.device, self.m_spa, self.n_emb
+        B = label.numel()
+        dense = dense.to(torch.float32).contiguous()
+        label = label.to(torch.float32).contiguous()
+        sp = sparse.to(torch.int64)
+        ok = (sp >= 0) & (sp < self.rows_t)                                   # the reference's gather raises on these
+        self.bad_id |= (~ok).any()
+        g = torch.where(ok, sp + self.offsets, torch.full_like(sp, -1)).reshape(-1)          # combined row ids [B*nf]
+        # ---- 1. requests to the owners
+        n = g.numel()
+        cap = int(math.ceil(n / N * self.slack)) + 8
+        slot, ov = bucket_slots(torch.where(g >= 0, g % N, g), N, cap)
+        self.overflow |= ov
+        trash = N * cap
+        slot_t = torch.where(slot >= 0, slot, torch.full_like(slot, trash))
+        send = torch.full((trash + 1,), -1, dtype=torch.int32, device=dev)
+        send.index_copy_(0, slot_t, g.to(torch.int32))
+        req = self._a2a(send[:trash].contiguous()).to(torch.int64)
+        req_loc = torch.where(req >= 0, torch.div(req, N, rounding_mode="floor"), req).to(torch.int32).contiguous()
+        # ---- 2. owners gather, rows travel back
+        rows_out = torch.zeros((trash, d), dtype=torch.float32, device=dev)
+        self.be.gather_rows(self.emb, req_loc, rows_out)
+        rows_in = torch.zeros((trash + 1, d), dtype=torch.float32, device=dev)
+        rows_in[:trash] = self._a2a(rows_out)
+        emb_rows = rows_in.index_select(0, slot_t).contiguous()              # [B*nf, d] in lookup order (dropped: zeros)
+        # ---- 3. local forward + backward
+        emb_grads = torch.empty((n, d), dtype=torch.float32, device=dev)
+        self.be.grads(dense, emb_rows, label, B * N, emb_grads, self.loss_accum)
+        # ---- 4. dense gradients: one all-reduce, then the dense rule on every replica
+        self.be.dense_pack(self.flat)
+        self._allreduce(self.flat)
+        self.be.dense_apply(self.flat)
+        # ---- 5. embedding gradients back to the owners
+        send_g = torch.zeros((trash + 1, d), dtype=torch.float32, device=dev)
+        send_g.index_copy_(0, slot_t, emb_grads)
+        g_in = self._a2a(send_g[:trash].contiguous())
+        self.be.apply_rows(self.emb, req_loc, g_in)
+        return None
+
+    # ---- results ---------------------------------------------------------------
+    def loss_sum(self):
+        """sum over the steps so far of the global-batch loss"""
+        if hasattr(self.be, "stream"):
+            self.be.stream.synchronize()
+        t = self.loss_accum.clone()
+        self._allreduce(t)
+        return float(t.item())
+
+    def check(self):
+        if hasattr(self.be, "stream"):
+            self.be.stream.synchronize()
+        if bool(self.overflow.item()):
+            raise RuntimeError("sharded DLRM: an exchange bucket overflowed (raise `slack`)")
+        if bool(self.bad_id.item()):
+            raise IndexError("sharded DLRM: embedding id out of range")
+        if hasattr(self.be, "check"):
+            self.be.check()

@@ -79,10 +79,15 @@ class DLRMOracle:
             outs.append(x)
         return outs
 
-    def forward(self, dense, sparse):
+    def forward(self, dense, sparse, emb_rows=None):
+        """emb_rows [B, n_emb, d]: embedding vectors handed in instead of looked up (the hybrid-parallel
+        step of openrec_amd/sharded_dlrm.py exchanges them between ranks first)."""
         dense = dense.astype(self.dt)
         bot = self._mlp(dense, self.bot, self.bot_act)                                  # dlrm.py:87
-        vecs = [self.emb[f][sparse[:, f]] for f in range(len(self.emb))] + [bot[-1]]    # dlrm.py:83-85, :91
+        if emb_rows is not None:
+            vecs = [emb_rows[:, f, :].astype(self.dt) for f in range(emb_rows.shape[1])] + [bot[-1]]
+        else:
+            vecs = [self.emb[f][sparse[:, f]] for f in range(len(self.emb))] + [bot[-1]]    # dlrm.py:83-85, :91
         Z = np.stack(vecs, 1)                                                           # [B, F, d]
         dots = np.einsum("bfd,bgd->bfg", Z, Z)
         if self.compat:
@@ -102,17 +107,19 @@ class DLRMOracle:
         return self.forward(dense, sparse)["pred"]
 
     # ----------------------------------------------------------- loss + backward
-    def loss_and_grads(self, dense, sparse, label):
-        c = self.forward(dense, sparse)
+    def loss_and_grads(self, dense, sparse, label, emb_rows=None, global_batch=None):
+        """global_batch: the loss mean runs over that many samples (this call sees a slice of them);
+        the returned loss is then this slice's share of the global mean."""
+        c = self.forward(dense, sparse, emb_rows)
         p, y = c["pred"], label.astype(self.dt)
-        B = p.shape[0]
+        B = p.shape[0] if global_batch is None else int(global_batch)
         if self.loss_func == "mse":                                                     # Keras MeanSquaredError
-            loss = ((y - p) ** 2).mean(dtype=self.dt)
+            loss = ((y - p) ** 2).sum(dtype=self.dt) / self.dt.type(B)
             dp = 2 * (p - y) / self.dt.type(B)
         else:                                                                           # Keras BinaryCrossentropy
             eps = self.dt.type(KERAS_EPS)
             pc = np.clip(p, eps, 1 - eps)
-            loss = -(y * np.log(pc + eps) + (1 - y) * np.log(1 - pc + eps)).mean(dtype=self.dt)
+            loss = -(y * np.log(pc + eps) + (1 - y) * np.log(1 - pc + eps)).sum(dtype=self.dt) / self.dt.type(B)
             inside = ((p >= eps) & (p <= 1 - eps)).astype(self.dt)
             dp = -(y / (pc + eps) - (1 - y) / (1 - pc + eps)) * inside / self.dt.type(B)
         dp = (dp * c["clip_mask"]).reshape(-1, 1)
