@@ -19,7 +19,7 @@ global batch; reference: recommenders/dlrm.py:63-74 + tf2_examples/dlrm_criteo.p
 
 Exchanges use fixed-capacity buckets (no size exchange, no host sync);
 `check()` reports a capacity overflow.  Compute is libopenrec_hip.so through
-`HipDLRMBackend`; the tests inject an oracle-backed backend for the CPU (gloo) runs.
+`HipDLRMBackend`; the tests inject their own CPU backend for the gloo runs.
 """
 from __future__ import annotations
 
