@@ -85,12 +85,81 @@ def cpu_baseline(args, budget_s=15.0, max_steps=2000):
                        f"oracle/orx_oracle.c (OpenMP), {dt:.1f} s")
 
 
+CRITEO_KAGGLE_COUNTS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306, 10,
+                        5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+
+
+def bench_dlrm(args, torch, rt, world, rank, local_rank, device, dist):
+    """Secondary workload (C5): DLRM with the Criteo-Kaggle cardinalities, dim 128, bottom 13-512-256-128,
+    top 479-1024-1024-512-256-1, B samples per GPU per step, SGD.  N = 1: orx_dlrm_step on batches resident
+    in HBM; N > 1: embedding tables row-sharded, MLPs data-parallel (openrec_amd/sharded_dlrm.py)."""
+    K, W, B = args.steps, args.warmup, args.batch
+    cfg = dict(m_spa=128, ln_emb=CRITEO_KAGGLE_COUNTS, ln_bot=[512, 256, 128], ln_top=[1024, 1024, 512, 256, 1], dense_dim=13,
+               reference_compat=False)
+    g = torch.Generator(device=device); g.manual_seed(99 + rank)
+    n = (K + W) * B
+    dense = torch.log1p(torch.randint(0, 100, (n, 13), device=device, generator=g).float()).contiguous()
+    sparse = torch.stack([torch.randint(0, c, (n,), device=device, generator=g, dtype=torch.int32) for c in CRITEO_KAGGLE_COUNTS], 1).contiguous()
+    label = (torch.rand((n,), device=device, generator=g) < 0.25).float().contiguous()
+    if world == 1 and not args.sharded:
+        ctx = rt.Context(local_rank)
+        m = rt.DLRMModel(ctx=ctx, fp16_mlp=args.fp16_mlp, **cfg)
+        opt = rt.Optimizer.sgd(0.01, ctx=ctx)
+        es = lambda t: t.element_size()
+        run = lambda first, count: m.step_device(opt, dense.data_ptr() + first * B * 13 * es(dense), sparse.data_ptr() + first * B * 26 * es(sparse),
+                                                 label.data_ptr() + first * B * es(label), count, B)
+        torch.cuda.synchronize()
+        if W:
+            run(0, W)
+        ctx.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(W, K)
+        ctx.synchronize(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        par = "single-gpu"
+    else:
+        from openrec_amd.sharded_dlrm import ShardedDLRM
+        eng = ShardedDLRM(rank=rank, world=world, device=device, opt="sgd", lr=0.01, seed=0, fp16_mlp=args.fp16_mlp, **cfg)
+        for s in range(W):
+            eng.step(dense[s * B:(s + 1) * B], sparse[s * B:(s + 1) * B], label[s * B:(s + 1) * B])
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(W, W + K):
+            eng.step(dense[s * B:(s + 1) * B], sparse[s * B:(s + 1) * B], label[s * B:(s + 1) * B])
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        eng.check()
+        par = f"embedding tables row-sharded x{world} (all-to-all), MLPs data-parallel (all-reduce)"
+    if rank == 0:
+        print(json.dumps({
+            "metric": "DLRM training samples/sec (Criteo-Kaggle cardinalities, dim 128)", "value": K * B * world / dt,
+            "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16 MFMA MLP products, f32 elsewhere" if args.fp16_mlp else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"dlrm 26 tables (33.8 M rows x 128), bottom 13-512-256-128, top 479-1024-1024-512-256-1, "
+                                   f"batch={B} samples/GPU, sgd lr=0.01, mse loss", "parallelism": par}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--model", default="bpr", choices=["bpr", "ucml", "gmf", "wrmf"],
+    ap.add_argument("--fp16-mlp", action="store_true", help="dlrm: MLP products on fp16 MFMA (performance mode)")
+    ap.add_argument("--model", default="bpr", choices=["bpr", "ucml", "gmf", "wrmf", "dlrm"],
                     help="gmf / wrmf: the pointwise step over B (user, item, label) samples (secondary workloads)")
     ap.add_argument("--opt", default="sgd", choices=["sgd", "adagrad"])
     ap.add_argument("--dim", type=int, default=64)
@@ -124,6 +193,10 @@ def main():
 
     K, W = args.steps, args.warmup
     lr = 0.05
+    if args.model == "dlrm":
+        if args.batch == 65536:
+            args.batch = 8192
+        return bench_dlrm(args, torch, rt, world, rank, local_rank, device, dist)
     if world == 1 and not args.sharded:
         ctx = rt.Context(local_rank)
         U = rt.Table(args.users, args.dim, ctx).init_uniform(seed=0)

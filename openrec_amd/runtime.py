@@ -341,6 +341,14 @@ class DLRMModel:
             x = x.numpy()
         return np.ascontiguousarray(x, dtype=dtype)
 
+    def step_device(self, opt, dense_ptr, sparse_ptr, label_ptr, K, B, want_loss=False):
+        """K steps on batches that already sit in HBM (device pointers, layout as `step`)."""
+        loss = np.empty(K, np.float32) if want_loss else None
+        check(self._lib.orx_dlrm_step(self._h, opt._h, dense_ptr, sparse_ptr, label_ptr, int(K), int(B), _ffi.ORX_IDS_DEVICE,
+                                      loss.ctypes.data if want_loss else None))
+        opt._tables.append(self)
+        return loss
+
     def step(self, opt, dense, sparse, label, K=1, want_loss=True):
         d, s, y = self._host(dense, np.float32), self._host(sparse, np.int32), self._host(label, np.float32)
         B = y.size // K
