@@ -293,6 +293,11 @@ int orx_shard_route(orx_ctx* ctx, const int32_t* uid, const int32_t* pid, const 
 int orx_shard_request(orx_ctx* ctx, const int32_t* trip, int64_t T, int32_t world, int32_t cap,
                       int32_t* send_ids, int32_t* slot, int32_t* u_loc, int32_t* counters, int32_t* overflow);
 int orx_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int32_t world, int32_t* out);
+/* generic request plan (hybrid-parallel DLRM lookups): every id >= 0 claims a slot in the bucket of its
+ * owner rank (id % world): send_ids[world*cap] (-1 = empty), slot[n] = position in send_ids or -1;
+ * counters[world] scratch, overflow[1] sticky flag (a bucket was full: that id is dropped) */
+int orx_shard_bucket(orx_ctx* ctx, const int32_t* ids, int64_t n, int32_t world, int32_t cap,
+                     int32_t* send_ids, int32_t* slot, int32_t* counters, int32_t* overflow);
 int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const float* rows_in, const int32_t* u_loc,
                     const int32_t* slot, int64_t T, int64_t row_stride, int64_t B_global, float margin, int flags,
                     float* gu, float* send_g, double* loss_l2_accum);

@@ -302,6 +302,16 @@ extern "C" int orx_shard_request(orx_ctx* ctx, const int32_t* trip, int64_t T, i
     return orx_launch_shard_request(ctx, a);
 }
 
+extern "C" int orx_shard_bucket(orx_ctx* ctx, const int32_t* ids, int64_t n, int32_t world, int32_t cap,
+                                int32_t* send_ids, int32_t* slot, int32_t* counters, int32_t* overflow) {
+    ORX_ARG(ctx && (n == 0 || ids) && send_ids && slot && counters && overflow, "orx_shard_bucket: NULL argument");
+    ORX_ARG(world >= 1 && world <= 64 && cap >= 1, "orx_shard_bucket: world must be in [1, 64] and cap positive");
+    ORX_HIP(hipSetDevice(ctx->device));
+    ORX_HIP(hipMemsetAsync(send_ids, 0xFF, (size_t)world * cap * sizeof(int32_t), ctx->stream));
+    ORX_HIP(hipMemsetAsync(counters, 0, (size_t)world * sizeof(int32_t), ctx->stream));
+    return orx_launch_shard_bucket(ctx, ids, n, world, cap, send_ids, slot, counters, overflow);
+}
+
 extern "C" int orx_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int32_t world, int32_t* out) {
     ORX_ARG(ctx && (n == 0 || (ids && out)) && world >= 1, "orx_shard_localize: bad argument");
     ORX_HIP(hipSetDevice(ctx->device));

@@ -340,6 +340,31 @@ int orx_launch_shard_request(orx_ctx* ctx, const RequestArgs& a) {
     return ORX_OK;
 }
 
+// generic request plan: every live id (>= 0) claims a slot in the bucket of its owner (id % world)
+__global__ __launch_bounds__(256) void shard_bucket_kernel(const int32_t* ids, int64_t n, int world, int cap, int32_t* send_ids,
+                                                           int32_t* slot, int* counters, int* overflow) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inb = i < n;
+    const int id = inb ? ids[i] : -1;
+    const bool live = id >= 0;
+    const int dest = live ? id % world : 0;
+    const int s = claim_slot(dest, live, world, counters);
+    if (!inb) return;
+    int g = -1;
+    if (live) {
+        if (s < cap) { g = dest * cap + s; send_ids[g] = id; } else *overflow = 1;
+    }
+    slot[i] = g;
+}
+
+int orx_launch_shard_bucket(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int cap, int32_t* send_ids, int32_t* slot,
+                            int* counters, int* overflow) {
+    if (n == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, shard_bucket_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ids, n, world, cap, send_ids, slot, counters, overflow);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
 int orx_launch_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int32_t* out) {
     if (n == 0) return ORX_OK;
     ORX_LAUNCH(ctx, shard_localize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ids, n, world, out);

@@ -330,6 +330,8 @@ struct ShardGradArgs {
 
 int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a);
 int orx_launch_shard_request(orx_ctx* ctx, const RequestArgs& a);
+int orx_launch_shard_bucket(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int cap, int32_t* send_ids, int32_t* slot,
+                            int* counters, int* overflow);
 int orx_launch_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int32_t* out);
 int orx_launch_shard_grads(orx_ctx* ctx, int model, const ShardGradArgs& a, int* nwaves);
 

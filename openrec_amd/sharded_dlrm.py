@@ -71,6 +71,13 @@ class HipDLRMBackend:
         self._ffi.check(self.lib.orx_apply_rows(self.ctx._h, self.opt._h, table._h, None, ids.data_ptr(), ids.numel(),
                                                 grads.data_ptr(), grads.shape[1]))
 
+    def bucket(self, ids, world, cap, send_ids, slot, counters, overflow):
+        self._ffi.check(self.lib.orx_shard_bucket(self.ctx._h, ids.data_ptr(), ids.numel(), world, cap, send_ids.data_ptr(),
+                                                  slot.data_ptr(), counters.data_ptr(), overflow.data_ptr()))
+
+    def localize(self, ids, world, out):
+        self._ffi.check(self.lib.orx_shard_localize(self.ctx._h, ids.data_ptr(), ids.numel(), world, out.data_ptr()))
+
     def grads(self, dense, emb_rows, label, global_b, emb_grads, loss_accum):
         self.model.grads(dense.data_ptr(), emb_rows.data_ptr(), label.data_ptr(), label.numel(), global_b,
                          emb_grads.data_ptr(), loss_accum.data_ptr())
@@ -113,6 +120,8 @@ class ShardedDLRM:
         self.loss_accum = torch.zeros(1, dtype=torch.float64, device=device)
         self.overflow = torch.zeros((), dtype=torch.bool, device=device)
         self.bad_id = torch.zeros((), dtype=torch.bool, device=device)
+        self._cnt = torch.zeros(64, dtype=torch.int32, device=device)
+        self._ovf = torch.zeros(1, dtype=torch.int32, device=device)
 
     # ---- table access by GLOBAL combined row (tests, checkpoints) ----------
     def load_embeddings(self, combined):
@@ -161,33 +170,62 @@ class ShardedDLRM:
         # ---- 1. requests to the owners
         n = g.numel()
         cap = int(math.ceil(n / N * self.slack)) + 8
-        slot, ov = bucket_slots(torch.where(g >= 0, g % N, g), N, cap)
-        self.overflow |= ov
         trash = N * cap
-        slot_t = torch.where(slot >= 0, slot, torch.full_like(slot, trash))
-        send = torch.full((trash + 1,), -1, dtype=torch.int32, device=dev)
-        send.index_copy_(0, slot_t, g.to(torch.int32))
-        req = self._a2a(send[:trash].contiguous()).to(torch.int64)
-        req_loc = torch.where(req >= 0, torch.div(req, N, rounding_mode="floor"), req).to(torch.int32).contiguous()
-        # ---- 2. owners gather, rows travel back
-        rows_out = torch.zeros((trash, d), dtype=torch.float32, device=dev)
+        if hasattr(self.be, "bucket"):                                     # device-side plan (ballot + popcount slot claims)
+            g32 = g.to(torch.int32).contiguous()
+            send = torch.empty((trash,), dtype=torch.int32, device=dev)
+            slot = torch.empty((n,), dtype=torch.int32, device=dev)
+            self.be.bucket(g32, N, cap, send, slot, self._cnt, self._ovf)
+            slot_t = torch.where(slot >= 0, slot, torch.full_like(slot, trash)).to(torch.int64)
+            req = self._a2a(send)
+            req_loc = torch.empty_like(req)
+            self.be.localize(req, N, req_loc)
+        else:                                                              # torch plan (CPU tests)
+            slot, ov = bucket_slots(torch.where(g >= 0, g % N, g), N, cap)
+            self.overflow |= ov
+            slot_t = torch.where(slot >= 0, slot, torch.full_like(slot, trash))
+            send = torch.full((trash + 1,), -1, dtype=torch.int32, device=dev)
+            send.index_copy_(0, slot_t, g.to(torch.int32))
+            req = self._a2a(send[:trash].contiguous()).to(torch.int64)
+            req_loc = torch.where(req >= 0, torch.div(req, N, rounding_mode="floor"), req).to(torch.int32).contiguous()
+        # ---- 2. owners gather, rows travel back.  Padding slots (request id -1) are skipped by the gather and
+        # never selected below, so the exchange buffers need no clearing; slot `trash` is a zero row that
+        # stands in for a lookup dropped by a full bucket.
+        buf = self._buffers(n, trash, d)
+        rows_out, rows_in, emb_grads, send_g = buf["rows_out"], buf["rows_in"], buf["emb_grads"], buf["send_g"]
         self.be.gather_rows(self.emb, req_loc, rows_out)
-        rows_in = torch.zeros((trash + 1, d), dtype=torch.float32, device=dev)
-        rows_in[:trash] = self._a2a(rows_out)
-        emb_rows = rows_in.index_select(0, slot_t).contiguous()              # [B*nf, d] in lookup order (dropped: zeros)
+        self._a2a_into(rows_in[:trash], rows_out)
+        emb_rows = rows_in.index_select(0, slot_t)                           # [B*nf, d] in lookup order
         # ---- 3. local forward + backward
-        emb_grads = torch.empty((n, d), dtype=torch.float32, device=dev)
         self.be.grads(dense, emb_rows, label, B * N, emb_grads, self.loss_accum)
         # ---- 4. dense gradients: one all-reduce, then the dense rule on every replica
         self.be.dense_pack(self.flat)
         self._allreduce(self.flat)
         self.be.dense_apply(self.flat)
-        # ---- 5. embedding gradients back to the owners
-        send_g = torch.zeros((trash + 1, d), dtype=torch.float32, device=dev)
+        # ---- 5. embedding gradients back to the owners (padding slots carry garbage and are skipped: id -1)
         send_g.index_copy_(0, slot_t, emb_grads)
-        g_in = self._a2a(send_g[:trash].contiguous())
+        g_in = self._a2a(send_g[:trash])
         self.be.apply_rows(self.emb, req_loc, g_in)
         return None
+
+    def _buffers(self, n, trash, d):
+        key = (n, trash)
+        if getattr(self, "_buf_key", None) != key:
+            dev, f32 = self.device, torch.float32
+            self._buf = dict(rows_out=torch.zeros((trash, d), dtype=f32, device=dev),
+                             rows_in=torch.zeros((trash + 1, d), dtype=f32, device=dev),
+                             emb_grads=torch.zeros((n, d), dtype=f32, device=dev),
+                             send_g=torch.zeros((trash + 1, d), dtype=f32, device=dev))
+            self._buf_key = key
+        return self._buf
+
+    def _a2a_into(self, out, x):
+        if self.a2a_fn is not None:
+            self.a2a_fn(out, x)
+        elif self.world == 1:
+            out.copy_(x)
+        else:
+            dist.all_to_all_single(out, x, group=self.group)
 
     # ---- results ---------------------------------------------------------------
     def loss_sum(self):
@@ -201,7 +239,7 @@ class ShardedDLRM:
     def check(self):
         if hasattr(self.be, "stream"):
             self.be.stream.synchronize()
-        if bool(self.overflow.item()):
+        if bool(self.overflow.item()) or int(self._ovf.item()) != 0:
             raise RuntimeError("sharded DLRM: an exchange bucket overflowed (raise `slack`)")
         if bool(self.bad_id.item()):
             raise IndexError("sharded DLRM: embedding id out of range")
