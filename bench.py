@@ -120,6 +120,7 @@ def bench_dlrm(args, torch, rt, world, rank, local_rank, device, dist):
     else:
         from openrec_amd.sharded_dlrm import ShardedDLRM
         eng = ShardedDLRM(rank=rank, world=world, device=device, opt="sgd", lr=0.01, seed=0, fp16_mlp=args.fp16_mlp, **cfg)
+        eng.force_collectives = dist is not None
         for s in range(W):
             eng.step(dense[s * B:(s + 1) * B], sparse[s * B:(s + 1) * B], label[s * B:(s + 1) * B])
         torch.cuda.synchronize()
@@ -246,15 +247,14 @@ def main():
                                       rank=rank, world=world, device=device, seed=0)
         eng.force_collectives = dist is not None
         uid, pid, nid = make_ids(torch, args.users, args.items, K + W, args.batch, 1234 + rank, device)
-        for s in range(W):
-            eng.step(uid[s], pid[s], nid[s])
+        if W:
+            eng.steps(uid[:W], pid[:W], nid[:W])
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for s in range(W, W + K):
-            eng.step(uid[s], pid[s], nid[s])
+        eng.steps(uid[W:W + K], pid[W:W + K], nid[W:W + K])          # one K-step call, like the single-GPU path
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

@@ -210,6 +210,57 @@ class ShardedPairwise:
         be.apply_rows(self.V, self.b, f["req_loc"], g_in)
         return None
 
+    def steps(self, uid, pid, nid, plan_chunk=64):
+        """K steps: uid/pid/nid int32 [K, B] on self.device.  The exchange PLAN of a step (which triplet goes
+        to which user-owner, which item rows are requested from whom) depends on the ids alone, so it is made for
+        `plan_chunk` steps at a time with ONE all-to-all per phase (routes 1 and 2 of the module docstring);
+        the per-step dependency chain is then gather -> all-to-all (rows) -> gradients -> all-to-all (gradients)
+        -> apply: two collectives per step instead of four."""
+        K = uid.shape[0]
+        if not self.fast:
+            for k in range(K):
+                self.step(uid[k], pid[k], nid[k])
+            return None
+        with self.be.stream_ctx():
+            for k0 in range(0, K, plan_chunk):
+                self._steps_planned(uid[k0:k0 + plan_chunk], pid[k0:k0 + plan_chunk], nid[k0:k0 + plan_chunk])
+        return None
+
+    def _a2a_steps(self, x, N):
+        """x: [Kc, N * c, ...] per-step buckets -> the same layout after ONE all-to-all over all Kc steps"""
+        if self.world == 1 and not self.force_collectives and self.a2a_fn is None:
+            return x
+        Kc = x.shape[0]
+        c = x.shape[1] // N
+        tail = x.shape[2:]
+        send = x.reshape(Kc, N, c, *tail).transpose(0, 1).contiguous().reshape(N * Kc * c, *tail)     # [dest][step][slot]
+        recv = self._a2a(send)
+        return recv.reshape(N, Kc, c, *tail).transpose(0, 1).contiguous().reshape(Kc, N * c, *tail)   # [step][src][slot]
+
+    def _steps_planned(self, uid, pid, nid):
+        be, N = self.be, self.world
+        Kc, B = uid.shape
+        f = self._buffers(B)
+        T, M = f["T"], f["M"]
+        i32 = dict(dtype=torch.int32, device=self.device)
+        send1 = torch.empty((Kc, T, 3), **i32)
+        for k in range(Kc):
+            be.shard_route(uid[k], pid[k], nid[k], self.n_users, self.n_items, N, f["cap1"], send1[k], f["cnt"], self._ovf)
+        mine = self._a2a_steps(send1, N)                                           # 1. triplets -> user owner, all steps
+        send2 = torch.empty((Kc, M), **i32); slot = torch.empty((Kc, 2 * T), **i32); u_loc = torch.empty((Kc, T), **i32)
+        for k in range(Kc):
+            be.shard_request(mine[k], N, f["cap2"], send2[k], slot[k], u_loc[k], f["cnt"], self._ovf)
+        req = self._a2a_steps(send2, N)                                            # 2. item ids -> item owner, all steps
+        req_loc = torch.empty_like(req)
+        be.shard_localize(req.reshape(-1), N, req_loc.reshape(-1))
+        for k in range(Kc):
+            be.gather_rows(self.V, self.b, req_loc[k], f["rows_out"])
+            rows_in = self._a2a(f["rows_out"], f["rows_in"])                       # 3. item rows back
+            be.shard_grads(self.model, self.U, rows_in, u_loc[k], slot[k], B * N, self.margin, f["gu"], f["send_g"], self.accum)
+            be.apply_rows(self.U, None, u_loc[k], f["gu"])                         # 5. user rows are local
+            g_in = self._a2a(f["send_g"], f["g_in"])                               # 6. item-row gradients -> owners
+            be.apply_rows(self.V, self.b, req_loc[k], g_in)
+
     def step(self, uid, pid, nid):
         """uid/pid/nid: int32 [B] on self.device -- this rank's slice of the global batch."""
         if hasattr(self.be, "stream_ctx"):

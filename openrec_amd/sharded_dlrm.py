@@ -120,6 +120,7 @@ class ShardedDLRM:
         self.loss_accum = torch.zeros(1, dtype=torch.float64, device=device)
         self.overflow = torch.zeros((), dtype=torch.bool, device=device)
         self.bad_id = torch.zeros((), dtype=torch.bool, device=device)
+        self.force_collectives = False          # world size 1 still goes through RCCL (bench.py --sharded under torchrun)
         self._cnt = torch.zeros(64, dtype=torch.int32, device=device)
         self._ovf = torch.zeros(1, dtype=torch.int32, device=device)
 
@@ -137,7 +138,7 @@ class ShardedDLRM:
             out = torch.empty_like(x)
             self.a2a_fn(out, x)
             return out
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return x
         out = torch.empty_like(x)
         dist.all_to_all_single(out, x, group=self.group)
@@ -146,7 +147,7 @@ class ShardedDLRM:
     def _allreduce(self, x):
         if self.allreduce_fn is not None:      # tests: in-place sum over the fake cluster
             self.allreduce_fn(x)
-        elif self.world > 1:
+        elif self.world > 1 or self.force_collectives:
             dist.all_reduce(x, group=self.group)
         return x
 
@@ -222,7 +223,7 @@ class ShardedDLRM:
     def _a2a_into(self, out, x):
         if self.a2a_fn is not None:
             self.a2a_fn(out, x)
-        elif self.world == 1:
+        elif self.world == 1 and not self.force_collectives:
             out.copy_(x)
         else:
             dist.all_to_all_single(out, x, group=self.group)

@@ -89,8 +89,10 @@ class _FakeCluster:
 
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("model,optk", [("bpr", "sgd"), ("bpr", "adagrad"), ("ucml", "sgd")])
-@pytest.mark.parametrize("fast", [True, False])
+@pytest.mark.parametrize("fast", [True, False, "planned"])
 def test_virtual_cluster_matches_oracle(world, model, optk, fast):
+    planned = fast == "planned"             # K-step call: the exchange plan of all steps in one all-to-all per phase
+    fast = bool(fast)
     import threading
     import torch
     from openrec_amd import sharded
@@ -109,9 +111,13 @@ def test_virtual_cluster_matches_oracle(world, model, optk, fast):
             e.U.write(U[rank::world]); e.V.write(V[rank::world]); e.b.write(b[rank::world])
             engs[rank] = e
             per = Bg // world
-            for s in range(3):
+            sl = slice(rank * per, (rank + 1) * per)
+            if planned:
+                stack = lambda f: torch.from_numpy(np.stack([f(s)[sl] for s in range(3)])).to(dev)
+                e.steps(stack(lambda s: np.roll(u, s)), stack(lambda s: np.roll(p, 5 * s)), stack(lambda s: np.roll(n, 2 * s)),
+                        plan_chunk=2)
+            for s in range(0 if not planned else 3, 3):
                 uu, pp, nn = np.roll(u, s), np.roll(p, 5 * s), np.roll(n, 2 * s)
-                sl = slice(rank * per, (rank + 1) * per)
                 e.step(torch.from_numpy(uu[sl].copy()).to(dev), torch.from_numpy(pp[sl].copy()).to(dev),
                        torch.from_numpy(nn[sl].copy()).to(dev))
             torch.cuda.synchronize()
