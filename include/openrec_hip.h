@@ -275,6 +275,14 @@ int orx_pair_grads(orx_ctx* ctx, int model, int32_t D,
                    float* gu, float* gp, float* gn, int64_t g_stride, double* loss_l2_accum);
 int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias,
                    const int32_t* ids, int64_t n, const float* grads, int64_t g_stride);
+/* K-step plans know every id list up front: duplicate flags of K lists in one launch
+ * (dflag[k*n + i] = 1 iff row ids[k*id_stride + i] occurs more than once in list k), and the SGD
+ * apply that uses them: rows referenced once are plain read-modify-writes, only duplicated rows
+ * take atomics.  Same result as orx_apply_rows. */
+int orx_rows_dupflags(orx_ctx* ctx, int64_t rows, const int32_t* ids, int64_t K, int64_t n, int64_t id_stride,
+                      unsigned char* dflag);
+int orx_apply_rows_flagged(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
+                           const float* grads, int64_t g_stride, const unsigned char* dflag);
 
 /* Device-side exchange plan of the sharded step (openrec_amd/sharded.py): fixed-capacity
  * buckets, no host synchronization.  Row r of a table lives on rank r % world at local

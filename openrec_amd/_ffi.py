@@ -77,6 +77,8 @@ SIGNATURES = {
     "orx_pair_grads": (c_int, [_p, c_int, c_int32, _fp, _fp, _fp, c_int64, _ip, c_int64, c_int64, c_float, c_int,
                                _fp, _fp, _fp, c_int64, _p]),
     "orx_apply_rows": (c_int, [_p, _p, _p, _p, _ip, c_int64, _fp, c_int64]),
+    "orx_rows_dupflags": (c_int, [_p, c_int64, _ip, c_int64, c_int64, c_int64, _p]),
+    "orx_apply_rows_flagged": (c_int, [_p, _p, _p, _p, _ip, c_int64, _fp, c_int64, _p]),
     "orx_shard_route": (c_int, [_p, _ip, _ip, _ip, c_int64, c_int64, c_int64, c_int32, c_int32, _ip, _ip, _ip]),
     "orx_shard_request": (c_int, [_p, _ip, c_int64, c_int32, c_int32, _ip, _ip, _ip, _ip, _ip]),
     "orx_shard_localize": (c_int, [_p, _ip, c_int64, c_int32, _ip]),

@@ -271,6 +271,43 @@ extern "C" int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_tabl
     return orx_launch_dup_apply(ctx, ORX_ADAGRAD, pa);
 }
 
+// duplicate flags of K id lists against a table of `rows` rows: dflag[k*n + i] = 1 iff the row ids[k*id_stride + i]
+// occurs more than once in list k (ids < 0 are skipped, their flag is not written)
+extern "C" int orx_rows_dupflags(orx_ctx* ctx, int64_t rows, const int32_t* ids, int64_t K, int64_t n, int64_t id_stride,
+                                 unsigned char* dflag) {
+    ORX_ARG(ctx && rows > 0 && (K == 0 || n == 0 || (ids && dflag)), "orx_rows_dupflags: bad argument");
+    if (K == 0 || n == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(ctx->device));
+    const int64_t list_stride = n / 2 + 1;
+    ENSURE(ctx->d_dlist, ctx->d_dlist_cap, (size_t)K * list_stride * sizeof(uint32_t));
+    ENSURE(ctx->d_dcount, ctx->d_dcount_cap, (size_t)K * sizeof(int));
+    ORX_HIP(hipMemsetAsync(ctx->d_dcount, 0, (size_t)K * sizeof(int), ctx->stream));
+    DedupArgs d;
+    memset(&d, 0, sizeof(d));
+    d.uid = ids; d.pid = ids; d.nid = ids; d.id_stride = id_stride;
+    d.dflag = dflag; d.dlist = ctx->d_dlist; d.dcount = ctx->d_dcount;
+    d.flag_stride = n; d.list_stride = list_stride;
+    d.nU = 0; d.nP = n; d.nN = 0; d.NU = 0; d.NI = rows; d.nbu = 0; d.nbi = orx_dedup_buckets(rows);
+    return orx_launch_dedup(ctx, d, K);
+}
+
+// orx_apply_rows for SGD with the duplicate flags of the id list already known (orx_rows_dupflags)
+extern "C" int orx_apply_rows_flagged(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
+                                      const float* grads, int64_t g_stride, const unsigned char* dflag) {
+    ORX_ARG(ctx && opt && t && (n == 0 || (ids && grads && dflag)), "orx_apply_rows_flagged: NULL argument");
+    ORX_ARG(opt->kind == ORX_SGD, "orx_apply_rows_flagged: SGD only (Adagrad / Adam: orx_apply_rows)");
+    ORX_ARG(g_stride >= t->dim + (bias ? 1 : 0), "orx_apply_rows_flagged: g_stride too small");
+    ORX_ARG(!bias || (bias->dim == 1 && bias->rows == t->rows), "orx_apply_rows_flagged: bias must be [%lld, 1]", (long long)t->rows);
+    if (n == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(ctx->device));
+    RowsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.W = t->w; a.bias = bias ? bias->w : nullptr;
+    a.ids = ids; a.grads = grads; a.g_stride = g_stride; a.n = n; a.rows = t->rows; a.D = t->dim;
+    a.lr = opt->lr; a.err = ctx->d_err; a.dflag = dflag;
+    return orx_launch_apply_rows(ctx, ORX_SGD, true, a);
+}
+
 // ------------------------------------------------- device-side exchange plan ---
 extern "C" int orx_shard_route(orx_ctx* ctx, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t B,
                                int64_t users_global, int64_t items_global, int32_t world, int32_t cap,

@@ -149,6 +149,37 @@ __global__ __launch_bounds__(256) void apply_rows_sgd_kernel(RowsArgs a) {
     }
 }
 
+// SGD with duplicate flags (computed once for all steps of a planned K-step call): a row referenced
+// once in the list is a plain float4 read-modify-write by its lane group, only duplicated rows take
+// the 64 atomics per reference.  LPR lanes per reference.
+template <int LPR>
+__global__ __launch_bounds__(256) void apply_rows_sgd_flagged_kernel(RowsArgs a) {
+    constexpr int TPW = 64 / LPR;
+    constexpr int D = 4 * LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
+    for (int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + grp; k < a.n; k += stride) {
+        const int r = a.ids[k];
+        if (r < 0) continue;
+        if ((int64_t)r >= a.rows) { if (sub == 0) *a.err = 1; continue; }
+        const bool dup = a.dflag[k] != 0;
+        const f4 g = *reinterpret_cast<const f4*>(a.grads + k * a.g_stride + 4 * sub);
+        float* w = a.W + (size_t)r * D + 4 * sub;
+        if (dup) {
+            atomic_add_f4(w, -a.lr * g);
+        } else {
+            *reinterpret_cast<f4*>(w) = *reinterpret_cast<const f4*>(w) - a.lr * g;
+        }
+        if (a.bias != nullptr && sub == 0) {
+            const float gb = a.grads[k * a.g_stride + D];
+            if (dup) unsafeAtomicAdd(a.bias + r, -a.lr * gb);
+            else a.bias[r] = a.bias[r] - a.lr * gb;
+        }
+    }
+}
+
 // Adagrad: rows referenced once are updated in place, duplicated rows sum into
 // gsum first (dup_apply_kernel finishes them).  One wavefront per reference.
 __global__ __launch_bounds__(256) void apply_rows_adagrad_kernel(RowsArgs a) {
@@ -176,7 +207,18 @@ __global__ __launch_bounds__(256) void apply_rows_adagrad_kernel(RowsArgs a) {
 int orx_launch_apply_rows(orx_ctx* ctx, int optkind, bool use_dflag, const RowsArgs& a) {
     ProfScope ps(ctx, ORX_K_DUPAPPLY);
     if (a.n == 0) return ORX_OK;
-    if (optkind == ORX_SGD) {
+    int lpr = 0;
+    switch (a.D) { case 16: lpr = 4; break; case 32: lpr = 8; break; case 64: lpr = 16; break; case 128: lpr = 32; break; case 256: lpr = 64; break; }
+    if (optkind == ORX_SGD && use_dflag && lpr != 0 && a.g_stride % 4 == 0) {
+        const dim3 g(grid_for_rows(lpr, a.n));
+        switch (lpr) {
+            case 4: ORX_LAUNCH(ctx, (apply_rows_sgd_flagged_kernel<4>), g, dim3(256), 0, a); break;
+            case 8: ORX_LAUNCH(ctx, (apply_rows_sgd_flagged_kernel<8>), g, dim3(256), 0, a); break;
+            case 16: ORX_LAUNCH(ctx, (apply_rows_sgd_flagged_kernel<16>), g, dim3(256), 0, a); break;
+            case 32: ORX_LAUNCH(ctx, (apply_rows_sgd_flagged_kernel<32>), g, dim3(256), 0, a); break;
+            default: ORX_LAUNCH(ctx, (apply_rows_sgd_flagged_kernel<64>), g, dim3(256), 0, a); break;
+        }
+    } else if (optkind == ORX_SGD) {
         int64_t g = (a.n * (a.D + 1) + 255) / 256;
         if (g > 65536) g = 65536;
         ORX_LAUNCH(ctx, apply_rows_sgd_kernel, dim3((unsigned)g), dim3(256), 0, a);
@@ -192,7 +234,7 @@ int orx_launch_apply_rows(orx_ctx* ctx, int optkind, bool use_dflag, const RowsA
 __global__ __launch_bounds__(256) void loss_accumulate_kernel(const float* partial, int nwaves, double* accum) {
     __shared__ double sh[2][4];
     double s0 = 0.0, s1 = 0.0;
-    for (int i = threadIdx.x; i < nwaves; i += blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nwaves; i += gridDim.x * blockDim.x) {
         const float2 v = *reinterpret_cast<const float2*>(partial + 2 * i);
         s0 += (double)v.x; s1 += (double)v.y;
     }
@@ -200,15 +242,15 @@ __global__ __launch_bounds__(256) void loss_accumulate_kernel(const float* parti
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { sh[0][w] = s0; sh[1][w] = s1; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        accum[0] += sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-        accum[1] += sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    if (threadIdx.x == 0) {     // a few blocks, one fp64 atomic pair each (a single block over 16 k partials took 18 us)
+        atomicAdd(accum + 0, sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+        atomicAdd(accum + 1, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
     }
 }
 
 int orx_launch_loss_accumulate(orx_ctx* ctx, const float* partial, int nwaves, double* accum) {
     ProfScope ps(ctx, ORX_K_REDUCE);
-    ORX_LAUNCH(ctx, loss_accumulate_kernel, dim3(1), dim3(256), 0, partial, nwaves, accum);
+    ORX_LAUNCH(ctx, loss_accumulate_kernel, dim3(nwaves > 2048 ? 16 : 1), dim3(256), 0, partial, nwaves, accum);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

@@ -102,6 +102,16 @@ class HipBackend:
                                                 bias._h if bias is not None else None,
                                                 ids.data_ptr(), ids.numel(), grads.data_ptr(), grads.shape[1]))
 
+    def rows_dupflags(self, table, ids2d, out):
+        """ids2d [K, n] int32 (local row ids, < 0 = padding) -> out [K, n] uint8 duplicate flags per list"""
+        K, n = ids2d.shape
+        self._ffi.check(self.lib.orx_rows_dupflags(self.ctx._h, table.rows, ids2d.data_ptr(), K, n, n, out.data_ptr()))
+
+    def apply_rows_flagged(self, table, bias, ids, grads, dflag):
+        self._ffi.check(self.lib.orx_apply_rows_flagged(self.ctx._h, self.opt._h, table._h,
+                                                        bias._h if bias is not None else None, ids.data_ptr(), ids.numel(),
+                                                        grads.data_ptr(), grads.shape[1], dflag.data_ptr()))
+
     # ---- device-side exchange plan (fast path) ----------------------------
     fast = True
 
@@ -142,6 +152,7 @@ class ShardedPairwise:
         self.rank, self.world, self.device, self.group = rank, world, device, group
         self.n_users, self.n_items = n_users, n_items
         self.be = backend if backend is not None else HipBackend(device, opt, lr, opt_kw)
+        self.opt_kind = opt
         self.U = self.be.make_table(rows_on_rank(n_users, rank, world), dim, seed * 3 + 0 + 1000 * rank)
         self.V = self.be.make_table(rows_on_rank(n_items, rank, world), dim, seed * 3 + 1 + 1000 * rank)
         self.b = self.be.make_table(rows_on_rank(n_items, rank, world), 1, seed * 3 + 2 + 1000 * rank)
@@ -253,13 +264,26 @@ class ShardedPairwise:
         req = self._a2a_steps(send2, N)                                            # 2. item ids -> item owner, all steps
         req_loc = torch.empty_like(req)
         be.shard_localize(req.reshape(-1), N, req_loc.reshape(-1))
+        # SGD: the duplicate flags of every step's two apply lists, one launch each for the whole chunk
+        flagged = self.opt_kind == "sgd" and hasattr(be, "rows_dupflags")
+        if flagged:
+            fu = torch.empty((Kc, T), dtype=torch.uint8, device=self.device)
+            fv = torch.empty((Kc, M), dtype=torch.uint8, device=self.device)
+            be.rows_dupflags(self.U, u_loc, fu)
+            be.rows_dupflags(self.V, req_loc, fv)
         for k in range(Kc):
             be.gather_rows(self.V, self.b, req_loc[k], f["rows_out"])
             rows_in = self._a2a(f["rows_out"], f["rows_in"])                       # 3. item rows back
             be.shard_grads(self.model, self.U, rows_in, u_loc[k], slot[k], B * N, self.margin, f["gu"], f["send_g"], self.accum)
-            be.apply_rows(self.U, None, u_loc[k], f["gu"])                         # 5. user rows are local
+            if flagged:
+                be.apply_rows_flagged(self.U, None, u_loc[k], f["gu"], fu[k])      # 5. user rows are local
+            else:
+                be.apply_rows(self.U, None, u_loc[k], f["gu"])
             g_in = self._a2a(f["send_g"], f["g_in"])                               # 6. item-row gradients -> owners
-            be.apply_rows(self.V, self.b, req_loc[k], g_in)
+            if flagged:
+                be.apply_rows_flagged(self.V, self.b, req_loc[k], g_in, fv[k])
+            else:
+                be.apply_rows(self.V, self.b, req_loc[k], g_in)
 
     def step(self, uid, pid, nid):
         """uid/pid/nid: int32 [B] on self.device -- this rank's slice of the global batch."""
