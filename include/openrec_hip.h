@@ -300,6 +300,14 @@ int orx_shard_route(orx_ctx* ctx, const int32_t* uid, const int32_t* pid, const 
                     int32_t* send, int32_t* counters, int32_t* overflow);
 int orx_shard_request(orx_ctx* ctx, const int32_t* trip, int64_t T, int32_t world, int32_t cap,
                       int32_t* send_ids, int32_t* slot, int32_t* u_loc, int32_t* counters, int32_t* overflow);
+/* the same two plans for K steps in one launch each (the plan depends on the ids alone): uid/pid/nid
+ * [K][id_stride], send [K][world*cap][3], trip [K][T][3], send_ids [K][world*cap], slot [K][2T],
+ * u_loc [K][T], counters [K][world] */
+int orx_shard_route_steps(orx_ctx* ctx, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t K, int64_t B,
+                          int64_t id_stride, int64_t users_global, int64_t items_global, int32_t world, int32_t cap,
+                          int32_t* send, int32_t* counters, int32_t* overflow);
+int orx_shard_request_steps(orx_ctx* ctx, const int32_t* trip, int64_t K, int64_t T, int32_t world, int32_t cap,
+                            int32_t* send_ids, int32_t* slot, int32_t* u_loc, int32_t* counters, int32_t* overflow);
 int orx_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int32_t world, int32_t* out);
 /* generic request plan (hybrid-parallel DLRM lookups): every id >= 0 claims a slot in the bucket of its
  * owner rank (id % world): send_ids[world*cap] (-1 = empty), slot[n] = position in send_ids or -1;

@@ -82,6 +82,8 @@ SIGNATURES = {
     "orx_shard_route": (c_int, [_p, _ip, _ip, _ip, c_int64, c_int64, c_int64, c_int32, c_int32, _ip, _ip, _ip]),
     "orx_shard_request": (c_int, [_p, _ip, c_int64, c_int32, c_int32, _ip, _ip, _ip, _ip, _ip]),
     "orx_shard_localize": (c_int, [_p, _ip, c_int64, c_int32, _ip]),
+    "orx_shard_route_steps": (c_int, [_p, _ip, _ip, _ip, c_int64, c_int64, c_int64, c_int64, c_int64, c_int32, c_int32, _ip, _ip, _ip]),
+    "orx_shard_request_steps": (c_int, [_p, _ip, c_int64, c_int64, c_int32, c_int32, _ip, _ip, _ip, _ip, _ip]),
     "orx_shard_bucket": (c_int, [_p, _ip, c_int64, c_int32, c_int32, _ip, _ip, _ip, _ip]),
     "orx_shard_grads": (c_int, [_p, c_int, _p, _fp, _ip, _ip, c_int64, c_int64, c_int64, c_float, c_int, _fp, _fp, _p]),
     "orx_prof_enable": (c_int, [_p, c_int]),

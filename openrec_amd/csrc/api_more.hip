@@ -325,6 +325,38 @@ extern "C" int orx_shard_route(orx_ctx* ctx, const int32_t* uid, const int32_t* 
     return orx_launch_shard_route(ctx, a);
 }
 
+// K steps at once (the plan of a K-step call depends on the ids alone): per-step arrays are contiguous,
+// uid/pid/nid [K][id_stride], send [K][world*cap][3], counters [K][world]
+extern "C" int orx_shard_route_steps(orx_ctx* ctx, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t K, int64_t B,
+                                     int64_t id_stride, int64_t users_global, int64_t items_global, int32_t world, int32_t cap,
+                                     int32_t* send, int32_t* counters, int32_t* overflow) {
+    ORX_ARG(ctx && uid && pid && nid && send && counters && overflow, "orx_shard_route_steps: NULL argument");
+    ORX_ARG(world >= 1 && world <= 64 && cap >= 1 && K >= 0 && K < 65536, "orx_shard_route_steps: world in [1, 64], cap positive, K < 65536");
+    ORX_HIP(hipSetDevice(ctx->device));
+    ORX_HIP(hipMemsetAsync(send, 0xFF, (size_t)K * world * cap * 3 * sizeof(int32_t), ctx->stream));
+    ORX_HIP(hipMemsetAsync(counters, 0, (size_t)K * world * sizeof(int32_t), ctx->stream));
+    RouteArgs a;
+    memset(&a, 0, sizeof(a));
+    a.uid = uid; a.pid = pid; a.nid = nid; a.B = B; a.world = world; a.cap = cap; a.id_stride = id_stride;
+    a.send = send; a.counters = counters; a.overflow = overflow; a.err = ctx->d_err;
+    a.NU = users_global; a.NI = items_global;
+    return orx_launch_shard_route(ctx, a, K);
+}
+
+extern "C" int orx_shard_request_steps(orx_ctx* ctx, const int32_t* trip, int64_t K, int64_t T, int32_t world, int32_t cap,
+                                       int32_t* send_ids, int32_t* slot, int32_t* u_loc, int32_t* counters, int32_t* overflow) {
+    ORX_ARG(ctx && trip && send_ids && slot && u_loc && counters && overflow, "orx_shard_request_steps: NULL argument");
+    ORX_ARG(world >= 1 && world <= 64 && cap >= 1 && K >= 0 && K < 65536, "orx_shard_request_steps: world in [1, 64], cap positive, K < 65536");
+    ORX_HIP(hipSetDevice(ctx->device));
+    ORX_HIP(hipMemsetAsync(send_ids, 0xFF, (size_t)K * world * cap * sizeof(int32_t), ctx->stream));
+    ORX_HIP(hipMemsetAsync(counters, 0, (size_t)K * world * sizeof(int32_t), ctx->stream));
+    RequestArgs a;
+    memset(&a, 0, sizeof(a));
+    a.trip = trip; a.T = T; a.world = world; a.cap = cap;
+    a.send_ids = send_ids; a.slot = slot; a.u_loc = u_loc; a.counters = counters; a.overflow = overflow;
+    return orx_launch_shard_request(ctx, a, K);
+}
+
 extern "C" int orx_shard_request(orx_ctx* ctx, const int32_t* trip, int64_t T, int32_t world, int32_t cap,
                                  int32_t* send_ids, int32_t* slot, int32_t* u_loc, int32_t* counters, int32_t* overflow) {
     ORX_ARG(ctx && trip && send_ids && slot && u_loc && counters && overflow, "orx_shard_request: NULL argument");

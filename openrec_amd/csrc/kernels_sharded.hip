@@ -281,6 +281,9 @@ __device__ __forceinline__ int claim_slot(int dest, bool active, int world, int*
 
 // 1. route each triplet to the owner of its user row (rank = uid % world)
 __global__ __launch_bounds__(256) void shard_route_kernel(RouteArgs a) {
+    const int64_t step = blockIdx.y;                    // K-step launch: one grid row per step
+    a.uid += step * a.id_stride; a.pid += step * a.id_stride; a.nid += step * a.id_stride;
+    a.send += step * (int64_t)a.world * a.cap * 3; a.counters += step * a.world;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool active = t < a.B;
     int u = 0, p = 0, n = 0;
@@ -299,6 +302,9 @@ __global__ __launch_bounds__(256) void shard_route_kernel(RouteArgs a) {
 
 // 2. request the two item rows of every live triplet from their owners (rank = id % world)
 __global__ __launch_bounds__(256) void shard_request_kernel(RequestArgs a) {
+    const int64_t step = blockIdx.y;                    // K-step launch: one grid row per step
+    a.trip += step * a.T * 3; a.send_ids += step * (int64_t)a.world * a.cap; a.slot += step * 2 * a.T;
+    a.u_loc += step * a.T; a.counters += step * a.world;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool inb = t < a.T;
     int u = -1, p = 0, n = 0;
@@ -368,16 +374,16 @@ __global__ __launch_bounds__(256) void shard_grads_kernel(ShardGradArgs a) {
     }
 }
 
-int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a) {
-    if (a.B == 0) return ORX_OK;
-    ORX_LAUNCH(ctx, shard_route_kernel, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, a);
+int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a, int64_t K) {
+    if (a.B == 0 || K == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, shard_route_kernel, dim3((unsigned)((a.B + 255) / 256), (unsigned)K), dim3(256), 0, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
 
-int orx_launch_shard_request(orx_ctx* ctx, const RequestArgs& a) {
-    if (a.T == 0) return ORX_OK;
-    ORX_LAUNCH(ctx, shard_request_kernel, dim3((unsigned)((a.T + 255) / 256)), dim3(256), 0, a);
+int orx_launch_shard_request(orx_ctx* ctx, const RequestArgs& a, int64_t K) {
+    if (a.T == 0 || K == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, shard_request_kernel, dim3((unsigned)((a.T + 255) / 256), (unsigned)K), dim3(256), 0, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

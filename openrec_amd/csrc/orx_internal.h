@@ -304,6 +304,8 @@ struct RouteArgs {
     int* counters;           // [world], zeroed
     int* overflow; int* err;
     int64_t NU, NI;          // GLOBAL table rows (id validation)
+    int64_t id_stride;       // K-step launch (grid.y = step): ids of step k at + k*id_stride, send / counters of step k
+                             // at + k*world*cap*3 / + k*world
 };
 
 struct RequestArgs {
@@ -314,6 +316,7 @@ struct RequestArgs {
     int32_t* u_loc;          // [T]: local user row or -1
     int* counters;           // [world], zeroed
     int* overflow;
+    // K-step launch (grid.y = step): every array of step k at + k * (its per-step size)
 };
 
 struct ShardGradArgs {
@@ -328,8 +331,8 @@ struct ShardGradArgs {
     float* partial;
 };
 
-int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a);
-int orx_launch_shard_request(orx_ctx* ctx, const RequestArgs& a);
+int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a, int64_t K = 1);
+int orx_launch_shard_request(orx_ctx* ctx, const RequestArgs& a, int64_t K = 1);
 int orx_launch_shard_bucket(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int cap, int32_t* send_ids, int32_t* slot,
                             int* counters, int* overflow);
 int orx_launch_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int32_t* out);

@@ -125,6 +125,17 @@ class HipBackend:
                                                    send_ids.data_ptr(), slot.data_ptr(), u_loc.data_ptr(),
                                                    counters.data_ptr(), overflow.data_ptr()))
 
+    def shard_route_steps(self, uid, pid, nid, n_users, n_items, world, cap, send, counters, overflow):
+        K, B = uid.shape
+        self._ffi.check(self.lib.orx_shard_route_steps(self.ctx._h, uid.data_ptr(), pid.data_ptr(), nid.data_ptr(), K, B, uid.stride(0),
+                                                       n_users, n_items, world, cap, send.data_ptr(), counters.data_ptr(),
+                                                       overflow.data_ptr()))
+
+    def shard_request_steps(self, trip, world, cap, send_ids, slot, u_loc, counters, overflow):
+        K, T = trip.shape[0], trip.shape[1]
+        self._ffi.check(self.lib.orx_shard_request_steps(self.ctx._h, trip.data_ptr(), K, T, world, cap, send_ids.data_ptr(),
+                                                         slot.data_ptr(), u_loc.data_ptr(), counters.data_ptr(), overflow.data_ptr()))
+
     def shard_localize(self, ids, world, out):
         self._ffi.check(self.lib.orx_shard_localize(self.ctx._h, ids.data_ptr(), ids.numel(), world, out.data_ptr()))
 
@@ -255,12 +266,12 @@ class ShardedPairwise:
         T, M = f["T"], f["M"]
         i32 = dict(dtype=torch.int32, device=self.device)
         send1 = torch.empty((Kc, T, 3), **i32)
-        for k in range(Kc):
-            be.shard_route(uid[k], pid[k], nid[k], self.n_users, self.n_items, N, f["cap1"], send1[k], f["cnt"], self._ovf)
-        mine = self._a2a_steps(send1, N)                                           # 1. triplets -> user owner, all steps
+        cnt = torch.empty((Kc, N), **i32)
+        uid, pid, nid = uid.contiguous(), pid.contiguous(), nid.contiguous()
+        be.shard_route_steps(uid, pid, nid, self.n_users, self.n_items, N, f["cap1"], send1, cnt, self._ovf)
+        mine = self._a2a_steps(send1, N).contiguous()                              # 1. triplets -> user owner, all steps
         send2 = torch.empty((Kc, M), **i32); slot = torch.empty((Kc, 2 * T), **i32); u_loc = torch.empty((Kc, T), **i32)
-        for k in range(Kc):
-            be.shard_request(mine[k], N, f["cap2"], send2[k], slot[k], u_loc[k], f["cnt"], self._ovf)
+        be.shard_request_steps(mine, N, f["cap2"], send2, slot, u_loc, cnt, self._ovf)
         req = self._a2a_steps(send2, N)                                            # 2. item ids -> item owner, all steps
         req_loc = torch.empty_like(req)
         be.shard_localize(req.reshape(-1), N, req_loc.reshape(-1))
