@@ -36,6 +36,7 @@ def alg_bytes_per_triplet(dim, opt, model="bpr"):
     # SGD 24*D + 28, Adagrad 48*D + 44 bytes per triplet; GMF / WRMF 16*D + 20 per (user, item, label)
     if model in ("gmf", "wrmf"):
         return 16 * dim + 20 if opt == "sgd" else 32 * dim + 28
+    # (TF-2.0 sparse Adam sweeps whole tables: its step is not priced per triplet; the Adagrad figure is reported)
     return 24 * dim + 28 if opt == "sgd" else 48 * dim + 44
 
 
@@ -162,7 +163,7 @@ def main():
     ap.add_argument("--fp16-mlp", action="store_true", help="dlrm: MLP products on fp16 MFMA (performance mode)")
     ap.add_argument("--model", default="bpr", choices=["bpr", "ucml", "gmf", "wrmf", "dlrm"],
                     help="gmf / wrmf: the pointwise step over B (user, item, label) samples (secondary workloads)")
-    ap.add_argument("--opt", default="sgd", choices=["sgd", "adagrad"])
+    ap.add_argument("--opt", default="sgd", choices=["sgd", "adagrad", "adam"])
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--users", type=int, default=1_000_000)
     ap.add_argument("--items", type=int, default=1_000_000)
@@ -203,7 +204,8 @@ def main():
         U = rt.Table(args.users, args.dim, ctx).init_uniform(seed=0)
         V = rt.Table(args.items, args.dim, ctx).init_uniform(seed=1)
         b = rt.Table(args.items, 1, ctx).init_uniform(seed=2)
-        opt = rt.Optimizer.sgd(lr, ctx=ctx) if args.opt == "sgd" else rt.Optimizer.adagrad(lr, ctx=ctx)
+        opt = {"sgd": lambda: rt.Optimizer.sgd(lr, ctx=ctx), "adagrad": lambda: rt.Optimizer.adagrad(lr, ctx=ctx),
+               "adam": lambda: rt.Optimizer.adam(0.001, ctx=ctx)}[args.opt]()
         uid, pid, nid = make_ids(torch, args.users, args.items, K + W, args.batch, 1234, device, args.zipf)
         torch.cuda.synchronize()
         pointwise = args.model in ("gmf", "wrmf")
