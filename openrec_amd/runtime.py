@@ -93,6 +93,13 @@ class Table:
         self.rows, self.dim = int(rows), int(dim)
         self._keepalive = (keepalive, self.ctx)
         self._fin = weakref.finalize(self, self._lib.orx_table_destroy, h)
+        self.pre_access = None          # callable run before any host-visible access (queued train steps flush here)
+
+    pre_access = None
+
+    def _sync_pending(self):
+        if self.pre_access is not None:
+            self.pre_access()
 
     @property
     def shape(self):
@@ -103,14 +110,17 @@ class Table:
         return self._lib.orx_table_device_ptr(self._h)
 
     def init_uniform(self, lo=-0.05, hi=0.05, seed=0):
+        self._sync_pending()
         check(self._lib.orx_table_init_uniform(self._h, lo, hi, int(seed) & (2 ** 64 - 1)))
         return self
 
     def fill(self, v):
+        self._sync_pending()
         check(self._lib.orx_table_fill(self._h, float(v)))
         return self
 
     def read(self, row0=0, nrows=None):
+        self._sync_pending()
         nrows = self.rows - row0 if nrows is None else nrows
         out = np.empty((nrows, self.dim), np.float32)
         check(self._lib.orx_table_read(self._h, int(row0), int(nrows), out.ctypes.data))
@@ -120,11 +130,13 @@ class Table:
         return self.read()
 
     def write(self, values, row0=0):
+        self._sync_pending()
         a = np.ascontiguousarray(values, np.float32).reshape(-1, self.dim)
         check(self._lib.orx_table_write(self._h, int(row0), a.shape[0], a.ctypes.data))
         return self
 
     def gather(self, ids):
+        self._sync_pending()
         ptr, n, dev, keep = _ids_arg(ids)
         if dev:
             raise ValueError("Table.gather returns host rows; pass host ids (use gather_rows for device buffers)")
@@ -133,6 +145,7 @@ class Table:
         return out
 
     def censor(self, ids, min_norm=0.1):
+        self._sync_pending()
         ptr, n, dev, keep = _ids_arg(ids)
         check(self._lib.orx_table_censor(self._h, ptr, n, float(min_norm), _ffi.ORX_IDS_DEVICE if dev else 0))
 

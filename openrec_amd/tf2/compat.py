@@ -102,15 +102,29 @@ class Mean:
 
     def update_state(self, values):
         for v in (values if isinstance(values, (tuple, list)) else [values]):
+            if isinstance(v, LazyScalar):
+                self._pending.append(v)         # reading it now would force the queued train steps to run
+                if len(self._pending) > 4096:
+                    self._drain()
+                continue
             a = np.asarray(v.numpy() if hasattr(v, "numpy") else v, np.float64)
             self._sum += float(a.sum())
             self._n += a.size
 
+    __call__ = update_state
+
+    def _drain(self):
+        for v in self._pending:
+            self._sum += float(v.numpy())
+            self._n += 1
+        self._pending = []
+
     def result(self):
+        self._drain()
         return np.float32(self._sum / max(self._n, 1))
 
     def reset_states(self):
-        self._sum, self._n = 0.0, 0
+        self._sum, self._n, self._pending = 0.0, 0, []
 
 
 optimizers = types.SimpleNamespace(SGD=SGD, Adagrad=Adagrad, Adam=Adam)

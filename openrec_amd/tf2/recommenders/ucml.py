@@ -13,7 +13,10 @@ class UCML(PairwiseRecommender):
         self.margin = margin
 
     def censor_vec(self, user_id, p_item_id, n_item_id):
-        """ucml.py:44-48: users, then positive items, then negative items (sequential)."""
+        """ucml.py:44-48: users, then positive items, then negative items (sequential).  Right after a queued
+        train step on the same ids it becomes that step's in-kernel censor (ORX_CENSOR) instead of three passes."""
+        if self._queue.mark_censor((_ids(user_id), _ids(p_item_id), _ids(n_item_id))):
+            return tuple(self.trainable_variables[:2]) + (self.trainable_variables[1],)
         return (self.user_latent_factor.censor(_ids(user_id)),
                 self.item_latent_factor.censor(_ids(p_item_id)),
                 self.item_latent_factor.censor(_ids(n_item_id)))

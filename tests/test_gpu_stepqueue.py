@@ -1,0 +1,101 @@
+"""The drop-in training loop (one `train_step` per batch, tf2_examples/bpr_citeulike.py:33-39) queues its
+steps and runs them as K-step device calls; nothing observable may change: losses, tables, metrics and
+interleaved reads are compared with the oracle stepped one batch at a time."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _loop(model_name, n_steps, B, NU, NI, D, read_at=(), device_ids=False, censor=False, seed=0):
+    from openrec_amd.tf2 import compat as tf
+    from openrec_amd.tf2 import recommenders as R
+    from oracle import numpy_oracle as orc
+    rng = np.random.default_rng(seed)
+    m = {"bpr": R.BPR, "ucml": R.UCML}[model_name](dim_user_embed=D, dim_item_embed=D, total_users=NU, total_items=NI)
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    if censor:
+        U *= 30; V *= 30
+    m.user_latent_factor.variables[0].assign(U); m.item_latent_factor.variables[0].assign(V); m.item_bias.variables[0].assign(b)
+    optimizer = tf.keras.optimizers.SGD(0.02)
+    mean = tf.keras.metrics.Mean()
+    oo = orc.SGD(0.02)
+    got, want = [], []
+    for s in range(n_steps):
+        u = rng.integers(0, NU, B).astype(np.int32); p = rng.integers(0, NI, B).astype(np.int32); n = rng.integers(0, NI, B).astype(np.int32)
+        ids = (u, p, n)
+        if device_ids:
+            import torch
+            ids = tuple(torch.from_numpy(x).cuda() for x in ids)
+        with tf.GradientTape() as tape:
+            loss, l2 = m(*ids)
+        grads = tape.gradient((loss, l2), m.trainable_variables)
+        optimizer.apply_gradients(zip(grads, m.trainable_variables))
+        if censor:
+            m.censor_vec(*ids)
+        mean.update_state(loss)
+        got.append(loss)
+        if model_name == "bpr":
+            lw, _ = orc.bpr_step(U, V, b, u, p, n, oo)
+        else:
+            lw, _ = orc.ucml_step(U, V, b, u, p, n, oo, margin=0.5, do_censor=censor)
+        want.append(float(lw))
+        if s in read_at:                                          # observing the model mid-way flushes the queue
+            assert rel_err(m.user_latent_factor.variables[0].numpy(), U) < 2e-5
+            assert abs(float(loss) - want[-1]) <= 2e-5 * abs(want[-1])
+    assert abs(float(mean.result()) - np.mean(want)) <= 2e-5 * abs(np.mean(want))
+    for g, w in zip(got, want):
+        assert abs(float(g) - w) <= 2e-5 * abs(w)
+    assert rel_err(m.user_latent_factor.variables[0].numpy(), U) < 2e-5
+    assert rel_err(m.item_latent_factor.variables[0].numpy(), V) < 2e-5
+    assert rel_err(m.item_bias.variables[0].numpy(), b) < 2e-5
+    return m
+
+
+def test_queued_loop_equals_stepwise_oracle():
+    m = _loop("bpr", 75, 512, 700, 900, 64)                       # 2 full queues + a partial one
+    assert not m._queue.steps
+
+
+def test_reads_in_the_middle_flush_the_queue():
+    _loop("bpr", 40, 256, 300, 400, 32, read_at=(0, 7, 8, 33))
+
+
+def test_device_ids_and_ucml_censor():
+    _loop("bpr", 37, 512, 700, 900, 64, device_ids=True)
+    _loop("ucml", 37, 512, 700, 900, 64, censor=True)             # censor_vec folds into the queued steps
+
+
+def test_queue_is_really_used(monkeypatch):
+    from openrec_amd import runtime as rt
+    calls = []
+    real = rt.pairwise_step
+    monkeypatch.setattr(rt, "pairwise_step", lambda *a, **k: (calls.append(k.get("K")), real(*a, **k))[1])
+    _loop("bpr", 70, 256, 300, 400, 32)
+    assert calls.count(32) == 2 and sum(calls) == 70 and len(calls) <= 4
+
+
+def test_pointwise_loop_is_queued():
+    from openrec_amd.tf2 import compat as tf
+    from openrec_amd.tf2 import recommenders as R
+    from oracle import numpy_oracle as orc
+    rng = np.random.default_rng(2)
+    NU, NI, D, B = 500, 600, 32, 384
+    m = R.WRMF(dim_user_embed=D, dim_item_embed=D, total_users=NU, total_items=NI, a=2.0, b=0.5)
+    U = m.user_latent_factor.variables[0].numpy(); V = m.item_latent_factor.variables[0].numpy(); b = m.item_bias.variables[0].numpy()
+    optimizer = tf.keras.optimizers.SGD(0.01)
+    oo = orc.SGD(0.01)
+    got, want = [], []
+    for s in range(45):
+        u = rng.integers(0, NU, B).astype(np.int32); i = rng.integers(0, NI, B).astype(np.int32); y = (rng.random(B) < 0.4).astype(np.float32)
+        with tf.GradientTape() as tape:
+            loss, l2 = m(u, i, y)
+        optimizer.apply_gradients(zip(tape.gradient((loss, l2), m.trainable_variables), m.trainable_variables))
+        got.append(loss)
+        want.append(float(orc.wrmf_step(U, V, b, u, i, y, oo, a=2.0, b_w=0.5)[0]))
+    for g, w in zip(got, want):
+        assert abs(float(g) - w) <= 2e-5 * abs(w)
+    assert rel_err(m.user_latent_factor.variables[0].numpy(), U) < 2e-5 and rel_err(m.item_latent_factor.variables[0].numpy(), V) < 2e-5
