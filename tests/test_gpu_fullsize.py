@@ -1,0 +1,73 @@
+"""Parity at BASELINE.json's full sizes (configs[1]: BPR D=64, 1M x 1M, B=65536; configs[2]: UCML D=128) against the
+C/OpenMP oracle (oracle/orx_oracle.c, itself pinned to the NumPy oracle by tests/test_c_oracle.py), plus
+size-independent properties of a train step: rows that no triplet references keep their exact bits, the update of
+the item-bias table sums to zero for BPR (every triplet adds +g to one bias gradient and -g to another), and the
+K-step call equals K single-step calls."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(NU, NI, D, seed):
+    rng = np.random.default_rng(seed)
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32)
+    V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    return U, V, b
+
+
+@pytest.mark.parametrize("model,D,optname", [("bpr", 64, "sgd"), ("ucml", 128, "sgd"), ("bpr", 64, "adagrad")])
+def test_full_size_steps_match_the_c_oracle(model, D, optname):
+    from openrec_amd import runtime as rt
+    from oracle import c_oracle
+    NU = NI = 1_000_000
+    B, K = 65536, 3
+    U, V, b = _tables(NU, NI, D, 1)
+    rng = np.random.default_rng(2)
+    uid = rng.integers(0, NU, (K, B)).astype(np.int32); pid = rng.integers(0, NI, (K, B)).astype(np.int32)
+    nid = rng.integers(0, NI, (K, B)).astype(np.int32)
+    tU = rt.Table(NU, D).write(U); tV = rt.Table(NI, D).write(V); tb = rt.Table(NI, 1).write(b)
+    opt = rt.Optimizer.sgd(0.05) if optname == "sgd" else rt.Optimizer.adagrad(0.05)
+    U0, V0, b0 = U.copy(), V.copy(), b.copy()
+    loss, l2 = rt.pairwise_step(model, opt, tU, tV, tb, uid, pid, nid, K=K, B=B, margin=0.5)
+    cpu = c_oracle.PairwiseCPU(model, optname, U, V, b, lr=0.05)
+    for s in range(K):
+        lw, l2w = cpu.step(uid[s], pid[s], nid[s])
+        assert abs(loss[s] - lw) <= 1e-5 * abs(lw) and abs(l2[s] - l2w) <= 1e-5 * abs(l2w)
+    gU, gV, gb = tU.read(), tV.read(), tb.read()
+    for got, want in ((gU, U), (gV, V), (gb, b)):
+        assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+    # rows outside every id list keep their exact bits
+    untouched_u = np.ones(NU, bool); untouched_u[uid.reshape(-1)] = False
+    untouched_i = np.ones(NI, bool); untouched_i[pid.reshape(-1)] = False; untouched_i[nid.reshape(-1)] = False
+    assert untouched_u.sum() > 0.7 * NU and untouched_i.sum() > 0.5 * NI
+    assert np.array_equal(gU[untouched_u], U0[untouched_u]) and np.array_equal(gV[untouched_i], V0[untouched_i])
+    assert np.array_equal(gb[untouched_i], b0[untouched_i])
+    if model == "bpr" and optname == "sgd":
+        # d loss / d b_p = -d loss / d b_n for every triplet, and bias takes no l2: the SGD update of the table sums to 0
+        delta = (gb.astype(np.float64) - b0).sum()
+        assert abs(delta) <= 1e-4 * np.abs(gb.astype(np.float64) - b0).sum()
+
+
+def test_k_step_call_equals_single_step_calls_at_full_size():
+    """the K-step path (duplicate apply inside the next launch, ready-flag hand-off) and K one-step calls
+    (separate apply launches) must leave the same tables"""
+    from openrec_amd import runtime as rt
+    NU = NI = 1_000_000
+    B, K, D = 65536, 6, 64
+    rng = np.random.default_rng(5)
+    uid = rng.integers(0, NU, (K, B)).astype(np.int32); pid = rng.integers(0, NI, (K, B)).astype(np.int32)
+    nid = rng.integers(0, NI, (K, B)).astype(np.int32)
+    res = []
+    for split in (False, True):
+        tU = rt.Table(NU, D).init_uniform(seed=1); tV = rt.Table(NI, D).init_uniform(seed=2); tb = rt.Table(NI, 1).init_uniform(seed=3)
+        opt = rt.Optimizer.sgd(0.05)
+        if split:
+            ls = [rt.pairwise_step("bpr", opt, tU, tV, tb, uid[s], pid[s], nid[s], K=1, B=B)[0][0] for s in range(K)]
+        else:
+            ls = list(rt.pairwise_step("bpr", opt, tU, tV, tb, uid, pid, nid, K=K, B=B)[0])
+        res.append((tU.read(), tV.read(), tb.read(), np.array(ls)))
+    for a, c in zip(res[0][:3], res[1][:3]):
+        assert np.abs(a - c).max() <= 2e-7 * np.abs(c).max()          # only the fp32 order of >= 3-reference sums differs
+    assert np.allclose(res[0][3], res[1][3], rtol=1e-6)
