@@ -97,6 +97,7 @@ def bench_dlrm(args, torch, rt, world, rank, local_rank, device, dist):
     K, W, B = args.steps, args.warmup, args.batch
     cfg = dict(m_spa=128, ln_emb=CRITEO_KAGGLE_COUNTS, ln_bot=[512, 256, 128], ln_top=[1024, 1024, 512, 256, 1], dense_dim=13,
                reference_compat=False)
+    extra = {}
     g = torch.Generator(device=device); g.manual_seed(99 + rank)
     n = (K + W) * B
     dense = torch.log1p(torch.randint(0, 100, (n, 13), device=device, generator=g).float()).contiguous()
@@ -118,6 +119,20 @@ def bench_dlrm(args, torch, rt, world, rank, local_rank, device, dist):
         ctx.synchronize(); torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         par = "single-gpu"
+        # MLP products against the MFMA roofline: 3 products per Dense layer and step (forward, dX, dW;
+        # no dX for the first bottom layer), 2*B*in*out flops each; kernel time from dispatch-attached events
+        ctx.prof_reset(); ctx.prof_enable(True)
+        run(W, K)
+        ctx.prof_enable(False)
+        gp = ctx.prof_get().get("gemm", {})
+        dims = list(zip([13] + cfg["ln_bot"][:-1], cfg["ln_bot"])) + list(zip([128 + 27 * 26 // 2] + cfg["ln_top"][:-1], cfg["ln_top"]))
+        flops = sum(2.0 * B * i * o * (2 if k == 0 else 3) for k, (i, o) in enumerate(dims))
+        if gp.get("launches"):
+            tf = flops * K / (gp["total_ms"] * 1e-3) / 1e12
+            peak = 2500.0 if args.fp16_mlp else 157.3         # MI355X_MICROARCH.md: dense fp16 MFMA / fp32 (xf32-less) matrix peak, TFLOP/s
+            extra = {"roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel" if args.fp16_mlp else "gemm_f32_kernel", "achieved": tf,
+                                  "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+                                  "gemm_ms_per_step": gp["total_ms"] / K, "flops_per_step": flops}}
     else:
         from openrec_amd.sharded_dlrm import ShardedDLRM
         eng = ShardedDLRM(rank=rank, world=world, device=device, opt="sgd", lr=0.01, seed=0, fp16_mlp=args.fp16_mlp, **cfg)
@@ -144,6 +159,7 @@ def bench_dlrm(args, torch, rt, world, rank, local_rank, device, dist):
         par = f"embedding tables row-sharded x{world} (all-to-all), MLPs data-parallel (all-reduce)"
     if rank == 0:
         print(json.dumps({
+            **(extra if world == 1 and not args.sharded else {}),
             "metric": "DLRM training samples/sec (Criteo-Kaggle cardinalities, dim 128)", "value": K * B * world / dt,
             "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16 MFMA MLP products, f32 elsewhere" if args.fp16_mlp else "f32",

@@ -72,7 +72,8 @@ enum orx_kernel_id {
     ORX_K_CENSOR = 4,
     ORX_K_POINT = 5,      /* fused pointwise (GMF/WRMF) step                    */
     ORX_K_DUPAPPLY = 6,   /* optimizer apply of the duplicate rows of a step    */
-    ORX_K_NUM = 7
+    ORX_K_GEMM = 7,       /* DLRM MLP products (fp32 or fp16 MFMA)              */
+    ORX_K_NUM = 8
 };
 
 int orx_version(void);

@@ -18,9 +18,9 @@ ORX_IDS_DEVICE, ORX_HOGWILD, ORX_NO_L2, ORX_CENSOR = 1, 2, 4, 8
 ORX_DLRM_INTERACT_ITSELF, ORX_DLRM_SIGMOID_BOT, ORX_DLRM_SIGMOID_TOP, ORX_DLRM_LOSS_BCE, ORX_DLRM_REFERENCE_COMPAT = 1, 2, 4, 8, 16
 ORX_DLRM_FP16_MLP = 32
 ORX_DLRM_NO_EMB = 64
-ORX_K_DEDUP, ORX_K_FUSED, ORX_K_REDUCE, ORX_K_SWEEP, ORX_K_CENSOR, ORX_K_POINT, ORX_K_DUPAPPLY, ORX_K_NUM = 0, 1, 2, 3, 4, 5, 6, 7
+ORX_K_DEDUP, ORX_K_FUSED, ORX_K_REDUCE, ORX_K_SWEEP, ORX_K_CENSOR, ORX_K_POINT, ORX_K_DUPAPPLY, ORX_K_GEMM, ORX_K_NUM = 0, 1, 2, 3, 4, 5, 6, 7, 8
 KERNEL_NAMES = {ORX_K_DEDUP: "dedup", ORX_K_FUSED: "fused", ORX_K_REDUCE: "loss_reduce", ORX_K_SWEEP: "adam_sweep",
-                ORX_K_CENSOR: "censor", ORX_K_POINT: "pointwise", ORX_K_DUPAPPLY: "dup_apply"}
+                ORX_K_CENSOR: "censor", ORX_K_POINT: "pointwise", ORX_K_DUPAPPLY: "dup_apply", ORX_K_GEMM: "gemm"}
 
 _p = c_void_p
 _pp = POINTER(c_void_p)
@@ -109,6 +109,13 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m openrec_amd.build` "
             "(hipcc, gfx950).  openrec_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 and must be the one that gets
+    # loaded (the library resolves the same soname).  With the system runtime loaded first, a later
+    # `import torch` finds no usable device ("No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -124,6 +124,22 @@ struct TileLoader {
             }
         }
     }
+    // fp32 tile T[row][k] (exact-fp32 kernel)
+    __device__ __forceinline__ void storef(float* T, int LD) const {
+        const int t = threadIdx.x;
+        if (KC) {
+            const int r = t >> 1, kb = (t & 1) * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(T + r * LD + kb + 4 * q) = v[q];
+        } else {
+            const int rb = (t & 31) * 4, kb = (t >> 5) * 4;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 w; w.x = v[0][m]; w.y = v[1][m]; w.z = v[2][m]; w.w = v[3][m];
+                *reinterpret_cast<f32x4*>(T + (rb + m) * LD + kb) = w;
+            }
+        }
+    }
     __device__ __forceinline__ void store(_Float16* T, int LD) const {
         const int t = threadIdx.x;
         if (KC) {
@@ -205,9 +221,99 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int vec_a, in
             }
 }
 
+// Exact-fp32 product with the structure of gemm_f16_kernel: 128x128 block tile, 4 wavefronts x (4x4 tiles of
+// 16x16), K staged 32 at a time through registers into fp32 LDS tiles [row][k], v_mfma_f32_16x16x4_f32.
+// K order inside a staged tile: MFMA step s of lane group q = lane >> 4 multiplies physical column 8q + s,
+// for A and B alike, so every lane fetches its 8 operands of a row with two 16-byte LDS reads (the sum over
+// k is a permutation of the same terms).
+template <bool A_KC, bool B_NC>
+__global__ __launch_bounds__(256) void gemm_f32v_kernel(GemmArgs g, int vec_a, int vec_b) {
+    constexpr int BM = 128, BN = 128, BK = 32, LD = BK + 4;      // 144-byte rows: 16-B aligned, rotate over the banks
+    __shared__ __attribute__((aligned(16))) float As[BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[i][j].x = acc[i][j].y = acc[i][j].z = acc[i][j].w = 0.0f; }
+    TileLoader<A_KC> la;
+    TileLoader<!B_NC> lb;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    la.load(g.A, g.sa0, g.sa1, bm, g.M, kbeg, kend, vec_a != 0);
+    lb.load(g.B, g.sb1, g.sb0, bn, g.N, kbeg, kend, vec_b != 0);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        la.storef(As, LD);
+        lb.storef(Bs, LD);
+        __syncthreads();
+        if (k0 + BK < kend) {
+            la.load(g.A, g.sa0, g.sa1, bm, g.M, k0 + BK, kend, vec_a != 0);
+            lb.load(g.B, g.sb1, g.sb0, bn, g.N, k0 + BK, kend, vec_b != 0);
+        }
+        const int q8 = (lane >> 4) * 8;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                   // 4 of the 8 k-steps at a time (register pressure)
+            f32x4 a[4], b[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(&As[(wm + mi * 16 + (lane & 15)) * LD + q8 + 4 * half]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(&Bs[(wn + ni * 16 + (lane & 15)) * LD + q8 + 4 * half]);
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][st], b[ni][st], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = bm + wm + mi * 16 + (lane >> 4) * 4 + r;
+                const int col = bn + wn + ni * 16 + (lane & 15);
+                if (row < g.M && col < g.N) {
+                    float v = acc[mi][ni][r];
+                    if (gridDim.z > 1) { unsafeAtomicAdd(g.C + (int64_t)row * g.ldc + col, v); continue; }
+                    if (g.bias) v += g.bias[col];
+                    if (g.act == 1) v = fmaxf(v, 0.0f);
+                    else if (g.act == 2) v = 1.0f / (1.0f + __expf(-v));
+                    g.C[(int64_t)row * g.ldc + col] = v;
+                }
+            }
+}
+
+// grid, split-K factor and vectorization flags shared by the two 128x128 kernels
+static int gemm_plan(const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1, float* C, int64_t ldc,
+                     const float* bias, int M, int N, int K, int act, GemmArgs* g, dim3* grid, int* va, int* vb, bool* akc, bool* bnc) {
+    const int tiles = ((N + 127) / 128) * ((M + 127) / 128);
+    int splits = 1;
+    if (bias == nullptr && act == 0 && ldc == N && tiles < 256 && K >= 1024) {
+        splits = (512 + tiles - 1) / tiles;
+        if (splits > K / 256) splits = K / 256;
+        if (splits < 1) splits = 1;
+    }
+    g->kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
+    splits = (K + g->kchunk - 1) / g->kchunk;
+    *grid = dim3((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)splits);
+    *akc = sa1 == 1; *bnc = sb1 == 1;
+    // 16-byte loads need an aligned base and a leading stride that keeps every row aligned
+    *va = (((uintptr_t)A & 15) == 0) && ((*akc ? sa0 : sa1) % 4 == 0);
+    *vb = (((uintptr_t)B & 15) == 0) && ((*bnc ? sb0 : sb1) % 4 == 0);
+    return splits;
+}
+
 int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
                         float* C, int64_t ldc, const float* bias, int M, int N, int K, int act) {
     if (M == 0 || N == 0) return ORX_OK;
+    ProfScope ps(ctx, ORX_K_GEMM);
     GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0};
     // split-K when the output has too few tiles to fill the chip (the X^T*dY weight-gradient products:
     // small M x N, K = batch); partial tiles are combined with fp32 atomics into a zeroed output
@@ -238,7 +344,19 @@ int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, 
 int orx_launch_gemm(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
                     float* C, int64_t ldc, const float* bias, int M, int N, int K, int act) {
     if (M == 0 || N == 0) return ORX_OK;
+    ProfScope ps(ctx, ORX_K_GEMM);
     GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0};
+    if ((sa1 == 1 || sa0 == 1) && (sb1 == 1 || sb0 == 1) && getenv("ORX_GEMM_F32_SIMPLE") == nullptr) {
+        dim3 grid; int va, vb; bool akc, bnc;
+        const int splits = gemm_plan(A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, &g, &grid, &va, &vb, &akc, &bnc);
+        if (splits > 1) ORX_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * ldc, ctx->stream));
+        if (akc && bnc) ORX_LAUNCH(ctx, (gemm_f32v_kernel<true, true>), grid, dim3(256), 0, g, va, vb);
+        else if (akc) ORX_LAUNCH(ctx, (gemm_f32v_kernel<true, false>), grid, dim3(256), 0, g, va, vb);
+        else if (bnc) ORX_LAUNCH(ctx, (gemm_f32v_kernel<false, true>), grid, dim3(256), 0, g, va, vb);
+        else ORX_LAUNCH(ctx, (gemm_f32v_kernel<false, false>), grid, dim3(256), 0, g, va, vb);
+        ORX_HIP(hipGetLastError());
+        return ORX_OK;
+    }
     ORX_LAUNCH(ctx, gemm_f32_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0, g);
     ORX_HIP(hipGetLastError());
     return ORX_OK;

@@ -26,6 +26,7 @@ def test_sharded_world1_matches_oracle(model, optk, D):
     import torch
     from openrec_amd import sharded
     from oracle import numpy_oracle as orc
+    torch.cuda.init()                                   # in the main thread, before the rank threads touch the device
     dev = torch.device("cuda", 0)
     U, V, b, u, p, n = _case(3, 700, 900, 2051, D)
     eng = sharded.ShardedPairwise(model, optk, 700, 900, D, lr=0.05, rank=0, world=1, device=dev, slack=1.0)
@@ -49,6 +50,7 @@ def test_sharded_world1_matches_oracle(model, optk, D):
 def test_gather_rows_skips_padding_and_is_bit_exact():
     import torch
     from openrec_amd import runtime as rt, _ffi
+    torch.cuda.init()                                   # in the main thread, before the rank threads touch the device
     dev = torch.device("cuda", 0)
     ctx = rt.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
     rng = np.random.default_rng(0)
@@ -97,6 +99,7 @@ def test_virtual_cluster_matches_oracle(world, model, optk, fast):
     import torch
     from openrec_amd import sharded
     from oracle import numpy_oracle as orc
+    torch.cuda.init()                                   # in the main thread, before the rank threads touch the device
     dev = torch.device("cuda", 0)
     NU, NI, D, Bg = 1001, 1503, 64, 4096
     U, V, b, u, p, n = _case(7, NU, NI, Bg, D)

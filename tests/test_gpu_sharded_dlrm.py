@@ -66,6 +66,7 @@ def test_virtual_cluster_dlrm_matches_oracle(world, optk, compat, loss):
     from openrec_amd.sharded_dlrm import ShardedDLRM
     from oracle.dlrm_oracle import DLRMOracle
     from oracle import numpy_oracle as orc
+    torch.cuda.init()                                   # in the main thread, before the rank threads touch the device
     dev = torch.device("cuda", 0)
     Bg, steps = 512, 3
     kw = dict(reference_compat=compat, loss_func=loss)
