@@ -38,6 +38,9 @@ struct orx_dlrm {
     float *Z = nullptr, *dZ = nullptr, *R = nullptr;
     std::vector<float*> bot_y, top_y;   // outputs of every layer (bot last layer lives in Z)
     float *gA = nullptr, *gB = nullptr; // ping-pong gradient buffers [cap, maxwidth]
+    DenseParam* d_params = nullptr;     // descriptors of the dense parameters for the multi-tensor optimizer launch
+    orx_opt* params_opt = nullptr;
+    bool grads_pending = false;         // orx_dlrm_grads ran, orx_dlrm_dense_apply not yet
     double* d_loss = nullptr;           // [Kcap]
     int64_t loss_cap = 0;
     int maxw = 0;
@@ -111,7 +114,7 @@ extern "C" int orx_dlrm_destroy(orx_dlrm* m) {
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     free_buffers(m);
-    hipFree(m->d_offset); hipFree(m->d_rows); hipFree(m->d_loss);
+    hipFree(m->d_offset); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params);
     orx_table_destroy(m->emb);
     for (auto& d : m->bot) { orx_table_destroy(d.W); orx_table_destroy(d.b); }
     for (auto& d : m->top) { orx_table_destroy(d.W); orx_table_destroy(d.b); }
@@ -161,9 +164,9 @@ struct Batch { const float* dense; const int32_t* sparse; const float* label; };
 
 // MLP product: exact fp32 MFMA, or fp16 MFMA in the performance mode
 static int mlp_gemm(orx_dlrm* m, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
-                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act) {
-    if (m->flags & ORX_DLRM_FP16_MLP) return orx_launch_gemm_f16(m->ctx, A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act);
-    return orx_launch_gemm(m->ctx, A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act);
+                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero = false) {
+    if (m->flags & ORX_DLRM_FP16_MLP) return orx_launch_gemm_f16(m->ctx, A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, c_zero);
+    return orx_launch_gemm(m->ctx, A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, c_zero);
 }
 
 // forward of one batch; leaves every activation in the model's buffers.  emb_rows != NULL: the
@@ -201,6 +204,30 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
     return ORX_OK;
 }
 
+// SGD / Adagrad on every dense parameter in one launch (gradients in the tables' gsum)
+static int dense_apply_all(orx_dlrm* m, orx_opt* opt) {
+    orx_ctx* c = m->ctx;
+    std::vector<DenseParam> h;
+    int64_t max_n = 0;
+    auto add = [&](orx_table* t) -> int {
+        OptSlots s;
+        CHECK(orx_opt_slots(opt, t, &s));
+        CHECK(orx_table_scratch(t));
+        DenseParam p; p.w = t->w; p.acc = s.s0; p.g = t->gsum; p.n = t->rows * t->dim;
+        h.push_back(p); max_n = std::max(max_n, p.n);
+        return ORX_OK;
+    };
+    for (auto& D : m->bot) { CHECK(add(D.W)); CHECK(add(D.b)); }
+    for (auto& D : m->top) { CHECK(add(D.W)); CHECK(add(D.b)); }
+    if (m->d_params == nullptr || m->params_opt != opt) {       // pointers are stable: upload once per optimizer
+        if (!m->d_params) ORX_HIP(hipMalloc((void**)&m->d_params, h.size() * sizeof(DenseParam)));
+        ORX_HIP(hipMemcpyAsync(m->d_params, h.data(), h.size() * sizeof(DenseParam), hipMemcpyHostToDevice, c->stream));
+        ORX_HIP(hipStreamSynchronize(c->stream));
+        m->params_opt = opt;
+    }
+    return orx_launch_dense_apply_multi(c, m->d_params, (int)h.size(), max_n, opt->kind, opt->lr, opt->p1);
+}
+
 // dense optimizer rule on one parameter whose gradient sits in t->gsum
 static int dense_apply(orx_ctx* c, orx_opt* opt, orx_table* t, float lr_t) {
     OptSlots s;
@@ -217,11 +244,11 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
     orx_ctx* c = m->ctx;
     for (int l = (int)L.size() - 1; l >= 0; --l) {
         DenseLayer& D = L[l];
-        CHECK(orx_launch_act_bwd(c, dy, outs[l], ld_out[l], (int)B, D.out, D.act));
         CHECK(orx_table_scratch(D.W)); CHECK(orx_table_scratch(D.b));
-        // gW [in, out] = X^T * dZ ; gb = colsum(dZ)
-        CHECK(mlp_gemm(m, ins[l], 1, ld_in[l], dy, D.out, 1, D.W->gsum, D.out, nullptr, D.in, D.out, (int)B, 0));
-        CHECK(orx_launch_colsum(c, dy, (int)B, D.out, D.b->gsum));
+        // dZ = dY * act'(Y) and gb = colsum(dZ) in one pass; gW [in, out] = X^T * dZ.  Both gradient buffers are
+        // zero here (the optimizer kernels zero them behind themselves), so split-K / the slab sums just add.
+        CHECK(orx_launch_act_bwd_colsum(c, dy, outs[l], ld_out[l], (int)B, D.out, D.act, D.b->gsum));
+        CHECK(mlp_gemm(m, ins[l], 1, ld_in[l], dy, D.out, 1, D.W->gsum, D.out, nullptr, D.in, D.out, (int)B, 0, true));
         if (l > 0 || need_dx0) {
             // dX [B, in] = dZ * W^T
             CHECK(mlp_gemm(m, dy, D.out, 1, D.W->w, 1, D.out, other, ld_in[l], nullptr, (int)B, D.in, D.out, 0));
@@ -306,8 +333,12 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         }
         // sparse: per-occurrence rows dZ[b, f, :] onto the combined table (dense slot has id -1)
         CHECK(orx_apply_rows(c, opt, m->emb, nullptr, m->d_idx, B * F, m->dZ, d));
-        for (auto& D : m->bot) { CHECK(dense_apply(c, opt, D.W, lr_t)); CHECK(dense_apply(c, opt, D.b, lr_t)); }
-        for (auto& D : m->top) { CHECK(dense_apply(c, opt, D.W, lr_t)); CHECK(dense_apply(c, opt, D.b, lr_t)); }
+        if (opt->kind == ORX_ADAM) {
+            for (auto& D : m->bot) { CHECK(dense_apply(c, opt, D.W, lr_t)); CHECK(dense_apply(c, opt, D.b, lr_t)); }
+            for (auto& D : m->top) { CHECK(dense_apply(c, opt, D.W, lr_t)); CHECK(dense_apply(c, opt, D.b, lr_t)); }
+        } else {
+            CHECK(dense_apply_all(m, opt));
+        }
     }
     if (loss_out) {
         std::vector<double> h((size_t)K);
@@ -351,6 +382,7 @@ extern "C" int orx_dlrm_grads(orx_dlrm* m, const float* dense, const float* emb_
                               int64_t global_B, float* emb_grads, double* loss_accum) {
     ORX_ARG(m && dense && emb_rows && label && emb_grads && loss_accum, "orx_dlrm_grads: NULL argument");
     ORX_ARG(B > 0 && global_B >= B, "orx_dlrm_grads: need 0 < B <= global_B");
+    ORX_ARG(!m->grads_pending, "orx_dlrm_grads: the dense gradients of the previous call were not applied (orx_dlrm_dense_apply)");
     orx_ctx* c = m->ctx;
     ORX_HIP(hipSetDevice(c->device));
     CHECK(ensure_buffers(m, B));
@@ -359,6 +391,7 @@ extern "C" int orx_dlrm_grads(orx_dlrm* m, const float* dense, const float* emb_
     CHECK(orx_launch_dlrm_loss(c, m->top_y.back(), label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, loss_accum,
                                global_B, 1));
     CHECK(backward(m, bt, B));
+    m->grads_pending = true;
     const int d = m->m_spa;
     return orx_launch_copy2d(c, emb_grads, (int64_t)m->n_emb * d, m->dZ, (int64_t)m->F * d, (int)B, m->n_emb * d);
 }
@@ -401,7 +434,9 @@ extern "C" int orx_dlrm_dense_apply(orx_dlrm* m, orx_opt* opt, const float* flat
         const size_t n = (size_t)t->rows * t->dim;
         ORX_HIP(hipMemcpyAsync(t->gsum, flat, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
         flat += n;
-        CHECK(dense_apply(c, opt, t, lr_t));
+        if (opt->kind == ORX_ADAM) CHECK(dense_apply(c, opt, t, lr_t));
     }
+    if (opt->kind != ORX_ADAM) CHECK(dense_apply_all(m, opt));
+    m->grads_pending = false;
     return ORX_OK;
 }

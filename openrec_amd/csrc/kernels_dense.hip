@@ -311,7 +311,7 @@ static int gemm_plan(const float* A, int64_t sa0, int64_t sa1, const float* B, i
 }
 
 int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
-                        float* C, int64_t ldc, const float* bias, int M, int N, int K, int act) {
+                        float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero) {
     if (M == 0 || N == 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_GEMM);
     GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0};
@@ -326,7 +326,7 @@ int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, 
     }
     g.kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
     splits = (K + g.kchunk - 1) / g.kchunk;
-    if (splits > 1) ORX_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * ldc, ctx->stream));
+    if (splits > 1 && !c_zero) ORX_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * ldc, ctx->stream));
     const dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)splits);
     const bool akc = sa1 == 1, bnc = sb1 == 1;
     ORX_ARG((akc || sa0 == 1) && (bnc || sb0 == 1), "gemm_f16: every operand needs one unit stride");
@@ -342,14 +342,14 @@ int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, 
 }
 
 int orx_launch_gemm(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
-                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act) {
+                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero) {
     if (M == 0 || N == 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_GEMM);
     GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0};
     if ((sa1 == 1 || sa0 == 1) && (sb1 == 1 || sb0 == 1) && getenv("ORX_GEMM_F32_SIMPLE") == nullptr) {
         dim3 grid; int va, vb; bool akc, bnc;
         const int splits = gemm_plan(A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, &g, &grid, &va, &vb, &akc, &bnc);
-        if (splits > 1) ORX_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * ldc, ctx->stream));
+        if (splits > 1 && !c_zero) ORX_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * ldc, ctx->stream));
         if (akc && bnc) ORX_LAUNCH(ctx, (gemm_f32v_kernel<true, true>), grid, dim3(256), 0, g, va, vb);
         else if (akc) ORX_LAUNCH(ctx, (gemm_f32v_kernel<true, false>), grid, dim3(256), 0, g, va, vb);
         else if (bnc) ORX_LAUNCH(ctx, (gemm_f32v_kernel<false, true>), grid, dim3(256), 0, g, va, vb);
@@ -380,6 +380,36 @@ int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int
     if (act == 0 || M == 0) return ORX_OK;
     int64_t g = ((int64_t)M * N + 255) / 256; if (g > 8192) g = 8192;
     ORX_LAUNCH(ctx, act_bwd_kernel, dim3((unsigned)g), dim3(256), 0, dY, Y, ldy, M, N, act);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// dZ = dY * act'(Y) in place AND gb[c] += sum_r dZ[r, c] in the same pass (the bias gradient; gb must be zero:
+// the dense optimizer kernels leave every gradient buffer zeroed).  grid = (columns / 64, row slabs of 256).
+__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb) {
+    __shared__ float sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * 256, r1 = min(M, r0 + 256);
+    float s = 0.0f;
+    if (c < N) {
+        for (int r = r0 + part; r < r1; r += 4) {
+            const float y = Y[(int64_t)r * ldy + c];
+            float d = dY[(int64_t)r * N + c];
+            if (act == 1) d = y > 0.0f ? d : 0.0f;
+            else if (act == 2) d = d * y * (1.0f - y);
+            dY[(int64_t)r * N + c] = d;
+            s += d;
+        }
+    }
+    sh[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && c < N) unsafeAtomicAdd(gb + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb) {
+    if (M == 0 || N == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, act_bwd_colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 255) / 256)), dim3(256), 0, dY, Y, ldy, M, N, act, gb);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -593,6 +623,33 @@ int orx_launch_rows_accum(orx_ctx* ctx, float* G, const int32_t* ids, const floa
     if (n == 0) return ORX_OK;
     int64_t g = (n * D + 255) / 256; if (g > 65536) g = 65536;
     ORX_LAUNCH(ctx, rows_accum_kernel, dim3((unsigned)g), dim3(256), 0, G, ids, grads, g_stride, n, D, rows, ctx->d_err);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// ------------------------------------------------------- multi-tensor dense apply ---
+// The SGD / Adagrad rule of every dense parameter of a model in ONE launch (16 launches of a few microseconds
+// each otherwise): grid.y = parameter, grid.x covers the largest one.  Gradients are zeroed behind.
+__global__ __launch_bounds__(256) void dense_apply_multi_kernel(const DenseParam* ps, int optkind, float lr, float eps) {
+    const DenseParam p = ps[blockIdx.y];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
+        const float gi = p.g[i];
+        p.g[i] = 0.0f;
+        if (optkind == ORX_ADAGRAD) {
+            const float a2 = p.acc[i] + gi * gi;
+            p.acc[i] = a2;
+            p.w[i] = p.w[i] - lr * gi / (sqrtf(a2) + eps);
+        } else {
+            p.w[i] = p.w[i] - lr * gi;
+        }
+    }
+}
+
+int orx_launch_dense_apply_multi(orx_ctx* ctx, const DenseParam* ps_dev, int count, int64_t max_n, int optkind, float lr, float eps) {
+    if (count == 0) return ORX_OK;
+    int64_t gx = (max_n + 255) / 256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
+    ORX_LAUNCH(ctx, dense_apply_multi_kernel, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, ps_dev, optkind, lr, eps);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

@@ -282,9 +282,12 @@ int orx_launch_adam_sweep(orx_ctx* ctx, float* w, float* m, float* v, float* gsu
 
 // kernels_dense.hip (DLRM dense side)
 int orx_launch_gemm(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
-                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act);
+                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero = false);
 int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
-                        float* C, int64_t ldc, const float* bias, int M, int N, int K, int act);
+                        float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero = false);
+struct DenseParam { float* w; float* acc; float* g; int64_t n; };
+int orx_launch_dense_apply_multi(orx_ctx* ctx, const DenseParam* ps_dev, int count, int64_t max_n, int optkind, float lr, float eps);
+int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb);
 int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act);
 int orx_launch_colsum(orx_ctx* ctx, const float* X, int M, int N, float* out);
 int orx_launch_copy2d(orx_ctx* ctx, float* dst, int64_t ldd, const float* src, int64_t lds_, int M, int N);
