@@ -38,6 +38,9 @@ struct orx_dlrm {
     float *Z = nullptr, *dZ = nullptr, *R = nullptr;
     std::vector<float*> bot_y, top_y;   // outputs of every layer (bot last layer lives in Z)
     float *gA = nullptr, *gB = nullptr; // ping-pong gradient buffers [cap, maxwidth]
+    // tables of <= TINY_ROWS rows: SGD gradient sums through LDS (dlrm_tiny_apply_kernel)
+    std::vector<int> tiny_f; int tiny_max_rows = 0;
+    int* d_tiny_f = nullptr; unsigned char* d_is_tiny = nullptr; int32_t* d_idx_big = nullptr;
     DenseParam* d_params = nullptr;     // descriptors of the dense parameters for the multi-tensor optimizer launch
     orx_opt* params_opt = nullptr;
     bool grads_pending = false;         // orx_dlrm_grads ran, orx_dlrm_dense_apply not yet
@@ -85,6 +88,20 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
     ORX_HIP(hipMalloc((void**)&m->d_rows, sizeof(int64_t) * n_emb));
     ORX_HIP(hipMemcpy(m->d_offset, m->offset.data(), sizeof(int64_t) * n_emb, hipMemcpyHostToDevice));
     ORX_HIP(hipMemcpy(m->d_rows, m->ln_emb.data(), sizeof(int64_t) * n_emb, hipMemcpyHostToDevice));
+    {   // tiny tables (LDS must hold rows * m_spa floats)
+        const int TINY_ROWS = 64;
+        std::vector<unsigned char> is_tiny((size_t)n_emb + 1, 0);
+        for (int f = 0; f < n_emb; ++f)
+            if (ln_emb[f] <= TINY_ROWS && ln_emb[f] * (int64_t)m_spa * 4 <= 48 * 1024 && m_spa <= 256) {
+                m->tiny_f.push_back(f); is_tiny[f] = 1; m->tiny_max_rows = std::max(m->tiny_max_rows, (int)ln_emb[f]);
+            }
+        if (!m->tiny_f.empty()) {
+            ORX_HIP(hipMalloc((void**)&m->d_tiny_f, m->tiny_f.size() * sizeof(int)));
+            ORX_HIP(hipMemcpy(m->d_tiny_f, m->tiny_f.data(), m->tiny_f.size() * sizeof(int), hipMemcpyHostToDevice));
+            ORX_HIP(hipMalloc((void**)&m->d_is_tiny, is_tiny.size()));
+            ORX_HIP(hipMemcpy(m->d_is_tiny, is_tiny.data(), is_tiny.size(), hipMemcpyHostToDevice));
+        }
+    }
     m->F = n_emb + 1;
     const bool itself = flags & ORX_DLRM_INTERACT_ITSELF;
     m->P = itself ? m->F * (m->F + 1) / 2 : m->F * (m->F - 1) / 2;
@@ -99,7 +116,7 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
 }
 
 static void free_buffers(orx_dlrm* m) {
-    hipFree(m->d_dense); hipFree(m->d_label); hipFree(m->d_sparse); hipFree(m->d_idx);
+    hipFree(m->d_dense); hipFree(m->d_label); hipFree(m->d_sparse); hipFree(m->d_idx); hipFree(m->d_idx_big); m->d_idx_big = nullptr;
     hipFree(m->Z); hipFree(m->dZ); hipFree(m->R); hipFree(m->gA); hipFree(m->gB);
     for (float* p : m->bot_y) hipFree(p);
     for (float* p : m->top_y) hipFree(p);
@@ -114,7 +131,7 @@ extern "C" int orx_dlrm_destroy(orx_dlrm* m) {
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     free_buffers(m);
-    hipFree(m->d_offset); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params);
+    hipFree(m->d_offset); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params); hipFree(m->d_tiny_f); hipFree(m->d_is_tiny);
     orx_table_destroy(m->emb);
     for (auto& d : m->bot) { orx_table_destroy(d.W); orx_table_destroy(d.b); }
     for (auto& d : m->top) { orx_table_destroy(d.W); orx_table_destroy(d.b); }
@@ -144,6 +161,7 @@ static int ensure_buffers(orx_dlrm* m, int64_t B) {
     ORX_HIP(hipMalloc((void**)&m->d_label, sizeof(float) * B));
     ORX_HIP(hipMalloc((void**)&m->d_sparse, sizeof(int32_t) * B * m->n_emb));
     ORX_HIP(hipMalloc((void**)&m->d_idx, sizeof(int32_t) * B * F));
+    ORX_HIP(hipMalloc((void**)&m->d_idx_big, sizeof(int32_t) * B * F));
     ORX_HIP(hipMalloc((void**)&m->Z, sizeof(float) * B * F * d));
     ORX_HIP(hipMalloc((void**)&m->dZ, sizeof(float) * B * F * d));
     ORX_HIP(hipMalloc((void**)&m->R, sizeof(float) * B * m->ldR));
@@ -332,7 +350,15 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
             lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, (double)opt->t)) / (1.0 - std::pow(b1, (double)opt->t)));
         }
         // sparse: per-occurrence rows dZ[b, f, :] onto the combined table (dense slot has id -1)
-        CHECK(orx_apply_rows(c, opt, m->emb, nullptr, m->d_idx, B * F, m->dZ, d));
+        if (opt->kind == ORX_SGD && !m->tiny_f.empty()) {
+            // tiny tables: per-slab LDS sums; the generic scatter then skips their slots
+            CHECK(orx_launch_dlrm_tiny_apply(c, m->d_idx, m->dZ, m->d_tiny_f, (int)m->tiny_f.size(), m->tiny_max_rows, m->d_offset,
+                                             m->d_rows, F, d, B, opt->lr, m->emb->w));
+            CHECK(orx_launch_dlrm_mask_tiny(c, m->d_idx, m->d_is_tiny, F, B * F, m->d_idx_big));
+            CHECK(orx_apply_rows(c, opt, m->emb, nullptr, m->d_idx_big, B * F, m->dZ, d));
+        } else {
+            CHECK(orx_apply_rows(c, opt, m->emb, nullptr, m->d_idx, B * F, m->dZ, d));
+        }
         if (opt->kind == ORX_ADAM) {
             for (auto& D : m->bot) { CHECK(dense_apply(c, opt, D.W, lr_t)); CHECK(dense_apply(c, opt, D.b, lr_t)); }
             for (auto& D : m->top) { CHECK(dense_apply(c, opt, D.W, lr_t)); CHECK(dense_apply(c, opt, D.b, lr_t)); }

@@ -653,3 +653,68 @@ int orx_launch_dense_apply_multi(orx_ctx* ctx, const DenseParam* ps_dev, int cou
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
+
+// ------------------------------------------------- tiny embedding tables (SGD) ---
+// Criteo has tables of 3 .. 27 rows: a batch of 8192 samples puts thousands of gradient rows on each of
+// their rows, and fp32 atomics on one address serialize (~60-100 ns each).  One block per (tiny table, slab
+// of samples) sums its slab into an LDS copy of the table's gradient ([rows][d], LDS atomics), then adds
+// -lr * sum to the table with rows*d global atomics.  Exact scatter_add semantics (only the fp32 summation
+// order differs).  apply_rows sees these slots as padding (idx_big = -1).
+__global__ __launch_bounds__(256) void dlrm_tiny_apply_kernel(const int32_t* idx, const float* dZ, const int* tiny_f, const int64_t* offset,
+                                                              const int64_t* rows, int F, int d, int64_t B, int slab, float lr, float* W) {
+    extern __shared__ float acc[];                       // [R][d]
+    const int f = tiny_f[blockIdx.x];
+    const int R = (int)rows[f];
+    const int64_t off = offset[f];
+    for (int i = threadIdx.x; i < R * d; i += blockDim.x) acc[i] = 0.0f;
+    __syncthreads();
+    const int64_t b0 = (int64_t)blockIdx.y * slab, b1 = min(B, b0 + slab);
+    const int per = blockDim.x / d > 0 ? blockDim.x / d : 1;   // samples handled concurrently (d <= 256)
+    const int e = threadIdx.x % d, sub = threadIdx.x / d;
+    if (sub < per) {
+        // four samples in flight per thread: the loop is otherwise bound by one global-load latency per sample
+        for (int64_t bb = b0 + sub; bb < b1; bb += 4 * per) {
+            int r[4]; float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t x = bb + (int64_t)k * per;
+                r[k] = x < b1 ? idx[x * F + f] : -1;
+                v[k] = r[k] >= 0 ? dZ[(x * F + f) * d + e] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (r[k] >= 0) atomicAdd(&acc[(int)(r[k] - off) * d + e], v[k]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * d; i += blockDim.x) {
+        const float v = acc[i];
+        if (v != 0.0f) unsafeAtomicAdd(W + off * d + i, -lr * v);
+    }
+}
+
+int orx_launch_dlrm_tiny_apply(orx_ctx* ctx, const int32_t* idx, const float* dZ, const int* tiny_f_dev, int n_tiny, int max_rows,
+                               const int64_t* offset, const int64_t* rows, int F, int d, int64_t B, float lr, float* W) {
+    if (n_tiny == 0 || B == 0) return ORX_OK;
+    const int slab = 64;
+    ORX_LAUNCH(ctx, dlrm_tiny_apply_kernel, dim3((unsigned)n_tiny, (unsigned)((B + slab - 1) / slab)), dim3(256),
+               (size_t)max_rows * d * sizeof(float), idx, dZ, tiny_f_dev, offset, rows, F, d, B, slab, lr, W);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// idx_big[i] = idx[i] unless slot i belongs to a tiny table (then -1)
+__global__ void dlrm_mask_tiny_kernel(const int32_t* idx, const unsigned char* is_tiny, int F, int64_t total, int32_t* out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int f = (int)(i % F);
+        out[i] = is_tiny[f] ? -1 : idx[i];
+    }
+}
+
+int orx_launch_dlrm_mask_tiny(orx_ctx* ctx, const int32_t* idx, const unsigned char* is_tiny_dev, int F, int64_t total, int32_t* out) {
+    int64_t g = (total + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1;
+    ORX_LAUNCH(ctx, dlrm_mask_tiny_kernel, dim3((unsigned)g), dim3(256), 0, idx, is_tiny_dev, F, total, out);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}

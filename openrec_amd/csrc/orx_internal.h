@@ -295,6 +295,9 @@ int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR,
                         float* out, int P, int64_t B, int ldR);
 int orx_launch_dlrm_loss(orx_ctx* ctx, float* P, const float* y, int64_t B, int bce, float thr, float* dP, double* loss_out,
                          int64_t n_mean = 0, int accumulate = 0);
+int orx_launch_dlrm_tiny_apply(orx_ctx* ctx, const int32_t* idx, const float* dZ, const int* tiny_f_dev, int n_tiny, int max_rows,
+                               const int64_t* offset, const int64_t* rows, int F, int d, int64_t B, float lr, float* W);
+int orx_launch_dlrm_mask_tiny(orx_ctx* ctx, const int32_t* idx, const unsigned char* is_tiny_dev, int F, int64_t total, int32_t* out);
 int orx_launch_dlrm_ids(orx_ctx* ctx, const int32_t* sparse, const int64_t* offset, const int64_t* rows, int nf, int64_t B,
                         int32_t* idx);
 int orx_launch_rows_accum(orx_ctx* ctx, float* G, const int32_t* ids, const float* grads, int64_t g_stride, int64_t n, int D, int64_t rows);
