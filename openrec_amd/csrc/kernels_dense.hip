@@ -520,9 +520,99 @@ __global__ __launch_bounds__(256) void interact_bwd_kernel(const float* Z, const
     }
 }
 
+// ---- MFMA versions (compat = 0, F <= 32, d % 32 == 0): one wavefront per sample, exact fp32 --------------
+// forward: G = Z Z^T on the lower triangle of 16x16 tiles (v_mfma_f32_16x16x4_f32; the B operand of tile
+// (ti, tj) is the A operand of row tile tj: both are "lane (i, q) holds Z[16 t + i][k]").  K order inside a
+// 32-wide block: step s of lane group q multiplies column 8q + s (two 16-byte loads per row and block).
+__global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(const float* Z, int F, int d, int itself, float* R, int64_t B, int ldR) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int i = lane & 15, q = lane >> 4;
+    const float* zb = Z + b * F * d;
+    f32x4 a00, a10, a11;
+    a00.x = a00.y = a00.z = a00.w = 0.0f; a10 = a00; a11 = a00;
+    for (int kb = 0; kb < d; kb += 32) {
+        f32x4 t0[2], t1[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 z; z.x = z.y = z.z = z.w = 0.0f;
+            t0[h] = i < F ? *reinterpret_cast<const f32x4*>(zb + (int64_t)i * d + kb + 8 * q + 4 * h) : z;
+            t1[h] = 16 + i < F ? *reinterpret_cast<const f32x4*>(zb + (int64_t)(16 + i) * d + kb + 8 * q + 4 * h) : z;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                a00 = __builtin_amdgcn_mfma_f32_16x16x4f32(t0[h][st], t0[h][st], a00, 0, 0, 0);
+                a10 = __builtin_amdgcn_mfma_f32_16x16x4f32(t1[h][st], t0[h][st], a10, 0, 0, 0);
+                a11 = __builtin_amdgcn_mfma_f32_16x16x4f32(t1[h][st], t1[h][st], a11, 0, 0, 0);
+            }
+    }
+    float* rb = R + b * ldR;
+    for (int k = lane; k < d; k += 64) rb[k] = zb[(int64_t)(F - 1) * d + k];
+    auto emit = [&](const f32x4& acc, int r0, int c0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gi = r0 + q * 4 + r, gj = c0 + i;
+            if (gi < F && (itself ? gj <= gi : gj < gi)) rb[d + (itself ? gi * (gi + 1) / 2 + gj : gi * (gi - 1) / 2 + gj)] = acc[r];
+        }
+    };
+    emit(a00, 0, 0); emit(a10, 16, 0); emit(a11, 16, 16);
+}
+
+// backward: dZ = (Gs + Gs^T) Z (+ dR[0:d] on the dense slot), Gs = the pair gradients scattered back to [F][F].
+// A operand: lane (i, q) holds S[16 ti + i][4 s + q], built straight from dR; B operand: Z[4 s + q][16 tj + j].
+__global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(const float* Z, const float* dR, int F, int d, int itself, float* dZ,
+                                                                int64_t B, int ldR) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int i = lane & 15, q = lane >> 4;
+    const float* zb = Z + b * F * d;
+    const float* rb = dR + b * ldR;
+    auto sval = [&](int r, int c) -> float {             // (Gs + Gs^T)[r][c]
+        if (r >= F || c >= F) return 0.0f;
+        if (r == c) return itself ? 2.0f * rb[d + r * (r + 1) / 2 + r] : 0.0f;
+        const int hi = r > c ? r : c, lo = r > c ? c : r;
+        return rb[d + (itself ? hi * (hi + 1) / 2 + lo : hi * (hi - 1) / 2 + lo)];
+    };
+    float sa[2][8];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) sa[ti][s] = sval(16 * ti + i, 4 * s + q);
+    for (int tj = 0; tj < d / 16; ++tj) {
+        f32x4 acc0, acc1;
+        acc0.x = acc0.y = acc0.z = acc0.w = 0.0f; acc1 = acc0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = 4 * s + q;
+            const float zv = k < F ? zb[(int64_t)k * d + 16 * tj + i] : 0.0f;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][s], zv, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][s], zv, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = 16 * tj + i;
+            const int g0 = q * 4 + r, g1 = 16 + q * 4 + r;
+            if (g0 < F) dZ[(b * F + g0) * d + col] = acc0[r] + (g0 == F - 1 ? rb[col] : 0.0f);
+            if (g1 < F) dZ[(b * F + g1) * d + col] = acc1[r] + (g1 == F - 1 ? rb[col] : 0.0f);
+        }
+    }
+}
+
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
                         float* out, int P, int64_t B, int ldR) {
     if (B == 0) return ORX_OK;
+    const bool mfma = !compat && F <= 32 && d % 32 == 0 && ldR % 1 == 0 && ((uintptr_t)Z & 15) == 0 && getenv("ORX_INTERACT_SIMPLE") == nullptr;
+    if (mfma) {
+        const dim3 g((unsigned)((B + 3) / 4));
+        if (fwd) ORX_LAUNCH(ctx, interact_fwd_mfma_kernel, g, dim3(256), 0, Z, F, d, itself, out, B, ldR);
+        else ORX_LAUNCH(ctx, interact_bwd_mfma_kernel, g, dim3(256), 0, Z, dR, F, d, itself, out, B, ldR);
+        ORX_HIP(hipGetLastError());
+        return ORX_OK;
+    }
     if (fwd) ORX_LAUNCH(ctx, interact_fwd_kernel, dim3((unsigned)B), dim3(256), (size_t)F * (d + 1) * sizeof(float), Z, F, d, compat, itself, out, P, B, ldR);
     else ORX_LAUNCH(ctx, interact_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(F * (d + 1) + F * F) * sizeof(float), Z, dR, F, d, compat, itself, out, P, B, ldR);
     ORX_HIP(hipGetLastError());

@@ -141,3 +141,41 @@ def test_dlrm_fp16_mlp_mode_tracks_the_fp32_oracle():
                           ("emb", m.param("emb").read(), np.concatenate(o.emb))):
         du, dr = dev - before[key], ref - before[key]
         assert np.abs(du - dr).max() < 0.03 * np.abs(dr).max() + 1e-7, key
+
+
+@pytest.mark.parametrize("m_spa,n_emb,itself,optname", [(32, 26, False, "sgd"), (64, 5, True, "sgd"), (128, 26, False, "adagrad"),
+                                                        (32, 31, True, "sgd"), (64, 16, False, "sgd")])
+def test_dlrm_wide_embeddings_mfma_interaction(m_spa, n_emb, itself, optname):
+    """dim 32 / 64 / 128 with up to 32 feature slots: the feature interaction runs on the MFMA kernels
+    (interact_*_mfma_kernel; 16 feature slots = exactly one row tile, 32 = the maximum), the MLP products on the
+    128x128 fp32 MFMA kernel; tiny tables (<= 64 rows) take the LDS gradient path with SGD."""
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    from oracle.dlrm_oracle import DLRMOracle
+    rng = np.random.default_rng(4)
+    ln_emb = [int(x) for x in rng.integers(3, 3000, n_emb)]
+    ln_emb[0], ln_emb[-1] = 3, 40
+    P = (n_emb + 1) * (n_emb + 2) // 2 if itself else (n_emb + 1) * n_emb // 2
+    cfg = dict(m_spa=m_spa, ln_emb=ln_emb, ln_bot=[48, m_spa], ln_top=[96, 32, 1], dense_dim=13, arch_interaction_itself=itself)
+    o = DLRMOracle(dtype=np.float32, seed=3, reference_compat=False, loss_func="bce", **cfg)
+    m = rt.DLRMModel(reference_compat=False, loss_func="bce", **cfg)
+    assert o.top[0][0].shape[0] == m_spa + P
+    m.param("emb").write(np.concatenate(o.emb))
+    for nm, layers in (("bot", o.bot), ("top", o.top)):
+        for l, (W, b) in enumerate(layers):
+            m.param(nm + "_w", l).write(W); m.param(nm + "_b", l).write(b.reshape(1, -1))
+    B = 777
+    dense = np.log1p(rng.integers(0, 100, (B, 13))).astype(np.float32)
+    sparse = np.stack([rng.integers(0, n, B) for n in ln_emb], 1).astype(np.int32)
+    label = (rng.uniform(size=B) < 0.25).astype(np.float32)
+    assert rel_err(m.inference(dense, sparse), o.inference(dense, sparse)) < 1e-5
+    opt, oo = ((rt.Optimizer.sgd(0.05), orc.SGD(0.05)) if optname == "sgd" else (rt.Optimizer.adagrad(0.05, 0.1, 1e-7), orc.Adagrad(0.05, 0.1, 1e-7)))
+    for s in range(3):
+        l = m.step(opt, dense, sparse, label)[0]
+        lr = o.step(dense, sparse, label, oo)
+        assert abs(l - lr) <= 2e-5 * abs(lr)
+    assert rel_err(m.param("emb").read(), np.concatenate(o.emb)) < 5e-5
+    for nm, layers in (("bot", o.bot), ("top", o.top)):
+        for l, (W, b) in enumerate(layers):
+            assert rel_err(m.param(nm + "_w", l).read(), W) < 5e-5, (nm, l)
+            assert rel_err(m.param(nm + "_b", l).read().reshape(-1), b) < 5e-5, (nm, l)
