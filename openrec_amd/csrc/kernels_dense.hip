@@ -562,9 +562,13 @@ __global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(const float* Z, 
 }
 
 // backward: dZ = (Gs + Gs^T) Z (+ dR[0:d] on the dense slot), Gs = the pair gradients scattered back to [F][F].
-// A operand: lane (i, q) holds S[16 ti + i][4 s + q], built straight from dR; B operand: Z[4 s + q][16 tj + j].
-__global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(const float* Z, const float* dR, int F, int d, int itself, float* dZ,
+// A operand: lane (i, q) holds S[16 ti + i][4 s + q], built straight from dR.  B operand: lane (j, q) owns the
+// CPL = d/16 consecutive columns CPL*j .. CPL*j + CPL-1 of Z row 4 s + q (float4 loads); column tile t of the
+// MFMA grid is {CPL*j + t}, so every lane ends up with CPL consecutive columns of its output rows (float4 stores).
+template <int CPL>
+__global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(const float* Z, const float* dR, int F, int itself, float* dZ,
                                                                 int64_t B, int ldR) {
+    constexpr int d = 16 * CPL;
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -582,34 +586,57 @@ __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(const float* Z, 
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int s = 0; s < 8; ++s) sa[ti][s] = sval(16 * ti + i, 4 * s + q);
-    for (int tj = 0; tj < d / 16; ++tj) {
-        f32x4 acc0, acc1;
-        acc0.x = acc0.y = acc0.z = acc0.w = 0.0f; acc1 = acc0;
+    float zr[8][CPL];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int k = 4 * s + q;
-            const float zv = k < F ? zb[(int64_t)k * d + 16 * tj + i] : 0.0f;
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][s], zv, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][s], zv, acc1, 0, 0, 0);
-        }
+    for (int s = 0; s < 8; ++s) {
+        const int k = 4 * s + q;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col = 16 * tj + i;
-            const int g0 = q * 4 + r, g1 = 16 + q * 4 + r;
-            if (g0 < F) dZ[(b * F + g0) * d + col] = acc0[r] + (g0 == F - 1 ? rb[col] : 0.0f);
-            if (g1 < F) dZ[(b * F + g1) * d + col] = acc1[r] + (g1 == F - 1 ? rb[col] : 0.0f);
+        for (int c4 = 0; c4 < CPL; c4 += 4) {
+            f32x4 v; v.x = v.y = v.z = v.w = 0.0f;
+            if (k < F) {
+                if (CPL >= 4) v = *reinterpret_cast<const f32x4*>(zb + (int64_t)k * d + CPL * i + c4);
+                else { v.x = zb[(int64_t)k * d + CPL * i]; v.y = zb[(int64_t)k * d + CPL * i + 1]; }
+            }
+            zr[s][c4] = v.x; if (c4 + 1 < CPL) zr[s][c4 + 1] = v.y;
+            if (c4 + 2 < CPL) zr[s][c4 + 2] = v.z; if (c4 + 3 < CPL) zr[s][c4 + 3] = v.w;
         }
     }
+    f32x4 acc[2][CPL];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) { acc[ti][t].x = acc[ti][t].y = acc[ti][t].z = acc[ti][t].w = 0.0f; }
+#pragma unroll
+    for (int t = 0; t < CPL; ++t)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][s], zr[s][t], acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][s], zr[s][t], acc[1][t], 0, 0, 0);
+        }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int g = 16 * ti + q * 4 + r;
+            if (g >= F) continue;
+            float* out = dZ + (b * F + g) * d + CPL * i;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) out[t] = acc[ti][t][r] + (g == F - 1 ? rb[CPL * i + t] : 0.0f);
+        }
 }
 
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
                         float* out, int P, int64_t B, int ldR) {
     if (B == 0) return ORX_OK;
-    const bool mfma = !compat && F <= 32 && d % 32 == 0 && ldR % 1 == 0 && ((uintptr_t)Z & 15) == 0 && getenv("ORX_INTERACT_SIMPLE") == nullptr;
-    if (mfma) {
+    const bool mfma = !compat && F <= 32 && d % 32 == 0 && ((uintptr_t)Z & 15) == 0 && getenv("ORX_INTERACT_SIMPLE") == nullptr;
+    const bool bwd_ok = d == 32 || d == 64 || d == 128 || d == 256;
+    if (mfma && (fwd || bwd_ok)) {
         const dim3 g((unsigned)((B + 3) / 4));
         if (fwd) ORX_LAUNCH(ctx, interact_fwd_mfma_kernel, g, dim3(256), 0, Z, F, d, itself, out, B, ldR);
-        else ORX_LAUNCH(ctx, interact_bwd_mfma_kernel, g, dim3(256), 0, Z, dR, F, d, itself, out, B, ldR);
+        else if (d == 32) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<2>), g, dim3(256), 0, Z, dR, F, itself, out, B, ldR);
+        else if (d == 64) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4>), g, dim3(256), 0, Z, dR, F, itself, out, B, ldR);
+        else if (d == 128) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8>), g, dim3(256), 0, Z, dR, F, itself, out, B, ldR);
+        else ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<16>), g, dim3(256), 0, Z, dR, F, itself, out, B, ldR);
         ORX_HIP(hipGetLastError());
         return ORX_OK;
     }
