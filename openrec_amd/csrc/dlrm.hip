@@ -18,7 +18,12 @@ struct DenseLayer {
     int in = 0, out = 0, act = 0;       // act: 1 relu, 2 sigmoid
     orx_table* W = nullptr;             // [in, out]
     orx_table* b = nullptr;             // [1, out]
+    // fp16 copies of W for ORX_DLRM_FP16_MLP: w16 [in][ld16] (operand of dY*W^T), w16t [out][ld16t] (operand of X*W)
+    void* w16 = nullptr; void* w16t = nullptr;
+    int ld16 = 0, ld16t = 0;
 };
+
+static inline int up8(int x) { return (x + 7) & ~7; }
 
 struct orx_dlrm {
     orx_ctx* ctx = nullptr;
@@ -41,6 +46,11 @@ struct orx_dlrm {
     // tables of <= TINY_ROWS rows: SGD gradient sums through LDS (dlrm_tiny_apply_kernel)
     std::vector<int> tiny_f; int tiny_max_rows = 0;
     int* d_tiny_f = nullptr; unsigned char* d_is_tiny = nullptr; int32_t* d_idx_big = nullptr;
+    // fp16 copies of the activations that feed MLP products (ORX_DLRM_FP16_MLP)
+    void* R16 = nullptr; int ldR16 = 0;
+    std::vector<void*> top_y16;         // output of top layer l (l < last), [cap][up8(out)]
+    void* g16 = nullptr;                // dY after the activation backward, [cap][up8(maxw)]
+    ShadowParam* d_shadow = nullptr; int n_shadow = 0; int64_t shadow_max = 0;
     DenseParam* d_params = nullptr;     // descriptors of the dense parameters for the multi-tensor optimizer launch
     orx_opt* params_opt = nullptr;
     bool grads_pending = false;         // orx_dlrm_grads ran, orx_dlrm_dense_apply not yet
@@ -107,6 +117,21 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
     m->P = itself ? m->F * (m->F + 1) / 2 : m->F * (m->F - 1) / 2;
     CHECK(make_layers(ctx, m->bot, dense_dim, n_bot, ln_bot, (flags & ORX_DLRM_SIGMOID_BOT) ? 2 : 1, seed + 7));
     CHECK(make_layers(ctx, m->top, m_spa + m->P, n_top, ln_top, (flags & ORX_DLRM_SIGMOID_TOP) ? 2 : 1, seed + 13));
+    if (flags & ORX_DLRM_FP16_MLP) {
+        std::vector<ShadowParam> sp;
+        auto add = [&](DenseLayer& D) -> int {
+            D.ld16 = up8(D.out); D.ld16t = up8(D.in);
+            ORX_HIP(hipMalloc(&D.w16, (size_t)D.in * D.ld16 * 2)); ORX_HIP(hipMemset(D.w16, 0, (size_t)D.in * D.ld16 * 2));
+            ORX_HIP(hipMalloc(&D.w16t, (size_t)D.out * D.ld16t * 2)); ORX_HIP(hipMemset(D.w16t, 0, (size_t)D.out * D.ld16t * 2));
+            ShadowParam p; p.w = D.W->w; p.w16 = D.w16; p.w16t = D.w16t; p.in = D.in; p.out = D.out; p.ld16 = D.ld16; p.ld16t = D.ld16t;
+            sp.push_back(p); m->shadow_max = std::max<int64_t>(m->shadow_max, (int64_t)D.in * D.out);
+            return ORX_OK;
+        };
+        for (auto& D : m->top) CHECK(add(D));           // the bottom MLP is tiny and starts from fp32 input: fp32 operands
+        m->n_shadow = (int)sp.size();
+        ORX_HIP(hipMalloc((void**)&m->d_shadow, sp.size() * sizeof(ShadowParam)));
+        ORX_HIP(hipMemcpy(m->d_shadow, sp.data(), sp.size() * sizeof(ShadowParam), hipMemcpyHostToDevice));
+    }
     m->ldR = (m_spa + m->P + 3) & ~3;
     m->maxw = m->ldR;
     for (auto& d : m->bot) m->maxw = std::max(m->maxw, std::max(d.in, d.out));
@@ -116,6 +141,9 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
 }
 
 static void free_buffers(orx_dlrm* m) {
+    hipFree(m->R16); hipFree(m->g16); m->R16 = m->g16 = nullptr;
+    for (void* p : m->top_y16) hipFree(p);
+    m->top_y16.clear();
     hipFree(m->d_dense); hipFree(m->d_label); hipFree(m->d_sparse); hipFree(m->d_idx); hipFree(m->d_idx_big); m->d_idx_big = nullptr;
     hipFree(m->Z); hipFree(m->dZ); hipFree(m->R); hipFree(m->gA); hipFree(m->gB);
     for (float* p : m->bot_y) hipFree(p);
@@ -134,7 +162,8 @@ extern "C" int orx_dlrm_destroy(orx_dlrm* m) {
     hipFree(m->d_offset); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params); hipFree(m->d_tiny_f); hipFree(m->d_is_tiny);
     orx_table_destroy(m->emb);
     for (auto& d : m->bot) { orx_table_destroy(d.W); orx_table_destroy(d.b); }
-    for (auto& d : m->top) { orx_table_destroy(d.W); orx_table_destroy(d.b); }
+    for (auto& d : m->top) { orx_table_destroy(d.W); orx_table_destroy(d.b); hipFree(d.w16); hipFree(d.w16t); }
+    hipFree(m->d_shadow);
     delete m;
     return ORX_OK;
 }
@@ -174,6 +203,16 @@ static int ensure_buffers(orx_dlrm* m, int64_t B) {
     for (size_t l = 0; l < m->top.size(); ++l) {
         float* p; ORX_HIP(hipMalloc((void**)&p, sizeof(float) * B * m->top[l].out)); m->top_y.push_back(p);
     }
+    if (m->flags & ORX_DLRM_FP16_MLP) {
+        m->ldR16 = up8(m->m_spa + m->P);
+        ORX_HIP(hipMalloc(&m->R16, (size_t)B * m->ldR16 * 2)); ORX_HIP(hipMemsetAsync(m->R16, 0, (size_t)B * m->ldR16 * 2, m->ctx->stream));
+        ORX_HIP(hipMalloc(&m->g16, (size_t)B * up8(m->maxw) * 2));
+        for (size_t l = 0; l + 1 < m->top.size(); ++l) {
+            void* p; const size_t bytes = (size_t)B * up8(m->top[l].out) * 2;
+            ORX_HIP(hipMalloc(&p, bytes)); ORX_HIP(hipMemsetAsync(p, 0, bytes, m->ctx->stream));
+            m->top_y16.push_back(p);
+        }
+    }
     m->cap = B;
     return ORX_OK;
 }
@@ -212,11 +251,23 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
         x = y; ldx = ldy;
     }
     // dlrm.py:89-92: R = concat(dense_emb, interaction)
-    CHECK(orx_launch_interact(c, true, m->Z, nullptr, F, d, compat, itself, m->R, m->P, B, m->ldR));
+    const bool f16 = (m->flags & ORX_DLRM_FP16_MLP) != 0;
+    bool have16 = false;                                         // does the current activation have an fp16 copy?
+    if (f16) CHECK(orx_launch_dense_shadow(c, m->d_shadow, m->n_shadow, m->shadow_max));   // W changed since the last step
+    CHECK(orx_launch_interact(c, true, m->Z, nullptr, F, d, compat, itself, m->R, m->P, B, m->ldR, f16 ? m->R16 : nullptr, m->ldR16, &have16));
     x = m->R; ldx = m->ldR;
+    const void* x16 = m->R16; int64_t ldx16 = m->ldR16;
     for (size_t l = 0; l < m->top.size(); ++l) {
         const DenseLayer& L = m->top[l];
-        CHECK(mlp_gemm(m, x, ldx, 1, L.W->w, L.out, 1, m->top_y[l], L.out, L.b->w, (int)B, L.out, L.in, L.act));
+        const bool last = l + 1 == m->top.size();
+        if (f16 && have16) {            // X16 * W16T: fp16-resident operands, fp16 copy of the output for the next layer
+            void* y16 = last ? nullptr : m->top_y16[l];
+            CHECK(orx_launch_gemm_f16s(c, x16, ldx16, L.w16t, L.ld16t, m->top_y[l], L.out, y16, up8(L.out), L.b->w, (int)B, L.out, L.in, L.act));
+            x16 = y16; ldx16 = up8(L.out); have16 = y16 != nullptr;
+        } else {
+            CHECK(mlp_gemm(m, x, ldx, 1, L.W->w, L.out, 1, m->top_y[l], L.out, L.b->w, (int)B, L.out, L.in, L.act));
+            have16 = false;
+        }
         x = m->top_y[l]; ldx = L.out;
     }
     return ORX_OK;
@@ -265,11 +316,13 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
         CHECK(orx_table_scratch(D.W)); CHECK(orx_table_scratch(D.b));
         // dZ = dY * act'(Y) and gb = colsum(dZ) in one pass; gW [in, out] = X^T * dZ.  Both gradient buffers are
         // zero here (the optimizer kernels zero them behind themselves), so split-K / the slab sums just add.
-        CHECK(orx_launch_act_bwd_colsum(c, dy, outs[l], ld_out[l], (int)B, D.out, D.act, D.b->gsum));
+        const bool s16 = D.w16 != nullptr && m->g16 != nullptr && D.out % 8 == 0 && (l > 0 || need_dx0);
+        CHECK(orx_launch_act_bwd_colsum(c, dy, outs[l], ld_out[l], (int)B, D.out, D.act, D.b->gsum, s16 ? m->g16 : nullptr, D.out));
         CHECK(mlp_gemm(m, ins[l], 1, ld_in[l], dy, D.out, 1, D.W->gsum, D.out, nullptr, D.in, D.out, (int)B, 0, true));
         if (l > 0 || need_dx0) {
-            // dX [B, in] = dZ * W^T
-            CHECK(mlp_gemm(m, dy, D.out, 1, D.W->w, 1, D.out, other, ld_in[l], nullptr, (int)B, D.in, D.out, 0));
+            // dX [B, in] = dZ * W^T  (fp16-resident operands where they exist: dZ16 from the pass above, W16)
+            if (s16) CHECK(orx_launch_gemm_f16s(c, m->g16, D.out, D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, (int)B, D.in, D.out, 0));
+            else CHECK(mlp_gemm(m, dy, D.out, 1, D.W->w, 1, D.out, other, ld_in[l], nullptr, (int)B, D.in, D.out, 0));
             float* t = dy; dy = other; other = t;
         }
     }

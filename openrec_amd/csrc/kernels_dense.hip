@@ -290,6 +290,131 @@ __global__ __launch_bounds__(256) void gemm_f32v_kernel(GemmArgs g, int vec_a, i
             }
 }
 
+// ---- fp16-resident operands ("shadows") -------------------------------------------------------------
+// gemm_f16_kernel reads fp32 operands and is bound by L2 -> CU bandwidth (a 1024x1024 layer at batch 8192 moves
+// 512 MB for 17 GFLOP: ~8 TB/s at the measured 66 us).  The forward product X*W and the input-gradient product
+// dY*W^T can read fp16 copies that their producers write anyway (the previous layer's epilogue, the activation
+// backward, the optimizer): half the bytes, no conversion in the loop.  Both operands K-contiguous:
+//   A16 [M][lda] (k contiguous), B16 [N][ldb] (k contiguous), leading dims multiples of 8 halves, zero padded
+// to them.  Same rounding point as gemm_f16_kernel (operand -> fp16 once), so the products are identical.
+struct Gemm16Args {
+    const _Float16* A; int64_t lda;
+    const _Float16* B; int64_t ldb;
+    float* C; int64_t ldc;
+    _Float16* C16; int64_t ldc16;      // optional fp16 copy of the output (next layer's operand)
+    const float* bias;
+    int M, N, K;
+    int act;
+};
+
+struct TileLoader16 {
+    h8 v[2];
+    __device__ __forceinline__ void load(const _Float16* P, int64_t ld, int row0, int nrows, int k0) {
+        const int t = threadIdx.x;
+        const int r = t >> 1, kb = (t & 1) * 16;
+        const bool rok = row0 + r < nrows;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + kb + 8 * h;
+            h8 z; for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
+            v[h] = (rok && k < ld) ? *reinterpret_cast<const h8*>(P + (int64_t)(row0 + r) * ld + k) : z;
+        }
+    }
+    __device__ __forceinline__ void store(_Float16* T, int LD) const {
+        const int t = threadIdx.x;
+        const int r = t >> 1, kb = (t & 1) * 16;
+        *reinterpret_cast<h8*>(T + r * LD + kb) = v[0];
+        *reinterpret_cast<h8*>(T + r * LD + kb + 8) = v[1];
+    }
+};
+
+__global__ __launch_bounds__(256) void gemm_f16s_kernel(Gemm16Args g) {
+    constexpr int BM = 128, BN = 128, BK = 32, LD = BK + 8;
+    __shared__ __attribute__((aligned(16))) _Float16 As[BM * LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[BN * LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[i][j].x = acc[i][j].y = acc[i][j].z = acc[i][j].w = 0.0f; }
+    TileLoader16 la, lb;
+    la.load(g.A, g.lda, bm, g.M, 0);
+    lb.load(g.B, g.ldb, bn, g.N, 0);
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        la.store(As, LD);
+        lb.store(Bs, LD);
+        __syncthreads();
+        if (k0 + BK < g.K) {
+            la.load(g.A, g.lda, bm, g.M, k0 + BK);
+            lb.load(g.B, g.ldb, bn, g.N, k0 + BK);
+        }
+        h8 a[4], b[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const h8*>(&As[(wm + mi * 16 + (lane & 15)) * LD + (lane >> 4) * 8]);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const h8*>(&Bs[(wn + ni * 16 + (lane & 15)) * LD + (lane >> 4) * 8]);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = bm + wm + mi * 16 + (lane >> 4) * 4 + r;
+                const int col = bn + wn + ni * 16 + (lane & 15);
+                if (row < g.M && col < g.N) {
+                    float v = acc[mi][ni][r];
+                    if (g.bias) v += g.bias[col];
+                    if (g.act == 1) v = fmaxf(v, 0.0f);
+                    else if (g.act == 2) v = 1.0f / (1.0f + __expf(-v));
+                    g.C[(int64_t)row * g.ldc + col] = v;
+                    if (g.C16) g.C16[(int64_t)row * g.ldc16 + col] = (_Float16)v;
+                }
+            }
+}
+
+int orx_launch_gemm_f16s(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
+                         void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act) {
+    if (M == 0 || N == 0) return ORX_OK;
+    ORX_ARG(lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)A16 | (uintptr_t)B16) & 15) == 0, "gemm_f16s: operands need 16-byte rows");
+    ProfScope ps(ctx, ORX_K_GEMM);
+    Gemm16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, (_Float16*)C16, ldc16, bias, M, N, K, act};
+    ORX_LAUNCH(ctx, gemm_f16s_kernel, dim3((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128)), dim3(256), 0, g);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// fp16 copies of the dense kernels after an optimizer step: W16 [in][ld16] (same layout, operand of dY*W^T)
+// and W16T [out][ld16t] (transposed, operand of X*W); one launch for all layers (grid.y = layer)
+__global__ __launch_bounds__(256) void dense_shadow_kernel(const ShadowParam* ps) {
+    const ShadowParam p = ps[blockIdx.y];
+    const int64_t n = (int64_t)p.in * p.out;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int i = (int)(e / p.out), j = (int)(e - (int64_t)i * p.out);
+        const _Float16 h = (_Float16)p.w[e];
+        ((_Float16*)p.w16)[(int64_t)i * p.ld16 + j] = h;
+        ((_Float16*)p.w16t)[(int64_t)j * p.ld16t + i] = h;
+    }
+}
+
+int orx_launch_dense_shadow(orx_ctx* ctx, const ShadowParam* ps_dev, int count, int64_t max_n) {
+    if (count == 0) return ORX_OK;
+    int64_t gx = (max_n + 255) / 256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
+    ORX_LAUNCH(ctx, dense_shadow_kernel, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, ps_dev);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
 // grid, split-K factor and vectorization flags shared by the two 128x128 kernels
 static int gemm_plan(const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1, float* C, int64_t ldc,
                      const float* bias, int M, int N, int K, int act, GemmArgs* g, dim3* grid, int* va, int* vb, bool* akc, bool* bnc) {
@@ -386,7 +511,8 @@ int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int
 
 // dZ = dY * act'(Y) in place AND gb[c] += sum_r dZ[r, c] in the same pass (the bias gradient; gb must be zero:
 // the dense optimizer kernels leave every gradient buffer zeroed).  grid = (columns / 64, row slabs of 256).
-__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb) {
+__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb,
+                                                             _Float16* d16, int64_t ld16) {
     __shared__ float sh[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
@@ -399,6 +525,7 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* dY, const fl
             if (act == 1) d = y > 0.0f ? d : 0.0f;
             else if (act == 2) d = d * y * (1.0f - y);
             dY[(int64_t)r * N + c] = d;
+            if (d16) d16[(int64_t)r * ld16 + c] = (_Float16)d;
             s += d;
         }
     }
@@ -407,9 +534,10 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* dY, const fl
     if (part == 0 && c < N) unsafeAtomicAdd(gb + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
-int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb) {
+int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb, void* d16, int64_t ld16) {
     if (M == 0 || N == 0) return ORX_OK;
-    ORX_LAUNCH(ctx, act_bwd_colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 255) / 256)), dim3(256), 0, dY, Y, ldy, M, N, act, gb);
+    ORX_LAUNCH(ctx, act_bwd_colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 255) / 256)), dim3(256), 0, dY, Y, ldy, M, N, act, gb,
+               (_Float16*)d16, ld16);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -524,7 +652,8 @@ __global__ __launch_bounds__(256) void interact_bwd_kernel(const float* Z, const
 // forward: G = Z Z^T on the lower triangle of 16x16 tiles (v_mfma_f32_16x16x4_f32; the B operand of tile
 // (ti, tj) is the A operand of row tile tj: both are "lane (i, q) holds Z[16 t + i][k]").  K order inside a
 // 32-wide block: step s of lane group q multiplies column 8q + s (two 16-byte loads per row and block).
-__global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(const float* Z, int F, int d, int itself, float* R, int64_t B, int ldR) {
+__global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(const float* Z, int F, int d, int itself, float* R, int64_t B, int ldR,
+                                                                _Float16* R16, int ldR16) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -550,12 +679,21 @@ __global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(const float* Z, 
             }
     }
     float* rb = R + b * ldR;
-    for (int k = lane; k < d; k += 64) rb[k] = zb[(int64_t)(F - 1) * d + k];
+    _Float16* rh = R16 ? R16 + b * ldR16 : nullptr;
+    for (int k = lane; k < d; k += 64) {
+        const float v = zb[(int64_t)(F - 1) * d + k];
+        rb[k] = v;
+        if (rh) rh[k] = (_Float16)v;
+    }
     auto emit = [&](const f32x4& acc, int r0, int c0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gi = r0 + q * 4 + r, gj = c0 + i;
-            if (gi < F && (itself ? gj <= gi : gj < gi)) rb[d + (itself ? gi * (gi + 1) / 2 + gj : gi * (gi - 1) / 2 + gj)] = acc[r];
+            if (gi < F && (itself ? gj <= gi : gj < gi)) {
+                const int o = d + (itself ? gi * (gi + 1) / 2 + gj : gi * (gi - 1) / 2 + gj);
+                rb[o] = acc[r];
+                if (rh) rh[o] = (_Float16)acc[r];
+            }
         }
     };
     emit(a00, 0, 0); emit(a10, 16, 0); emit(a11, 16, 16);
@@ -620,19 +758,30 @@ __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(const float* Z, 
             const int g = 16 * ti + q * 4 + r;
             if (g >= F) continue;
             float* out = dZ + (b * F + g) * d + CPL * i;
+            float o[CPL];
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) out[t] = acc[ti][t][r] + (g == F - 1 ? rb[CPL * i + t] : 0.0f);
+            for (int t = 0; t < CPL; ++t) o[t] = acc[ti][t][r] + (g == F - 1 ? rb[CPL * i + t] : 0.0f);
+            if (CPL >= 4) {
+#pragma unroll
+                for (int t = 0; t < CPL; t += 4) { f32x4 v; v.x = o[t]; v.y = o[t + 1]; v.z = o[t + 2]; v.w = o[t + 3]; *reinterpret_cast<f32x4*>(out + t) = v; }
+            } else {
+                out[0] = o[0]; out[1] = o[1];
+            }
         }
 }
 
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
-                        float* out, int P, int64_t B, int ldR) {
+                        float* out, int P, int64_t B, int ldR, void* R16, int ldR16, bool* wrote16) {
+    if (wrote16) *wrote16 = false;
     if (B == 0) return ORX_OK;
     const bool mfma = !compat && F <= 32 && d % 32 == 0 && ((uintptr_t)Z & 15) == 0 && getenv("ORX_INTERACT_SIMPLE") == nullptr;
     const bool bwd_ok = d == 32 || d == 64 || d == 128 || d == 256;
     if (mfma && (fwd || bwd_ok)) {
         const dim3 g((unsigned)((B + 3) / 4));
-        if (fwd) ORX_LAUNCH(ctx, interact_fwd_mfma_kernel, g, dim3(256), 0, Z, F, d, itself, out, B, ldR);
+        if (fwd) {
+            ORX_LAUNCH(ctx, interact_fwd_mfma_kernel, g, dim3(256), 0, Z, F, d, itself, out, B, ldR, (_Float16*)R16, ldR16);
+            if (wrote16 && R16) *wrote16 = true;
+        }
         else if (d == 32) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<2>), g, dim3(256), 0, Z, dR, F, itself, out, B, ldR);
         else if (d == 64) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4>), g, dim3(256), 0, Z, dR, F, itself, out, B, ldR);
         else if (d == 128) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8>), g, dim3(256), 0, Z, dR, F, itself, out, B, ldR);
