@@ -49,7 +49,7 @@ struct orx_dlrm {
     // fp16 copies of the activations that feed MLP products (ORX_DLRM_FP16_MLP)
     void* R16 = nullptr; int ldR16 = 0;
     std::vector<void*> top_y16;         // output of top layer l (l < last), [cap][up8(out)]
-    void* g16 = nullptr;                // dY after the activation backward, [cap][up8(maxw)]
+    void* g16 = nullptr, *g16b = nullptr;   // dY after the activation backward, [cap][up8(maxw)], ping-pong
     ShadowParam* d_shadow = nullptr; int n_shadow = 0; int64_t shadow_max = 0;
     DenseParam* d_params = nullptr;     // descriptors of the dense parameters for the multi-tensor optimizer launch
     orx_opt* params_opt = nullptr;
@@ -141,7 +141,7 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
 }
 
 static void free_buffers(orx_dlrm* m) {
-    hipFree(m->R16); hipFree(m->g16); m->R16 = m->g16 = nullptr;
+    hipFree(m->R16); hipFree(m->g16); hipFree(m->g16b); m->R16 = m->g16 = m->g16b = nullptr;
     for (void* p : m->top_y16) hipFree(p);
     m->top_y16.clear();
     hipFree(m->d_dense); hipFree(m->d_label); hipFree(m->d_sparse); hipFree(m->d_idx); hipFree(m->d_idx_big); m->d_idx_big = nullptr;
@@ -207,6 +207,7 @@ static int ensure_buffers(orx_dlrm* m, int64_t B) {
         m->ldR16 = up8(m->m_spa + m->P);
         ORX_HIP(hipMalloc(&m->R16, (size_t)B * m->ldR16 * 2)); ORX_HIP(hipMemsetAsync(m->R16, 0, (size_t)B * m->ldR16 * 2, m->ctx->stream));
         ORX_HIP(hipMalloc(&m->g16, (size_t)B * up8(m->maxw) * 2));
+        ORX_HIP(hipMalloc(&m->g16b, (size_t)B * up8(m->maxw) * 2));
         for (size_t l = 0; l + 1 < m->top.size(); ++l) {
             void* p; const size_t bytes = (size_t)B * up8(m->top[l].out) * 2;
             ORX_HIP(hipMalloc(&p, bytes)); ORX_HIP(hipMemsetAsync(p, 0, bytes, m->ctx->stream));
@@ -311,18 +312,40 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
                         const std::vector<const float*>& outs, const std::vector<int64_t>& ld_out,
                         float* dy, float* other, int64_t B, bool need_dx0, float** dx_out) {
     orx_ctx* c = m->ctx;
+    bool act_done = false;              // the activation backward of layer l was fused into the product above it
+    void* dy16 = nullptr;               // fp16 copy of the current dy (g16 / g16b ping-pong)
     for (int l = (int)L.size() - 1; l >= 0; --l) {
         DenseLayer& D = L[l];
         CHECK(orx_table_scratch(D.W)); CHECK(orx_table_scratch(D.b));
-        // dZ = dY * act'(Y) and gb = colsum(dZ) in one pass; gW [in, out] = X^T * dZ.  Both gradient buffers are
-        // zero here (the optimizer kernels zero them behind themselves), so split-K / the slab sums just add.
-        const bool s16 = D.w16 != nullptr && m->g16 != nullptr && D.out % 8 == 0 && (l > 0 || need_dx0);
-        CHECK(orx_launch_act_bwd_colsum(c, dy, outs[l], ld_out[l], (int)B, D.out, D.act, D.b->gsum, s16 ? m->g16 : nullptr, D.out));
+        const bool want_dx = l > 0 || need_dx0;
+        const bool s16 = D.w16 != nullptr && m->g16 != nullptr && D.out % 8 == 0 && want_dx;
+        // dZ = dY * act'(Y) and gb = colsum(dZ) in one pass (unless the product above already did it).  The gradient
+        // buffers are zero here (the optimizer kernels zero them behind themselves), so slab sums / split-K just add.
+        if (!act_done) {
+            dy16 = s16 ? m->g16 : nullptr;
+            CHECK(orx_launch_act_bwd_colsum(c, dy, outs[l], ld_out[l], (int)B, D.out, D.act, D.b->gsum, dy16, D.out));
+        }
+        act_done = false;
+        // gW [in, out] = X^T * dZ
         CHECK(mlp_gemm(m, ins[l], 1, ld_in[l], dy, D.out, 1, D.W->gsum, D.out, nullptr, D.in, D.out, (int)B, 0, true));
-        if (l > 0 || need_dx0) {
-            // dX [B, in] = dZ * W^T  (fp16-resident operands where they exist: dZ16 from the pass above, W16)
-            if (s16) CHECK(orx_launch_gemm_f16s(c, m->g16, D.out, D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, (int)B, D.in, D.out, 0));
-            else CHECK(mlp_gemm(m, dy, D.out, 1, D.W->w, 1, D.out, other, ld_in[l], nullptr, (int)B, D.in, D.out, 0));
+        if (want_dx) {
+            // dX [B, in] = dZ * W^T  (fp16-resident operands where they exist: dZ16, W16).  With a layer below, the
+            // epilogue also applies that layer's activation backward, sums its bias gradient and writes its dZ16.
+            if (s16 && dy16 != nullptr) {
+                const bool fuse = l > 0 && L[l - 1].w16 != nullptr && L[l - 1].out % 8 == 0 && ld_in[l] == L[l - 1].out;
+                void* next16 = (dy16 == m->g16) ? m->g16b : m->g16;
+                if (fuse) {
+                    CHECK(orx_table_scratch(L[l - 1].b));
+                    CHECK(orx_launch_gemm_f16s(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], (l - 1 > 0 || need_dx0) ? next16 : nullptr, L[l - 1].out,
+                                               nullptr, (int)B, D.in, D.out, 0, outs[l - 1], ld_out[l - 1], L[l - 1].act, L[l - 1].b->gsum));
+                    act_done = true;
+                    dy16 = (l - 1 > 0 || need_dx0) ? next16 : nullptr;
+                } else {
+                    CHECK(orx_launch_gemm_f16s(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, (int)B, D.in, D.out, 0));
+                }
+            } else {
+                CHECK(mlp_gemm(m, dy, D.out, 1, D.W->w, 1, D.out, other, ld_in[l], nullptr, (int)B, D.in, D.out, 0));
+            }
             float* t = dy; dy = other; other = t;
         }
     }

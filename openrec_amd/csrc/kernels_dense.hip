@@ -305,6 +305,10 @@ struct Gemm16Args {
     const float* bias;
     int M, N, K;
     int act;
+    // fused activation backward of the layer BELOW (input-gradient product dX = dZ * W^T): the epilogue turns dX into
+    // that layer's dZ = dX * act'(Y), adds its column sums to the bias gradient gb (zero before) -- the separate
+    // act_bwd_colsum pass over [batch, width] disappears
+    const float* actY; int64_t ldy; int act_y; float* gb;
 };
 
 struct TileLoader16 {
@@ -364,30 +368,43 @@ __global__ __launch_bounds__(256) void gemm_f16s_kernel(Gemm16Args g) {
         __syncthreads();
     }
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int ni = 0; ni < 4; ++ni) {
+        const int col = bn + wn + ni * 16 + (lane & 15);
+        float csum = 0.0f;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = bm + wm + mi * 16 + (lane >> 4) * 4 + r;
-                const int col = bn + wn + ni * 16 + (lane & 15);
                 if (row < g.M && col < g.N) {
                     float v = acc[mi][ni][r];
                     if (g.bias) v += g.bias[col];
                     if (g.act == 1) v = fmaxf(v, 0.0f);
                     else if (g.act == 2) v = 1.0f / (1.0f + __expf(-v));
+                    if (g.actY) {
+                        const float y = g.actY[(int64_t)row * g.ldy + col];
+                        v = g.act_y == 1 ? (y > 0.0f ? v : 0.0f) : (g.act_y == 2 ? v * y * (1.0f - y) : v);
+                        csum += v;
+                    }
                     g.C[(int64_t)row * g.ldc + col] = v;
                     if (g.C16) g.C16[(int64_t)row * g.ldc16 + col] = (_Float16)v;
                 }
             }
+        if (g.gb) {                                      // the 4 lane groups hold different rows of the same column
+            csum += __shfl_xor(csum, 16);
+            csum += __shfl_xor(csum, 32);
+            if (lane < 16 && col < g.N) unsafeAtomicAdd(g.gb + col, csum);
+        }
+    }
 }
 
 int orx_launch_gemm_f16s(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
-                         void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act) {
+                         void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act,
+                         const float* actY, int64_t ldy, int act_y, float* gb) {
     if (M == 0 || N == 0) return ORX_OK;
     ORX_ARG(lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)A16 | (uintptr_t)B16) & 15) == 0, "gemm_f16s: operands need 16-byte rows");
     ProfScope ps(ctx, ORX_K_GEMM);
-    Gemm16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, (_Float16*)C16, ldc16, bias, M, N, K, act};
+    Gemm16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, (_Float16*)C16, ldc16, bias, M, N, K, act, actY, ldy, act_y, gb};
     ORX_LAUNCH(ctx, gemm_f16s_kernel, dim3((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128)), dim3(256), 0, g);
     ORX_HIP(hipGetLastError());
     return ORX_OK;

@@ -290,7 +290,8 @@ int orx_launch_dense_apply_multi(orx_ctx* ctx, const DenseParam* ps_dev, int cou
 int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb,
                               void* d16 = nullptr, int64_t ld16 = 0);
 int orx_launch_gemm_f16s(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
-                         void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act);
+                         void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act,
+                         const float* actY = nullptr, int64_t ldy = 0, int act_y = 0, float* gb = nullptr);
 struct ShadowParam { const float* w; void* w16; void* w16t; int in, out, ld16, ld16t; };
 int orx_launch_dense_shadow(orx_ctx* ctx, const ShadowParam* ps_dev, int count, int64_t max_n);
 int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act);
