@@ -93,3 +93,27 @@ def test_skewed_items_use_staging_and_hot_reduce(model, D, optname, K):
         assert abs(loss[s] - ref) <= 2e-5 * abs(ref) and abs(l2[s] - l2r) <= 2e-5 * abs(l2r), (s, loss[s], ref)
     for got, want in ((tU.read(), U), (tV.read(), V), (tb.read(), b)):
         assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+
+
+def test_skewed_items_with_fused_censor():
+    """hot rows (staging plan, reduction tree) together with censor_vec fused into the apply"""
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    NU, NI, B, D, K = 5000, 3000, 4096, 64, 4
+    rng = np.random.default_rng(12)
+    U = (rng.uniform(-.05, .05, (NU, D)) * 25).astype(np.float32); V = (rng.uniform(-.05, .05, (NI, D)) * 25).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    w = 1.0 / np.arange(1, NI + 1) ** 1.05
+    cdf = np.cumsum(w / w.sum())
+    perm = rng.permutation(NI)
+    draw = lambda: perm[np.minimum(np.searchsorted(cdf, rng.random((K, B))), NI - 1)].astype(np.int32)
+    uid = rng.integers(0, NU, (K, B)).astype(np.int32); pid = draw(); nid = draw()
+    tU = rt.Table(NU, D).write(U); tV = rt.Table(NI, D).write(V); tb = rt.Table(NI, 1).write(b)
+    U, V, b = U.astype(np.float64), V.astype(np.float64), b.astype(np.float64)
+    loss, l2 = rt.pairwise_step("ucml", rt.Optimizer.sgd(0.001), tU, tV, tb, uid, pid, nid, K=K, B=B, margin=0.5, censor=True)
+    oo = orc.SGD(0.001)
+    for s in range(K):
+        ref, l2r = orc.ucml_step(U, V, b, uid[s], pid[s], nid[s], oo, margin=0.5, do_censor=True)
+        assert abs(loss[s] - ref) <= 2e-5 * abs(ref) and abs(l2[s] - l2r) <= 2e-5 * abs(l2r), (s, loss[s], ref)
+    for got, want in ((tU.read(), U), (tV.read(), V), (tb.read(), b)):
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
