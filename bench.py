@@ -188,6 +188,9 @@ def main():
     ap.add_argument("--hogwild", action="store_true", help="racy non-reference mode (never the headline)")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded engine even on one GPU (debug)")
     ap.add_argument("--zipf", type=float, default=0.0, help="item ids ~ Zipf(alpha) instead of uniform (secondary workload)")
+    ap.add_argument("--host-ids", action="store_true",
+                    help="hand the ids over as host buffers (the C ABI stages them over PCIe inside the timed call); "
+                         "reported for DESIGN.md, never the headline")
     ap.add_argument("--censor", action="store_true",
                     help="UCML: LatentFactor.censor of the touched rows after every step (ucml.py:44-48)")
     args = ap.parse_args()
@@ -224,6 +227,8 @@ def main():
                "adam": lambda: rt.Optimizer.adam(0.001, ctx=ctx)}[args.opt]()
         uid, pid, nid = make_ids(torch, args.users, args.items, K + W, args.batch, 1234, device, args.zipf)
         torch.cuda.synchronize()
+        if args.host_ids:
+            uid, pid, nid = (x.cpu().numpy() for x in (uid, pid, nid))
         pointwise = args.model in ("gmf", "wrmf")
         if pointwise:
             g = torch.Generator(device=device); g.manual_seed(7)
@@ -301,6 +306,7 @@ def main():
                                    f"batch={args.batch} triplets/GPU, {args.opt} lr={lr}, objective loss+l2_loss, "
                                    f"{'HOGWILD (non-reference)' if args.hogwild else 'exact TF duplicate semantics'}"
                                    f"{', censor after each step' if args.censor else ''}"
+                                   f"{', ids handed over as HOST buffers (PCIe inside the timed call)' if args.host_ids else ''}"
                                    f"{', items ~ Zipf(%g)' % args.zipf if args.zipf else ''}",
                        "parallelism": parallelism},
         }
