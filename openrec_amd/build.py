@@ -20,7 +20,8 @@ LIB = os.path.join(OUT, "libopenrec_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics",
-            "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
+            "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value",
+            "-Wno-bitwise-instead-of-logical"]
 
 
 def _sources():
