@@ -409,7 +409,6 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         ORX_HIP(hipMalloc((void**)&m->d_loss, sizeof(double) * K)); m->loss_cap = K;
     }
     const int F = m->F, d = m->m_spa;
-    const int compat = (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0, itself = (m->flags & ORX_DLRM_INTERACT_ITSELF) ? 1 : 0;
     for (int64_t s = 0; s < K; ++s) {
         Batch bt;
         CHECK(stage(m, dense + s * B * m->dense_dim, sparse + s * B * m->n_emb, label + s * B, B, flags, &bt));
