@@ -395,12 +395,10 @@ int fetch_losses(orx_ctx* c, int64_t K, float* loss_out, float* l2_out) {
     return ORX_OK;
 }
 
-struct PairPlan { int nw; int64_t chunk; int64_t list_stride; int64_t Bp; int64_t item_stride; int tree_off[3]; };
 
 // sizes every per-call buffer of the exact pairwise step (grow-only)
-static int pair_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t B, int mode, bool role_bits,
-                        bool inline_apply, bool staging, int nb_total, PairPlan* plan) {
-    const int nw = orx_fused_nwaves(U->dim, B);
+int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t B, int mode, bool role_bits,
+                      bool inline_apply, bool staging, int nb_total, int nw, PairPlan* plan) {
     // steps are processed in chunks so that the per-step scratch stays bounded (~80 B per triplet and
     // step with a staging plan, ~25 B without)
     int64_t chunk = (int64_t)((256ull << 20) / ((size_t)3 * B * sizeof(int32_t)));
@@ -441,6 +439,87 @@ static int pair_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64
 
     plan->nw = nw; plan->chunk = chunk; plan->list_stride = list_stride; plan->Bp = Bp;
     return ORX_OK;
+}
+
+// The plan of a chunk of kc steps of an exact step (pairwise: three id lists per step; pointwise: two, nN = 0):
+// duplicate detection, roles, staging plan, and the host-side decisions read back from it.
+int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,
+                 int64_t nU, int64_t nP, int64_t nN, int64_t kc, int64_t B, bool role_bits, bool inline_apply, bool staging,
+                 const PairPlan& plan, ExactChunk* out) {
+    *out = ExactChunk();
+    // duplicate detection for every step of the chunk, on the id arrays alone
+    DedupArgs d;
+    memset(&d, 0, sizeof(d));
+    d.uid = uid; d.pid = pid; d.nid = nid; d.id_stride = ds;
+    d.dflag = nullptr; d.ids_out = c->d_ids2; d.dlist = c->d_dlist; d.dcount = c->d_dcount;
+    d.roles = role_bits ? c->d_roles : nullptr;
+    d.dupbits = inline_apply ? c->d_dupbits : nullptr;
+    d.flag_stride = 3 * plan.Bp; d.role_stride = plan.Bp; d.list_stride = plan.list_stride;
+    d.nU = nU; d.nP = nP; d.nN = nN; d.NU = U->rows; d.NI = V->rows;
+    d.nbu = orx_dedup_buckets(U->rows); d.nbi = orx_dedup_buckets(V->rows);
+    ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));
+    if (staging) {
+        d.refinfo = c->d_refinfo; d.tricnt = c->d_tricnt; d.segstart = c->d_segstart; d.alloc = c->d_alloc;
+        d.dseg = c->d_dseg; d.dcnt = c->d_dcnt; d.items = c->d_chunks;
+        d.tri_stride = B; d.item_stride = plan.item_stride;
+        for (int l = 0; l < 3; ++l) d.tree_off[l] = plan.tree_off[l];
+        ORX_HIP(hipMemsetAsync(c->d_tricnt, 0, (size_t)kc * B * sizeof(int), c->stream));
+        ORX_HIP(hipMemsetAsync(c->d_alloc, 0, (size_t)kc * 8 * sizeof(int), c->stream));
+    }
+    CHECK(orx_launch_dedup(c, d, kc));
+    if (inline_apply) {
+        // The in-launch apply hides the duplicate apply behind the next step while few references have
+        // to wait for it (the headline: ~0.16 B duplicated rows per step, 34 vs 39 us).  With many
+        // duplicated rows most references of the next step wait and the launch serializes (100k x 100k
+        // tables: 148 vs 56 us per step; break-even measured at ~0.19 B, 800k x 800k tables), so from
+        // B/5 duplicated rows on the apply is its own launch.
+        std::vector<int> dc((size_t)kc);
+        ORX_HIP(hipMemcpyAsync(dc.data(), c->d_dcount, dc.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        ORX_HIP(hipStreamSynchronize(c->stream));
+        int max_dup = 0;
+        for (int64_t i = 0; i < kc; ++i) max_dup = std::max(max_dup, dc[i]);
+        const char* thr = getenv("ORX_INLINE_DUP_DIV");        // debug: threshold = B / value
+        out->dense_dups = (int64_t)max_dup * (thr ? atoi(thr) : 5) > B;
+    }
+    if (staging) {
+        // long segments (a row referenced > 16 times in one step) need the hot_reduce_kernel levels between the
+        // fused launch and the apply: one small read-back per chunk of steps decides
+        std::vector<int> al((size_t)kc * 8);
+        ORX_HIP(hipMemcpyAsync(al.data(), c->d_alloc, al.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        ORX_HIP(hipStreamSynchronize(c->stream));
+        out->hot = false; out->tree_levels = 0;
+        int max_staged = 0;
+        for (int64_t i = 0; i < kc; ++i) {
+            for (int l = 0; l < 3; ++l) if (al[8 * i + 2 + l] > 0) out->tree_levels = std::max(out->tree_levels, l + 1);
+            max_staged = std::max(max_staged, al[8 * i + 1]);
+        }
+        out->hot = out->tree_levels > 0;
+        // dedup_kernel plans staging only for row ranges where atomics would pile up; without any plan in
+        // the chunk the kernels without the segment bookkeeping are launched
+        out->use_stage = max_staged > 0;
+    }
+    if (inline_apply && !out->hot && !out->dense_dups) CHECK(orx_launch_urgent(c, d, kc));
+    return ORX_OK;
+}
+
+// per-step views into the plan arrays of the current chunk (step i of the chunk)
+void orx_exact_step_views(orx_ctx* c, const PairPlan& plan, int64_t i, int64_t B, int D, bool use_stage, PairArgs* a) {
+    const int64_t Bp = plan.Bp, list_stride = plan.list_stride;
+    a->dlist = c->d_dlist + (size_t)i * list_stride; a->dcount = c->d_dcount + i;
+    if (use_stage) {
+        const size_t par = (size_t)(i & 1), ppar = par ^ 1;
+        a->refinfo = c->d_refinfo + (size_t)i * 3 * Bp; a->segstart = c->d_segstart + (size_t)i * B;
+        a->stage = c->d_stage + par * 3 * B * D; a->stageb = c->d_stageb + par * 3 * B;
+        a->dseg = c->d_dseg + (size_t)i * list_stride; a->dcnt = c->d_dcnt + (size_t)i * list_stride;
+        a->items = c->d_chunks + (size_t)i * plan.item_stride; a->nitems = c->d_alloc + 8 * i + 2;
+        a->part = c->d_part; a->partb = c->d_partb;
+        for (int l = 0; l < 3; ++l) a->tree_off[l] = plan.tree_off[l];
+        a->prev_stage = c->d_stage + ppar * 3 * B * D; a->prev_stageb = c->d_stageb + ppar * 3 * B;
+        a->prev_dseg = i > 0 ? c->d_dseg + (size_t)(i - 1) * list_stride : nullptr;
+        a->prev_dcnt = i > 0 ? c->d_dcnt + (size_t)(i - 1) * list_stride : nullptr;
+    } else {
+        a->stage = nullptr; a->stageb = nullptr; a->dcnt = nullptr; a->dseg = nullptr; a->prev_dcnt = nullptr; a->prev_dseg = nullptr;
+    }
 }
 
 extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
@@ -490,7 +569,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     CHECK(orx_opt_slots(opt, U, &sU)); CHECK(orx_opt_slots(opt, V, &sV)); CHECK(orx_opt_slots(opt, b, &sb));
 
     PairPlan plan;
-    CHECK(pair_buffers(c, U, V, K, B, mode, role_bits, inline_apply, staging, nb_total, &plan));
+    CHECK(orx_exact_buffers(c, U, V, K, B, mode, role_bits, inline_apply, staging, nb_total, orx_fused_nwaves(U->dim, B), &plan));
     const int nw = plan.nw;
     const int64_t chunk = plan.chunk, list_stride = plan.list_stride, Bp = plan.Bp;
 
@@ -523,58 +602,10 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
         bool hot = false, use_stage = false, dense_dups = false;
         int tree_levels = 0;
         if (mode == MODE_EXACT) {
-            // duplicate detection for every step of the chunk, on the id arrays alone
-            DedupArgs d;
-            memset(&d, 0, sizeof(d));
-            d.uid = du + s0 * ds; d.pid = dp + s0 * ds; d.nid = dn + s0 * ds; d.id_stride = ds;
-            d.dflag = nullptr; d.ids_out = c->d_ids2; d.dlist = c->d_dlist; d.dcount = c->d_dcount;
-            d.roles = role_bits ? c->d_roles : nullptr;
-            d.dupbits = inline_apply ? c->d_dupbits : nullptr;
-            d.flag_stride = 3 * Bp; d.role_stride = Bp; d.list_stride = list_stride;
-            d.nU = B; d.nP = B; d.nN = B; d.NU = U->rows; d.NI = V->rows;
-            d.nbu = orx_dedup_buckets(U->rows); d.nbi = orx_dedup_buckets(V->rows);
-            ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));
-            if (staging) {
-                d.refinfo = c->d_refinfo; d.tricnt = c->d_tricnt; d.segstart = c->d_segstart; d.alloc = c->d_alloc;
-                d.dseg = c->d_dseg; d.dcnt = c->d_dcnt; d.items = c->d_chunks;
-                d.tri_stride = B; d.item_stride = plan.item_stride;
-                for (int l = 0; l < 3; ++l) d.tree_off[l] = plan.tree_off[l];
-                ORX_HIP(hipMemsetAsync(c->d_tricnt, 0, (size_t)kc * B * sizeof(int), c->stream));
-                ORX_HIP(hipMemsetAsync(c->d_alloc, 0, (size_t)kc * 8 * sizeof(int), c->stream));
-            }
-            CHECK(orx_launch_dedup(c, d, kc));
-            if (inline_apply) {
-                // The in-launch apply hides the duplicate apply behind the next step while few references have
-                // to wait for it (the headline: ~0.16 B duplicated rows per step, 34 vs 39 us).  With many
-                // duplicated rows most references of the next step wait and the launch serializes (100k x 100k
-                // tables: 148 vs 56 us per step; break-even measured at ~0.19 B, 800k x 800k tables), so from
-                // B/5 duplicated rows on the apply is its own launch.
-                std::vector<int> dc((size_t)kc);
-                ORX_HIP(hipMemcpyAsync(dc.data(), c->d_dcount, dc.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                ORX_HIP(hipStreamSynchronize(c->stream));
-                int max_dup = 0;
-                for (int64_t i = 0; i < kc; ++i) max_dup = std::max(max_dup, dc[i]);
-                const char* thr = getenv("ORX_INLINE_DUP_DIV");        // debug: threshold = B / value
-                dense_dups = (int64_t)max_dup * (thr ? atoi(thr) : 5) > B;
-            }
-            if (staging) {
-                // long segments (a row referenced > 16 times in one step) need the hot_reduce_kernel levels between the
-                // fused launch and the apply: one small read-back per chunk of steps decides
-                std::vector<int> al((size_t)kc * 8);
-                ORX_HIP(hipMemcpyAsync(al.data(), c->d_alloc, al.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                ORX_HIP(hipStreamSynchronize(c->stream));
-                hot = false; tree_levels = 0;
-                int max_staged = 0;
-                for (int64_t i = 0; i < kc; ++i) {
-                    for (int l = 0; l < 3; ++l) if (al[8 * i + 2 + l] > 0) tree_levels = std::max(tree_levels, l + 1);
-                    max_staged = std::max(max_staged, al[8 * i + 1]);
-                }
-                hot = tree_levels > 0;
-                // dedup_kernel plans staging only for row ranges where atomics would pile up; without any plan in
-                // the chunk the kernels without the segment bookkeeping are launched
-                use_stage = max_staged > 0;
-            }
-            if (inline_apply && !hot && !dense_dups) CHECK(orx_launch_urgent(c, d, kc));
+            ExactChunk ck;
+            CHECK(orx_exact_plan_chunk(c, U, V, du + s0 * ds, dp + s0 * ds, dn + s0 * ds, ds, B, B, B, kc, B, role_bits, inline_apply, staging,
+                                       plan, &ck));
+            hot = ck.hot; use_stage = ck.use_stage; dense_dups = ck.dense_dups; tree_levels = ck.tree_levels;
         }
         const bool inl = inline_apply && !hot && !dense_dups;
         if (censor) {
@@ -598,23 +629,9 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             } else {
                 a.uid = du + s * ds; a.pid = dp + s * ds; a.nid = dn + s * ds;
             }
-            a.dlist = c->d_dlist + (size_t)i * list_stride; a.dcount = c->d_dcount + i;
+            orx_exact_step_views(c, plan, i, B, U->dim, use_stage, &a);
             a.partial = c->d_partial + (size_t)i * nw * 2;
             a.epoch = ++c->epoch;           // one epoch per step: ready flags and censor side marks are tagged with it
-            if (use_stage) {
-                const size_t par = (size_t)(i & 1), ppar = par ^ 1;
-                a.refinfo = c->d_refinfo + (size_t)i * 3 * Bp; a.segstart = c->d_segstart + (size_t)i * B;
-                a.stage = c->d_stage + par * 3 * B * U->dim; a.stageb = c->d_stageb + par * 3 * B;
-                a.dseg = c->d_dseg + (size_t)i * list_stride; a.dcnt = c->d_dcnt + (size_t)i * list_stride;
-                a.items = c->d_chunks + (size_t)i * plan.item_stride; a.nitems = c->d_alloc + 8 * i + 2;
-                a.part = c->d_part; a.partb = c->d_partb;
-                for (int l = 0; l < 3; ++l) a.tree_off[l] = plan.tree_off[l];
-                a.prev_stage = c->d_stage + ppar * 3 * B * U->dim; a.prev_stageb = c->d_stageb + ppar * 3 * B;
-                a.prev_dseg = i > 0 ? c->d_dseg + (size_t)(i - 1) * list_stride : nullptr;
-                a.prev_dcnt = i > 0 ? c->d_dcnt + (size_t)(i - 1) * list_stride : nullptr;
-            } else {
-                a.stage = nullptr; a.stageb = nullptr; a.dcnt = nullptr; a.dseg = nullptr; a.prev_dcnt = nullptr; a.prev_dseg = nullptr;
-            }
             if (inl && i > 0) {    // this launch also applies the duplicated rows of step i-1
                 // one lane group per duplicated row in a single pass for the usual ~0.15*B duplicated rows
                 // (the count lives in device memory; surplus blocks exit, a larger count grid-strides)
@@ -665,7 +682,7 @@ extern "C" int orx_pairwise_reserve(orx_ctx* c, orx_opt* opt, orx_table* U, orx_
     OptSlots s;
     CHECK(orx_opt_slots(opt, U, &s)); CHECK(orx_opt_slots(opt, V, &s)); CHECK(orx_opt_slots(opt, b, &s));
     PairPlan plan;
-    CHECK(pair_buffers(c, U, V, K, B, mode, role_bits, inline_apply, staging, nb_total, &plan));
+    CHECK(orx_exact_buffers(c, U, V, K, B, mode, role_bits, inline_apply, staging, nb_total, orx_fused_nwaves(U->dim, B), &plan));
     ORX_HIP(hipStreamSynchronize(c->stream));
     return ORX_OK;
 }

@@ -70,7 +70,23 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     ENSURE(c->d_loss, c->d_loss_cap, (size_t)K * 2 * sizeof(double));
     if (model == ORX_GMF) ENSURE(c->d_wpart, c->d_wpart_cap, (size_t)(nw + 256) * D * sizeof(float));   // + stage-1 rows of dense_reduce
     const int64_t list_stride = 2 * B;
-    if (mode == MODE_EXACT) {
+    // exact mode on the float4 dims below 2^28 rows: the plan of the pairwise step (roles: rows referenced twice get
+    // plain stores; staging plan + reduction tree for hot rows), made once for all K steps.  Otherwise byte flags +
+    // atomics for every duplicate.
+    const char* fb_env = getenv("ORX_FORCE_FALLBACK");
+    const int fb = fb_env ? atoi(fb_env) : 0;
+    const bool role_bits = mode == MODE_EXACT && orx_fused_can_inline_apply(D) && U->rows < (1LL << 28) && V->rows < (1LL << 28) && !(fb & 1);
+    const bool staging = role_bits && !(fb & 8);
+    PairPlan plan;
+    memset(&plan, 0, sizeof(plan));
+    if (role_bits) {
+        CHECK(orx_table_scratch(U, true)); CHECK(orx_table_scratch(V, true)); CHECK(orx_table_scratch(b, true));
+        const int nb_total = orx_dedup_buckets(U->rows) + orx_dedup_buckets(V->rows);
+        const size_t part_cap = c->d_partial_cap;       // orx_exact_buffers sizes d_partial for its own use: keep ours
+        CHECK(orx_exact_buffers(c, U, V, K, B, mode, true, false, staging, nb_total, nslot, &plan));
+        (void)part_cap;
+        ENSURE(c->d_partial, c->d_partial_cap, (size_t)K * nslot * 2 * sizeof(float));
+    } else if (mode == MODE_EXACT) {
         ENSURE(c->d_dflag, c->d_dflag_cap, (size_t)K * 2 * B);
         ENSURE(c->d_dlist, c->d_dlist_cap, (size_t)K * list_stride * sizeof(uint32_t));
         ENSURE(c->d_dcount, c->d_dcount_cap, (size_t)K * sizeof(int));
@@ -93,17 +109,33 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     a.lr = opt->lr; a.eps = opt->kind == ORX_ADAGRAD ? opt->p1 : 0.f;
     a.invB = 1.0f / (float)B; a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f; a.a_w = a_w; a.b_w = b_w;
     a.wpartial = c->d_wpart; a.err = c->d_err;
-    PairArgs pa;                                 // view of the same tables for dup_apply_kernel
+    if (role_bits) { a.role_bits = 1; a.gU2 = U->gsum2; a.gV2 = V->gsum2; a.gb2 = b->gsum2; }
+    PairArgs pa;                                 // view of the same tables for dup_apply_kernel / hot_reduce_kernel
     memset(&pa, 0, sizeof(pa));
     pa.U = U->w; pa.V = V->w; pa.b = b->w; pa.gU = U->gsum; pa.gV = V->gsum; pa.gb = b->gsum;
+    if (role_bits) { pa.gU2 = U->gsum2; pa.gV2 = V->gsum2; pa.gb2 = b->gsum2; pa.role_bits = 1; }
     pa.aU = sU.s0; pa.aV = sV.s0; pa.ab = sb.s0; pa.B = B; pa.D = D; pa.lr = a.lr; pa.eps = a.eps;
-    for (int64_t s = 0; s < K; ++s) {
-        a.uid = du + s * ds; a.iid = di + s * ds; a.label = dl + s * ds;
-        a.dflag = c->d_dflag + (size_t)s * 2 * B;
+    const int64_t chunk = role_bits ? plan.chunk : K;
+    for (int64_t s0 = 0; s0 < K; s0 += chunk) {
+    const int64_t kc = (K - s0 < chunk) ? (K - s0) : chunk;
+    ExactChunk ck;
+    if (role_bits) CHECK(orx_exact_plan_chunk(c, U, V, du + s0 * ds, di + s0 * ds, di + s0 * ds, ds, B, B, 0, kc, B, true, false, staging, plan, &ck));
+    for (int64_t i = 0; i < kc; ++i) {
+        const int64_t s = s0 + i;
+        a.label = dl + s * ds;
         a.partial = c->d_partial + (size_t)s * nslot * 2;
+        if (role_bits) {
+            a.uid = c->d_ids2 + (size_t)i * 3 * plan.Bp; a.iid = a.uid + plan.Bp;
+            orx_exact_step_views(c, plan, i, B, D, ck.use_stage, &pa);
+            a.refinfo = pa.refinfo; a.segstart = pa.segstart; a.stage = pa.stage; a.stageb = pa.stageb;
+        } else {
+            a.uid = du + s * ds; a.iid = di + s * ds;
+            a.dflag = c->d_dflag + (size_t)s * 2 * B;
+            pa.dlist = c->d_dlist + (size_t)s * list_stride; pa.dcount = c->d_dcount + s;
+        }
         CHECK(orx_launch_point_fused(c, model, opt->kind, mode, a));
         if (mode == MODE_EXACT) {
-            pa.dlist = c->d_dlist + (size_t)s * list_stride; pa.dcount = c->d_dcount + s;
+            for (int l = 0; l < ck.tree_levels; ++l) CHECK(orx_launch_hot_reduce(c, pa, l));
             CHECK(orx_launch_dup_apply(c, opt->kind, pa));
         }
         float lr_t = 0.f;
@@ -123,6 +155,7 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
                 CHECK(orx_launch_dense_reduce(c, c->d_wpart, nw, D, w->w, a.l2w, nullptr, a.partial + 2 * nw, sw.s0, opt->kind, opt->lr, a.eps));
             }
         }
+    }
     }
     ReduceArgs r;
     r.partial = c->d_partial; r.out = c->d_loss; r.nwaves = nslot;

@@ -43,10 +43,19 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
     if (MODEL == ORX_GMF) wv = *reinterpret_cast<const f4*>(a.w + 4 * sub);
     f4 gw_acc; gw_acc.x = gw_acc.y = gw_acc.z = gw_acc.w = 0.0f;
     for (int64_t t = wave_global * TPW + grp; t < a.B; t += stride) {
-        const int u = a.uid[t], i = a.iid[t];
+        int u = a.uid[t], i = a.iid[t];
         const float y = a.label[t];
         int du = 0, di = 0;
-        if (MODE == MODE_EXACT) { du = a.dflag[t]; di = a.dflag[a.B + t]; }
+        int ku = 2, ki = 2;                     // duplicate role: 0 / 1 = plain store into scratch row 1 / 2, 2 = staged or atomics
+        if (MODE == MODE_EXACT) {
+            if (a.role_bits) {                  // ids rewritten by dedup_kernel
+                du = (uint32_t)u >> 31; di = (uint32_t)i >> 31;
+                ku = ((uint32_t)u >> 29) & 3; ki = ((uint32_t)i >> 29) & 3;
+                u &= 0x0fffffff; i &= 0x0fffffff;
+            } else {
+                du = a.dflag[t]; di = a.dflag[a.B + t];
+            }
+        }
         if (MODE == MODE_ACCUM) { du = di = 1; }
         if (!(id_ok(u, a.NU) & id_ok(i, a.NI))) { if (sub == 0) *a.err = 1; continue; }
         float* Up = a.U + (size_t)u * D + 4 * sub;
@@ -64,14 +73,21 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
         const f4 gu = gs * (ri * wv) + a.l2w * ru;
         const f4 gi = gs * (ru * wv) + a.l2w * ri;
         if (MODEL == ORX_GMF) gw_acc += gs * ui;
+        // staged references: slot = segment start of the row + rank of the reference (refinfo (-1, 0): no plan)
+        auto slot_of = [&](int64_t ref) -> int {
+            if (MODE != MODE_EXACT || a.stage == nullptr) return -1;
+            const int2 ri2 = a.refinfo[ref];
+            return ri2.x < 0 ? -1 : a.segstart[ri2.x] + ri2.y;
+        };
         if (du == 0) opt_apply4<OPT>(Up, a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
-        else atomic_add_f4(a.gU + (size_t)u * D + 4 * sub, gu);
+        else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t) : -1, D, sub);
         if (di == 0) {
             opt_apply4<OPT>(Ip, a.aV + (size_t)i * D + 4 * sub, ri, gi, a.lr, a.eps);
             if (sub == 0) opt_apply1<OPT>(a.b + i, a.ab + i, bi, gs, a.lr, a.eps);
         } else {
-            atomic_add_f4(a.gV + (size_t)i * D + 4 * sub, gi);
-            if (sub == 0) unsafeAtomicAdd(a.gb + i, gs);
+            const int si = ki == 2 ? slot_of((a.iid - a.uid) + t) : -1;
+            dup_store4s(a.gV, a.gV2, (size_t)i * D + 4 * sub, gi, ki, a.stage, si, D, sub);
+            if (sub == 0) dup_store1s(a.gb, a.gb2, i, gs, ki, a.stageb, si);
         }
     }
     const float ls = wave_sum(loss_acc);

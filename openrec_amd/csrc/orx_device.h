@@ -137,3 +137,31 @@ __device__ __forceinline__ void opt_apply1(float* w_ptr, float* a_ptr, float w_o
     }
 }
 
+// ------------------------------------------------- duplicated-row deposits ---
+// Gradient of a duplicated reference.  Rows referenced exactly twice in the batch get one PLAIN
+// store per reference, into scratch row 1 (role 0) or scratch row 2 (role 1): no atomics and a
+// summation that is bitwise reproducible.  Rows referenced three or more times (role 2) use
+// fp32 atomics into scratch row 1.  dup_apply_kernel adds the two scratch rows.
+__device__ __forceinline__ void dup_store4(float* G1, float* G2, size_t off, f4 g, int role) {
+    if (role == 0) *reinterpret_cast<f4*>(G1 + off) = g;
+    else if (role == 1) *reinterpret_cast<f4*>(G2 + off) = g;
+    else atomic_add_f4(G1 + off, g);
+}
+
+__device__ __forceinline__ void dup_store1(float* G1, float* G2, size_t off, float g, int role) {
+    if (role == 0) G1[off] = g;
+    else if (role == 1) G2[off] = g;
+    else unsafeAtomicAdd(G1 + off, g);
+}
+
+// with a staging plan (slot >= 0) a role-2 reference owns one staging slot: plain store, no atomics
+__device__ __forceinline__ void dup_store4s(float* G1, float* G2, size_t off, f4 g, int role, float* stage, int slot, int D, int sub) {
+    if (role == 2 && slot >= 0) *reinterpret_cast<f4*>(stage + (size_t)slot * D + 4 * sub) = g;
+    else dup_store4(G1, G2, off, g, role);
+}
+
+__device__ __forceinline__ void dup_store1s(float* G1, float* G2, size_t off, float g, int role, float* stageb, int slot) {
+    if (role == 2 && slot >= 0) stageb[slot] = g;
+    else dup_store1(G1, G2, off, g, role);
+}
+

@@ -231,7 +231,11 @@ struct PointArgs {
     float* gU; float* gV; float* gb;
     float* aU; float* aV; float* ab;
     const int32_t* uid; const int32_t* iid; const float* label;
-    const unsigned char* dflag;               // [2B]: user refs then item refs
+    const unsigned char* dflag;               // [2B]: user refs then item refs (tables >= 2^28 rows / generic dims)
+    // exact mode with role bits: uid / iid are the ids REWRITTEN by dedup_kernel (flag 31, role 30:29), iid = uid + Bp
+    int role_bits;
+    float* gU2; float* gV2; float* gb2;       // second scratch rows (rows referenced exactly twice)
+    const int2* refinfo; const int* segstart; float* stage; float* stageb;   // staging plan (stage NULL: atomics)
     int64_t B; int64_t NU; int64_t NI;
     int D;
     float lr; float eps; float invB; float l2w; float a_w; float b_w;
@@ -252,6 +256,15 @@ int orx_point_nwaves(int D, int64_t B);
 int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K);
 int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairArgs& a);
 int orx_launch_hot_reduce(orx_ctx* ctx, const PairArgs& a, int level);
+// host-side plan of the exact steps (api.hip), shared by the pairwise and the pointwise step
+struct PairPlan { int nw; int64_t chunk; int64_t list_stride; int64_t Bp; int64_t item_stride; int tree_off[3]; };
+struct ExactChunk { bool hot = false, use_stage = false, dense_dups = false; int tree_levels = 0; };
+int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t B, int mode, bool role_bits,
+                      bool inline_apply, bool staging, int nb_total, int nw, PairPlan* plan);
+int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,
+                         int64_t nU, int64_t nP, int64_t nN, int64_t kc, int64_t B, bool role_bits, bool inline_apply, bool staging,
+                         const PairPlan& plan, ExactChunk* out);
+void orx_exact_step_views(orx_ctx* c, const PairPlan& plan, int64_t i, int64_t B, int D, bool use_stage, PairArgs* a);
 int orx_launch_dup_apply(orx_ctx* ctx, int optkind, const PairArgs& a);
 int orx_launch_urgent(orx_ctx* ctx, const DedupArgs& a, int64_t K);
 int orx_fused_can_inline_apply(int D);

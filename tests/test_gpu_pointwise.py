@@ -87,3 +87,43 @@ def test_inference_scores():
         assert rel_err(rt.score_all_items("l2", tU, tV, tb, uid), orc.ucml_inference(U, V, b, uid)) < TOL
         ref = (U[uid][:, None, :] * V[None, :, :]) @ w[:, 0] + b[:, 0][None, :]
         assert rel_err(rt.score_all_items("gmf", tU, tV, tb, uid, w=tw), ref) < TOL
+
+
+@pytest.mark.parametrize("model,optkind,D,fallback", [("wrmf", "sgd", 64, "0"), ("gmf", "sgd", 128, "0"), ("wrmf", "adagrad", 32, "0"),
+                                                      ("gmf", "sgd", 64, "8"), ("wrmf", "sgd", 64, "1")])
+def test_skewed_items_and_hot_user(model, optkind, D, fallback, monkeypatch):
+    """Items ~ Zipf(1.05) plus one hot user: rows referenced twice take the plain-store roles, hot rows the staging
+    plan and the reduction tree (fallback 8: atomics instead of staging; 1: byte flags + atomics for every duplicate).
+    fp64 oracle: a row that sums hundreds of gradients has no unique fp32 answer."""
+    monkeypatch.setenv("ORX_FORCE_FALLBACK", fallback)
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    NU, NI, B, K = 9000, 5000, 8192, 4
+    rng = np.random.default_rng(8)
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    wk = rng.uniform(-.3, .3, (D, 1)).astype(np.float32)
+    pw = 1.0 / np.arange(1, NI + 1) ** 1.05
+    cdf = np.cumsum(pw / pw.sum()); perm = rng.permutation(NI)
+    uid = rng.integers(0, NU, (K, B)).astype(np.int32); uid[:, :400] = 11
+    iid = perm[np.minimum(np.searchsorted(cdf, rng.random((K, B))), NI - 1)].astype(np.int32)
+    lab = (rng.random((K, B)) < 0.4).astype(np.float32)
+    assert np.bincount(iid[0], minlength=NI).max() > 300
+    tU = rt.Table(NU, D).write(U); tV = rt.Table(NI, D).write(V); tb = rt.Table(NI, 1).write(b)
+    tw = rt.Table(D, 1).write(wk) if model == "gmf" else None
+    lr = 0.002
+    opt = rt.Optimizer.sgd(lr) if optkind == "sgd" else rt.Optimizer.adagrad(lr)
+    oo = orc.SGD(lr) if optkind == "sgd" else orc.Adagrad(lr)
+    loss, l2 = rt.pointwise_step(model, opt, tU, tV, tb, tw, uid, iid, lab, K=K, B=B, a=2.0, b_w=0.5)
+    U, V, b, wk = (x.astype(np.float64) for x in (U, V, b, wk))
+    for s in range(K):
+        if model == "gmf":
+            lw, l2w = orc.gmf_step(U, V, b, wk, uid[s], iid[s], lab[s], oo)
+        else:
+            lw, l2w = orc.wrmf_step(U, V, b, uid[s], iid[s], lab[s], oo, a=2.0, b_w=0.5)
+        assert abs(loss[s] - lw) <= 3e-5 * abs(lw) and abs(l2[s] - l2w) <= 3e-5 * abs(l2w), (s, loss[s], lw)
+    tol = 2e-5 if fallback == "0" else 1e-4          # atomics add in arrival order
+    for got, want in ((tU.read(), U), (tV.read(), V), (tb.read(), b)):
+        assert np.abs(got - want).max() <= tol * np.abs(want).max()
+    if model == "gmf":
+        assert np.abs(tw.read() - wk).max() <= 1e-4 * np.abs(wk).max()
