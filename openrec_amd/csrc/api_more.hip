@@ -304,6 +304,48 @@ extern "C" int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_tabl
     return orx_launch_dup_apply(ctx, ORX_ADAGRAD, pa);
 }
 
+// ---- planned apply of K id lists against one table (see orx_internal.h) ------------------------------------------
+int orx_apply_rows_plan(orx_ctx* c, orx_table* t, const int32_t* ids, int64_t K, int64_t n, int64_t id_stride, RowsPlan* out) {
+    out->ready = false;
+    if (K == 0 || n == 0) return ORX_OK;
+    ORX_ARG(orx_fused_can_inline_apply(t->dim) && t->rows < (1LL << 28), "apply_rows_plan: needs a float4 dim and fewer than 2^28 rows");
+    ORX_HIP(hipSetDevice(c->device));
+    CHECK(orx_table_scratch(t, true));
+    const int nb_total = orx_dedup_buckets(t->rows);
+    CHECK(orx_exact_buffers(c, t, t, K, n, MODE_EXACT, true, false, true, nb_total, 1, &out->plan));
+    ORX_ARG(out->plan.chunk >= K, "apply_rows_plan: %lld lists of %lld ids exceed one plan chunk (%lld)", (long long)K, (long long)n,
+            (long long)out->plan.chunk);
+    // the id lists play the ITEM role (so that dup_apply also finishes a bias column); no user list
+    CHECK(orx_exact_plan_chunk(c, t, t, ids, ids, ids, id_stride, 0, n, 0, K, n, true, false, true, out->plan, &out->ck));
+    out->n = n; out->ready = true;
+    return ORX_OK;
+}
+
+int orx_apply_rows_planned_step(orx_ctx* c, orx_opt* opt, orx_table* t, orx_table* bias, const RowsPlan& rp, int64_t i,
+                                const int32_t* ids, const float* grads, int64_t g_stride) {
+    ORX_ARG(rp.ready && (opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD), "apply_rows_planned_step: no plan, or not SGD / Adagrad");
+    if (bias) CHECK(orx_table_scratch(bias, true));
+    OptSlots st, sb;
+    CHECK(orx_opt_slots(opt, t, &st));
+    if (bias) CHECK(orx_opt_slots(opt, bias, &sb));
+    const int64_t n = rp.n;
+    PairArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.V = t->w; pa.gV = t->gsum; pa.gV2 = t->gsum2; pa.aV = st.s0; pa.role_bits = 1;
+    pa.b = bias ? bias->w : nullptr; pa.gb = bias ? bias->gsum : nullptr; pa.gb2 = bias ? bias->gsum2 : nullptr; pa.ab = bias ? sb.s0 : nullptr;
+    pa.B = n; pa.D = t->dim; pa.lr = opt->lr; pa.eps = opt->kind == ORX_ADAGRAD ? opt->p1 : 0.f;
+    orx_exact_step_views(c, rp.plan, i, n, t->dim, rp.ck.use_stage, &pa);
+    RowsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.W = t->w; a.bias = pa.b; a.G = t->gsum; a.G2 = t->gsum2; a.gb = pa.gb; a.gb2 = pa.gb2; a.A = st.s0; a.ab = pa.ab;
+    a.ids = ids; a.ids2 = c->d_ids2 + (size_t)i * 3 * rp.plan.Bp + rp.plan.Bp;      // the item list of step i
+    a.grads = grads; a.g_stride = g_stride; a.n = n; a.rows = t->rows; a.D = t->dim; a.lr = pa.lr; a.eps = pa.eps; a.err = c->d_err;
+    a.refinfo = pa.refinfo ? pa.refinfo + rp.plan.Bp : nullptr; a.segstart = pa.segstart; a.stage = pa.stage; a.stageb = pa.stageb;
+    CHECK(orx_launch_rows_planned(c, opt->kind, a));
+    for (int l = 0; l < rp.ck.tree_levels; ++l) CHECK(orx_launch_hot_reduce(c, pa, l));
+    return orx_launch_dup_apply(c, opt->kind, pa);
+}
+
 // duplicate flags of K id lists against a table of `rows` rows: dflag[k*n + i] = 1 iff the row ids[k*id_stride + i]
 // occurs more than once in list k (ids < 0 are skipped, their flag is not written)
 extern "C" int orx_rows_dupflags(orx_ctx* ctx, int64_t rows, const int32_t* ids, int64_t K, int64_t n, int64_t id_stride,

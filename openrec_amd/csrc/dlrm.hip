@@ -51,6 +51,8 @@ struct orx_dlrm {
     std::vector<void*> top_y16;         // output of top layer l (l < last), [cap][up8(out)]
     void* g16 = nullptr, *g16b = nullptr;   // dY after the activation backward, [cap][up8(maxw)], ping-pong
     ShadowParam* d_shadow = nullptr; int n_shadow = 0; int64_t shadow_max = 0;
+    int32_t* d_idx_all = nullptr; int64_t idx_all_cap = 0;          // combined row ids of a chunk of steps (planned sparse apply)
+    int32_t* d_sparse_all = nullptr; int64_t sparse_all_cap = 0;
     DenseParam* d_params = nullptr;     // descriptors of the dense parameters for the multi-tensor optimizer launch
     orx_opt* params_opt = nullptr;
     bool grads_pending = false;         // orx_dlrm_grads ran, orx_dlrm_dense_apply not yet
@@ -159,7 +161,7 @@ extern "C" int orx_dlrm_destroy(orx_dlrm* m) {
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     free_buffers(m);
-    hipFree(m->d_offset); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params); hipFree(m->d_tiny_f); hipFree(m->d_is_tiny);
+    hipFree(m->d_offset); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params); hipFree(m->d_idx_all); hipFree(m->d_sparse_all); hipFree(m->d_tiny_f); hipFree(m->d_is_tiny);
     orx_table_destroy(m->emb);
     for (auto& d : m->bot) { orx_table_destroy(d.W); orx_table_destroy(d.b); }
     for (auto& d : m->top) { orx_table_destroy(d.W); orx_table_destroy(d.b); hipFree(d.w16); hipFree(d.w16t); }
@@ -229,7 +231,7 @@ static int mlp_gemm(orx_dlrm* m, const float* A, int64_t sa0, int64_t sa1, const
 
 // forward of one batch; leaves every activation in the model's buffers.  emb_rows != NULL: the
 // embedding rows [B, n_emb, d] are handed in (hybrid-parallel step) instead of gathered here.
-static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_rows = nullptr) {
+static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_rows = nullptr, const int32_t* idx = nullptr) {
     orx_ctx* c = m->ctx;
     const int F = m->F, d = m->m_spa;
     const int compat = (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0, itself = (m->flags & ORX_DLRM_INTERACT_ITSELF) ? 1 : 0;
@@ -237,9 +239,12 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
         CHECK(orx_launch_copy2d(c, m->Z, (int64_t)F * d, emb_rows, (int64_t)m->n_emb * d, (int)B, m->n_emb * d));
     } else {
         ORX_ARG(m->emb, "dlrm: the model was created with ORX_DLRM_NO_EMB (use orx_dlrm_grads)");
-        CHECK(orx_launch_dlrm_ids(c, bt.sparse, m->d_offset, m->d_rows, m->n_emb, B, m->d_idx));
+        if (idx == nullptr) {           // combined-table row ids of this batch (a K-step call computes them up front)
+            CHECK(orx_launch_dlrm_ids(c, bt.sparse, m->d_offset, m->d_rows, m->n_emb, B, m->d_idx));
+            idx = m->d_idx;
+        }
         // dlrm.py:83-85: the n_emb gathers = one gather on the combined table (dense slot skipped)
-        CHECK(orx_launch_gather(c, m->emb->w, nullptr, m->emb->rows, d, m->d_idx, B * F, m->Z, d, c->d_err, 1));
+        CHECK(orx_launch_gather(c, m->emb->w, nullptr, m->emb->rows, d, idx, B * F, m->Z, d, c->d_err, 1));
     }
     // dlrm.py:87: bottom MLP; its last layer writes straight into slot F-1 of Z
     const float* x = bt.dense; int64_t ldx = m->dense_dim;
@@ -409,10 +414,43 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         ORX_HIP(hipMalloc((void**)&m->d_loss, sizeof(double) * K)); m->loss_cap = K;
     }
     const int F = m->F, d = m->m_spa;
+    // Sparse optimizer with a plan: the row ids of all K steps are known up front, so duplicate roles, staging plan
+    // and reduction tree are made once per (up to 64-step) chunk and every step applies its rows without atomics
+    // (orx_apply_rows_planned_step).  SGD / Adagrad on float4 dims; Adam keeps accumulate + sweep.  The plan costs one
+    // dedup workgroup per 425 984-row range and step, each streaming all B*F ids: right for combined tables of a few
+    // ranges, wrong for Criteo's 33.8 M rows (80 ranges: +120 us per step, measured) -- those keep the atomics path
+    // with the LDS sums for the tiny tables.
+    const bool planned = m->emb != nullptr && (opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD) && orx_fused_can_inline_apply(d) &&
+                         orx_dedup_buckets(m->emb->rows) <= 8 && getenv("ORX_DLRM_NO_PLAN") == nullptr;
+    // steps per plan: what orx_exact_buffers accepts as one chunk for B*F ids per step
+    const int64_t PC = std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)((256ull << 20) / ((size_t)3 * B * F * sizeof(int32_t)))));
+    RowsPlan rp;
+    const int32_t* sparse_dev = sparse;
+    if (planned) {
+        const int64_t kp = std::min<int64_t>(K, PC);
+        if (m->idx_all_cap < kp * B * F) {
+            if (m->d_idx_all) ORX_HIP(hipFree(m->d_idx_all));
+            ORX_HIP(hipMalloc((void**)&m->d_idx_all, sizeof(int32_t) * kp * B * F)); m->idx_all_cap = kp * B * F;
+        }
+        if (!(flags & ORX_IDS_DEVICE)) {                      // all K steps' sparse ids to the device at once
+            if (m->sparse_all_cap < K * B * m->n_emb) {
+                if (m->d_sparse_all) ORX_HIP(hipFree(m->d_sparse_all));
+                ORX_HIP(hipMalloc((void**)&m->d_sparse_all, sizeof(int32_t) * K * B * m->n_emb)); m->sparse_all_cap = K * B * m->n_emb;
+            }
+            ORX_HIP(hipMemcpyAsync(m->d_sparse_all, sparse, sizeof(int32_t) * K * B * m->n_emb, hipMemcpyHostToDevice, c->stream));
+            sparse_dev = m->d_sparse_all;
+        }
+    }
     for (int64_t s = 0; s < K; ++s) {
+        if (planned && s % PC == 0) {
+            const int64_t kp = std::min<int64_t>(K - s, PC);
+            CHECK(orx_launch_dlrm_ids(c, sparse_dev + s * B * m->n_emb, m->d_offset, m->d_rows, m->n_emb, kp * B, m->d_idx_all));
+            CHECK(orx_apply_rows_plan(c, m->emb, m->d_idx_all, kp, B * F, B * F, &rp));
+        }
+        const int32_t* idx_s = planned ? m->d_idx_all + (s % PC) * B * F : nullptr;
         Batch bt;
         CHECK(stage(m, dense + s * B * m->dense_dim, sparse + s * B * m->n_emb, label + s * B, B, flags, &bt));
-        CHECK(forward(m, bt, B));
+        CHECK(forward(m, bt, B, nullptr, idx_s));
         float* pred = m->top_y.back();
         // loss + dLoss/dP  (dlrm.py:72-73, :97-98)
         CHECK(orx_launch_dlrm_loss(c, pred, bt.label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, m->d_loss + s));
@@ -425,7 +463,9 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
             lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, (double)opt->t)) / (1.0 - std::pow(b1, (double)opt->t)));
         }
         // sparse: per-occurrence rows dZ[b, f, :] onto the combined table (dense slot has id -1)
-        if (opt->kind == ORX_SGD && !m->tiny_f.empty()) {
+        if (planned) {
+            CHECK(orx_apply_rows_planned_step(c, opt, m->emb, nullptr, rp, s % PC, idx_s, m->dZ, d));
+        } else if (opt->kind == ORX_SGD && !m->tiny_f.empty()) {
             // tiny tables: per-slab LDS sums; the generic scatter then skips their slots
             CHECK(orx_launch_dlrm_tiny_apply(c, m->d_idx, m->dZ, m->d_tiny_f, (int)m->tiny_f.size(), m->tiny_max_rows, m->d_offset,
                                              m->d_rows, F, d, B, opt->lr, m->emb->w));

@@ -180,6 +180,62 @@ __global__ __launch_bounds__(256) void apply_rows_sgd_flagged_kernel(RowsArgs a)
     }
 }
 
+// Planned apply: one lane group per reference.  The row's duplicate status / role comes from the ids rewritten by
+// dedup_kernel: referenced once -> the optimizer rule in place (plain float4 read-modify-write); twice -> one plain
+// store per reference into the two scratch rows; more -> the reference's private staging slot (or atomics where the
+// range made no plan).  dup_apply_kernel (+ hot_reduce_kernel) finishes the duplicated rows.
+template <int LPR, int OPT>
+__global__ __launch_bounds__(256) void rows_planned_kernel(RowsArgs a) {
+    constexpr int TPW = 64 / LPR;
+    constexpr int D = 4 * LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
+    for (int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + grp; k < a.n; k += stride) {
+        const int r0 = a.ids[k];
+        if (r0 < 0) continue;                                                  // padding
+        if ((int64_t)r0 >= a.rows) { if (sub == 0) *a.err = 1; continue; }
+        const uint32_t v = (uint32_t)a.ids2[k];
+        const int dup = v >> 31, role = (v >> 29) & 3;
+        const size_t off = (size_t)r0 * D + 4 * sub;
+        const f4 g = *reinterpret_cast<const f4*>(a.grads + k * a.g_stride + 4 * sub);
+        const float gb = (a.bias != nullptr && sub == 0) ? a.grads[k * a.g_stride + D] : 0.0f;
+        if (!dup) {
+            opt_apply4<OPT>(a.W + off, a.A + off, *reinterpret_cast<const f4*>(a.W + off), g, a.lr, a.eps);
+            if (a.bias != nullptr && sub == 0) opt_apply1<OPT>(a.bias + r0, a.ab + r0, a.bias[r0], gb, a.lr, a.eps);
+        } else {
+            int slot = -1;
+            if (role == 2 && a.stage != nullptr) { const int2 ri = a.refinfo[k]; slot = ri.x < 0 ? -1 : a.segstart[ri.x] + ri.y; }
+            dup_store4s(a.G, a.G2, off, g, role, a.stage, slot, D, sub);
+            if (a.bias != nullptr && sub == 0) dup_store1s(a.gb, a.gb2, r0, gb, role, a.stageb, slot);
+        }
+    }
+}
+
+template <int OPT>
+static void launch_rows_planned(orx_ctx* ctx, int lpr, const RowsArgs& a) {
+    const dim3 g(grid_for_rows(lpr, a.n));
+    switch (lpr) {
+        case 4: ORX_LAUNCH(ctx, (rows_planned_kernel<4, OPT>), g, dim3(256), 0, a); break;
+        case 8: ORX_LAUNCH(ctx, (rows_planned_kernel<8, OPT>), g, dim3(256), 0, a); break;
+        case 16: ORX_LAUNCH(ctx, (rows_planned_kernel<16, OPT>), g, dim3(256), 0, a); break;
+        case 32: ORX_LAUNCH(ctx, (rows_planned_kernel<32, OPT>), g, dim3(256), 0, a); break;
+        default: ORX_LAUNCH(ctx, (rows_planned_kernel<64, OPT>), g, dim3(256), 0, a); break;
+    }
+}
+
+int orx_launch_rows_planned(orx_ctx* ctx, int optkind, const RowsArgs& a) {
+    ProfScope ps(ctx, ORX_K_DUPAPPLY);
+    int lpr = 0;
+    switch (a.D) { case 16: lpr = 4; break; case 32: lpr = 8; break; case 64: lpr = 16; break; case 128: lpr = 32; break; case 256: lpr = 64; break; }
+    ORX_ARG(lpr != 0 && a.g_stride % 4 == 0, "rows_planned: dim must be 16/32/64/128/256 and the gradient rows 16-byte aligned");
+    if (optkind == ORX_ADAGRAD) launch_rows_planned<ORX_ADAGRAD>(ctx, lpr, a);
+    else launch_rows_planned<ORX_SGD>(ctx, lpr, a);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
 // Adagrad: rows referenced once are updated in place, duplicated rows sum into
 // gsum first (dup_apply_kernel finishes them).  One wavefront per reference.
 __global__ __launch_bounds__(256) void apply_rows_adagrad_kernel(RowsArgs a) {

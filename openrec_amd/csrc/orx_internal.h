@@ -210,6 +210,9 @@ struct RowsArgs {                              // sharded building blocks (kerne
     int64_t n; int64_t rows; int D;
     float lr; float eps;
     int* err;
+    // planned apply (orx_apply_rows_planned): ids rewritten by dedup_kernel (item role), scratch rows, staging
+    const int32_t* ids2; float* G2; float* gb2;
+    const int2* refinfo; const int* segstart; float* stage; float* stageb;
 };
 
 struct GradArgs {
@@ -256,6 +259,7 @@ int orx_point_nwaves(int D, int64_t B);
 int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K);
 int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairArgs& a);
 int orx_launch_hot_reduce(orx_ctx* ctx, const PairArgs& a, int level);
+
 // host-side plan of the exact steps (api.hip), shared by the pairwise and the pointwise step
 struct PairPlan { int nw; int64_t chunk; int64_t list_stride; int64_t Bp; int64_t item_stride; int tree_off[3]; };
 struct ExactChunk { bool hot = false, use_stage = false, dense_dups = false; int tree_levels = 0; };
@@ -265,6 +269,13 @@ int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
                          int64_t nU, int64_t nP, int64_t nN, int64_t kc, int64_t B, bool role_bits, bool inline_apply, bool staging,
                          const PairPlan& plan, ExactChunk* out);
 void orx_exact_step_views(orx_ctx* c, const PairPlan& plan, int64_t i, int64_t B, int D, bool use_stage, PairArgs* a);
+int orx_launch_rows_planned(orx_ctx* ctx, int optkind, const RowsArgs& a);
+// K id lists of n local rows each (ids [K][n], < 0 = padding) against ONE table: plan once (duplicate roles, staging
+// plan, reduction tree), then per list i: orx_apply_rows_planned_step(i, grads).  SGD / Adagrad.
+struct RowsPlan { PairPlan plan; ExactChunk ck; int64_t n = 0; bool ready = false; };
+int orx_apply_rows_plan(orx_ctx* ctx, orx_table* t, const int32_t* ids, int64_t K, int64_t n, int64_t id_stride, RowsPlan* out);
+int orx_apply_rows_planned_step(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const RowsPlan& rp, int64_t i,
+                                const int32_t* ids, const float* grads, int64_t g_stride);
 int orx_launch_dup_apply(orx_ctx* ctx, int optkind, const PairArgs& a);
 int orx_launch_urgent(orx_ctx* ctx, const DedupArgs& a, int64_t K);
 int orx_fused_can_inline_apply(int D);
