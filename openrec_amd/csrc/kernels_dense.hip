@@ -437,9 +437,10 @@ static int gemm_plan(const float* A, int64_t sa0, int64_t sa1, const float* B, i
                      const float* bias, int M, int N, int K, int act, GemmArgs* g, dim3* grid, int* va, int* vb, bool* akc, bool* bnc) {
     const int tiles = ((N + 127) / 128) * ((M + 127) / 128);
     int splits = 1;
-    if (bias == nullptr && act == 0 && ldc == N && tiles < 256 && K >= 1024) {
+    if (bias == nullptr && act == 0 && ldc == N && tiles < 256 && K >= 256) {
         splits = (512 + tiles - 1) / tiles;
-        if (splits > K / 256) splits = K / 256;
+        const int max_splits = K >= 4096 ? K / 256 : K / 64;           // small batches: down to two 32-wide iterations per split
+        if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
     }
     g->kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
@@ -461,9 +462,10 @@ int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, 
     // small M x N, K = batch); partial tiles are combined with fp32 atomics into a zeroed output
     const int tiles = ((N + 127) / 128) * ((M + 127) / 128);
     int splits = 1;
-    if (bias == nullptr && act == 0 && ldc == N && tiles < 256 && K >= 1024) {
+    if (bias == nullptr && act == 0 && ldc == N && tiles < 256 && K >= 256) {
         splits = (512 + tiles - 1) / tiles;
-        if (splits > K / 256) splits = K / 256;
+        const int max_splits = K >= 4096 ? K / 256 : K / 64;
+        if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
     }
     g.kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
@@ -529,11 +531,11 @@ int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int
 // dZ = dY * act'(Y) in place AND gb[c] += sum_r dZ[r, c] in the same pass (the bias gradient; gb must be zero:
 // the dense optimizer kernels leave every gradient buffer zeroed).  grid = (columns / 64, row slabs of 256).
 __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb,
-                                                             _Float16* d16, int64_t ld16) {
+                                                             _Float16* d16, int64_t ld16, int slab) {
     __shared__ float sh[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * 256, r1 = min(M, r0 + 256);
+    const int r0 = blockIdx.y * slab, r1 = min(M, r0 + slab);
     float s = 0.0f;
     if (c < N) {
         for (int r = r0 + part; r < r1; r += 4) {
@@ -553,8 +555,9 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* dY, const fl
 
 int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb, void* d16, int64_t ld16) {
     if (M == 0 || N == 0) return ORX_OK;
-    ORX_LAUNCH(ctx, act_bwd_colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 255) / 256)), dim3(256), 0, dY, Y, ldy, M, N, act, gb,
-               (_Float16*)d16, ld16);
+    const int slab = (int64_t)M * N >= (4 << 20) ? 256 : 32;          // small layers: more, shorter slabs (the pass is latency-bound)
+    ORX_LAUNCH(ctx, act_bwd_colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + slab - 1) / slab)), dim3(256), 0, dY, Y, ldy, M, N, act, gb,
+               (_Float16*)d16, ld16, slab);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
