@@ -15,6 +15,7 @@ import numpy as np
 from ... import runtime as rt
 from .._lazy import LazyScalar, PendingStep, active_tape
 from ..modules.latent_factor import Variable
+from ._base import _StepQueue, STEP_QUEUE
 
 
 class DLRM:
@@ -30,15 +31,29 @@ class DLRM:
             sys.exit("ERROR: loss_func=" + loss_func + " is not supported")       # dlrm.py:56-61
         self._model = rt.DLRMModel(m_spa, ln_emb, ln_bot, ln_top, dense_dim, arch_interaction_itself, sigmoid_bot,
                                    sigmoid_top, loss_func, loss_threshold, reference_compat, seed, ctx)
+        self._queue = _StepQueue()          # applied train steps wait here and run as one K-step device call
+        self._hooked = set()
+
+    def flush(self):
+        self._queue.run()
+
+    def _param(self, kind, layer=0):
+        """parameter table whose host-visible accesses first run the queued steps"""
+        t = self._model.param(kind, layer)
+        t.pre_access = self.flush
+        return t
 
     @property
     def trainable_variables(self):
+        if getattr(self, "_vars", None) is not None:        # the loop asks for this list twice per step
+            return self._vars
         m = self._model
-        out = [Variable(m.param("emb"), "latent_factors/embeddings")]
+        out = [Variable(self._param("emb"), "latent_factors/embeddings")]
         for nm, n in (("bot", len(m.ln_bot)), ("top", len(m.ln_top))):
             for l in range(n):
-                out.append(Variable(m.param(nm + "_w", l), f"mlp_{nm}/dense_{l}/kernel"))
-                out.append(Variable(m.param(nm + "_b", l), f"mlp_{nm}/dense_{l}/bias"))
+                out.append(Variable(self._param(nm + "_w", l), f"mlp_{nm}/dense_{l}/kernel"))
+                out.append(Variable(self._param(nm + "_b", l), f"mlp_{nm}/dense_{l}/bias"))
+        self._vars = out
         return out
 
     def __call__(self, dense_features, sparse_features, label):
@@ -46,11 +61,24 @@ class DLRM:
         d, s, y = (np.asarray(x.numpy() if hasattr(x, "numpy") else x) for x in (dense_features, sparse_features, label))
 
         def run_forward():
+            self.flush()
             p = m.inference(d, s)
             yy = y.astype(np.float32).reshape(-1)
             return (float(np.mean((yy - p) ** 2)), 0.0)        # only used outside a tape (mse); see inference
 
         def run_train(optimizer, no_l2):
+            def runner(bufs, K):
+                loss = m.step(optimizer, bufs[0].reshape(-1, d.shape[-1]), bufs[1].reshape(-1, s.shape[-1]), bufs[2].reshape(-1), K=K)
+                return loss, np.zeros(K, np.float32)
+            if STEP_QUEUE > 1:
+                q = self._queue
+                key = ("dlrm", id(optimizer), d.shape, s.shape)
+                if q.steps and q.key != key:
+                    q.run()
+                q.add(step, key, (np.asarray(d, np.float32), np.asarray(s, np.int32), np.asarray(y, np.float32).reshape(-1)), runner)
+                if len(q.steps) >= STEP_QUEUE:
+                    q.run()
+                return None
             loss = m.step(optimizer, d, s, y, K=1)
             return float(loss[0]), 0.0
 
@@ -67,8 +95,9 @@ class DLRM:
     @property
     def user_latent_factor(self):
         class _T:
-            table = self._model.param("emb")
+            table = self._model.param("emb")       # context lookup only: no host-visible access, no flush
         return _T
 
     def inference(self, dense_features, sparse_features):
+        self.flush()
         return self._model.inference(dense_features, sparse_features)

@@ -16,7 +16,7 @@ for B in (1024, 8192):
             l = m(dense, sparse, label)
         opt.apply_gradients(zip(tape.gradient(l, m.trainable_variables), m.trainable_variables))
         return l
-    for _ in range(10): step()
+    for _ in range(70): step()          # past the first full queue: buffers sized for K = 32
     float(step())
     t0 = time.perf_counter()
     for _ in range(100): l = step()

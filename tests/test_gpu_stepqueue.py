@@ -99,3 +99,43 @@ def test_pointwise_loop_is_queued():
     for g, w in zip(got, want):
         assert abs(float(g) - w) <= 2e-5 * abs(w)
     assert rel_err(m.user_latent_factor.variables[0].numpy(), U) < 2e-5 and rel_err(m.item_latent_factor.variables[0].numpy(), V) < 2e-5
+
+
+def test_dlrm_loop_is_queued(monkeypatch):
+    from openrec_amd import runtime as rt
+    from openrec_amd.tf2 import compat as tf
+    from openrec_amd.tf2.recommenders import DLRM
+    from oracle import numpy_oracle as orc
+    from oracle.dlrm_oracle import DLRMOracle
+    calls = []
+    real = rt.DLRMModel.step
+    monkeypatch.setattr(rt.DLRMModel, "step", lambda self, *a, **k: (calls.append(k.get("K", 1)), real(self, *a, **k))[1])
+    rng = np.random.default_rng(6)
+    counts = [40, 7, 300, 3, 90]
+    cfg = dict(m_spa=4, ln_emb=counts, ln_bot=[8, 4], ln_top=[16, 8, 1])
+    o = DLRMOracle(dtype=np.float32, seed=9, reference_compat=False, dense_dim=13, **cfg)
+    m = DLRM(reference_compat=False, **cfg)
+    tv = m.trainable_variables
+    tv[0].assign(np.concatenate(o.emb))
+    k = 1
+    for layers in (o.bot, o.top):
+        for W, b in layers:
+            tv[k].assign(W); tv[k + 1].assign(b.reshape(1, -1)); k += 2
+    optimizer = tf.keras.optimizers.SGD(0.05)
+    oo = orc.SGD(0.05)
+    got, want = [], []
+    for s in range(70):
+        dense = rng.normal(size=(64, 13)).astype(np.float32)
+        sparse = np.stack([rng.integers(0, n, 64) for n in counts], 1).astype(np.int32)
+        label = (rng.random(64) < 0.4).astype(np.float32)
+        with tf.GradientTape() as tape:
+            loss = m(dense, sparse, label)
+        optimizer.apply_gradients(zip(tape.gradient(loss, m.trainable_variables), m.trainable_variables))
+        got.append(loss)
+        want.append(float(o.step(dense, sparse, label, oo)))
+    pred = m.inference(dense, sparse)                        # observing the model runs the rest of the queue
+    assert calls.count(32) == 2 and sum(calls) == 70
+    for g, w in zip(got, want):
+        assert abs(float(g) - w) <= 2e-5 * abs(w)
+    assert rel_err(pred, o.inference(dense, sparse)) < 2e-5
+    assert rel_err(m.trainable_variables[0].numpy(), np.concatenate(o.emb)) < 2e-5
