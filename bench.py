@@ -69,7 +69,17 @@ def cpu_baseline(args, budget_s=15.0, max_steps=2000):
     U = rng.uniform(-0.05, 0.05, (args.users, args.dim)).astype(np.float32)
     V = rng.uniform(-0.05, 0.05, (args.items, args.dim)).astype(np.float32)
     b = rng.uniform(-0.05, 0.05, (args.items, 1)).astype(np.float32)
-    cpu = c_oracle.PairwiseCPU(args.model, args.opt, U, V, b, lr=0.05)
+    if args.opt == "adam":          # the C port has SGD/Adagrad; Adam's whole-table rule is timed on the numpy restatement
+        from oracle import numpy_oracle as orc
+        oo = orc.AdamTFSparse(0.05)
+        stepfn = {"bpr": orc.bpr_step, "ucml": lambda *a: orc.ucml_step(*a, margin=0.5, do_censor=False)}[args.model]
+
+        class _NP:
+            def step(self, u, p, n):
+                stepfn(U, V, b, u, p, n, oo)
+        cpu, cores, what = _NP(), 1, "oracle/numpy_oracle.py (numpy, one thread)"
+    else:
+        cpu, cores, what = c_oracle.PairwiseCPU(args.model, args.opt, U, V, b, lr=0.05), c_oracle.num_threads(), "oracle/orx_oracle.c (OpenMP)"
     ids = [(rng.integers(0, args.users, args.batch).astype(np.int32),
             rng.integers(0, args.items, args.batch).astype(np.int32),
             rng.integers(0, args.items, args.batch).astype(np.int32)) for _ in range(32)]
@@ -81,9 +91,8 @@ def cpu_baseline(args, budget_s=15.0, max_steps=2000):
         cpu.step(*ids[done % len(ids)])
         done += 1
     dt = time.perf_counter() - t0
-    return dict(value=done * args.batch / dt, unit="triplets/s", cores=c_oracle.num_threads(), kind="port",
-                sample=f"{done} steps of {args.batch} triplets on {args.users}x{args.items}x{args.dim} tables, "
-                       f"oracle/orx_oracle.c (OpenMP), {dt:.1f} s")
+    return dict(value=done * args.batch / dt, unit="triplets/s", cores=cores, kind="port",
+                sample=f"{done} steps of {args.batch} triplets on {args.users}x{args.items}x{args.dim} tables, {what}, {dt:.1f} s")
 
 
 CRITEO_KAGGLE_COUNTS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306, 10,

@@ -170,7 +170,11 @@ extern "C" int orx_table_destroy(orx_table* t) {
 
 extern "C" int64_t orx_table_rows(const orx_table* t) { return t ? t->rows : -1; }
 extern "C" int32_t orx_table_dim(const orx_table* t) { return t ? t->dim : -1; }
-extern "C" void* orx_table_device_ptr(const orx_table* t) { return t ? (void*)t->w : nullptr; }
+extern "C" void* orx_table_device_ptr(const orx_table* t) {
+    if (t == nullptr) return nullptr;
+    orx_table_sync(const_cast<orx_table*>(t));        // the raw pointer escapes: rows must be current
+    return (void*)t->w;
+}
 
 int orx_table_scratch(orx_table* t, bool second) {
     ORX_HIP(hipSetDevice(t->ctx->device));
@@ -199,12 +203,14 @@ int orx_table_side(orx_table* t) {
 }
 
 extern "C" int orx_table_init_uniform(orx_table* t, float lo, float hi, uint64_t seed) {
+    if (t) CHECK(orx_table_sync(t));
     ORX_ARG(t, "orx_table_init_uniform: NULL table");
     ORX_HIP(hipSetDevice(t->ctx->device));
     return orx_launch_init_uniform(t->ctx, t->w, t->rows * t->dim, lo, hi, seed);
 }
 
 extern "C" int orx_table_fill(orx_table* t, float value) {
+    if (t) CHECK(orx_table_sync(t));
     ORX_ARG(t, "orx_table_fill: NULL table");
     ORX_HIP(hipSetDevice(t->ctx->device));
     return orx_launch_fill(t->ctx, t->w, t->rows * t->dim, value);
@@ -226,11 +232,13 @@ static int rows_copy(orx_ctx* ctx, float* dev, int64_t rows, int32_t dim, int64_
 }
 
 extern "C" int orx_table_read(orx_table* t, int64_t row0, int64_t nrows, float* host_dst) {
+    if (t) CHECK(orx_table_sync(t));
     ORX_ARG(t, "orx_table_read: NULL table");
     return rows_copy(t->ctx, t->w, t->rows, t->dim, row0, nrows, host_dst, true);
 }
 
 extern "C" int orx_table_write(orx_table* t, int64_t row0, int64_t nrows, const float* host_src) {
+    if (t) CHECK(orx_table_sync(t));
     ORX_ARG(t, "orx_table_write: NULL table");
     return rows_copy(t->ctx, t->w, t->rows, t->dim, row0, nrows, (float*)host_src, false);
 }
@@ -242,6 +250,7 @@ int stage_ids(orx_ctx* c, const int32_t* host, int64_t n, int64_t off) {
 }
 
 extern "C" int orx_table_gather(orx_table* t, const int32_t* ids, int64_t n, float* out, int flags) {
+    if (t) CHECK(orx_table_sync(t));
     ORX_ARG(t && (n == 0 || (ids && out)), "orx_table_gather: NULL argument");
     if (n == 0) return ORX_OK;
     orx_ctx* c = t->ctx;
@@ -270,6 +279,7 @@ static int dedup_single(orx_ctx* c, const int32_t* d_ids, int64_t n, int64_t row
 }
 
 extern "C" int orx_table_censor(orx_table* t, const int32_t* ids, int64_t n, float min_norm, int flags) {
+    if (t) CHECK(orx_table_sync(t));
     ORX_ARG(t && (n == 0 || ids), "orx_table_censor: NULL argument");
     if (n == 0) return ORX_OK;
     orx_ctx* c = t->ctx;
@@ -300,13 +310,21 @@ extern "C" int orx_opt_destroy(orx_opt* o) {
     if (!o) return ORX_OK;
     hipSetDevice(o->ctx->device);
     hipStreamSynchronize(o->ctx->stream);
-    for (auto& kv : o->slots) { hipFree(kv.second.s0); hipFree(kv.second.s1); }
+    for (auto& kv : o->slots) {
+        if (kv.first->lazy == o) orx_table_sync(kv.first);       // the table outlives the optimizer: finish its rows
+        hipFree(kv.second.s0); hipFree(kv.second.s1); hipFree(kv.second.last);
+    }
+    hipFree(o->d_lrt);
     delete o;
     return ORX_OK;
 }
 
 extern "C" int orx_opt_set_lr(orx_opt* o, float lr) {
     ORX_ARG(o, "orx_opt_set_lr: NULL optimizer");
+    if (lr != o->lr && (int64_t)o->h_lrt.size() > o->t + 1) {      // steps already taken keep the rate they were taken with
+        o->h_lrt.resize((size_t)o->t + 1);
+        o->lrt_uploaded = std::min<int64_t>(o->lrt_uploaded, o->t + 1);
+    }
     o->lr = lr;
     return ORX_OK;
 }
@@ -331,6 +349,58 @@ int orx_opt_slots(orx_opt* o, orx_table* t, OptSlots* out) {
     return ORX_OK;
 }
 
+// lr_t of steps 1..upto on the device (host mirror keeps every value ever used: a row may replay old steps)
+int orx_adam_lrt(orx_opt* o, int64_t upto) {
+    if ((int64_t)o->h_lrt.size() < upto + 1) {
+        const double b1 = o->p0, b2 = o->p1;
+        const size_t old = o->h_lrt.size();
+        o->h_lrt.resize((size_t)upto + 1);
+        for (size_t k = old; k <= (size_t)upto; ++k)
+            o->h_lrt[k] = k == 0 ? 0.f : (float)(o->lr * std::sqrt(1.0 - std::pow(b2, (double)k)) / (1.0 - std::pow(b1, (double)k)));
+    }
+    if (o->lrt_uploaded >= upto + 1) return ORX_OK;
+    ORX_HIP(hipSetDevice(o->ctx->device));
+    if (o->lrt_cap < (size_t)upto + 1) {
+        const size_t cap = std::max<size_t>(4096, 2 * ((size_t)upto + 1));
+        float* p = nullptr;
+        ORX_HIP(hipMalloc((void**)&p, cap * sizeof(float)));
+        ORX_HIP(hipStreamSynchronize(o->ctx->stream));
+        if (o->d_lrt) { ORX_HIP(hipMemcpy(p, o->d_lrt, (size_t)o->lrt_uploaded * sizeof(float), hipMemcpyDeviceToDevice)); ORX_HIP(hipFree(o->d_lrt)); }
+        o->d_lrt = p; o->lrt_cap = cap;
+    }
+    ORX_HIP(hipMemcpyAsync(o->d_lrt + o->lrt_uploaded, o->h_lrt.data() + o->lrt_uploaded, (size_t)(upto + 1 - o->lrt_uploaded) * sizeof(float),
+                           hipMemcpyHostToDevice, o->ctx->stream));
+    o->lrt_uploaded = upto + 1;
+    return ORX_OK;
+}
+
+// bring every row of `t` up to its lazy optimizer's current step
+int orx_table_sync(orx_table* t) {
+    if (t == nullptr || t->lazy == nullptr) return ORX_OK;
+    orx_opt* o = t->lazy;
+    t->lazy = nullptr;
+    auto it = o->slots.find(t);
+    if (it == o->slots.end() || it->second.last == nullptr) return ORX_OK;
+    ORX_HIP(hipSetDevice(o->ctx->device));
+    CHECK(orx_adam_lrt(o, o->t));
+    return orx_launch_adam_flush(o->ctx, t->w, it->second.s0, it->second.s1, it->second.last, t->rows, t->dim, (int)o->t, o->d_lrt,
+                                 o->p0, o->p1, o->p2);
+}
+
+// per-row step stamps of the lazy Adam (all rows current at the optimizer's present step)
+int orx_opt_last(orx_opt* o, orx_table* t, bool restamp, int** out) {
+    OptSlots s;
+    CHECK(orx_opt_slots(o, t, &s));
+    auto& ref = o->slots[t];
+    if (ref.last == nullptr) {
+        ORX_HIP(hipMalloc((void**)&ref.last, (size_t)t->rows * sizeof(int)));
+        restamp = true;
+    }
+    if (restamp) CHECK(orx_launch_fill_int(o->ctx, ref.last, t->rows, (int)o->t));
+    *out = ref.last;
+    return ORX_OK;
+}
+
 static int slot_ptr(orx_opt* o, orx_table* t, int slot, float** p) {
     ORX_ARG(o && t, "optimizer slot: NULL argument");
     OptSlots s;
@@ -341,12 +411,14 @@ static int slot_ptr(orx_opt* o, orx_table* t, int slot, float** p) {
 }
 
 extern "C" int orx_opt_slot_read(orx_opt* o, orx_table* t, int slot, int64_t row0, int64_t nrows, float* host_dst) {
+    if (t) CHECK(orx_table_sync(t));
     float* p = nullptr;
     CHECK(slot_ptr(o, t, slot, &p));
     return rows_copy(t->ctx, p, t->rows, t->dim, row0, nrows, host_dst, true);
 }
 
 extern "C" int orx_opt_slot_write(orx_opt* o, orx_table* t, int slot, int64_t row0, int64_t nrows, const float* host_src) {
+    if (t) CHECK(orx_table_sync(t));
     float* p = nullptr;
     CHECK(slot_ptr(o, t, slot, &p));
     return rows_copy(t->ctx, p, t->rows, t->dim, row0, nrows, (float*)host_src, false);
@@ -522,6 +594,12 @@ void orx_exact_step_views(orx_ctx* c, const PairPlan& plan, int64_t i, int64_t B
     }
 }
 
+// TF-2.0 Adam applied lazily (see orx_pairwise_step): float4 dims, role bits available, no censor, not hogwild
+static bool lazy_adam_ok(const orx_opt* opt, const orx_table* U, const orx_table* V, int flags) {
+    return opt->kind == ORX_ADAM && !(flags & (ORX_HOGWILD | ORX_CENSOR)) && orx_fused_can_inline_apply(U->dim) &&
+           U->rows < (1LL << 28) && V->rows < (1LL << 28) && getenv("ORX_ADAM_DENSE") == nullptr;
+}
+
 extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
                                  orx_table* U, orx_table* V, orx_table* b,
                                  const int32_t* uid, const int32_t* pid, const int32_t* nid,
@@ -543,7 +621,16 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     CHECK(stage_triplets(c, uid, pid, nid, K, B, id_stride, flags, &du, &dp, &dn, &ds));
 
     const bool hogwild = (flags & ORX_HOGWILD) != 0;
-    const int mode = opt->kind == ORX_ADAM ? MODE_ACCUM : (hogwild ? MODE_HOGWILD : MODE_EXACT);
+    // TF-2.0 Adam decays m, v and moves var on EVERY row every step.  On the float4 dims that is applied lazily and
+    // exactly: a row's gradient-free steps are replayed when the row is next touched (or observed: orx_table_sync);
+    // the dense form (every reference accumulates, then three whole-table sweeps per step) remains for the other
+    // cases and behind ORX_ADAM_DENSE=1.
+    const bool lazy_adam = lazy_adam_ok(opt, U, V, flags);
+    const int mode = (opt->kind == ORX_ADAM && !lazy_adam) ? MODE_ACCUM : (hogwild ? MODE_HOGWILD : MODE_EXACT);
+    // the three tables are lazy together under one optimizer (the item rows and their biases then share step stamps),
+    // or not at all: anything else first brings every row up to date
+    const bool lazy_resume = lazy_adam && U->lazy == opt && V->lazy == opt && b->lazy == opt;
+    if (!lazy_resume) for (orx_table* t : {U, V, b}) CHECK(orx_table_sync(t));
     // rows referenced exactly twice get plain stores into two scratch rows; the role of a reference
     // travels in bits 30:29 of its id, which needs tables below 2^29 rows
     // ORX_FORCE_FALLBACK (debug / tests): bit 0 = behave as if the tables had >= 2^28 rows (no role bits: every
@@ -586,6 +673,15 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     a.invB = 1.0f / (float)B;
     a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f;
     a.err = c->d_err;
+    if (lazy_adam) {
+        a.a2U = sU.s1; a.a2V = sV.s1; a.a2b = sb.s1;
+        CHECK(orx_opt_last(opt, U, !lazy_resume, &a.lastU)); CHECK(orx_opt_last(opt, V, !lazy_resume, &a.lastV));
+        CHECK(orx_opt_last(opt, b, !lazy_resume, &a.lastb));
+        CHECK(orx_adam_lrt(opt, opt->t + K));
+        a.lrt = opt->d_lrt; a.b1 = opt->p0; a.b2 = opt->p1; a.eps = opt->p2;
+        a.newton = (1.0f - sqrtf(opt->p1)) <= 1e-3f && getenv("ORX_ADAM_NO_NEWTON") == nullptr;
+        U->lazy = opt; V->lazy = opt; b->lazy = opt;
+    }
     // epochs are consumed one per step; on wrap-around every table clears its epoch-tagged arrays
     if ((int64_t)c->epoch + K + 16 > 0x7fffffff) { c->epoch = 0; c->epoch_gen += 1; }
     for (orx_table* t : {U, V}) {
@@ -632,6 +728,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             orx_exact_step_views(c, plan, i, B, U->dim, use_stage, &a);
             a.partial = c->d_partial + (size_t)i * nw * 2;
             a.epoch = ++c->epoch;           // one epoch per step: ready flags and censor side marks are tagged with it
+            if (lazy_adam) { opt->t += 1; a.step_t = (int)opt->t; }
             if (inl && i > 0) {    // this launch also applies the duplicated rows of step i-1
                 // one lane group per duplicated row in a single pass for the usual ~0.15*B duplicated rows
                 // (the count lives in device memory; surplus blocks exit, a larger count grid-strides)
@@ -673,7 +770,7 @@ extern "C" int orx_pairwise_reserve(orx_ctx* c, orx_opt* opt, orx_table* U, orx_
     CHECK(check_pair_tables(U, V, b));
     ORX_ARG(K > 0 && B > 0, "orx_pairwise_reserve: K and B must be positive");
     ORX_HIP(hipSetDevice(c->device));
-    const int mode = opt->kind == ORX_ADAM ? MODE_ACCUM : MODE_EXACT;
+    const int mode = (opt->kind == ORX_ADAM && !lazy_adam_ok(opt, U, V, 0)) ? MODE_ACCUM : MODE_EXACT;
     const bool role_bits = mode == MODE_EXACT && U->rows < (1LL << 28) && V->rows < (1LL << 28);
     const bool inline_apply = role_bits && K > 1 && orx_fused_can_inline_apply(U->dim);
     const bool staging = role_bits && orx_fused_can_inline_apply(U->dim);
@@ -690,6 +787,9 @@ extern "C" int orx_pairwise_reserve(orx_ctx* c, orx_opt* opt, orx_table* U, orx_
 extern "C" int orx_pairwise_loss(orx_ctx* c, int model, orx_table* U, orx_table* V, orx_table* b,
                                  const int32_t* uid, const int32_t* pid, const int32_t* nid,
                                  int64_t B, float margin, int flags, float* loss_out, float* l2_out) {
+    if (U) CHECK(orx_table_sync(U));
+    if (V) CHECK(orx_table_sync(V));
+    if (b) CHECK(orx_table_sync(b));
     ORX_ARG(c, "orx_pairwise_loss: NULL context");
     ORX_ARG(model == ORX_BPR || model == ORX_UCML, "orx_pairwise_loss: unknown model %d", model);
     CHECK(check_pair_tables(U, V, b));

@@ -48,6 +48,10 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
                                   const int32_t* uid, const int32_t* iid, const float* label,
                                   int64_t K, int64_t B, int64_t id_stride, float a_w, float b_w, int flags,
                                   float* loss_out, float* l2_out) {
+    if (U) CHECK(orx_table_sync(U));
+    if (V) CHECK(orx_table_sync(V));
+    if (b) CHECK(orx_table_sync(b));
+    if (w) CHECK(orx_table_sync(w));
     ORX_ARG(c && opt, "orx_pointwise_step: NULL context/optimizer");
     CHECK(check_point_tables(model, U, V, b, w));
     ORX_ARG(K >= 0 && B > 0, "orx_pointwise_step: K must be >= 0 and B > 0");
@@ -168,6 +172,10 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
 extern "C" int orx_pointwise_loss(orx_ctx* c, int model, orx_table* U, orx_table* V, orx_table* b, orx_table* w,
                                   const int32_t* uid, const int32_t* iid, const float* label,
                                   int64_t B, float a_w, float b_w, int flags, float* loss_out, float* l2_out) {
+    if (U) CHECK(orx_table_sync(U));
+    if (V) CHECK(orx_table_sync(V));
+    if (b) CHECK(orx_table_sync(b));
+    if (w) CHECK(orx_table_sync(w));
     ORX_ARG(c, "orx_pointwise_loss: NULL context");
     CHECK(check_point_tables(model, U, V, b, w));
     ORX_ARG(B > 0 && uid && iid && label, "orx_pointwise_loss: empty batch or NULL pointer");
@@ -197,6 +205,10 @@ extern "C" int orx_pointwise_loss(orx_ctx* c, int model, orx_table* U, orx_table
 
 extern "C" int orx_score_all_items(orx_ctx* c, int kind, orx_table* U, orx_table* V, orx_table* b, orx_table* w,
                                    const int32_t* uid, int64_t n, float* out) {
+    if (U) CHECK(orx_table_sync(U));
+    if (V) CHECK(orx_table_sync(V));
+    if (b) CHECK(orx_table_sync(b));
+    if (w) CHECK(orx_table_sync(w));
     ORX_ARG(c && U && V && b && (n == 0 || (uid && out)), "orx_score_all_items: NULL argument");
     ORX_ARG(kind >= 0 && kind <= 2, "orx_score_all_items: unknown kind %d", kind);
     ORX_ARG(U->dim == V->dim && b->rows == V->rows && b->dim == 1, "orx_score_all_items: table shapes do not match");
@@ -214,6 +226,8 @@ extern "C" int orx_score_all_items(orx_ctx* c, int kind, orx_table* U, orx_table
 
 extern "C" int orx_gather_rows(orx_ctx* ctx, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
                                float* out, int64_t out_stride) {
+    if (t) CHECK(orx_table_sync(t));
+    if (bias) CHECK(orx_table_sync(bias));
     ORX_ARG(ctx && t && (n == 0 || (ids && out)), "orx_gather_rows: NULL argument");
     ORX_ARG(out_stride >= t->dim + (bias ? 1 : 0), "orx_gather_rows: out_stride %lld too small", (long long)out_stride);
     ORX_HIP(hipSetDevice(ctx->device));
@@ -247,6 +261,8 @@ extern "C" int orx_pair_grads(orx_ctx* ctx, int model, int32_t D,
 
 extern "C" int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias,
                               const int32_t* ids, int64_t n, const float* grads, int64_t g_stride) {
+    if (t) CHECK(orx_table_sync(t));
+    if (bias) CHECK(orx_table_sync(bias));
     ORX_ARG(ctx && opt && t && (n == 0 || (ids && grads)), "orx_apply_rows: NULL argument");
     ORX_ARG(opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD || (opt->kind == ORX_ADAM && !bias),
             "orx_apply_rows: SGD and Adagrad (and Adam without a bias column) are supported");
@@ -369,6 +385,8 @@ extern "C" int orx_rows_dupflags(orx_ctx* ctx, int64_t rows, const int32_t* ids,
 // orx_apply_rows for SGD with the duplicate flags of the id list already known (orx_rows_dupflags)
 extern "C" int orx_apply_rows_flagged(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
                                       const float* grads, int64_t g_stride, const unsigned char* dflag) {
+    if (t) CHECK(orx_table_sync(t));
+    if (bias) CHECK(orx_table_sync(bias));
     ORX_ARG(ctx && opt && t && (n == 0 || (ids && grads && dflag)), "orx_apply_rows_flagged: NULL argument");
     ORX_ARG(opt->kind == ORX_SGD, "orx_apply_rows_flagged: SGD only (Adagrad / Adam: orx_apply_rows)");
     ORX_ARG(g_stride >= t->dim + (bias ? 1 : 0), "orx_apply_rows_flagged: g_stride too small");
@@ -465,6 +483,7 @@ extern "C" int orx_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, i
 extern "C" int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const float* rows_in, const int32_t* u_loc,
                                const int32_t* slot, int64_t T, int64_t row_stride, int64_t B_global, float margin, int flags,
                                float* gu, float* send_g, double* loss_l2_accum) {
+    if (user) CHECK(orx_table_sync(user));
     ORX_ARG(ctx && user && rows_in && u_loc && slot && gu && send_g, "orx_shard_grads: NULL argument");
     ORX_ARG(model == ORX_BPR || model == ORX_UCML, "orx_shard_grads: unknown model %d", model);
     ORX_ARG(row_stride > user->dim && B_global > 0, "orx_shard_grads: row_stride must leave room for the bias column");
@@ -488,6 +507,10 @@ extern "C" int orx_rank_metrics(orx_ctx* c, int kind, orx_table* U, orx_table* V
                                 const int32_t* uid, const float* pred, const uint8_t* pos_mask, const uint8_t* excl_mask,
                                 int64_t n, int64_t items, const float* at, int32_t nat,
                                 float* auc, float* ndcg, float* recall) {
+    if (U) CHECK(orx_table_sync(U));
+    if (V) CHECK(orx_table_sync(V));
+    if (b) CHECK(orx_table_sync(b));
+    if (w) CHECK(orx_table_sync(w));
     ORX_ARG(c && pos_mask && excl_mask && at, "orx_rank_metrics: NULL argument");
     ORX_ARG(nat >= 1 && nat <= 16, "orx_rank_metrics: nat must be in [1, 16]");
     ORX_ARG(pred || (U && V && b && uid), "orx_rank_metrics: need either pred or tables + user ids");

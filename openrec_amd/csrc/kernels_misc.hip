@@ -1,6 +1,6 @@
 // Table utility kernels: initializers, Embedding gather (LatentFactor.__call__),
 // LatentFactor.censor, and the Adam dense-decay sweep.  gfx950.
-#include "orx_internal.h"
+#include "orx_device.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -149,11 +149,11 @@ __global__ __launch_bounds__(256) void adam_sweep_kernel(float* w, float* m, flo
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float g = gsum[i];
         if (g != 0.0f) gsum[i] = 0.0f;
-        const float mi = b1 * m[i] + (1.0f - b1) * g;
-        const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+        float wi = w[i], mi = m[i], vi = v[i];
+        adam_elem(wi, mi, vi, g, lr_t, b1, b2, eps);
         m[i] = mi;
         v[i] = vi;
-        w[i] = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+        w[i] = wi;
     }
 }
 
@@ -163,4 +163,40 @@ int orx_launch_adam_sweep(orx_ctx* ctx, float* w, float* m, float* v, float* gsu
     ORX_LAUNCH(ctx, adam_sweep_kernel, dim3(grid_for(n, 256)), dim3(256), 0, w, m, v, gsum, n, lr_t, b1, b2, eps);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
+}
+
+// lazy Adam: bring every row of a table up to optimizer step t_end (replaying its gradient-free steps), then
+// mark the rows current.  Two kernels: all elements of a row read last[row] before it changes.
+__global__ __launch_bounds__(256) void adam_flush_kernel(float* w, float* m, float* v, const int* last, int64_t n, int dim, int t_end,
+                                                         const float* lrt, float b1, float b2, float eps) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int from = last[i / dim];
+        if (from >= t_end) continue;
+        float wi = w[i], mi = m[i], vi = v[i];
+        adam_catchup1(wi, mi, vi, from, t_end, lrt, b1, b2, eps);
+        w[i] = wi; m[i] = mi; v[i] = vi;
+    }
+}
+
+__global__ void fill_int_kernel(int* p, int64_t n, int v) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+int orx_launch_fill_int(orx_ctx* ctx, int* p, int64_t n, int v) {
+    if (n == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, fill_int_kernel, dim3(grid_for(n, 256)), dim3(256), 0, p, n, v);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_launch_adam_flush(orx_ctx* ctx, float* w, float* m, float* v, int* last, int64_t rows, int dim, int t_end, const float* lrt,
+                          float b1, float b2, float eps) {
+    ProfScope ps(ctx, ORX_K_SWEEP);
+    const int64_t n = rows * dim;
+    if (n == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, adam_flush_kernel, dim3(grid_for(n, 256)), dim3(256), 0, w, m, v, last, n, dim, t_end, lrt, b1, b2, eps);
+    ORX_HIP(hipGetLastError());
+    return orx_launch_fill_int(ctx, last, rows, t_end);
 }

@@ -523,12 +523,26 @@ __device__ __forceinline__ void inline_apply(const PairArgs& a) {
         else g = *reinterpret_cast<const f4*>(g1) + *reinterpret_cast<const f4*>(g2);
         const f4 w = *reinterpret_cast<const f4*>(wp);
         f4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
-        if (OPT == ORX_ADAGRAD) acc = *reinterpret_cast<const f4*>(A + row * D + 4 * sub);
+        if (OPT == ORX_ADAGRAD || OPT == ORX_ADAM) acc = *reinterpret_cast<const f4*>(A + row * D + 4 * sub);
         float ac[4] = {acc.x, acc.y, acc.z, acc.w};
         f4 wn;
+        f4 vv; vv.x = vv.y = vv.z = vv.w = 0.0f;           // Adam v (acc holds m)
+        if (OPT == ORX_ADAM) {
+            // lazy Adam: the rows of step s-1 (optimizer step step_t - 1) are first caught up, then take their step
+            float* A2 = item ? a.a2V : a.a2U;
+            int* L = item ? a.lastV : a.lastU;
+            vv = *reinterpret_cast<const f4*>(A2 + row * D + 4 * sub);
+            wn = w;
+            const int tp = a.step_t - 1;
+            adam_catchup4(wn, acc, vv, L[row], tp - 1, a.lrt, a.b1, a.b2, a.eps);
+            adam_elem4(wn, acc, vv, g, a.lrt[tp], a.b1, a.b2, a.eps);
+            store_wt4(A2 + row * D + 4 * sub, vv);
+            if (sub == 0) __hip_atomic_store(L + row, tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
         wn.x = opt_rule<OPT>(w.x, g.x, ac[0], a.lr, a.eps); wn.y = opt_rule<OPT>(w.y, g.y, ac[1], a.lr, a.eps);
         wn.z = opt_rule<OPT>(w.z, g.z, ac[2], a.lr, a.eps); wn.w = opt_rule<OPT>(w.w, g.w, ac[3], a.lr, a.eps);
         acc.x = ac[0]; acc.y = ac[1]; acc.z = ac[2]; acc.w = ac[3];
+        }
         if (CENSOR) {                   // the rows of step s-1 are censored where they are applied
             wn = censor4<LPR>(wn, a.min_norm);
             if (item && censored_twice(a, row, a.epoch - 1)) wn = censor4<LPR>(wn, a.min_norm);
@@ -536,16 +550,27 @@ __device__ __forceinline__ void inline_apply(const PairArgs& a) {
         f4 z; z.x = z.y = z.z = z.w = 0.0f;
         store_wt4(wp, wn);
         if (!STAGED || scnt <= 0) { store_wt4(g1, z); store_wt4(g2, z); }
-        if (OPT == ORX_ADAGRAD) store_wt4(A + row * D + 4 * sub, acc);
+        if (OPT == ORX_ADAGRAD || OPT == ORX_ADAM) store_wt4(A + row * D + 4 * sub, acc);
         float gbs = 0.0f;
         if (STAGED && scnt > 0 && item) gbs = segment_sum1<LPR>(a.prev_stageb, sseg, scnt, sub);
         if (item && sub == 0) {
             const float gb = STAGED && scnt > 0 ? gbs : a.gb[row] + a.gb2[row];
-            float ab = OPT == ORX_ADAGRAD ? a.ab[row] : 0.0f;
-            const float bn = opt_rule<OPT>(a.b[row], gb, ab, a.lr, a.eps);
+            float ab = (OPT == ORX_ADAGRAD || OPT == ORX_ADAM) ? a.ab[row] : 0.0f;
+            float bn;
+            if (OPT == ORX_ADAM) {
+                float bw = a.b[row], bv = a.a2b[row];
+                const int tp = a.step_t - 1;
+                adam_catchup1(bw, ab, bv, a.lastb[row], tp - 1, a.lrt, a.b1, a.b2, a.eps);
+                adam_elem(bw, ab, bv, gb, a.lrt[tp], a.b1, a.b2, a.eps);
+                bn = bw;
+                store_wt(a.a2b + row, bv);
+                __hip_atomic_store(a.lastb + row, tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                bn = opt_rule<OPT>(a.b[row], gb, ab, a.lr, a.eps);
+            }
             store_wt(a.b + row, bn);
             if (!STAGED || scnt <= 0) { store_wt(a.gb + row, 0.0f); store_wt(a.gb2 + row, 0.0f); }
-            if (OPT == ORX_ADAGRAD) store_wt(a.ab + row, ab);
+            if (OPT == ORX_ADAGRAD || OPT == ORX_ADAM) store_wt(a.ab + row, ab);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store of this wave has been written through
         if (sub == 0) __hip_atomic_store((item ? a.readyV : a.readyU) + row, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -616,10 +641,25 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
         float* Up = a.U + (size_t)u * D + 4 * sub;
         float* Pp = a.V + (size_t)p * D + 4 * sub;
         float* Np = a.V + (size_t)n * D + 4 * sub;
-        const f4 ru = *reinterpret_cast<const f4*>(Up);
-        const f4 rp = *reinterpret_cast<const f4*>(Pp);
-        const f4 rn = *reinterpret_cast<const f4*>(Np);
-        const float bp = a.b[p], bn = a.b[n];
+        f4 ru = *reinterpret_cast<const f4*>(Up);
+        f4 rp = *reinterpret_cast<const f4*>(Pp);
+        f4 rn = *reinterpret_cast<const f4*>(Np);
+        float bp = a.b[p], bn = a.b[n];
+        // lazy Adam: (w, m, v) of the three rows and two biases, replayed up to the step before this one -- the
+        // forward then sees exactly what the whole-table sweeps of TF 2.0 would have left
+        f4 mu, vu, mp, vp, mn, vn;
+        float mbp = 0.f, vbp = 0.f, mbn = 0.f, vbn = 0.f;
+        if (OPT == ORX_ADAM) {
+            const int T1 = a.step_t - 1;
+            mu = *reinterpret_cast<const f4*>(a.aU + (size_t)u * D + 4 * sub); vu = *reinterpret_cast<const f4*>(a.a2U + (size_t)u * D + 4 * sub);
+            mp = *reinterpret_cast<const f4*>(a.aV + (size_t)p * D + 4 * sub); vp = *reinterpret_cast<const f4*>(a.a2V + (size_t)p * D + 4 * sub);
+            mn = *reinterpret_cast<const f4*>(a.aV + (size_t)n * D + 4 * sub); vn = *reinterpret_cast<const f4*>(a.a2V + (size_t)n * D + 4 * sub);
+            mbp = a.ab[p]; vbp = a.a2b[p]; mbn = a.ab[n]; vbn = a.a2b[n];
+            // (the bias of an item shares the item row's stamp: the three tables are lazy together, api.hip)
+            const int lu = a.lastU[u], lp = a.lastV[p], ln = a.lastV[n];
+            if (a.newton) adam_catchup_triplet<true, LPR>(ru, mu, vu, lu, rp, mp, vp, lp, rn, mn, vn, ln, bp, mbp, vbp, bn, mbn, vbn, T1, a.lrt, a.b1, a.b2, a.eps);
+            else adam_catchup_triplet<false, LPR>(ru, mu, vu, lu, rp, mp, vp, lp, rn, mn, vn, ln, bp, mbp, vbp, bn, mbn, vbn, T1, a.lrt, a.b1, a.b2, a.eps);
+        }
 
         const float red = group_allreduce<LPR>(score_partial<MODEL>(ru, rp, rn));
         float term, g;
@@ -658,6 +698,43 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             if (du == 0) *reinterpret_cast<f4*>(Up) = wu;
             if (dp == 0) *reinterpret_cast<f4*>(Pp) = wp;
             if (dn == 0) *reinterpret_cast<f4*>(Np) = wn;
+            continue;
+        }
+        if (OPT == ORX_ADAM) {
+            // a row referenced once takes its step here (replayed state + gradient), a duplicated one deposits the gradient
+            const float lrT = a.lrt[a.step_t];
+            if (du == 0) {
+                adam_elem4(ru, mu, vu, gu, lrT, a.b1, a.b2, a.eps);
+                *reinterpret_cast<f4*>(Up) = ru; *reinterpret_cast<f4*>(a.aU + (size_t)u * D + 4 * sub) = mu;
+                *reinterpret_cast<f4*>(a.a2U + (size_t)u * D + 4 * sub) = vu;
+                if (sub == 0) a.lastU[u] = a.step_t;
+            } else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t) : -1, D, sub);
+            if (dp == 0) {
+                adam_elem4(rp, mp, vp, gp, lrT, a.b1, a.b2, a.eps);
+                *reinterpret_cast<f4*>(Pp) = rp; *reinterpret_cast<f4*>(a.aV + (size_t)p * D + 4 * sub) = mp;
+                *reinterpret_cast<f4*>(a.a2V + (size_t)p * D + 4 * sub) = vp;
+                if (sub == 0) {
+                    adam_elem(bp, mbp, vbp, gbp, lrT, a.b1, a.b2, a.eps);
+                    a.b[p] = bp; a.ab[p] = mbp; a.a2b[p] = vbp; a.lastV[p] = a.step_t; a.lastb[p] = a.step_t;
+                }
+            } else {
+                const int sp = kp == 2 ? slot_of(Bp + t) : -1;
+                dup_store4s(a.gV, a.gV2, (size_t)p * D + 4 * sub, gp, kp, a.stage, sp, D, sub);
+                if (sub == 0) dup_store1s(a.gb, a.gb2, p, gbp, kp, a.stageb, sp);
+            }
+            if (dn == 0) {
+                adam_elem4(rn, mn, vn, gn, lrT, a.b1, a.b2, a.eps);
+                *reinterpret_cast<f4*>(Np) = rn; *reinterpret_cast<f4*>(a.aV + (size_t)n * D + 4 * sub) = mn;
+                *reinterpret_cast<f4*>(a.a2V + (size_t)n * D + 4 * sub) = vn;
+                if (sub == 0) {
+                    adam_elem(bn, mbn, vbn, gbn, lrT, a.b1, a.b2, a.eps);
+                    a.b[n] = bn; a.ab[n] = mbn; a.a2b[n] = vbn; a.lastV[n] = a.step_t; a.lastb[n] = a.step_t;
+                }
+            } else {
+                const int sn = kn == 2 ? slot_of(2 * Bp + t) : -1;
+                dup_store4s(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn, a.stage, sn, D, sub);
+                if (sub == 0) dup_store1s(a.gb, a.gb2, n, gbn, kn, a.stageb, sn);
+            }
             continue;
         }
         if (du == 0) opt_apply4<OPT>(Up, a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
@@ -726,7 +803,16 @@ __global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
                 *reinterpret_cast<f4*>(G2 + row * D + 4 * sub) = z;
             }
         }
-        if (a.censor) {
+        if (OPT == ORX_ADAM) {
+            float* A2 = item ? a.a2V : a.a2U;
+            int* L = item ? a.lastV : a.lastU;
+            f4 wn = w;
+            f4 mm = *reinterpret_cast<const f4*>(A + row * D + 4 * sub), vv = *reinterpret_cast<const f4*>(A2 + row * D + 4 * sub);
+            adam_catchup4(wn, mm, vv, L[row], a.step_t - 1, a.lrt, a.b1, a.b2, a.eps);
+            adam_elem4(wn, mm, vv, g, a.lrt[a.step_t], a.b1, a.b2, a.eps);
+            *reinterpret_cast<f4*>(wp) = wn; *reinterpret_cast<f4*>(A + row * D + 4 * sub) = mm; *reinterpret_cast<f4*>(A2 + row * D + 4 * sub) = vv;
+            if (sub == 0) L[row] = a.step_t;
+        } else if (a.censor) {
             f4 wn = censor4<LPR>(opt_new4<OPT>(A + row * D + 4 * sub, w, g, a.lr, a.eps), a.min_norm);
             if (item && censored_twice(a, row, a.epoch)) wn = censor4<LPR>(wn, a.min_norm);
             *reinterpret_cast<f4*>(wp) = wn;
@@ -743,7 +829,14 @@ __global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
                 a.gb[row] = 0.0f;
                 if (a.gb2 != nullptr) { gb += a.gb2[row]; a.gb2[row] = 0.0f; }
             }
-            opt_apply1<OPT>(a.b + row, a.ab + row, a.b[row], gb, a.lr, a.eps);
+            if (OPT == ORX_ADAM) {
+                float bw = a.b[row], bm = a.ab[row], bv = a.a2b[row];
+                adam_catchup1(bw, bm, bv, a.lastb[row], a.step_t - 1, a.lrt, a.b1, a.b2, a.eps);
+                adam_elem(bw, bm, bv, gb, a.lrt[a.step_t], a.b1, a.b2, a.eps);
+                a.b[row] = bw; a.ab[row] = bm; a.a2b[row] = bv; a.lastb[row] = a.step_t;
+            } else {
+                opt_apply1<OPT>(a.b + row, a.ab + row, a.b[row], gb, a.lr, a.eps);
+            }
         }
     }
 }
@@ -961,10 +1054,32 @@ static void launch_fused_lpr(int lpr, int mode, dim3 g, orx_ctx* s, const PairAr
 
 int orx_fused_can_inline_apply(int D) { return lpr_for_dim(D) != 0; }
 
+// lazy Adam (exact mode, float4 dims, no censor): its own small set of instantiations
+template <int MODEL>
+static void launch_fused_adam(int lpr, dim3 g, orx_ctx* s, const PairArgs& a) {
+#define ORX_FA(L) do { if (a.stage) ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, true>), g, dim3(256), 0, a); \
+                       else ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, false>), g, dim3(256), 0, a); } while (0)
+    switch (lpr) {
+        case 4: ORX_FA(4); break;
+        case 8: ORX_FA(8); break;
+        case 16: ORX_FA(16); break;
+        case 32: ORX_FA(32); break;
+        default: ORX_FA(64); break;
+    }
+#undef ORX_FA
+}
+
 int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairArgs& a) {
     ProfScope ps(ctx, ORX_K_FUSED);
     const int lpr = lpr_for_dim(a.D);
     const dim3 g((unsigned)(fused_grid(a.D, a.B) + (mode == MODE_EXACT ? a.n_apply_blocks : 0)));
+    if (optkind == ORX_ADAM && mode == MODE_EXACT) {
+        ORX_ARG(lpr != 0 && a.lrt != nullptr && !a.censor, "fused: the lazy Adam path needs a float4 dim and no fused censor");
+        if (model == ORX_BPR) launch_fused_adam<ORX_BPR>(lpr, g, ctx, a);
+        else launch_fused_adam<ORX_UCML>(lpr, g, ctx, a);
+        ORX_HIP(hipGetLastError());
+        return ORX_OK;
+    }
     const int ok = (optkind == ORX_ADAGRAD) ? ORX_ADAGRAD : ORX_SGD;
     if (model == ORX_BPR) {
         if (ok == ORX_ADAGRAD) launch_fused_lpr<ORX_BPR, ORX_ADAGRAD>(lpr, mode, g, ctx, a);
@@ -1013,7 +1128,15 @@ int orx_launch_dup_apply(orx_ctx* ctx, int optkind, const PairArgs& a) {
     if (want > 2048) want = 2048;
     if (want < 64) want = 64;
     const dim3 g((unsigned)want);
-    if (optkind == ORX_ADAGRAD) launch_dup_apply_lpr<ORX_ADAGRAD>(lpr, g, ctx, a);
+    if (optkind == ORX_ADAM && a.lrt != nullptr && lpr != 0) {       // lazy Adam (never the generic-dim kernel)
+        switch (lpr) {
+            case 4: ORX_LAUNCH(ctx, (dup_apply_kernel<4, ORX_ADAM>), g, dim3(256), 0, a); break;
+            case 8: ORX_LAUNCH(ctx, (dup_apply_kernel<8, ORX_ADAM>), g, dim3(256), 0, a); break;
+            case 16: ORX_LAUNCH(ctx, (dup_apply_kernel<16, ORX_ADAM>), g, dim3(256), 0, a); break;
+            case 32: ORX_LAUNCH(ctx, (dup_apply_kernel<32, ORX_ADAM>), g, dim3(256), 0, a); break;
+            default: ORX_LAUNCH(ctx, (dup_apply_kernel<64, ORX_ADAM>), g, dim3(256), 0, a); break;
+        }
+    } else if (optkind == ORX_ADAGRAD) launch_dup_apply_lpr<ORX_ADAGRAD>(lpr, g, ctx, a);
     else launch_dup_apply_lpr<ORX_SGD>(lpr, g, ctx, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;

@@ -137,6 +137,123 @@ __device__ __forceinline__ void opt_apply1(float* w_ptr, float* a_ptr, float w_o
     }
 }
 
+// ------------------------------------------------------------------ Adam ---
+// One element of keras.optimizers.Adam in TF 2.0 (dense and sparse apply share it): the SAME expression is used by
+// the whole-table sweep, the lazy catch-up (g = 0) and the fused step, so a replayed step rounds like a swept one.
+__device__ __forceinline__ void adam_elem(float& w, float& m, float& v, float g, float lr_t, float b1, float b2, float eps) {
+    const float mi = b1 * m + (1.0f - b1) * g;
+    const float vi = b2 * v + (1.0f - b2) * g * g;
+    m = mi;
+    v = vi;
+    w = w - lr_t * mi / (sqrtf(vi) + eps);
+}
+
+__device__ __forceinline__ void adam_elem4(f4& w, f4& m, f4& v, f4 g, float lr_t, float b1, float b2, float eps) {
+    float wx = w.x, wy = w.y, wz = w.z, ww = w.w, mx = m.x, my = m.y, mz = m.z, mw = m.w, vx = v.x, vy = v.y, vz = v.z, vw = v.w;
+    adam_elem(wx, mx, vx, g.x, lr_t, b1, b2, eps); adam_elem(wy, my, vy, g.y, lr_t, b1, b2, eps);
+    adam_elem(wz, mz, vz, g.z, lr_t, b1, b2, eps); adam_elem(ww, mw, vw, g.w, lr_t, b1, b2, eps);
+    w.x = wx; w.y = wy; w.z = wz; w.w = ww; m.x = mx; m.y = my; m.z = mz; m.w = mw; v.x = vx; v.y = vy; v.z = vz; v.w = vw;
+}
+
+// Replay of the gradient-free steps from+1 .. to of a row slice.  With g = 0 the rule is m <- b1*m, v <- b2*v,
+// w <- w - lr_k * m / (sqrt(v) + eps): m and v take the same multiplies as the whole-table sweep (bit-identical
+// slots); sqrt(v) follows as s <- sqrt(b2)*s from one square root, and the quotient uses the hardware reciprocal
+// (1 ulp).  The replayed var differs from the sweep's by rounding of the update term only (~1e-7 of an update).
+__device__ __forceinline__ f4 sqrt4(f4 v) { f4 r; r.x = sqrtf(v.x); r.y = sqrtf(v.y); r.z = sqrtf(v.z); r.w = sqrtf(v.w); return r; }
+__device__ __forceinline__ f4 rcp4(f4 v) {
+    f4 r; r.x = __builtin_amdgcn_rcpf(v.x); r.y = __builtin_amdgcn_rcpf(v.y); r.z = __builtin_amdgcn_rcpf(v.z); r.w = __builtin_amdgcn_rcpf(v.w);
+    return r;
+}
+
+__device__ __forceinline__ void adam_catchup4(f4& w, f4& m, f4& v, int from, int to, const float* lrt, float b1, float b2, float eps) {
+    if (from >= to) return;
+    f4 s = sqrt4(v);
+    const float sb2 = sqrtf(b2);
+    for (int k = from + 1; k <= to; ++k) {
+        m = m * b1; v = v * b2; s = s * sb2;
+        w = w - (lrt[k] * m) * rcp4(s + eps);
+    }
+}
+
+__device__ __forceinline__ void adam_catchup1(float& w, float& m, float& v, int from, int to, const float* lrt, float b1, float b2, float eps) {
+    if (from >= to) return;
+    float s = sqrtf(v);
+    const float sb2 = sqrtf(b2);
+    for (int k = from + 1; k <= to; ++k) {
+        m *= b1; v *= b2; s *= sb2;
+        w -= (lrt[k] * m) * __builtin_amdgcn_rcpf(s + eps);
+    }
+}
+
+// scalar (SMEM) load of a wave-uniform table entry, split into issue and wait so that a loop can fetch the next
+// entry under the current iteration's arithmetic (the compiler emits VMEM loads for a pointer it cannot prove
+// read-only, and waits for them with vmcnt(0) at the loop back-edge)
+__device__ __forceinline__ float sload_issue(const float* p, int idx) {
+    float v;
+    asm volatile("s_load_dword %0, %1, %2" : "=s"(v) : "s"(p), "s"(idx * 4));
+    return v;
+}
+__device__ __forceinline__ float sload_wait(float v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v));
+    return v;
+}
+
+// the three rows (and the two item biases, which share their item row's stamp) of one triplet in ONE loop: its trip
+// count is the longest of the three gaps, not their sum, and the three chains interleave.  A row whose gap is
+// shorter is masked out of the early iterations.
+// The denominator d = sqrt(v) + eps follows d <- sqrt(b2)*d + eps*(1 - sqrt(b2)) (one fma).  NEWTON: its reciprocal
+// is carried along by one Newton step per replayed step, r <- r*(2 - d*r): d moves by 1 - sqrt(b2) (5e-4 at the
+// default beta_2) per step, so the carried reciprocal stays within (5e-4)^2 = 2.5e-7 of exact with no
+// quarter-rate v_rcp in the loop; the caller selects it only for 1 - sqrt(b2) <= 1e-3.
+// The loop counter is wave-uniform (it starts at the smallest stamp of the wavefront's active lane groups: the
+// hardware loop runs to the longest gap of the wavefront either way), which makes lr_k a scalar load, fetched
+// two iterations ahead.
+template <bool NEWTON, int LPR>
+__device__ __forceinline__ void adam_catchup_triplet(f4& wu, f4& mu, f4& vu, int lu, f4& wp, f4& mp, f4& vp, int lp,
+                                                     f4& wn, f4& mn, f4& vn, int ln, float& bp, float& mbp, float& vbp,
+                                                     float& bn, float& mbn, float& vbn, int to, const float* lrt,
+                                                     float b1, float b2, float eps) {
+    const int mine = min(lu, min(lp, ln));
+    const unsigned long long act = __ballot(1);
+    int first = to;
+#pragma unroll
+    for (int g = 0; g < 64 / LPR; ++g) {
+        const int other = __builtin_amdgcn_readlane(mine, g * LPR);
+        if ((act >> (g * LPR)) & 1) first = min(first, other);
+    }
+    if (first >= to) return;
+    const float sb2 = sqrtf(b2);
+    const float ce = eps * (1.0f - sb2);
+    f4 du = sqrt4(vu) + eps, dp = sqrt4(vp) + eps, dn = sqrt4(vn) + eps;
+    float dbp = sqrtf(vbp) + eps, dbn = sqrtf(vbn) + eps;
+    f4 qu = rcp4(du), qp = rcp4(dp), qn = rcp4(dn);
+    float qbp = __builtin_amdgcn_rcpf(dbp), qbn = __builtin_amdgcn_rcpf(dbn);
+    float nxt = sload_wait(sload_issue(lrt, first + 1));
+    for (int k = first + 1; k <= to; ++k) {
+        const float lr = nxt;
+        nxt = sload_issue(lrt, k + 1);                          // (the table is allocated well past `to`)
+        // a row whose stamp is later than k sits this iteration out (EXEC mask; skipped when no lane group needs it)
+        if (k > lu) {
+            mu = mu * b1; vu = vu * b2; du = du * sb2 + ce;
+            if (NEWTON) qu = qu * (2.0f - du * qu); else qu = rcp4(du);
+            wu = wu - (lr * mu) * qu;
+        }
+        if (k > lp) {
+            mp = mp * b1; vp = vp * b2; dp = dp * sb2 + ce;
+            mbp *= b1; vbp *= b2; dbp = dbp * sb2 + ce;
+            if (NEWTON) { qp = qp * (2.0f - dp * qp); qbp = qbp * (2.0f - dbp * qbp); } else { qp = rcp4(dp); qbp = __builtin_amdgcn_rcpf(dbp); }
+            wp = wp - (lr * mp) * qp; bp -= (lr * mbp) * qbp;
+        }
+        if (k > ln) {
+            mn = mn * b1; vn = vn * b2; dn = dn * sb2 + ce;
+            mbn *= b1; vbn *= b2; dbn = dbn * sb2 + ce;
+            if (NEWTON) { qn = qn * (2.0f - dn * qn); qbn = qbn * (2.0f - dbn * qbn); } else { qn = rcp4(dn); qbn = __builtin_amdgcn_rcpf(dbn); }
+            wn = wn - (lr * mn) * qn; bn -= (lr * mbn) * qbn;
+        }
+        nxt = sload_wait(nxt);
+    }
+}
+
 // ------------------------------------------------- duplicated-row deposits ---
 // Gradient of a duplicated reference.  Rows referenced exactly twice in the batch get one PLAIN
 // store per reference, into scratch row 1 (role 0) or scratch row 2 (role 1): no atomics and a

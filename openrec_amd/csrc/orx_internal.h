@@ -91,11 +91,13 @@ struct orx_table {
     int* ready = nullptr;             // [rows] ready flags of the in-launch duplicate apply
     int tag_gen = 0;                  // ctx->epoch_gen the ready / side tags belong to
     int* side = nullptr;              // [rows][2] fused censor: last epoch with a duplicated pos / neg reference
+    struct orx_opt* lazy = nullptr;   // lazily-applied Adam: rows are caught up on demand (orx_table_sync flushes)
 };
 
 struct OptSlots {
     float* s0 = nullptr;              // Adagrad acc / Adam m
     float* s1 = nullptr;              // Adam v
+    int* last = nullptr;              // lazy Adam: optimizer step up to which (w, m, v) of the row are current
 };
 
 struct orx_opt {
@@ -104,7 +106,18 @@ struct orx_opt {
     float lr = 0.01f, p0 = 0.f, p1 = 0.f, p2 = 0.f;
     int64_t t = 0;                    // Adam step counter
     std::map<orx_table*, OptSlots> slots;
+    // lazy Adam: lr_t of every step taken so far (index = step), host mirror + device copy
+    std::vector<float> h_lrt; float* d_lrt = nullptr; size_t lrt_cap = 0; int64_t lrt_uploaded = 0;
 };
+// Lazily-applied TF-2.0 Adam: the dense decay of a row that no triplet touches (m *= b1, v *= b2, w -= lr_t m /
+// (sqrt(v)+eps), every step) is replayed exactly when the row is next needed.  orx_table_sync brings every row of a
+// table up to the optimizer's current step; every entry point that reads or writes a table calls it first.
+int orx_table_sync(orx_table* t);
+int orx_opt_last(orx_opt* o, orx_table* t, bool restamp, int** out);            // allocate / fetch the per-row step stamps
+int orx_launch_fill_int(orx_ctx* ctx, int* p, int64_t n, int v);
+int orx_adam_lrt(orx_opt* o, int64_t upto);                      // make lr_t of steps 1..upto available on the device
+int orx_launch_adam_flush(orx_ctx* ctx, float* w, float* m, float* v, int* last, int64_t rows, int dim, int t_end, const float* lrt,
+                          float b1, float b2, float eps);
 
 // ------------------------------------------------------- helpers (api.hip) ---
 int orx_ensure(void** p, size_t* cap, size_t bytes);           // grow a device buffer
@@ -140,7 +153,11 @@ struct PairArgs {
     float* U; float* V; float* b;
     float* gU; float* gV; float* gb;          // duplicate-row gradient sums (zero between steps)
     float* gU2; float* gV2; float* gb2;       // second scratch rows (rows referenced exactly twice), may be NULL
-    float* aU; float* aV; float* ab;          // Adagrad accumulators
+    float* aU; float* aV; float* ab;          // Adagrad accumulators / Adam m
+    float* a2U; float* a2V; float* a2b;       // Adam v
+    int* lastU; int* lastV; int* lastb;       // lazy Adam: per-row step stamps (NULL: not the lazy Adam path)
+    const float* lrt; float b1; float b2; int step_t;   // lr_t per step, betas, index of THIS step (its lr_t = lrt[step_t])
+    int newton;                 // lazy Adam: carry 1/(sqrt(v)+eps) by Newton steps (1 - sqrt(beta_2) <= 1e-3)
     const int32_t* uid; const int32_t* pid; const int32_t* nid;
     int role_bits;                            // ids carry role (bits 30:29) and urgent (bit 28): tables < 2^28 rows
     // in-launch application of the PREVIOUS step's duplicated rows (n_apply_blocks == 0: off)

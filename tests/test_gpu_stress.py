@@ -117,3 +117,53 @@ def test_skewed_items_with_fused_censor():
         assert abs(loss[s] - ref) <= 2e-5 * abs(ref) and abs(l2[s] - l2r) <= 2e-5 * abs(l2r), (s, loss[s], ref)
     for got, want in ((tU.read(), U), (tV.read(), V), (tb.read(), b)):
         assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("cfg", [(3000, 3000, 8192, 12, 64, 0.999), (60000, 50000, 4096, 20, 32, 0.999), (200000, 150000, 16384, 10, 128, 0.999),
+                                 (60000, 50000, 4096, 20, 64, 0.95)])
+def test_lazy_adam_is_the_dense_decay_adam(cfg, monkeypatch):
+    """TF-2.0 Adam moves EVERY row every step (m, v decay; var -= lr_t*m/(sqrt(v)+eps)).  The K-step path applies
+    that lazily (a row replays its gradient-free steps when next touched or read); it is compared with the
+    fp64 statement of the dense rule step by step, across a call boundary, a mid-run read (flush) and a
+    change of learning rate, and with the whole-table-sweep form of the same library (ORX_ADAM_DENSE=1)."""
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    NU, NI, B, K, D, beta2 = cfg                       # beta_2 = 0.95: the replay takes v_rcp instead of Newton steps
+    lr0 = 0.002 if beta2 == 0.999 else 0.0005          # (short v memory: larger normalised steps amplify fp32 rounding)
+    rng = np.random.default_rng(D + K)
+    U32 = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V32 = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b32 = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    uid = rng.integers(0, NU, (3 * K, B)).astype(np.int32); pid = rng.integers(0, NI, (3 * K, B)).astype(np.int32)
+    nid = rng.integers(0, NI, (3 * K, B)).astype(np.int32)
+    results = {}
+    for form in ("lazy", "dense"):
+        if form == "dense":
+            monkeypatch.setenv("ORX_ADAM_DENSE", "1")
+        tU = rt.Table(NU, D).write(U32); tV = rt.Table(NI, D).write(V32); tb = rt.Table(NI, 1).write(b32)
+        opt = rt.Optimizer.adam(lr0, 0.9, beta2, 1e-7)
+        losses = []
+        for rep in range(3):
+            sl = slice(rep * K, (rep + 1) * K)
+            loss, _ = rt.pairwise_step("bpr", opt, tU, tV, tb, uid[sl], pid[sl], nid[sl], K=K, B=B)
+            losses.append(loss.copy())
+            if rep == 0:
+                mid = tV.read().copy()                  # observes the table: every row must be current here
+            if rep == 1:
+                opt.set_lr(lr0 / 2)
+        results[form] = (np.concatenate(losses), mid, tU.read(), tV.read(), tb.read(), opt.slot(tV, 0), opt.slot(tV, 1), opt.slot(tb, 0))
+    U, V, b = U32.astype(np.float64), V32.astype(np.float64), b32.astype(np.float64)
+    oo = orc.AdamTFSparse(lr0, 0.9, beta2, 1e-7)
+    ref_loss = []
+    for s in range(3 * K):
+        if s == 2 * K:
+            oo.lr = lr0 / 2
+        ref, _ = orc.bpr_step(U, V, b, uid[s], pid[s], nid[s], oo)
+        ref_loss.append(ref)
+        if s == K - 1:
+            ref_mid = V.copy()
+    for form, (loss, mid, dU, dV, db, mV, vV, mb) in results.items():
+        assert np.abs(loss - np.array(ref_loss)).max() <= 2e-5 * np.abs(ref_loss).max(), form
+        assert np.abs(mid - ref_mid).max() <= 5e-5 * np.abs(ref_mid).max(), form
+        for dev, host in ((dU, U), (dV, V), (db, b), (mV, oo.m["V"]), (mb, oo.m["b"])):
+            assert np.abs(dev - host).max() <= 5e-5 * np.abs(host).max(), form
+        assert np.abs(vV - oo.v["V"]).max() <= 5e-4 * np.abs(oo.v["V"]).max(), form
