@@ -115,7 +115,8 @@ def bench_dlrm(args, torch, rt, world, rank, local_rank, device, dist):
     if world == 1 and not args.sharded:
         ctx = rt.Context(local_rank)
         m = rt.DLRMModel(ctx=ctx, fp16_mlp=args.fp16_mlp, **cfg)
-        opt = rt.Optimizer.sgd(0.01, ctx=ctx)
+        opt = {"sgd": lambda: rt.Optimizer.sgd(0.01, ctx=ctx), "adagrad": lambda: rt.Optimizer.adagrad(0.01, 0.1, 1e-7, ctx=ctx),
+               "adam": lambda: rt.Optimizer.adam(0.001, ctx=ctx)}[args.opt]()
         es = lambda t: t.element_size()
         run = lambda first, count: m.step_device(opt, dense.data_ptr() + first * B * 13 * es(dense), sparse.data_ptr() + first * B * 26 * es(sparse),
                                                  label.data_ptr() + first * B * es(label), count, B)
@@ -144,7 +145,7 @@ def bench_dlrm(args, torch, rt, world, rank, local_rank, device, dist):
                                   "gemm_ms_per_step": gp["total_ms"] / K, "flops_per_step": flops}}
     else:
         from openrec_amd.sharded_dlrm import ShardedDLRM
-        eng = ShardedDLRM(rank=rank, world=world, device=device, opt="sgd", lr=0.01, seed=0, fp16_mlp=args.fp16_mlp, **cfg)
+        eng = ShardedDLRM(rank=rank, world=world, device=device, opt=args.opt, lr=0.001 if args.opt == "adam" else 0.01, seed=0, fp16_mlp=args.fp16_mlp, **cfg)
         eng.force_collectives = dist is not None
         for s in range(W):
             eng.step(dense[s * B:(s + 1) * B], sparse[s * B:(s + 1) * B], label[s * B:(s + 1) * B])
@@ -174,7 +175,7 @@ def bench_dlrm(args, torch, rt, world, rank, local_rank, device, dist):
             "scaling": "weak", "vs_baseline": None, "dtype": "f16 MFMA MLP products, f32 elsewhere" if args.fp16_mlp else "f32",
             "data": "synthetic",
             "config": {"workload": f"dlrm 26 tables (33.8 M rows x 128), bottom 13-512-256-128, top 479-1024-1024-512-256-1, "
-                                   f"batch={B} samples/GPU, sgd lr=0.01, mse loss", "parallelism": par}}), flush=True)
+                                   f"batch={B} samples/GPU, {args.opt} lr={0.001 if args.opt == 'adam' else 0.01}, mse loss", "parallelism": par}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

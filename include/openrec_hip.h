@@ -44,7 +44,13 @@ enum orx_status {
     ORX_ERR_STATE = -5   /* call sequence error                                */
 };
 
-/* tensorflow.keras.optimizers.* used by tf2_examples/bpr_citeulike.py:31 */
+/* tensorflow.keras.optimizers.* used by tf2_examples/bpr_citeulike.py:31.
+ * ORX_ADAM is the TF-2.0 sparse rule: EVERY row of a table decays (m, v) and moves (var) at every step.
+ * orx_pairwise_step (float4 dims, no censor), orx_dlrm_step and orx_apply_rows apply it lazily: a row takes its
+ * gradient-free steps when it is next referenced, and every entry point that observes a table or its slots
+ * (read / gather / device_ptr / slot_read / inference / another optimizer / orx_opt_destroy) first brings
+ * the rows it exposes up to date, so the result is the dense rule's at every observation.
+ * ORX_ADAM_DENSE=1 in the environment selects the literal whole-table sweeps. */
 enum orx_opt_kind { ORX_SGD = 0, ORX_ADAGRAD = 1, ORX_ADAM = 2 };
 
 /* pairwise recommenders: recommenders/bpr.py:5, recommenders/ucml.py:5 */
@@ -266,7 +272,9 @@ int orx_dlrm_dense_apply(orx_dlrm* m, orx_opt* opt, const float* flat);
  *                 the loss mean is taken over B_global; triplet k is live iff
  *                 valid == NULL or valid[k] >= 0
  *   apply_rows  : optimizer sparse apply of per-occurrence gradient rows
- *                 (SGD: every occurrence accumulated; Adagrad: duplicates summed first)
+ *                 (SGD: every occurrence accumulated; Adagrad / Adam: duplicates summed first;
+ *                 Adam takes the step the optimizer's counter stands at -- orx_dlrm_dense_apply
+ *                 advances it once per step -- and needs bias == NULL)
  */
 int orx_gather_rows(orx_ctx* ctx, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
                     float* out, int64_t out_stride);

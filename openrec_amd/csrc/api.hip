@@ -388,7 +388,7 @@ int orx_table_sync(orx_table* t) {
 }
 
 // per-row step stamps of the lazy Adam (all rows current at the optimizer's present step)
-int orx_opt_last(orx_opt* o, orx_table* t, bool restamp, int** out) {
+int orx_opt_last(orx_opt* o, orx_table* t, bool restamp, int** out, int64_t stamp) {
     OptSlots s;
     CHECK(orx_opt_slots(o, t, &s));
     auto& ref = o->slots[t];
@@ -396,7 +396,7 @@ int orx_opt_last(orx_opt* o, orx_table* t, bool restamp, int** out) {
         ORX_HIP(hipMalloc((void**)&ref.last, (size_t)t->rows * sizeof(int)));
         restamp = true;
     }
-    if (restamp) CHECK(orx_launch_fill_int(o->ctx, ref.last, t->rows, (int)o->t));
+    if (restamp) CHECK(orx_launch_fill_int(o->ctx, ref.last, t->rows, (int)(stamp >= 0 ? stamp : o->t)));
     *out = ref.last;
     return ORX_OK;
 }

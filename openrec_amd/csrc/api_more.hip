@@ -226,7 +226,8 @@ extern "C" int orx_score_all_items(orx_ctx* c, int kind, orx_table* U, orx_table
 
 extern "C" int orx_gather_rows(orx_ctx* ctx, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
                                float* out, int64_t out_stride) {
-    if (t) CHECK(orx_table_sync(t));
+    if (t && !bias && true) CHECK(orx_table_touch(t, ids, n));      // a lazy table: only the rows read
+    else if (t) CHECK(orx_table_sync(t));
     if (bias) CHECK(orx_table_sync(bias));
     ORX_ARG(ctx && t && (n == 0 || (ids && out)), "orx_gather_rows: NULL argument");
     ORX_ARG(out_stride >= t->dim + (bias ? 1 : 0), "orx_gather_rows: out_stride %lld too small", (long long)out_stride);
@@ -259,9 +260,80 @@ extern "C" int orx_pair_grads(orx_ctx* ctx, int model, int32_t D,
     return ORX_OK;
 }
 
+// ---- lazy TF-2.0 Adam on gradient rows -------------------------------------------------------------
+// The rule moves every row every step; a row's gradient-free steps are replayed when it is next referenced
+// (gathered for a forward pass: touch; given a gradient: apply) or when the table is observed (orx_table_sync).
+bool orx_adam_rows_lazy(const orx_opt* opt, const orx_table* t) {
+    return opt->kind == ORX_ADAM && t->rows < (1LL << 31) && getenv("ORX_ADAM_DENSE") == nullptr;
+}
+
+// duplicate flags + list of the duplicated rows of `ids` (item role) into the context's dedup buffers
+int orx_adam_rows_dedup(orx_ctx* ctx, orx_table* t, const int32_t* ids, int64_t n) {
+    ENSURE(ctx->d_dflag, ctx->d_dflag_cap, (size_t)n);
+    ENSURE(ctx->d_dlist, ctx->d_dlist_cap, (size_t)(n / 2 + 1) * sizeof(uint32_t));
+    ENSURE(ctx->d_dcount, ctx->d_dcount_cap, sizeof(int));
+    ORX_HIP(hipMemsetAsync(ctx->d_dcount, 0, sizeof(int), ctx->stream));
+    DedupArgs d;
+    memset(&d, 0, sizeof(d));
+    d.uid = ids; d.pid = ids; d.nid = ids; d.id_stride = n;
+    d.dflag = ctx->d_dflag; d.dlist = ctx->d_dlist; d.dcount = ctx->d_dcount;
+    d.flag_stride = n; d.list_stride = n / 2 + 1;
+    d.nU = 0; d.nP = n; d.nN = 0; d.NU = 0; d.NI = t->rows; d.nbu = 0; d.nbi = orx_dedup_buckets(t->rows);
+    return orx_launch_dedup(ctx, d, 1);
+}
+
+// the table becomes (or stays) lazy under `opt`; every row is current at step `now` when it was not lazy before
+static int adam_rows_args(orx_ctx* ctx, orx_opt* opt, orx_table* t, int64_t now, AdamRowsArgs* a) {
+    if (t->lazy != nullptr && t->lazy != opt) CHECK(orx_table_sync(t));
+    const bool resume = t->lazy == opt;
+    OptSlots st;
+    CHECK(orx_opt_slots(opt, t, &st));
+    memset(a, 0, sizeof(*a));
+    CHECK(orx_opt_last(opt, t, !resume, &a->last, now));
+    CHECK(orx_adam_lrt(opt, opt->t + 1));
+    t->lazy = opt;
+    a->W = t->w; a->M = st.s0; a->V = st.s1; a->rows = t->rows; a->D = t->dim;
+    a->lrt = opt->d_lrt; a->b1 = opt->p0; a->b2 = opt->p1; a->eps = opt->p2;
+    a->newton = (1.0f - sqrtf(opt->p1)) <= 1e-3f;
+    a->err = ctx->d_err;
+    return ORX_OK;
+}
+
+int orx_adam_rows_touch(orx_ctx* ctx, orx_opt* opt, orx_table* t, const int32_t* ids, int64_t n, bool have_dedup) {
+    if (n == 0 || opt->t == 0) return ORX_OK;                // nothing has moved yet
+    if (t->lazy != opt) return orx_table_sync(t);           // not lazy under this optimizer: every row is (made) current
+    AdamRowsArgs a;
+    CHECK(adam_rows_args(ctx, opt, t, opt->t, &a));
+    if (!have_dedup) CHECK(orx_adam_rows_dedup(ctx, t, ids, n));
+    a.dflag = ctx->d_dflag; a.dlist = (const uint32_t*)ctx->d_dlist; a.dcount = ctx->d_dcount;     // (allocated by the dedup)
+    a.ids = ids; a.n = n; a.T = (int)opt->t;
+    return orx_launch_adam_rows(ctx, false, a, n / 2 + 1);
+}
+
+// step opt->t (the caller has advanced the counter) with per-occurrence gradient rows
+int orx_adam_rows_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const int32_t* ids, int64_t n, const float* grads, int64_t g_stride,
+                        bool have_dedup) {
+    ORX_ARG(opt->t >= 1, "adam_rows_apply: the step counter has not been advanced");
+    CHECK(orx_table_scratch(t));
+    AdamRowsArgs a;
+    CHECK(adam_rows_args(ctx, opt, t, opt->t - 1, &a));
+    if (!have_dedup) CHECK(orx_adam_rows_dedup(ctx, t, ids, n));
+    a.dflag = ctx->d_dflag; a.dlist = (const uint32_t*)ctx->d_dlist; a.dcount = ctx->d_dcount;
+    a.G = t->gsum; a.ids = ids; a.n = n; a.grads = grads; a.g_stride = g_stride;
+    a.T = (int)opt->t; a.lr_T = opt->h_lrt[(size_t)opt->t];
+    return orx_launch_adam_rows(ctx, true, a, n / 2 + 1);
+}
+
+// rows about to be read by a forward pass: replayed to the lazy optimizer's step (no-op for a table that is current)
+int orx_table_touch(orx_table* t, const int32_t* ids, int64_t n) {
+    if (t == nullptr || t->lazy == nullptr) return ORX_OK;
+    return orx_adam_rows_touch(t->ctx, t->lazy, t, ids, n, false);
+}
+
 extern "C" int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias,
                               const int32_t* ids, int64_t n, const float* grads, int64_t g_stride) {
-    if (t) CHECK(orx_table_sync(t));
+    const bool lazy = ctx && opt && t && !bias && orx_adam_rows_lazy(opt, t);
+    if (t && !lazy) CHECK(orx_table_sync(t));
     if (bias) CHECK(orx_table_sync(bias));
     ORX_ARG(ctx && opt && t && (n == 0 || (ids && grads)), "orx_apply_rows: NULL argument");
     ORX_ARG(opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD || (opt->kind == ORX_ADAM && !bias),
@@ -276,6 +348,7 @@ extern "C" int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_tabl
     a.ids = ids; a.grads = grads; a.g_stride = g_stride; a.n = n; a.rows = t->rows; a.D = t->dim;
     a.lr = opt->lr; a.err = ctx->d_err;
     if (opt->kind == ORX_SGD) return orx_launch_apply_rows(ctx, ORX_SGD, false, a);
+    if (lazy) return orx_adam_rows_apply(ctx, opt, t, ids, n, grads, g_stride, false);
     if (opt->kind == ORX_ADAM) {
         // TF-2.0 sparse Adam: summed gradient rows + a dense-decay sweep of the whole table.
         // The caller advances opt->t once per step (see dlrm.hip).

@@ -231,7 +231,8 @@ static int mlp_gemm(orx_dlrm* m, const float* A, int64_t sa0, int64_t sa1, const
 
 // forward of one batch; leaves every activation in the model's buffers.  emb_rows != NULL: the
 // embedding rows [B, n_emb, d] are handed in (hybrid-parallel step) instead of gathered here.
-static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_rows = nullptr, const int32_t* idx = nullptr) {
+static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_rows = nullptr, const int32_t* idx = nullptr,
+                   bool touched = false) {
     orx_ctx* c = m->ctx;
     const int F = m->F, d = m->m_spa;
     const int compat = (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0, itself = (m->flags & ORX_DLRM_INTERACT_ITSELF) ? 1 : 0;
@@ -243,6 +244,8 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
             CHECK(orx_launch_dlrm_ids(c, bt.sparse, m->d_offset, m->d_rows, m->n_emb, B, m->d_idx));
             idx = m->d_idx;
         }
+        // a table under the lazy Adam: the rows about to be read are replayed to the optimizer's step first
+        if (!touched) CHECK(orx_table_touch(m->emb, idx, B * F));
         // dlrm.py:83-85: the n_emb gathers = one gather on the combined table (dense slot skipped)
         CHECK(orx_launch_gather(c, m->emb->w, nullptr, m->emb->rows, d, idx, B * F, m->Z, d, c->d_err, 1));
     }
@@ -416,7 +419,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
     const int F = m->F, d = m->m_spa;
     // Sparse optimizer with a plan: the row ids of all K steps are known up front, so duplicate roles, staging plan
     // and reduction tree are made once per (up to 64-step) chunk and every step applies its rows without atomics
-    // (orx_apply_rows_planned_step).  SGD / Adagrad on float4 dims; Adam keeps accumulate + sweep.  The plan costs one
+    // (orx_apply_rows_planned_step).  SGD / Adagrad on float4 dims (Adam: the lazy rule below).  The plan costs one
     // dedup workgroup per 425 984-row range and step, each streaming all B*F ids: right for combined tables of a few
     // ranges, wrong for Criteo's 33.8 M rows (80 ranges: +120 us per step, measured) -- those keep the atomics path
     // with the LDS sums for the tiny tables.
@@ -426,6 +429,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
     const int64_t PC = std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)((256ull << 20) / ((size_t)3 * B * F * sizeof(int32_t)))));
     RowsPlan rp;
     const int32_t* sparse_dev = sparse;
+    const bool lazy_adam = m->emb != nullptr && orx_adam_rows_lazy(opt, m->emb);
     if (planned) {
         const int64_t kp = std::min<int64_t>(K, PC);
         if (m->idx_all_cap < kp * B * F) {
@@ -450,7 +454,20 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         const int32_t* idx_s = planned ? m->d_idx_all + (s % PC) * B * F : nullptr;
         Batch bt;
         CHECK(stage(m, dense + s * B * m->dense_dim, sparse + s * B * m->n_emb, label + s * B, B, flags, &bt));
-        CHECK(forward(m, bt, B, nullptr, idx_s));
+        // lazy Adam: the rows of this batch are replayed to the current step before the forward reads
+        // them; the duplicate analysis of the id list is shared with the apply below
+        bool deduped = false;
+        if (lazy_adam) {
+            CHECK(orx_launch_dlrm_ids(c, bt.sparse, m->d_offset, m->d_rows, m->n_emb, B, m->d_idx));
+            idx_s = m->d_idx;
+            if (m->emb->lazy == opt && opt->t > 0) {
+                CHECK(orx_adam_rows_touch(c, opt, m->emb, idx_s, B * F, false));
+                deduped = true;
+            } else {
+                CHECK(orx_table_sync(m->emb));
+            }
+        }
+        CHECK(forward(m, bt, B, nullptr, idx_s, lazy_adam));
         float* pred = m->top_y.back();
         // loss + dLoss/dP  (dlrm.py:72-73, :97-98)
         CHECK(orx_launch_dlrm_loss(c, pred, bt.label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, m->d_loss + s));
@@ -465,6 +482,8 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         // sparse: per-occurrence rows dZ[b, f, :] onto the combined table (dense slot has id -1)
         if (planned) {
             CHECK(orx_apply_rows_planned_step(c, opt, m->emb, nullptr, rp, s % PC, idx_s, m->dZ, d));
+        } else if (lazy_adam) {
+            CHECK(orx_adam_rows_apply(c, opt, m->emb, idx_s, B * F, m->dZ, d, deduped));
         } else if (opt->kind == ORX_SGD && !m->tiny_f.empty()) {
             // tiny tables: per-slab LDS sums; the generic scatter then skips their slots
             CHECK(orx_launch_dlrm_tiny_apply(c, m->d_idx, m->dZ, m->d_tiny_f, (int)m->tiny_f.size(), m->tiny_max_rows, m->d_offset,

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void adam_flush_kernel(float* w, float* m, flo
         const int from = last[i / dim];
         if (from >= t_end) continue;
         float wi = w[i], mi = m[i], vi = v[i];
-        adam_catchup1(wi, mi, vi, from, t_end, lrt, b1, b2, eps);
+        adam_replay1<false>(wi, mi, vi, from, t_end, lrt, b1, b2, eps, (1.0f - sqrtf(b2)) <= 1e-3f);     // bounded: see orx_device.h
         w[i] = wi; m[i] = mi; v[i] = vi;
     }
 }

@@ -260,6 +260,77 @@ __global__ __launch_bounds__(256) void apply_rows_adagrad_kernel(RowsArgs a) {
     }
 }
 
+// TF-2.0 Adam on gradient rows, applied lazily: a row replays its gradient-free steps when it is
+// next referenced.  One wavefront per reference (STEP) or per row to bring up to date (touch, !STEP); lane e
+// owns elements e, e+64, ...  `T` is the step being taken (STEP: rows are replayed to T-1, then step T with the
+// summed gradient) or the step to replay to (touch).  Rows referenced once are finished here, duplicated rows
+// (dflag) by adam_rows_dup_kernel over the dedup list: STEP sums their gradients into gsum first.
+template <bool STEP>
+__global__ __launch_bounds__(256) void adam_rows_kernel(AdamRowsArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int D = a.D;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < a.n; k += stride) {
+        const int r = a.ids[k];
+        if (r < 0) continue;
+        if ((int64_t)r >= a.rows) { if (lane == 0) *a.err = 1; continue; }
+        const bool dup = a.dflag[k] != 0;
+        if (dup) {
+            if (STEP) {
+                const float* g = a.grads + k * a.g_stride;
+                for (int e = lane; e < D; e += 64) unsafeAtomicAdd(a.G + (size_t)r * D + e, g[e]);
+            }
+            continue;
+        }
+        const int from = __builtin_amdgcn_readfirstlane(a.last[r]);
+        if (!STEP && from >= a.T) continue;
+        for (int e = lane; e < D; e += 64) {
+            const size_t i = (size_t)r * D + e;
+            float w = a.W[i], m = a.M[i], v = a.V[i];
+            adam_replay1<true>(w, m, v, from, STEP ? a.T - 1 : a.T, a.lrt, a.b1, a.b2, a.eps, a.newton != 0);
+            if (STEP) adam_elem(w, m, v, a.grads[k * a.g_stride + e], a.lr_T, a.b1, a.b2, a.eps);
+            a.W[i] = w; a.M[i] = m; a.V[i] = v;
+        }
+        if (lane == 0) a.last[r] = a.T;
+    }
+}
+
+template <bool STEP>
+__global__ __launch_bounds__(256) void adam_rows_dup_kernel(AdamRowsArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int D = a.D;
+    const int n = *a.dcount;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < n; k += stride) {
+        const size_t r = a.dlist[k] & 0x7fffffffu;
+        const int from = __builtin_amdgcn_readfirstlane(a.last[r]);
+        if (!STEP && from >= a.T) continue;
+        for (int e = lane; e < D; e += 64) {
+            const size_t i = r * D + e;
+            float w = a.W[i], m = a.M[i], v = a.V[i];
+            adam_replay1<true>(w, m, v, from, STEP ? a.T - 1 : a.T, a.lrt, a.b1, a.b2, a.eps, a.newton != 0);
+            if (STEP) { adam_elem(w, m, v, a.G[i], a.lr_T, a.b1, a.b2, a.eps); a.G[i] = 0.0f; }
+            a.W[i] = w; a.M[i] = m; a.V[i] = v;
+        }
+        if (lane == 0) a.last[r] = a.T;
+    }
+}
+
+int orx_launch_adam_rows(orx_ctx* ctx, bool step, const AdamRowsArgs& a, int64_t max_dups) {
+    ProfScope ps(ctx, ORX_K_DUPAPPLY);
+    if (a.n == 0) return ORX_OK;
+    const dim3 g(grid_for_rows(0, a.n)), gd(grid_for_rows(0, max_dups > 0 ? max_dups : 1));
+    if (step) {
+        ORX_LAUNCH(ctx, adam_rows_kernel<true>, g, dim3(256), 0, a);
+        ORX_LAUNCH(ctx, adam_rows_dup_kernel<true>, gd, dim3(256), 0, a);
+    } else {
+        ORX_LAUNCH(ctx, adam_rows_kernel<false>, g, dim3(256), 0, a);
+        ORX_LAUNCH(ctx, adam_rows_dup_kernel<false>, gd, dim3(256), 0, a);
+    }
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
 int orx_launch_apply_rows(orx_ctx* ctx, int optkind, bool use_dflag, const RowsArgs& a) {
     ProfScope ps(ctx, ORX_K_DUPAPPLY);
     if (a.n == 0) return ORX_OK;

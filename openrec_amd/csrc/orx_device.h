@@ -198,6 +198,51 @@ __device__ __forceinline__ float sload_wait(float v) {
     return v;
 }
 
+// Replay of ONE element per lane over a wave-uniform range (one row per wavefront: kernels_sharded.hip), and of
+// one element with its own range (the table flush).  Rows of a large table wait hundreds or thousands of steps
+// between references; the replay stays bounded because the update term lr_k*m/(sqrt(v)+eps) shrinks by >= 9 % per
+// step (m by beta_1, the denominator by at most sqrt(beta_2), lr_k grows < 0.5 %/step): once 4x the term no longer
+// changes w in fp32 it never will again, and the remaining steps only decay m and v, which is done in closed form
+// (m*b1^n, v*b2^n by exp2; relative error ~1e-7 * n*|log2 b|).  At the defaults the loop ends after ~170 steps.
+__device__ __forceinline__ void adam_decay_tail(float& m, float& v, int rem, float b1, float b2) {
+    if (rem <= 0) return;
+    m *= exp2f((float)rem * log2f(b1));
+    v *= exp2f((float)rem * log2f(b2));
+}
+
+template <bool UNIFORM>
+__device__ __forceinline__ void adam_replay1(float& w, float& m, float& v, int from, int to, const float* lrt, float b1, float b2, float eps,
+                                             bool newton) {
+    if (from >= to) return;
+    const float sb2 = sqrtf(b2);
+    const float ce = eps * (1.0f - sb2);
+    float d = sqrtf(v) + eps;
+    float q = __builtin_amdgcn_rcpf(d);
+    int k = from + 1;
+    if (UNIFORM) {
+        float nxt = sload_wait(sload_issue(lrt, k));
+        for (; k <= to; ++k) {
+            const float lr = nxt;
+            nxt = sload_issue(lrt, k + 1);
+            m *= b1; v *= b2; d = d * sb2 + ce;
+            q = newton ? q * (2.0f - d * q) : __builtin_amdgcn_rcpf(d);
+            const float u = (lr * m) * q;
+            w -= u;
+            nxt = sload_wait(nxt);
+            if ((k & 7) == 0 && !__any((w - 4.0f * u) != w)) { ++k; break; }
+        }
+    } else {
+        for (; k <= to; ++k) {
+            m *= b1; v *= b2; d = d * sb2 + ce;
+            q = newton ? q * (2.0f - d * q) : __builtin_amdgcn_rcpf(d);
+            const float u = (lrt[k] * m) * q;
+            w -= u;
+            if ((w - 4.0f * u) == w) { ++k; break; }
+        }
+    }
+    adam_decay_tail(m, v, to - k + 1, b1, b2);
+}
+
 // the three rows (and the two item biases, which share their item row's stamp) of one triplet in ONE loop: its trip
 // count is the longest of the three gaps, not their sum, and the three chains interleave.  A row whose gap is
 // shorter is masked out of the early iterations.

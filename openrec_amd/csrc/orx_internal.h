@@ -113,7 +113,7 @@ struct orx_opt {
 // (sqrt(v)+eps), every step) is replayed exactly when the row is next needed.  orx_table_sync brings every row of a
 // table up to the optimizer's current step; every entry point that reads or writes a table calls it first.
 int orx_table_sync(orx_table* t);
-int orx_opt_last(orx_opt* o, orx_table* t, bool restamp, int** out);            // allocate / fetch the per-row step stamps
+int orx_opt_last(orx_opt* o, orx_table* t, bool restamp, int** out, int64_t stamp = -1);            // allocate / fetch the per-row step stamps
 int orx_launch_fill_int(orx_ctx* ctx, int* p, int64_t n, int v);
 int orx_adam_lrt(orx_opt* o, int64_t upto);                      // make lr_t of steps 1..upto available on the device
 int orx_launch_adam_flush(orx_ctx* ctx, float* w, float* m, float* v, int* last, int64_t rows, int dim, int t_end, const float* lrt,
@@ -231,6 +231,26 @@ struct RowsArgs {                              // sharded building blocks (kerne
     const int32_t* ids2; float* G2; float* gb2;
     const int2* refinfo; const int* segstart; float* stage; float* stageb;
 };
+
+struct AdamRowsArgs {                          // lazy TF-2.0 Adam on gradient rows (kernels_sharded.hip)
+    float* W; float* M; float* V; int* last;  // table, slots, per-row step stamps
+    float* G;                                 // gsum scratch (duplicated rows)
+    const int32_t* ids;                       // local row ids, < 0 = skip
+    const unsigned char* dflag; const uint32_t* dlist; const int* dcount;    // dedup of ids (item role)
+    const float* grads; int64_t g_stride;
+    int64_t n; int64_t rows; int D;
+    const float* lrt; float lr_T; float b1; float b2; float eps;
+    int T; int newton;
+    int* err;
+};
+int orx_launch_adam_rows(orx_ctx* ctx, bool step, const AdamRowsArgs& a, int64_t max_dups);
+// lazy Adam on a table's gradient rows: replay the rows of `ids` to the optimizer's step (touch) / take step opt->t
+int orx_adam_rows_dedup(orx_ctx* ctx, orx_table* t, const int32_t* ids, int64_t n);
+int orx_adam_rows_touch(orx_ctx* ctx, orx_opt* opt, orx_table* t, const int32_t* ids, int64_t n, bool have_dedup);
+int orx_adam_rows_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const int32_t* ids, int64_t n, const float* grads, int64_t g_stride,
+                        bool have_dedup);
+int orx_table_touch(orx_table* t, const int32_t* ids, int64_t n);       // no-op unless the table is lazy
+bool orx_adam_rows_lazy(const orx_opt* opt, const orx_table* t);
 
 struct GradArgs {
     const float* u; const float* p; const float* n; int64_t row_stride;   // gathered rows, bias at column D

@@ -179,3 +179,53 @@ def test_dlrm_wide_embeddings_mfma_interaction(m_spa, n_emb, itself, optname):
         for l, (W, b) in enumerate(layers):
             assert rel_err(m.param(nm + "_w", l).read(), W) < 5e-5, (nm, l)
             assert rel_err(m.param(nm + "_b", l).read().reshape(-1), b) < 5e-5, (nm, l)
+
+
+@pytest.mark.parametrize("m_spa,beta2", [(4, 0.999), (128, 0.999), (32, 0.95)])
+def test_dlrm_lazy_adam_is_the_dense_decay_adam(m_spa, beta2, monkeypatch):
+    """dlrm_criteo.py:31 trains with Keras Adam, whose TF-2.0 sparse apply moves every embedding row every step.
+    The embedding table takes that rule lazily (rows replay their gradient-free steps when next gathered or given a
+    gradient); 40 steps on tables where most rows wait many steps between references, with an inference (touch of
+    its rows only) and a parameter read (full flush) in the middle, against the oracle's dense rule — and the
+    whole-table-sweep form of the library (ORX_ADAM_DENSE=1) against the same numbers."""
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    from oracle.dlrm_oracle import DLRMOracle
+    rng = np.random.default_rng(5)
+    ln_emb = [3, 40, 30000, 700, 9000, 20]
+    cfg = dict(m_spa=m_spa, ln_emb=ln_emb, ln_bot=[16, m_spa], ln_top=[64, 32, 1], dense_dim=13)
+    B, K = 96, 40
+    dense = np.log1p(rng.integers(0, 100, (K, B, 13))).astype(np.float32)
+    sparse = np.stack([rng.integers(0, n, (K, B)) for n in ln_emb], 2).astype(np.int32)
+    label = (rng.uniform(size=(K, B)) < 0.25).astype(np.float32)
+    o = DLRMOracle(dtype=np.float64, seed=2, **cfg)
+    oo = orc.AdamTFSparse(0.002, 0.9, beta2, 1e-7)
+    ref_loss, ref_mid_pred, ref_mid_emb = [], None, None
+    start = [np.concatenate(o.emb).astype(np.float32)] + [(W.astype(np.float32), b.astype(np.float32)) for W, b in o.bot + o.top]
+    for s in range(K):
+        ref_loss.append(o.step(dense[s], sparse[s], label[s], oo))
+        if s == 14:
+            ref_mid_pred = o.inference(dense[0], sparse[0])
+        if s == 24:
+            ref_mid_emb = np.concatenate(o.emb).copy()
+    for form in ("lazy", "dense"):
+        if form == "dense":
+            monkeypatch.setenv("ORX_ADAM_DENSE", "1")
+        m = rt.DLRMModel(**cfg)
+        m.param("emb").write(start[0])
+        for nm, n0, cnt in (("bot", 1, len(o.bot)), ("top", 1 + len(o.bot), len(o.top))):
+            for l in range(cnt):
+                m.param(nm + "_w", l).write(start[n0 + l][0]); m.param(nm + "_b", l).write(start[n0 + l][1].reshape(1, -1))
+        opt = rt.Optimizer.adam(0.002, 0.9, beta2, 1e-7)
+        loss = []
+        for lo, hi in ((0, 15), (15, 25), (25, K)):
+            loss += list(m.step(opt, dense[lo:hi].reshape(-1, 13), sparse[lo:hi].reshape(-1, len(ln_emb)), label[lo:hi].reshape(-1), K=hi - lo))
+            if hi == 15:
+                assert rel_err(m.inference(dense[0], sparse[0]), ref_mid_pred) < 5e-5, form
+            if hi == 25:
+                assert rel_err(m.param("emb").read(), ref_mid_emb) < 5e-5, form
+        assert np.abs(np.array(loss) - np.array(ref_loss)).max() <= 5e-5 * np.abs(ref_loss).max(), form
+        assert rel_err(m.param("emb").read(), np.concatenate(o.emb)) < 5e-5, form
+        assert rel_err(opt.slot(m.param("emb"), 0), np.concatenate([oo.m[("emb", f)] for f in range(len(ln_emb))])) < 1e-4, form
+        assert rel_err(opt.slot(m.param("emb"), 1), np.concatenate([oo.v[("emb", f)] for f in range(len(ln_emb))])) < 5e-4, form
+        assert rel_err(m.param("top_w", 0).read(), o.top[0][0]) < 1e-4, form
