@@ -124,6 +124,10 @@ int orx_table_censor(orx_table* t, const int32_t* ids, int64_t n, float min_norm
 int orx_opt_create(orx_ctx* ctx, int kind, float lr, float p0, float p1, float p2, orx_opt** out);
 int orx_opt_destroy(orx_opt* opt);
 int orx_opt_set_lr(orx_opt* opt, float lr);
+/* the optimizer's step counter (Keras `optimizer.iterations`: Adam's bias correction depends on it);
+ * a checkpoint saves it next to the slots, a resume sets it before the next step */
+int orx_opt_get_step(orx_opt* opt, int64_t* step_out);
+int orx_opt_set_step(orx_opt* opt, int64_t step);
 /* read/write an optimizer slot of a table (checkpointing, parity):
  * slot 0 = Adagrad accumulator / Adam m, slot 1 = Adam v. */
 int orx_opt_slot_read(orx_opt* opt, orx_table* t, int slot, int64_t row0, int64_t nrows, float* host_dst);

@@ -50,6 +50,8 @@ SIGNATURES = {
     "orx_opt_create": (c_int, [_p, c_int, c_float, c_float, c_float, c_float, _pp]),
     "orx_opt_destroy": (c_int, [_p]),
     "orx_opt_set_lr": (c_int, [_p, c_float]),
+    "orx_opt_get_step": (c_int, [_p, POINTER(c_int64)]),
+    "orx_opt_set_step": (c_int, [_p, c_int64]),
     "orx_opt_slot_read": (c_int, [_p, _p, c_int, c_int64, c_int64, _fp]),
     "orx_opt_slot_write": (c_int, [_p, _p, c_int, c_int64, c_int64, _fp]),
     "orx_pairwise_step": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, _ip, _ip, c_int64, c_int64, c_int64,

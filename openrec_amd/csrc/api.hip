@@ -329,6 +329,20 @@ extern "C" int orx_opt_set_lr(orx_opt* o, float lr) {
     return ORX_OK;
 }
 
+extern "C" int orx_opt_get_step(orx_opt* o, int64_t* step_out) {
+    ORX_ARG(o && step_out, "orx_opt_get_step: NULL argument");
+    *step_out = o->t;
+    return ORX_OK;
+}
+
+extern "C" int orx_opt_set_step(orx_opt* o, int64_t step) {
+    ORX_ARG(o && step >= 0 && step < 0x7fffffff, "orx_opt_set_step: NULL optimizer or step out of range");
+    for (auto& kv : o->slots)               // rows pending under the old counter are finished under it
+        if (kv.first->lazy == o) CHECK(orx_table_sync(kv.first));
+    o->t = step;
+    return ORX_OK;
+}
+
 int orx_opt_slots(orx_opt* o, orx_table* t, OptSlots* out) {
     auto it = o->slots.find(t);
     if (it != o->slots.end()) { *out = it->second; return ORX_OK; }

@@ -282,8 +282,8 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
     return ORX_OK;
 }
 
-// SGD / Adagrad on every dense parameter in one launch (gradients in the tables' gsum)
-static int dense_apply_all(orx_dlrm* m, orx_opt* opt) {
+// SGD / Adagrad / Adam (lr_t of the step) on every dense parameter in one launch (gradients in the tables' gsum)
+static int dense_apply_all(orx_dlrm* m, orx_opt* opt, float lr_t = 0.f) {
     orx_ctx* c = m->ctx;
     std::vector<DenseParam> h;
     int64_t max_n = 0;
@@ -291,7 +291,7 @@ static int dense_apply_all(orx_dlrm* m, orx_opt* opt) {
         OptSlots s;
         CHECK(orx_opt_slots(opt, t, &s));
         CHECK(orx_table_scratch(t));
-        DenseParam p; p.w = t->w; p.acc = s.s0; p.g = t->gsum; p.n = t->rows * t->dim;
+        DenseParam p; p.w = t->w; p.acc = s.s0; p.acc2 = s.s1; p.g = t->gsum; p.n = t->rows * t->dim;
         h.push_back(p); max_n = std::max(max_n, p.n);
         return ORX_OK;
     };
@@ -303,16 +303,8 @@ static int dense_apply_all(orx_dlrm* m, orx_opt* opt) {
         ORX_HIP(hipStreamSynchronize(c->stream));
         m->params_opt = opt;
     }
+    if (opt->kind == ORX_ADAM) return orx_launch_dense_apply_multi(c, m->d_params, (int)h.size(), max_n, ORX_ADAM, lr_t, opt->p2, opt->p0, opt->p1);
     return orx_launch_dense_apply_multi(c, m->d_params, (int)h.size(), max_n, opt->kind, opt->lr, opt->p1);
-}
-
-// dense optimizer rule on one parameter whose gradient sits in t->gsum
-static int dense_apply(orx_ctx* c, orx_opt* opt, orx_table* t, float lr_t) {
-    OptSlots s;
-    CHECK(orx_opt_slots(opt, t, &s));
-    const int64_t n = t->rows * t->dim;
-    if (opt->kind == ORX_ADAM) return orx_launch_adam_sweep(c, t->w, s.s0, s.s1, t->gsum, n, lr_t, opt->p0, opt->p1, opt->p2);
-    return orx_launch_dense_apply(c, t->w, s.s0, t->gsum, (int)n, opt->kind, opt->lr, opt->p1);
 }
 
 // backward through one MLP; dy [B, last.out] is consumed (in place), returns d(input) in *dx_out
@@ -493,12 +485,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         } else {
             CHECK(orx_apply_rows(c, opt, m->emb, nullptr, m->d_idx, B * F, m->dZ, d));
         }
-        if (opt->kind == ORX_ADAM) {
-            for (auto& D : m->bot) { CHECK(dense_apply(c, opt, D.W, lr_t)); CHECK(dense_apply(c, opt, D.b, lr_t)); }
-            for (auto& D : m->top) { CHECK(dense_apply(c, opt, D.W, lr_t)); CHECK(dense_apply(c, opt, D.b, lr_t)); }
-        } else {
-            CHECK(dense_apply_all(m, opt));
-        }
+        CHECK(dense_apply_all(m, opt, lr_t));
     }
     if (loss_out) {
         std::vector<double> h((size_t)K);
@@ -594,9 +581,8 @@ extern "C" int orx_dlrm_dense_apply(orx_dlrm* m, orx_opt* opt, const float* flat
         const size_t n = (size_t)t->rows * t->dim;
         ORX_HIP(hipMemcpyAsync(t->gsum, flat, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
         flat += n;
-        if (opt->kind == ORX_ADAM) CHECK(dense_apply(c, opt, t, lr_t));
     }
-    if (opt->kind != ORX_ADAM) CHECK(dense_apply_all(m, opt));
+    CHECK(dense_apply_all(m, opt, lr_t));
     m->grads_pending = false;
     return ORX_OK;
 }

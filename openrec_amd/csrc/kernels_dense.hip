@@ -914,15 +914,19 @@ int orx_launch_rows_accum(orx_ctx* ctx, float* G, const int32_t* ids, const floa
 }
 
 // ------------------------------------------------------- multi-tensor dense apply ---
-// The SGD / Adagrad rule of every dense parameter of a model in ONE launch (16 launches of a few microseconds
+// The SGD / Adagrad / Adam rule of every dense parameter of a model in ONE launch (16 launches of a few microseconds
 // each otherwise): grid.y = parameter, grid.x covers the largest one.  Gradients are zeroed behind.
-__global__ __launch_bounds__(256) void dense_apply_multi_kernel(const DenseParam* ps, int optkind, float lr, float eps) {
+__global__ __launch_bounds__(256) void dense_apply_multi_kernel(const DenseParam* ps, int optkind, float lr, float eps, float b1, float b2) {
     const DenseParam p = ps[blockIdx.y];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
         const float gi = p.g[i];
         p.g[i] = 0.0f;
-        if (optkind == ORX_ADAGRAD) {
+        if (optkind == ORX_ADAM) {          // lr = lr_t of this step; acc = m, acc2 = v
+            float w = p.w[i], m = p.acc[i], v = p.acc2[i];
+            adam_elem(w, m, v, gi, lr, b1, b2, eps);
+            p.w[i] = w; p.acc[i] = m; p.acc2[i] = v;
+        } else if (optkind == ORX_ADAGRAD) {
             const float a2 = p.acc[i] + gi * gi;
             p.acc[i] = a2;
             p.w[i] = p.w[i] - lr * gi / (sqrtf(a2) + eps);
@@ -932,10 +936,11 @@ __global__ __launch_bounds__(256) void dense_apply_multi_kernel(const DenseParam
     }
 }
 
-int orx_launch_dense_apply_multi(orx_ctx* ctx, const DenseParam* ps_dev, int count, int64_t max_n, int optkind, float lr, float eps) {
+int orx_launch_dense_apply_multi(orx_ctx* ctx, const DenseParam* ps_dev, int count, int64_t max_n, int optkind, float lr, float eps,
+                                 float b1, float b2) {
     if (count == 0) return ORX_OK;
     int64_t gx = (max_n + 255) / 256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
-    ORX_LAUNCH(ctx, dense_apply_multi_kernel, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, ps_dev, optkind, lr, eps);
+    ORX_LAUNCH(ctx, dense_apply_multi_kernel, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, ps_dev, optkind, lr, eps, b1, b2);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

@@ -346,8 +346,9 @@ int orx_launch_gemm(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, cons
                     float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero = false);
 int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
                         float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero = false);
-struct DenseParam { float* w; float* acc; float* g; int64_t n; };
-int orx_launch_dense_apply_multi(orx_ctx* ctx, const DenseParam* ps_dev, int count, int64_t max_n, int optkind, float lr, float eps);
+struct DenseParam { float* w; float* acc; float* acc2; float* g; int64_t n; };
+int orx_launch_dense_apply_multi(orx_ctx* ctx, const DenseParam* ps_dev, int count, int64_t max_n, int optkind, float lr, float eps,
+                                 float b1 = 0.f, float b2 = 0.f);
 int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb,
                               void* d16 = nullptr, int64_t ld16 = 0);
 int orx_launch_gemm_f16s(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,

@@ -178,6 +178,17 @@ class Optimizer:
     def set_lr(self, lr):
         check(self._lib.orx_opt_set_lr(self._h, lr))
 
+    @property
+    def step(self):
+        """the step counter (Keras `optimizer.iterations`)"""
+        t = c_int64(0)
+        check(self._lib.orx_opt_get_step(self._h, byref(t)))
+        return int(t.value)
+
+    @step.setter
+    def step(self, value):
+        check(self._lib.orx_opt_set_step(self._h, int(value)))
+
     def slot(self, table, slot=0):
         out = np.empty((table.rows, table.dim), np.float32)
         check(self._lib.orx_opt_slot_read(self._h, table._h, slot, 0, table.rows, out.ctypes.data))
@@ -434,6 +445,7 @@ def save_checkpoint(path, tables, opt=None):
                 out["slot1/" + name] = opt.slot(t, 1)
     if opt is not None:
         out["opt/kind"] = np.array(opt.kind)
+        out["opt/step"] = np.array(opt.step, np.int64)          # Adam's bias correction resumes where it stopped
     np.savez(path, **out)
 
 
@@ -445,6 +457,8 @@ def load_checkpoint(path, tables, opt=None):
             opt.set_slot(t, z["slot0/" + name], 0)
             if ("slot1/" + name) in z:
                 opt.set_slot(t, z["slot1/" + name], 1)
+    if opt is not None and "opt/step" in z:
+        opt.step = int(z["opt/step"])
 
 
 class DeviceSampler:

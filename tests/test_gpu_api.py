@@ -131,3 +131,25 @@ def test_checkpoint_roundtrip_resumes(tmp_path):
     for x, y in ((U, U2), (V, V2), (b, b2)):
         assert np.abs(x.read() - y.read()).max() <= 1e-6 * np.abs(x.read()).max()
     assert np.abs(opt.slot(V) - opt2.slot(V2)).max() <= 1e-6 * np.abs(opt.slot(V)).max()
+
+
+def test_adam_checkpoint_resumes_with_its_step_counter(tmp_path):
+    """Adam's bias correction depends on the step counter and (TF 2.0) every row moves every step: a resume from a
+    checkpoint taken mid-run (tables, m, v, counter) must continue exactly like the uninterrupted run."""
+    from openrec_amd import runtime as rt
+    rng = np.random.default_rng(1)
+    mk = lambda: (rt.Table(3000, 64).init_uniform(seed=1), rt.Table(4000, 64).init_uniform(seed=2), rt.Table(4000, 1).init_uniform(seed=3))
+    ids = [rng.integers(0, n, (12, 256)).astype(np.int32) for n in (3000, 4000, 4000)]
+    U, V, b = mk(); opt = rt.Optimizer.adam(0.002)
+    rt.pairwise_step("bpr", opt, U, V, b, ids[0][:6], ids[1][:6], ids[2][:6], K=6, B=256)
+    rt.save_checkpoint(str(tmp_path / "ck.npz"), dict(U=U, V=V, b=b), opt)
+    assert opt.step == 6
+    rt.pairwise_step("bpr", opt, U, V, b, ids[0][6:], ids[1][6:], ids[2][6:], K=6, B=256)
+    U2, V2, b2 = mk(); opt2 = rt.Optimizer.adam(0.002)
+    rt.load_checkpoint(str(tmp_path / "ck.npz"), dict(U=U2, V=V2, b=b2), opt2)
+    assert opt2.step == 6
+    rt.pairwise_step("bpr", opt2, U2, V2, b2, ids[0][6:], ids[1][6:], ids[2][6:], K=6, B=256)
+    for x, y in ((U, U2), (V, V2), (b, b2)):
+        assert np.abs(x.read() - y.read()).max() <= 1e-6 * np.abs(x.read()).max()
+    for sl in (0, 1):
+        assert np.abs(opt.slot(V, sl) - opt2.slot(V2, sl)).max() <= 1e-6 * np.abs(opt.slot(V, sl)).max()
