@@ -125,7 +125,9 @@ int orx_opt_create(orx_ctx* ctx, int kind, float lr, float p0, float p1, float p
 int orx_opt_destroy(orx_opt* opt);
 int orx_opt_set_lr(orx_opt* opt, float lr);
 /* the optimizer's step counter (Keras `optimizer.iterations`: Adam's bias correction depends on it);
- * a checkpoint saves it next to the slots, a resume sets it before the next step */
+ * a checkpoint saves it next to the slots, a resume sets it before the next step.  The step entry points
+ * advance it themselves; a host that drives Adam through orx_apply_rows advances it by one per step
+ * (set_step(get_step + 1)) after the step's gathers and before its applies. */
 int orx_opt_get_step(orx_opt* opt, int64_t* step_out);
 int orx_opt_set_step(orx_opt* opt, int64_t step);
 /* read/write an optimizer slot of a table (checkpointing, parity):
@@ -277,8 +279,8 @@ int orx_dlrm_dense_apply(orx_dlrm* m, orx_opt* opt, const float* flat);
  *                 valid == NULL or valid[k] >= 0
  *   apply_rows  : optimizer sparse apply of per-occurrence gradient rows
  *                 (SGD: every occurrence accumulated; Adagrad / Adam: duplicates summed first;
- *                 Adam takes the step the optimizer's counter stands at -- orx_dlrm_dense_apply
- *                 advances it once per step -- and needs bias == NULL)
+ *                 Adam takes the step the optimizer's counter stands at: orx_dlrm_dense_apply
+ *                 advances it once per step, otherwise the host does with orx_opt_set_step)
  */
 int orx_gather_rows(orx_ctx* ctx, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
                     float* out, int64_t out_stride);

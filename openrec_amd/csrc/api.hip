@@ -159,6 +159,12 @@ extern "C" int orx_table_destroy(orx_table* t) {
     if (!t) return ORX_OK;
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
+    for (orx_opt* o : t->ctx->opts) {       // optimizer state of this table goes with it (and never meets a new table at this address)
+        auto it = o->slots.find(t);
+        if (it == o->slots.end()) continue;
+        hipFree(it->second.s0); hipFree(it->second.s1); hipFree(it->second.last);
+        o->slots.erase(it);
+    }
     if (t->owned) hipFree(t->w);
     hipFree(t->gsum);
     hipFree(t->gsum2);
@@ -302,6 +308,7 @@ extern "C" int orx_opt_create(orx_ctx* ctx, int kind, float lr, float p0, float 
     ORX_ARG(kind == ORX_SGD || kind == ORX_ADAGRAD || kind == ORX_ADAM, "orx_opt_create: unknown optimizer kind %d", kind);
     orx_opt* o = new orx_opt();
     o->ctx = ctx; o->kind = kind; o->lr = lr; o->p0 = p0; o->p1 = p1; o->p2 = p2;
+    ctx->opts.push_back(o);
     *out = o;
     return ORX_OK;
 }
@@ -310,11 +317,13 @@ extern "C" int orx_opt_destroy(orx_opt* o) {
     if (!o) return ORX_OK;
     hipSetDevice(o->ctx->device);
     hipStreamSynchronize(o->ctx->stream);
-    for (auto& kv : o->slots) {
+    for (auto& kv : o->slots) {             // (keys are live tables: a destroyed table erases its entry)
         if (kv.first->lazy == o) orx_table_sync(kv.first);       // the table outlives the optimizer: finish its rows
         hipFree(kv.second.s0); hipFree(kv.second.s1); hipFree(kv.second.last);
     }
     hipFree(o->d_lrt);
+    auto& live = o->ctx->opts;
+    live.erase(std::remove(live.begin(), live.end(), o), live.end());
     delete o;
     return ORX_OK;
 }
@@ -337,8 +346,9 @@ extern "C" int orx_opt_get_step(orx_opt* o, int64_t* step_out) {
 
 extern "C" int orx_opt_set_step(orx_opt* o, int64_t step) {
     ORX_ARG(o && step >= 0 && step < 0x7fffffff, "orx_opt_set_step: NULL optimizer or step out of range");
-    for (auto& kv : o->slots)               // rows pending under the old counter are finished under it
-        if (kv.first->lazy == o) CHECK(orx_table_sync(kv.first));
+    if (step != o->t + 1)                   // a jump (resume): rows pending under the old counter are finished under it;
+        for (auto& kv : o->slots)           // advancing by one is what every step does and leaves the stamps valid
+            if (kv.first->lazy == o) CHECK(orx_table_sync(kv.first));
     o->t = step;
     return ORX_OK;
 }

@@ -226,9 +226,8 @@ extern "C" int orx_score_all_items(orx_ctx* c, int kind, orx_table* U, orx_table
 
 extern "C" int orx_gather_rows(orx_ctx* ctx, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
                                float* out, int64_t out_stride) {
-    if (t && !bias && true) CHECK(orx_table_touch(t, ids, n));      // a lazy table: only the rows read
-    else if (t) CHECK(orx_table_sync(t));
-    if (bias) CHECK(orx_table_sync(bias));
+    if (t) CHECK(orx_table_touch(t, ids, n));            // a lazy table: only the rows read are brought up to date
+    if (bias) CHECK(orx_table_touch(bias, ids, n));
     ORX_ARG(ctx && t && (n == 0 || (ids && out)), "orx_gather_rows: NULL argument");
     ORX_ARG(out_stride >= t->dim + (bias ? 1 : 0), "orx_gather_rows: out_stride %lld too small", (long long)out_stride);
     ORX_HIP(hipSetDevice(ctx->device));
@@ -332,12 +331,12 @@ int orx_table_touch(orx_table* t, const int32_t* ids, int64_t n) {
 
 extern "C" int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias,
                               const int32_t* ids, int64_t n, const float* grads, int64_t g_stride) {
-    const bool lazy = ctx && opt && t && !bias && orx_adam_rows_lazy(opt, t);
+    const bool lazy = ctx && opt && t && orx_adam_rows_lazy(opt, t);
     if (t && !lazy) CHECK(orx_table_sync(t));
-    if (bias) CHECK(orx_table_sync(bias));
+    if (bias && !lazy) CHECK(orx_table_sync(bias));
     ORX_ARG(ctx && opt && t && (n == 0 || (ids && grads)), "orx_apply_rows: NULL argument");
-    ORX_ARG(opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD || (opt->kind == ORX_ADAM && !bias),
-            "orx_apply_rows: SGD and Adagrad (and Adam without a bias column) are supported");
+    ORX_ARG(opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD || (opt->kind == ORX_ADAM && (!bias || lazy)),
+            "orx_apply_rows: the whole-table-sweep form of Adam (ORX_ADAM_DENSE) takes no bias column");
     ORX_ARG(g_stride >= t->dim + (bias ? 1 : 0), "orx_apply_rows: g_stride too small");
     ORX_ARG(!bias || (bias->dim == 1 && bias->rows == t->rows), "orx_apply_rows: bias must be [%lld, 1]", (long long)t->rows);
     if (n == 0) return ORX_OK;
@@ -348,7 +347,11 @@ extern "C" int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_tabl
     a.ids = ids; a.grads = grads; a.g_stride = g_stride; a.n = n; a.rows = t->rows; a.D = t->dim;
     a.lr = opt->lr; a.err = ctx->d_err;
     if (opt->kind == ORX_SGD) return orx_launch_apply_rows(ctx, ORX_SGD, false, a);
-    if (lazy) return orx_adam_rows_apply(ctx, opt, t, ids, n, grads, g_stride, false);
+    if (lazy) {             // the bias column is a [rows, 1] table of its own with the same id list (one duplicate analysis)
+        CHECK(orx_adam_rows_apply(ctx, opt, t, ids, n, grads, g_stride, false));
+        if (bias) CHECK(orx_adam_rows_apply(ctx, opt, bias, ids, n, grads + t->dim, g_stride, true));
+        return ORX_OK;
+    }
     if (opt->kind == ORX_ADAM) {
         // TF-2.0 sparse Adam: summed gradient rows + a dense-decay sweep of the whole table.
         // The caller advances opt->t once per step (see dlrm.hip).
@@ -556,7 +559,7 @@ extern "C" int orx_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, i
 extern "C" int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const float* rows_in, const int32_t* u_loc,
                                const int32_t* slot, int64_t T, int64_t row_stride, int64_t B_global, float margin, int flags,
                                float* gu, float* send_g, double* loss_l2_accum) {
-    if (user) CHECK(orx_table_sync(user));
+    if (user && u_loc) CHECK(orx_table_touch(user, u_loc, T));        // a lazy table: the user rows read here are brought up to date
     ORX_ARG(ctx && user && rows_in && u_loc && slot && gu && send_g, "orx_shard_grads: NULL argument");
     ORX_ARG(model == ORX_BPR || model == ORX_UCML, "orx_shard_grads: unknown model %d", model);
     ORX_ARG(row_stride > user->dim && B_global > 0, "orx_shard_grads: row_stride must leave room for the bias column");

@@ -45,6 +45,7 @@ struct orx_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int* d_err = nullptr;             // sticky device-side "id out of range" flag
+    std::vector<struct orx_opt*> opts;  // live optimizers: a table that is destroyed takes its slots out of them
     // staging buffers (grown on demand)
     int32_t* d_ids = nullptr;  size_t d_ids_cap = 0;       // host-id upload
     float* d_lab = nullptr;    size_t d_lab_cap = 0;

@@ -79,9 +79,19 @@ class HipBackend:
             self.opt = rt.Optimizer.sgd(lr, ctx=self.ctx)
         elif opt_kind == "adagrad":
             self.opt = rt.Optimizer.adagrad(lr, kw.get("initial_accumulator_value", 0.1), kw.get("epsilon", 1e-7), ctx=self.ctx)
+        elif opt_kind == "adam":
+            # TF-2.0 dense-decay Adam, applied lazily by the library (rows replay their gradient-free steps when
+            # next gathered or given a gradient); the step counter advances once per step, see begin_step()
+            self.opt = rt.Optimizer.adam(lr, kw.get("beta_1", 0.9), kw.get("beta_2", 0.999), kw.get("epsilon", 1e-7), ctx=self.ctx)
         else:
-            raise ValueError("sharded tables support sgd and adagrad")
+            raise ValueError("sharded tables support sgd, adagrad and adam")
+        self.opt_kind = opt_kind
         self.lib = self.ctx._lib
+
+    def begin_step(self):
+        """after the step's gathers, before its applies: Keras `iterations` += 1 (Adam's lr_t and the lazy replay)"""
+        if self.opt_kind == "adam":
+            self.opt.step = self.opt.step + 1
 
     def make_table(self, rows, dim, seed):
         return self.rt.Table(max(rows, 1), dim, self.ctx).init_uniform(seed=seed)
@@ -227,6 +237,7 @@ class ShardedPairwise:
         rows_in = self._a2a(f["rows_out"], f["rows_in"])                           # 3. item rows back
         be.shard_grads(self.model, self.U, rows_in, f["u_loc"], f["slot"], B * N, self.margin, f["gu"], f["send_g"],
                        self.accum)
+        be.begin_step()
         be.apply_rows(self.U, None, f["u_loc"], f["gu"])                           # 5. user rows are local
         g_in = self._a2a(f["send_g"], f["g_in"])                                   # 6. item-row gradients -> owners
         be.apply_rows(self.V, self.b, f["req_loc"], g_in)
@@ -286,6 +297,7 @@ class ShardedPairwise:
             be.gather_rows(self.V, self.b, req_loc[k], f["rows_out"])
             rows_in = self._a2a(f["rows_out"], f["rows_in"])                       # 3. item rows back
             be.shard_grads(self.model, self.U, rows_in, u_loc[k], slot[k], B * N, self.margin, f["gu"], f["send_g"], self.accum)
+            be.begin_step()
             if flagged:
                 be.apply_rows_flagged(self.U, None, u_loc[k], f["gu"], fu[k])      # 5. user rows are local
             else:
@@ -349,6 +361,7 @@ class ShardedPairwise:
         gn = torch.zeros((T, DS), dtype=torch.float32, device=dev)
         self.be.pair_grads(self.model, D, u_rows, p_rows, n_rows, valid, b_global, self.margin, gu, gp, gn, self.accum)
         # ---- 5. user rows are local
+        self.be.begin_step()
         self.be.apply_rows(self.U, None, valid, gu)
         # ---- 6. item-row gradients go back along route 2 and are applied by the owners
         send_g = torch.zeros((trash2 + 1, DS), dtype=torch.float32, device=dev)

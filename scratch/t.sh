@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 600 python -m pytest tests/test_gpu_api.py -x -q 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_api.py -x -q 2>&1 | tail -5

@@ -16,7 +16,11 @@ class Tab:
 class OracleBackend:
     def __init__(self, opt_kind, lr):
         self.opt_kind, self.lr = opt_kind, lr
-        self.opt = orc.SGD(lr) if opt_kind == "sgd" else orc.Adagrad(lr, 0.1, 1e-7)
+        self.opt = {"sgd": lambda: orc.SGD(lr), "adagrad": lambda: orc.Adagrad(lr, 0.1, 1e-7), "adam": lambda: orc.AdamTFSparse(lr)}[opt_kind]()
+
+    def begin_step(self):
+        if hasattr(self.opt, "begin_step"):
+            self.opt.begin_step()
 
     def make_table(self, rows, dim, seed):
         return Tab(max(rows, 1), dim)

@@ -153,3 +153,19 @@ def test_adam_checkpoint_resumes_with_its_step_counter(tmp_path):
         assert np.abs(x.read() - y.read()).max() <= 1e-6 * np.abs(x.read()).max()
     for sl in (0, 1):
         assert np.abs(opt.slot(V, sl) - opt2.slot(V2, sl)).max() <= 1e-6 * np.abs(opt.slot(V, sl)).max()
+
+
+def test_tables_may_die_before_their_optimizer():
+    """Optimizer state is keyed by table: a table destroyed first takes its slots (and any pending lazy-Adam rows)
+    with it, and a new table that lands on the same address starts with fresh slots of its own size."""
+    from openrec_amd import runtime as rt
+    rng = np.random.default_rng(2)
+    opt = rt.Optimizer.adam(0.002)
+    for rows in (500, 900, 500):
+        U, V, b = rt.Table(rows, 64).init_uniform(seed=1), rt.Table(rows + 7, 64).init_uniform(seed=2), rt.Table(rows + 7, 1).init_uniform(seed=3)
+        ids = [rng.integers(0, n, (3, 256)).astype(np.int32) for n in (rows, rows + 7, rows + 7)]
+        rt.pairwise_step("bpr", opt, U, V, b, *ids, K=3, B=256)          # leaves the tables lazy under `opt`
+        assert opt.slot(V, 0).shape == (rows + 7, 64) and np.isfinite(opt.slot(V, 1)).all()
+        for t in (U, V, b):
+            t._fin()                                                       # orx_table_destroy, before the optimizer
+    opt._fin()

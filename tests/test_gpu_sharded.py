@@ -6,6 +6,7 @@ import pytest
 from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
+LR_ADAM = 0.002
 TOL = 1e-5
 
 
@@ -20,7 +21,7 @@ def _case(seed, NU, NI, B, D):
 
 
 @pytest.mark.parametrize("model", ["bpr", "ucml"])
-@pytest.mark.parametrize("optk", ["sgd", "adagrad"])
+@pytest.mark.parametrize("optk", ["sgd", "adagrad", "adam"])
 @pytest.mark.parametrize("D", [50, 64, 128])
 def test_sharded_world1_matches_oracle(model, optk, D):
     import torch
@@ -29,9 +30,9 @@ def test_sharded_world1_matches_oracle(model, optk, D):
     torch.cuda.init()                                   # in the main thread, before the rank threads touch the device
     dev = torch.device("cuda", 0)
     U, V, b, u, p, n = _case(3, 700, 900, 2051, D)
-    eng = sharded.ShardedPairwise(model, optk, 700, 900, D, lr=0.05, rank=0, world=1, device=dev, slack=1.0)
+    eng = sharded.ShardedPairwise(model, optk, 700, 900, D, lr=LR_ADAM if optk == "adam" else 0.05, rank=0, world=1, device=dev, slack=1.0)
     eng.U.write(U); eng.V.write(V); eng.b.write(b)
-    o = orc.SGD(0.05) if optk == "sgd" else orc.Adagrad(0.05, 0.1, 1e-7)
+    o = {"sgd": lambda: orc.SGD(0.05), "adagrad": lambda: orc.Adagrad(0.05, 0.1, 1e-7), "adam": lambda: orc.AdamTFSparse(LR_ADAM)}[optk]()
     tl = tl2 = 0.0
     for s in range(3):
         uu, pp, nn = np.roll(u, s), np.roll(p, 5 * s), np.roll(n, 2 * s)
@@ -43,8 +44,9 @@ def test_sharded_world1_matches_oracle(model, optk, D):
         tl += float(l); tl2 += float(l2)
     eng.check()
     loss, l2s = eng.loss_sums()
+    tol = 5e-5 if optk == "adam" else TOL           # (the fp32 oracle's own rounding enters m / (sqrt(v) + eps) amplified)
     assert abs(loss - tl) <= TOL * abs(tl) and abs(l2s - tl2) <= TOL * abs(tl2)
-    assert rel_err(eng.U.read(), U) < TOL and rel_err(eng.V.read(), V) < TOL and rel_err(eng.b.read(), b) < TOL
+    assert rel_err(eng.U.read(), U) < tol and rel_err(eng.V.read(), V) < tol and rel_err(eng.b.read(), b) < tol
 
 
 def test_gather_rows_skips_padding_and_is_bit_exact():
@@ -90,7 +92,7 @@ class _FakeCluster:
 
 
 @pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("model,optk", [("bpr", "sgd"), ("bpr", "adagrad"), ("ucml", "sgd")])
+@pytest.mark.parametrize("model,optk", [("bpr", "sgd"), ("bpr", "adagrad"), ("ucml", "sgd"), ("bpr", "adam")])
 @pytest.mark.parametrize("fast", [True, False, "planned"])
 def test_virtual_cluster_matches_oracle(world, model, optk, fast):
     planned = fast == "planned"             # K-step call: the exchange plan of all steps in one all-to-all per phase
@@ -108,7 +110,7 @@ def test_virtual_cluster_matches_oracle(world, model, optk, fast):
 
     def run(rank):
         try:
-            e = sharded.ShardedPairwise(model, optk, NU, NI, D, lr=0.05, rank=rank, world=world, device=dev,
+            e = sharded.ShardedPairwise(model, optk, NU, NI, D, lr=LR_ADAM if optk == "adam" else 0.05, rank=rank, world=world, device=dev,
                                         slack=1.5, a2a_fn=cl.a2a(rank), fast=fast)
             assert e.fast == fast
             e.U.write(U[rank::world]); e.V.write(V[rank::world]); e.b.write(b[rank::world])
@@ -131,7 +133,7 @@ def test_virtual_cluster_matches_oracle(world, model, optk, fast):
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     [t.start() for t in th]; [t.join() for t in th]
     assert not errs, errs
-    o = orc.SGD(0.05) if optk == "sgd" else orc.Adagrad(0.05, 0.1, 1e-7)
+    o = {"sgd": lambda: orc.SGD(0.05), "adagrad": lambda: orc.Adagrad(0.05, 0.1, 1e-7), "adam": lambda: orc.AdamTFSparse(LR_ADAM)}[optk]()
     tl = 0.0
     for s in range(3):
         uu, pp, nn = np.roll(u, s), np.roll(p, 5 * s), np.roll(n, 2 * s)
@@ -141,8 +143,9 @@ def test_virtual_cluster_matches_oracle(world, model, optk, fast):
     for r, e in enumerate(engs):
         assert int(e._ovf[0]) == 0 if e._ovf is not None else True
         assert not bool(e.overflow)
-        assert rel_err(e.U.read()[:len(U[r::world])], U[r::world]) < 2e-5
-        assert rel_err(e.V.read()[:len(V[r::world])], V[r::world]) < 2e-5
-        assert rel_err(e.b.read()[:len(b[r::world])], b[r::world]) < 2e-5
+        tol = 5e-5 if optk == "adam" else 2e-5
+        assert rel_err(e.U.read()[:len(U[r::world])], U[r::world]) < tol
+        assert rel_err(e.V.read()[:len(V[r::world])], V[r::world]) < tol
+        assert rel_err(e.b.read()[:len(b[r::world])], b[r::world]) < tol
         got += float(e.accum[0])
     assert abs(got - tl) <= 1e-5 * abs(tl)

@@ -58,7 +58,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world", [1, 2])
-@pytest.mark.parametrize("model,optk", [("bpr", "sgd"), ("bpr", "adagrad"), ("ucml", "sgd")])
+@pytest.mark.parametrize("model,optk", [("bpr", "sgd"), ("bpr", "adagrad"), ("ucml", "sgd"), ("bpr", "adam")])
 def test_sharded_equals_single_process(tmp_path, world, model, optk):
     out = str(tmp_path / "r%d.npz")
     if world == 1:
@@ -66,7 +66,7 @@ def test_sharded_equals_single_process(tmp_path, world, model, optk):
     else:
         mp.spawn(_run_rank, args=(world, _free_port(), model, optk, out), nprocs=world, join=True)
     U, V, b, steps = _global_case(model)
-    o = orc.SGD(0.05) if optk == "sgd" else orc.Adagrad(0.05, 0.1, 1e-7)
+    o = {"sgd": lambda: orc.SGD(0.05), "adagrad": lambda: orc.Adagrad(0.05, 0.1, 1e-7), "adam": lambda: orc.AdamTFSparse(0.05)}[optk]()
     tl = tl2 = 0.0
     for (u, p, n) in steps:
         if model == "bpr":
