@@ -618,9 +618,9 @@ void orx_exact_step_views(orx_ctx* c, const PairPlan& plan, int64_t i, int64_t B
     }
 }
 
-// TF-2.0 Adam applied lazily (see orx_pairwise_step): float4 dims, role bits available, no censor, not hogwild
+// TF-2.0 Adam applied lazily (see orx_pairwise_step): float4 dims, role bits available, not hogwild
 static bool lazy_adam_ok(const orx_opt* opt, const orx_table* U, const orx_table* V, int flags) {
-    return opt->kind == ORX_ADAM && !(flags & (ORX_HOGWILD | ORX_CENSOR)) && orx_fused_can_inline_apply(U->dim) &&
+    return opt->kind == ORX_ADAM && !(flags & ORX_HOGWILD) && orx_fused_can_inline_apply(U->dim) &&
            U->rows < (1LL << 28) && V->rows < (1LL << 28) && getenv("ORX_ADAM_DENSE") == nullptr;
 }
 

@@ -671,6 +671,46 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
         f4 gu, gp, gn; float gbp, gbn;
         row_grads<MODEL>(ru, rp, rn, g, a.l2w, gu, gp, gn, gbp, gbn);
 
+        if (OPT == ORX_ADAM) {
+            // a row referenced once takes its step here (replayed state + gradient), a duplicated one deposits the gradient
+            const float lrT = a.lrt[a.step_t];
+            if (du == 0) {
+                adam_elem4(ru, mu, vu, gu, lrT, a.b1, a.b2, a.eps);
+                if (CENSOR) ru = censor4<LPR>(ru, a.min_norm);      // censor_vec fused into the write-back (see below)
+                *reinterpret_cast<f4*>(Up) = ru; *reinterpret_cast<f4*>(a.aU + (size_t)u * D + 4 * sub) = mu;
+                *reinterpret_cast<f4*>(a.a2U + (size_t)u * D + 4 * sub) = vu;
+                if (sub == 0) a.lastU[u] = a.step_t;
+            } else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t) : -1, D, sub);
+            if (dp == 0) {
+                adam_elem4(rp, mp, vp, gp, lrT, a.b1, a.b2, a.eps);
+                if (CENSOR) rp = censor4<LPR>(rp, a.min_norm);
+                *reinterpret_cast<f4*>(Pp) = rp; *reinterpret_cast<f4*>(a.aV + (size_t)p * D + 4 * sub) = mp;
+                *reinterpret_cast<f4*>(a.a2V + (size_t)p * D + 4 * sub) = vp;
+                if (sub == 0) {
+                    adam_elem(bp, mbp, vbp, gbp, lrT, a.b1, a.b2, a.eps);
+                    a.b[p] = bp; a.ab[p] = mbp; a.a2b[p] = vbp; a.lastV[p] = a.step_t; a.lastb[p] = a.step_t;
+                }
+            } else {
+                const int sp = kp == 2 ? slot_of(Bp + t) : -1;
+                dup_store4s(a.gV, a.gV2, (size_t)p * D + 4 * sub, gp, kp, a.stage, sp, D, sub);
+                if (sub == 0) { dup_store1s(a.gb, a.gb2, p, gbp, kp, a.stageb, sp); if (CENSOR) a.sideV[2 * (size_t)p] = a.epoch; }
+            }
+            if (dn == 0) {
+                adam_elem4(rn, mn, vn, gn, lrT, a.b1, a.b2, a.eps);
+                if (CENSOR) rn = censor4<LPR>(rn, a.min_norm);
+                *reinterpret_cast<f4*>(Np) = rn; *reinterpret_cast<f4*>(a.aV + (size_t)n * D + 4 * sub) = mn;
+                *reinterpret_cast<f4*>(a.a2V + (size_t)n * D + 4 * sub) = vn;
+                if (sub == 0) {
+                    adam_elem(bn, mbn, vbn, gbn, lrT, a.b1, a.b2, a.eps);
+                    a.b[n] = bn; a.ab[n] = mbn; a.a2b[n] = vbn; a.lastV[n] = a.step_t; a.lastb[n] = a.step_t;
+                }
+            } else {
+                const int sn = kn == 2 ? slot_of(2 * Bp + t) : -1;
+                dup_store4s(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn, a.stage, sn, D, sub);
+                if (sub == 0) { dup_store1s(a.gb, a.gb2, n, gbn, kn, a.stageb, sn); if (CENSOR) a.sideV[2 * (size_t)n + 1] = a.epoch; }
+            }
+            continue;
+        }
         // unique row: in place.  duplicated row: gradient into gsum, row untouched.
         if (CENSOR) {
             // censor_vec fused into the write-back: a row referenced once is censored once, here;
@@ -698,43 +738,6 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             if (du == 0) *reinterpret_cast<f4*>(Up) = wu;
             if (dp == 0) *reinterpret_cast<f4*>(Pp) = wp;
             if (dn == 0) *reinterpret_cast<f4*>(Np) = wn;
-            continue;
-        }
-        if (OPT == ORX_ADAM) {
-            // a row referenced once takes its step here (replayed state + gradient), a duplicated one deposits the gradient
-            const float lrT = a.lrt[a.step_t];
-            if (du == 0) {
-                adam_elem4(ru, mu, vu, gu, lrT, a.b1, a.b2, a.eps);
-                *reinterpret_cast<f4*>(Up) = ru; *reinterpret_cast<f4*>(a.aU + (size_t)u * D + 4 * sub) = mu;
-                *reinterpret_cast<f4*>(a.a2U + (size_t)u * D + 4 * sub) = vu;
-                if (sub == 0) a.lastU[u] = a.step_t;
-            } else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t) : -1, D, sub);
-            if (dp == 0) {
-                adam_elem4(rp, mp, vp, gp, lrT, a.b1, a.b2, a.eps);
-                *reinterpret_cast<f4*>(Pp) = rp; *reinterpret_cast<f4*>(a.aV + (size_t)p * D + 4 * sub) = mp;
-                *reinterpret_cast<f4*>(a.a2V + (size_t)p * D + 4 * sub) = vp;
-                if (sub == 0) {
-                    adam_elem(bp, mbp, vbp, gbp, lrT, a.b1, a.b2, a.eps);
-                    a.b[p] = bp; a.ab[p] = mbp; a.a2b[p] = vbp; a.lastV[p] = a.step_t; a.lastb[p] = a.step_t;
-                }
-            } else {
-                const int sp = kp == 2 ? slot_of(Bp + t) : -1;
-                dup_store4s(a.gV, a.gV2, (size_t)p * D + 4 * sub, gp, kp, a.stage, sp, D, sub);
-                if (sub == 0) dup_store1s(a.gb, a.gb2, p, gbp, kp, a.stageb, sp);
-            }
-            if (dn == 0) {
-                adam_elem4(rn, mn, vn, gn, lrT, a.b1, a.b2, a.eps);
-                *reinterpret_cast<f4*>(Np) = rn; *reinterpret_cast<f4*>(a.aV + (size_t)n * D + 4 * sub) = mn;
-                *reinterpret_cast<f4*>(a.a2V + (size_t)n * D + 4 * sub) = vn;
-                if (sub == 0) {
-                    adam_elem(bn, mbn, vbn, gbn, lrT, a.b1, a.b2, a.eps);
-                    a.b[n] = bn; a.ab[n] = mbn; a.a2b[n] = vbn; a.lastV[n] = a.step_t; a.lastb[n] = a.step_t;
-                }
-            } else {
-                const int sn = kn == 2 ? slot_of(2 * Bp + t) : -1;
-                dup_store4s(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn, a.stage, sn, D, sub);
-                if (sub == 0) dup_store1s(a.gb, a.gb2, n, gbn, kn, a.stageb, sn);
-            }
             continue;
         }
         if (du == 0) opt_apply4<OPT>(Up, a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
@@ -810,6 +813,10 @@ __global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
             f4 mm = *reinterpret_cast<const f4*>(A + row * D + 4 * sub), vv = *reinterpret_cast<const f4*>(A2 + row * D + 4 * sub);
             adam_catchup4(wn, mm, vv, L[row], a.step_t - 1, a.lrt, a.b1, a.b2, a.eps);
             adam_elem4(wn, mm, vv, g, a.lrt[a.step_t], a.b1, a.b2, a.eps);
+            if (a.censor) {
+                wn = censor4<LPR>(wn, a.min_norm);
+                if (item && censored_twice(a, row, a.epoch)) wn = censor4<LPR>(wn, a.min_norm);
+            }
             *reinterpret_cast<f4*>(wp) = wn; *reinterpret_cast<f4*>(A + row * D + 4 * sub) = mm; *reinterpret_cast<f4*>(A2 + row * D + 4 * sub) = vv;
             if (sub == 0) L[row] = a.step_t;
         } else if (a.censor) {
@@ -1054,10 +1061,12 @@ static void launch_fused_lpr(int lpr, int mode, dim3 g, orx_ctx* s, const PairAr
 
 int orx_fused_can_inline_apply(int D) { return lpr_for_dim(D) != 0; }
 
-// lazy Adam (exact mode, float4 dims, no censor): its own small set of instantiations
+// lazy Adam (exact mode, float4 dims): its own small set of instantiations
 template <int MODEL>
 static void launch_fused_adam(int lpr, dim3 g, orx_ctx* s, const PairArgs& a) {
-#define ORX_FA(L) do { if (a.stage) ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, true>), g, dim3(256), 0, a); \
+#define ORX_FA(L) do { if (a.censor) { if (a.stage) ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, true, true>), g, dim3(256), 0, a); \
+                                         else ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, true, false>), g, dim3(256), 0, a); } \
+                       else if (a.stage) ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, true>), g, dim3(256), 0, a); \
                        else ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, false>), g, dim3(256), 0, a); } while (0)
     switch (lpr) {
         case 4: ORX_FA(4); break;
@@ -1074,7 +1083,7 @@ int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairA
     const int lpr = lpr_for_dim(a.D);
     const dim3 g((unsigned)(fused_grid(a.D, a.B) + (mode == MODE_EXACT ? a.n_apply_blocks : 0)));
     if (optkind == ORX_ADAM && mode == MODE_EXACT) {
-        ORX_ARG(lpr != 0 && a.lrt != nullptr && !a.censor, "fused: the lazy Adam path needs a float4 dim and no fused censor");
+        ORX_ARG(lpr != 0 && a.lrt != nullptr, "fused: the lazy Adam path needs a float4 dim");
         if (model == ORX_BPR) launch_fused_adam<ORX_BPR>(lpr, g, ctx, a);
         else launch_fused_adam<ORX_UCML>(lpr, g, ctx, a);
         ORX_HIP(hipGetLastError());
