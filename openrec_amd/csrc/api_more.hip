@@ -48,10 +48,6 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
                                   const int32_t* uid, const int32_t* iid, const float* label,
                                   int64_t K, int64_t B, int64_t id_stride, float a_w, float b_w, int flags,
                                   float* loss_out, float* l2_out) {
-    if (U) CHECK(orx_table_sync(U));
-    if (V) CHECK(orx_table_sync(V));
-    if (b) CHECK(orx_table_sync(b));
-    if (w) CHECK(orx_table_sync(w));
     ORX_ARG(c && opt, "orx_pointwise_step: NULL context/optimizer");
     CHECK(check_point_tables(model, U, V, b, w));
     ORX_ARG(K >= 0 && B > 0, "orx_pointwise_step: K must be >= 0 and B > 0");
@@ -61,7 +57,17 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     const int32_t *du, *di; const float* dl; int64_t ds;
     CHECK(stage_point(c, uid, iid, label, K, B, id_stride, flags, &du, &di, &dl, &ds));
     const bool hogwild = (flags & ORX_HOGWILD) != 0;
-    const int mode = opt->kind == ORX_ADAM ? MODE_ACCUM : (hogwild ? MODE_HOGWILD : MODE_EXACT);
+    const char* fb_env = getenv("ORX_FORCE_FALLBACK");
+    const int fb = fb_env ? atoi(fb_env) : 0;
+    // TF-2.0 Adam applied lazily, as in orx_pairwise_step: float4 dims with the exact-step plan; the
+    // Dense(1) kernel of GMF is a dense parameter and takes the plain rule.  Otherwise every reference accumulates
+    // and the tables are swept whole.
+    const bool lazy_adam = opt->kind == ORX_ADAM && !hogwild && orx_fused_can_inline_apply(U->dim) && U->rows < (1LL << 28) &&
+                           V->rows < (1LL << 28) && !(fb & 1) && getenv("ORX_ADAM_DENSE") == nullptr;
+    const int mode = (opt->kind == ORX_ADAM && !lazy_adam) ? MODE_ACCUM : (hogwild ? MODE_HOGWILD : MODE_EXACT);
+    const bool lazy_resume = lazy_adam && U->lazy == opt && V->lazy == opt && b->lazy == opt;
+    if (!lazy_resume) for (orx_table* t : {U, V, b}) CHECK(orx_table_sync(t));
+    if (w) CHECK(orx_table_sync(w));
     CHECK(orx_table_scratch(U)); CHECK(orx_table_scratch(V)); CHECK(orx_table_scratch(b));
     if (w) CHECK(orx_table_scratch(w));
     OptSlots sU, sV, sb, sw;
@@ -77,8 +83,6 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     // exact mode on the float4 dims below 2^28 rows: the plan of the pairwise step (roles: rows referenced twice get
     // plain stores; staging plan + reduction tree for hot rows), made once for all K steps.  Otherwise byte flags +
     // atomics for every duplicate.
-    const char* fb_env = getenv("ORX_FORCE_FALLBACK");
-    const int fb = fb_env ? atoi(fb_env) : 0;
     const bool role_bits = mode == MODE_EXACT && orx_fused_can_inline_apply(D) && U->rows < (1LL << 28) && V->rows < (1LL << 28) && !(fb & 1);
     const bool staging = role_bits && !(fb & 8);
     PairPlan plan;
@@ -119,6 +123,16 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     pa.U = U->w; pa.V = V->w; pa.b = b->w; pa.gU = U->gsum; pa.gV = V->gsum; pa.gb = b->gsum;
     if (role_bits) { pa.gU2 = U->gsum2; pa.gV2 = V->gsum2; pa.gb2 = b->gsum2; pa.role_bits = 1; }
     pa.aU = sU.s0; pa.aV = sV.s0; pa.ab = sb.s0; pa.B = B; pa.D = D; pa.lr = a.lr; pa.eps = a.eps;
+    if (lazy_adam) {
+        a.a2U = pa.a2U = sU.s1; a.a2V = pa.a2V = sV.s1; a.a2b = pa.a2b = sb.s1;
+        CHECK(orx_opt_last(opt, U, !lazy_resume, &a.lastU)); CHECK(orx_opt_last(opt, V, !lazy_resume, &a.lastV));
+        CHECK(orx_opt_last(opt, b, !lazy_resume, &a.lastb));
+        pa.lastU = a.lastU; pa.lastV = a.lastV; pa.lastb = a.lastb;
+        CHECK(orx_adam_lrt(opt, opt->t + K));
+        a.lrt = pa.lrt = opt->d_lrt; a.b1 = pa.b1 = opt->p0; a.b2 = pa.b2 = opt->p1; a.eps = pa.eps = opt->p2;
+        a.newton = pa.newton = (1.0f - sqrtf(opt->p1)) <= 1e-3f && getenv("ORX_ADAM_NO_NEWTON") == nullptr;
+        U->lazy = opt; V->lazy = opt; b->lazy = opt;
+    }
     const int64_t chunk = role_bits ? plan.chunk : K;
     for (int64_t s0 = 0; s0 < K; s0 += chunk) {
     const int64_t kc = (K - s0 < chunk) ? (K - s0) : chunk;
@@ -137,12 +151,13 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
             a.dflag = c->d_dflag + (size_t)s * 2 * B;
             pa.dlist = c->d_dlist + (size_t)s * list_stride; pa.dcount = c->d_dcount + s;
         }
+        if (lazy_adam) { opt->t += 1; a.step_t = pa.step_t = (int)opt->t; }
         CHECK(orx_launch_point_fused(c, model, opt->kind, mode, a));
         if (mode == MODE_EXACT) {
             for (int l = 0; l < ck.tree_levels; ++l) CHECK(orx_launch_hot_reduce(c, pa, l));
             CHECK(orx_launch_dup_apply(c, opt->kind, pa));
         }
-        float lr_t = 0.f;
+        float lr_t = lazy_adam ? opt->h_lrt[(size_t)opt->t] : 0.f;
         if (mode == MODE_ACCUM) {
             opt->t += 1;
             const double b1 = opt->p0, b2 = opt->p1;
@@ -152,7 +167,7 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
             CHECK(orx_launch_adam_sweep(c, b->w, sb.s0, sb.s1, b->gsum, b->rows, lr_t, opt->p0, opt->p1, opt->p2));
         }
         if (model == ORX_GMF) {                  // dense Dense(1) kernel: reduce partials, apply the dense rule
-            if (mode == MODE_ACCUM) {
+            if (mode == MODE_ACCUM || lazy_adam) {
                 CHECK(orx_launch_dense_reduce(c, c->d_wpart, nw, D, w->w, a.l2w, w->gsum, a.partial + 2 * nw, nullptr, -1, 0.f, 0.f));
                 CHECK(orx_launch_adam_sweep(c, w->w, sw.s0, sw.s1, w->gsum, D, lr_t, opt->p0, opt->p1, opt->p2));
             } else {        // reduce + dense SGD / Adagrad rule in one launch

@@ -60,9 +60,20 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
         if (!(id_ok(u, a.NU) & id_ok(i, a.NI))) { if (sub == 0) *a.err = 1; continue; }
         float* Up = a.U + (size_t)u * D + 4 * sub;
         float* Ip = a.V + (size_t)i * D + 4 * sub;
-        const f4 ru = *reinterpret_cast<const f4*>(Up);
-        const f4 ri = *reinterpret_cast<const f4*>(Ip);
-        const float bi = a.b[i];
+        f4 ru = *reinterpret_cast<const f4*>(Up);
+        f4 ri = *reinterpret_cast<const f4*>(Ip);
+        float bi = a.b[i];
+        // lazy Adam: (w, m, v) of the two rows and the bias, replayed up to the step before this one
+        f4 mu, vu, mi, vi;
+        float mbi = 0.f, vbi = 0.f;
+        if (OPT == ORX_ADAM) {
+            mu = *reinterpret_cast<const f4*>(a.aU + (size_t)u * D + 4 * sub); vu = *reinterpret_cast<const f4*>(a.a2U + (size_t)u * D + 4 * sub);
+            mi = *reinterpret_cast<const f4*>(a.aV + (size_t)i * D + 4 * sub); vi = *reinterpret_cast<const f4*>(a.a2V + (size_t)i * D + 4 * sub);
+            mbi = a.ab[i]; vbi = a.a2b[i];
+            const int lu = a.lastU[u], li = a.lastV[i];
+            if (a.newton) adam_catchup_pair<true, LPR>(ru, mu, vu, lu, ri, mi, vi, li, bi, mbi, vbi, a.step_t - 1, a.lrt, a.b1, a.b2, a.eps);
+            else adam_catchup_pair<false, LPR>(ru, mu, vu, lu, ri, mi, vi, li, bi, mbi, vbi, a.step_t - 1, a.lrt, a.b1, a.b2, a.eps);
+        }
         const f4 ui = ru * ri;
         const float s = group_allreduce<LPR>(dot4(ui, wv)) + bi;
         float term, gs;
@@ -79,6 +90,29 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
             const int2 ri2 = a.refinfo[ref];
             return ri2.x < 0 ? -1 : a.segstart[ri2.x] + ri2.y;
         };
+        if (OPT == ORX_ADAM) {          // a row referenced once takes its step here, a duplicated one deposits its gradient
+            const float lrT = a.lrt[a.step_t];
+            if (du == 0) {
+                adam_elem4(ru, mu, vu, gu, lrT, a.b1, a.b2, a.eps);
+                *reinterpret_cast<f4*>(Up) = ru; *reinterpret_cast<f4*>(a.aU + (size_t)u * D + 4 * sub) = mu;
+                *reinterpret_cast<f4*>(a.a2U + (size_t)u * D + 4 * sub) = vu;
+                if (sub == 0) a.lastU[u] = a.step_t;
+            } else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t) : -1, D, sub);
+            if (di == 0) {
+                adam_elem4(ri, mi, vi, gi, lrT, a.b1, a.b2, a.eps);
+                *reinterpret_cast<f4*>(Ip) = ri; *reinterpret_cast<f4*>(a.aV + (size_t)i * D + 4 * sub) = mi;
+                *reinterpret_cast<f4*>(a.a2V + (size_t)i * D + 4 * sub) = vi;
+                if (sub == 0) {
+                    adam_elem(bi, mbi, vbi, gs, lrT, a.b1, a.b2, a.eps);
+                    a.b[i] = bi; a.ab[i] = mbi; a.a2b[i] = vbi; a.lastV[i] = a.step_t; a.lastb[i] = a.step_t;
+                }
+            } else {
+                const int si = ki == 2 ? slot_of((a.iid - a.uid) + t) : -1;
+                dup_store4s(a.gV, a.gV2, (size_t)i * D + 4 * sub, gi, ki, a.stage, si, D, sub);
+                if (sub == 0) dup_store1s(a.gb, a.gb2, i, gs, ki, a.stageb, si);
+            }
+            continue;
+        }
         if (du == 0) opt_apply4<OPT>(Up, a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
         else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t) : -1, D, sub);
         if (di == 0) {
@@ -324,10 +358,29 @@ static void launch_point_lpr(int lpr, int mode, dim3 g, orx_ctx* c, const PointA
     }
 }
 
+// lazy Adam: exact mode on the float4 dims only
+template <int MODEL>
+static void launch_point_adam(int lpr, dim3 g, orx_ctx* c, const PointArgs& a) {
+    switch (lpr) {
+        case 4: ORX_LAUNCH(c, (point_fused_kernel<4, MODEL, ORX_ADAM, MODE_EXACT>), g, dim3(256), 0, a); break;
+        case 8: ORX_LAUNCH(c, (point_fused_kernel<8, MODEL, ORX_ADAM, MODE_EXACT>), g, dim3(256), 0, a); break;
+        case 16: ORX_LAUNCH(c, (point_fused_kernel<16, MODEL, ORX_ADAM, MODE_EXACT>), g, dim3(256), 0, a); break;
+        case 32: ORX_LAUNCH(c, (point_fused_kernel<32, MODEL, ORX_ADAM, MODE_EXACT>), g, dim3(256), 0, a); break;
+        default: ORX_LAUNCH(c, (point_fused_kernel<64, MODEL, ORX_ADAM, MODE_EXACT>), g, dim3(256), 0, a); break;
+    }
+}
+
 int orx_launch_point_fused(orx_ctx* ctx, int model, int optkind, int mode, const PointArgs& a) {
     ProfScope ps(ctx, ORX_K_POINT);
     const int lpr = lpr_for_dim_p(a.D);
     const dim3 g((unsigned)point_grid(a.D, a.B));
+    if (optkind == ORX_ADAM && mode == MODE_EXACT) {
+        ORX_ARG(lpr != 0 && a.lrt != nullptr && a.role_bits, "point_fused: the lazy Adam path needs a float4 dim and the exact-step plan");
+        if (model == ORX_GMF) launch_point_adam<ORX_GMF>(lpr, g, ctx, a);
+        else launch_point_adam<ORX_WRMF>(lpr, g, ctx, a);
+        ORX_HIP(hipGetLastError());
+        return ORX_OK;
+    }
     const bool ada = optkind == ORX_ADAGRAD;
     if (model == ORX_GMF) {
         if (ada) launch_point_lpr<ORX_GMF, ORX_ADAGRAD>(lpr, mode, g, ctx, a);

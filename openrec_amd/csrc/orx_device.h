@@ -299,6 +299,45 @@ __device__ __forceinline__ void adam_catchup_triplet(f4& wu, f4& mu, f4& vu, int
     }
 }
 
+// the two rows (and the item bias) of one pointwise sample: same scheme as adam_catchup_triplet
+template <bool NEWTON, int LPR>
+__device__ __forceinline__ void adam_catchup_pair(f4& wu, f4& mu, f4& vu, int lu, f4& wi, f4& mi, f4& vi, int li,
+                                                  float& bi, float& mbi, float& vbi, int to, const float* lrt,
+                                                  float b1, float b2, float eps) {
+    const int mine = min(lu, li);
+    const unsigned long long act = __ballot(1);
+    int first = to;
+#pragma unroll
+    for (int g = 0; g < 64 / LPR; ++g) {
+        const int other = __builtin_amdgcn_readlane(mine, g * LPR);
+        if ((act >> (g * LPR)) & 1) first = min(first, other);
+    }
+    if (first >= to) return;
+    const float sb2 = sqrtf(b2);
+    const float ce = eps * (1.0f - sb2);
+    f4 du = sqrt4(vu) + eps, di = sqrt4(vi) + eps;
+    float dbi = sqrtf(vbi) + eps;
+    f4 qu = rcp4(du), qi = rcp4(di);
+    float qbi = __builtin_amdgcn_rcpf(dbi);
+    float nxt = sload_wait(sload_issue(lrt, first + 1));
+    for (int k = first + 1; k <= to; ++k) {
+        const float lr = nxt;
+        nxt = sload_issue(lrt, k + 1);
+        if (k > lu) {
+            mu = mu * b1; vu = vu * b2; du = du * sb2 + ce;
+            if (NEWTON) qu = qu * (2.0f - du * qu); else qu = rcp4(du);
+            wu = wu - (lr * mu) * qu;
+        }
+        if (k > li) {
+            mi = mi * b1; vi = vi * b2; di = di * sb2 + ce;
+            mbi *= b1; vbi *= b2; dbi = dbi * sb2 + ce;
+            if (NEWTON) { qi = qi * (2.0f - di * qi); qbi = qbi * (2.0f - dbi * qbi); } else { qi = rcp4(di); qbi = __builtin_amdgcn_rcpf(dbi); }
+            wi = wi - (lr * mi) * qi; bi -= (lr * mbi) * qbi;
+        }
+        nxt = sload_wait(nxt);
+    }
+}
+
 // ------------------------------------------------- duplicated-row deposits ---
 // Gradient of a duplicated reference.  Rows referenced exactly twice in the batch get one PLAIN
 // store per reference, into scratch row 1 (role 0) or scratch row 2 (role 1): no atomics and a

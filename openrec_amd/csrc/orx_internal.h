@@ -283,6 +283,9 @@ struct PointArgs {
     float* partial;                           // [nwaves][2]
     float* wpartial;                          // [nwaves][D] (GMF)
     int* err;
+    // lazy TF-2.0 Adam: second slots, per-row step stamps (the bias shares its item row's), lr_t table
+    float* a2U; float* a2V; float* a2b; int* lastU; int* lastV; int* lastb;
+    const float* lrt; float b1; float b2; int step_t; int newton;
 };
 
 int orx_launch_point_fused(orx_ctx* ctx, int model, int optkind, int mode, const PointArgs& a);

@@ -127,3 +127,56 @@ def test_skewed_items_and_hot_user(model, optkind, D, fallback, monkeypatch):
         assert np.abs(got - want).max() <= tol * np.abs(want).max()
     if model == "gmf":
         assert np.abs(tw.read() - wk).max() <= 1e-4 * np.abs(wk).max()
+
+
+@pytest.mark.parametrize("model,NU,NI,B,K,D", [("gmf", 40000, 30000, 4096, 16, 64), ("wrmf", 3000, 2500, 8192, 10, 32),
+                                               ("wrmf", 90000, 70000, 2048, 24, 128)])
+def test_lazy_adam_is_the_dense_decay_adam(model, NU, NI, B, K, D, monkeypatch):
+    """GMF / WRMF with TF-2.0 Adam: the K-step path applies the every-row-every-step rule lazily (rows replay their
+    gradient-free steps when next referenced or read); two calls of K steps with a read in between, against the
+    fp64 oracle's dense rule, and the whole-table-sweep form (ORX_ADAM_DENSE=1) against the same numbers."""
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    rng = np.random.default_rng(K + D)
+    U32 = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V32 = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b32 = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32); w32 = rng.uniform(-.3, .3, (D, 1)).astype(np.float32)
+    uid = rng.integers(0, NU, (2 * K, B)).astype(np.int32); iid = rng.integers(0, NI, (2 * K, B)).astype(np.int32)
+    lab = (rng.uniform(size=(2 * K, B)) < 0.4).astype(np.float32)
+    U, V, b, w = (x.astype(np.float64) for x in (U32, V32, b32, w32))
+    oo = orc.AdamTFSparse(0.002, 0.9, 0.999, 1e-7)
+    ref_loss, ref_mid = [], None
+    for s in range(2 * K):
+        if model == "gmf":
+            ref_loss.append(orc.gmf_step(U, V, b, w, uid[s], iid[s], lab[s], oo)[0])
+        else:
+            ref_loss.append(orc.wrmf_step(U, V, b, uid[s], iid[s], lab[s], oo, a=1.5, b_w=0.7)[0])
+        if s == K - 1:
+            ref_mid = U.copy()
+    # fp32 against the fp64 oracle: Adam normalises every gradient to a step of ~lr, so a handful of rows whose
+    # gradient is nearly zero part from the oracle by 1e-4 .. 5e-4 after 2K steps, in BOTH forms alike: all but
+    # 0.1 % of the rows must be within 5e-5, none beyond 2e-3 -- and the two forms must agree with each other to 1e-5
+    def close(dev, host):
+        e = np.abs(np.asarray(dev, np.float64) - host).max(axis=1) / np.abs(host).max()
+        return (e > 5e-5).mean() <= 1e-3 and e.max() < 2e-3
+    got = {}
+    for form in ("lazy", "dense"):
+        if form == "dense":
+            monkeypatch.setenv("ORX_ADAM_DENSE", "1")
+        tU = rt.Table(NU, D).write(U32); tV = rt.Table(NI, D).write(V32); tb = rt.Table(NI, 1).write(b32)
+        tw = rt.Table(D, 1).write(w32) if model == "gmf" else None
+        opt = rt.Optimizer.adam(0.002, 0.9, 0.999, 1e-7)
+        loss = []
+        for rep in range(2):
+            sl = slice(rep * K, (rep + 1) * K)
+            loss += list(rt.pointwise_step(model, opt, tU, tV, tb, tw, uid[sl], iid[sl], lab[sl], K=K, B=B, a=1.5, b_w=0.7)[0])
+            if rep == 0:
+                assert close(tU.read(), ref_mid), form
+        assert np.abs(np.array(loss) - np.array(ref_loss)).max() <= 2e-5 * np.abs(ref_loss).max(), form
+        assert close(tU.read(), U) and close(tV.read(), V) and close(tb.read(), b), form
+        assert close(opt.slot(tV, 0), oo.m["V"]) and rel_err(opt.slot(tV, 1), oo.v["V"]) < 2e-3, form
+        if model == "gmf":
+            assert rel_err(tw.read(), w) < 5e-5, form
+        got[form] = (tU.read(), tV.read(), tb.read())
+    for x, y in zip(got["lazy"], got["dense"]):       # (the same few rows amplify the replay's rounding)
+        e = np.abs(x.astype(np.float64) - y).max(axis=1) / np.abs(y).max()
+        assert (e > 1e-5).mean() <= 1e-3 and e.max() < 2e-3
