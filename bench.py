@@ -69,17 +69,7 @@ def cpu_baseline(args, budget_s=15.0, max_steps=2000):
     U = rng.uniform(-0.05, 0.05, (args.users, args.dim)).astype(np.float32)
     V = rng.uniform(-0.05, 0.05, (args.items, args.dim)).astype(np.float32)
     b = rng.uniform(-0.05, 0.05, (args.items, 1)).astype(np.float32)
-    if args.opt == "adam":          # the C port has SGD/Adagrad; Adam's whole-table rule is timed on the numpy restatement
-        from oracle import numpy_oracle as orc
-        oo = orc.AdamTFSparse(0.05)
-        stepfn = {"bpr": orc.bpr_step, "ucml": lambda *a: orc.ucml_step(*a, margin=0.5, do_censor=False)}[args.model]
-
-        class _NP:
-            def step(self, u, p, n):
-                stepfn(U, V, b, u, p, n, oo)
-        cpu, cores, what = _NP(), 1, "oracle/numpy_oracle.py (numpy, one thread)"
-    else:
-        cpu, cores, what = c_oracle.PairwiseCPU(args.model, args.opt, U, V, b, lr=0.05), c_oracle.num_threads(), "oracle/orx_oracle.c (OpenMP)"
+    cpu, cores, what = c_oracle.PairwiseCPU(args.model, args.opt, U, V, b, lr=0.05), c_oracle.num_threads(), "oracle/orx_oracle.c (OpenMP)"
     ids = [(rng.integers(0, args.users, args.batch).astype(np.int32),
             rng.integers(0, args.items, args.batch).astype(np.int32),
             rng.integers(0, args.items, args.batch).astype(np.int32)) for _ in range(32)]

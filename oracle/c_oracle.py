@@ -40,6 +40,11 @@ def lib():
                                         ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                         fp, ctypes.POINTER(ctypes.c_double)]
         L.orc_pairwise_step.restype = ctypes.c_int
+        L.orc_pairwise_step_adam.argtypes = [ctypes.c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp,
+                                             ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ip, ip, ip, ctypes.c_int64,
+                                             ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                             fp, ctypes.POINTER(ctypes.c_double)]
+        L.orc_pairwise_step_adam.restype = ctypes.c_int
         L.orc_censor.argtypes = [fp, ctypes.c_int64, ctypes.c_int, ip, ctypes.c_int64, ctypes.c_float]
         L.orc_censor.restype = ctypes.c_int
         L.orc_num_threads.restype = ctypes.c_int
@@ -56,11 +61,12 @@ def _ip(a):
 
 
 class PairwiseCPU:
-    """Holds scratch + Adagrad slots; tables are caller-owned float32 C-contiguous arrays."""
+    """Holds scratch + Adagrad / Adam slots; tables are caller-owned float32 C-contiguous arrays."""
 
-    def __init__(self, model, opt, U, V, b, lr, eps=1e-7, init_acc=0.1, margin=0.5):
+    def __init__(self, model, opt, U, V, b, lr, eps=1e-7, init_acc=0.1, margin=0.5, beta_1=0.9, beta_2=0.999):
         self.model = {"bpr": 0, "ucml": 1}[model]
-        self.opt = {"sgd": 0, "adagrad": 1}[opt]
+        self.opt = {"sgd": 0, "adagrad": 1, "adam": 2}[opt]
+        self.b1, self.b2, self.t = beta_1, beta_2, 0
         self.U, self.V, self.b = U, V, b.reshape(-1)
         assert U.dtype == np.float32 and U.flags.c_contiguous and V.flags.c_contiguous
         self.lr, self.eps, self.margin = lr, eps, margin
@@ -70,6 +76,9 @@ class PairwiseCPU:
             self.accb = np.full_like(self.b, init_acc)
         else:
             self.accU = self.accV = self.accb = None
+        if self.opt == 2:
+            self.m = [np.zeros_like(x) for x in (U, V, self.b)]
+            self.v = [np.zeros_like(x) for x in (U, V, self.b)]
         self.scratch = None
 
     def step(self, uid, pid, nid):
@@ -78,6 +87,15 @@ class PairwiseCPU:
         if self.scratch is None or self.scratch.size < need:
             self.scratch = np.empty(need, np.float32)
         out = (ctypes.c_double * 2)()
+        if self.opt == 2:
+            self.t += 1
+            lr_t = self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+            rc = lib().orc_pairwise_step_adam(self.model, _fp(self.U), _fp(self.V), _fp(self.b), _fp(self.m[0]), _fp(self.v[0]),
+                                              _fp(self.m[1]), _fp(self.v[1]), _fp(self.m[2]), _fp(self.v[2]),
+                                              self.U.shape[0], self.V.shape[0], D, _ip(uid), _ip(pid), _ip(nid), B,
+                                              lr_t, self.b1, self.b2, self.eps, self.margin, _fp(self.scratch), out)
+            assert rc == 0
+            return out[0], out[1]
         rc = lib().orc_pairwise_step(self.model, self.opt, _fp(self.U), _fp(self.V), _fp(self.b),
                                      _fp(self.accU), _fp(self.accV), _fp(self.accb),
                                      self.U.shape[0], self.V.shape[0], D, _ip(uid), _ip(pid), _ip(nid), B,

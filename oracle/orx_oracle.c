@@ -9,8 +9,9 @@
  *   openrec/tf2/recommenders/bpr.py:21-37, ucml.py:21-42,
  *   openrec/tf2/modules/pairwise_log_loss.py:15-34,
  *   tf2_examples/bpr_citeulike.py:33-39 (tape over (loss, l2_loss) + apply)
- * with TF-2.0 Keras SGD / Adagrad sparse-apply semantics (snapshot gradients,
- * SGD accumulates every occurrence, Adagrad sums duplicates first).
+ * with TF-2.0 Keras SGD / Adagrad / Adam sparse-apply semantics (snapshot gradients,
+ * SGD accumulates every occurrence, Adagrad and Adam sum duplicates first, Adam decays and
+ * moves every row of a table at every step).
  *
  * Build:  gcc -O3 -march=native -fopenmp -shared -fPIC orx_oracle.c -o _build/liborx_oracle.so -lm
  */
@@ -43,22 +44,13 @@ static inline float sigmoidf_(float x) {
 
 /* scratch layout: gu,gp,gn [B*D] each, gb [B] -> (3*B*D + B) floats */
 
-/* One train step.  Tables U[NU,D], V[NI,D], b[NI] are updated in place.
- * accU/accV/accb are the Adagrad accumulators (ignored for SGD).
- * Returns loss and l2_loss through out[0], out[1]. */
-int orc_pairwise_step(int model, int opt, float* U, float* V, float* b,
-                      float* accU, float* accV, float* accb,
-                      int64_t NU, int64_t NI, int D,
-                      const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t B,
-                      float lr, float eps, float margin, float* scratch, double* out) {
-    float* gu = scratch;
-    float* gp = gu + (size_t)B * D;
-    float* gn = gp + (size_t)B * D;
-    float* gb = gn + (size_t)B * D;
+/* forward + per-occurrence gradients on the PRE-step tables (objective loss + l2_loss) */
+static void forward_grads(int model, const float* U, const float* V, const float* b, int D,
+                          const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t B, float margin,
+                          float* gu, float* gp, float* gn, float* gb, double* out) {
     double loss = 0.0, l2 = 0.0;
     const float invB = 1.0f / (float)B;
 
-    /* ---- forward + per-occurrence gradients on the PRE-step tables ---- */
 #pragma omp parallel for reduction(+ : loss, l2) schedule(static)
     for (int64_t k = 0; k < B; ++k) {
         const float* u = U + (size_t)uid[k] * D;
@@ -98,6 +90,21 @@ int orc_pairwise_step(int model, int opt, float* U, float* V, float* b,
         l2 += 0.5 * (double)sq;
     }
     out[0] = loss; out[1] = l2;
+}
+
+/* One train step.  Tables U[NU,D], V[NI,D], b[NI] are updated in place.
+ * accU/accV/accb are the Adagrad accumulators (ignored for SGD).
+ * Returns loss and l2_loss through out[0], out[1]. */
+int orc_pairwise_step(int model, int opt, float* U, float* V, float* b,
+                      float* accU, float* accV, float* accb,
+                      int64_t NU, int64_t NI, int D,
+                      const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t B,
+                      float lr, float eps, float margin, float* scratch, double* out) {
+    float* gu = scratch;
+    float* gp = gu + (size_t)B * D;
+    float* gn = gp + (size_t)B * D;
+    float* gb = gn + (size_t)B * D;
+    forward_grads(model, U, V, b, D, uid, pid, nid, B, margin, gu, gp, gn, gb, out);
 
     /* ---- optimizer sparse apply ---- */
     if (opt == ORC_SGD) {
@@ -163,6 +170,76 @@ int orc_pairwise_step(int model, int opt, float* U, float* V, float* b,
         }
         free(headU); free(headV); free(nextU); free(nextV); free(G);
     }
+    return 0;
+}
+
+/* TF-2.0 Keras Adam, sparse apply ("dense decay", numpy_oracle.AdamTFSparse): for every variable
+ *   m <- b1*m (whole table);  m[idx] += (1-b1)*G   (G: duplicates summed first)
+ *   v <- b2*v (whole table);  v[idx] += (1-b2)*G*G
+ *   var <- var - lr_t * m / (sqrt(v) + eps)        (whole table)
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller (step counter t). */
+static void adam_decay(float* m, float* v, size_t n, float b1, float b2) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) { m[i] *= b1; v[i] *= b2; }
+}
+static void adam_update(float* w, const float* m, const float* v, size_t n, float lr_t, float eps) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) w[i] -= lr_t * m[i] / (sqrtf(v[i]) + eps);
+}
+
+int orc_pairwise_step_adam(int model, float* U, float* V, float* b,
+                           float* mU, float* vU, float* mV, float* vV, float* mb, float* vb,
+                           int64_t NU, int64_t NI, int D,
+                           const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t B,
+                           float lr_t, float b1, float b2, float eps, float margin, float* scratch, double* out) {
+    float* gu = scratch;
+    float* gp = gu + (size_t)B * D;
+    float* gn = gp + (size_t)B * D;
+    float* gb = gn + (size_t)B * D;
+    forward_grads(model, U, V, b, D, uid, pid, nid, B, margin, gu, gp, gn, gb, out);
+    adam_decay(mU, vU, (size_t)NU * D, b1, b2);
+    adam_decay(mV, vV, (size_t)NI * D, b1, b2);
+    adam_decay(mb, vb, (size_t)NI, b1, b2);
+    {   /* summed gradient of every distinct row (reference chains as in the Adagrad branch) */
+        int64_t* headU = (int64_t*)malloc(sizeof(int64_t) * (size_t)NU);
+        int64_t* headV = (int64_t*)malloc(sizeof(int64_t) * (size_t)NI);
+        int64_t* nextU = (int64_t*)malloc(sizeof(int64_t) * (size_t)B);
+        int64_t* nextV = (int64_t*)malloc(sizeof(int64_t) * (size_t)B * 2);
+        float* G = (float*)malloc(sizeof(float) * (size_t)D);
+        if (!headU || !headV || !nextU || !nextV || !G) return -1;
+        for (int64_t k = 0; k < B; ++k) { headU[uid[k]] = -1; headV[pid[k]] = -1; headV[nid[k]] = -1; }
+        for (int64_t k = B - 1; k >= 0; --k) { nextU[k] = headU[uid[k]]; headU[uid[k]] = k; }
+        for (int64_t k = 2 * B - 1; k >= 0; --k) {
+            int32_t r = k < B ? pid[k] : nid[k - B];
+            nextV[k] = headV[r]; headV[r] = k;
+        }
+        for (int64_t k = 0; k < B; ++k) {
+            int32_t r = uid[k];
+            if (headU[r] != k) continue;
+            memset(G, 0, sizeof(float) * D);
+            for (int64_t j = k; j >= 0; j = nextU[j]) for (int d = 0; d < D; ++d) G[d] += gu[j * D + d];
+            float* m = mU + (size_t)r * D; float* v = vU + (size_t)r * D;
+            for (int d = 0; d < D; ++d) { m[d] += (1.f - b1) * G[d]; v[d] += (1.f - b2) * G[d] * G[d]; }
+        }
+        for (int64_t k = 0; k < 2 * B; ++k) {
+            int32_t r = k < B ? pid[k] : nid[k - B];
+            if (headV[r] != k) continue;
+            memset(G, 0, sizeof(float) * D);
+            float Gb = 0.f;
+            for (int64_t j = k; j >= 0; j = nextV[j]) {
+                const float* src = j < B ? gp + j * D : gn + (j - B) * D;
+                for (int d = 0; d < D; ++d) G[d] += src[d];
+                Gb += j < B ? gb[j] : -gb[j - B];
+            }
+            float* m = mV + (size_t)r * D; float* v = vV + (size_t)r * D;
+            for (int d = 0; d < D; ++d) { m[d] += (1.f - b1) * G[d]; v[d] += (1.f - b2) * G[d] * G[d]; }
+            mb[r] += (1.f - b1) * Gb; vb[r] += (1.f - b2) * Gb * Gb;
+        }
+        free(headU); free(headV); free(nextU); free(nextV); free(G);
+    }
+    adam_update(U, mU, vU, (size_t)NU * D, lr_t, eps);
+    adam_update(V, mV, vV, (size_t)NI * D, lr_t, eps);
+    adam_update(b, mb, vb, (size_t)NI, lr_t, eps);
     return 0;
 }
 
