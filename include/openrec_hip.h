@@ -50,7 +50,9 @@ enum orx_status {
  * gradient-free steps when it is next referenced, and every entry point that observes a table or its slots
  * (read / gather / device_ptr / slot_read / inference / another optimizer / orx_opt_destroy) first brings
  * the rows it exposes up to date, so the result is the dense rule's at every observation.
- * ORX_ADAM_DENSE=1 in the environment selects the literal whole-table sweeps. */
+ * Tables over caller-owned memory (orx_table_wrap) always take the literal whole-table sweeps, as does
+ * everything with ORX_ADAM_DENSE=1 in the environment.  A pointer obtained from orx_table_device_ptr is
+ * current when returned; after further Adam steps, ask again. */
 enum orx_opt_kind { ORX_SGD = 0, ORX_ADAGRAD = 1, ORX_ADAM = 2 };
 
 /* pairwise recommenders: recommenders/bpr.py:5, recommenders/ucml.py:5 */

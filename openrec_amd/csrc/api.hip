@@ -621,7 +621,8 @@ void orx_exact_step_views(orx_ctx* c, const PairPlan& plan, int64_t i, int64_t B
 // TF-2.0 Adam applied lazily (see orx_pairwise_step): float4 dims, role bits available, not hogwild
 static bool lazy_adam_ok(const orx_opt* opt, const orx_table* U, const orx_table* V, int flags) {
     return opt->kind == ORX_ADAM && !(flags & ORX_HOGWILD) && orx_fused_can_inline_apply(U->dim) &&
-           U->rows < (1LL << 28) && V->rows < (1LL << 28) && getenv("ORX_ADAM_DENSE") == nullptr;
+           U->rows < (1LL << 28) && V->rows < (1LL << 28) && U->owned && V->owned &&      // (wrapped memory is read behind our back)
+           getenv("ORX_ADAM_DENSE") == nullptr;
 }
 
 extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
@@ -649,7 +650,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     // exactly: a row's gradient-free steps are replayed when the row is next touched (or observed: orx_table_sync);
     // the dense form (every reference accumulates, then three whole-table sweeps per step) remains for the other
     // cases and behind ORX_ADAM_DENSE=1.
-    const bool lazy_adam = lazy_adam_ok(opt, U, V, flags);
+    const bool lazy_adam = lazy_adam_ok(opt, U, V, flags) && b->owned;
     const int mode = (opt->kind == ORX_ADAM && !lazy_adam) ? MODE_ACCUM : (hogwild ? MODE_HOGWILD : MODE_EXACT);
     // the three tables are lazy together under one optimizer (the item rows and their biases then share step stamps),
     // or not at all: anything else first brings every row up to date

@@ -63,7 +63,7 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     // Dense(1) kernel of GMF is a dense parameter and takes the plain rule.  Otherwise every reference accumulates
     // and the tables are swept whole.
     const bool lazy_adam = opt->kind == ORX_ADAM && !hogwild && orx_fused_can_inline_apply(U->dim) && U->rows < (1LL << 28) &&
-                           V->rows < (1LL << 28) && !(fb & 1) && getenv("ORX_ADAM_DENSE") == nullptr;
+                           V->rows < (1LL << 28) && !(fb & 1) && U->owned && V->owned && b->owned && getenv("ORX_ADAM_DENSE") == nullptr;
     const int mode = (opt->kind == ORX_ADAM && !lazy_adam) ? MODE_ACCUM : (hogwild ? MODE_HOGWILD : MODE_EXACT);
     const bool lazy_resume = lazy_adam && U->lazy == opt && V->lazy == opt && b->lazy == opt;
     if (!lazy_resume) for (orx_table* t : {U, V, b}) CHECK(orx_table_sync(t));
@@ -278,7 +278,7 @@ extern "C" int orx_pair_grads(orx_ctx* ctx, int model, int32_t D,
 // The rule moves every row every step; a row's gradient-free steps are replayed when it is next referenced
 // (gathered for a forward pass: touch; given a gradient: apply) or when the table is observed (orx_table_sync).
 bool orx_adam_rows_lazy(const orx_opt* opt, const orx_table* t) {
-    return opt->kind == ORX_ADAM && t->rows < (1LL << 31) && getenv("ORX_ADAM_DENSE") == nullptr;
+    return opt->kind == ORX_ADAM && t->rows < (1LL << 31) && t->owned && getenv("ORX_ADAM_DENSE") == nullptr;
 }
 
 // duplicate flags + list of the duplicated rows of `ids` (item role) into the context's dedup buffers

@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_pointwise.py -q 2>&1 | grep -E "^E   +assert|AssertionError|passed|failed|Error|^tests/.*:[0-9]+:" | head -20
+timeout 900 python -m pytest tests/test_gpu_api.py tests/test_gpu_stress.py tests/test_gpu_pointwise.py tests/test_gpu_dlrm.py -x -q 2>&1 | tail -4

@@ -169,3 +169,32 @@ def test_tables_may_die_before_their_optimizer():
         for t in (U, V, b):
             t._fin()                                                       # orx_table_destroy, before the optimizer
     opt._fin()
+
+
+@pytest.mark.parametrize("optk", ["sgd", "adam"])
+def test_wrapped_torch_tensors_are_updated_in_place(optk):
+    """orx_table_wrap adopts caller-owned device memory: the caller reads it directly (no orx_table_read), so every
+    step must leave it current -- in particular Adam, which is applied lazily only to tables the library owns."""
+    import torch
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    torch.cuda.init()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    NU, NI, D, B, K = 900, 700, 64, 512, 5
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    tU, tV, tb = (torch.from_numpy(x.copy()).to(dev) for x in (U, V, b))
+    torch.cuda.synchronize()                     # the tensors are in place before the library's stream touches them
+    ctx = rt.default_context()
+    wU = rt.Table(NU, D, ctx, device_ptr=tU.data_ptr(), keepalive=tU); wV = rt.Table(NI, D, ctx, device_ptr=tV.data_ptr(), keepalive=tV)
+    wb = rt.Table(NI, 1, ctx, device_ptr=tb.data_ptr(), keepalive=tb)
+    opt = rt.Optimizer.sgd(0.05, ctx=ctx) if optk == "sgd" else rt.Optimizer.adam(0.002, ctx=ctx)
+    oo = orc.SGD(0.05) if optk == "sgd" else orc.AdamTFSparse(0.002)
+    ids = [rng.integers(0, n, (K, B)).astype(np.int32) for n in (NU, NI, NI)]
+    rt.pairwise_step("bpr", opt, wU, wV, wb, *ids, K=K, B=B)
+    ctx.synchronize(); torch.cuda.synchronize()
+    for s in range(K):
+        orc.bpr_step(U, V, b, ids[0][s], ids[1][s], ids[2][s], oo)
+    tol = 5e-5 if optk == "adam" else 1e-5
+    assert rel_err(tU.cpu().numpy(), U) < tol and rel_err(tV.cpu().numpy(), V) < tol and rel_err(tb.cpu().numpy(), b) < tol
