@@ -61,7 +61,7 @@ def test_batch_larger_than_the_grid_cap():
 
 
 @pytest.mark.parametrize("model,D,optname,K", [("bpr", 64, "sgd", 5), ("ucml", 128, "sgd", 3), ("bpr", 16, "adagrad", 4),
-                                               ("bpr", 64, "sgd", 1)])
+                                               ("bpr", 64, "sgd", 1), ("bpr", 64, "adam", 6), ("ucml", 32, "adam", 4)])
 def test_skewed_items_use_staging_and_hot_reduce(model, D, optname, K):
     """Items ~ Zipf(1.05): the hottest row takes ~10 % of the 2B item references of a step (hundreds of
     references -> long staging segments, hot_reduce_kernel), a long tail of rows takes 3..64 (segments summed
@@ -84,15 +84,16 @@ def test_skewed_items_use_staging_and_hot_reduce(model, D, optname, K):
     tU = rt.Table(NU, D).write(U); tV = rt.Table(NI, D).write(V); tb = rt.Table(NI, 1).write(b)
     U, V, b = U.astype(np.float64), V.astype(np.float64), b.astype(np.float64)
     lr = 0.002
-    opt = rt.Optimizer.sgd(lr) if optname == "sgd" else rt.Optimizer.adagrad(lr)
-    oo = orc.SGD(lr) if optname == "sgd" else orc.Adagrad(lr)
-    loss, l2 = rt.pairwise_step(model, opt, tU, tV, tb, uid, pid, nid, K=K, B=B)
+    opt = {"sgd": lambda: rt.Optimizer.sgd(lr), "adagrad": lambda: rt.Optimizer.adagrad(lr), "adam": lambda: rt.Optimizer.adam(lr)}[optname]()
+    oo = {"sgd": lambda: orc.SGD(lr), "adagrad": lambda: orc.Adagrad(lr), "adam": lambda: orc.AdamTFSparse(lr)}[optname]()
+    loss, l2 = rt.pairwise_step(model, opt, tU, tV, tb, uid, pid, nid, K=K, B=B)     # (adam: the lazy rule on staged / tree-reduced rows)
     step = orc.bpr_step if model == "bpr" else (lambda *a: orc.ucml_step(*a, margin=0.5, do_censor=False))
     for s in range(K):
         ref, l2r = step(U, V, b, uid[s], pid[s], nid[s], oo)
         assert abs(loss[s] - ref) <= 2e-5 * abs(ref) and abs(l2[s] - l2r) <= 2e-5 * abs(l2r), (s, loss[s], ref)
+    tol = 5e-5 if optname == "adam" else 2e-5
     for got, want in ((tU.read(), U), (tV.read(), V), (tb.read(), b)):
-        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+        assert np.abs(got - want).max() <= tol * np.abs(want).max()
 
 
 def test_skewed_items_with_fused_censor():
