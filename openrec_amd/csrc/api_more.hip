@@ -282,7 +282,7 @@ bool orx_adam_rows_lazy(const orx_opt* opt, const orx_table* t) {
 }
 
 // duplicate flags + list of the duplicated rows of `ids` (item role) into the context's dedup buffers
-int orx_adam_rows_dedup(orx_ctx* ctx, orx_table* t, const int32_t* ids, int64_t n) {
+int orx_adam_rows_dedup(orx_ctx* ctx, orx_table* t, const int32_t* ids, int64_t n, ColWindows cw) {
     ENSURE(ctx->d_dflag, ctx->d_dflag_cap, (size_t)n);
     ENSURE(ctx->d_dlist, ctx->d_dlist_cap, (size_t)(n / 2 + 1) * sizeof(uint32_t));
     ENSURE(ctx->d_dcount, ctx->d_dcount_cap, sizeof(int));
@@ -293,6 +293,7 @@ int orx_adam_rows_dedup(orx_ctx* ctx, orx_table* t, const int32_t* ids, int64_t 
     d.dflag = ctx->d_dflag; d.dlist = ctx->d_dlist; d.dcount = ctx->d_dcount;
     d.flag_stride = n; d.list_stride = n / 2 + 1;
     d.nU = 0; d.nP = n; d.nN = 0; d.NU = 0; d.NI = t->rows; d.nbu = 0; d.nbi = orx_dedup_buckets(t->rows);
+    if (cw.win != nullptr && cw.F > 0 && n % cw.F == 0) { d.col_F = cw.F; d.col_win = cw.win; }
     return orx_launch_dedup(ctx, d, 1);
 }
 
@@ -313,12 +314,12 @@ static int adam_rows_args(orx_ctx* ctx, orx_opt* opt, orx_table* t, int64_t now,
     return ORX_OK;
 }
 
-int orx_adam_rows_touch(orx_ctx* ctx, orx_opt* opt, orx_table* t, const int32_t* ids, int64_t n, bool have_dedup) {
+int orx_adam_rows_touch(orx_ctx* ctx, orx_opt* opt, orx_table* t, const int32_t* ids, int64_t n, bool have_dedup, ColWindows cw) {
     if (n == 0 || opt->t == 0) return ORX_OK;                // nothing has moved yet
     if (t->lazy != opt) return orx_table_sync(t);           // not lazy under this optimizer: every row is (made) current
     AdamRowsArgs a;
     CHECK(adam_rows_args(ctx, opt, t, opt->t, &a));
-    if (!have_dedup) CHECK(orx_adam_rows_dedup(ctx, t, ids, n));
+    if (!have_dedup) CHECK(orx_adam_rows_dedup(ctx, t, ids, n, cw));
     a.dflag = ctx->d_dflag; a.dlist = (const uint32_t*)ctx->d_dlist; a.dcount = ctx->d_dcount;     // (allocated by the dedup)
     a.ids = ids; a.n = n; a.T = (int)opt->t;
     return orx_launch_adam_rows(ctx, false, a, n / 2 + 1);
@@ -326,12 +327,12 @@ int orx_adam_rows_touch(orx_ctx* ctx, orx_opt* opt, orx_table* t, const int32_t*
 
 // step opt->t (the caller has advanced the counter) with per-occurrence gradient rows
 int orx_adam_rows_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const int32_t* ids, int64_t n, const float* grads, int64_t g_stride,
-                        bool have_dedup) {
+                        bool have_dedup, ColWindows cw) {
     ORX_ARG(opt->t >= 1, "adam_rows_apply: the step counter has not been advanced");
     CHECK(orx_table_scratch(t));
     AdamRowsArgs a;
     CHECK(adam_rows_args(ctx, opt, t, opt->t - 1, &a));
-    if (!have_dedup) CHECK(orx_adam_rows_dedup(ctx, t, ids, n));
+    if (!have_dedup) CHECK(orx_adam_rows_dedup(ctx, t, ids, n, cw));
     a.dflag = ctx->d_dflag; a.dlist = (const uint32_t*)ctx->d_dlist; a.dcount = ctx->d_dcount;
     a.G = t->gsum; a.ids = ids; a.n = n; a.grads = grads; a.g_stride = g_stride;
     a.T = (int)opt->t; a.lr_T = opt->h_lrt[(size_t)opt->t];
@@ -342,6 +343,45 @@ int orx_adam_rows_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const int32_t*
 int orx_table_touch(orx_table* t, const int32_t* ids, int64_t n) {
     if (t == nullptr || t->lazy == nullptr) return ORX_OK;
     return orx_adam_rows_touch(t->ctx, t->lazy, t, ids, n, false);
+}
+
+// Adagrad on per-occurrence gradient rows: dedup-sum semantics (duplicate flags + gsum + dup_apply)
+int orx_adagrad_rows_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n, const float* grads,
+                           int64_t g_stride, ColWindows cw) {
+    RowsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.W = t->w; a.bias = bias ? bias->w : nullptr;
+    a.ids = ids; a.grads = grads; a.g_stride = g_stride; a.n = n; a.rows = t->rows; a.D = t->dim;
+    a.lr = opt->lr; a.err = ctx->d_err;
+    CHECK(orx_table_scratch(t));
+    if (bias) CHECK(orx_table_scratch(bias));
+    OptSlots st, sb;
+    CHECK(orx_opt_slots(opt, t, &st));
+    if (bias) CHECK(orx_opt_slots(opt, bias, &sb));
+    ENSURE(ctx->d_dflag, ctx->d_dflag_cap, (size_t)n);
+    ENSURE(ctx->d_dlist, ctx->d_dlist_cap, (size_t)(n / 2 + 1) * sizeof(uint32_t));
+    ENSURE(ctx->d_dcount, ctx->d_dcount_cap, sizeof(int));
+    ORX_HIP(hipMemsetAsync(ctx->d_dcount, 0, sizeof(int), ctx->stream));
+    DedupArgs d;
+    memset(&d, 0, sizeof(d));
+    // scan the id list in the ITEM role so that dup_apply also finishes the bias
+    d.uid = ids; d.pid = ids; d.nid = ids; d.id_stride = n;
+    d.dflag = ctx->d_dflag; d.dlist = ctx->d_dlist; d.dcount = ctx->d_dcount;
+    d.flag_stride = n; d.list_stride = n / 2 + 1;
+    d.nU = 0; d.nP = n; d.nN = 0; d.NU = 0; d.NI = t->rows; d.nbu = 0; d.nbi = orx_dedup_buckets(t->rows);
+    if (cw.win != nullptr && cw.F > 0 && n % cw.F == 0) { d.col_F = cw.F; d.col_win = cw.win; }
+    CHECK(orx_launch_dedup(ctx, d, 1));
+    a.G = t->gsum; a.gb = bias ? bias->gsum : nullptr;
+    a.A = st.s0; a.ab = bias ? sb.s0 : nullptr;
+    a.dflag = ctx->d_dflag; a.eps = opt->p1;
+    CHECK(orx_launch_apply_rows(ctx, ORX_ADAGRAD, true, a));
+    PairArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.V = t->w; pa.gV = t->gsum; pa.aV = st.s0;
+    pa.b = bias ? bias->w : nullptr; pa.gb = bias ? bias->gsum : nullptr; pa.ab = bias ? sb.s0 : nullptr;
+    pa.dlist = ctx->d_dlist; pa.dcount = ctx->d_dcount;
+    pa.B = n; pa.D = t->dim; pa.lr = opt->lr; pa.eps = opt->p1;
+    return orx_launch_dup_apply(ctx, ORX_ADAGRAD, pa);
 }
 
 extern "C" int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias,
@@ -380,35 +420,7 @@ extern "C" int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_tabl
         return orx_launch_adam_sweep(ctx, t->w, st.s0, st.s1, t->gsum, t->rows * t->dim, lr_t, opt->p0, opt->p1, opt->p2);
     }
 
-    // Adagrad: dedup-sum semantics
-    CHECK(orx_table_scratch(t));
-    if (bias) CHECK(orx_table_scratch(bias));
-    OptSlots st, sb;
-    CHECK(orx_opt_slots(opt, t, &st));
-    if (bias) CHECK(orx_opt_slots(opt, bias, &sb));
-    ENSURE(ctx->d_dflag, ctx->d_dflag_cap, (size_t)n);
-    ENSURE(ctx->d_dlist, ctx->d_dlist_cap, (size_t)(n / 2 + 1) * sizeof(uint32_t));
-    ENSURE(ctx->d_dcount, ctx->d_dcount_cap, sizeof(int));
-    ORX_HIP(hipMemsetAsync(ctx->d_dcount, 0, sizeof(int), ctx->stream));
-    DedupArgs d;
-    memset(&d, 0, sizeof(d));
-    // scan the id list in the ITEM role so that dup_apply also finishes the bias
-    d.uid = ids; d.pid = ids; d.nid = ids; d.id_stride = n;
-    d.dflag = ctx->d_dflag; d.dlist = ctx->d_dlist; d.dcount = ctx->d_dcount;
-    d.flag_stride = n; d.list_stride = n / 2 + 1;
-    d.nU = 0; d.nP = n; d.nN = 0; d.NU = 0; d.NI = t->rows; d.nbu = 0; d.nbi = orx_dedup_buckets(t->rows);
-    CHECK(orx_launch_dedup(ctx, d, 1));
-    a.G = t->gsum; a.gb = bias ? bias->gsum : nullptr;
-    a.A = st.s0; a.ab = bias ? sb.s0 : nullptr;
-    a.dflag = ctx->d_dflag; a.eps = opt->p1;
-    CHECK(orx_launch_apply_rows(ctx, ORX_ADAGRAD, true, a));
-    PairArgs pa;
-    memset(&pa, 0, sizeof(pa));
-    pa.V = t->w; pa.gV = t->gsum; pa.aV = st.s0;
-    pa.b = bias ? bias->w : nullptr; pa.gb = bias ? bias->gsum : nullptr; pa.ab = bias ? sb.s0 : nullptr;
-    pa.dlist = ctx->d_dlist; pa.dcount = ctx->d_dcount;
-    pa.B = n; pa.D = t->dim; pa.lr = opt->lr; pa.eps = opt->p1;
-    return orx_launch_dup_apply(ctx, ORX_ADAGRAD, pa);
+    return orx_adagrad_rows_apply(ctx, opt, t, bias, ids, n, grads, g_stride);
 }
 
 // ---- planned apply of K id lists against one table (see orx_internal.h) ------------------------------------------

@@ -31,6 +31,7 @@ struct orx_dlrm {
     float thr = 0.f;
     std::vector<int64_t> ln_emb, offset;
     int64_t* d_offset = nullptr;
+    int2* d_colwin = nullptr;          // per dedup range of the combined table: (first id column, number of columns) that can hold its rows
     int64_t* d_rows = nullptr;
     orx_table* emb = nullptr;           // combined [sum(ln_emb), m_spa]
     std::vector<DenseLayer> bot, top;
@@ -100,6 +101,19 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
     ORX_HIP(hipMalloc((void**)&m->d_rows, sizeof(int64_t) * n_emb));
     ORX_HIP(hipMemcpy(m->d_offset, m->offset.data(), sizeof(int64_t) * n_emb, hipMemcpyHostToDevice));
     ORX_HIP(hipMemcpy(m->d_rows, m->ln_emb.data(), sizeof(int64_t) * n_emb, hipMemcpyHostToDevice));
+    if (m->emb) {   // column f of the id matrix only holds rows of table f: the duplicate analysis of a row range reads those columns only
+        const int64_t R = orx_dedup_range_rows();
+        std::vector<int2> win((size_t)orx_dedup_buckets(total));
+        for (size_t bk = 0; bk < win.size(); ++bk) {
+            const int64_t r0 = (int64_t)bk * R, r1 = r0 + R;
+            int lo = n_emb, hi = -1;
+            for (int f = 0; f < n_emb; ++f)
+                if (m->offset[f] < r1 && m->offset[f] + m->ln_emb[f] > r0) { lo = std::min(lo, f); hi = std::max(hi, f); }
+            win[bk] = make_int2(hi >= lo ? lo : 0, hi >= lo ? hi - lo + 1 : 0);
+        }
+        ORX_HIP(hipMalloc((void**)&m->d_colwin, sizeof(int2) * win.size()));
+        ORX_HIP(hipMemcpy(m->d_colwin, win.data(), sizeof(int2) * win.size(), hipMemcpyHostToDevice));
+    }
     {   // tiny tables (LDS must hold rows * m_spa floats)
         const int TINY_ROWS = 64;
         std::vector<unsigned char> is_tiny((size_t)n_emb + 1, 0);
@@ -161,7 +175,7 @@ extern "C" int orx_dlrm_destroy(orx_dlrm* m) {
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     free_buffers(m);
-    hipFree(m->d_offset); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params); hipFree(m->d_idx_all); hipFree(m->d_sparse_all); hipFree(m->d_tiny_f); hipFree(m->d_is_tiny);
+    hipFree(m->d_offset); hipFree(m->d_colwin); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params); hipFree(m->d_idx_all); hipFree(m->d_sparse_all); hipFree(m->d_tiny_f); hipFree(m->d_is_tiny);
     orx_table_destroy(m->emb);
     for (auto& d : m->bot) { orx_table_destroy(d.W); orx_table_destroy(d.b); }
     for (auto& d : m->top) { orx_table_destroy(d.W); orx_table_destroy(d.b); hipFree(d.w16); hipFree(d.w16t); }
@@ -422,6 +436,8 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
     RowsPlan rp;
     const int32_t* sparse_dev = sparse;
     const bool lazy_adam = m->emb != nullptr && orx_adam_rows_lazy(opt, m->emb);
+    ColWindows cw;
+    if (getenv("ORX_DLRM_NO_COLWIN") == nullptr) { cw.F = F; cw.win = m->d_colwin; }
     if (planned) {
         const int64_t kp = std::min<int64_t>(K, PC);
         if (m->idx_all_cap < kp * B * F) {
@@ -453,7 +469,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
             CHECK(orx_launch_dlrm_ids(c, bt.sparse, m->d_offset, m->d_rows, m->n_emb, B, m->d_idx));
             idx_s = m->d_idx;
             if (m->emb->lazy == opt && opt->t > 0) {
-                CHECK(orx_adam_rows_touch(c, opt, m->emb, idx_s, B * F, false));
+                CHECK(orx_adam_rows_touch(c, opt, m->emb, idx_s, B * F, false, cw));
                 deduped = true;
             } else {
                 CHECK(orx_table_sync(m->emb));
@@ -475,7 +491,10 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         if (planned) {
             CHECK(orx_apply_rows_planned_step(c, opt, m->emb, nullptr, rp, s % PC, idx_s, m->dZ, d));
         } else if (lazy_adam) {
-            CHECK(orx_adam_rows_apply(c, opt, m->emb, idx_s, B * F, m->dZ, d, deduped));
+            CHECK(orx_adam_rows_apply(c, opt, m->emb, idx_s, B * F, m->dZ, d, deduped, cw));
+        } else if (opt->kind == ORX_ADAGRAD) {
+            CHECK(orx_table_sync(m->emb));
+            CHECK(orx_adagrad_rows_apply(c, opt, m->emb, nullptr, m->d_idx, B * F, m->dZ, d, cw));
         } else if (opt->kind == ORX_SGD && !m->tiny_f.empty()) {
             // tiny tables: per-slab LDS sums; the generic scatter then skips their slots
             CHECK(orx_launch_dlrm_tiny_apply(c, m->d_idx, m->dZ, m->d_tiny_f, (int)m->tiny_f.size(), m->tiny_max_rows, m->d_offset,

@@ -59,8 +59,21 @@ constexpr int DD_LDS_BYTES = 3 * DD_WORDS * 4;  // three bitmaps: seen / seen tw
 
 // visit every reference j in [0, n) of a table's id stream (segment A of length nA, then
 // segment B); int4 loads when both segments are 16-byte aligned multiples of 4
+// Column window (colF > 0): the id stream is a [n / colF][colF] matrix and only columns c0 .. c0+nc-1 can hold rows
+// of this workgroup's range (DLRM: column f of the combined-table ids only holds rows of table f) -- the others
+// are not read at all.
 template <class F>
-__device__ __forceinline__ void for_each_ref(const int32_t* idsA, int64_t nA, const int32_t* idsB, int64_t n, bool vec, F f) {
+__device__ __forceinline__ void for_each_ref(const int32_t* idsA, int64_t nA, const int32_t* idsB, int64_t n, bool vec, F f,
+                                             int colF = 0, int c0 = 0, int nc = 0) {
+    if (colF > 0) {
+        const int64_t m = (n / colF) * nc;
+        for (int64_t t = threadIdx.x; t < m; t += DD_THREADS) {
+            const int64_t r = t / nc;
+            const int64_t j = r * colF + c0 + (t - r * nc);
+            f(j, idsA[j]);
+        }
+        return;
+    }
     if (vec) {
         // four independent 16-byte loads in flight per thread: the scan is latency-bound otherwise
         const int64_t n4 = n >> 2, nA4 = nA >> 2;
@@ -158,6 +171,8 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
     if (threadIdx.x == 0) { list_cnt = 0; sh_late = 0; }
     __syncthreads();
     int late = 0;                                            // third-or-later references seen by this thread
+    const int colF = (!is_user && a.col_win != nullptr) ? a.col_F : 0;
+    const int2 cwin = colF ? a.col_win[bk] : make_int2(0, 0);   // (first column, number of columns) of this range
     for_each_ref(idsA, nA, idsB, n, vec, [&](int64_t j, int id) {
         const int64_t l = (int64_t)id - r0;
         if ((uint64_t)l < (uint64_t)DD_ROWS && id_ok(id, rows)) {
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
             if (roles) roles[out_index(j)] = (unsigned char)role;
             if (a.first_only) dflag[ref0 + j] = (old & bit) ? 1 : 0;
         }
-    });
+    }, colF, cwin.x, cwin.y);
     if (a.refinfo != nullptr && late) atomicAdd(&sh_late, late);
     if (a.first_only) return;
     __syncthreads();
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
         } else if (!ok && bk == 0 && ids_out) {
             ids_out[out_index(j)] = 0x7fffffff;              // out-of-range id: can never be a valid row
         }
-    });
+    }, colF, cwin.x, cwin.y);
     if (a.dupbits != nullptr) {      // keep the "seen twice" bitmap of (step, range) for urgent_kernel
         unsigned int* out = a.dupbits + ((size_t)s * per_step + (is_user ? bk : a.nbu + bk)) * DD_WORDS;
         for (int w = threadIdx.x; w < DD_WORDS; w += DD_THREADS) out[w] = dup[w];
@@ -340,6 +355,7 @@ __global__ __launch_bounds__(DD_THREADS) void dedup_kernel(DedupArgs a) {
 }
 
 int orx_dedup_buckets(int64_t rows) { return (int)((rows + DD_ROWS - 1) / DD_ROWS); }
+int64_t orx_dedup_range_rows() { return DD_ROWS; }
 int orx_dedup_words(void) { return DD_WORDS; }
 
 int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K) {

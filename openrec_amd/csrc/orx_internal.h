@@ -200,6 +200,9 @@ struct DedupArgs {
     int64_t NU; int64_t NI;                   // table rows
     int nbu; int nbi;                         // row-range buckets per table (0 = table not scanned)
     int first_only;                           // censor: dflag = 1 only on non-first references
+    // column windows (DLRM): the item id stream is an [nP / col_F][col_F] matrix whose column c only holds rows of one
+    // table; item range bk scans columns col_win[bk].x .. +col_win[bk].y-1 only (NULL: the whole stream)
+    int col_F; const int2* col_win;
     // staging plan (all NULL: rows referenced >= 3 times keep role 2 = atomics)
     int2* refinfo;                            // [K][flag_stride]
     int* tricnt; int* segstart;               // [K][tri_stride], tricnt zeroed before the launch
@@ -246,10 +249,13 @@ struct AdamRowsArgs {                          // lazy TF-2.0 Adam on gradient r
 };
 int orx_launch_adam_rows(orx_ctx* ctx, bool step, const AdamRowsArgs& a, int64_t max_dups);
 // lazy Adam on a table's gradient rows: replay the rows of `ids` to the optimizer's step (touch) / take step opt->t
-int orx_adam_rows_dedup(orx_ctx* ctx, orx_table* t, const int32_t* ids, int64_t n);
-int orx_adam_rows_touch(orx_ctx* ctx, orx_opt* opt, orx_table* t, const int32_t* ids, int64_t n, bool have_dedup);
+struct ColWindows { int F = 0; const int2* win = nullptr; };    // device array, one entry per 425 984-row range of the table
+int orx_adam_rows_dedup(orx_ctx* ctx, orx_table* t, const int32_t* ids, int64_t n, ColWindows cw = ColWindows());
+int orx_adam_rows_touch(orx_ctx* ctx, orx_opt* opt, orx_table* t, const int32_t* ids, int64_t n, bool have_dedup, ColWindows cw = ColWindows());
 int orx_adam_rows_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const int32_t* ids, int64_t n, const float* grads, int64_t g_stride,
-                        bool have_dedup);
+                        bool have_dedup, ColWindows cw = ColWindows());
+int orx_adagrad_rows_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n, const float* grads,
+                           int64_t g_stride, ColWindows cw = ColWindows());
 int orx_table_touch(orx_table* t, const int32_t* ids, int64_t n);       // no-op unless the table is lazy
 bool orx_adam_rows_lazy(const orx_opt* opt, const orx_table* t);
 
@@ -324,6 +330,7 @@ int orx_dedup_words(void);
 int orx_launch_loss_reduce(orx_ctx* ctx, const ReduceArgs& a, int64_t K);
 int orx_fused_nwaves(int D, int64_t B);
 int orx_dedup_buckets(int64_t rows);
+int64_t orx_dedup_range_rows();                  // rows per dedup range (one workgroup)
 
 // fused-kernel modes
 enum { MODE_EXACT = 0,     // unique rows in place; duplicate rows -> gsum, applied by dup_apply
