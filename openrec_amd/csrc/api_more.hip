@@ -305,7 +305,9 @@ static int adam_rows_args(orx_ctx* ctx, orx_opt* opt, orx_table* t, int64_t now,
     CHECK(orx_opt_slots(opt, t, &st));
     memset(a, 0, sizeof(*a));
     CHECK(orx_opt_last(opt, t, !resume, &a->last, now));
-    CHECK(orx_adam_lrt(opt, opt->t + 1));
+    // lr_t entries are uploaded well ahead of use (one small copy per 1024 steps instead of one per step; the kernels
+    // fetch them through the scalar cache, so an entry is also in place before any kernel can have cached its line)
+    if ((int64_t)opt->lrt_uploaded < opt->t + 2) CHECK(orx_adam_lrt(opt, opt->t + 1024));
     t->lazy = opt;
     a->W = t->w; a->M = st.s0; a->V = st.s1; a->rows = t->rows; a->D = t->dim;
     a->lrt = opt->d_lrt; a->b1 = opt->p0; a->b2 = opt->p1; a->eps = opt->p2;

@@ -470,7 +470,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
             idx_s = m->d_idx;
             if (m->emb->lazy == opt && opt->t > 0) {
                 CHECK(orx_adam_rows_touch(c, opt, m->emb, idx_s, B * F, false, cw));
-                deduped = true;
+                deduped = getenv("ORX_DLRM_NO_SHARED_DEDUP") == nullptr;
             } else {
                 CHECK(orx_table_sync(m->emb));
             }

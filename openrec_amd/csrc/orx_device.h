@@ -185,18 +185,12 @@ __device__ __forceinline__ void adam_catchup1(float& w, float& m, float& v, int 
     }
 }
 
-// scalar (SMEM) load of a wave-uniform table entry, split into issue and wait so that a loop can fetch the next
-// entry under the current iteration's arithmetic (the compiler emits VMEM loads for a pointer it cannot prove
-// read-only, and waits for them with vmcnt(0) at the loop back-edge)
-__device__ __forceinline__ float sload_issue(const float* p, int idx) {
-    float v;
-    asm volatile("s_load_dword %0, %1, %2" : "=s"(v) : "s"(p), "s"(idx * 4));
-    return v;
-}
-__device__ __forceinline__ float sload_wait(float v) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v));
-    return v;
-}
+// Scalar (SMEM) load of a wave-uniform entry of a table that no kernel writes (lr_t per step): read through the
+// constant address space, the compiler emits s_load_dword and tracks its completion itself.  (A hand-written
+// s_load / s_waitcnt pair in inline asm is NOT safe: the compiler may copy the destination SGPR while the load is
+// still in flight -- it did, in the row kernels: every replay of two or more steps went wrong.)
+typedef const __attribute__((address_space(4))) float* orx_const_fp;
+__device__ __forceinline__ float sload(const float* p, int idx) { return ((orx_const_fp)p)[idx]; }
 
 // Replay of ONE element per lane over a wave-uniform range (one row per wavefront: kernels_sharded.hip), and of
 // one element with its own range (the table flush).  Rows of a large table wait hundreds or thousands of steps
@@ -220,15 +214,12 @@ __device__ __forceinline__ void adam_replay1(float& w, float& m, float& v, int f
     float q = __builtin_amdgcn_rcpf(d);
     int k = from + 1;
     if (UNIFORM) {
-        float nxt = sload_wait(sload_issue(lrt, k));
         for (; k <= to; ++k) {
-            const float lr = nxt;
-            nxt = sload_issue(lrt, k + 1);
+            const float lr = sload(lrt, k);
             m *= b1; v *= b2; d = d * sb2 + ce;
             q = newton ? q * (2.0f - d * q) : __builtin_amdgcn_rcpf(d);
             const float u = (lr * m) * q;
             w -= u;
-            nxt = sload_wait(nxt);
             if ((k & 7) == 0 && !__any((w - 4.0f * u) != w)) { ++k; break; }
         }
     } else {
@@ -251,8 +242,7 @@ __device__ __forceinline__ void adam_replay1(float& w, float& m, float& v, int f
 // default beta_2) per step, so the carried reciprocal stays within (5e-4)^2 = 2.5e-7 of exact with no
 // quarter-rate v_rcp in the loop; the caller selects it only for 1 - sqrt(b2) <= 1e-3.
 // The loop counter is wave-uniform (it starts at the smallest stamp of the wavefront's active lane groups: the
-// hardware loop runs to the longest gap of the wavefront either way), which makes lr_k a scalar load, fetched
-// two iterations ahead.
+// hardware loop runs to the longest gap of the wavefront either way), which makes lr_k a scalar load.
 template <bool NEWTON, int LPR>
 __device__ __forceinline__ void adam_catchup_triplet(f4& wu, f4& mu, f4& vu, int lu, f4& wp, f4& mp, f4& vp, int lp,
                                                      f4& wn, f4& mn, f4& vn, int ln, float& bp, float& mbp, float& vbp,
@@ -273,10 +263,8 @@ __device__ __forceinline__ void adam_catchup_triplet(f4& wu, f4& mu, f4& vu, int
     float dbp = sqrtf(vbp) + eps, dbn = sqrtf(vbn) + eps;
     f4 qu = rcp4(du), qp = rcp4(dp), qn = rcp4(dn);
     float qbp = __builtin_amdgcn_rcpf(dbp), qbn = __builtin_amdgcn_rcpf(dbn);
-    float nxt = sload_wait(sload_issue(lrt, first + 1));
     for (int k = first + 1; k <= to; ++k) {
-        const float lr = nxt;
-        nxt = sload_issue(lrt, k + 1);                          // (the table is allocated well past `to`)
+        const float lr = sload(lrt, k);
         // a row whose stamp is later than k sits this iteration out (EXEC mask; skipped when no lane group needs it)
         if (k > lu) {
             mu = mu * b1; vu = vu * b2; du = du * sb2 + ce;
@@ -295,7 +283,6 @@ __device__ __forceinline__ void adam_catchup_triplet(f4& wu, f4& mu, f4& vu, int
             if (NEWTON) { qn = qn * (2.0f - dn * qn); qbn = qbn * (2.0f - dbn * qbn); } else { qn = rcp4(dn); qbn = __builtin_amdgcn_rcpf(dbn); }
             wn = wn - (lr * mn) * qn; bn -= (lr * mbn) * qbn;
         }
-        nxt = sload_wait(nxt);
     }
 }
 
@@ -319,10 +306,8 @@ __device__ __forceinline__ void adam_catchup_pair(f4& wu, f4& mu, f4& vu, int lu
     float dbi = sqrtf(vbi) + eps;
     f4 qu = rcp4(du), qi = rcp4(di);
     float qbi = __builtin_amdgcn_rcpf(dbi);
-    float nxt = sload_wait(sload_issue(lrt, first + 1));
     for (int k = first + 1; k <= to; ++k) {
-        const float lr = nxt;
-        nxt = sload_issue(lrt, k + 1);
+        const float lr = sload(lrt, k);
         if (k > lu) {
             mu = mu * b1; vu = vu * b2; du = du * sb2 + ce;
             if (NEWTON) qu = qu * (2.0f - du * qu); else qu = rcp4(du);
@@ -334,7 +319,6 @@ __device__ __forceinline__ void adam_catchup_pair(f4& wu, f4& mu, f4& vu, int lu
             if (NEWTON) { qi = qi * (2.0f - di * qi); qbi = qbi * (2.0f - dbi * qbi); } else { qi = rcp4(di); qbi = __builtin_amdgcn_rcpf(dbi); }
             wi = wi - (lr * mi) * qi; bi -= (lr * mbi) * qbi;
         }
-        nxt = sload_wait(nxt);
     }
 }
 
