@@ -4,7 +4,7 @@ from openrec_amd import runtime as rt, _ffi
 from oracle import numpy_oracle as orc
 torch.cuda.init(); dev = torch.device("cuda", 0)
 ctx = rt.default_context(); lib = ctx._lib
-for rows, D, n, K, use_gather in ((40000, 4, 600, 15, False), (40000, 4, 600, 15, True), (40000, 128, 600, 15, True), (500, 16, 600, 15, True)):
+for rows, D, n, K, use_gather in ((40000, 4, 600, 15, False), (40000, 128, 600, 15, True), (500, 16, 600, 15, True), (50, 64, 600, 40, True), (200000, 32, 3000, 60, True), (7, 8, 900, 25, False)):
     rng = np.random.default_rng(1)
     W0 = rng.uniform(-.05, .05, (rows, D)).astype(np.float32)
     t = rt.Table(rows, D, ctx).write(W0)

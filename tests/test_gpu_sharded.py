@@ -149,3 +149,37 @@ def test_virtual_cluster_matches_oracle(world, model, optk, fast):
         assert rel_err(e.b.read()[:len(b[r::world])], b[r::world]) < tol
         got += float(e.accum[0])
     assert abs(got - tl) <= 1e-5 * abs(tl)
+
+
+@pytest.mark.parametrize("rows,D,n,K", [(40000, 128, 600, 15), (50, 64, 600, 40), (200000, 32, 3000, 60), (7, 8, 900, 25)])
+def test_gather_apply_rows_adam_is_the_dense_decay_rule(rows, D, n, K):
+    """The building blocks a host drives Adam with (orx_gather_rows / orx_opt_set_step / orx_apply_rows): the table
+    is updated lazily (rows replay their gradient-free steps when gathered or given a gradient), every gather must
+    return the rows of the dense every-row-every-step rule, and so must the table after K steps (full flush)."""
+    import torch
+    from openrec_amd import runtime as rt, _ffi
+    from oracle import numpy_oracle as orc
+    torch.cuda.init()
+    dev = torch.device("cuda", 0)
+    ctx = rt.default_context(); lib = ctx._lib
+    rng = np.random.default_rng(1)
+    W0 = rng.uniform(-.05, .05, (rows, D)).astype(np.float32)
+    t = rt.Table(rows, D, ctx).write(W0)
+    opt = rt.Optimizer.adam(0.002, ctx=ctx)
+    W = W0.astype(np.float64); oo = orc.AdamTFSparse(0.002)
+    ids_all = rng.integers(0, rows, (K, n)).astype(np.int32); ids_all[:, :5] = -1          # padding slots
+    g_all = rng.normal(0, 1e-3, (K, n, D)).astype(np.float32)
+    out = torch.zeros((n, D), device=dev)
+    for s in range(K):
+        ids = torch.from_numpy(ids_all[s]).to(dev); g = torch.from_numpy(g_all[s]).to(dev)
+        torch.cuda.synchronize()
+        live = ids_all[s] >= 0
+        _ffi.check(lib.orx_gather_rows(ctx._h, t._h, None, ids.data_ptr(), n, out.data_ptr(), D))
+        ctx.synchronize()
+        assert np.abs(out.cpu().numpy()[live] - W[ids_all[s][live]]).max() <= 2e-5 * 0.05, s
+        opt.step = opt.step + 1
+        _ffi.check(lib.orx_apply_rows(ctx._h, opt._h, t._h, None, ids.data_ptr(), n, g.data_ptr(), D))
+        ctx.synchronize()
+        oo.begin_step(); oo.apply(W, ids_all[s][live], g_all[s][live].astype(np.float64), key="W")
+    assert rel_err(t.read(), W) < 2e-5
+    assert rel_err(opt.slot(t, 0), oo.m["W"]) < 5e-5 and rel_err(opt.slot(t, 1), oo.v["W"]) < 5e-4
