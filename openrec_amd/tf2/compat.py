@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import sys
 import types
+import weakref
 
 import numpy as np
 
@@ -38,6 +39,9 @@ class _Optimizer:
 
     def __init__(self):
         self._native = None
+        self._models = weakref.WeakSet()       # models with steps applied through this optimizer (their queues hold it)
+        self._lr = None
+        self._iterations = 0
 
     def _make(self, ctx):
         raise NotImplementedError
@@ -46,6 +50,33 @@ class _Optimizer:
         if self._native is None:
             self._native = self._make(ctx)
         return self._native
+
+    def _flush_models(self):
+        for m in list(self._models):
+            flush = getattr(m, "flush", None)
+            if flush is not None:
+                flush()
+
+    # Keras `optimizer.learning_rate` (also `.lr`): assignable at any time.  Steps already applied -- queued or not --
+    # keep the rate they were applied with: the queues run first, then the device-side optimizer takes the new rate.
+    @property
+    def learning_rate(self):
+        return self._lr
+
+    @learning_rate.setter
+    def learning_rate(self, value):
+        value = float(value)
+        if self._native is not None and value != self._lr:
+            self._flush_models()
+            self._native.set_lr(value)
+        self._lr = value
+
+    lr = learning_rate
+
+    @property
+    def iterations(self):
+        """Keras `optimizer.iterations`: steps applied so far (the queued ones included)"""
+        return self._iterations
 
     def apply_gradients(self, grads_and_vars):
         """Consumes the tokens of `GradientTape.gradient`: all tokens of one recorded
@@ -58,7 +89,9 @@ class _Optimizer:
                 steps.append((g.step, g.no_l2))
         for step, no_l2 in steps:
             ctx = step.model.user_latent_factor.table.ctx
+            self._models.add(step.model)
             step.train(self.native(ctx), no_l2)
+            self._iterations += 1
 
 
 class SGD(_Optimizer):

@@ -139,3 +139,41 @@ def test_dlrm_loop_is_queued(monkeypatch):
         assert abs(float(g) - w) <= 2e-5 * abs(w)
     assert rel_err(pred, o.inference(dense, sparse)) < 2e-5
     assert rel_err(m.trainable_variables[0].numpy(), np.concatenate(o.emb)) < 2e-5
+
+
+@pytest.mark.parametrize("optname", ["sgd", "adam"])
+def test_learning_rate_assigned_mid_run_applies_from_the_next_step(optname):
+    """Keras scripts schedule the rate by assigning `optimizer.learning_rate`.  Steps already applied (still queued or
+    not) keep their rate; `optimizer.iterations` counts the applied steps, queued ones included."""
+    from openrec_amd.tf2 import compat as tf
+    from openrec_amd.tf2 import recommenders as R
+    from oracle import numpy_oracle as orc
+    rng = np.random.default_rng(3)
+    NU, NI, D, B, n_steps = 600, 800, 32, 256, 50
+    m = R.BPR(dim_user_embed=D, dim_item_embed=D, total_users=NU, total_items=NI)
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    m.user_latent_factor.variables[0].assign(U); m.item_latent_factor.variables[0].assign(V); m.item_bias.variables[0].assign(b)
+    lr0 = 0.02 if optname == "sgd" else 0.002
+    optimizer = tf.keras.optimizers.SGD(lr0) if optname == "sgd" else tf.keras.optimizers.Adam(lr0)
+    oo = orc.SGD(lr0) if optname == "sgd" else orc.AdamTFSparse(lr0)
+    losses, want = [], []
+    for s in range(n_steps):
+        if s == 20:                                   # 20 steps sit in the queue at this point
+            optimizer.learning_rate = lr0 / 4
+            oo.lr = lr0 / 4
+            assert optimizer.learning_rate == lr0 / 4 and optimizer.lr == lr0 / 4
+        if s == 37:
+            assert optimizer.iterations == 37
+        u = rng.integers(0, NU, B).astype(np.int32); p = rng.integers(0, NI, B).astype(np.int32); n = rng.integers(0, NI, B).astype(np.int32)
+        with tf.GradientTape() as tape:
+            loss, l2 = m(u, p, n)
+        grads = tape.gradient((loss, l2), m.trainable_variables)
+        optimizer.apply_gradients(zip(grads, m.trainable_variables))
+        losses.append(loss)
+        want.append(float(orc.bpr_step(U, V, b, u, p, n, oo)[0]))
+    tol = 5e-5 if optname == "adam" else 2e-5
+    for g, w in zip(losses, want):
+        assert abs(float(g) - w) <= tol * abs(w)
+    assert rel_err(m.user_latent_factor.variables[0].numpy(), U) < tol and rel_err(m.item_latent_factor.variables[0].numpy(), V) < tol
+    assert optimizer.iterations == n_steps
