@@ -71,3 +71,30 @@ def test_k_step_call_equals_single_step_calls_at_full_size():
     for a, c in zip(res[0][:3], res[1][:3]):
         assert np.abs(a - c).max() <= 2e-7 * np.abs(c).max()          # only the fp32 order of >= 3-reference sums differs
     assert np.allclose(res[0][3], res[1][3], rtol=1e-6)
+
+
+def test_full_size_lazy_adam_matches_the_c_oracles_dense_rule():
+    """TF-2.0 Adam at configs[1] sizes: the lazily-applied rule (rows replay their gradient-free steps when next
+    referenced; the final read flushes every row) against the C oracle, which sweeps the whole tables every step."""
+    from openrec_amd import runtime as rt
+    from oracle import c_oracle
+    NU = NI = 1_000_000
+    B, K, D = 65536, 8, 64
+    U, V, b = _tables(NU, NI, D, 3)
+    rng = np.random.default_rng(4)
+    uid = rng.integers(0, NU, (K, B)).astype(np.int32); pid = rng.integers(0, NI, (K, B)).astype(np.int32)
+    nid = rng.integers(0, NI, (K, B)).astype(np.int32)
+    tU = rt.Table(NU, D).write(U); tV = rt.Table(NI, D).write(V); tb = rt.Table(NI, 1).write(b)
+    opt = rt.Optimizer.adam(0.002)
+    U0 = U.copy()
+    loss, l2 = rt.pairwise_step("bpr", opt, tU, tV, tb, uid, pid, nid, K=K, B=B)
+    cpu = c_oracle.PairwiseCPU("bpr", "adam", U, V, b, lr=0.002)
+    for s in range(K):
+        lw, l2w = cpu.step(uid[s], pid[s], nid[s])
+        assert abs(loss[s] - lw) <= 2e-5 * abs(lw) and abs(l2[s] - l2w) <= 2e-5 * abs(l2w)
+    gU, gV, gb = tU.read(), tV.read(), tb.read()
+    for got, want in ((gU, U), (gV, V), (gb, b)):
+        assert np.abs(got - want).max() <= 5e-5 * np.abs(want).max()
+    assert np.abs(opt.slot(tV, 0) - cpu.m[1]).max() <= 5e-5 * np.abs(cpu.m[1]).max()
+    untouched_u = np.ones(NU, bool); untouched_u[uid.reshape(-1)] = False      # m = v = 0 there: the rule moves nothing
+    assert untouched_u.sum() > 0.5 * NU and np.array_equal(gU[untouched_u], U0[untouched_u])
