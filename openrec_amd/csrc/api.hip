@@ -705,6 +705,8 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
         CHECK(orx_adam_lrt(opt, opt->t + K));
         a.lrt = opt->d_lrt; a.b1 = opt->p0; a.b2 = opt->p1; a.eps = opt->p2;
         a.newton = (1.0f - sqrtf(opt->p1)) <= 1e-3f && getenv("ORX_ADAM_NO_NEWTON") == nullptr;
+        // expected steps between two references of a row = rows / references per step
+        a.long_gap = (U->rows / B > 64 || V->rows / (2 * B) > 64) && getenv("ORX_ADAM_NO_LONGGAP") == nullptr;
         U->lazy = opt; V->lazy = opt; b->lazy = opt;
     }
     // epochs are consumed one per step; on wrap-around every table clears its epoch-tagged arrays

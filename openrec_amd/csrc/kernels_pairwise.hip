@@ -609,7 +609,7 @@ __device__ __forceinline__ void wait_ready(const int* flag, int epoch) {
 
 // ------------------------------------------------------------ fused kernel ---
 // LPR lanes own one row (D = 4*LPR).  MODE: see orx_internal.h.
-template <int LPR, int MODEL, int OPT, int MODE, bool CENSOR = false, bool STAGED = false>
+template <int LPR, int MODEL, int OPT, int MODE, bool CENSOR = false, bool STAGED = false, bool LONGGAP = false>
 __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
@@ -682,7 +682,16 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             mn = *reinterpret_cast<const f4*>(a.aV + (size_t)n * D + 4 * sub); vn = *reinterpret_cast<const f4*>(a.a2V + (size_t)n * D + 4 * sub);
             mbp = a.ab[p]; vbp = a.a2b[p]; mbn = a.ab[n]; vbn = a.a2b[n];
             // (the bias of an item shares the item row's stamp: the three tables are lazy together, api.hip)
-            const int lu = a.lastU[u], lp = a.lastV[p], ln = a.lastV[n];
+            int lu = a.lastU[u], lp = a.lastV[p], ln = a.lastV[n];
+            if (LONGGAP) {      // large tables: rows that have waited very long take the bounded replay and leave the merged loop
+                if (T1 - lu > ORX_ADAM_LONG_GAP) {
+                    float z0 = 0.f, z1 = 0.f, z2 = 0.f;
+                    adam_replay4_bounded(ru, mu, vu, z0, z1, z2, lu, T1, a.lrt, a.b1, a.b2, a.eps);
+                    lu = T1;
+                }
+                if (T1 - lp > ORX_ADAM_LONG_GAP) { adam_replay4_bounded(rp, mp, vp, bp, mbp, vbp, lp, T1, a.lrt, a.b1, a.b2, a.eps); lp = T1; }
+                if (T1 - ln > ORX_ADAM_LONG_GAP) { adam_replay4_bounded(rn, mn, vn, bn, mbn, vbn, ln, T1, a.lrt, a.b1, a.b2, a.eps); ln = T1; }
+            }
             if (a.newton) adam_catchup_triplet<true, LPR>(ru, mu, vu, lu, rp, mp, vp, lp, rn, mn, vn, ln, bp, mbp, vbp, bn, mbn, vbn, T1, a.lrt, a.b1, a.b2, a.eps);
             else adam_catchup_triplet<false, LPR>(ru, mu, vu, lu, rp, mp, vp, lp, rn, mn, vn, ln, bp, mbp, vbp, bn, mbn, vbn, T1, a.lrt, a.b1, a.b2, a.eps);
         }
@@ -1090,6 +1099,19 @@ int orx_fused_can_inline_apply(int D) { return lpr_for_dim(D) != 0; }
 // lazy Adam (exact mode, float4 dims): its own small set of instantiations
 template <int MODEL>
 static void launch_fused_adam(int lpr, dim3 g, orx_ctx* s, const PairArgs& a) {
+#define ORX_FL(L) do { if (a.stage) ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, true, true>), g, dim3(256), 0, a); \
+                       else ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, false, true>), g, dim3(256), 0, a); } while (0)
+    if (a.long_gap && !a.censor) {      // tables large relative to the batch: the variant with the bounded per-row replay
+        switch (lpr) {
+            case 4: ORX_FL(4); break;
+            case 8: ORX_FL(8); break;
+            case 16: ORX_FL(16); break;
+            case 32: ORX_FL(32); break;
+            default: ORX_FL(64); break;
+        }
+        return;
+    }
+#undef ORX_FL
 #define ORX_FA(L) do { if (a.censor) { if (a.stage) ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, true, true>), g, dim3(256), 0, a); \
                                          else ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, true, false>), g, dim3(256), 0, a); } \
                        else if (a.stage) ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, true>), g, dim3(256), 0, a); \

@@ -234,6 +234,41 @@ __device__ __forceinline__ void adam_replay1(float& w, float& m, float& v, int f
     adam_decay_tail(m, v, to - k + 1, b1, b2);
 }
 
+// One row slice (4 elements per lane, plus the item bias carried along) whose stamp is FAR behind: replayed on its
+// own, bounded like adam_replay1 (the loop ends once no element of the lane moves any more, the remaining steps decay
+// m and v in closed form).  Rows of a large table wait hundreds of steps between references; in the merged loop
+// below they would run -- and make the whole wavefront run -- the entire gap.  Costs ~58 VGPRs when inlined, so it
+// lives in its own instantiation of the fused kernel (LONGGAP), chosen by the host for tables that are large
+// relative to the batch.
+constexpr int ORX_ADAM_LONG_GAP = 256;
+__device__ __forceinline__ void adam_replay4_bounded(f4& w, f4& m, f4& v, float& bw, float& bm, float& bv, int from, int to,
+                                                     const float* lrt, float b1, float b2, float eps) {
+    if (from >= to) return;
+    const float sb2 = sqrtf(b2);
+    const float ce = eps * (1.0f - sb2);
+    f4 d = sqrt4(v) + eps;
+    float db = sqrtf(bv) + eps;
+    int k = from + 1;
+    for (; k <= to; ++k) {
+        const float lr = lrt[k];
+        m = m * b1; v = v * b2; d = d * sb2 + ce;
+        bm *= b1; bv *= b2; db = db * sb2 + ce;
+        const f4 u = (lr * m) * rcp4(d);
+        const float ub = (lr * bm) * __builtin_amdgcn_rcpf(db);
+        const f4 wn = w - u;
+        const float bn = bw - ub;
+        const f4 t = wn - 4.0f * u;
+        const bool still = (t.x != wn.x) | (t.y != wn.y) | (t.z != wn.z) | (t.w != wn.w) | ((bn - 4.0f * ub) != bn);
+        w = wn; bw = bn;
+        if (!still) { ++k; break; }
+    }
+    const int rem = to - k + 1;
+    if (rem > 0) {
+        const float f1 = exp2f((float)rem * log2f(b1)), f2 = exp2f((float)rem * log2f(b2));
+        m = m * f1; v = v * f2; bm *= f1; bv *= f2;
+    }
+}
+
 // the three rows (and the two item biases, which share their item row's stamp) of one triplet in ONE loop: its trip
 // count is the longest of the three gaps, not their sum, and the three chains interleave.  A row whose gap is
 // shorter is masked out of the early iterations.

@@ -159,6 +159,7 @@ struct PairArgs {
     int* lastU; int* lastV; int* lastb;       // lazy Adam: per-row step stamps (NULL: not the lazy Adam path)
     const float* lrt; float b1; float b2; int step_t;   // lr_t per step, betas, index of THIS step (its lr_t = lrt[step_t])
     int newton;                 // lazy Adam: carry 1/(sqrt(v)+eps) by Newton steps (1 - sqrt(beta_2) <= 1e-3)
+    int long_gap;               // lazy Adam: tables large relative to the batch (rows wait hundreds of steps): LONGGAP kernel
     const int32_t* uid; const int32_t* pid; const int32_t* nid;
     int role_bits;                            // ids carry role (bits 30:29) and urgent (bit 28): tables < 2^28 rows
     // in-launch application of the PREVIOUS step's duplicated rows (n_apply_blocks == 0: off)
