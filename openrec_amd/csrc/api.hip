@@ -101,6 +101,9 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     prof_collect(c);
     hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_cflag); hipFree(c->d_dupbits); hipFree(c->d_dlist);
     hipFree(c->d_dcount); hipFree(c->d_refinfo); hipFree(c->d_tricnt); hipFree(c->d_segstart); hipFree(c->d_alloc); hipFree(c->d_dseg); hipFree(c->d_dcnt); hipFree(c->d_chunks); hipFree(c->d_part); hipFree(c->d_partb); hipFree(c->d_stage); hipFree(c->d_stageb); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
+    hipFree(c->d_wpart); hipFree(c->d_pl_cnt); hipFree(c->d_pl_cur); hipFree(c->d_pl_list);
+    if (c->h_plan) hipHostFree(c->h_plan);
+    if (c->plan_ev) hipEventDestroy(c->plan_ev);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return ORX_OK;
@@ -492,6 +495,12 @@ int fetch_losses(orx_ctx* c, int64_t K, float* loss_out, float* l2_out) {
 }
 
 
+// the bucketed plan (kernels_plan.hip) needs the role bits; ORX_PLAN_V1=1 keeps dedup_kernel + urgent_kernel
+bool orx_plan_v2(bool role_bits) {
+    static const bool v1 = getenv("ORX_PLAN_V1") != nullptr;
+    return role_bits && !v1;
+}
+
 // sizes every per-call buffer of the exact pairwise step (grow-only)
 int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t B, int mode, bool role_bits,
                       bool inline_apply, bool staging, int nb_total, int nw, PairPlan* plan) {
@@ -507,10 +516,25 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
     // the three rewritten id arrays of a step are padded apart: with B a power of two their
     // addresses would otherwise differ by exact multiples of 256 KiB (same cache set / HBM channel)
     const int64_t Bp = ((B + 3) / 4) * 4 + 96;
+    const bool v2 = orx_plan_v2(role_bits);
     if (mode == MODE_EXACT) {
         ENSURE(c->d_ids2, c->d_ids2_cap, (size_t)chunk * 3 * Bp * sizeof(int32_t));
-        if (role_bits) ENSURE(c->d_roles, c->d_roles_cap, (size_t)chunk * 3 * Bp);
-        if (inline_apply) ENSURE(c->d_dupbits, c->d_dupbits_cap, (size_t)chunk * nb_total * orx_dedup_words() * sizeof(unsigned int));
+        if (v2) {
+            // bucketed plan (kernels_plan.hip): bucket counters, lists of up to 3 B references per step, per-range bitmaps
+            const int shift = orx_plan_shift(U->rows, V->rows);
+            const int nb2 = orx_plan_ranges(U->rows, shift) + orx_plan_ranges(V->rows, shift);
+            CHECK(orx_plan_buffers(c, chunk, 3 * B, nb2, shift, inline_apply));
+            if (c->h_plan_cap < (size_t)chunk * 9 * sizeof(int)) {
+                if (c->h_plan) ORX_HIP(hipHostFree(c->h_plan));
+                c->h_plan = nullptr; c->h_plan_cap = 0;
+                ORX_HIP(hipHostMalloc((void**)&c->h_plan, (size_t)chunk * 9 * sizeof(int), hipHostMallocDefault));
+                c->h_plan_cap = (size_t)chunk * 9 * sizeof(int);
+            }
+            if (!c->plan_ev) ORX_HIP(hipEventCreateWithFlags(&c->plan_ev, hipEventDisableTiming));
+        } else {
+            if (role_bits) ENSURE(c->d_roles, c->d_roles_cap, (size_t)chunk * 3 * Bp);
+            if (inline_apply) ENSURE(c->d_dupbits, c->d_dupbits_cap, (size_t)chunk * nb_total * orx_dedup_words() * sizeof(unsigned int));
+        }
         ENSURE(c->d_dlist, c->d_dlist_cap, (size_t)chunk * list_stride * sizeof(uint32_t));
         ENSURE(c->d_dcount, c->d_dcount_cap, (size_t)chunk * sizeof(int));
     }
@@ -520,7 +544,7 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
     const int64_t item_stride = cap1 + cap2 + cap3;
     if (staging) {
         ENSURE(c->d_refinfo, c->d_refinfo_cap, (size_t)chunk * 3 * Bp * sizeof(int2));
-        ENSURE(c->d_tricnt, c->d_tricnt_cap, (size_t)chunk * B * sizeof(int));
+        ENSURE(c->d_tricnt, c->d_tricnt_cap, (size_t)chunk * B * sizeof(int));      // (v2: only ranges with > 2048 tri rows use it)
         ENSURE(c->d_segstart, c->d_segstart_cap, (size_t)chunk * B * sizeof(int));
         ENSURE(c->d_alloc, c->d_alloc_cap, (size_t)chunk * 8 * sizeof(int));
         ENSURE(c->d_dseg, c->d_dseg_cap, (size_t)chunk * list_stride * sizeof(int));
@@ -534,6 +558,7 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
     plan->item_stride = item_stride; plan->tree_off[0] = 0; plan->tree_off[1] = (int)cap1; plan->tree_off[2] = (int)(cap1 + cap2);
 
     plan->nw = nw; plan->chunk = chunk; plan->list_stride = list_stride; plan->Bp = Bp;
+    plan->min_late = -1;
     return ORX_OK;
 }
 
@@ -553,25 +578,52 @@ int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
     d.flag_stride = 3 * plan.Bp; d.role_stride = plan.Bp; d.list_stride = plan.list_stride;
     d.nU = nU; d.nP = nP; d.nN = nN; d.NU = U->rows; d.NI = V->rows;
     d.nbu = orx_dedup_buckets(U->rows); d.nbi = orx_dedup_buckets(V->rows);
+    d.min_late = plan.min_late;
     ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));
+    const bool v2 = orx_plan_v2(role_bits);
     if (staging) {
         d.refinfo = c->d_refinfo; d.tricnt = c->d_tricnt; d.segstart = c->d_segstart; d.alloc = c->d_alloc;
         d.dseg = c->d_dseg; d.dcnt = c->d_dcnt; d.items = c->d_chunks;
         d.tri_stride = B; d.item_stride = plan.item_stride;
         for (int l = 0; l < 3; ++l) d.tree_off[l] = plan.tree_off[l];
-        ORX_HIP(hipMemsetAsync(c->d_tricnt, 0, (size_t)kc * B * sizeof(int), c->stream));
+        if (!v2) ORX_HIP(hipMemsetAsync(c->d_tricnt, 0, (size_t)kc * B * sizeof(int), c->stream));
         ORX_HIP(hipMemsetAsync(c->d_alloc, 0, (size_t)kc * 8 * sizeof(int), c->stream));
     }
-    CHECK(orx_launch_dedup(c, d, kc));
+    std::vector<int> dc_v1, al_v1;
+    const int* dc = nullptr;            // duplicated rows per step
+    const int* al = nullptr;            // staging allocators per step
+    if (v2) {
+        // bucketed plan; ONE read-back of the per-step counters into pinned memory, and the urgent marks are made while
+        // the host waits for it (the fused kernel ignores them in a launch without apply blocks)
+        d.roles = nullptr; d.dupbits = nullptr;
+        CHECK(orx_launch_plan(c, d, kc, inline_apply));
+        ORX_HIP(hipMemcpyAsync(c->h_plan, c->d_dcount, (size_t)kc * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        if (staging) ORX_HIP(hipMemcpyAsync(c->h_plan + kc, c->d_alloc, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        ORX_HIP(hipEventRecord(c->plan_ev, c->stream));
+        if (inline_apply) CHECK(orx_launch_plan_urgent(c, d, kc));
+        ORX_HIP(hipEventSynchronize(c->plan_ev));
+        dc = c->h_plan; al = c->h_plan + kc;
+    } else {
+        CHECK(orx_launch_dedup(c, d, kc));
+        if (inline_apply) {
+            dc_v1.resize((size_t)kc);
+            ORX_HIP(hipMemcpyAsync(dc_v1.data(), c->d_dcount, dc_v1.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            ORX_HIP(hipStreamSynchronize(c->stream));
+            dc = dc_v1.data();
+        }
+        if (staging) {
+            al_v1.resize((size_t)kc * 8);
+            ORX_HIP(hipMemcpyAsync(al_v1.data(), c->d_alloc, al_v1.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            ORX_HIP(hipStreamSynchronize(c->stream));
+            al = al_v1.data();
+        }
+    }
     if (inline_apply) {
         // The in-launch apply hides the duplicate apply behind the next step while few references have
         // to wait for it (the headline: ~0.16 B duplicated rows per step, 34 vs 39 us).  With many
         // duplicated rows most references of the next step wait and the launch serializes (100k x 100k
         // tables: 148 vs 56 us per step; break-even measured at ~0.19 B, 800k x 800k tables), so from
         // B/5 duplicated rows on the apply is its own launch.
-        std::vector<int> dc((size_t)kc);
-        ORX_HIP(hipMemcpyAsync(dc.data(), c->d_dcount, dc.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        ORX_HIP(hipStreamSynchronize(c->stream));
         int max_dup = 0;
         for (int64_t i = 0; i < kc; ++i) max_dup = std::max(max_dup, dc[i]);
         const char* thr = getenv("ORX_INLINE_DUP_DIV");        // debug: threshold = B / value
@@ -579,10 +631,7 @@ int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
     }
     if (staging) {
         // long segments (a row referenced > 16 times in one step) need the hot_reduce_kernel levels between the
-        // fused launch and the apply: one small read-back per chunk of steps decides
-        std::vector<int> al((size_t)kc * 8);
-        ORX_HIP(hipMemcpyAsync(al.data(), c->d_alloc, al.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        ORX_HIP(hipStreamSynchronize(c->stream));
+        // fused launch and the apply: the per-step allocators decide
         out->hot = false; out->tree_levels = 0;
         int max_staged = 0;
         for (int64_t i = 0; i < kc; ++i) {
@@ -590,11 +639,11 @@ int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
             max_staged = std::max(max_staged, al[8 * i + 1]);
         }
         out->hot = out->tree_levels > 0;
-        // dedup_kernel plans staging only for row ranges where atomics would pile up; without any plan in
-        // the chunk the kernels without the segment bookkeeping are launched
+        // the plan covers only row ranges where atomics would pile up; without any plan in the chunk the kernels
+        // without the segment bookkeeping are launched
         out->use_stage = max_staged > 0;
     }
-    if (inline_apply && !out->hot && !out->dense_dups) CHECK(orx_launch_urgent(c, d, kc));
+    if (!v2 && inline_apply && !out->hot && !out->dense_dups) CHECK(orx_launch_urgent(c, d, kc));
     return ORX_OK;
 }
 
@@ -684,6 +733,9 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     CHECK(orx_exact_buffers(c, U, V, K, B, mode, role_bits, inline_apply, staging, nb_total, orx_fused_nwaves(U->dim, B), &plan));
     const int nw = plan.nw;
     const int64_t chunk = plan.chunk, list_stride = plan.list_stride, Bp = plan.Bp;
+    // Adam's normalised update amplifies summation-order noise where an element's summed gradient nearly cancels: its
+    // rows referenced >= 3 times always take staging slots (fixed summation order), never fp32 atomics
+    if (opt->kind == ORX_ADAM) plan.min_late = 1;
 
     PairArgs a;
     memset(&a, 0, sizeof(a));

@@ -92,6 +92,7 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
         const int nb_total = orx_dedup_buckets(U->rows) + orx_dedup_buckets(V->rows);
         const size_t part_cap = c->d_partial_cap;       // orx_exact_buffers sizes d_partial for its own use: keep ours
         CHECK(orx_exact_buffers(c, U, V, K, B, mode, true, false, staging, nb_total, nslot, &plan));
+        if (opt->kind == ORX_ADAM) plan.min_late = 1;      // Adam: fixed summation order for every row referenced >= 3 times (api.hip)
         (void)part_cap;
         ENSURE(c->d_partial, c->d_partial_cap, (size_t)K * nslot * 2 * sizeof(float));
     } else if (mode == MODE_EXACT) {

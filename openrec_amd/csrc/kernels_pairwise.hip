@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             const int2 ri = a.refinfo[ref];
             return ri.x < 0 ? -1 : a.segstart[ri.x] + ri.y;      // (-1, 0): the row's range made no plan -> atomics
         };
-        if (MODE == MODE_EXACT && urgent) {
+        if (MODE == MODE_EXACT && urgent && nab) {      // (the marks are made before the host knows whether the launch applies)
             // a row of this triplet is being updated by an apply block of this launch
             if (sub == 0) {
                 if (urgent & 1) wait_ready(a.readyU + u, a.epoch);

@@ -54,6 +54,13 @@ struct orx_ctx {
     unsigned char* d_roles = nullptr; size_t d_roles_cap = 0;    // [K][3B] dedup scratch
     unsigned char* d_cflag = nullptr; size_t d_cflag_cap = 0;    // [3][K][B] censor election flags
     unsigned int* d_dupbits = nullptr; size_t d_dupbits_cap = 0; // [K][buckets][words] duplicate bitmaps
+    // bucketed plan (kernels_plan.hip): references per (step, row range), scatter cursors, bucket lists
+    int* d_pl_cnt = nullptr;   size_t d_pl_cnt_cap = 0;          // [K][ranges + 1]
+    int* d_pl_cur = nullptr;   size_t d_pl_cur_cap = 0;          // [K][ranges]
+    int2* d_pl_list = nullptr; size_t d_pl_list_cap = 0;         // [K][references per step] (id, output position | role << 30)
+    int* h_plan = nullptr;                                       // pinned host mirror of the per-step plan counters
+    size_t h_plan_cap = 0;
+    hipEvent_t plan_ev = nullptr;                                // "plan counters have arrived on the host"
     int epoch = 0;                                               // step epoch: tags ready flags and censor side marks
     int epoch_gen = 0;                                           // bumped when `epoch` wraps (tables then clear their tags)
     // staging plan of rows referenced >= 3 times in a step (see kernels_pairwise.hip, "staging")
@@ -212,6 +219,7 @@ struct DedupArgs {
     int4* items;                              // [K][item_stride] tree work items (src, len, dst, -), level l at offset tree_off[l]
     int64_t tri_stride; int64_t item_stride;
     int tree_off[3];
+    int min_late;                             // bucketed plan: see PairPlan
 };
 constexpr int ORX_SEG_DIRECT = 16;            // the apply sums up to this many staged gradients / partial sums of a row itself
 constexpr int ORX_PIECE = 64;                 // longer segments: a tree of 64-to-1 partial sums (hot_reduce_kernel, one wavefront per piece)
@@ -309,7 +317,8 @@ int orx_launch_fused(orx_ctx* ctx, int model, int optkind, int mode, const PairA
 int orx_launch_hot_reduce(orx_ctx* ctx, const PairArgs& a, int level);
 
 // host-side plan of the exact steps (api.hip), shared by the pairwise and the pointwise step
-struct PairPlan { int nw; int64_t chunk; int64_t list_stride; int64_t Bp; int64_t item_stride; int tree_off[3]; };
+struct PairPlan { int nw; int64_t chunk; int64_t list_stride; int64_t Bp; int64_t item_stride; int tree_off[3];
+                  int min_late = -1; };   // staging plan from this many third-or-later references per range on (< 0: max(64, n / 512))
 struct ExactChunk { bool hot = false, use_stage = false, dense_dups = false; int tree_levels = 0; };
 int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t B, int mode, bool role_bits,
                       bool inline_apply, bool staging, int nb_total, int nw, PairPlan* plan);
@@ -326,6 +335,13 @@ int orx_apply_rows_planned_step(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_ta
                                 const int32_t* ids, const float* grads, int64_t g_stride);
 int orx_launch_dup_apply(orx_ctx* ctx, int optkind, const PairArgs& a);
 int orx_launch_urgent(orx_ctx* ctx, const DedupArgs& a, int64_t K);
+// bucketed plan (kernels_plan.hip): same outputs as orx_launch_dedup (+ orx_launch_urgent) with `d` filled the same way
+bool orx_plan_v2(bool role_bits);
+int orx_plan_shift(int64_t NU, int64_t NI);
+int orx_plan_ranges(int64_t rows, int shift);
+int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t nref, int nb, int shift, bool want_dupbits);
+int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupbits);
+int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc);
 int orx_fused_can_inline_apply(int D);
 int orx_dedup_words(void);
 int orx_launch_loss_reduce(orx_ctx* ctx, const ReduceArgs& a, int64_t K);
