@@ -579,15 +579,15 @@ int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
     d.nU = nU; d.nP = nP; d.nN = nN; d.NU = U->rows; d.NI = V->rows;
     d.nbu = orx_dedup_buckets(U->rows); d.nbi = orx_dedup_buckets(V->rows);
     d.min_late = plan.min_late;
-    ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));
     const bool v2 = orx_plan_v2(role_bits);
+    if (!v2) ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));     // (the bucketed plan zeroes its counters itself)
     if (staging) {
         d.refinfo = c->d_refinfo; d.tricnt = c->d_tricnt; d.segstart = c->d_segstart; d.alloc = c->d_alloc;
         d.dseg = c->d_dseg; d.dcnt = c->d_dcnt; d.items = c->d_chunks;
         d.tri_stride = B; d.item_stride = plan.item_stride;
         for (int l = 0; l < 3; ++l) d.tree_off[l] = plan.tree_off[l];
         if (!v2) ORX_HIP(hipMemsetAsync(c->d_tricnt, 0, (size_t)kc * B * sizeof(int), c->stream));
-        ORX_HIP(hipMemsetAsync(c->d_alloc, 0, (size_t)kc * 8 * sizeof(int), c->stream));
+        if (!v2) ORX_HIP(hipMemsetAsync(c->d_alloc, 0, (size_t)kc * 8 * sizeof(int), c->stream));
     }
     std::vector<int> dc_v1, al_v1;
     const int* dc = nullptr;            // duplicated rows per step

@@ -83,6 +83,11 @@ __global__ __launch_bounds__(PL_THREADS) void plan_part_kernel(PlanArgs a) {
     __syncthreads();
     int* cnt = a.bcnt + s * (nb + 1);
     if (!SCATTER) {
+        // the step's list and allocator counters start at zero (first used by plan_range_kernel): no memsets of their own
+        if (blockIdx.x == 0 && threadIdx.x < 9) {
+            if (threadIdx.x == 8) a.d.dcount[s] = 0;
+            else if (a.d.alloc) a.d.alloc[8 * s + threadIdx.x] = 0;
+        }
         for (int i = threadIdx.x; i < nb; i += PL_THREADS) { const int c = hist[i]; if (c) atomicAdd(cnt + i, c); }
         return;
     }

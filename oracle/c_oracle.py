@@ -48,6 +48,8 @@ def lib():
         L.orc_censor.argtypes = [fp, ctypes.c_int64, ctypes.c_int, ip, ctypes.c_int64, ctypes.c_float]
         L.orc_censor.restype = ctypes.c_int
         L.orc_num_threads.restype = ctypes.c_int
+        L.orc_set_l2w.argtypes = [ctypes.c_float]
+        L.orc_set_l2w.restype = None
         _lib = L
     return _lib
 
@@ -63,7 +65,8 @@ def _ip(a):
 class PairwiseCPU:
     """Holds scratch + Adagrad / Adam slots; tables are caller-owned float32 C-contiguous arrays."""
 
-    def __init__(self, model, opt, U, V, b, lr, eps=1e-7, init_acc=0.1, margin=0.5, beta_1=0.9, beta_2=0.999):
+    def __init__(self, model, opt, U, V, b, lr, eps=1e-7, init_acc=0.1, margin=0.5, beta_1=0.9, beta_2=0.999, l2w=1.0):
+        self.l2w = float(l2w)       # weight of l2_loss in the differentiated objective (0: the library's ORX_NO_L2)
         self.model = {"bpr": 0, "ucml": 1}[model]
         self.opt = {"sgd": 0, "adagrad": 1, "adam": 2}[opt]
         self.b1, self.b2, self.t = beta_1, beta_2, 0
@@ -87,6 +90,7 @@ class PairwiseCPU:
         if self.scratch is None or self.scratch.size < need:
             self.scratch = np.empty(need, np.float32)
         out = (ctypes.c_double * 2)()
+        lib().orc_set_l2w(self.l2w)
         if self.opt == 2:
             self.t += 1
             lr_t = self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)

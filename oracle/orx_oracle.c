@@ -42,6 +42,12 @@ static inline float sigmoidf_(float x) {
     return x >= 0 ? 1.f / (1.f + e) : e / (1.f + e);
 }
 
+/* weight of l2_loss in the differentiated objective: 1 = tape over the tuple (loss, l2_loss) as in
+ * tf2_examples/bpr_citeulike.py:35-37; 0 = tape over `loss` alone (the library's ORX_NO_L2).  The l2 VALUE is
+ * reported either way. */
+static float g_l2w = 1.f;
+void orc_set_l2w(float w) { g_l2w = w; }
+
 /* scratch layout: gu,gp,gn [B*D] each, gb [B] -> (3*B*D + B) floats */
 
 /* forward + per-occurrence gradients on the PRE-step tables (objective loss + l2_loss) */
@@ -50,6 +56,7 @@ static void forward_grads(int model, const float* U, const float* V, const float
                           float* gu, float* gp, float* gn, float* gb, double* out) {
     double loss = 0.0, l2 = 0.0;
     const float invB = 1.0f / (float)B;
+    const float l2w = g_l2w;
 
 #pragma omp parallel for reduction(+ : loss, l2) schedule(static)
     for (int64_t k = 0; k < B; ++k) {
@@ -65,9 +72,9 @@ static void forward_grads(int model, const float* U, const float* V, const float
             loss += -(double)log_sigmoidf(m) * invB;
             g = (s >= -30.f) ? -sigmoidf_(-s) * invB : 0.f;
             for (int d = 0; d < D; ++d) {
-                gu[k * D + d] = g * (p[d] - n[d]) + u[d];
-                gp[k * D + d] = g * u[d] + p[d];
-                gn[k * D + d] = -g * u[d] + n[d];
+                gu[k * D + d] = g * (p[d] - n[d]) + l2w * u[d];
+                gp[k * D + d] = g * u[d] + l2w * p[d];
+                gn[k * D + d] = -g * u[d] + l2w * n[d];
             }
             gb[k] = g;                               /* d/db[p] = g, d/db[n] = -g */
         } else {
@@ -81,9 +88,9 @@ static void forward_grads(int model, const float* U, const float* V, const float
             loss += (double)fmaxf(h, 0.f);
             float a = (h >= 0.f) ? 1.f : 0.f;
             for (int d = 0; d < D; ++d) {
-                gu[k * D + d] = -2.f * a * (p[d] - n[d]) + u[d];
-                gp[k * D + d] = -2.f * a * (u[d] - p[d]) + p[d];
-                gn[k * D + d] = 2.f * a * (u[d] - n[d]) + n[d];
+                gu[k * D + d] = -2.f * a * (p[d] - n[d]) + l2w * u[d];
+                gp[k * D + d] = -2.f * a * (u[d] - p[d]) + l2w * p[d];
+                gn[k * D + d] = 2.f * a * (u[d] - n[d]) + l2w * n[d];
             }
             gb[k] = -a;                              /* d/db[p] = -a, d/db[n] = +a */
         }

@@ -3,7 +3,7 @@ with the NumPy oracle.  CPU only."""
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import TOL, TOL_ADAM, rel_err
 from oracle import numpy_oracle as orc
 from oracle import c_oracle
 
@@ -36,8 +36,8 @@ def test_c_oracle_matches_numpy(model, opt, D):
         else:
             l_ref = orc.ucml_step(U, V, b, u, p, n, o, margin=0.5, do_censor=False)
         l_c = cpu.step(u, p, n)
-        assert rel_err(l_c, l_ref) < (5e-5 if opt == "adam" else 1e-5)
-    tol = 5e-5 if opt == "adam" else 1e-5             # (fp32 on both sides; Adam's m / (sqrt(v) + eps) amplifies rounding)
+        assert rel_err(l_c, l_ref) < (TOL_ADAM if opt == "adam" else TOL)
+    tol = TOL_ADAM if opt == "adam" else TOL          # (conftest.TOL_ADAM: the derivation)
     assert rel_err(U2, U) < tol and rel_err(V2, V) < tol and rel_err(b2, b) < tol
     if opt == "adam":
         assert rel_err(cpu.m[1], o.m["V"]) < tol and rel_err(cpu.v[0], o.v["U"]) < tol and rel_err(cpu.m[2], o.m["b"][:, 0]) < tol

@@ -43,11 +43,11 @@ def test_dlrm_golden(fname):
     _load(m, g)
     opt = _opt(rt, optkind)
     losses = [m.step(opt, g["dense"], g["sparse"], g["label"])[0] for _ in range(2)]
-    tol = 2e-5
+    tol = 1e-5
     assert rel_err(losses, g["losses"]) < tol
     emb = m.param("emb").read()
     ref = np.concatenate([g[f"out_emb{f}"] for f in range(3)])
-    assert rel_err(emb, ref) < 5 * tol
+    assert rel_err(emb, ref) < tol
     for nm, n in (("bot", 2), ("top", 3)):
         for l in range(n):
             assert rel_err(m.param(nm + "_w", l).read(), g[f"out_{nm}{l}W"]) < 5 * tol, (nm, l)
@@ -80,7 +80,7 @@ def test_dlrm_example_shapes_vs_oracle(compat):
     for s in range(2):
         l = m.step(opt, dense, sparse, label)[0]
         lr = o.step(dense, sparse, label, oo)
-        assert abs(l - lr) <= 2e-5 * abs(lr)
+        assert abs(l - lr) <= 1e-5 * abs(lr)
     assert rel_err(m.param("emb").read(), np.concatenate(o.emb)) < 1e-4
     assert rel_err(m.param("top_w", 0).read(), o.top[0][0]) < 1e-4
     assert rel_err(m.param("bot_w", 0).read(), o.bot[0][0]) < 1e-4
@@ -173,12 +173,12 @@ def test_dlrm_wide_embeddings_mfma_interaction(m_spa, n_emb, itself, optname):
     for s in range(3):
         l = m.step(opt, dense, sparse, label)[0]
         lr = o.step(dense, sparse, label, oo)
-        assert abs(l - lr) <= 2e-5 * abs(lr)
-    assert rel_err(m.param("emb").read(), np.concatenate(o.emb)) < 5e-5
+        assert abs(l - lr) <= 1e-5 * abs(lr)
+    assert rel_err(m.param("emb").read(), np.concatenate(o.emb)) < 1e-5
     for nm, layers in (("bot", o.bot), ("top", o.top)):
         for l, (W, b) in enumerate(layers):
-            assert rel_err(m.param(nm + "_w", l).read(), W) < 5e-5, (nm, l)
-            assert rel_err(m.param(nm + "_b", l).read().reshape(-1), b) < 5e-5, (nm, l)
+            assert rel_err(m.param(nm + "_w", l).read(), W) < 1e-5, (nm, l)
+            assert rel_err(m.param(nm + "_b", l).read().reshape(-1), b) < 1e-5, (nm, l)
 
 
 @pytest.mark.parametrize("m_spa,beta2", [(4, 0.999), (128, 0.999), (32, 0.95)])

@@ -59,7 +59,9 @@ def test_golden_fixtures(fname):
         assert rel_err(opt.slot(tb), g["slot_b_acc"]) < TOL
     if optkind == "adam":
         assert rel_err(opt.slot(tV, 0), g["slot_V_m"]) < TOL
-        assert rel_err(opt.slot(tV, 1), g["slot_V_v"]) < 10 * TOL
+        # v accumulates (1 - beta_2) * g^2 with beta_2 held in fp32 like TF's apply op (the hyper-parameter is cast to the
+        # variable's dtype): 1 - fp32(0.999) = 1e-3 * (1 + 1.29e-5); the golden file was minted in fp64 with 1e-3 exactly
+        assert rel_err(opt.slot(tV, 1), g["slot_V_v"]) < TOL + 1.3e-5
 
 
 def _rand_case(seed, NU, NI, B, D, hot=True):
@@ -202,8 +204,8 @@ def test_ucml_censor_inside_multi_step_call(D):
     oo = orc.SGD(lr=0.01)
     for s in range(K):
         lr, _ = orc.ucml_step(U, V, b, uid[s], pid[s], nid[s], oo, margin=0.5, do_censor=True)
-        assert abs(loss[s] - lr) <= 2e-5 * abs(lr)
-    assert rel_err(tU.read(), U) < 2e-5 and rel_err(tV.read(), V) < 2e-5 and rel_err(tb.read(), b) < 2e-5
+        assert abs(loss[s] - lr) <= 1e-5 * abs(lr)
+    assert rel_err(tU.read(), U) < 1e-5 and rel_err(tV.read(), V) < 1e-5 and rel_err(tb.read(), b) < 1e-5
 
 
 @pytest.mark.parametrize("D,optname,fallback", [(64, "sgd", "0"), (128, "sgd", "0"), (16, "adagrad", "0"), (128, "adagrad", "0"),
@@ -229,5 +231,5 @@ def test_fused_censor_matches_censor_vec(D, optname, fallback, monkeypatch):
     loss, l2 = rt.pairwise_step("ucml", opt, tU, tV, tb, uid, pid, nid, K=K, B=B, margin=0.5, censor=True)
     for s in range(K):
         lr, l2r = orc.ucml_step(U, V, b, uid[s], pid[s], nid[s], oo, margin=0.5, do_censor=True)
-        assert abs(loss[s] - lr) <= 2e-5 * abs(lr) and abs(l2[s] - l2r) <= 2e-5 * abs(l2r)
-    assert rel_err(tU.read(), U) < 2e-5 and rel_err(tV.read(), V) < 2e-5 and rel_err(tb.read(), b) < 2e-5
+        assert abs(loss[s] - lr) <= 1e-5 * abs(lr) and abs(l2[s] - l2r) <= 1e-5 * abs(l2r)
+    assert rel_err(tU.read(), U) < 1e-5 and rel_err(tV.read(), V) < 1e-5 and rel_err(tb.read(), b) < 1e-5

@@ -3,7 +3,7 @@ scorer (Recommender.inference) against the oracle and the golden fixtures."""
 import numpy as np
 import pytest
 
-from conftest import golden_files, load_golden, parse_case, rel_err, OPT_KW
+from conftest import TOL_ADAM, golden_files, load_golden, parse_case, rel_err, OPT_KW
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -64,7 +64,7 @@ def test_random_batches_vs_oracle(model, optkind, D):
         else:
             lr, l2r = orc.wrmf_step(U, V, b, u, i, y, oo, a=1.5, b_w=0.7)
         assert abs(l[0] - lr) <= TOL * abs(lr) and abs(l2[0] - l2r) <= TOL * abs(l2r)
-    tol = TOL if optkind != "adam" else 5e-5      # Adam's m/(sqrt(v)+eps) amplifies rounding of tiny gradients
+    tol = TOL if optkind != "adam" else TOL_ADAM      # (conftest.TOL_ADAM)
     assert rel_err(tU.read(), U) < tol and rel_err(tV.read(), V) < tol and rel_err(tb.read(), b) < tol
     if model == "gmf":
         assert rel_err(tw.read(), w) < tol

@@ -3,7 +3,7 @@ orx_apply_rows) and of the whole sharded step at world size 1 against the oracle
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import TOL, TOL_ADAM, rel_err
 
 pytestmark = pytest.mark.gpu
 LR_ADAM = 0.002
@@ -44,7 +44,7 @@ def test_sharded_world1_matches_oracle(model, optk, D):
         tl += float(l); tl2 += float(l2)
     eng.check()
     loss, l2s = eng.loss_sums()
-    tol = 5e-5 if optk == "adam" else TOL           # (the fp32 oracle's own rounding enters m / (sqrt(v) + eps) amplified)
+    tol = TOL_ADAM if optk == "adam" else TOL       # (conftest.TOL_ADAM)
     assert abs(loss - tl) <= TOL * abs(tl) and abs(l2s - tl2) <= TOL * abs(tl2)
     assert rel_err(eng.U.read(), U) < tol and rel_err(eng.V.read(), V) < tol and rel_err(eng.b.read(), b) < tol
 
@@ -143,7 +143,7 @@ def test_virtual_cluster_matches_oracle(world, model, optk, fast):
     for r, e in enumerate(engs):
         assert int(e._ovf[0]) == 0 if e._ovf is not None else True
         assert not bool(e.overflow)
-        tol = 5e-5 if optk == "adam" else 2e-5
+        tol = TOL_ADAM if optk == "adam" else TOL
         assert rel_err(e.U.read()[:len(U[r::world])], U[r::world]) < tol
         assert rel_err(e.V.read()[:len(V[r::world])], V[r::world]) < tol
         assert rel_err(e.b.read()[:len(b[r::world])], b[r::world]) < tol

@@ -48,6 +48,7 @@ def test_device_metrics_match_oracle(D):
     got = rt.rank_metrics(pos, excl, at, kind="dot", user=tU, item=tV, bias=tb, uid=uid)
     assert np.allclose(got["auc"], ref["auc"], rtol=2e-4, atol=2e-4)       # scores differ in the last ulp -> rare rank ties
     assert np.allclose(got["recall"], ref["recall"], rtol=1e-3, atol=1e-3)
+    assert np.allclose(got["ndcg"], ref["ndcg"], rtol=1e-3, atol=1e-3)   # (ranking_metrics.py:31-52; same rare rank ties)
     dm = metrics.DictMean({"AUC": [], "Recall": [2]})
     dm.update_state({"AUC": got["auc"], "Recall": got["recall"]})
     r = dm.result()
