@@ -93,6 +93,12 @@ const char* orx_last_error(void);
 int orx_ctx_create(int device, void* stream, orx_ctx** out);
 int orx_ctx_destroy(orx_ctx* ctx);
 int orx_synchronize(orx_ctx* ctx);
+/* Ordering contract for device buffers handed over with ORX_IDS_DEVICE (ids, labels, gradient rows ...): the library
+ * reads them on the context's stream.  A buffer produced on ANOTHER stream (a framework's current stream) must be
+ * complete there first: orx_ctx_wait_stream makes every later call on `ctx` wait for the work `producer_stream`
+ * (a hipStream_t; NULL = the legacy default stream) holds now -- an event, no host synchronisation.  The reference
+ * has no such notion: TensorFlow orders its own ops (tf2_examples/bpr_citeulike.py:33-39 runs inside tf.function). */
+int orx_ctx_wait_stream(orx_ctx* ctx, void* producer_stream);
 /* raises the sticky "id out of range" condition recorded by the kernels
  * (returns ORX_ERR_INDEX once, then clears it).  Synchronizes. */
 int orx_check_index_error(orx_ctx* ctx);
@@ -128,10 +134,19 @@ int orx_opt_destroy(orx_opt* opt);
 int orx_opt_set_lr(orx_opt* opt, float lr);
 /* the optimizer's step counter (Keras `optimizer.iterations`: Adam's bias correction depends on it);
  * a checkpoint saves it next to the slots, a resume sets it before the next step.  The step entry points
- * advance it themselves; a host that drives Adam through orx_apply_rows advances it by one per step
- * (set_step(get_step + 1)) after the step's gathers and before its applies. */
+ * advance it themselves; a host that drives Adam through orx_apply_rows advances it by one per step with
+ * orx_opt_advance after the step's gathers and before its applies.
+ *   set_step : a jump of the counter (resume, Keras `iterations.assign`).  Every table that is lazily applied
+ *              under `opt` is first finished under the old counter; no row is replayed across the jump.
+ *   advance  : "the next apply_gradients of `opt` updates exactly these tables" (tf2_examples/bpr_citeulike.py:38 passes
+ *              the model's variables): counter += 1.  Keras' Adam touches only the variables it is handed, so any
+ *              OTHER table lazily applied under `opt` (a second model sharing the optimizer) is finished first and
+ *              takes no decay step for this one.  The step entry points (orx_pairwise_step, orx_pointwise_step,
+ *              orx_dlrm_step) do the same for their own tables.  n_tables < 0: the step is over every table the
+ *              optimizer holds (an engine with an optimizer of its own): the counter advances, nothing is finished. */
 int orx_opt_get_step(orx_opt* opt, int64_t* step_out);
 int orx_opt_set_step(orx_opt* opt, int64_t step);
+int orx_opt_advance(orx_opt* opt, orx_table* const* tables, int32_t n_tables);
 /* read/write an optimizer slot of a table (checkpointing, parity):
  * slot 0 = Adagrad accumulator / Adam m, slot 1 = Adam v. */
 int orx_opt_slot_read(orx_opt* opt, orx_table* t, int slot, int64_t row0, int64_t nrows, float* host_dst);
@@ -282,7 +297,7 @@ int orx_dlrm_dense_apply(orx_dlrm* m, orx_opt* opt, const float* flat);
  *   apply_rows  : optimizer sparse apply of per-occurrence gradient rows
  *                 (SGD: every occurrence accumulated; Adagrad / Adam: duplicates summed first;
  *                 Adam takes the step the optimizer's counter stands at: orx_dlrm_dense_apply
- *                 advances it once per step, otherwise the host does with orx_opt_set_step)
+ *                 advances it once per step, otherwise the host does with orx_opt_advance)
  */
 int orx_gather_rows(orx_ctx* ctx, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
                     float* out, int64_t out_stride);

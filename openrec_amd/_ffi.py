@@ -34,6 +34,7 @@ SIGNATURES = {
     "orx_ctx_create": (c_int, [c_int, _p, _pp]),
     "orx_ctx_destroy": (c_int, [_p]),
     "orx_synchronize": (c_int, [_p]),
+    "orx_ctx_wait_stream": (c_int, [_p, _p]),
     "orx_check_index_error": (c_int, [_p]),
     "orx_table_create": (c_int, [_p, c_int64, c_int32, _pp]),
     "orx_table_wrap": (c_int, [_p, _p, c_int64, c_int32, _pp]),
@@ -52,6 +53,7 @@ SIGNATURES = {
     "orx_opt_set_lr": (c_int, [_p, c_float]),
     "orx_opt_get_step": (c_int, [_p, POINTER(c_int64)]),
     "orx_opt_set_step": (c_int, [_p, c_int64]),
+    "orx_opt_advance": (c_int, [_p, _p, c_int32]),
     "orx_opt_slot_read": (c_int, [_p, _p, c_int, c_int64, c_int64, _fp]),
     "orx_opt_slot_write": (c_int, [_p, _p, c_int, c_int64, c_int64, _fp]),
     "orx_pairwise_step": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, _ip, _ip, c_int64, c_int64, c_int64,

@@ -104,6 +104,7 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipFree(c->d_wpart); hipFree(c->d_pl_cnt); hipFree(c->d_pl_cur); hipFree(c->d_pl_list);
     if (c->h_plan) hipHostFree(c->h_plan);
     if (c->plan_ev) hipEventDestroy(c->plan_ev);
+    if (c->wait_ev) hipEventDestroy(c->wait_ev);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return ORX_OK;
@@ -112,6 +113,16 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
 extern "C" int orx_synchronize(orx_ctx* c) {
     ORX_ARG(c, "orx_synchronize: NULL context");
     ORX_HIP(hipStreamSynchronize(c->stream));
+    return ORX_OK;
+}
+
+extern "C" int orx_ctx_wait_stream(orx_ctx* c, void* producer_stream) {
+    ORX_ARG(c, "orx_ctx_wait_stream: NULL context");
+    if ((hipStream_t)producer_stream == c->stream) return ORX_OK;
+    ORX_HIP(hipSetDevice(c->device));
+    if (!c->wait_ev) ORX_HIP(hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming));
+    ORX_HIP(hipEventRecord(c->wait_ev, (hipStream_t)producer_stream));
+    ORX_HIP(hipStreamWaitEvent(c->stream, c->wait_ev, 0));
     return ORX_OK;
 }
 
@@ -347,12 +358,39 @@ extern "C" int orx_opt_get_step(orx_opt* o, int64_t* step_out) {
     return ORX_OK;
 }
 
+// Keras' Adam updates only the variables handed to apply_gradients.  The lazily-applied form replays every increment of
+// the step counter as a gradient-free step of a lazy table's rows, so before the counter advances for a step over `keep`,
+// every OTHER table that is lazy under `o` (a second model sharing the optimizer) is brought up to date and leaves the
+// lazy set: it takes no decay for steps it is not part of (and re-enters, stamped with the then-current step, with its
+// own next step).
+int orx_opt_isolate(orx_opt* o, orx_table* const* keep, int n_keep) {
+    if (o->kind != ORX_ADAM) return ORX_OK;
+    for (auto& kv : o->slots) {
+        orx_table* t = kv.first;
+        if (t->lazy != o) continue;
+        bool kept = false;
+        for (int i = 0; i < n_keep; ++i) kept = kept || keep[i] == t;
+        if (!kept) CHECK(orx_table_sync(t));
+    }
+    return ORX_OK;
+}
+
 extern "C" int orx_opt_set_step(orx_opt* o, int64_t step) {
     ORX_ARG(o && step >= 0 && step < 0x7fffffff, "orx_opt_set_step: NULL optimizer or step out of range");
-    if (step != o->t + 1)                   // a jump (resume): rows pending under the old counter are finished under it;
-        for (auto& kv : o->slots)           // advancing by one is what every step does and leaves the stamps valid
-            if (kv.first->lazy == o) CHECK(orx_table_sync(kv.first));
+    // rows pending under the old counter are finished under it; nothing is replayed across the jump, so the cache of
+    // per-step rates (indexed by absolute step, filled with the rate in force when a step was taken) starts afresh
+    for (auto& kv : o->slots)
+        if (kv.first->lazy == o) CHECK(orx_table_sync(kv.first));
+    if (step != o->t) { o->h_lrt.clear(); o->lrt_uploaded = 0; }
     o->t = step;
+    return ORX_OK;
+}
+
+extern "C" int orx_opt_advance(orx_opt* o, orx_table* const* tables, int32_t n_tables) {
+    ORX_ARG(o && (n_tables <= 0 || tables), "orx_opt_advance: NULL optimizer or table list");
+    ORX_ARG(o->t + 1 < 0x7fffffff, "orx_opt_advance: step counter overflow");
+    if (n_tables >= 0) CHECK(orx_opt_isolate(o, tables, n_tables));      // (< 0: the step is over every table the optimizer holds)
+    o->t += 1;
     return ORX_OK;
 }
 
@@ -705,6 +743,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     // or not at all: anything else first brings every row up to date
     const bool lazy_resume = lazy_adam && U->lazy == opt && V->lazy == opt && b->lazy == opt;
     if (!lazy_resume) for (orx_table* t : {U, V, b}) CHECK(orx_table_sync(t));
+    { orx_table* mine[3] = {U, V, b}; CHECK(orx_opt_isolate(opt, mine, 3)); }      // (a shared optimizer: see orx_opt_isolate)
     // rows referenced exactly twice get plain stores into two scratch rows; the role of a reference
     // travels in bits 30:29 of its id, which needs tables below 2^29 rows
     // ORX_FORCE_FALLBACK (debug / tests): bit 0 = behave as if the tables had >= 2^28 rows (no role bits: every

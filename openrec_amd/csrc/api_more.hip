@@ -67,6 +67,7 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     const int mode = (opt->kind == ORX_ADAM && !lazy_adam) ? MODE_ACCUM : (hogwild ? MODE_HOGWILD : MODE_EXACT);
     const bool lazy_resume = lazy_adam && U->lazy == opt && V->lazy == opt && b->lazy == opt;
     if (!lazy_resume) for (orx_table* t : {U, V, b}) CHECK(orx_table_sync(t));
+    { orx_table* mine[3] = {U, V, b}; CHECK(orx_opt_isolate(opt, mine, 3)); }      // (a shared optimizer: api.hip orx_opt_isolate)
     if (w) CHECK(orx_table_sync(w));
     CHECK(orx_table_scratch(U)); CHECK(orx_table_scratch(V)); CHECK(orx_table_scratch(b));
     if (w) CHECK(orx_table_scratch(w));

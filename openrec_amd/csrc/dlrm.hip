@@ -436,6 +436,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
     RowsPlan rp;
     const int32_t* sparse_dev = sparse;
     const bool lazy_adam = m->emb != nullptr && orx_adam_rows_lazy(opt, m->emb);
+    { orx_table* mine[1] = {m->emb}; CHECK(orx_opt_isolate(opt, mine, m->emb ? 1 : 0)); }   // (a shared optimizer: api.hip orx_opt_isolate)
     ColWindows cw;
     if (getenv("ORX_DLRM_NO_COLWIN") == nullptr) { cw.F = F; cw.win = m->d_colwin; }
     if (planned) {

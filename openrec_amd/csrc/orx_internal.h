@@ -61,6 +61,7 @@ struct orx_ctx {
     int* h_plan = nullptr;                                       // pinned host mirror of the per-step plan counters
     size_t h_plan_cap = 0;
     hipEvent_t plan_ev = nullptr;                                // "plan counters have arrived on the host"
+    hipEvent_t wait_ev = nullptr;                                // orx_ctx_wait_stream
     int epoch = 0;                                               // step epoch: tags ready flags and censor side marks
     int epoch_gen = 0;                                           // bumped when `epoch` wraps (tables then clear their tags)
     // staging plan of rows referenced >= 3 times in a step (see kernels_pairwise.hip, "staging")
@@ -121,6 +122,7 @@ struct orx_opt {
 // (sqrt(v)+eps), every step) is replayed exactly when the row is next needed.  orx_table_sync brings every row of a
 // table up to the optimizer's current step; every entry point that reads or writes a table calls it first.
 int orx_table_sync(orx_table* t);
+int orx_opt_isolate(orx_opt* o, orx_table* const* keep, int n_keep);   // finish every OTHER table that is lazy under `o`
 int orx_opt_last(orx_opt* o, orx_table* t, bool restamp, int** out, int64_t stamp = -1);            // allocate / fetch the per-row step stamps
 int orx_launch_fill_int(orx_ctx* ctx, int* p, int64_t n, int v);
 int orx_adam_lrt(orx_opt* o, int64_t upto);                      // make lr_t of steps 1..upto available on the device

@@ -52,6 +52,18 @@ class Context:
     def synchronize(self):
         check(self._lib.orx_synchronize(self._h))
 
+    def wait_stream(self, stream_handle):
+        """later calls on this context wait for the work `stream_handle` (a hipStream_t as int; 0 = default stream) holds now"""
+        check(self._lib.orx_ctx_wait_stream(self._h, c_void_p(int(stream_handle)) if stream_handle else None))
+
+    def after_torch(self, *tensors):
+        """device tensors produced by torch ops are read by the library on ITS stream: order it behind torch's current one"""
+        for t in tensors:
+            if _is_device_tensor(t):
+                import torch
+                self.wait_stream(torch.cuda.current_stream(t.device).cuda_stream)
+                return
+
     def check_index_error(self):
         check(self._lib.orx_check_index_error(self._h))
 
@@ -189,6 +201,17 @@ class Optimizer:
     def step(self, value):
         check(self._lib.orx_opt_set_step(self._h, int(value)))
 
+    def advance(self, tables=None):
+        """One optimizer step begins (Keras `iterations` += 1) for a host that applies gradients through `apply_rows`.
+        `tables`: the tables this step updates -- any other table lazily applied under this optimizer is finished first
+        and takes no Adam decay for the step (Keras updates only the variables handed to apply_gradients); None: the
+        optimizer's own tables, all of them."""
+        if tables is None:
+            check(self._lib.orx_opt_advance(self._h, None, -1))
+        else:
+            arr = (c_void_p * len(tables))(*[t._h for t in tables])
+            check(self._lib.orx_opt_advance(self._h, ctypes.cast(arr, c_void_p), len(tables)))
+
     def slot(self, table, slot=0):
         out = np.empty((table.rows, table.dim), np.float32)
         check(self._lib.orx_opt_slot_read(self._h, table._h, slot, 0, table.rows, out.ctypes.data))
@@ -209,6 +232,7 @@ def pairwise_step(model, opt, user, item, bias, uid, pid, nid, K=1, B=None, id_s
     pn, nn, dn, k2 = _ids_arg(nid)
     assert du == dp == dn, "ids must be all host or all device"
     assert nu == npn == nn, "id arrays differ in length"
+    user.ctx.after_torch(uid, pid, nid)
     if B is None:
         B = nu // K
     if id_stride is None:
@@ -269,6 +293,7 @@ def pointwise_step(model, opt, user, item, bias, w, uid, iid, label, K=1, B=None
     pi, ni, di, k1 = _ids_arg(iid)
     pl, nl, dl, k2 = _label_arg(label)
     assert du == di == dl and nu == ni == nl
+    user.ctx.after_torch(uid, iid, label)
     if B is None:
         B = nu // K
     if id_stride is None:
@@ -331,6 +356,7 @@ class DLRMModel:
         lib = self._lib = self.ctx._lib
         self.m_spa, self.ln_emb, self.ln_bot, self.ln_top = int(m_spa), [int(x) for x in ln_emb], list(ln_bot), list(ln_top)
         self.dense_dim = int(dense_dim)
+        self.loss_func = loss_func
         flags = ((_ffi.ORX_DLRM_INTERACT_ITSELF if arch_interaction_itself else 0)
                  | (_ffi.ORX_DLRM_SIGMOID_BOT if sigmoid_bot else 0) | (_ffi.ORX_DLRM_SIGMOID_TOP if sigmoid_top else 0)
                  | (_ffi.ORX_DLRM_LOSS_BCE if loss_func == "bce" else 0)

@@ -91,7 +91,7 @@ class HipBackend:
     def begin_step(self):
         """after the step's gathers, before its applies: Keras `iterations` += 1 (Adam's lr_t and the lazy replay)"""
         if self.opt_kind == "adam":
-            self.opt.step = self.opt.step + 1
+            self.opt.advance()           # (the engine's optimizer holds only the engine's tables)
 
     def make_table(self, rows, dim, seed):
         return self.rt.Table(max(rows, 1), dim, self.ctx).init_uniform(seed=seed)

@@ -75,7 +75,12 @@ class _Optimizer:
 
     @property
     def iterations(self):
-        """Keras `optimizer.iterations`: steps applied so far (the queued ones included)"""
+        """Keras `optimizer.iterations`: steps applied so far (the queued ones included).  An Adam optimizer keeps the
+        counter natively (it is part of a checkpoint, runtime.load_checkpoint restores it): the queues run, then the
+        native counter answers."""
+        if self._native is not None and self._native.kind == "adam":
+            self._flush_models()
+            return self._native.step
         return self._iterations
 
     def apply_gradients(self, grads_and_vars):

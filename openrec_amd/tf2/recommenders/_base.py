@@ -123,7 +123,9 @@ class Recommender:
         return (self.user_latent_factor.variables + self.item_latent_factor.variables
                 + self.item_bias.variables)
 
-    variables = trainable_variables
+    @property
+    def variables(self):           # (every variable of these models is trainable; a subclass that adds some is followed)
+        return self.trainable_variables
 
     def _tables(self, flush=True):
         if flush:

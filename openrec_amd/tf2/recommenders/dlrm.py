@@ -62,9 +62,12 @@ class DLRM:
 
         def run_forward():
             self.flush()
-            p = m.inference(d, s)
+            p = m.inference(d, s).astype(np.float32)           # (already clipped to the loss threshold, dlrm.py:97-98)
             yy = y.astype(np.float32).reshape(-1)
-            return (float(np.mean((yy - p) ** 2)), 0.0)        # only used outside a tape (mse); see inference
+            if m.loss_func == "bce":                            # keras BinaryCrossentropy on probabilities (dlrm.py:54-55, :72-73)
+                pc = np.clip(p, np.float32(1e-7), np.float32(1.0 - 1e-7))
+                return (float(np.mean(-(yy * np.log(pc) + (1.0 - yy) * np.log(1.0 - pc)))), 0.0)
+            return (float(np.mean((yy - p) ** 2)), 0.0)        # keras MeanSquaredError (dlrm.py:52-53)
 
         def run_train(optimizer, no_l2):
             def runner(bufs, K):

@@ -307,22 +307,24 @@ class AdamTFSparse:
 # --------------------------------------------------------------------------
 # whole train steps  (tf2_examples/bpr_citeulike.py:33-39)
 # --------------------------------------------------------------------------
-def _pair_apply(opt, U, V, b, uid, pid, nid, gr):
+def _pair_apply(opt, U, V, b, uid, pid, nid, gr, keys=("U", "V", "b")):
+    # `keys` name the optimizer's slot variables: one optimizer shared by several models (apply_gradients only touches
+    # the variables it is handed, tf2_examples/bpr_citeulike.py:38) keeps one (m, v) pair per VARIABLE
     if hasattr(opt, "begin_step"):
         opt.begin_step()
-    opt.apply(U, uid, gr["gu"], key="U")
+    opt.apply(U, uid, gr["gu"], key=keys[0])
     # item IndexedSlices = concat of the two lookups of the same variable
-    opt.apply(V, np.concatenate([pid, nid]), np.concatenate([gr["gp"], gr["gn"]]), key="V")
+    opt.apply(V, np.concatenate([pid, nid]), np.concatenate([gr["gp"], gr["gn"]]), key=keys[1])
     opt.apply(b, np.concatenate([pid, nid]),
-              np.concatenate([gr["gbp"], gr["gbn"]])[:, None], key="b")
+              np.concatenate([gr["gbp"], gr["gbn"]])[:, None], key=keys[2])
 
 
-def bpr_step(U, V, b, uid, pid, nid, opt):
+def bpr_step(U, V, b, uid, pid, nid, opt, keys=("U", "V", "b")):
     """One ``train_step``: forward on pre-step tables, gradients of
     loss + l2_loss, optimizer sparse apply.  Returns (loss, l2_loss)."""
     loss, l2, _ = bpr_forward(U, V, b, uid, pid, nid)
     gr = bpr_grads(U, V, b, uid, pid, nid)
-    _pair_apply(opt, U, V, b, uid, pid, nid, gr)
+    _pair_apply(opt, U, V, b, uid, pid, nid, gr, keys)
     return loss, l2
 
 

@@ -22,7 +22,7 @@ for rows, D, n, K, use_gather in ((40000, 4, 600, 15, False), (40000, 128, 600, 
             m = ids_all[s] >= 0
             ge = np.abs(out.cpu().numpy()[m] - W[ids_all[s][m]]).max() / 0.05
             if ge > 1e-5: print("  gather err at step", s, ge)
-        opt.step = opt.step + 1
+        opt.advance([t])
         _ffi.check(lib.orx_apply_rows(ctx._h, opt._h, t._h, None, ids.data_ptr(), n, g.data_ptr(), D))
         ctx.synchronize()
         m = ids_all[s] >= 0

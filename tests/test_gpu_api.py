@@ -185,8 +185,8 @@ def test_wrapped_torch_tensors_are_updated_in_place(optk):
     U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
     b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
     tU, tV, tb = (torch.from_numpy(x.copy()).to(dev) for x in (U, V, b))
-    torch.cuda.synchronize()                     # the tensors are in place before the library's stream touches them
     ctx = rt.default_context()
+    ctx.wait_stream(torch.cuda.current_stream(dev).cuda_stream)     # orx_ctx_wait_stream: the library's stream runs behind the copies
     wU = rt.Table(NU, D, ctx, device_ptr=tU.data_ptr(), keepalive=tU); wV = rt.Table(NI, D, ctx, device_ptr=tV.data_ptr(), keepalive=tV)
     wb = rt.Table(NI, 1, ctx, device_ptr=tb.data_ptr(), keepalive=tb)
     opt = rt.Optimizer.sgd(0.05, ctx=ctx) if optk == "sgd" else rt.Optimizer.adam(0.002, ctx=ctx)

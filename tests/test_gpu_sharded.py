@@ -177,7 +177,7 @@ def test_gather_apply_rows_adam_is_the_dense_decay_rule(rows, D, n, K):
         _ffi.check(lib.orx_gather_rows(ctx._h, t._h, None, ids.data_ptr(), n, out.data_ptr(), D))
         ctx.synchronize()
         assert np.abs(out.cpu().numpy()[live] - W[ids_all[s][live]]).max() <= 2e-5 * 0.05, s
-        opt.step = opt.step + 1
+        opt.advance([t])
         _ffi.check(lib.orx_apply_rows(ctx._h, opt._h, t._h, None, ids.data_ptr(), n, g.data_ptr(), D))
         ctx.synchronize()
         oo.begin_step(); oo.apply(W, ids_all[s][live], g_all[s][live].astype(np.float64), key="W")

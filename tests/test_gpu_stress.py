@@ -217,3 +217,40 @@ def test_lazy_adam_long_gaps_in_the_fused_step(monkeypatch):
         assert (em > 1e-4).mean() <= 1e-2 and em.max() < 2e-2, (form, float(em.max()))
     for x, y in zip(got["longgap"][1:4], got["plain"][1:4]):
         assert np.abs(x - y).max() <= 1e-4 * np.abs(y).max()      # (v_rcp in the bounded loop, carried reciprocal in the merged one)
+
+
+@pytest.mark.parametrize("form", ["lazy", "dense"])
+def test_shared_adam_optimizer_updates_only_the_tables_of_a_step(form, monkeypatch):
+    """ONE Adam optimizer driving several models (Keras: apply_gradients touches only the variables it is handed, the
+    step counter `iterations` is shared).  Model A = (UA, VA, bA), model B = (UB, VB, bB), model C = (UA, VC, bC) shares
+    A's user table.  The lazily-applied rule must not replay another model's steps as decay steps of this model's rows
+    (advisor finding, round 1): both forms against the fp64 oracle with one shared AdamTFSparse."""
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    from conftest import TOL_ADAM
+    if form == "dense":
+        monkeypatch.setenv("ORX_ADAM_DENSE", "1")
+    D, B = 64, 512
+    rng = np.random.default_rng(21)
+    sizes = dict(UA=700, VA=900, UB=300, VB=400, VC=500)
+    host = {k: rng.uniform(-.05, .05, (n, D)).astype(np.float32) for k, n in sizes.items()}
+    host.update(bA=rng.uniform(-.05, .05, (900, 1)).astype(np.float32), bB=rng.uniform(-.05, .05, (400, 1)).astype(np.float32),
+                bC=rng.uniform(-.05, .05, (500, 1)).astype(np.float32))
+    dev = {k: rt.Table(*v.shape).write(v) for k, v in host.items()}
+    ref = {k: v.astype(np.float64) for k, v in host.items()}
+    models = dict(A=("UA", "VA", "bA"), B=("UB", "VB", "bB"), C=("UA", "VC", "bC"))
+    opt = rt.Optimizer.adam(0.002)
+    oo = orc.AdamTFSparse(0.002)
+    for name, K in (("A", 3), ("B", 2), ("A", 2), ("C", 3), ("B", 1), ("A", 1), ("C", 1)):
+        u, v, b = models[name]
+        uid = rng.integers(0, sizes[u], (K, B)).astype(np.int32); pid = rng.integers(0, sizes[v], (K, B)).astype(np.int32)
+        nid = rng.integers(0, sizes[v], (K, B)).astype(np.int32)
+        loss, _ = rt.pairwise_step("bpr", opt, dev[u], dev[v], dev[b], uid, pid, nid, K=K, B=B)
+        for s in range(K):
+            lr, _ = orc.bpr_step(ref[u], ref[v], ref[b], uid[s], pid[s], nid[s], oo, keys=(u, v, b))
+            assert abs(loss[s] - lr) <= 1e-5 * abs(lr), (name, s)
+    assert opt.step == 13
+    for k in host:
+        assert np.abs(dev[k].read() - ref[k]).max() <= TOL_ADAM * np.abs(ref[k]).max(), k
+    for k in ("UA", "VA", "VB", "VC"):
+        assert np.abs(opt.slot(dev[k], 0) - oo.m[k]).max() <= 1e-5 * np.abs(oo.m[k]).max(), k
