@@ -131,6 +131,17 @@ class Adam(_Optimizer):
         return rt.Optimizer.adam(self.learning_rate, self.beta_1, self.beta_2, self.epsilon, ctx=ctx)
 
 
+class HostTensor(np.ndarray):
+    """What the metric objects hand back: an ndarray that also answers `.numpy()`, as the reference scripts print
+    `average_loss.result().numpy()` / `result['AUC'].numpy()` (tf2_examples/bpr_citeulike.py:64-65)."""
+
+    def __new__(cls, value, dtype=np.float32):
+        return np.asarray(value, dtype=dtype).view(cls)
+
+    def numpy(self):
+        return np.asarray(self)
+
+
 class Mean:
     """tf.keras.metrics.Mean; `update_state((loss, l2))` averages the two scalars
     together, like the reference script does (bpr_citeulike.py:54)."""
@@ -159,21 +170,111 @@ class Mean:
 
     def result(self):
         self._drain()
-        return np.float32(self._sum / max(self._n, 1))
+        return HostTensor(self._sum / max(self._n, 1))
 
     def reset_states(self):
         self._sum, self._n, self._pending = 0.0, 0, []
 
 
+class AUC:
+    """tf.keras.metrics.AUC() with its defaults (200 thresholds, ROC, 'interpolation' = trapezoids), the validation metric of
+    tf2_examples/dlrm_criteo.py:40, :50-53, :67.  Evaluation side of the script, host arithmetic."""
+
+    def __init__(self, num_thresholds=200):
+        n = int(num_thresholds)
+        eps = 1e-7                                                   # keras: first / last threshold just outside [0, 1]
+        self._thr = np.array([0.0 - eps] + [(i + 1) / (n - 1) for i in range(n - 2)] + [1.0 + eps])
+        self.reset_states()
+
+    def reset_states(self):
+        self._tp = np.zeros(len(self._thr)); self._fp = np.zeros(len(self._thr))
+        self._tn = np.zeros(len(self._thr)); self._fn = np.zeros(len(self._thr))
+
+    def update_state(self, y_true, y_pred, sample_weight=None):
+        y = np.asarray(y_true.numpy() if hasattr(y_true, "numpy") else y_true).reshape(-1) > 0
+        p = np.asarray(y_pred.numpy() if hasattr(y_pred, "numpy") else y_pred, np.float64).reshape(-1)
+        ps, ns = np.sort(p[y]), np.sort(p[~y])
+        above_p = len(ps) - np.searchsorted(ps, self._thr, side="right")       # predictions > threshold
+        above_n = len(ns) - np.searchsorted(ns, self._thr, side="right")
+        self._tp += above_p; self._fn += len(ps) - above_p
+        self._fp += above_n; self._tn += len(ns) - above_n
+
+    def result(self):
+        tpr = self._tp / np.maximum(self._tp + self._fn, 1e-7)
+        fpr = self._fp / np.maximum(self._fp + self._tn, 1e-7)
+        return HostTensor(np.sum((fpr[:-1] - fpr[1:]) * (tpr[:-1] + tpr[1:]) / 2.0))
+
+
+class TensorSliceDataset:
+    """tensorflow.data.Dataset as tf2_examples/dlrm_criteo.py:18-29 uses it: from_tensor_slices(dict) .batch .prefetch
+    .shuffle, iterated once per epoch.  `shuffle(k)` after `batch` shuffles BATCHES through a k-element buffer, reshuffled
+    at every iteration (TF's reshuffle_each_iteration default)."""
+
+    def __init__(self, arrays, batch=None, shuffle=None, seed=None):
+        self._arrays, self._batch, self._shuffle = arrays, batch, shuffle
+        self._rng = np.random.default_rng(seed)
+
+    @classmethod
+    def from_tensor_slices(cls, tensors):
+        arrays = {k: np.asarray(v.numpy() if hasattr(v, "numpy") else v) for k, v in dict(tensors).items()}
+        n = {len(v) for v in arrays.values()}
+        if len(n) != 1:
+            raise ValueError("from_tensor_slices: components differ in their first dimension")
+        return cls(arrays)
+
+    def batch(self, batch_size, drop_remainder=False):
+        d = TensorSliceDataset(self._arrays, int(batch_size), self._shuffle)
+        d._drop = drop_remainder
+        return d
+
+    def prefetch(self, _buffer_size):
+        return self
+
+    def shuffle(self, buffer_size, seed=None, reshuffle_each_iteration=True):
+        d = TensorSliceDataset(self._arrays, self._batch, int(buffer_size), seed)
+        d._drop = getattr(self, "_drop", False)
+        return d
+
+    def _elements(self):
+        n = len(next(iter(self._arrays.values())))
+        if self._batch is None:
+            for i in range(n):
+                yield {k: v[i] for k, v in self._arrays.items()}
+            return
+        for lo in range(0, n, self._batch):
+            if lo + self._batch > n and getattr(self, "_drop", False):
+                return
+            yield {k: v[lo:lo + self._batch] for k, v in self._arrays.items()}
+
+    def __iter__(self):
+        if not self._shuffle:
+            yield from self._elements()
+            return
+        buf = []
+        for e in self._elements():                      # TF's shuffle: fill the buffer, then emit a random slot per new element
+            if len(buf) < self._shuffle:
+                buf.append(e)
+                continue
+            j = int(self._rng.integers(len(buf)))
+            out, buf[j] = buf[j], e
+            yield out
+        while buf:
+            yield buf.pop(int(self._rng.integers(len(buf))))
+
+
 optimizers = types.SimpleNamespace(SGD=SGD, Adagrad=Adagrad, Adam=Adam)
-keras = types.SimpleNamespace(optimizers=optimizers, metrics=types.SimpleNamespace(Mean=Mean))
-tf = types.SimpleNamespace(function=function, GradientTape=GradientTape, constant=constant, keras=keras,
+keras = types.SimpleNamespace(optimizers=optimizers, metrics=types.SimpleNamespace(Mean=Mean, AUC=AUC))
+data = types.SimpleNamespace(Dataset=TensorSliceDataset)
+tf = types.SimpleNamespace(function=function, GradientTape=GradientTape, constant=constant, keras=keras, data=data,
                            int32=int32, float32=float32, bool=bool_)
 
 
 def install():
-    """Make `import tensorflow as tf` / `from tensorflow.keras import optimizers`
-    resolve to this shim when (and only when) TensorFlow is absent."""
+    """Make `import tensorflow as tf` / `from tensorflow.keras import optimizers` / `from tensorflow.data import Dataset`
+    resolve to this shim when (and only when) TensorFlow is absent, and `openrec.tf2.{data, recommenders, metrics, modules}`
+    to this package when the reference package is absent -- what an unmodified tf2_examples script imports
+    (tf2_examples/bpr_citeulike.py:1-7, dlrm_criteo.py:1-5).  Returns True if the TensorFlow shim was installed."""
+    install_openrec_alias()
     try:
         import tensorflow  # noqa: F401
         return False
@@ -186,8 +287,39 @@ def install():
     kmod.optimizers, kmod.metrics = optimizers, keras.metrics
     omod = types.ModuleType("tensorflow.keras.optimizers")
     omod.SGD, omod.Adagrad, omod.Adam = SGD, Adagrad, Adam
-    mod.keras = kmod
+    mmod = types.ModuleType("tensorflow.keras.metrics")
+    mmod.Mean, mmod.AUC = Mean, AUC
+    dmod = types.ModuleType("tensorflow.data")
+    dmod.Dataset = TensorSliceDataset
+    mod.keras, mod.data = kmod, dmod
     sys.modules["tensorflow"] = mod
     sys.modules["tensorflow.keras"] = kmod
     sys.modules["tensorflow.keras.optimizers"] = omod
+    sys.modules["tensorflow.keras.metrics"] = mmod
+    sys.modules["tensorflow.data"] = dmod
+    return True
+
+
+def install_openrec_alias():
+    """`openrec.tf2.*` -> `openrec_amd.tf2.*` (same class names and signatures), unless a real
+    `openrec` package is importable."""
+    import importlib
+    import importlib.util
+    if "openrec" in sys.modules and getattr(sys.modules["openrec"], "__openrec_amd_alias__", False):
+        return True
+    try:
+        if importlib.util.find_spec("openrec") is not None:
+            return False
+    except (ImportError, ValueError):
+        pass
+    top = types.ModuleType("openrec")
+    top.__openrec_amd_alias__ = True
+    top.__path__ = []
+    tf2 = importlib.import_module("openrec_amd.tf2")
+    sys.modules["openrec"] = top
+    sys.modules["openrec.tf2"] = tf2
+    top.tf2 = tf2
+    for sub in ("data", "recommenders", "metrics", "modules"):
+        m = importlib.import_module("openrec_amd.tf2." + sub)
+        sys.modules["openrec.tf2." + sub] = m
     return True

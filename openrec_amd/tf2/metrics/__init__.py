@@ -43,4 +43,5 @@ class DictMean:
             self._count[k] += float(v.shape[0])
 
     def result(self):
-        return {k: self._sum[k] / np.float32(self._count[k]) for k in self._sum}
+        from ..compat import HostTensor          # (`.numpy()` on every entry, as bpr_citeulike.py:64-65 prints them)
+        return {k: HostTensor(self._sum[k] / np.float32(self._count[k])) for k in self._sum}
