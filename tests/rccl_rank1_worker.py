@@ -1,0 +1,101 @@
+"""Worker of tests/test_gpu_rccl_rank1.py, launched as ONE rank by torch.distributed.run with backend "nccl" (= RCCL):
+the row-sharded pairwise engine (K-step planned path and the per-step path) and the hybrid-parallel DLRM step, every
+exchange forced through torch.distributed (`force_collectives`), against the NumPy oracles.  What this holds that the
+in-process virtual cluster cannot: the library's private stream and RCCL's collectives order correctly through the
+engine's torch stream, on the real backend the 8-GPU bench uses."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def rel_err(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from openrec_amd import sharded
+    from openrec_amd.sharded_dlrm import ShardedDLRM
+    from oracle import numpy_oracle as orc
+    from oracle.dlrm_oracle import DLRMOracle
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert world == 1
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group("nccl", device_id=dev)
+    assert dist.get_backend() == "nccl"
+
+    # ---- row-sharded BPR / UCML: 6 steps through the planned K-step path, 2 through the per-step path
+    for model, optk, D in (("bpr", "sgd", 64), ("bpr", "adagrad", 64), ("ucml", "sgd", 128), ("bpr", "adam", 64)):
+        rng = np.random.default_rng(5)
+        NU, NI, B, K = 3000, 4000, 4096, 8
+        U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+        b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+        uid = rng.integers(0, NU, (K, B)).astype(np.int32); pid = rng.integers(0, NI, (K, B)).astype(np.int32)
+        nid = rng.integers(0, NI, (K, B)).astype(np.int32)
+        uid[:, :9] = 3
+        lr = 0.002 if optk == "adam" else 0.05
+        eng = sharded.ShardedPairwise(model, optk, NU, NI, D, lr=lr, rank=0, world=1, device=dev, slack=1.0)
+        eng.force_collectives = True
+        eng.U.write(U); eng.V.write(V); eng.b.write(b)
+        tu, tp, tn = (torch.from_numpy(x).to(dev) for x in (uid, pid, nid))
+        torch.cuda.synchronize()
+        eng.steps(tu[:6], tp[:6], tn[:6], plan_chunk=4)
+        for s in (6, 7):
+            eng.step(tu[s], tp[s], tn[s])
+        eng.check()
+        oo = {"sgd": lambda: orc.SGD(lr), "adagrad": lambda: orc.Adagrad(lr, 0.1, 1e-7), "adam": lambda: orc.AdamTFSparse(lr)}[optk]()
+        tl = 0.0
+        for s in range(K):
+            step = orc.bpr_step if model == "bpr" else (lambda *a: orc.ucml_step(*a, do_censor=False))
+            tl += float(step(U, V, b, uid[s], pid[s], nid[s], oo)[0])
+        loss, _ = eng.loss_sums()
+        tol = 5e-5 if optk == "adam" else 1e-5          # (tests/conftest.py: TOL_ADAM, TOL)
+        assert abs(loss - tl) <= 1e-5 * abs(tl), (model, optk, loss, tl)
+        for got, want, nm in ((eng.U.read(), U, "U"), (eng.V.read(), V, "V"), (eng.b.read(), b, "b")):
+            assert rel_err(got, want) < tol, (model, optk, nm, rel_err(got, want))
+        print(f"rccl-rank1 pairwise {model} {optk} D={D}: ok", flush=True)
+
+    # ---- hybrid-parallel DLRM: embedding rows through all-to-all, dense gradients through all-reduce
+    CFG = dict(m_spa=16, ln_emb=[1000, 37, 5000, 3, 250], ln_bot=[64, 16], ln_top=[128, 64, 1], dense_dim=13)
+    for optk, loss_func in (("sgd", "bce"), ("adam", "mse")):
+        kw = dict(reference_compat=False, loss_func=loss_func)
+        ref = DLRMOracle(seed=5, **dict(CFG, **kw))
+        e = ShardedDLRM(rank=0, world=1, device=dev, opt=optk, lr=0.05, slack=2.0, seed=5, **CFG, **kw)
+        e.force_collectives = True
+        e.load_embeddings(np.concatenate(ref.emb))
+        for name, layers in (("bot", ref.bot), ("top", ref.top)):
+            for l, (W, bb) in enumerate(layers):
+                e.be.dense_param(name + "_w", l).write(W); e.be.dense_param(name + "_b", l).write(bb.reshape(1, -1))
+        rng = np.random.default_rng(3)
+        oo = {"sgd": lambda: orc.SGD(0.05), "adam": lambda: orc.AdamTFSparse(0.05)}[optk]()
+        total = 0.0
+        for s in range(3):
+            dense = rng.normal(size=(512, 13)).astype(np.float32)
+            sparse = np.stack([rng.integers(0, n, 512) for n in CFG["ln_emb"]], 1).astype(np.int32)
+            label = (rng.random(512) < 0.3).astype(np.float32)
+            e.step(torch.from_numpy(dense).to(dev), torch.from_numpy(sparse).to(dev), torch.from_numpy(label).to(dev))
+            total += float(ref.step(dense, sparse, label, oo))
+        e.check()
+        tol = 5e-5 if optk == "adam" else 1e-5
+        assert rel_err(e.local_embeddings(), np.concatenate(ref.emb)) < tol, optk
+        for name, layers in (("bot", ref.bot), ("top", ref.top)):
+            for l, (W, bb) in enumerate(layers):
+                assert rel_err(e.be.dense_param(name + "_w", l).read(), W) < tol, (optk, name, l)
+        assert abs(float(e.loss_accum.item()) - total) < 1e-5 * abs(total)
+        print(f"rccl-rank1 dlrm {optk} {loss_func}: ok", flush=True)
+
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RCCL_RANK1_OK", flush=True)
+
+
+if __name__ == "__main__":
+    main()
