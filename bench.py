@@ -297,7 +297,7 @@ def main():
         bpt = alg_bytes_per_triplet(args.dim, args.opt, args.model)
         unit = "samples/s" if args.model in ("gmf", "wrmf") else "triplets/s"
         out = {
-            "metric": "BPR training triplets/sec at dim=64, 1Mx1M table" if (args.model, args.dim) == ("bpr", 64)
+            "metric": "BPR training triplets/sec at dim=64, 1Mx1M table" if (args.model, args.dim, args.users, args.items) == ("bpr", 64, 1_000_000, 1_000_000)
                       else f"{args.model.upper()} training {unit[:-2]}/sec at dim={args.dim}",
             "value": total / dt, "unit": unit, "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -559,9 +559,7 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
         ENSURE(c->d_ids2, c->d_ids2_cap, (size_t)chunk * 3 * Bp * sizeof(int32_t));
         if (v2) {
             // bucketed plan (kernels_plan.hip): bucket counters, lists of up to 3 B references per step, per-range bitmaps
-            const int shift = orx_plan_shift(U->rows, V->rows);
-            const int nb2 = orx_plan_ranges(U->rows, shift) + orx_plan_ranges(V->rows, shift);
-            CHECK(orx_plan_buffers(c, chunk, 3 * B, nb2, shift, inline_apply));
+            CHECK(orx_plan_buffers(c, chunk, 3 * B, U->rows, V->rows, inline_apply));
             if (c->h_plan_cap < (size_t)chunk * 9 * sizeof(int)) {
                 if (c->h_plan) ORX_HIP(hipHostFree(c->h_plan));
                 c->h_plan = nullptr; c->h_plan_cap = 0;

@@ -330,24 +330,33 @@ __global__ __launch_bounds__(PL_THREADS) void plan_urgent_kernel(PlanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ host side ---
-int orx_plan_shift(int64_t NU, int64_t NI) {
-    static const char* env = getenv("ORX_PLAN_SHIFT");      // experiments: rows per range = 1 << value (14 .. 16)
-    int shift = env ? atoi(env) : 14;
-    if (shift < 10) shift = 10;
-    if (shift > 16) shift = 16;
+// rows per range = 1 << shift: 16 384 rows up to 64 ranges per table, then as many ranges as give a workgroup ~1 k
+// references (a range with a handful of references costs a workgroup's fixed work: 10 M x 50 M tables at 16 384 rows per
+// range are 3663 workgroups per step, 16 us; at 131 072 rows 459 and 5 us)
+int orx_plan_shift(int64_t NU, int64_t NI, int64_t nref) {
+    static const char* env = getenv("ORX_PLAN_SHIFT");      // experiments: rows per range = 1 << value
     const int64_t rows = NU > NI ? NU : NI;
-    while (shift < 20 && ((rows + (1LL << shift) - 1) >> shift) > 4096) ++shift;
+    const int cap = rows > (1LL << 27) ? 18 : 17;
+    if (env) { const int v = atoi(env); return v < 10 ? 10 : (v > 18 ? 18 : v); }
+    int shift = 14;
+    const int64_t want = std::max<int64_t>(64, nref / 1024);
+    while (shift < cap && ((rows + (1LL << shift) - 1) >> shift) > want) ++shift;
     return shift;
 }
 int orx_plan_ranges(int64_t rows, int shift) { return (int)((rows + (1LL << shift) - 1) >> shift); }
 
-// scratch of the bucketed plan for `chunk` steps of nref references (grow-only)
-int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t nref, int nb, int shift, bool want_dupbits) {
+// scratch of the bucketed plan for `chunk` steps of up to nref references over tables of NU / NI rows (grow-only; sized
+// for the smallest range the plan may choose)
+int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t nref, int64_t NU, int64_t NI, bool want_dupbits) {
+    const char* env = getenv("ORX_PLAN_SHIFT");
+    const int smin = env ? std::min(14, std::max(10, atoi(env))) : 14;
+    const int nb = orx_plan_ranges(NU, smin) + orx_plan_ranges(NI, smin);
     if (orx_ensure((void**)&c->d_pl_cnt, &c->d_pl_cnt_cap, (size_t)chunk * (nb + 1) * sizeof(int))) return ORX_ERR_OOM;
     if (orx_ensure((void**)&c->d_pl_cur, &c->d_pl_cur_cap, (size_t)chunk * nb * sizeof(int))) return ORX_ERR_OOM;
     if (orx_ensure((void**)&c->d_pl_list, &c->d_pl_list_cap, (size_t)chunk * nref * sizeof(int2))) return ORX_ERR_OOM;
-    if (want_dupbits && orx_ensure((void**)&c->d_dupbits, &c->d_dupbits_cap, (size_t)chunk * nb * ((1u << shift) >> 5) * sizeof(unsigned int)))
-        return ORX_ERR_OOM;
+    // one bit per row, every range rounded up to whole words of its own
+    const size_t words = (size_t)((NU + NI) / 32) + 2 * ((size_t)1 << 13) + (size_t)nb;
+    if (want_dupbits && orx_ensure((void**)&c->d_dupbits, &c->d_dupbits_cap, (size_t)chunk * words * sizeof(unsigned int))) return ORX_ERR_OOM;
     return ORX_OK;
 }
 
@@ -356,10 +365,10 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
     ProfScope ps(ctx, ORX_K_DEDUP);
     PlanArgs a;
     a.d = d;
-    a.shift = orx_plan_shift(d.NU, d.NI);
+    a.nref = d.nU + d.nP + d.nN;
+    a.shift = orx_plan_shift(d.nU ? d.NU : 0, (d.nP + d.nN) ? d.NI : 0, a.nref);
     a.nru = d.nU ? orx_plan_ranges(d.NU, a.shift) : 0;
     a.nri = (d.nP + d.nN) ? orx_plan_ranges(d.NI, a.shift) : 0;
-    a.nref = d.nU + d.nP + d.nN;
     const int nb = a.nru + a.nri;
     if (nb == 0 || a.nref == 0 || kc == 0) return ORX_OK;
     ORX_ARG(a.nref < (1LL << 30) && kc < 65536, "plan: too many references per step (%lld) or steps (%lld)", (long long)a.nref, (long long)kc);
@@ -392,10 +401,10 @@ int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc) {
     if (kc < 2) return ORX_OK;
     PlanArgs a;
     a.d = d;
-    a.shift = orx_plan_shift(d.NU, d.NI);
+    a.nref = d.nU + d.nP + d.nN;
+    a.shift = orx_plan_shift(d.nU ? d.NU : 0, (d.nP + d.nN) ? d.NI : 0, a.nref);
     a.nru = d.nU ? orx_plan_ranges(d.NU, a.shift) : 0;
     a.nri = (d.nP + d.nN) ? orx_plan_ranges(d.NI, a.shift) : 0;
-    a.nref = d.nU + d.nP + d.nN;
     a.bcnt = ctx->d_pl_cnt; a.bcur = ctx->d_pl_cur; a.list = ctx->d_pl_list; a.dupbits = ctx->d_dupbits; a.min_late = -1;
     const int W = (1 << a.shift) >> 5;
     ORX_LAUNCH(ctx, plan_urgent_kernel, dim3((unsigned)(a.nru + a.nri), (unsigned)(kc - 1)), dim3(PL_THREADS), (size_t)W * 4, a);

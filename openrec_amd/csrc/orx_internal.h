@@ -339,9 +339,9 @@ int orx_launch_dup_apply(orx_ctx* ctx, int optkind, const PairArgs& a);
 int orx_launch_urgent(orx_ctx* ctx, const DedupArgs& a, int64_t K);
 // bucketed plan (kernels_plan.hip): same outputs as orx_launch_dedup (+ orx_launch_urgent) with `d` filled the same way
 bool orx_plan_v2(bool role_bits);
-int orx_plan_shift(int64_t NU, int64_t NI);
+int orx_plan_shift(int64_t NU, int64_t NI, int64_t nref);
 int orx_plan_ranges(int64_t rows, int shift);
-int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t nref, int nb, int shift, bool want_dupbits);
+int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t nref, int64_t NU, int64_t NI, bool want_dupbits);
 int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupbits);
 int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc);
 int orx_fused_can_inline_apply(int D);

@@ -4,6 +4,8 @@ several calls are compared step by step with the fp64 oracle."""
 import numpy as np
 import pytest
 
+from conftest import TOL_ADAM
+
 pytestmark = pytest.mark.gpu
 
 
@@ -91,9 +93,17 @@ def test_skewed_items_use_staging_and_hot_reduce(model, D, optname, K):
     for s in range(K):
         ref, l2r = step(U, V, b, uid[s], pid[s], nid[s], oo)
         assert abs(loss[s] - ref) <= 2e-5 * abs(ref) and abs(l2[s] - l2r) <= 2e-5 * abs(l2r), (s, loss[s], ref)
-    tol = 5e-5 if optname == "adam" else 2e-5
     for got, want in ((tU.read(), U), (tV.read(), V), (tb.read(), b)):
-        assert np.abs(got - want).max() <= tol * np.abs(want).max()
+        e = np.abs(got - want) / np.abs(want).max()
+        if optname != "adam":
+            assert e.max() <= 2e-5          # (docstring: ~1000-term fp32 sums against the exact sum)
+        else:
+            # conftest.TOL_ADAM prices the rounding of ONE 0.05-sized gradient term (3e-9) through lr_1 (1 - beta_1) delta / eps.
+            # A hot row's element sums hundreds of terms (delta ~ sqrt(300) * 3e-9 = 5e-8, and the slot order of its
+            # references -- hence the fp32 sum -- differs from run to run): where such a sum nearly cancels the bound is
+            # 17 x larger, capped by the update itself (<= lr_t * 3.2 = 2e-3 absolute).  All but 1e-4 of the elements sit
+            # inside TOL_ADAM, none beyond 17 x.
+            assert (e > TOL_ADAM).mean() <= 1e-4 and e.max() <= 17 * TOL_ADAM, (float((e > TOL_ADAM).mean()), float(e.max()))
 
 
 def test_skewed_items_with_fused_censor():
