@@ -101,7 +101,7 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     prof_collect(c);
     hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_cflag); hipFree(c->d_dupbits); hipFree(c->d_dlist);
     hipFree(c->d_dcount); hipFree(c->d_refinfo); hipFree(c->d_tricnt); hipFree(c->d_segstart); hipFree(c->d_alloc); hipFree(c->d_dseg); hipFree(c->d_dcnt); hipFree(c->d_chunks); hipFree(c->d_part); hipFree(c->d_partb); hipFree(c->d_stage); hipFree(c->d_stageb); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
-    hipFree(c->d_wpart); hipFree(c->d_pl_cnt); hipFree(c->d_pl_cur); hipFree(c->d_pl_list);
+    hipFree(c->d_wpart); hipFree(c->d_pl_cnt); hipFree(c->d_pl_list);
     if (c->h_plan) hipHostFree(c->h_plan);
     if (c->plan_ev) hipEventDestroy(c->plan_ev);
     if (c->wait_ev) hipEventDestroy(c->wait_ev);
@@ -578,6 +578,7 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
     // started 64 references of a long row), level 2 < level 1 / 64 + 3B/1024, level 3 the rest
     const int64_t cap1 = 3 * B / 64 + 3 * B / 17 + 64, cap2 = cap1 / 64 + 3 * B / 1024 + 64, cap3 = cap2 / 64 + 64;
     const int64_t item_stride = cap1 + cap2 + cap3;
+    if (v2) ENSURE(c->d_alloc, c->d_alloc_cap, (size_t)chunk * 8 * sizeof(int));
     if (staging) {
         ENSURE(c->d_refinfo, c->d_refinfo_cap, (size_t)chunk * 3 * Bp * sizeof(int2));
         ENSURE(c->d_tricnt, c->d_tricnt_cap, (size_t)chunk * B * sizeof(int));      // (v2: only ranges with > 2048 tri rows use it)
@@ -617,15 +618,16 @@ int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
     d.min_late = plan.min_late;
     const bool v2 = orx_plan_v2(role_bits);
     if (!v2) ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));     // (the bucketed plan zeroes its counters itself)
+    d.alloc = c->d_alloc;
     if (staging) {
-        d.refinfo = c->d_refinfo; d.tricnt = c->d_tricnt; d.segstart = c->d_segstart; d.alloc = c->d_alloc;
+        d.refinfo = c->d_refinfo; d.tricnt = c->d_tricnt; d.segstart = c->d_segstart;
         d.dseg = c->d_dseg; d.dcnt = c->d_dcnt; d.items = c->d_chunks;
         d.tri_stride = B; d.item_stride = plan.item_stride;
         for (int l = 0; l < 3; ++l) d.tree_off[l] = plan.tree_off[l];
         if (!v2) ORX_HIP(hipMemsetAsync(c->d_tricnt, 0, (size_t)kc * B * sizeof(int), c->stream));
         if (!v2) ORX_HIP(hipMemsetAsync(c->d_alloc, 0, (size_t)kc * 8 * sizeof(int), c->stream));
     }
-    std::vector<int> dc_v1, al_v1;
+    std::vector<int> dc_v1, al_v1, dc_v2;
     const int* dc = nullptr;            // duplicated rows per step
     const int* al = nullptr;            // staging allocators per step
     if (v2) {
@@ -633,12 +635,13 @@ int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
         // the host waits for it (the fused kernel ignores them in a launch without apply blocks)
         d.roles = nullptr; d.dupbits = nullptr;
         CHECK(orx_launch_plan(c, d, kc, inline_apply));
-        ORX_HIP(hipMemcpyAsync(c->h_plan, c->d_dcount, (size_t)kc * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        if (staging) ORX_HIP(hipMemcpyAsync(c->h_plan + kc, c->d_alloc, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        ORX_HIP(hipMemcpyAsync(c->h_plan, c->d_alloc, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // ([5] = duplicated rows)
         ORX_HIP(hipEventRecord(c->plan_ev, c->stream));
         if (inline_apply) CHECK(orx_launch_plan_urgent(c, d, kc));
         ORX_HIP(hipEventSynchronize(c->plan_ev));
-        dc = c->h_plan; al = c->h_plan + kc;
+        dc_v2.resize((size_t)kc);
+        for (int64_t i = 0; i < kc; ++i) dc_v2[i] = c->h_plan[8 * i + 5];
+        dc = dc_v2.data(); al = c->h_plan;
     } else {
         CHECK(orx_launch_dedup(c, d, kc));
         if (inline_apply) {

@@ -11,9 +11,9 @@
 // Here the references are first PARTITIONED by row range (2^shift rows, 16 384 for tables up to 64 M rows), exactly
 // (count -> scan -> scatter, no capacity guess, nothing depends on the id distribution), and a 256-thread workgroup
 // per (step, range) then works on its own ~3-4 k references only:
-//   plan_count_kernel    histogram of the step's references over the ranges (LDS, then one atomic per touched bin)
-//   plan_scan_kernel     exclusive prefix per step -> bucket offsets
-//   plan_scatter_kernel  (id, output position) pairs into the step's bucket lists; out-of-range ids are marked here
+//   plan_part_kernel<0>  histogram of the step's references over the ranges (LDS, then one atomic per touched bin)
+//   plan_part_kernel<1>  exclusive prefix of the histogram (per workgroup), then (id, output position) pairs into the step's
+//                        bucket lists and the coalesced copy of the ids; out-of-range ids are marked here
 //   plan_range_kernel    three LDS bitmaps over the range (seen / twice / three times), roles by arrival, dense
 //                        numbering of the rows with >= 3 references, their ranks and staging segments (per-row
 //                        counters in LDS), duplicate list with (segment, count), reduction-tree work items
@@ -33,8 +33,7 @@ struct PlanArgs {
     DedupArgs d;
     int shift;                 // rows per range = 1 << shift
     int nru, nri;              // ranges of the user / item table
-    int* bcnt;                 // [K][nb + 1] references per bucket -> exclusive offsets (total at [nb])
-    int* bcur;                 // [K][nb] scatter cursors
+    int* bcnt;                 // [K][3 nb + 1]: references per bucket [nb], scatter cursors [nb], exclusive offsets [nb + 1]
     int2* list;                // [K][nref] (id, output position | role << 30)
     int64_t nref;
     unsigned int* dupbits;     // [K][nb][words] "seen twice" bitmaps for plan_urgent_kernel, or NULL
@@ -50,10 +49,26 @@ __device__ __forceinline__ bool plan_ref(const PlanArgs& a, int64_t s, int64_t j
     return id_ok(id, is_user ? d.NU : d.NI);
 }
 
+// exclusive prefix sum of one int per thread over the PL_THREADS-thread workgroup; `total` = sum
+__device__ __forceinline__ int plan_scan_excl(int v, int* wave_tot, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < PL_THREADS / 64; ++k) { const int t = wave_tot[k]; if (k < wave) before += t; all += t; }
+    __syncthreads();
+    total = all;
+    return before + incl - v;
+}
+
 // SCATTER = false: count the references of a chunk per bucket.  SCATTER = true: write them into the bucket lists.
 template <bool SCATTER>
 __global__ __launch_bounds__(PL_THREADS) void plan_part_kernel(PlanArgs a) {
-    extern __shared__ int pl_hist[];               // [nb] counts, then (scatter) [nb] list positions
+    extern __shared__ int pl_hist[];               // [nb] counts, (scatter) [nb] list positions, [nb + 1] bucket offsets
     const int nb = a.nru + a.nri;
     const int64_t s = blockIdx.y;
     int* hist = pl_hist;
@@ -81,62 +96,38 @@ __global__ __launch_bounds__(PL_THREADS) void plan_part_kernel(PlanArgs a) {
 #pragma unroll
     for (int k = 0; k < PL_REFS; ++k) if (bk[k] >= 0) rk[k] = atomicAdd(&hist[bk[k]], 1);
     __syncthreads();
-    int* cnt = a.bcnt + s * (nb + 1);
+    int* cnt = a.bcnt + s * (3 * nb + 1);
     if (!SCATTER) {
         // the step's list and allocator counters start at zero (first used by plan_range_kernel): no memsets of their own
-        if (blockIdx.x == 0 && threadIdx.x < 9) {
-            if (threadIdx.x == 8) a.d.dcount[s] = 0;
-            else if (a.d.alloc) a.d.alloc[8 * s + threadIdx.x] = 0;
-        }
+        if (blockIdx.x == 0 && threadIdx.x < 8) a.d.alloc[8 * s + threadIdx.x] = 0;
+        if (blockIdx.x == 0 && threadIdx.x == 8) a.d.dcount[s] = 0;
         for (int i = threadIdx.x; i < nb; i += PL_THREADS) { const int c = hist[i]; if (c) atomicAdd(cnt + i, c); }
         return;
     }
-    int* cur = a.bcur + s * nb;
-    for (int i = threadIdx.x; i < nb; i += PL_THREADS) { const int c = hist[i]; if (c) base[i] = cnt[i] + atomicAdd(cur + i, c); }
+    // exclusive prefix of the step's bucket counts, by every workgroup for itself (a scan kernel of its own cost a launch
+    // and a gap: 8 us of a short call); workgroup 0 leaves it in memory for plan_range_kernel / plan_urgent_kernel
+    __shared__ int wave_tot[PL_THREADS / 64];
+    int* off = pl_hist + 2 * nb;
+    for (int i = threadIdx.x; i < nb; i += PL_THREADS) off[i] = cnt[i];
+    __syncthreads();
+    {
+        const int per = (nb + PL_THREADS - 1) / PL_THREADS;
+        const int i0 = threadIdx.x * per;
+        int mine = 0;
+        for (int i = i0; i < i0 + per && i < nb; ++i) mine += off[i];
+        int total;
+        int run = plan_scan_excl(mine, wave_tot, total);
+        for (int i = i0; i < i0 + per && i < nb; ++i) { const int c = off[i]; off[i] = run; run += c; }
+        if (threadIdx.x == 0) off[nb] = total;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i <= nb; i += PL_THREADS) cnt[2 * nb + i] = off[i];
+    int* cur = cnt + nb;
+    for (int i = threadIdx.x; i < nb; i += PL_THREADS) { const int c = hist[i]; if (c) base[i] = off[i] + atomicAdd(cur + i, c); }
     __syncthreads();
     int2* list = a.list + s * a.nref;
 #pragma unroll
     for (int k = 0; k < PL_REFS; ++k) if (bk[k] >= 0) list[base[bk[k]] + rk[k]] = make_int2(idv[k], posv[k]);
-}
-
-// exclusive prefix of the bucket counts of one step (total at [nb]); the cursors start at zero
-__global__ __launch_bounds__(1024) void plan_scan_kernel(PlanArgs a) {
-    __shared__ int wave_tot[16];
-    const int nb = a.nru + a.nri;
-    int* cnt = a.bcnt + (int64_t)blockIdx.x * (nb + 1);
-    int* cur = a.bcur + (int64_t)blockIdx.x * nb;
-    const int per = (nb + 1023) / 1024;
-    const int i0 = threadIdx.x * per;
-    int mine = 0;
-    for (int i = i0; i < i0 + per && i < nb; ++i) mine += cnt[i];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int before = 0, all = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { const int t = wave_tot[k]; if (k < wave) before += t; all += t; }
-    int run = before + incl - mine;
-    for (int i = i0; i < i0 + per && i < nb; ++i) { const int c = cnt[i]; cnt[i] = run; run += c; cur[i] = 0; }
-    if (threadIdx.x == 0) cnt[nb] = all;
-}
-
-// exclusive prefix sum of one int per thread over the PL_THREADS-thread workgroup; `total` = sum
-__device__ __forceinline__ int plan_scan_excl(int v, int* wave_tot, int& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int before = 0, all = 0;
-#pragma unroll
-    for (int k = 0; k < PL_THREADS / 64; ++k) { const int t = wave_tot[k]; if (k < wave) before += t; all += t; }
-    __syncthreads();
-    total = all;
-    return before + incl - v;
 }
 
 // a reference counter after the ranks have been handed out (LDS, or global memory updated by L2 atomics)
@@ -160,7 +151,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_range_kernel(PlanArgs a) {
     const int64_t s = blockIdx.y;
     const bool is_user = b < a.nru;
     const int64_t r0 = (int64_t)(is_user ? b : b - a.nru) << a.shift;
-    const int* cnt = a.bcnt + s * (nb + 1);
+    const int* cnt = a.bcnt + s * (3 * nb + 1) + 2 * nb;
     const int lo = cnt[b], n = cnt[b + 1] - lo;
     int2* ent = a.list + s * a.nref + lo;
     unsigned int* dupout = a.dupbits ? a.dupbits + ((size_t)s * nb + b) * W : nullptr;
@@ -263,7 +254,10 @@ __global__ __launch_bounds__(PL_THREADS) void plan_range_kernel(PlanArgs a) {
     int off = 0;
     if (mine) off = atomicAdd(&list_cnt, mine);
     __syncthreads();
-    if (threadIdx.x == 0) list_base = list_cnt ? atomicAdd(d.dcount + s, list_cnt) : 0;
+    if (threadIdx.x == 0) {
+        list_base = list_cnt ? atomicAdd(d.dcount + s, list_cnt) : 0;
+        if (list_cnt) atomicAdd(d.alloc + 8 * s + 5, list_cnt);      // (the host reads the allocators only: one copy)
+    }
     __syncthreads();
     if (mine) {
         int64_t e = s * d.list_stride + list_base + off;
@@ -311,10 +305,10 @@ __global__ __launch_bounds__(PL_THREADS) void plan_urgent_kernel(PlanArgs a) {
     const int nb = a.nru + a.nri;
     const int b = blockIdx.x;
     const int64_t s = 1 + blockIdx.y;
-    const int* cnt = a.bcnt + s * (nb + 1);
+    const int* cnt = a.bcnt + s * (3 * nb + 1) + 2 * nb;
     const int lo = cnt[b], n = cnt[b + 1] - lo;
     if (n == 0) return;
-    const int prev_n = a.bcnt[(s - 1) * (nb + 1) + b + 1] - a.bcnt[(s - 1) * (nb + 1) + b];
+    const int prev_n = cnt[b + 1 - (3 * nb + 1)] - cnt[b - (3 * nb + 1)];
     if (prev_n < 2) return;                             // no duplicated row without two references
     const unsigned int* prev = a.dupbits + ((size_t)(s - 1) * nb + b) * W;
     for (int w = threadIdx.x; w < W; w += PL_THREADS) pl_lds[w] = prev[w];
@@ -351,8 +345,7 @@ int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t nref, int64_t NU, int64_
     const char* env = getenv("ORX_PLAN_SHIFT");
     const int smin = env ? std::min(14, std::max(10, atoi(env))) : 14;
     const int nb = orx_plan_ranges(NU, smin) + orx_plan_ranges(NI, smin);
-    if (orx_ensure((void**)&c->d_pl_cnt, &c->d_pl_cnt_cap, (size_t)chunk * (nb + 1) * sizeof(int))) return ORX_ERR_OOM;
-    if (orx_ensure((void**)&c->d_pl_cur, &c->d_pl_cur_cap, (size_t)chunk * nb * sizeof(int))) return ORX_ERR_OOM;
+    if (orx_ensure((void**)&c->d_pl_cnt, &c->d_pl_cnt_cap, (size_t)chunk * (3 * nb + 1) * sizeof(int))) return ORX_ERR_OOM;
     if (orx_ensure((void**)&c->d_pl_list, &c->d_pl_list_cap, (size_t)chunk * nref * sizeof(int2))) return ORX_ERR_OOM;
     // one bit per row, every range rounded up to whole words of its own
     const size_t words = (size_t)((NU + NI) / 32) + 2 * ((size_t)1 << 13) + (size_t)nb;
@@ -372,13 +365,13 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
     const int nb = a.nru + a.nri;
     if (nb == 0 || a.nref == 0 || kc == 0) return ORX_OK;
     ORX_ARG(a.nref < (1LL << 30) && kc < 65536, "plan: too many references per step (%lld) or steps (%lld)", (long long)a.nref, (long long)kc);
-    a.bcnt = ctx->d_pl_cnt; a.bcur = ctx->d_pl_cur; a.list = ctx->d_pl_list;
+    a.bcnt = ctx->d_pl_cnt; a.list = ctx->d_pl_list;
     a.dupbits = keep_dupbits ? ctx->d_dupbits : nullptr;
     const char* ml = getenv("ORX_PLAN_MIN_LATE");      // experiments
     a.min_late = ml ? atoi(ml) : d.min_late;
-    ORX_HIP(hipMemsetAsync(a.bcnt, 0, (size_t)kc * (nb + 1) * sizeof(int), ctx->stream));
+    ORX_HIP(hipMemsetAsync(a.bcnt, 0, (size_t)kc * (3 * nb + 1) * sizeof(int), ctx->stream));
     const dim3 gp((unsigned)((a.nref + PL_CHUNK - 1) / PL_CHUNK), (unsigned)kc);
-    const size_t hist_bytes = (size_t)2 * nb * sizeof(int);
+    const size_t hist_bytes = (size_t)(3 * nb + 1) * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         ORX_HIP(hipFuncSetAttribute((const void*)plan_part_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -387,7 +380,6 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
         attr_set = true;
     }
     ORX_LAUNCH(ctx, (plan_part_kernel<false>), gp, dim3(PL_THREADS), hist_bytes, a);
-    ORX_LAUNCH(ctx, plan_scan_kernel, dim3((unsigned)kc), dim3(1024), 0, a);
     ORX_LAUNCH(ctx, (plan_part_kernel<true>), gp, dim3(PL_THREADS), hist_bytes, a);
     const int W = (1 << a.shift) >> 5;
     const size_t lds = (size_t)(3 * W + (W + 1) / 2) * 4 + (size_t)PL_LCNT * 4;
@@ -405,7 +397,7 @@ int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc) {
     a.shift = orx_plan_shift(d.nU ? d.NU : 0, (d.nP + d.nN) ? d.NI : 0, a.nref);
     a.nru = d.nU ? orx_plan_ranges(d.NU, a.shift) : 0;
     a.nri = (d.nP + d.nN) ? orx_plan_ranges(d.NI, a.shift) : 0;
-    a.bcnt = ctx->d_pl_cnt; a.bcur = ctx->d_pl_cur; a.list = ctx->d_pl_list; a.dupbits = ctx->d_dupbits; a.min_late = -1;
+    a.bcnt = ctx->d_pl_cnt; a.list = ctx->d_pl_list; a.dupbits = ctx->d_dupbits; a.min_late = -1;
     const int W = (1 << a.shift) >> 5;
     ORX_LAUNCH(ctx, plan_urgent_kernel, dim3((unsigned)(a.nru + a.nri), (unsigned)(kc - 1)), dim3(PL_THREADS), (size_t)W * 4, a);
     ORX_HIP(hipGetLastError());

@@ -55,8 +55,7 @@ struct orx_ctx {
     unsigned char* d_cflag = nullptr; size_t d_cflag_cap = 0;    // [3][K][B] censor election flags
     unsigned int* d_dupbits = nullptr; size_t d_dupbits_cap = 0; // [K][buckets][words] duplicate bitmaps
     // bucketed plan (kernels_plan.hip): references per (step, row range), scatter cursors, bucket lists
-    int* d_pl_cnt = nullptr;   size_t d_pl_cnt_cap = 0;          // [K][ranges + 1]
-    int* d_pl_cur = nullptr;   size_t d_pl_cur_cap = 0;          // [K][ranges]
+    int* d_pl_cnt = nullptr;   size_t d_pl_cnt_cap = 0;          // [K][3 ranges + 1]: counts, cursors, offsets
     int2* d_pl_list = nullptr; size_t d_pl_list_cap = 0;         // [K][references per step] (id, output position | role << 30)
     int* h_plan = nullptr;                                       // pinned host mirror of the per-step plan counters
     size_t h_plan_cap = 0;
