@@ -228,6 +228,18 @@ int orx_sampler_create(orx_ctx* ctx, const int32_t* rec_user, const int32_t* rec
 int orx_sampler_destroy(orx_sampler* s);
 int orx_sampler_pairwise(orx_sampler* s, uint64_t seed, int64_t first, int64_t n,
                          int32_t* uid_dev, int32_t* pid_dev, int32_t* nid_dev);
+/* The pointwise producers of GMF / WRMF (dataset.py:18-36 _stratified_pointwise_generator, :38-58
+ * _per_pos_stratified_pointwise_generator): samples [first, first + n) as (user, item, label) DEVICE arrays.
+ *   stratified         : with probability pos_ratio the next record of the shuffled epoch (label 1), otherwise a uniform
+ *                        (user, item) pair that is not a positive (label 0).  Sequential stream, like the reference's
+ *                        generator: a call continues at the sample the previous one (same seed) stopped at; first = 0 restarts.
+ *   per_pos_stratified : groups of 1 + int((1 - pos_ratio) / pos_ratio): a record (label 1), then that many DISTINCT items
+ *                        other than the record's (label 0; not checked against the user's other positives, as in the
+ *                        reference).  Counter-based: any window can be regenerated. */
+int orx_sampler_stratified(orx_sampler* s, uint64_t seed, int64_t first, int64_t n, float pos_ratio,
+                           int32_t* uid_dev, int32_t* iid_dev, float* label_dev);
+int orx_sampler_per_pos_stratified(orx_sampler* s, uint64_t seed, int64_t first, int64_t n, float pos_ratio,
+                                   int32_t* uid_dev, int32_t* iid_dev, float* label_dev);
 
 /* ---- DLRM (recommenders/dlrm.py:6-100, modules/multi_layer_perceptron.py:5-18,
  * modules/second_order_feature_interaction.py:4-34; train step as in

@@ -668,6 +668,9 @@ struct orx_sampler {
     int64_t* ptr = nullptr;
     int64_t R = 0, total_users = 0, total_items = 0;
     int h = 1;
+    // stratified pointwise stream: positives consumed so far (device), next sample index and seed the counter belongs to
+    int64_t* d_counter = nullptr; int64_t strat_next = -1; uint64_t strat_seed = 0;
+    int* d_blockcnt = nullptr; int64_t* d_blockbase = nullptr; size_t block_cap = 0;
 };
 
 extern "C" int orx_sampler_create(orx_ctx* ctx, const int32_t* rec_user, const int32_t* rec_item, int64_t n_records,
@@ -697,6 +700,7 @@ extern "C" int orx_sampler_destroy(orx_sampler* s) {
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
     hipFree(s->rec_user); hipFree(s->rec_item); hipFree(s->ptr); hipFree(s->items);
+    hipFree(s->d_counter); hipFree(s->d_blockcnt); hipFree(s->d_blockbase);
     delete s;
     return ORX_OK;
 }
@@ -707,7 +711,50 @@ extern "C" int orx_sampler_pairwise(orx_sampler* s, uint64_t seed, int64_t first
     ORX_HIP(hipSetDevice(s->ctx->device));
     SamplerArgs a;
     a.rec_user = s->rec_user; a.rec_item = s->rec_item; a.R = s->R; a.ptr = s->ptr; a.items = s->items;
-    a.total_items = s->total_items; a.seed = seed; a.first = first; a.n = n; a.h = s->h;
+    a.total_items = s->total_items; a.total_users = s->total_users; a.seed = seed; a.first = first; a.n = n; a.h = s->h;
     a.uid = uid_dev; a.pid = pid_dev; a.nid = nid_dev;
     return orx_launch_sample_pairwise(s->ctx, a);
+}
+
+static void sampler_args(orx_sampler* s, uint64_t seed, int64_t first, int64_t n, int32_t* uid, int32_t* iid, SamplerArgs* a) {
+    a->rec_user = s->rec_user; a->rec_item = s->rec_item; a->R = s->R; a->ptr = s->ptr; a->items = s->items;
+    a->total_items = s->total_items; a->total_users = s->total_users; a->seed = seed; a->first = first; a->n = n; a->h = s->h;
+    a->uid = uid; a->pid = iid; a->nid = nullptr;
+}
+
+extern "C" int orx_sampler_stratified(orx_sampler* s, uint64_t seed, int64_t first, int64_t n, float pos_ratio,
+                                      int32_t* uid_dev, int32_t* iid_dev, float* label_dev) {
+    ORX_ARG(s && uid_dev && iid_dev && label_dev && first >= 0 && n >= 0, "orx_sampler_stratified: bad argument");
+    ORX_ARG(pos_ratio >= 0.f && pos_ratio <= 1.f, "orx_sampler_stratified: pos_ratio must lie in [0, 1]");
+    ORX_ARG(first == 0 || (first == s->strat_next && seed == s->strat_seed),
+            "orx_sampler_stratified: the stream is sequential (a positive's place in the epoch counts the positives before it): "
+            "continue at sample %lld of the same seed, or restart at 0", (long long)s->strat_next);
+    ORX_HIP(hipSetDevice(s->ctx->device));
+    if (!s->d_counter) ORX_HIP(hipMalloc((void**)&s->d_counter, sizeof(int64_t)));
+    if (first == 0) ORX_HIP(hipMemsetAsync(s->d_counter, 0, sizeof(int64_t), s->ctx->stream));
+    const size_t nblocks = (size_t)((n + 255) / 256);
+    if (s->block_cap < nblocks) {
+        ORX_HIP(hipStreamSynchronize(s->ctx->stream));
+        hipFree(s->d_blockcnt); hipFree(s->d_blockbase); s->d_blockcnt = nullptr; s->d_blockbase = nullptr; s->block_cap = 0;
+        ORX_HIP(hipMalloc((void**)&s->d_blockcnt, sizeof(int) * nblocks));
+        ORX_HIP(hipMalloc((void**)&s->d_blockbase, sizeof(int64_t) * nblocks));
+        s->block_cap = nblocks;
+    }
+    SamplerArgs a;
+    sampler_args(s, seed, first, n, uid_dev, iid_dev, &a);
+    s->strat_next = first + n; s->strat_seed = seed;
+    return orx_launch_sample_stratified(s->ctx, a, pos_ratio, label_dev, s->d_blockcnt, s->d_blockbase, s->d_counter);
+}
+
+extern "C" int orx_sampler_per_pos_stratified(orx_sampler* s, uint64_t seed, int64_t first, int64_t n, float pos_ratio,
+                                              int32_t* uid_dev, int32_t* iid_dev, float* label_dev) {
+    ORX_ARG(s && uid_dev && iid_dev && label_dev && first >= 0 && n >= 0, "orx_sampler_per_pos_stratified: bad argument");
+    ORX_ARG(pos_ratio > 0.f && pos_ratio <= 1.f, "orx_sampler_per_pos_stratified: pos_ratio must lie in (0, 1]");
+    const int nneg = (int)((1.0f - pos_ratio) / pos_ratio);          // dataset.py:40
+    ORX_ARG(nneg + 1 <= s->total_items, "orx_sampler_per_pos_stratified: %d negatives per positive need more than %lld items "
+            "(random.sample would raise ValueError)", nneg, (long long)s->total_items);
+    ORX_HIP(hipSetDevice(s->ctx->device));
+    SamplerArgs a;
+    sampler_args(s, seed, first, n, uid_dev, iid_dev, &a);
+    return orx_launch_sample_perpos(s->ctx, a, nneg, label_dev);
 }

@@ -457,8 +457,11 @@ int orx_launch_rank_metrics(orx_ctx* ctx, const EvalArgs& a, int64_t n);
 struct SamplerArgs {
     const int32_t* rec_user; const int32_t* rec_item; int64_t R;      // interaction records
     const int64_t* ptr; const int32_t* items;                          // CSR of positives (sorted per user)
-    int64_t total_items;
+    int64_t total_items; int64_t total_users;
     uint64_t seed; int64_t first; int64_t n; int h;
     int32_t* uid; int32_t* pid; int32_t* nid;
 };
 int orx_launch_sample_pairwise(orx_ctx* ctx, const SamplerArgs& a);
+int orx_launch_sample_stratified(orx_ctx* ctx, const SamplerArgs& a, float pos_ratio, float* label, int* blockcnt, int64_t* blockbase,
+                                 int64_t* counter);
+int orx_launch_sample_perpos(orx_ctx* ctx, const SamplerArgs& a, int nneg, float* label);

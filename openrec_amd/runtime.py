@@ -514,3 +514,17 @@ class DeviceSampler:
         pu, nu, du, _ = _ids_arg(uid); pp, _, dp, _ = _ids_arg(pid); pn, _, dn, _ = _ids_arg(nid)
         assert du and dp and dn and nu >= n, "the sampler writes device buffers"
         check(self._lib.orx_sampler_pairwise(self._h, int(seed) & (2 ** 64 - 1), int(first), int(n), pu, pp, pn))
+
+    def _pointwise(self, fn, seed, first, n, pos_ratio, uid, iid, label):
+        pu, nu, du, _ = _ids_arg(uid); pi, _, di, _ = _ids_arg(iid); pl, nl, dl, _ = _label_arg(label)
+        assert du and di and dl and nu >= n and nl >= n, "the sampler writes device buffers"
+        check(fn(self._h, int(seed) & (2 ** 64 - 1), int(first), int(n), float(pos_ratio), pu, pi, pl))
+
+    def stratified_pointwise(self, seed, first, n, pos_ratio, uid, iid, label):
+        """(user, item, label) samples [first, first + n) of `Dataset.stratified_pointwise` into DEVICE buffers; the stream
+        is sequential (first = 0, then each call continues where the previous one stopped)."""
+        self._pointwise(self._lib.orx_sampler_stratified, seed, first, n, pos_ratio, uid, iid, label)
+
+    def per_pos_stratified_pointwise(self, seed, first, n, pos_ratio, uid, iid, label):
+        """(user, item, label) samples [first, first + n) of `Dataset.per_pos_stratified_pointwise` into DEVICE buffers"""
+        self._pointwise(self._lib.orx_sampler_per_pos_stratified, seed, first, n, pos_ratio, uid, iid, label)
