@@ -414,6 +414,12 @@ int orx_launch_dense_apply(orx_ctx* ctx, float* w, float* acc, float* g, int n, 
 
 int orx_launch_score_all(orx_ctx* ctx, const float* U, const float* V, const float* b, const float* w,
                          const int32_t* uid, int64_t nq, int64_t NU, int64_t NI, int D, int kind, float* out) {
+    ProfScope ps(ctx, ORX_K_GEMM);
+    if (getenv("ORX_SCORE_SIMPLE") == nullptr) {         // the matrix-core scorer (kernels_score.hip); this kernel remains for
+        bool launched = false;                           // dims whose tiles do not fit the LDS and as the A/B reference
+        const int rc = orx_launch_score_mfma(ctx, U, V, b, w, uid, nq, NU, NI, D, kind, out, &launched);
+        if (rc != ORX_OK || launched) return rc;
+    }
     const dim3 g((unsigned)((NI + 63) / 64), (unsigned)((nq + 15) / 16));
     ORX_LAUNCH(ctx, score_all_kernel, g, dim3(256), (size_t)16 * D * sizeof(float), U, V, b, w, uid, nq, NU, NI, D, kind, out, ctx->d_err);
     ORX_HIP(hipGetLastError());

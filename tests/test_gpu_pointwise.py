@@ -77,15 +77,15 @@ def test_inference_scores():
     from openrec_amd import runtime as rt
     from oracle import numpy_oracle as orc
     rng = np.random.default_rng(1)
-    for D in (50, 64):
-        NU, NI = 300, 1000
+    for D, NI, nq in ((50, 1000, 37), (64, 1000, 37), (128, 4133, 130), (256, 777, 65), (16, 90, 3), (64, 70000, 200)):
+        NU = 300
         U = rng.normal(size=(NU, D)).astype(np.float32); V = rng.normal(size=(NI, D)).astype(np.float32)
         b = rng.normal(size=(NI, 1)).astype(np.float32); w = rng.normal(size=(D, 1)).astype(np.float32)
         tU = rt.Table(NU, D).write(U); tV = rt.Table(NI, D).write(V); tb = rt.Table(NI, 1).write(b); tw = rt.Table(D, 1).write(w)
-        uid = rng.integers(0, NU, 37).astype(np.int32)
+        uid = rng.integers(0, NU, nq).astype(np.int32)
         assert rel_err(rt.score_all_items("dot", tU, tV, tb, uid), orc.bpr_inference(U, V, b, uid)) < TOL
         assert rel_err(rt.score_all_items("l2", tU, tV, tb, uid), orc.ucml_inference(U, V, b, uid)) < TOL
-        ref = (U[uid][:, None, :] * V[None, :, :]) @ w[:, 0] + b[:, 0][None, :]
+        ref = (U[uid].astype(np.float64) * w[:, 0]) @ V.T.astype(np.float64) + b[:, 0][None, :]
         assert rel_err(rt.score_all_items("gmf", tU, tV, tb, uid, w=tw), ref) < TOL
 
 
