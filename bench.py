@@ -314,15 +314,29 @@ def main():
         if fused.get("launches"):
             dur = fused["total_ms"] / fused["launches"] * 1e-3
             achieved = args.batch * bpt / dur / 1e9
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "fused_hbm_traffic.json")
+            # HBM bytes per launch from the PMC passes of scripts/collect_profiles.sh -- only if they were measured on THIS
+            # build (source hash) and THIS workload; otherwise null, never a stale constant
+            traffic, traffic_src = None, None
+            tfile = os.path.join(ROOT, "profiles", "traffic.json")
             if world == 1 and os.path.exists(tfile):
                 try:
-                    traffic = json.load(open(tfile)).get(f"{args.model}_d{args.dim}_{args.opt}")
+                    from openrec_amd.build import source_hash
+                    tj = json.load(open(tfile))
+                    key = {("bpr", 64, "sgd"): "c2", ("ucml", 128, "sgd"): "c3_ucml128_censor", ("bpr", 64, "adagrad"): "bpr_adagrad",
+                           ("wrmf", 64, "sgd"): "wrmf"}.get((args.model, args.dim, args.opt))
+                    default_shape = (args.users, args.items, args.batch, args.zipf, args.hogwild) == (1_000_000, 1_000_000, 65536, 0.0, False)
+                    if key == "c3_ucml128_censor" and not args.censor:
+                        key = None
+                    if key in tj.get("workloads", {}) and default_shape:
+                        if tj.get("source_hash") == source_hash():
+                            traffic = tj["workloads"][key]["bytes_per_launch"]
+                            traffic_src = f"profiles/{tj['tag']}_pmc_summary.csv"
+                        else:
+                            traffic_src = f"profiles/{tj['tag']}_pmc_summary.csv was measured on another build: not reported"
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": "point_fused_kernel" if args.model in ("gmf", "wrmf") else "fused_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                "bytes_per_triplet": bpt, "kernel_us": dur * 1e6,
                                "other_kernels_us": {k: v["total_ms"] / v["launches"] * 1e3
                                                     for k, v in prof.items() if v.get("launches") and k not in ("fused", "pointwise")}}

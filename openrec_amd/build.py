@@ -33,6 +33,16 @@ def _deps():
         glob.glob(os.path.join(HERE, "..", "include", "*.h")) + [os.path.abspath(__file__)]
 
 
+def source_hash():
+    """sha256 (16 hex digits) of the sources libopenrec_hip.so is built from: profiles/*_traffic.json carries it, so a PMC
+    figure is only ever reported next to the build it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(_sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

@@ -559,7 +559,7 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
         ENSURE(c->d_ids2, c->d_ids2_cap, (size_t)chunk * 3 * Bp * sizeof(int32_t));
         if (v2) {
             // bucketed plan (kernels_plan.hip): bucket counters, lists of up to 3 B references per step, per-range bitmaps
-            CHECK(orx_plan_buffers(c, chunk, 3 * B, U->rows, V->rows, inline_apply));
+            CHECK(orx_plan_buffers(c, chunk, B, U->rows, V->rows, inline_apply));
             if (c->h_plan_cap < (size_t)chunk * 9 * sizeof(int)) {
                 if (c->h_plan) ORX_HIP(hipHostFree(c->h_plan));
                 c->h_plan = nullptr; c->h_plan_cap = 0;
@@ -640,7 +640,9 @@ int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
         if (inline_apply) CHECK(orx_launch_plan_urgent(c, d, kc));
         ORX_HIP(hipEventSynchronize(c->plan_ev));
         dc_v2.resize((size_t)kc);
-        for (int64_t i = 0; i < kc; ++i) dc_v2[i] = c->h_plan[8 * i + 5];
+        int big = 0;
+        for (int64_t i = 0; i < kc; ++i) { dc_v2[i] = c->h_plan[8 * i + 5]; big = std::max(big, c->h_plan[8 * i + 6]); }
+        c->plan_big = big > 16384;          // ([6] = the step's largest bucket, if above 8 k references)
         dc = dc_v2.data(); al = c->h_plan;
     } else {
         CHECK(orx_launch_dedup(c, d, kc));

@@ -24,6 +24,8 @@
 
 #include "orx_device.h"
 
+#include <cstring>
+
 constexpr int PL_THREADS = 256;
 constexpr int PL_REFS = 8;                        // references per thread in the count / scatter kernels
 constexpr int PL_CHUNK = PL_THREADS * PL_REFS;
@@ -31,8 +33,10 @@ constexpr int PL_LCNT = 2048;                     // per-row reference counters 
 
 struct PlanArgs {
     DedupArgs d;
-    int shift;                 // rows per range = 1 << shift
-    int nru, nri;              // ranges of the user / item table
+    int shift;                 // rows per bucket <= 1 << shift
+    int nru, nri;              // buckets of the user / item table: POWERS OF TWO.  Row r of a table belongs to bucket r & (n - 1) and is
+    int lgu, lgi;              // row r >> lg(n) inside it: interleaved, so that a contiguous run of hot ids (a vocabulary sorted by
+                               // frequency: the head of a Zipf distribution) spreads over all buckets instead of filling one
     int* bcnt;                 // [K][3 nb + 1]: references per bucket [nb], scatter cursors [nb], exclusive offsets [nb + 1]
     int2* list;                // [K][nref] (id, output position | role << 30)
     int64_t nref;
@@ -50,6 +54,7 @@ __device__ __forceinline__ bool plan_ref(const PlanArgs& a, int64_t s, int64_t j
 }
 
 // exclusive prefix sum of one int per thread over the PL_THREADS-thread workgroup; `total` = sum
+template <int T = PL_THREADS>
 __device__ __forceinline__ int plan_scan_excl(int v, int* wave_tot, int& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = v;
@@ -59,7 +64,7 @@ __device__ __forceinline__ int plan_scan_excl(int v, int* wave_tot, int& total) 
     __syncthreads();
     int before = 0, all = 0;
 #pragma unroll
-    for (int k = 0; k < PL_THREADS / 64; ++k) { const int t = wave_tot[k]; if (k < wave) before += t; all += t; }
+    for (int k = 0; k < T / 64; ++k) { const int t = wave_tot[k]; if (k < wave) before += t; all += t; }
     __syncthreads();
     total = all;
     return before + incl - v;
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_part_kernel(PlanArgs a) {
             int id, pos; bool is_user;
             const bool ok = plan_ref(a, s, j, id, is_user, pos);
             if (ok) {
-                bk[k] = (is_user ? 0 : a.nru) + (id >> a.shift);
+                bk[k] = is_user ? (id & (a.nru - 1)) : a.nru + (id & (a.nri - 1));
                 idv[k] = id; posv[k] = pos;
             }
             // the rewritten ids start as a (coalesced) copy; plan_range_kernel then touches only the duplicated references --
@@ -134,8 +139,49 @@ __global__ __launch_bounds__(PL_THREADS) void plan_part_kernel(PlanArgs a) {
 __device__ __forceinline__ int pl_cnt(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned int pl_peek(const unsigned int* p) { return *reinterpret_cast<const volatile unsigned int*>(p); }
 
+// visit the n entries of a bucket list, PL_UN independent 8-byte loads in flight per thread: a skewed id distribution puts
+// most of a step's references into ONE bucket (Zipf(1.05) items: 80 k of 131 k), whose workgroup would otherwise walk its
+// 300 entries per thread one dependent L2 round trip at a time (measured: 1-3 ms per such workgroup, 15 us per step)
+constexpr int PL_UN = 8;
+template <int T, class F>
+__device__ __forceinline__ void pl_for_each(const int2* ent, int n, F f) {
+    for (int i0 = threadIdx.x; i0 < n; i0 += PL_UN * T) {
+        int2 e[PL_UN];
+#pragma unroll
+        for (int k = 0; k < PL_UN; ++k) { const int i = i0 + k * T; if (i < n) e[k] = ent[i]; }
+#pragma unroll
+        for (int k = 0; k < PL_UN; ++k) { const int i = i0 + k * T; if (i < n) f(i, e[k]); }
+    }
+}
+
+// rank of a reference among its row's references = atomicAdd(count[row], 1) -- wave-aggregated for the rows that many lanes
+// of the wavefront share: same-address LDS atomics with return serialize (a row with 12 k references of a Zipf step cost its
+// workgroup 12 k of them; the ranges that hold the head of the distribution took 1-3 ms).  Up to four rounds peel off the
+// groups of >= 4 lanes with one atomic each, the rest go one by one.
+__device__ __forceinline__ int pl_rank(int* cnt, int dn) {
+    const int lane = threadIdx.x & 63;
+    int rank = -1;
+    for (int round = 0; round < 4; ++round) {
+        const unsigned long long todo = __ballot(rank < 0);
+        if (!todo) break;
+        const int ld = __shfl(dn, __ffsll((long long)todo) - 1);
+        const bool mine = rank < 0 && dn == ld;
+        const unsigned long long grp = __ballot(mine);
+        const int gsz = __popcll(grp);
+        if (gsz < 4) break;
+        const int first = __ffsll((long long)grp) - 1;
+        int base = 0;
+        if (lane == first) base = atomicAdd(cnt + ld, gsz);
+        base = __shfl(base, first);
+        if (mine) rank = base + __popcll(grp & ((1ull << lane) - 1ull));
+    }
+    if (rank < 0) rank = atomicAdd(cnt + dn, 1);
+    return rank;
+}
+
 // One workgroup per (range, step): the same plan dedup_kernel makes for its range, on the range's own references.
-__global__ __launch_bounds__(PL_THREADS) void plan_range_kernel(PlanArgs a) {
+template <int T>
+__global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned int pl_lds[];
     const DedupArgs& d = a.d;
     const int W = (1 << a.shift) >> 5;                  // 32-bit words per bitmap
@@ -144,31 +190,32 @@ __global__ __launch_bounds__(PL_THREADS) void plan_range_kernel(PlanArgs a) {
     unsigned int* tri = pl_lds + 2 * W;
     unsigned short* prefix16 = reinterpret_cast<unsigned short*>(pl_lds + 3 * W);     // dense number of a word's first tri row
     int* lcnt = reinterpret_cast<int*>(pl_lds + 3 * W + (W + 1) / 2);                  // references per dense tri row (LDS or global)
-    __shared__ int wave_tot[PL_THREADS / 64];
+    __shared__ int wave_tot[T / 64];
     __shared__ int sh_late, sh_dense, sh_seg, list_cnt, list_base;
     const int nb = a.nru + a.nri;
     const int b = blockIdx.x;
     const int64_t s = blockIdx.y;
     const bool is_user = b < a.nru;
-    const int64_t r0 = (int64_t)(is_user ? b : b - a.nru) << a.shift;
+    const int lg = is_user ? a.lgu : a.lgi;             // local row of id: id >> lg; id of local row l: (l << lg) | bl
+    const int bl = is_user ? b : b - a.nru;
     const int* cnt = a.bcnt + s * (3 * nb + 1) + 2 * nb;
     const int lo = cnt[b], n = cnt[b + 1] - lo;
     int2* ent = a.list + s * a.nref + lo;
     unsigned int* dupout = a.dupbits ? a.dupbits + ((size_t)s * nb + b) * W : nullptr;
+    if (threadIdx.x == 0 && n > 8192) atomicMax(d.alloc + 8 * s + 6, n);      // (the host sizes the next plan's workgroups by it)
     if (n == 0) {                                       // nothing references this range in this step
-        if (dupout) for (int w = threadIdx.x; w < W; w += PL_THREADS) dupout[w] = 0u;
+        if (dupout) for (int w = threadIdx.x; w < W; w += T) dupout[w] = 0u;
         return;
     }
     int32_t* ids_out = d.ids_out + s * d.flag_stride;
     int2* refinfo = d.refinfo ? d.refinfo + s * d.flag_stride : nullptr;
-    for (int i = threadIdx.x; i < 3 * W; i += PL_THREADS) pl_lds[i] = 0u;
+    for (int i = threadIdx.x; i < 3 * W; i += T) pl_lds[i] = 0u;
     if (threadIdx.x == 0) { sh_late = 0; list_cnt = 0; }
     __syncthreads();
     // pass 1: bitmaps; the role of a reference among its row's references (first / second / later, by arrival)
     int late = 0;
-    for (int i = threadIdx.x; i < n; i += PL_THREADS) {
-        const int2 e = ent[i];
-        const int l = (int)(e.x - r0);
+    pl_for_each<T>(ent, n, [&](int i, int2 e) {
+        const int l = e.x >> lg;
         const unsigned int bit = 1u << (l & 31);
         // the bitmaps only gain bits: a plain read that already shows the bit decides like the atomic would (a hot row
         // would otherwise serialize thousands of LDS atomics on one word)
@@ -185,7 +232,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_range_kernel(PlanArgs a) {
             }
         }
         if (role) ent[i].y = (int)((uint32_t)e.y | ((uint32_t)role << 30));       // (read back by the same thread in pass 2)
-    }
+    });
     if (refinfo != nullptr && late) atomicAdd(&sh_late, late);
     __syncthreads();
     // staging plan where atomics would pile up: ranges with at least max(64, n / 512) third-or-later references
@@ -195,11 +242,11 @@ __global__ __launch_bounds__(PL_THREADS) void plan_range_kernel(PlanArgs a) {
     if (plan) {
         segstart = d.segstart + s * d.tri_stride;
         // dense numbers of the tri rows in row order: a thread owns a contiguous run of words, so its running count is the prefix
-        const int per = (W + PL_THREADS - 1) / PL_THREADS;
+        const int per = (W + T - 1) / T;
         const int w0 = threadIdx.x * per;
         int mine3 = 0;
         for (int w = w0; w < w0 + per && w < W; ++w) mine3 += __popc(tri[w]);
-        int pre = plan_scan_excl(mine3, wave_tot, ntri);
+        int pre = plan_scan_excl<T>(mine3, wave_tot, ntri);
         if (ntri > 65535) ntri = 0;                    // (ranges above 65 536 rows only: no plan, atomics)
         if (ntri) {
             if (threadIdx.x == 0) sh_dense = atomicAdd(d.alloc + 8 * s, ntri);
@@ -208,14 +255,13 @@ __global__ __launch_bounds__(PL_THREADS) void plan_range_kernel(PlanArgs a) {
             dense0 = sh_dense;
             // the rows' reference counters: LDS for up to PL_LCNT tri rows, this range's own slice of tricnt otherwise
             if (ntri > PL_LCNT) lcnt = d.tricnt + s * d.tri_stride + dense0;
-            for (int i = threadIdx.x; i < ntri; i += PL_THREADS) lcnt[i] = 0;
+            for (int i = threadIdx.x; i < ntri; i += T) lcnt[i] = 0;
             __syncthreads();
         }
     }
     // pass 2: rewritten ids, (dense row, rank) of the references that stage
-    for (int i = threadIdx.x; i < n; i += PL_THREADS) {
-        const int2 e = ent[i];
-        const int l = (int)(e.x - r0);
+    pl_for_each<T>(ent, n, [&](int, int2 e) {
+        const int l = e.x >> lg;
         const int pos = e.y & 0x3fffffff;
         const unsigned int dd = (dup[l >> 5] >> (l & 31)) & 1u;
         if (dd) {                                       // (references of unique rows keep the plain id plan_part_kernel wrote)
@@ -225,23 +271,23 @@ __global__ __launch_bounds__(PL_THREADS) void plan_range_kernel(PlanArgs a) {
             v |= (t3 ? 2u : ((uint32_t)e.y >> 30)) << 29;
             if (t3 && ntri) {
                 const int dn = (int)prefix16[l >> 5] + __popc(tw & ((1u << (l & 31)) - 1u));
-                refinfo[pos] = make_int2(dense0 + dn, atomicAdd(lcnt + dn, 1));
+                refinfo[pos] = make_int2(dense0 + dn, pl_rank(lcnt, dn));
             } else if (t3 && refinfo != nullptr) {
                 refinfo[pos] = make_int2(-1, 0);
             }
             ids_out[pos] = (int32_t)v;
         }
-    }
-    if (dupout) for (int w = threadIdx.x; w < W; w += PL_THREADS) dupout[w] = dup[w];
+    });
+    if (dupout) for (int w = threadIdx.x; w < W; w += T) dupout[w] = dup[w];
     // segment start of every tri row (its references' slots are contiguous: segstart + rank)
     if (ntri) {
         __syncthreads();                               // the counts are final
-        const int per = (ntri + PL_THREADS - 1) / PL_THREADS;
+        const int per = (ntri + T - 1) / T;
         const int d0 = threadIdx.x * per;
         int csum = 0;
         for (int k = d0; k < d0 + per && k < ntri; ++k) csum += pl_cnt(lcnt + k);
         int total_refs;
-        int run = plan_scan_excl(csum, wave_tot, total_refs);
+        int run = plan_scan_excl<T>(csum, wave_tot, total_refs);
         if (threadIdx.x == 0) sh_seg = atomicAdd(d.alloc + 8 * s + 1, total_refs);
         __syncthreads();
         run += sh_seg;
@@ -250,7 +296,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_range_kernel(PlanArgs a) {
     }
     // append the duplicated rows of this range to the step's list
     int mine = 0;
-    for (int w = threadIdx.x; w < W; w += PL_THREADS) mine += __popc(dup[w]);
+    for (int w = threadIdx.x; w < W; w += T) mine += __popc(dup[w]);
     int off = 0;
     if (mine) off = atomicAdd(&list_cnt, mine);
     __syncthreads();
@@ -262,13 +308,13 @@ __global__ __launch_bounds__(PL_THREADS) void plan_range_kernel(PlanArgs a) {
     if (mine) {
         int64_t e = s * d.list_stride + list_base + off;
         const uint32_t tag = is_user ? 0u : 0x80000000u;
-        for (int w = threadIdx.x; w < W; w += PL_THREADS) {
+        for (int w = threadIdx.x; w < W; w += T) {
             unsigned int m = dup[w];
             const unsigned int tw = tri[w];
             while (m) {
                 const int bpos = __ffs(m) - 1;
                 m &= m - 1;
-                d.dlist[e] = (uint32_t)(r0 + (int64_t)w * 32 + bpos) | tag;
+                d.dlist[e] = (uint32_t)((((int64_t)w * 32 + bpos) << lg) | bl) | tag;
                 if (d.dcnt != nullptr) {
                     int c = 0, sg = 0;
                     if (ntri && ((tw >> bpos) & 1u)) {
@@ -299,7 +345,8 @@ __global__ __launch_bounds__(PL_THREADS) void plan_range_kernel(PlanArgs a) {
 }
 
 // bit 28 on the references of step s (= 1 + blockIdx.y) whose row was duplicated in step s-1
-__global__ __launch_bounds__(PL_THREADS) void plan_urgent_kernel(PlanArgs a) {
+template <int T>
+__global__ __launch_bounds__(T) void plan_urgent_kernel(PlanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned int pl_lds[];
     const int W = (1 << a.shift) >> 5;
     const int nb = a.nru + a.nri;
@@ -311,45 +358,65 @@ __global__ __launch_bounds__(PL_THREADS) void plan_urgent_kernel(PlanArgs a) {
     const int prev_n = cnt[b + 1 - (3 * nb + 1)] - cnt[b - (3 * nb + 1)];
     if (prev_n < 2) return;                             // no duplicated row without two references
     const unsigned int* prev = a.dupbits + ((size_t)(s - 1) * nb + b) * W;
-    for (int w = threadIdx.x; w < W; w += PL_THREADS) pl_lds[w] = prev[w];
+    for (int w = threadIdx.x; w < W; w += T) pl_lds[w] = prev[w];
     __syncthreads();
-    const int64_t r0 = (int64_t)(b < a.nru ? b : b - a.nru) << a.shift;
+    const int lg = b < a.nru ? a.lgu : a.lgi;
     const int2* ent = a.list + s * a.nref + lo;
     int32_t* ids_out = a.d.ids_out + s * a.d.flag_stride;
-    for (int i = threadIdx.x; i < n; i += PL_THREADS) {
-        const int2 e = ent[i];
-        const int l = (int)(e.x - r0);
+    pl_for_each<T>(ent, n, [&](int, int2 e) {
+        const int l = e.x >> lg;
         if ((pl_lds[l >> 5] >> (l & 31)) & 1u) ids_out[e.y & 0x3fffffff] |= (1 << 28);
-    }
+    });
 }
 
 // ------------------------------------------------------------------------------------------ host side ---
-// rows per range = 1 << shift: 16 384 rows up to 64 ranges per table, then as many ranges as give a workgroup ~1 k
-// references (a range with a handful of references costs a workgroup's fixed work: 10 M x 50 M tables at 16 384 rows per
-// range are 3663 workgroups per step, 16 us; at 131 072 rows 459 and 5 us)
-int orx_plan_shift(int64_t NU, int64_t NI, int64_t nref) {
-    static const char* env = getenv("ORX_PLAN_SHIFT");      // experiments: rows per range = 1 << value
-    const int64_t rows = NU > NI ? NU : NI;
+// Geometry of the plan: buckets per table (a power of two; row r -> bucket r & (n - 1)) such that a workgroup gets ~2-4 k
+// references -- few references per bucket cost a workgroup's fixed work (10 M x 50 M tables in 16 384-row buckets were 3663
+// workgroups per step, 16 us), many make one workgroup the whole plan's critical path (a 10 000-row table in ONE bucket:
+// 131 k references, 23 us per step) -- within what the bitmaps allow (<= 2^17 rows per bucket, 2^18 above 2^27 rows).
+static int plan_buckets(int64_t rows, int64_t nref_t) {
+    if (rows <= 0 || nref_t <= 0) return 0;
     const int cap = rows > (1LL << 27) ? 18 : 17;
-    if (env) { const int v = atoi(env); return v < 10 ? 10 : (v > 18 ? 18 : v); }
-    int shift = 14;
-    const int64_t want = std::max<int64_t>(64, nref / 1024);
-    while (shift < cap && ((rows + (1LL << shift) - 1) >> shift) > want) ++shift;
-    return shift;
+    int64_t want = std::max<int64_t>((rows + (1LL << cap) - 1) >> cap, std::min<int64_t>(nref_t / 2048, rows / 64));
+    static const char* env = getenv("ORX_PLAN_SHIFT");      // experiments: at most 1 << value rows per bucket
+    if (env) want = std::max<int64_t>(want, (rows + (1LL << atoi(env)) - 1) >> atoi(env));
+    int n = 1;
+    while (n < want && n < 8192) n *= 2;
+    return n;
 }
-int orx_plan_ranges(int64_t rows, int shift) { return (int)((rows + (1LL << shift) - 1) >> shift); }
+static int ilog2(int64_t n) { int l = 0; while ((1LL << l) < n) ++l; return l; }
+static void plan_geometry(const DedupArgs& d, PlanArgs* a) {
+    a->nref = d.nU + d.nP + d.nN;
+    a->nru = plan_buckets(d.nU ? d.NU : 0, d.nU);
+    a->nri = plan_buckets((d.nP + d.nN) ? d.NI : 0, d.nP + d.nN);
+    a->lgu = ilog2(a->nru > 0 ? a->nru : 1); a->lgi = ilog2(a->nri > 0 ? a->nri : 1);
+    const int64_t per_u = a->nru ? (d.NU + a->nru - 1) / a->nru : 1, per_i = a->nri ? (d.NI + a->nri - 1) / a->nri : 1;
+    a->shift = std::max(5, ilog2(std::max(per_u, per_i)));          // bitmaps of 1 << shift bits
+}
 
-// scratch of the bucketed plan for `chunk` steps of up to nref references over tables of NU / NI rows (grow-only; sized
-// for the smallest range the plan may choose)
-int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t nref, int64_t NU, int64_t NI, bool want_dupbits) {
-    const char* env = getenv("ORX_PLAN_SHIFT");
-    const int smin = env ? std::min(14, std::max(10, atoi(env))) : 14;
-    const int nb = orx_plan_ranges(NU, smin) + orx_plan_ranges(NI, smin);
+// scratch of the bucketed plan of `chunk` steps with this geometry (grow-only)
+static int plan_ensure(orx_ctx* c, int64_t chunk, const PlanArgs& a, bool want_dupbits) {
+    const int nb = a.nru + a.nri;
     if (orx_ensure((void**)&c->d_pl_cnt, &c->d_pl_cnt_cap, (size_t)chunk * (3 * nb + 1) * sizeof(int))) return ORX_ERR_OOM;
-    if (orx_ensure((void**)&c->d_pl_list, &c->d_pl_list_cap, (size_t)chunk * nref * sizeof(int2))) return ORX_ERR_OOM;
-    // one bit per row, every range rounded up to whole words of its own
-    const size_t words = (size_t)((NU + NI) / 32) + 2 * ((size_t)1 << 13) + (size_t)nb;
+    if (orx_ensure((void**)&c->d_pl_list, &c->d_pl_list_cap, (size_t)chunk * a.nref * sizeof(int2))) return ORX_ERR_OOM;
+    const size_t words = (size_t)nb * ((1u << a.shift) >> 5);
     if (want_dupbits && orx_ensure((void**)&c->d_dupbits, &c->d_dupbits_cap, (size_t)chunk * words * sizeof(unsigned int))) return ORX_ERR_OOM;
+    return ORX_OK;
+}
+
+// pre-sizing (orx_pairwise_reserve and friends keep allocations out of a timed call): the geometries of a pairwise step
+// (B user, 2 B item references), a pointwise step (B + B) and an id-list apply (B item references) over these tables
+int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t B, int64_t NU, int64_t NI, bool want_dupbits) {
+    const int64_t shapes[3][3] = {{B, B, B}, {B, B, 0}, {0, B, 0}};
+    for (const auto& sh : shapes) {
+        DedupArgs d;
+        memset(&d, 0, sizeof(d));
+        d.nU = sh[0]; d.nP = sh[1]; d.nN = sh[2]; d.NU = NU; d.NI = NI;
+        PlanArgs a;
+        plan_geometry(d, &a);
+        const int rc = plan_ensure(c, chunk, a, want_dupbits);
+        if (rc != ORX_OK) return rc;
+    }
     return ORX_OK;
 }
 
@@ -358,13 +425,11 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
     ProfScope ps(ctx, ORX_K_DEDUP);
     PlanArgs a;
     a.d = d;
-    a.nref = d.nU + d.nP + d.nN;
-    a.shift = orx_plan_shift(d.nU ? d.NU : 0, (d.nP + d.nN) ? d.NI : 0, a.nref);
-    a.nru = d.nU ? orx_plan_ranges(d.NU, a.shift) : 0;
-    a.nri = (d.nP + d.nN) ? orx_plan_ranges(d.NI, a.shift) : 0;
+    plan_geometry(d, &a);
     const int nb = a.nru + a.nri;
     if (nb == 0 || a.nref == 0 || kc == 0) return ORX_OK;
     ORX_ARG(a.nref < (1LL << 30) && kc < 65536, "plan: too many references per step (%lld) or steps (%lld)", (long long)a.nref, (long long)kc);
+    { const int rc = plan_ensure(ctx, kc, a, keep_dupbits); if (rc != ORX_OK) return rc; }     // (a no-op after a reserve)
     a.bcnt = ctx->d_pl_cnt; a.list = ctx->d_pl_list;
     a.dupbits = keep_dupbits ? ctx->d_dupbits : nullptr;
     const char* ml = getenv("ORX_PLAN_MIN_LATE");      // experiments
@@ -376,14 +441,18 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
     if (!attr_set) {
         ORX_HIP(hipFuncSetAttribute((const void*)plan_part_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         ORX_HIP(hipFuncSetAttribute((const void*)plan_part_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        ORX_HIP(hipFuncSetAttribute((const void*)plan_range_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        ORX_HIP(hipFuncSetAttribute((const void*)plan_range_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        ORX_HIP(hipFuncSetAttribute((const void*)plan_range_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
         attr_set = true;
     }
     ORX_LAUNCH(ctx, (plan_part_kernel<false>), gp, dim3(PL_THREADS), hist_bytes, a);
     ORX_LAUNCH(ctx, (plan_part_kernel<true>), gp, dim3(PL_THREADS), hist_bytes, a);
     const int W = (1 << a.shift) >> 5;
     const size_t lds = (size_t)(3 * W + (W + 1) / 2) * 4 + (size_t)PL_LCNT * 4;
-    ORX_LAUNCH(ctx, plan_range_kernel, dim3((unsigned)nb, (unsigned)kc), dim3(PL_THREADS), lds, a);
+    // workgroups of 1024 threads where the previous plan met a bucket with more than 16 k references (skewed ids: the head of
+    // a Zipf distribution puts 100 k of a step's 131 k item references into one range, 0.7 ms for 256 threads)
+    if (ctx->plan_big) ORX_LAUNCH(ctx, plan_range_kernel<1024>, dim3((unsigned)nb, (unsigned)kc), dim3(1024), lds, a);
+    else ORX_LAUNCH(ctx, plan_range_kernel<256>, dim3((unsigned)nb, (unsigned)kc), dim3(256), lds, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -393,13 +462,11 @@ int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc) {
     if (kc < 2) return ORX_OK;
     PlanArgs a;
     a.d = d;
-    a.nref = d.nU + d.nP + d.nN;
-    a.shift = orx_plan_shift(d.nU ? d.NU : 0, (d.nP + d.nN) ? d.NI : 0, a.nref);
-    a.nru = d.nU ? orx_plan_ranges(d.NU, a.shift) : 0;
-    a.nri = (d.nP + d.nN) ? orx_plan_ranges(d.NI, a.shift) : 0;
+    plan_geometry(d, &a);
     a.bcnt = ctx->d_pl_cnt; a.list = ctx->d_pl_list; a.dupbits = ctx->d_dupbits; a.min_late = -1;
     const int W = (1 << a.shift) >> 5;
-    ORX_LAUNCH(ctx, plan_urgent_kernel, dim3((unsigned)(a.nru + a.nri), (unsigned)(kc - 1)), dim3(PL_THREADS), (size_t)W * 4, a);
+    if (ctx->plan_big) ORX_LAUNCH(ctx, plan_urgent_kernel<1024>, dim3((unsigned)(a.nru + a.nri), (unsigned)(kc - 1)), dim3(1024), (size_t)W * 4, a);
+    else ORX_LAUNCH(ctx, plan_urgent_kernel<256>, dim3((unsigned)(a.nru + a.nri), (unsigned)(kc - 1)), dim3(256), (size_t)W * 4, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

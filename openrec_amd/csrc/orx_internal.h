@@ -57,6 +57,7 @@ struct orx_ctx {
     // bucketed plan (kernels_plan.hip): references per (step, row range), scatter cursors, bucket lists
     int* d_pl_cnt = nullptr;   size_t d_pl_cnt_cap = 0;          // [K][3 ranges + 1]: counts, cursors, offsets
     int2* d_pl_list = nullptr; size_t d_pl_list_cap = 0;         // [K][references per step] (id, output position | role << 30)
+    bool plan_big = false;                                       // the last plan met a bucket of > 16 k references: 1024-thread workgroups
     int* h_plan = nullptr;                                       // pinned host mirror of the per-step plan counters
     size_t h_plan_cap = 0;
     hipEvent_t plan_ev = nullptr;                                // "plan counters have arrived on the host"
@@ -340,9 +341,7 @@ int orx_launch_dup_apply(orx_ctx* ctx, int optkind, const PairArgs& a);
 int orx_launch_urgent(orx_ctx* ctx, const DedupArgs& a, int64_t K);
 // bucketed plan (kernels_plan.hip): same outputs as orx_launch_dedup (+ orx_launch_urgent) with `d` filled the same way
 bool orx_plan_v2(bool role_bits);
-int orx_plan_shift(int64_t NU, int64_t NI, int64_t nref);
-int orx_plan_ranges(int64_t rows, int shift);
-int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t nref, int64_t NU, int64_t NI, bool want_dupbits);
+int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t B, int64_t NU, int64_t NI, bool want_dupbits);
 int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupbits);
 int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc);
 int orx_fused_can_inline_apply(int D);

@@ -1,10 +1,18 @@
 #!/usr/bin/env python3
-"""Boils the rocprofv3 output of scripts/collect_profiles.sh down to the small files kept under profiles/."""
-import csv, glob, json, os, sys
+"""Boils the rocprofv3 output of scripts/collect_profiles.sh down to the small files kept under profiles/:
+<tag>_<workload>_kernel_stats.csv (the rows of our kernels), <tag>_<workload>_bench.json, <tag>_pmc_summary.csv and
+<tag>_traffic.json -- HBM bytes per launch of the dominant kernel of each workload, stamped with the hash of the sources
+the library was built from (bench.py reports `roofline.traffic` only when that hash is the running build's)."""
+import csv, glob, json, os, re, sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openrec_amd.build import source_hash  # noqa: E402
 
 tag = sys.argv[1]
 out = "gpurun_out"
+OURS = ("fused", "plan_", "dup_apply", "dedup", "urgent", "loss_reduce", "hot_reduce", "censor", "point_", "dense_", "gemm", "interact",
+        "adam", "apply_rows", "gather", "dlrm", "act_bwd", "colsum", "copy2d", "score", "shard", "sample", "init_uniform")
 
 
 def find(d, suffix):
@@ -12,36 +20,46 @@ def find(d, suffix):
     return hits[0] if hits else None
 
 
-stats = find(f"prof_{tag}", "kernel_stats.csv")
-if stats:
-    rows = list(csv.reader(open(stats)))
-    with open(f"{out}/{tag}_bench_kernel_stats.csv", "w", newline="") as f:
-        csv.writer(f).writerows(rows)
-trace = find(f"prof_{tag}", "kernel_trace.csv")
-if trace:
-    r = csv.DictReader(open(trace))
-    keep = [row for row in r if "orx" in row["Kernel_Name"] or "fused" in row["Kernel_Name"] or "dedup" in row["Kernel_Name"]
-            or "urgent" in row["Kernel_Name"] or "dup_apply" in row["Kernel_Name"]][:40]
-    if keep:
-        with open(f"{out}/{tag}_bench_kernel_trace_head.csv", "w", newline="") as f:
-            w = csv.DictWriter(f, fieldnames=list(keep[0].keys())); w.writeheader(); w.writerows(keep)
-
-pmc = defaultdict(lambda: defaultdict(list))
-for d, name in ((f"pmc_fetch_{tag}", "FETCH_SIZE"), (f"pmc_write_{tag}", "WRITE_SIZE")):
-    p = find(d, "counter_collection.csv")
-    if not p:
-        continue
-    for row in csv.DictReader(open(p)):
-        if row["Counter_Name"] == name:
-            pmc[row["Kernel_Name"]][name].append(float(row["Counter_Value"]))
-if pmc:
-    with open(f"{out}/{tag}_pmc_fused_summary.csv", "w", newline="") as f:
+workloads = sorted({re.match(rf"prof_{tag}_(.+)", os.path.basename(d)).group(1) for d in glob.glob(f"{out}/prof_{tag}_*")})
+traffic = {}
+pmc_rows = []
+for wl in workloads:
+    stats = find(f"prof_{tag}_{wl}", "kernel_stats.csv")
+    if stats:
+        rows = list(csv.reader(open(stats)))
+        keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in OURS)][:24]
+        with open(f"{out}/{tag}_{wl}_kernel_stats.csv", "w", newline="") as f:
+            csv.writer(f).writerows(keep)
+    pmc = defaultdict(lambda: defaultdict(list))
+    for d, name in ((f"pmcf_{tag}_{wl}", "FETCH_SIZE"), (f"pmcw_{tag}_{wl}", "WRITE_SIZE")):
+        p = find(d, "counter_collection.csv")
+        if not p:
+            continue
+        for row in csv.DictReader(open(p)):
+            if row["Counter_Name"] == name:
+                pmc[row["Kernel_Name"]][name].append(float(row["Counter_Value"]))
+    best = None
+    for k, v in sorted(pmc.items()):
+        fe, wr = v.get("FETCH_SIZE", []), v.get("WRITE_SIZE", [])
+        if not fe or not wr or not any(x in k for x in OURS):
+            continue
+        fm, wm = sum(fe) / len(fe), sum(wr) / len(wr)
+        b = (2 * fm + wm) * 1024          # MI355X_MICROARCH.md (HBM): FETCH_SIZE counts half of a wide read on gfx950
+        pmc_rows.append([wl, k[:90], max(len(fe), len(wr)), f"{fm:.1f}", f"{wm:.1f}", f"{b:.0f}"])
+        if ("fused_kernel" in k or "point_fused" in k) and (best is None or len(fe) > best[0]):
+            best = (len(fe), k, b)
+    if best:
+        traffic[wl] = {"kernel": best[1][:90], "bytes_per_launch": best[2]}
+if pmc_rows:
+    with open(f"{out}/{tag}_pmc_summary.csv", "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "dispatches", "FETCH_SIZE_KiB_mean", "WRITE_SIZE_KiB_mean", "hbm_bytes_per_launch=(2*FETCH+WRITE)*1024"])
-        for k, v in sorted(pmc.items()):
-            fe, wr = v.get("FETCH_SIZE", []), v.get("WRITE_SIZE", [])
-            fm = sum(fe) / len(fe) if fe else float("nan"); wm = sum(wr) / len(wr) if wr else float("nan")
-            w.writerow([k[:100], max(len(fe), len(wr)), f"{fm:.1f}", f"{wm:.1f}", f"{(2 * fm + wm) * 1024:.0f}"])
-            if "fused_kernel<16" in k and fe and wr:
-                json.dump({"bpr_d64_sgd": (2 * fm + wm) * 1024}, open(f"{out}/{tag}_traffic.json", "w"))
-print(open(f"{out}/{tag}_bench.json").read() if os.path.exists(f"{out}/{tag}_bench.json") else "no bench line")
+        w.writerow(["workload", "kernel", "dispatches", "FETCH_SIZE_KiB_mean", "WRITE_SIZE_KiB_mean", "hbm_bytes_per_launch=(2*FETCH+WRITE)*1024"])
+        w.writerows(pmc_rows)
+if traffic:
+    json.dump({"tag": tag, "source_hash": source_hash(), "workloads": traffic,
+               "_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (the x2 is the gfx950 "
+                        "correction of MI355X_MICROARCH.md, HBM section, re-checked on scratch/ubench.hip in round 1)"},
+              open(f"{out}/{tag}_traffic.json", "w"), indent=1)
+for f in sorted(glob.glob(f"{out}/{tag}_*_bench.json")):
+    line = open(f).read().strip()
+    print(os.path.basename(f), line[:330])
