@@ -8,6 +8,8 @@
 
 #include "orx_internal.h"
 
+#include <functional>
+
 // ----------------------------------------------------------------- errors ---
 static thread_local char g_err[1024] = "";
 
@@ -603,7 +605,7 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
 // duplicate detection, roles, staging plan, and the host-side decisions read back from it.
 int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,
                  int64_t nU, int64_t nP, int64_t nN, int64_t kc, int64_t B, bool role_bits, bool inline_apply, bool staging,
-                 const PairPlan& plan, ExactChunk* out) {
+                 const PairPlan& plan, ExactChunk* out, const std::function<int()>* while_waiting) {
     *out = ExactChunk();
     // duplicate detection for every step of the chunk, on the id arrays alone
     DedupArgs d;
@@ -638,6 +640,9 @@ int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
         ORX_HIP(hipMemcpyAsync(c->h_plan, c->d_alloc, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // ([5] = duplicated rows)
         ORX_HIP(hipEventRecord(c->plan_ev, c->stream));
         if (inline_apply) CHECK(orx_launch_plan_urgent(c, d, kc));
+        // work that does not depend on the counters goes to the device before the host blocks on them (the first fused launch
+        // of the chunk: the device would otherwise idle through the host's wake-up and the first launch's latency)
+        if (while_waiting && *while_waiting) CHECK((*while_waiting)());
         ORX_HIP(hipEventSynchronize(c->plan_ev));
         dc_v2.resize((size_t)kc);
         int big = 0;
@@ -818,10 +823,38 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
         const int64_t kc = (K - s0 < chunk) ? (K - s0) : chunk;
         bool hot = false, use_stage = false, dense_dups = false;
         int tree_levels = 0;
+        // arguments of step i of the chunk, and its fused launch
+        auto launch_step = [&](int64_t i, bool stage_views, bool with_apply) -> int {
+            const int64_t s = s0 + i;
+            if (mode == MODE_EXACT) {       // ids rewritten by the plan (duplicate flag in bit 31)
+                a.uid = c->d_ids2 + (size_t)i * 3 * Bp; a.pid = a.uid + Bp; a.nid = a.uid + 2 * Bp;
+            } else {
+                a.uid = du + s * ds; a.pid = dp + s * ds; a.nid = dn + s * ds;
+            }
+            orx_exact_step_views(c, plan, i, B, U->dim, stage_views, &a);
+            a.partial = c->d_partial + (size_t)i * nw * 2;
+            a.epoch = ++c->epoch;           // one epoch per step: ready flags and censor side marks are tagged with it
+            if (lazy_adam) { opt->t += 1; a.step_t = (int)opt->t; }
+            if (with_apply && i > 0) {    // this launch also applies the duplicated rows of step i-1
+                // one lane group per duplicated row in a single pass for the usual ~0.15*B duplicated rows
+                // (the count lives in device memory; surplus blocks exit, a larger count grid-strides)
+                a.n_apply_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(16, (B / 4) / (1024 / U->dim) + 1));
+                a.prev_dlist = c->d_dlist + (size_t)(i - 1) * list_stride; a.prev_dcount = c->d_dcount + (i - 1);
+            } else {
+                a.n_apply_blocks = 0; a.prev_dlist = nullptr; a.prev_dcount = nullptr;
+            }
+            return orx_launch_fused(c, model, opt->kind, mode, a);
+        };
+        bool first_launched = false;
         if (mode == MODE_EXACT) {
             ExactChunk ck;
+            // With the bucketed plan the chunk's FIRST fused launch goes out before the host waits for the plan's counters:
+            // step 0 never carries apply blocks, and the kernel built with the staging bookkeeping is right whether or not
+            // any range made a staging plan (references without one carry (-1, 0) and use atomics).
+            const std::function<int()> early = [&]() -> int { first_launched = true; return launch_step(0, staging, false); };
+            const bool can_early = orx_plan_v2(role_bits) && !censor && getenv("ORX_PLAN_NO_EARLY") == nullptr;
             CHECK(orx_exact_plan_chunk(c, U, V, du + s0 * ds, dp + s0 * ds, dn + s0 * ds, ds, B, B, B, kc, B, role_bits, inline_apply, staging,
-                                       plan, &ck));
+                                       plan, &ck, can_early ? &early : nullptr));
             hot = ck.hot; use_stage = ck.use_stage; dense_dups = ck.dense_dups; tree_levels = ck.tree_levels;
         }
         const bool inl = inline_apply && !hot && !dense_dups;
@@ -841,24 +874,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
         }
         for (int64_t i = 0; i < kc; ++i) {
             const int64_t s = s0 + i;
-            if (mode == MODE_EXACT) {       // ids rewritten by dedup (duplicate flag in bit 31)
-                a.uid = c->d_ids2 + (size_t)i * 3 * Bp; a.pid = a.uid + Bp; a.nid = a.uid + 2 * Bp;
-            } else {
-                a.uid = du + s * ds; a.pid = dp + s * ds; a.nid = dn + s * ds;
-            }
-            orx_exact_step_views(c, plan, i, B, U->dim, use_stage, &a);
-            a.partial = c->d_partial + (size_t)i * nw * 2;
-            a.epoch = ++c->epoch;           // one epoch per step: ready flags and censor side marks are tagged with it
-            if (lazy_adam) { opt->t += 1; a.step_t = (int)opt->t; }
-            if (inl && i > 0) {    // this launch also applies the duplicated rows of step i-1
-                // one lane group per duplicated row in a single pass for the usual ~0.15*B duplicated rows
-                // (the count lives in device memory; surplus blocks exit, a larger count grid-strides)
-                a.n_apply_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(16, (B / 4) / (1024 / U->dim) + 1));
-                a.prev_dlist = c->d_dlist + (size_t)(i - 1) * list_stride; a.prev_dcount = c->d_dcount + (i - 1);
-            } else {
-                a.n_apply_blocks = 0; a.prev_dlist = nullptr; a.prev_dcount = nullptr;
-            }
-            CHECK(orx_launch_fused(c, model, opt->kind, mode, a));
+            if (!(i == 0 && first_launched)) CHECK(launch_step(i, use_stage, inl));
             for (int l = 0; l < tree_levels; ++l) CHECK(orx_launch_hot_reduce(c, a, l));
             if (mode == MODE_EXACT && (!inl || i == kc - 1)) CHECK(orx_launch_dup_apply(c, opt->kind, a));
             if (mode == MODE_ACCUM) {   // Adam: dense-decay sweep of TF 2.0 over the whole tables

@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 
 #include <cstdarg>
+#include <functional>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -328,7 +329,7 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
                       bool inline_apply, bool staging, int nb_total, int nw, PairPlan* plan);
 int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,
                          int64_t nU, int64_t nP, int64_t nN, int64_t kc, int64_t B, bool role_bits, bool inline_apply, bool staging,
-                         const PairPlan& plan, ExactChunk* out);
+                         const PairPlan& plan, ExactChunk* out, const std::function<int()>* while_waiting = nullptr);
 void orx_exact_step_views(orx_ctx* c, const PairPlan& plan, int64_t i, int64_t B, int D, bool use_stage, PairArgs* a);
 int orx_launch_rows_planned(orx_ctx* ctx, int optkind, const RowsArgs& a);
 // K id lists of n local rows each (ids [K][n], < 0 = padding) against ONE table: plan once (duplicate roles, staging
