@@ -361,6 +361,13 @@ int orx_shard_bucket(orx_ctx* ctx, const int32_t* ids, int64_t n, int32_t world,
 int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const float* rows_in, const int32_t* u_loc,
                     const int32_t* slot, int64_t T, int64_t row_stride, int64_t B_global, float margin, int flags,
                     float* gu, float* send_g, double* loss_l2_accum);
+/* orx_shard_grads with SGD's apply of the local user rows folded in (row-sharded BPR / UCML step, phases 4 + 5 of
+ * openrec_amd/sharded.py; the reference's single-process apply is tf2_examples/bpr_citeulike.py:38): a user row referenced
+ * once in the step is updated in place; the references of a duplicated row leave gu[t] and u_apply[t] = local row for
+ * orx_apply_rows_flagged (u_apply[t] = -1 elsewhere).  dup_u[T]: orx_rows_dupflags of u_loc. */
+int orx_shard_grads_sgd(orx_ctx* ctx, int model, orx_opt* opt, orx_table* user, const float* rows_in, const int32_t* u_loc,
+                        const int32_t* slot, const uint8_t* dup_u, int64_t T, int64_t row_stride, int64_t B_global,
+                        float margin, int flags, float* gu, int32_t* u_apply, float* send_g, double* loss_l2_accum);
 
 /* ---- device-time sampling of the kernels (HIP events on the ctx stream) --- */
 int orx_prof_enable(orx_ctx* ctx, int on);

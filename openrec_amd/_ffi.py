@@ -92,6 +92,7 @@ SIGNATURES = {
     "orx_shard_request_steps": (c_int, [_p, _ip, c_int64, c_int64, c_int32, c_int32, _ip, _ip, _ip, _ip, _ip]),
     "orx_shard_bucket": (c_int, [_p, _ip, c_int64, c_int32, c_int32, _ip, _ip, _ip, _ip]),
     "orx_shard_grads": (c_int, [_p, c_int, _p, _fp, _ip, _ip, c_int64, c_int64, c_int64, c_float, c_int, _fp, _fp, _p]),
+    "orx_shard_grads_sgd": (c_int, [_p, c_int, _p, _p, _fp, _ip, _ip, _p, c_int64, c_int64, c_int64, c_float, c_int, _fp, _ip, _fp, _p]),
     "orx_prof_enable": (c_int, [_p, c_int]),
     "orx_prof_reset": (c_int, [_p]),
     "orx_prof_get": (c_int, [_p, c_int, POINTER(c_double), POINTER(c_int64)]),

@@ -609,6 +609,33 @@ extern "C" int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const f
     return ORX_OK;
 }
 
+// orx_shard_grads with the SGD apply of the (local) user rows folded in: rows referenced once in the step are updated in
+// place by the gradient kernel, the references of duplicated rows leave (u_apply[t] = local row, gu[t] = gradient) for
+// orx_apply_rows_flagged; u_apply[t] = -1 everywhere else.  dup_u: the flags orx_rows_dupflags made for u_loc.
+extern "C" int orx_shard_grads_sgd(orx_ctx* ctx, int model, orx_opt* opt, orx_table* user, const float* rows_in, const int32_t* u_loc,
+                                   const int32_t* slot, const uint8_t* dup_u, int64_t T, int64_t row_stride, int64_t B_global,
+                                   float margin, int flags, float* gu, int32_t* u_apply, float* send_g, double* loss_l2_accum) {
+    ORX_ARG(ctx && opt && user && rows_in && u_loc && slot && dup_u && gu && u_apply && send_g, "orx_shard_grads_sgd: NULL argument");
+    ORX_ARG(opt->kind == ORX_SGD, "orx_shard_grads_sgd: the folded apply is SGD's (Adagrad / Adam sum duplicates first: orx_shard_grads + orx_apply_rows)");
+    ORX_ARG(model == ORX_BPR || model == ORX_UCML, "orx_shard_grads_sgd: unknown model %d", model);
+    ORX_ARG(row_stride > user->dim && B_global > 0, "orx_shard_grads_sgd: row_stride must leave room for the bias column");
+    CHECK(orx_table_sync(user));
+    if (T == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(ctx->device));
+    ShardGradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.U = user->w; a.rows_in = rows_in; a.u_loc = u_loc; a.slot = slot; a.gu = gu; a.send_g = send_g;
+    a.T = T; a.D = user->dim; a.DS = (int)row_stride;
+    a.invB = 1.0f / (float)B_global; a.margin = margin; a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f;
+    a.fu = dup_u; a.Uw = user->w; a.lr = opt->lr; a.u_apply = u_apply;
+    ENSURE(ctx->d_partial, ctx->d_partial_cap, (size_t)(T + 4) * 2 * sizeof(float));
+    a.partial = ctx->d_partial;
+    int nw = 0;
+    CHECK(orx_launch_shard_grads(ctx, model, a, &nw));
+    if (loss_l2_accum) CHECK(orx_launch_loss_accumulate(ctx, ctx->d_partial, nw, loss_l2_accum));
+    return ORX_OK;
+}
+
 // ------------------------------------------------------------- ranking metrics ---
 extern "C" int orx_rank_metrics(orx_ctx* c, int kind, orx_table* U, orx_table* V, orx_table* b, orx_table* w,
                                 const int32_t* uid, const float* pred, const uint8_t* pos_mask, const uint8_t* excl_mask,

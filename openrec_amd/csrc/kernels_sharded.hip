@@ -391,23 +391,34 @@ int orx_launch_loss_accumulate(orx_ctx* ctx, const float* partial, int nwaves, d
 // atomics per wavefront.  The order inside a bucket is arbitrary (it only
 // changes fp32 summation order downstream).
 __device__ __forceinline__ int claim_slot(int dest, bool active, int world, int* counters) {
-    int slot = -1;
+    // Two levels: the wavefronts of a workgroup claim their places inside the WORKGROUP's share with LDS atomics, one lane per
+    // destination then claims the share with ONE global atomic.  Same-address global atomics serialize at ~100 ns: with one
+    // per wavefront and destination, a step's 1024 wavefronts of a one-rank world queued 200 us on a single counter.
+    __shared__ int blk_cnt[64], blk_base[64];          // (world <= 64)
     const int lane = threadIdx.x & 63;
+    for (int k = threadIdx.x; k < world; k += blockDim.x) blk_cnt[k] = 0;
+    __syncthreads();
+    int slot = -1;
     for (int k = 0; k < world; ++k) {
         const unsigned long long m = __ballot(active && dest == k);
         if (m == 0ull) continue;
         const int leader = __ffsll((long long)m) - 1;
         int base = 0;
-        if (lane == leader) base = atomicAdd(counters + k, __popcll(m));
+        if (lane == leader) base = atomicAdd(&blk_cnt[k], __popcll(m));
         base = __shfl(base, leader);
         if (active && dest == k) slot = base + __popcll(m & ((1ull << lane) - 1ull));
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < world; k += blockDim.x) blk_base[k] = blk_cnt[k] ? atomicAdd(counters + k, blk_cnt[k]) : 0;
+    __syncthreads();
+    if (active) slot += blk_base[dest];
+    __syncthreads();                                     // (the arrays are reused by the next call)
     return slot;
 }
 
 
 // 1. route each triplet to the owner of its user row (rank = uid % world)
-__global__ __launch_bounds__(256) void shard_route_kernel(RouteArgs a) {
+__global__ __launch_bounds__(1024) void shard_route_kernel(RouteArgs a) {
     const int64_t step = blockIdx.y;                    // K-step launch: one grid row per step
     a.uid += step * a.id_stride; a.pid += step * a.id_stride; a.nid += step * a.id_stride;
     a.send += step * (int64_t)a.world * a.cap * 3; a.counters += step * a.world;
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(256) void shard_route_kernel(RouteArgs a) {
 
 
 // 2. request the two item rows of every live triplet from their owners (rank = id % world)
-__global__ __launch_bounds__(256) void shard_request_kernel(RequestArgs a) {
+__global__ __launch_bounds__(1024) void shard_request_kernel(RequestArgs a) {
     const int64_t step = blockIdx.y;                    // K-step launch: one grid row per step
     a.trip += step * a.T * 3; a.send_ids += step * (int64_t)a.world * a.cap; a.slot += step * 2 * a.T;
     a.u_loc += step * a.T; a.counters += step * a.world;
@@ -458,7 +469,7 @@ __global__ void shard_localize_kernel(const int32_t* ids, int64_t n, int world, 
 
 // 4. per live triplet: user row straight from the local shard, item rows from the receive
 // buffer; gradients of the item rows go straight into the send buffer of the return trip.
-template <int LPR, int MODEL>
+template <int LPR, int MODEL, bool APPLY = false>
 __global__ __launch_bounds__(256) void shard_grads_kernel(ShardGradArgs a) {
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
@@ -475,6 +486,7 @@ __global__ __launch_bounds__(256) void shard_grads_kernel(ShardGradArgs a) {
             f4 z; z.x = z.y = z.z = z.w = 0.0f;                     // its surviving request gets a zero gradient
             if (sp >= 0) { *reinterpret_cast<f4*>(a.send_g + (int64_t)sp * a.DS + 4 * sub) = z; if (sub == 0) a.send_g[(int64_t)sp * a.DS + D] = 0.f; }
             if (sn >= 0) { *reinterpret_cast<f4*>(a.send_g + (int64_t)sn * a.DS + 4 * sub) = z; if (sub == 0) a.send_g[(int64_t)sn * a.DS + D] = 0.f; }
+            if (APPLY && sub == 0) a.u_apply[t] = -1;
             continue;
         }
         const f4 ru = *reinterpret_cast<const f4*>(a.U + (size_t)ul * D + 4 * sub);
@@ -488,7 +500,16 @@ __global__ __launch_bounds__(256) void shard_grads_kernel(ShardGradArgs a) {
         if (sub == 0) loss_acc += term;
         f4 gu, gp, gn; float gbp, gbn;
         row_grads<MODEL>(ru, rp, rn, g, a.l2w, gu, gp, gn, gbp, gbn);
-        *reinterpret_cast<f4*>(a.gu + t * D + 4 * sub) = gu;
+        if (APPLY) {
+            // SGD: a user row referenced once in this rank's step is updated right here (nobody else reads or writes it);
+            // the references of a duplicated row leave their gradients for the flagged apply (atomics), as before
+            const bool dup = a.fu[t] != 0;
+            if (!dup) *reinterpret_cast<f4*>(a.Uw + (size_t)ul * D + 4 * sub) = ru - a.lr * gu;
+            else *reinterpret_cast<f4*>(a.gu + t * D + 4 * sub) = gu;
+            if (sub == 0) a.u_apply[t] = dup ? ul : -1;
+        } else {
+            *reinterpret_cast<f4*>(a.gu + t * D + 4 * sub) = gu;
+        }
         *reinterpret_cast<f4*>(a.send_g + (int64_t)sp * a.DS + 4 * sub) = gp;
         *reinterpret_cast<f4*>(a.send_g + (int64_t)sn * a.DS + 4 * sub) = gn;
         if (sub == 0) { a.send_g[(int64_t)sp * a.DS + D] = gbp; a.send_g[(int64_t)sn * a.DS + D] = gbn; }
@@ -503,20 +524,20 @@ __global__ __launch_bounds__(256) void shard_grads_kernel(ShardGradArgs a) {
 
 int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a, int64_t K) {
     if (a.B == 0 || K == 0) return ORX_OK;
-    ORX_LAUNCH(ctx, shard_route_kernel, dim3((unsigned)((a.B + 255) / 256), (unsigned)K), dim3(256), 0, a);
+    ORX_LAUNCH(ctx, shard_route_kernel, dim3((unsigned)((a.B + 1023) / 1024), (unsigned)K), dim3(1024), 0, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
 
 int orx_launch_shard_request(orx_ctx* ctx, const RequestArgs& a, int64_t K) {
     if (a.T == 0 || K == 0) return ORX_OK;
-    ORX_LAUNCH(ctx, shard_request_kernel, dim3((unsigned)((a.T + 255) / 256), (unsigned)K), dim3(256), 0, a);
+    ORX_LAUNCH(ctx, shard_request_kernel, dim3((unsigned)((a.T + 1023) / 1024), (unsigned)K), dim3(1024), 0, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
 
 // generic request plan: every live id (>= 0) claims a slot in the bucket of its owner (id % world)
-__global__ __launch_bounds__(256) void shard_bucket_kernel(const int32_t* ids, int64_t n, int world, int cap, int32_t* send_ids,
+__global__ __launch_bounds__(1024) void shard_bucket_kernel(const int32_t* ids, int64_t n, int world, int cap, int32_t* send_ids,
                                                            int32_t* slot, int* counters, int* overflow) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool inb = i < n;
@@ -535,7 +556,7 @@ __global__ __launch_bounds__(256) void shard_bucket_kernel(const int32_t* ids, i
 int orx_launch_shard_bucket(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int cap, int32_t* send_ids, int32_t* slot,
                             int* counters, int* overflow) {
     if (n == 0) return ORX_OK;
-    ORX_LAUNCH(ctx, shard_bucket_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ids, n, world, cap, send_ids, slot, counters, overflow);
+    ORX_LAUNCH(ctx, shard_bucket_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, ids, n, world, cap, send_ids, slot, counters, overflow);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -554,8 +575,10 @@ int orx_launch_shard_grads(orx_ctx* ctx, int model, const ShardGradArgs& a, int*
     ORX_ARG(lpr != 0 && a.DS % 4 == 0, "sharded fast path: dim must be 16/32/64/128/256 (got %d)", a.D);
     const dim3 g(grid_for_rows(lpr, a.T));
     if (nwaves) *nwaves = (int)g.x * 4;
-#define SG(L) (model == ORX_BPR ? (void)ORX_LAUNCH(ctx, (shard_grads_kernel<L, ORX_BPR>), g, dim3(256), 0, a) \
-                                : (void)ORX_LAUNCH(ctx, (shard_grads_kernel<L, ORX_UCML>), g, dim3(256), 0, a))
+#define SG(L) do { if (a.fu) { if (model == ORX_BPR) ORX_LAUNCH(ctx, (shard_grads_kernel<L, ORX_BPR, true>), g, dim3(256), 0, a); \
+                                 else ORX_LAUNCH(ctx, (shard_grads_kernel<L, ORX_UCML, true>), g, dim3(256), 0, a); } \
+                    else if (model == ORX_BPR) ORX_LAUNCH(ctx, (shard_grads_kernel<L, ORX_BPR>), g, dim3(256), 0, a); \
+                    else ORX_LAUNCH(ctx, (shard_grads_kernel<L, ORX_UCML>), g, dim3(256), 0, a); } while (0)
     switch (lpr) { case 4: SG(4); break; case 8: SG(8); break; case 16: SG(16); break; case 32: SG(32); break; default: SG(64); break; }
 #undef SG
     ORX_HIP(hipGetLastError());

@@ -434,6 +434,9 @@ struct ShardGradArgs {
     int64_t T; int D; int DS;
     float invB; float margin; float l2w;
     float* partial;
+    // SGD with the user apply folded in (orx_shard_grads_sgd): duplicate flags of the u_loc list, writable table, rate,
+    // and the id list left for the flagged apply of the duplicated rows (-1: already applied)
+    const unsigned char* fu; float* Uw; float lr; int32_t* u_apply;
 };
 
 int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a, int64_t K = 1);

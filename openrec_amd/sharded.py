@@ -155,6 +155,13 @@ class HipBackend:
                                                  slot.data_ptr(), u_loc.numel(), rows_in.shape[1], b_global, margin, 0,
                                                  gu.data_ptr(), send_g.data_ptr(), accum.data_ptr()))
 
+    def shard_grads_sgd(self, model, user, rows_in, u_loc, slot, dup_u, b_global, margin, gu, u_apply, send_g, accum):
+        """gradients + SGD apply of the user rows referenced once (the duplicated ones are left in gu / u_apply)"""
+        mid = {"bpr": self._ffi.ORX_BPR, "ucml": self._ffi.ORX_UCML}[model]
+        self._ffi.check(self.lib.orx_shard_grads_sgd(self.ctx._h, mid, self.opt._h, user._h, rows_in.data_ptr(), u_loc.data_ptr(),
+                                                     slot.data_ptr(), dup_u.data_ptr(), u_loc.numel(), rows_in.shape[1], b_global, margin, 0,
+                                                     gu.data_ptr(), u_apply.data_ptr(), send_g.data_ptr(), accum.data_ptr()))
+
     def stream_ctx(self):
         return torch.cuda.stream(self.stream)
 
@@ -219,7 +226,7 @@ class ShardedPairwise:
                 cap1=cap1, T=T, cap2=cap2, M=M,
                 send1=torch.empty((T, 3), **i32), recv1=torch.empty((T, 3), **i32), cnt=torch.zeros(N, **i32),
                 send2=torch.empty(M, **i32), req=torch.empty(M, **i32), req_loc=torch.empty(M, **i32),
-                slot=torch.empty(2 * T, **i32), u_loc=torch.empty(T, **i32),
+                slot=torch.empty(2 * T, **i32), u_loc=torch.empty(T, **i32), u_apply=torch.empty(T, **i32),
                 rows_out=torch.zeros((M, DS), **f32), rows_in=torch.empty((M, DS), **f32),
                 gu=torch.zeros((T, D), **f32), send_g=torch.zeros((M, DS), **f32), g_in=torch.empty((M, DS), **f32))
         return self._bufs[B]
@@ -296,12 +303,19 @@ class ShardedPairwise:
         for k in range(Kc):
             be.gather_rows(self.V, self.b, req_loc[k], f["rows_out"])
             rows_in = self._a2a(f["rows_out"], f["rows_in"])                       # 3. item rows back
-            be.shard_grads(self.model, self.U, rows_in, u_loc[k], slot[k], B * N, self.margin, f["gu"], f["send_g"], self.accum)
-            be.begin_step()
-            if flagged:
-                be.apply_rows_flagged(self.U, None, u_loc[k], f["gu"], fu[k])      # 5. user rows are local
+            if flagged and hasattr(be, "shard_grads_sgd"):
+                # 4 + 5: user rows referenced once are updated by the gradient kernel itself; the duplicated ones follow
+                be.shard_grads_sgd(self.model, self.U, rows_in, u_loc[k], slot[k], fu[k], B * N, self.margin, f["gu"], f["u_apply"],
+                                   f["send_g"], self.accum)
+                be.begin_step()
+                be.apply_rows_flagged(self.U, None, f["u_apply"], f["gu"], fu[k])
             else:
-                be.apply_rows(self.U, None, u_loc[k], f["gu"])
+                be.shard_grads(self.model, self.U, rows_in, u_loc[k], slot[k], B * N, self.margin, f["gu"], f["send_g"], self.accum)
+                be.begin_step()
+                if flagged:
+                    be.apply_rows_flagged(self.U, None, u_loc[k], f["gu"], fu[k])      # 5. user rows are local
+                else:
+                    be.apply_rows(self.U, None, u_loc[k], f["gu"])
             g_in = self._a2a(f["send_g"], f["g_in"])                               # 6. item-row gradients -> owners
             if flagged:
                 be.apply_rows_flagged(self.V, self.b, req_loc[k], g_in, fv[k])
