@@ -215,21 +215,31 @@ class ShardedPairwise:
         dist.all_to_all_single(recv, send, group=self.group)
         return recv
 
+    def _a2a_async(self, send, recv):
+        """start an all-to-all; returns (recv, wait) -- wait() orders the caller's stream behind it.  RCCL runs it on the
+        process group's own stream, so kernels enqueued before wait() overlap with the exchange."""
+        if self.a2a_fn is not None or (self.world == 1 and not self.force_collectives):
+            out = self._a2a(send, recv)
+            return out, (lambda: None)
+        work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+        return recv, work.wait
+
     # ------------------------------------------------------------------ fast path
-    def _buffers(self, B):
-        if B not in self._bufs:
+    def _buffers(self, B, idx=0):
+        """exchange buffers for steps of B triplets per rank (`idx`: a second, independent set for the overlapped halves)"""
+        if (B, idx) not in self._bufs:
             N, dev, DS, D = self.world, self.device, self.DS, self.dim
             cap1 = self._cap(B); T = N * cap1
             cap2 = self._cap(2 * T); M = N * cap2
             i32 = dict(dtype=torch.int32, device=dev); f32 = dict(dtype=torch.float32, device=dev)
-            self._bufs[B] = dict(
+            self._bufs[(B, idx)] = dict(
                 cap1=cap1, T=T, cap2=cap2, M=M,
                 send1=torch.empty((T, 3), **i32), recv1=torch.empty((T, 3), **i32), cnt=torch.zeros(N, **i32),
                 send2=torch.empty(M, **i32), req=torch.empty(M, **i32), req_loc=torch.empty(M, **i32),
                 slot=torch.empty(2 * T, **i32), u_loc=torch.empty(T, **i32), u_apply=torch.empty(T, **i32),
                 rows_out=torch.zeros((M, DS), **f32), rows_in=torch.empty((M, DS), **f32),
                 gu=torch.zeros((T, D), **f32), send_g=torch.zeros((M, DS), **f32), g_in=torch.empty((M, DS), **f32))
-        return self._bufs[B]
+        return self._bufs[(B, idx)]
 
     def _step_fast(self, uid, pid, nid):
         be, N = self.be, self.world
@@ -250,7 +260,7 @@ class ShardedPairwise:
         be.apply_rows(self.V, self.b, f["req_loc"], g_in)
         return None
 
-    def steps(self, uid, pid, nid, plan_chunk=64):
+    def steps(self, uid, pid, nid, plan_chunk=64, overlap=None):
         """K steps: uid/pid/nid int32 [K, B] on self.device.  The exchange PLAN of a step (which triplet goes
         to which user-owner, which item rows are requested from whom) depends on the ids alone, so it is made for
         `plan_chunk` steps at a time with ONE all-to-all per phase (routes 1 and 2 of the module docstring);
@@ -261,10 +271,82 @@ class ShardedPairwise:
             for k in range(K):
                 self.step(uid[k], pid[k], nid[k])
             return None
+        B = uid.shape[1]
+        if overlap is None:       # two half-batches per step pay once there is a link to hide behind
+            overlap = (self.world > 1 or self.force_collectives) and self.a2a_fn is None
+        overlap = bool(overlap) and B % 2 == 0 and B >= 2
         with self.be.stream_ctx():
             for k0 in range(0, K, plan_chunk):
-                self._steps_planned(uid[k0:k0 + plan_chunk], pid[k0:k0 + plan_chunk], nid[k0:k0 + plan_chunk])
+                sl = slice(k0, k0 + plan_chunk)
+                if overlap:
+                    self._steps_overlapped(uid[sl], pid[sl], nid[sl])
+                else:
+                    self._steps_planned(uid[sl], pid[sl], nid[sl])
         return None
+
+    def _steps_overlapped(self, uid, pid, nid):
+        """The planned K-step path with every step cut into two HALF-BATCHES whose exchanges overlap with the other half's
+        kernels.  Within a step nothing depends on anything but the pre-step tables until the applies, so the order is
+            gather A | a2a rows A || gather B | a2a rows B || grads A | a2a grads A || grads B | a2a grads B || apply V(A) | apply V(B)
+        (|| = runs concurrently: the collectives are asynchronous on RCCL's stream, the kernels on the engine's).  All
+        gathers and all gradient kernels of a step precede its applies (TF's snapshot semantics); the duplicate flags of the
+        two apply lists are taken over BOTH halves together, so a row the halves share is still treated as duplicated.
+        The next step's gathers need this step's applies: steps do not overlap with each other."""
+        be, N = self.be, self.world
+        Kc, B = uid.shape
+        H = B // 2
+        fA, fB = dict(self._buffers(H, 0)), dict(self._buffers(H, 1))
+        T, M = fA["T"], fA["M"]
+        if ("ov", H) not in self._bufs:     # the halves' gradient buffers side by side: Adagrad / Adam apply a step's list in ONE call
+            f32 = dict(dtype=torch.float32, device=self.device)
+            self._bufs[("ov", H)] = (torch.zeros((2 * T, self.dim), **f32), torch.empty((2 * M, self.DS), **f32))
+        gu2, g_in2 = self._bufs[("ov", H)]
+        fA["gu"], fB["gu"], fA["g_in"], fB["g_in"] = gu2[:T], gu2[T:], g_in2[:M], g_in2[M:]
+        i32 = dict(dtype=torch.int32, device=self.device)
+        # plan 2 Kc half-steps: half h of step k is list 2k + h
+        uh, ph, nh = (x.contiguous().reshape(2 * Kc, H) for x in (uid, pid, nid))
+        send1 = torch.empty((2 * Kc, T, 3), **i32); cnt = torch.empty((2 * Kc, N), **i32)
+        be.shard_route_steps(uh, ph, nh, self.n_users, self.n_items, N, fA["cap1"], send1, cnt, self._ovf)
+        mine = self._a2a_steps(send1, N).contiguous()
+        send2 = torch.empty((2 * Kc, M), **i32); slot = torch.empty((2 * Kc, 2 * T), **i32); u_loc = torch.empty((2 * Kc, T), **i32)
+        be.shard_request_steps(mine, N, fA["cap2"], send2, slot, u_loc, cnt, self._ovf)
+        req = self._a2a_steps(send2, N)
+        req_loc = torch.empty_like(req)
+        be.shard_localize(req.reshape(-1), N, req_loc.reshape(-1))
+        flagged = self.opt_kind == "sgd" and hasattr(be, "rows_dupflags")
+        if flagged:        # flags over the two halves of a step TOGETHER ([Kc, 2T] / [Kc, 2M] views of the same memory)
+            fu = torch.empty((2 * Kc, T), dtype=torch.uint8, device=self.device)
+            fv = torch.empty((2 * Kc, M), dtype=torch.uint8, device=self.device)
+            be.rows_dupflags(self.U, u_loc.view(Kc, 2 * T), fu.view(Kc, 2 * T))
+            be.rows_dupflags(self.V, req_loc.view(Kc, 2 * M), fv.view(Kc, 2 * M))
+        folded = flagged and hasattr(be, "shard_grads_sgd")
+        for k in range(Kc):
+            a, b = 2 * k, 2 * k + 1
+            be.gather_rows(self.V, self.b, req_loc[a], fA["rows_out"])
+            rows_a, wait_ra = self._a2a_async(fA["rows_out"], fA["rows_in"])
+            be.gather_rows(self.V, self.b, req_loc[b], fB["rows_out"])
+            rows_b, wait_rb = self._a2a_async(fB["rows_out"], fB["rows_in"])
+            waits = []
+            for h, f, rows, wait_rows in ((a, fA, rows_a, wait_ra), (b, fB, rows_b, wait_rb)):
+                wait_rows()
+                if folded:
+                    be.shard_grads_sgd(self.model, self.U, rows, u_loc[h], slot[h], fu[h], B * N, self.margin, f["gu"], f["u_apply"],
+                                       f["send_g"], self.accum)
+                else:
+                    be.shard_grads(self.model, self.U, rows, u_loc[h], slot[h], B * N, self.margin, f["gu"], f["send_g"], self.accum)
+                waits.append(self._a2a_async(f["send_g"], f["g_in"]))
+            be.begin_step()
+            if flagged:                                                      # SGD: every occurrence accumulates, half by half
+                for h, f in ((a, fA), (b, fB)):                              # user rows are local
+                    be.apply_rows_flagged(self.U, None, f["u_apply"] if folded else u_loc[h], f["gu"], fu[h])
+                for h, (g_in, wait_g) in zip((a, b), waits):                 # item-row gradients at their owners
+                    wait_g()
+                    be.apply_rows_flagged(self.V, self.b, req_loc[h], g_in, fv[h])
+            else:                                                            # Adagrad / Adam sum a row's duplicates FIRST: one list per step
+                be.apply_rows(self.U, None, u_loc.view(Kc, 2 * T)[k], gu2)
+                for _, wait_g in waits:
+                    wait_g()
+                be.apply_rows(self.V, self.b, req_loc.view(Kc, 2 * M)[k], g_in2)
 
     def _a2a_steps(self, x, N):
         """x: [Kc, N * c, ...] per-step buckets -> the same layout after ONE all-to-all over all Kc steps"""

@@ -93,9 +93,10 @@ class _FakeCluster:
 
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("model,optk", [("bpr", "sgd"), ("bpr", "adagrad"), ("ucml", "sgd"), ("bpr", "adam")])
-@pytest.mark.parametrize("fast", [True, False, "planned"])
+@pytest.mark.parametrize("fast", [True, False, "planned", "overlapped"])
 def test_virtual_cluster_matches_oracle(world, model, optk, fast):
-    planned = fast == "planned"             # K-step call: the exchange plan of all steps in one all-to-all per phase
+    overlapped = fast == "overlapped"       # ... with every step cut into two half-batches (exchange / kernel overlap on RCCL)
+    planned = fast in ("planned", "overlapped")     # K-step call: the exchange plan of all steps in one all-to-all per phase
     fast = bool(fast)
     import threading
     import torch
@@ -120,7 +121,7 @@ def test_virtual_cluster_matches_oracle(world, model, optk, fast):
             if planned:
                 stack = lambda f: torch.from_numpy(np.stack([f(s)[sl] for s in range(3)])).to(dev)
                 e.steps(stack(lambda s: np.roll(u, s)), stack(lambda s: np.roll(p, 5 * s)), stack(lambda s: np.roll(n, 2 * s)),
-                        plan_chunk=2)
+                        plan_chunk=2, overlap=overlapped)
             for s in range(0 if not planned else 3, 3):
                 uu, pp, nn = np.roll(u, s), np.roll(p, 5 * s), np.roll(n, 2 * s)
                 e.step(torch.from_numpy(uu[sl].copy()).to(dev), torch.from_numpy(pp[sl].copy()).to(dev),
