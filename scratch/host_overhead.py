@@ -13,6 +13,12 @@ uid, pid, nid = (torch.randint(0, N, (K + W, B), device=dev, dtype=torch.int32, 
 rt.pairwise_reserve(opt, U, V, b, K, B)
 rt.pairwise_step("bpr", opt, U, V, b, uid[:W], pid[:W], nid[:W], K=W, B=B, want_loss=False)
 ctx.synchronize(); torch.cuda.synchronize()
+if os.environ.get("SPIN_MS"):
+    x = torch.empty(64 << 20, device=dev); y = torch.empty_like(x)
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < float(os.environ["SPIN_MS"]):
+        y.copy_(x)
+    torch.cuda.synchronize()
 for rep in range(4):
     t0 = time.perf_counter()
     a, bb, c = uid[W:W + K], pid[W:W + K], nid[W:W + K]
