@@ -117,6 +117,14 @@ class GradientTape:
         """`target` is what the model call returned: the (loss, l2_loss) tuple
         (TF sums a nested target) or only its loss element."""
         flat = list(target) if isinstance(target, (tuple, list)) else [target]
+        from .modules._compose import L2Sum
+        for i, t in enumerate(flat):            # tf.nn.l2_loss of a composition's lookups = the step's second output
+            if isinstance(t, L2Sum):
+                st = t.resolve()
+                if st is None or st not in self.steps:
+                    raise NotImplementedError("tape.gradient: this l2 term is not the l2_loss of one recorded step's lookups "
+                                              "(bpr.py:35 / wrmf.py:32 sum tf.nn.l2_loss over exactly the looked-up vectors)")
+                flat[i] = LazyScalar(st, 1)
         lazies = [t for t in flat if isinstance(t, LazyScalar)]
         if not lazies:
             raise ValueError("tape.gradient: target does not come from a recommender call under this tape")

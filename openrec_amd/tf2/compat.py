@@ -262,11 +262,107 @@ class TensorSliceDataset:
             yield buf.pop(int(self._rng.integers(len(buf))))
 
 
+class Model:
+    """tensorflow.keras.Model as the reference's recommender classes use it (recommenders/bpr.py:5-9: subclass, assign
+    modules as attributes, define `call`): `model(...)` runs `call`, `trainable_variables` collects the variables of the
+    attributes in assignment order."""
+
+    def __init__(self, *_, **__):
+        pass
+
+    def __call__(self, *args, **kwargs):
+        kwargs.pop("training", None)
+        return self.call(*args, **kwargs)
+
+    @property
+    def trainable_variables(self):
+        out, seen = [], set()
+        for v in vars(self).values():
+            for var in (getattr(v, "trainable_variables", None) or getattr(v, "variables", None) or []):
+                if id(var) not in seen:
+                    seen.add(id(var))
+                    out.append(var)
+        return out
+
+    variables = trainable_variables
+
+
+class _AllItemScores:
+    """`tf.linalg.matmul(user_vec, V, transpose_b=True)` of looked-up user rows and a whole item table (bpr.py:42):
+    stays symbolic until the bias row is added, then runs the all-item scorer on the device."""
+
+    def __init__(self, rows, item_var):
+        self.rows, self.item_var = rows, item_var
+
+    def __add__(self, other):
+        from .modules.latent_factor import Variable
+        bias = getattr(other, "flat_of", None)
+        if isinstance(bias, Variable) and bias.table.dim == 1 and bias.table.rows == self.item_var.table.rows:
+            ids = self.rows.flat_ids()
+            return HostTensor(rt.score_all_items("dot", self.rows.factor.table, self.item_var.table, bias.table, ids))
+        return HostTensor(np.asarray(self) + np.asarray(other))
+
+    __radd__ = __add__
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.asarray(self.rows, np.float32) @ self.item_var.numpy().T
+        return a.astype(dtype) if dtype is not None else a
+
+    def numpy(self):
+        return np.asarray(self)
+
+
+class _Flat:
+    """tf.reshape(variable, [-1]): symbolic (the table stays in HBM) until something needs the values"""
+
+    def __init__(self, var, shape):
+        self.var, self.shape_arg = var, shape
+        self.flat_of = var if list(np.atleast_1d(shape)) == [-1] else None
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.var.numpy().reshape(self.shape_arg)
+        return a.astype(dtype) if dtype is not None else a
+
+    def numpy(self):
+        return np.asarray(self)
+
+    def __add__(self, other):
+        if isinstance(other, _AllItemScores):
+            return other.__add__(self)
+        return np.asarray(self) + np.asarray(other)
+
+    __radd__ = __add__
+
+
+def matmul(a, b, transpose_a=False, transpose_b=False):
+    from .modules.latent_factor import GatheredRows, Variable
+    if isinstance(a, GatheredRows) and isinstance(b, Variable) and transpose_b and not transpose_a and a.ndim == 2 \
+            and a.factor.dim == b.table.dim:
+        return _AllItemScores(a, b)
+    a = np.asarray(a.numpy() if isinstance(a, Variable) else a, np.float32)
+    b = np.asarray(b.numpy() if isinstance(b, Variable) else b, np.float32)
+    return HostTensor((a.T if transpose_a else a) @ (b.T if transpose_b else b))
+
+
+def reshape(x, shape):
+    from .modules.latent_factor import Variable
+    if isinstance(x, Variable):
+        return _Flat(x, shape)
+    return np.asarray(x).reshape(shape)
+
+
+def _l2_loss(x):
+    from .modules._compose import l2_loss
+    return l2_loss(x)
+
+
 optimizers = types.SimpleNamespace(SGD=SGD, Adagrad=Adagrad, Adam=Adam)
-keras = types.SimpleNamespace(optimizers=optimizers, metrics=types.SimpleNamespace(Mean=Mean, AUC=AUC))
+keras = types.SimpleNamespace(optimizers=optimizers, metrics=types.SimpleNamespace(Mean=Mean, AUC=AUC), Model=Model)
 data = types.SimpleNamespace(Dataset=TensorSliceDataset)
-tf = types.SimpleNamespace(function=function, GradientTape=GradientTape, constant=constant, keras=keras, data=data,
-                           int32=int32, float32=float32, bool=bool_)
+nn = types.SimpleNamespace(l2_loss=_l2_loss)
+linalg = types.SimpleNamespace(matmul=matmul)
+tf = types.SimpleNamespace(function=function, GradientTape=GradientTape, constant=constant, keras=keras, data=data, nn=nn,
+                           linalg=linalg, matmul=matmul, reshape=reshape, int32=int32, float32=float32, bool=bool_)
 
 
 def install():
@@ -284,7 +380,7 @@ def install():
     for k, v in vars(tf).items():
         setattr(mod, k, v)
     kmod = types.ModuleType("tensorflow.keras")
-    kmod.optimizers, kmod.metrics = optimizers, keras.metrics
+    kmod.optimizers, kmod.metrics, kmod.Model = optimizers, keras.metrics, Model
     omod = types.ModuleType("tensorflow.keras.optimizers")
     omod.SGD, omod.Adagrad, omod.Adam = SGD, Adagrad, Adam
     mmod = types.ModuleType("tensorflow.keras.metrics")

@@ -31,6 +31,81 @@ class Variable:
         return f"<Variable {self.name} shape={self.table.shape} (HBM)>"
 
 
+class GatheredRows:
+    """What `LatentFactor.__call__` returns: the rows of `ids`, gathered from HBM when (and only when) somebody looks at them.
+
+    The reference's recommenders are COMPOSITIONS of modules (bpr.py:23-33: five lookups, then `PairwiseLogLoss`, then
+    `tf.nn.l2_loss` of the looked-up vectors).  Materialising the lookups on the host would take the composition off the
+    device path -- 16 MB per gather at B = 65536 -- so a lookup stays a (table, ids) pair: `PairwiseLogLoss` /
+    `PointwiseMSELoss` recognise their arguments and record ONE fused step (modules/_compose.py), exactly what
+    `BPR.__call__` / `WRMF.__call__` of this package record.  Anything else that touches the object (np.asarray,
+    arithmetic, indexing, `.numpy()`) gathers the rows to the host and continues there, as a plain array."""
+
+    __array_priority__ = 100.0
+
+    def __init__(self, factor, ids):
+        self.factor = factor
+        self.ids = ids
+        self._host = None
+        self._l2_step = None
+
+    def flat_ids(self):
+        i = self.ids
+        if hasattr(i, "numpy") and not isinstance(i, np.ndarray) and not getattr(i, "is_cuda", False):
+            i = i.numpy()
+        return i if getattr(i, "is_cuda", False) else np.asarray(i)
+
+    @property
+    def shape(self):
+        return tuple(np.shape(self.ids) if not hasattr(self.ids, "shape") else tuple(self.ids.shape)) + (self.factor.dim,)
+
+    ndim = property(lambda self: len(self.shape))
+    dtype = np.dtype(np.float32)
+
+    def numpy(self):
+        if self._host is None:
+            i = self.flat_ids()
+            if getattr(i, "is_cuda", False):
+                i = i.cpu().numpy()
+            self._host = self.factor.table.gather(np.asarray(i).reshape(-1)).reshape(self.shape)
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, k):
+        return self.numpy()[k]
+
+    def __getattr__(self, name):               # .sum(), .mean(), .reshape(), .T ... : the host array's
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.numpy(), name)
+
+    def _bin(op):
+        def f(self, other):
+            return op(self.numpy(), np.asarray(other))
+        def r(self, other):
+            return op(np.asarray(other), self.numpy())
+        return f, r
+
+    __add__, __radd__ = _bin(np.add)
+    __sub__, __rsub__ = _bin(np.subtract)
+    __mul__, __rmul__ = _bin(np.multiply)
+    __truediv__, __rtruediv__ = _bin(np.true_divide)
+    __matmul__, __rmatmul__ = _bin(np.matmul)
+    del _bin
+
+    def __neg__(self):
+        return -self.numpy()
+
+    def __repr__(self):
+        return f"<GatheredRows {self.factor.name or 'latent_factor'}[{self.shape[0] if self.shape else ''}...] shape={self.shape} (lazy)>"
+
+
 class LatentFactor:
 
     def __init__(self, num_instances, dim, zero_init=False, name=None, ctx=None, seed=None):
@@ -52,10 +127,11 @@ class LatentFactor:
     trainable_variables = variables
 
     def __call__(self, ids):
-        """Embedding gather: [*] int ids -> [*, dim] fp32 (host array)."""
-        ids = np.asarray(ids)
-        out = self.table.gather(ids.reshape(-1))
-        return out.reshape(ids.shape + (self.dim,))
+        """Embedding gather: [*] int ids -> [*, dim] fp32 -- lazily (see GatheredRows): `np.asarray(lf(ids))` is the host
+        array, bit-exact rows of the table; an out-of-range id raises IndexError when the rows are gathered."""
+        return GatheredRows(self, ids)
+
+    call = __call__
 
     def censor(self, censor_id):
         """latent_factor.py:17-23: rows of the DISTINCT ids are divided by max(norm, 0.1)."""
