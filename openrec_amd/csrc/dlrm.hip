@@ -21,6 +21,12 @@ struct DenseLayer {
     // fp16 copies of W for ORX_DLRM_FP16_MLP: w16 [in][ld16] (operand of dY*W^T), w16t [out][ld16t] (operand of X*W)
     void* w16 = nullptr; void* w16t = nullptr;
     int ld16 = 0, ld16t = 0;
+    // second-generation fp16 path (kernels_gemm16.hip)
+    bool lean = false;                  // the layer's output lives only as its fp16 copy (no fp32 store): its consumers -- the next
+                                        // layer's three products and the fused activation backward -- all read fp16
+    bool dw16 = false;                  // the weight gradient comes from the batch-major fp16 copies (gemm16_tn)
+    float* slab = nullptr;              // split-K slices of this layer's weight gradient, [tiles][S][128 * 128]
+    int slab_S = 1, slab_tiles = 0;
 };
 
 static inline int up8(int x) { return (x + 7) & ~7; }
@@ -52,6 +58,10 @@ struct orx_dlrm {
     std::vector<void*> top_y16;         // output of top layer l (l < last), [cap][up8(out)]
     void* g16 = nullptr, *g16b = nullptr;   // dY after the activation backward, [cap][up8(maxw)], ping-pong
     ShadowParam* d_shadow = nullptr; int n_shadow = 0; int64_t shadow_max = 0;
+    bool gen2 = false;                  // ORX_DLRM_FP16_MLP with the kernels of kernels_gemm16.hip (ORX_DLRM_GEMM_V1 = the round-1 kernels)
+    SlabReduce* d_slabjobs[2] = {nullptr, nullptr}; int n_slabjobs[2] = {0, 0}, slab_max_tiles[2] = {0, 0};   // [0] bottom, [1] top MLP
+    void* dense16 = nullptr; int ld_dense16 = 0;   // fp16 copy of the dense features (operand of the first bottom layer)
+    std::vector<void*> bot_y16;         // output of bottom layer l (l < last), [cap][up8(out)]
     int32_t* d_idx_all = nullptr; int64_t idx_all_cap = 0;          // combined row ids of a chunk of steps (planned sparse apply)
     int32_t* d_sparse_all = nullptr; int64_t sparse_all_cap = 0;
     DenseParam* d_params = nullptr;     // descriptors of the dense parameters for the multi-tensor optimizer launch
@@ -143,10 +153,27 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
             sp.push_back(p); m->shadow_max = std::max<int64_t>(m->shadow_max, (int64_t)D.in * D.out);
             return ORX_OK;
         };
-        for (auto& D : m->top) CHECK(add(D));           // the bottom MLP is tiny and starts from fp32 input: fp32 operands
+        for (auto& D : m->top) CHECK(add(D));
+        if (getenv("ORX_DLRM_GEMM_V1") == nullptr && getenv("ORX_DLRM_BOT_V1") == nullptr)
+            for (auto& D : m->bot) CHECK(add(D));       // (round 1: the bottom MLP read fp32 operands)
         m->n_shadow = (int)sp.size();
         ORX_HIP(hipMalloc((void**)&m->d_shadow, sp.size() * sizeof(ShadowParam)));
         ORX_HIP(hipMemcpy(m->d_shadow, sp.data(), sp.size() * sizeof(ShadowParam), hipMemcpyHostToDevice));
+    }
+    m->gen2 = (flags & ORX_DLRM_FP16_MLP) && getenv("ORX_DLRM_GEMM_V1") == nullptr;
+    if (m->gen2) {
+        // layer l's relu output is fp16-only when layer l + 1 runs all three of its products on fp16 copies
+        auto flags_of = [&](std::vector<DenseLayer>& L, int in0) {
+            for (size_t l = 0; l < L.size(); ++l) {
+                const int64_t ldx16 = up8(l == 0 ? in0 : L[l - 1].out);
+                L[l].dw16 = L[l].w16 != nullptr && L[l].out >= 32 && orx_gemm16_tn_ok(ldx16, L[l].out, L[l].out);
+            }
+            for (size_t l = 0; l + 1 < L.size(); ++l)
+                L[l].lean = L[l].act != 2 && L[l].out % 8 == 0 && L[l].out >= 64 && L[l + 1].dw16 &&
+                            orx_gemm16_nt_ok(L[l + 1].out, L[l + 1].ld16, L[l + 1].in, L[l + 1].out) && getenv("ORX_DLRM_NO_LEAN") == nullptr;
+        };
+        flags_of(m->bot, dense_dim);
+        flags_of(m->top, m_spa + m->P);
     }
     m->ldR = (m_spa + m->P + 3) & ~3;
     m->maxw = m->ldR;
@@ -158,6 +185,12 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
 
 static void free_buffers(orx_dlrm* m) {
     hipFree(m->R16); hipFree(m->g16); hipFree(m->g16b); m->R16 = m->g16 = m->g16b = nullptr;
+    for (auto& D : m->top) { hipFree(D.slab); D.slab = nullptr; }
+    for (auto& D : m->bot) { hipFree(D.slab); D.slab = nullptr; }
+    for (int k = 0; k < 2; ++k) { hipFree(m->d_slabjobs[k]); m->d_slabjobs[k] = nullptr; m->n_slabjobs[k] = 0; m->slab_max_tiles[k] = 0; }
+    hipFree(m->dense16); m->dense16 = nullptr;
+    for (void* p : m->bot_y16) hipFree(p);
+    m->bot_y16.clear();
     for (void* p : m->top_y16) hipFree(p);
     m->top_y16.clear();
     hipFree(m->d_dense); hipFree(m->d_label); hipFree(m->d_sparse); hipFree(m->d_idx); hipFree(m->d_idx_big); m->d_idx_big = nullptr;
@@ -177,7 +210,7 @@ extern "C" int orx_dlrm_destroy(orx_dlrm* m) {
     free_buffers(m);
     hipFree(m->d_offset); hipFree(m->d_colwin); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params); hipFree(m->d_idx_all); hipFree(m->d_sparse_all); hipFree(m->d_tiny_f); hipFree(m->d_is_tiny);
     orx_table_destroy(m->emb);
-    for (auto& d : m->bot) { orx_table_destroy(d.W); orx_table_destroy(d.b); }
+    for (auto& d : m->bot) { orx_table_destroy(d.W); orx_table_destroy(d.b); hipFree(d.w16); hipFree(d.w16t); }
     for (auto& d : m->top) { orx_table_destroy(d.W); orx_table_destroy(d.b); hipFree(d.w16); hipFree(d.w16t); }
     hipFree(m->d_shadow);
     delete m;
@@ -230,6 +263,39 @@ static int ensure_buffers(orx_dlrm* m, int64_t B) {
             m->top_y16.push_back(p);
         }
     }
+    if (m->gen2) {          // fp16 copies on the bottom side, weight-gradient split-K workspaces, descriptors of the reduce launches
+        if (m->bot[0].w16) {
+            m->ld_dense16 = up8(m->dense_dim);
+            ORX_HIP(hipMalloc(&m->dense16, (size_t)B * m->ld_dense16 * 2));
+            for (size_t l = 0; l + 1 < m->bot.size(); ++l) {
+                void* p; const size_t bytes = (size_t)B * up8(m->bot[l].out) * 2;
+                ORX_HIP(hipMalloc(&p, bytes)); ORX_HIP(hipMemsetAsync(p, 0, bytes, m->ctx->stream));
+                m->bot_y16.push_back(p);
+            }
+        }
+        for (int k = 0; k < 2; ++k) {
+            std::vector<DenseLayer>& L = k == 0 ? m->bot : m->top;
+            std::vector<SlabReduce> jobs;
+            for (size_t l = 0; l < L.size(); ++l) {
+                DenseLayer& D = L[l];
+                if (!D.dw16) continue;
+                int S, tiles, kchunk;
+                orx_gemm16_tn_plan(m->ctx, D.in, D.out, (int)B, &S, &tiles, &kchunk);
+                D.slab_S = S; D.slab_tiles = tiles;
+                if (S > 1) {
+                    ORX_HIP(hipMalloc((void**)&D.slab, (size_t)tiles * S * 128 * 128 * sizeof(float)));
+                    CHECK(orx_table_scratch(D.W));
+                    SlabReduce j; j.slab = D.slab; j.C = D.W->gsum; j.ldc = D.out; j.M = D.in; j.N = D.out; j.S = S; j.ntn = (D.out + 127) / 128; j.tiles = tiles;
+                    jobs.push_back(j); m->slab_max_tiles[k] = std::max(m->slab_max_tiles[k], tiles);
+                }
+            }
+            m->n_slabjobs[k] = (int)jobs.size();
+            if (!jobs.empty()) {
+                ORX_HIP(hipMalloc((void**)&m->d_slabjobs[k], jobs.size() * sizeof(SlabReduce)));
+                ORX_HIP(hipMemcpy(m->d_slabjobs[k], jobs.data(), jobs.size() * sizeof(SlabReduce), hipMemcpyHostToDevice));
+            }
+        }
+    }
     m->cap = B;
     return ORX_OK;
 }
@@ -263,21 +329,36 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
         // dlrm.py:83-85: the n_emb gathers = one gather on the combined table (dense slot skipped)
         CHECK(orx_launch_gather(c, m->emb->w, nullptr, m->emb->rows, d, idx, B * F, m->Z, d, c->d_err, 1));
     }
+    const bool f16 = (m->flags & ORX_DLRM_FP16_MLP) != 0;
+    if (f16) CHECK(orx_launch_dense_shadow(c, m->d_shadow, m->n_shadow, m->shadow_max));   // W changed since the last step
     // dlrm.py:87: bottom MLP; its last layer writes straight into slot F-1 of Z
     const float* x = bt.dense; int64_t ldx = m->dense_dim;
+    const bool bot16 = m->gen2 && m->dense16 != nullptr;
+    const void* bx16 = m->dense16; int64_t ldbx16 = m->ld_dense16;
+    if (bot16) CHECK(orx_launch_cast16(c, bt.dense, m->dense_dim, m->dense16, m->ld_dense16, (int)B, m->dense_dim));
     for (size_t l = 0; l < m->bot.size(); ++l) {
         const DenseLayer& L = m->bot[l];
         const bool last = l + 1 == m->bot.size();
         float* y = last ? m->Z + (size_t)(F - 1) * d : m->bot_y[l];
         const int64_t ldy = last ? (int64_t)F * d : L.out;
-        CHECK(mlp_gemm(m, x, ldx, 1, L.W->w, L.out, 1, y, ldy, L.b->w, (int)B, L.out, L.in, L.act));
+        if (bot16 && bx16 != nullptr && orx_gemm16_nt_ok(ldbx16, L.ld16t, L.out, L.in)) {
+            void* y16 = last ? nullptr : m->bot_y16[l];
+            CHECK(orx_launch_gemm16_nt(c, bx16, ldbx16, L.w16t, L.ld16t, L.lean ? nullptr : y, ldy, y16, up8(L.out), L.b->w, (int)B, L.out, L.in, L.act));
+            bx16 = y16; ldbx16 = up8(L.out);
+        } else {
+            ORX_ARG(l == 0 || !m->bot[l - 1].lean, "dlrm forward: bottom layer %d has no fp32 input", (int)l);
+            CHECK(mlp_gemm(m, x, ldx, 1, L.W->w, L.out, 1, y, ldy, L.b->w, (int)B, L.out, L.in, L.act));
+            bx16 = nullptr;
+        }
         x = y; ldx = ldy;
     }
     // dlrm.py:89-92: R = concat(dense_emb, interaction)
-    const bool f16 = (m->flags & ORX_DLRM_FP16_MLP) != 0;
     bool have16 = false;                                         // does the current activation have an fp16 copy?
-    if (f16) CHECK(orx_launch_dense_shadow(c, m->d_shadow, m->n_shadow, m->shadow_max));   // W changed since the last step
     CHECK(orx_launch_interact(c, true, m->Z, nullptr, F, d, compat, itself, m->R, m->P, B, m->ldR, f16 ? m->R16 : nullptr, m->ldR16, &have16));
+    if (m->gen2 && !have16) {            // (the LDS interaction kernels -- reference_compat, odd shapes -- write fp32 only)
+        CHECK(orx_launch_cast16(c, m->R, m->ldR, m->R16, m->ldR16, (int)B, m->m_spa + m->P));
+        have16 = true;
+    }
     x = m->R; ldx = m->ldR;
     const void* x16 = m->R16; int64_t ldx16 = m->ldR16;
     for (size_t l = 0; l < m->top.size(); ++l) {
@@ -285,6 +366,9 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
         const bool last = l + 1 == m->top.size();
         if (f16 && have16) {            // X16 * W16T: fp16-resident operands, fp16 copy of the output for the next layer
             void* y16 = last ? nullptr : m->top_y16[l];
+            if (m->gen2 && orx_gemm16_nt_ok(ldx16, L.ld16t, L.out, L.in))
+                CHECK(orx_launch_gemm16_nt(c, x16, ldx16, L.w16t, L.ld16t, L.lean ? nullptr : m->top_y[l], L.out, y16, up8(L.out), L.b->w, (int)B, L.out, L.in, L.act));
+            else
             CHECK(orx_launch_gemm_f16s(c, x16, ldx16, L.w16t, L.ld16t, m->top_y[l], L.out, y16, up8(L.out), L.b->w, (int)B, L.out, L.in, L.act));
             x16 = y16; ldx16 = up8(L.out); have16 = y16 != nullptr;
         } else {
@@ -321,13 +405,19 @@ static int dense_apply_all(orx_dlrm* m, orx_opt* opt, float lr_t = 0.f) {
     return orx_launch_dense_apply_multi(c, m->d_params, (int)h.size(), max_n, opt->kind, opt->lr, opt->p1);
 }
 
-// backward through one MLP; dy [B, last.out] is consumed (in place), returns d(input) in *dx_out
+// backward through one MLP; dy [B, last.out] is consumed (in place), returns d(input) in *dx_out.
+// ins16 / outs16 (top MLP in fp16 mode, else NULL): the fp16 copies of every layer's input and output.
 static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vector<const float*>& ins, const std::vector<int64_t>& ld_in,
                         const std::vector<const float*>& outs, const std::vector<int64_t>& ld_out,
-                        float* dy, float* other, int64_t B, bool need_dx0, float** dx_out) {
+                        float* dy, float* other, int64_t B, bool need_dx0, float** dx_out,
+                        const std::vector<const void*>* ins16 = nullptr, const std::vector<int64_t>* ld_in16 = nullptr,
+                        const std::vector<const void*>* outs16 = nullptr) {
     orx_ctx* c = m->ctx;
+    const int which = &L == &m->top ? 1 : 0;
     bool act_done = false;              // the activation backward of layer l was fused into the product above it
     void* dy16 = nullptr;               // fp16 copy of the current dy (g16 / g16b ping-pong)
+    bool dy32 = true;                   // does `dy` hold the fp32 gradient (false: only dy16 is valid)
+    int slabs = 0;
     for (int l = (int)L.size() - 1; l >= 0; --l) {
         DenseLayer& D = L[l];
         CHECK(orx_table_scratch(D.W)); CHECK(orx_table_scratch(D.b));
@@ -336,32 +426,61 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
         // dZ = dY * act'(Y) and gb = colsum(dZ) in one pass (unless the product above already did it).  The gradient
         // buffers are zero here (the optimizer kernels zero them behind themselves), so slab sums / split-K just add.
         if (!act_done) {
-            dy16 = s16 ? m->g16 : nullptr;
+            ORX_ARG(dy32, "dlrm backward: fp32 gradient missing for layer %d", l);
+            dy16 = (s16 || (D.dw16 && m->g16 != nullptr)) ? m->g16 : nullptr;
             CHECK(orx_launch_act_bwd_colsum(c, dy, outs[l], ld_out[l], (int)B, D.out, D.act, D.b->gsum, dy16, D.out));
         }
         act_done = false;
         // gW [in, out] = X^T * dZ
-        CHECK(mlp_gemm(m, ins[l], 1, ld_in[l], dy, D.out, 1, D.W->gsum, D.out, nullptr, D.in, D.out, (int)B, 0, true));
+        if (D.dw16) {
+            ORX_ARG(dy16 != nullptr && ins16 && (*ins16)[l], "dlrm backward: fp16 operands missing for layer %d", l);
+            CHECK(orx_launch_gemm16_tn(c, (*ins16)[l], (*ld_in16)[l], dy16, D.out, D.W->gsum, D.out, D.slab, D.in, D.out, (int)B));
+            if (D.slab_S > 1) ++slabs;
+        } else {
+            ORX_ARG(dy32, "dlrm backward: fp32 gradient missing for layer %d", l);
+            CHECK(mlp_gemm(m, ins[l], 1, ld_in[l], dy, D.out, 1, D.W->gsum, D.out, nullptr, D.in, D.out, (int)B, 0, true));
+        }
         if (want_dx) {
             // dX [B, in] = dZ * W^T  (fp16-resident operands where they exist: dZ16, W16).  With a layer below, the
             // epilogue also applies that layer's activation backward, sums its bias gradient and writes its dZ16.
             if (s16 && dy16 != nullptr) {
                 const bool fuse = l > 0 && L[l - 1].w16 != nullptr && L[l - 1].out % 8 == 0 && ld_in[l] == L[l - 1].out;
                 void* next16 = (dy16 == m->g16) ? m->g16b : m->g16;
+                const bool nt = m->gen2 && orx_gemm16_nt_ok(D.out, D.ld16, D.in, D.out);
                 if (fuse) {
                     CHECK(orx_table_scratch(L[l - 1].b));
-                    CHECK(orx_launch_gemm_f16s(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], (l - 1 > 0 || need_dx0) ? next16 : nullptr, L[l - 1].out,
-                                               nullptr, (int)B, D.in, D.out, 0, outs[l - 1], ld_out[l - 1], L[l - 1].act, L[l - 1].b->gsum));
+                    if (nt) {
+                        // the layer below runs both of its products on the fp16 copy: no fp32 store of its dZ
+                        const bool below16 = L[l - 1].dw16 && (l - 1 == 0 ? !need_dx0 || orx_gemm16_nt_ok(L[0].out, L[0].ld16, L[0].in, L[0].out)
+                                                                          : orx_gemm16_nt_ok(L[l - 1].out, L[l - 1].ld16, L[l - 1].in, L[l - 1].out));
+                        const bool y16 = L[l - 1].lean;
+                        ORX_ARG(!y16 || (outs16 && (*outs16)[l - 1]), "dlrm backward: fp16 activation missing for layer %d", l - 1);
+                        CHECK(orx_launch_gemm16_nt(c, dy16, D.out, D.w16, D.ld16, below16 ? nullptr : other, ld_in[l], next16, L[l - 1].out,
+                                                   nullptr, (int)B, D.in, D.out, 0, y16 ? nullptr : outs[l - 1], y16 ? (*outs16)[l - 1] : nullptr,
+                                                   y16 ? (int64_t)up8(L[l - 1].out) : ld_out[l - 1], L[l - 1].act, L[l - 1].b->gsum));
+                        dy16 = next16; dy32 = !below16;
+                    } else {
+                        ORX_ARG(!L[l - 1].lean, "dlrm backward: layer %d has no fp32 activation", l - 1);
+                        CHECK(orx_launch_gemm_f16s(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], (l - 1 > 0 || need_dx0) ? next16 : nullptr, L[l - 1].out,
+                                                   nullptr, (int)B, D.in, D.out, 0, outs[l - 1], ld_out[l - 1], L[l - 1].act, L[l - 1].b->gsum));
+                        dy16 = (l - 1 > 0 || need_dx0) ? next16 : nullptr; dy32 = true;
+                    }
                     act_done = true;
-                    dy16 = (l - 1 > 0 || need_dx0) ? next16 : nullptr;
                 } else {
-                    CHECK(orx_launch_gemm_f16s(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, (int)B, D.in, D.out, 0));
+                    if (nt) CHECK(orx_launch_gemm16_nt(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, (int)B, D.in, D.out, 0));
+                    else CHECK(orx_launch_gemm_f16s(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, (int)B, D.in, D.out, 0));
+                    dy32 = true;
                 }
             } else {
+                ORX_ARG(dy32, "dlrm backward: fp32 gradient missing for layer %d", l);
                 CHECK(mlp_gemm(m, dy, D.out, 1, D.W->w, 1, D.out, other, ld_in[l], nullptr, (int)B, D.in, D.out, 0));
             }
             float* t = dy; dy = other; other = t;
         }
+    }
+    if (slabs > 0) {
+        ORX_ARG(slabs == m->n_slabjobs[which], "dlrm backward: %d of %d split-K weight gradients were produced", slabs, m->n_slabjobs[which]);
+        CHECK(orx_launch_slab_reduce(c, m->d_slabjobs[which], m->n_slabjobs[which], m->slab_max_tiles[which]));
     }
     *dx_out = dy;
     return ORX_OK;
@@ -381,7 +500,13 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B) {
         outs.push_back(m->top_y[l]); ldo.push_back(m->top[l].out);
     }
     float* dR = nullptr;
-    CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR));
+    std::vector<const void*> ins16, outs16; std::vector<int64_t> ldi16;
+    if (m->gen2)
+        for (size_t l = 0; l < m->top.size(); ++l) {
+            ins16.push_back(l == 0 ? m->R16 : m->top_y16[l - 1]); ldi16.push_back(l == 0 ? m->ldR16 : up8(m->top[l - 1].out));
+            outs16.push_back(l + 1 < m->top.size() ? m->top_y16[l] : nullptr);
+        }
+    CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR, m->gen2 ? &ins16 : nullptr, &ldi16, &outs16));
     // ---- interaction backward: dZ for every slot (slot F-1 = d dense_emb)
     CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B, m->ldR));
     // ---- bottom MLP backward from dZ[:, F-1, :]
@@ -395,7 +520,14 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B) {
         outs.push_back(last ? m->Z + (size_t)(F - 1) * d : m->bot_y[l]); ldo.push_back(last ? (int64_t)F * d : m->bot[l].out);
     }
     float* dx0 = nullptr;
-    CHECK(mlp_backward(m, m->bot, ins, ldi, outs, ldo, dy, other, B, false, &dx0));
+    ins16.clear(); outs16.clear(); ldi16.clear();
+    const bool bot16 = m->gen2 && m->dense16 != nullptr;
+    if (bot16)
+        for (size_t l = 0; l < m->bot.size(); ++l) {
+            ins16.push_back(l == 0 ? m->dense16 : m->bot_y16[l - 1]); ldi16.push_back(l == 0 ? m->ld_dense16 : up8(m->bot[l - 1].out));
+            outs16.push_back(l + 1 < m->bot.size() ? m->bot_y16[l] : nullptr);
+        }
+    CHECK(mlp_backward(m, m->bot, ins, ldi, outs, ldo, dy, other, B, false, &dx0, bot16 ? &ins16 : nullptr, &ldi16, &outs16));
     }
     return ORX_OK;
 }

@@ -1,0 +1,457 @@
+// fp16-MFMA products of the DLRM top MLP on fp16-resident operands (ORX_DLRM_FP16_MLP; recommenders/dlrm.py:76-100,
+// modules/multi_layer_perceptron.py:5-18), second generation (scratch/exp_gemm.hip has the experiments):
+//
+//   gemm16_nt_kernel   C[M][N] = A16[M][K] * B16[N][K]^T  -- forward (X16 * W16T) and input gradient (dZ16 * W16): both
+//                      operands K-contiguous.  BK = 64, two LDS stages (one barrier per K step; the next tile is written to
+//                      LDS after the barrier while the tile after it is already in flight to registers), MFMA operands
+//                      swapped so a lane owns 4 consecutive columns of a row (16-byte epilogue accesses), workgroup ids
+//                      remapped so that an XCD (workgroup b runs on XCD b % 8) owns whole row blocks of A: its L2 then
+//                      holds that slice of A and all of B instead of all of A (128x128 tiles: 36.2 -> 32.7 us on
+//                      8192x1024x1024; 256x128 tiles of 8 wavefronts: 31.0; the round-1 kernel: 46.0).
+//                      Epilogue: + bias, activation, optional fp32 store, optional fp16 copy; or the fused activation
+//                      backward of the layer below (dZ = dX * act'(Y), Y from its fp32 or fp16 copy) with the bias-gradient
+//                      column sums.
+//   gemm16_tn_kernel   C[M][N] += A16[K][M]^T * B16[K][N] -- weight gradient X16^T * dZ16 straight from the BATCH-major fp16
+//                      copies the other two products already use (no transposed shadows, no fp32 re-read): the tiles stay
+//                      k-major in LDS and the MFMA fragments come from ds_read_b64_tr_b16.  Split-K over the batch; the
+//                      slices leave through fp32 slabs (plain 16-byte stores) that slab_reduce_kernel adds into the
+//                      gradient: fp32 atomics run at ~85 G/s here (+95 us for a 1024x1024 layer), an in-kernel last-arriver
+//                      reduction pays an L2 write-back + invalidate per workgroup (+50 us), slabs + one reduce launch +14 us.
+#include "orx_device.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+
+struct Nt16Args {
+    const _Float16* A; int64_t lda;
+    const _Float16* B; int64_t ldb;
+    float* C; int64_t ldc;              // optional
+    _Float16* C16; int64_t ldc16;       // optional
+    const float* bias;
+    int M, N, K, act;
+    const float* actY; const _Float16* actY16; int64_t ldy; int act_y; float* gb;      // fused activation backward (see above)
+};
+
+// XCD-aware tile order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so id b -> slot
+// (b % 8) * (n / 8) + b / 8 hands every XCD a contiguous run of the row-major tile list
+__device__ __forceinline__ int xcd_slot(int b, int n) { return (n & 7) ? b : (b & 7) * (n >> 3) + (b >> 3); }
+
+template <int WM, int WN, int TM, int TN, int MINB>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_kernel(Nt16Args g) {
+    constexpr int BK = 64, BM = WM * TM * 16, BN = WN * TN * 16, LD = BK + 8, NT = 64 * WM * WN;
+    constexpr int CPR = BK / 8;                                  // 16-byte chunks per tile row
+    constexpr int NA = BM * CPR / NT, NB = BN * CPR / NT;
+    static_assert(BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile / thread mismatch");
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds16[];
+    constexpr int STAGE = (BM + BN) * LD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = xcd_slot(blockIdx.x, gridDim.x);
+    const int ntn = (g.N + BN - 1) / BN;
+    const int bm = (t / ntn) * BM, bn = (t % ntn) * BN;
+    const int wm = (wave / WN) * TM * 16, wn = (wave % WN) * TN * 16;
+    const int r16 = lane & 15, q = lane >> 4;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { acc[i][j].x = acc[i][j].y = acc[i][j].z = acc[i][j].w = 0.0f; }
+    h8 ra[NA], rb[NB];
+    h8 zero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero[e] = (_Float16)0.0f;
+    auto gload = [&](int k0) {                                   // leading dims are multiples of 8 halves, zero padded
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = threadIdx.x + NT * i, row = c / CPR, k = k0 + (c % CPR) * 8;
+            ra[i] = (bm + row < g.M && k < g.lda) ? *reinterpret_cast<const h8*>(g.A + (int64_t)(bm + row) * g.lda + k) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int c = threadIdx.x + NT * i, row = c / CPR, k = k0 + (c % CPR) * 8;
+            rb[i] = (bn + row < g.N && k < g.ldb) ? *reinterpret_cast<const h8*>(g.B + (int64_t)(bn + row) * g.ldb + k) : zero;
+        }
+    };
+    // B rows are permuted on their way into LDS: column n = 32a + 8b + 4c + d of the tile sits in LDS row 32a + 16c + 4b + d, so
+    // MFMA tile ni = 2a + c, fragment row i = 4b + d is column 32a + 8b + 4c + d: lane group q = b then owns, over the tile
+    // pair (2a, 2a + 1), the 8 CONSECUTIVE columns 32a + 8q .. + 7 of its row (16-byte fp16 / 32-byte fp32 epilogue accesses)
+    auto lstore = [&](_Float16* S) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { const int c = threadIdx.x + NT * i; *reinterpret_cast<h8*>(S + (c / CPR) * LD + (c % CPR) * 8) = ra[i]; }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int c = threadIdx.x + NT * i, n = c / CPR;
+            const int row = (n & ~31) | ((n & 4) << 2) | ((n & 24) >> 1) | (n & 3);
+            *reinterpret_cast<h8*>(S + (BM + row) * LD + (c % CPR) * 8) = rb[i];
+        }
+    };
+    auto compute = [&](const _Float16* S) {
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            h8 a[TM], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) a[mi] = *reinterpret_cast<const h8*>(S + (wm + mi * 16 + r16) * LD + kk * 32 + q * 8);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const h8*>(S + (BM + wn + ni * 16 + r16) * LD + kk * 32 + q * 8);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)       // operands swapped: D[n][m], the lane holds C[m = r16][n = 4q .. 4q + 3]
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+        }
+    };
+    const int nk = (g.K + BK - 1) / BK;
+    gload(0);
+    lstore(lds16);
+    if (nk > 1) gload(BK);
+    __syncthreads();
+    for (int s = 0; s < nk; ++s) {
+        _Float16* cur = lds16 + (s & 1) * STAGE; _Float16* nxt = lds16 + ((s + 1) & 1) * STAGE;
+        if (s + 1 < nk) lstore(nxt);
+        if (s + 2 < nk) gload((s + 2) * BK);
+        compute(cur);
+        __syncthreads();
+    }
+    // ---- epilogue: the lane holds C[row = .. + r16][col = 32 * np + 8q .. + 7] for every tile pair np
+    static_assert(TN % 2 == 0, "tile pairs");
+    const bool vec = (g.N & 7) == 0;
+    float cs[TN / 2][8];
+#pragma unroll
+    for (int np = 0; np < TN / 2; ++np)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[np][e] = 0.0f;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int row = bm + wm + mi * 16 + r16;
+#pragma unroll
+        for (int np = 0; np < TN / 2; ++np) {
+            const int col = bn + wn + np * 32 + q * 8;
+            if (row >= g.M || col >= g.N) continue;
+            float v[8] = {acc[mi][2 * np].x, acc[mi][2 * np].y, acc[mi][2 * np].z, acc[mi][2 * np].w,
+                          acc[mi][2 * np + 1].x, acc[mi][2 * np + 1].y, acc[mi][2 * np + 1].z, acc[mi][2 * np + 1].w};
+            const bool full = vec && col + 7 < g.N;
+            if (g.bias) {
+                if (full) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + col), b1 = *reinterpret_cast<const f32x4*>(g.bias + col + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (col + e < g.N) v[e] += g.bias[col + e];
+                }
+            }
+            if (g.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+            } else if (g.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
+            }
+            if (g.actY || g.actY16) {
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = 0.0f;
+                if (g.actY16) {
+                    if (full && (g.ldy & 7) == 0) {
+                        const h8 t8 = *reinterpret_cast<const h8*>(g.actY16 + (int64_t)row * g.ldy + col);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) y[e] = (float)t8[e];
+                    } else {
+                        for (int e = 0; e < 8; ++e) if (col + e < g.N) y[e] = (float)g.actY16[(int64_t)row * g.ldy + col + e];
+                    }
+                } else {
+                    if (full && (g.ldy & 3) == 0) {
+                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(g.actY + (int64_t)row * g.ldy + col), t1 = *reinterpret_cast<const f32x4*>(g.actY + (int64_t)row * g.ldy + col + 4);
+                        y[0] = t0.x; y[1] = t0.y; y[2] = t0.z; y[3] = t0.w; y[4] = t1.x; y[5] = t1.y; y[6] = t1.z; y[7] = t1.w;
+                    } else {
+                        for (int e = 0; e < 8; ++e) if (col + e < g.N) y[e] = g.actY[(int64_t)row * g.ldy + col + e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = g.act_y == 1 ? (y[e] > 0.0f ? v[e] : 0.0f) : (g.act_y == 2 ? v[e] * y[e] * (1.0f - y[e]) : v[e]);
+                    if (col + e < g.N) cs[np][e] += v[e];
+                }
+            }
+            if (g.C) {
+                float* p = g.C + (int64_t)row * g.ldc + col;
+                if (full && (g.ldc & 3) == 0) {
+                    f32x4 o0, o1; o0.x = v[0]; o0.y = v[1]; o0.z = v[2]; o0.w = v[3]; o1.x = v[4]; o1.y = v[5]; o1.z = v[6]; o1.w = v[7];
+                    *reinterpret_cast<f32x4*>(p) = o0; *reinterpret_cast<f32x4*>(p + 4) = o1;
+                } else {
+                    for (int e = 0; e < 8; ++e) if (col + e < g.N) p[e] = v[e];
+                }
+            }
+            if (g.C16) {
+                _Float16* p = g.C16 + (int64_t)row * g.ldc16 + col;
+                if (full && (g.ldc16 & 7) == 0) {
+                    h8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+                    *reinterpret_cast<h8*>(p) = o;
+                } else {
+                    for (int e = 0; e < 8; ++e) if (col + e < g.N) p[e] = (_Float16)v[e];
+                }
+            }
+        }
+    }
+    if (g.gb) {
+        // column sums: over the 16 rows of a lane group (DPP), over the block's WM wavefronts through LDS (the stages are
+        // free now), then ONE atomic per (workgroup, column): same-address atomics from all row blocks serialize in L2, a
+        // per-wavefront atomic made the fused product of a 8192 x 512 x 256 layer take 42 us instead of ~15
+        float* red = reinterpret_cast<float*>(lds16);           // [WM][BN]
+#pragma unroll
+        for (int np = 0; np < TN / 2; ++np)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float s = group_allreduce<16>(cs[np][e]);
+                if (r16 == 0) red[(wave / WN) * BN + wn + np * 32 + q * 8 + e] = s;
+            }
+        __syncthreads();
+        for (int cidx = threadIdx.x; cidx < BN; cidx += NT) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) s += red[w * BN + cidx];
+            if (bn + cidx < g.N) unsafeAtomicAdd(g.gb + bn + cidx, s);
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int MINB>
+static int launch_nt(orx_ctx* ctx, const Nt16Args& g) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr size_t shm = (size_t)2 * (BM + BN) * 72 * 2;
+    auto kern = gemm16_nt_kernel<WM, WN, TM, TN, MINB>;
+    static bool attr = false;
+    if (!attr) { ORX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); attr = true; }
+    const unsigned nb = (unsigned)(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN));
+    ORX_LAUNCH(ctx, kern, dim3(nb), dim3(64 * WM * WN), shm, g);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+bool orx_gemm16_nt_ok(int64_t lda, int64_t ldb, int N, int K) { return lda % 8 == 0 && ldb % 8 == 0 && N >= 32 && K >= 8; }
+
+int orx_launch_gemm16_nt(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
+                         void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act,
+                         const float* actY, const void* actY16, int64_t ldy, int act_y, float* gb) {
+    if (M == 0 || N == 0) return ORX_OK;
+    ORX_ARG(lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)A16 | (uintptr_t)B16) & 15) == 0, "gemm16_nt: operands need 16-byte rows");
+    ProfScope ps(ctx, ORX_K_GEMM);
+    Nt16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, (_Float16*)C16, ldc16, bias, M, N, K, act,
+               actY, (const _Float16*)actY16, ldy, act_y, gb};
+    // the largest tile that still gives every CU a workgroup (256 CUs)
+    auto blocks = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    static const int force = getenv("ORX_GEMM16_TILE") ? atoi(getenv("ORX_GEMM16_TILE")) : 0;
+    const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+    if (force == 1 || (force == 0 && blocks(256, 128) >= cus)) return launch_nt<4, 2, 4, 4, 1>(ctx, g);
+    if (force == 2 || (force == 0 && blocks(128, 128) >= cus)) return launch_nt<2, 2, 4, 4, 2>(ctx, g);
+    return launch_nt<2, 2, 4, 2, 2>(ctx, g);
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+__device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
+    // lane i of a 16-lane group supplies &blk[i / 4][4 * (i % 4)] of a [4][16] fp16 block and receives column i
+    s4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)p);
+    return __builtin_bit_cast(h4, v);
+}
+
+struct Tn16Args {
+    const _Float16* A; int64_t lda;      // [K][lda]: rows = reduction index (samples), M columns used
+    const _Float16* B; int64_t ldb;      // [K][ldb]
+    float* C; int64_t ldc;               // S == 1: C += tile
+    float* slab;                         // S > 1: [tile][S][BM * BN]
+    int M, N, K, kchunk;
+};
+
+// k order inside a 32-deep MFMA step: lane group q holds rows 4q .. 4q + 3 and 16 + 4q .. 16 + 4q + 3 of the stage (the same
+// for both operands, so the sum is a permutation of the same terms); with a 288-byte row pitch the two 16-lane groups of
+// an LDS cycle then sit on different halves of the banks.
+template <int WM, int WN, int TM, int TN, int MINB>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_tn_kernel(Tn16Args g) {
+    constexpr int BK = 64, BM = WM * TM * 16, BN = WN * TN * 16, NT = 64 * WM * WN;
+    constexpr int LDM = BM + 16, LDN = BN + 16;
+    constexpr int CA = BM / 8, CB = BN / 8;
+    constexpr int NA = BK * CA / NT, NB = BK * CB / NT;
+    static_assert(BK * CA % NT == 0 && BK * CB % NT == 0, "tile / thread mismatch");
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds16[];
+    constexpr int STAGE = BK * (LDM + LDN);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM, nt = ntn * ntm;
+    // an XCD takes whole K slices: the tiles of a slice share its rows of A and B, different slices share nothing
+    const int t = xcd_slot(blockIdx.x, gridDim.x);
+    const int bz = t / nt, tile = t - bz * nt;
+    const int bm = (tile / ntn) * BM, bn = (tile % ntn) * BN;
+    const int wm = (wave / WN) * TM * 16, wn = (wave % WN) * TN * 16;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int kbeg = bz * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { acc[i][j].x = acc[i][j].y = acc[i][j].z = acc[i][j].w = 0.0f; }
+    h8 ra[NA], rb[NB];
+    h8 zero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero[e] = (_Float16)0.0f;
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = threadIdx.x + NT * i, kr = c / CA, col = bm + (c % CA) * 8;
+            ra[i] = (k0 + kr < kend && col < g.lda) ? *reinterpret_cast<const h8*>(g.A + (int64_t)(k0 + kr) * g.lda + col) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int c = threadIdx.x + NT * i, kr = c / CB, col = bn + (c % CB) * 8;
+            rb[i] = (k0 + kr < kend && col < g.ldb) ? *reinterpret_cast<const h8*>(g.B + (int64_t)(k0 + kr) * g.ldb + col) : zero;
+        }
+    };
+    auto lstore = [&](_Float16* S) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { const int c = threadIdx.x + NT * i; *reinterpret_cast<h8*>(S + (c / CA) * LDM + (c % CA) * 8) = ra[i]; }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { const int c = threadIdx.x + NT * i; *reinterpret_cast<h8*>(S + BK * LDM + (c / CB) * LDN + (c % CB) * 8) = rb[i]; }
+    };
+    const int tr_a = (q * 4 + i16 / 4) * LDM + (i16 % 4) * 4, tr_b = (q * 4 + i16 / 4) * LDN + (i16 % 4) * 4;
+    auto compute = [&](const _Float16* S) {
+        const _Float16* SA = S; const _Float16* SB = S + BK * LDM;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            h8 a[TM], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const h4 lo = lds_tr_read(SA + (kk * 32) * LDM + tr_a + wm + mi * 16), hi = lds_tr_read(SA + (kk * 32 + 16) * LDM + tr_a + wm + mi * 16);
+                a[mi] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const h4 lo = lds_tr_read(SB + (kk * 32) * LDN + tr_b + wn + ni * 16), hi = lds_tr_read(SB + (kk * 32 + 16) * LDN + tr_b + wn + ni * 16);
+                b[ni] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+        }
+    };
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        gload(kbeg);
+        lstore(lds16);
+        if (nk > 1) gload(kbeg + BK);
+        __syncthreads();
+        for (int s = 0; s < nk; ++s) {
+            _Float16* cur = lds16 + (s & 1) * STAGE; _Float16* nxt = lds16 + ((s + 1) & 1) * STAGE;
+            if (s + 1 < nk) lstore(nxt);
+            if (s + 2 < nk) gload(kbeg + (s + 2) * BK);
+            compute(cur);
+            __syncthreads();
+        }
+    }
+    const int S = gridDim.x / nt;
+    if (S > 1) {
+        float* mine = g.slab + ((size_t)tile * S + bz) * (BM * BN);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                *reinterpret_cast<f32x4*>(mine + (wm + mi * 16 + i16) * BN + wn + ni * 16 + q * 4) = acc[mi][ni];
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int row = bm + wm + mi * 16 + i16;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = bn + wn + ni * 16 + q * 4;
+            if (row >= g.M) continue;
+            const float v[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (col + e < g.N) g.C[(int64_t)row * g.ldc + col + e] += v[e];
+        }
+    }
+}
+
+// C += sum over the S slices of every tile; one launch serves all layers of an MLP backward.  grid = (max tiles, 8 parts, layers)
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduce* jobs) {
+    const SlabReduce j = jobs[blockIdx.z];
+    const int tile = blockIdx.x;
+    if (tile >= j.tiles) return;
+    const int by = tile / j.ntn, bx = tile - by * j.ntn;
+    const float* base = j.slab + (size_t)tile * j.S * (BM * BN);
+    for (int e = threadIdx.x + 256 * blockIdx.y; e < BM * BN / 4; e += 256 * gridDim.y) {
+        const int r = (e * 4) / BN, c = (e * 4) % BN;
+        const int row = by * BM + r, col = bx * BN + c;
+        if (row >= j.M || col >= j.N) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 8 <= j.S; z += 8) {                       // 8 slices in flight, summed in slice order
+            f32x4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (size_t)(z + u) * (BM * BN) + e * 4));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += w[u];
+        }
+        for (; z < j.S; ++z) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (size_t)z * (BM * BN) + e * 4));
+        float* p = j.C + (int64_t)row * j.ldc + col;
+        const float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (col + k < j.N) p[k] += o[k];
+    }
+}
+
+// the split the launcher will use for a [M x N] gradient over K samples (slab floats needed = tiles * S * 128 * 128)
+void orx_gemm16_tn_plan(orx_ctx* ctx, int M, int N, int K, int* S_out, int* tiles_out, int* kchunk_out) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+    int S = std::max(1, std::min(32, (2 * cus) / tiles));           // two 4-wavefront workgroups per CU
+    int kchunk = (((K + S - 1) / S + 63) / 64) * 64;
+    S = (K + kchunk - 1) / kchunk;
+    *S_out = S; *tiles_out = tiles; *kchunk_out = kchunk;
+}
+
+bool orx_gemm16_tn_ok(int64_t lda, int64_t ldb, int N) { return lda % 8 == 0 && ldb % 8 == 0 && N % 8 == 0; }
+
+int orx_launch_gemm16_tn(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
+                         float* slab, int M, int N, int K) {
+    if (M == 0 || N == 0 || K == 0) return ORX_OK;
+    ORX_ARG(lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)A16 | (uintptr_t)B16) & 15) == 0, "gemm16_tn: operands need 16-byte rows");
+    ProfScope ps(ctx, ORX_K_GEMM);
+    int S, tiles, kchunk;
+    orx_gemm16_tn_plan(ctx, M, N, K, &S, &tiles, &kchunk);
+    ORX_ARG(S == 1 || slab != nullptr, "gemm16_tn: split-K needs a slab workspace");
+    Tn16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, slab, M, N, K, kchunk};
+    constexpr size_t shm = (size_t)2 * 64 * (128 + 16 + 128 + 16) * 2;
+    auto kern = gemm16_tn_kernel<2, 2, 4, 4, 2>;
+    static bool attr = false;
+    if (!attr) { ORX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); attr = true; }
+    ORX_LAUNCH(ctx, kern, dim3((unsigned)(tiles * S)), dim3(256), shm, g);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_launch_slab_reduce(orx_ctx* ctx, const void* jobs_dev, int n_jobs, int max_tiles) {
+    if (n_jobs == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, (slab_reduce_kernel<128, 128>), dim3((unsigned)max_tiles, 8, (unsigned)n_jobs), dim3(256), 0, (const SlabReduce*)jobs_dev);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// fp16 copy of an fp32 activation [M][N] (row stride lds_) into [M][ld16], padding columns zeroed: the interaction kernels
+// other than the MFMA one leave R in fp32 only
+__global__ __launch_bounds__(256) void cast16_kernel(const float* src, int64_t lds_, _Float16* dst, int64_t ld16, int M, int N) {
+    const int64_t total = (int64_t)M * ld16, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / ld16; const int c = (int)(i - r * ld16);
+        dst[i] = c < N ? (_Float16)src[r * lds_ + c] : (_Float16)0.0f;
+    }
+}
+
+int orx_launch_cast16(orx_ctx* ctx, const float* src, int64_t lds_, void* dst16, int64_t ld16, int M, int N) {
+    if (M == 0 || N == 0) return ORX_OK;
+    int64_t g = ((int64_t)M * ld16 + 255) / 256; if (g > 8192) g = 8192;
+    ORX_LAUNCH(ctx, cast16_kernel, dim3((unsigned)g), dim3(256), 0, src, lds_, (_Float16*)dst16, ld16, M, N);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}

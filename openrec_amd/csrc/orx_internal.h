@@ -385,6 +385,19 @@ int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t l
 int orx_launch_gemm_f16s(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                          void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act,
                          const float* actY = nullptr, int64_t ldy = 0, int act_y = 0, float* gb = nullptr);
+// second-generation fp16 products (kernels_gemm16.hip): C = A16 * B16^T on K-contiguous fp16 operands with the fused epilogues,
+// and the weight gradient C += A16^T * B16 from batch-major fp16 copies (split-K through fp32 slabs + one reduce launch)
+bool orx_gemm16_nt_ok(int64_t lda, int64_t ldb, int N, int K);
+int orx_launch_gemm16_nt(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
+                         void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act,
+                         const float* actY = nullptr, const void* actY16 = nullptr, int64_t ldy = 0, int act_y = 0, float* gb = nullptr);
+struct SlabReduce { const float* slab; float* C; int64_t ldc; int M, N, S, ntn, tiles; };
+bool orx_gemm16_tn_ok(int64_t lda, int64_t ldb, int N);
+void orx_gemm16_tn_plan(orx_ctx* ctx, int M, int N, int K, int* S_out, int* tiles_out, int* kchunk_out);
+int orx_launch_gemm16_tn(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
+                         float* slab, int M, int N, int K);
+int orx_launch_slab_reduce(orx_ctx* ctx, const void* jobs_dev, int n_jobs, int max_tiles);
+int orx_launch_cast16(orx_ctx* ctx, const float* src, int64_t lds_, void* dst16, int64_t ld16, int M, int N);
 struct ShadowParam { const float* w; void* w16; void* w16t; int in, out, ld16, ld16t; };
 int orx_launch_dense_shadow(orx_ctx* ctx, const ShadowParam* ps_dev, int count, int64_t max_n);
 int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act);

@@ -143,6 +143,52 @@ def test_dlrm_fp16_mlp_mode_tracks_the_fp32_oracle():
         assert np.abs(du - dr).max() < 0.03 * np.abs(dr).max() + 1e-7, key
 
 
+@pytest.mark.parametrize("compat", [False, True])
+@pytest.mark.parametrize("cfg_name", ["narrow", "wide", "ragged"])
+def test_dlrm_fp16_mlp_mode_over_several_steps_and_shapes(cfg_name, compat):
+    """ORX_DLRM_FP16_MLP across several steps (the fp16 weight copies must follow every update: a copy refreshed one step late
+    would show as a first-order error in the second step's update), layer widths that exercise every tile shape of
+    kernels_gemm16.hip (256x128 / 128x128 / 128x64 blocks, partial tiles, widths not a multiple of 8 that fall back to the
+    fp32-operand kernels), the fp16-only ("lean") activations, and both interaction modes (reference_compat: R16 comes from the
+    cast kernel instead of the MFMA interaction)."""
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    from oracle.dlrm_oracle import DLRMOracle
+    rng = np.random.default_rng(11)
+    ln_emb = [50, 300, 7, 1000, 33]
+    cfg = {"narrow": dict(m_spa=16, ln_bot=[64, 16], ln_top=[128, 64, 1], B=700),
+           "wide": dict(m_spa=32, ln_bot=[512, 256, 32], ln_top=[1024, 512, 256, 1], B=2304),
+           "ragged": dict(m_spa=24, ln_bot=[100, 36, 24], ln_top=[136, 100, 40, 1], B=517)}[cfg_name]
+    B = cfg.pop("B")
+    cfg.update(ln_emb=ln_emb, dense_dim=13)
+    o = DLRMOracle(dtype=np.float32, seed=5, reference_compat=compat, **cfg)
+    m = rt.DLRMModel(reference_compat=compat, fp16_mlp=True, **cfg)
+    m.param("emb").write(np.concatenate(o.emb))
+    for nm, layers in (("bot", o.bot), ("top", o.top)):
+        for l, (W, b) in enumerate(layers):
+            b[:] = rng.normal(size=b.shape).astype(np.float32) * 0.1
+            m.param(nm + "_w", l).write(W); m.param(nm + "_b", l).write(b.reshape(1, -1))
+    opt, oo = rt.Optimizer.sgd(0.02), orc.SGD(0.02)     # (at lr 0.2 units go borderline-dead and fp16 noise flips relu masks: 22 % seen)
+    for step in range(3):
+        dense = np.log1p(rng.integers(0, 100, (B, 13))).astype(np.float32)
+        sparse = np.stack([rng.integers(0, n, B) for n in ln_emb], 1).astype(np.int32)
+        label = (rng.uniform(size=B) < 0.3).astype(np.float32)
+        before = [(nm, l, o.__dict__[nm][l][0].copy(), o.__dict__[nm][l][1].copy()) for nm in ("bot", "top") for l in range(len(o.__dict__[nm]))]
+        l16 = m.step(opt, dense, sparse, label)[0]
+        l32 = o.step(dense, sparse, label, oo)
+        assert abs(l16 - l32) < 5e-3 * abs(l32), (step, l16, l32)
+        for nm, l, W0, b0 in before:                       # every dense parameter's UPDATE of this step, to fp16 accuracy
+            W1, b1 = o.__dict__[nm][l]
+            dW, db = m.param(nm + "_w", l).read() - W0, m.param(nm + "_b", l).read().reshape(-1) - b0.reshape(-1)
+            rW, rb = W1 - W0, (b1 - b0).reshape(-1)
+            assert np.abs(dW - rW).max() < 0.06 * np.abs(rW).max() + 1e-7, (step, nm, l, "W")
+            assert np.abs(db - rb).max() < 0.06 * np.abs(rb).max() + 1e-7, (step, nm, l, "b")   # (fp16 operands through up to 7 chained products)
+            # the device keeps training from ITS parameters: re-sync so the per-step comparison stays first order
+            m.param(nm + "_w", l).write(W1); m.param(nm + "_b", l).write(b1.reshape(1, -1))
+        m.param("emb").write(np.concatenate(o.emb))
+    assert np.abs(m.inference(dense, sparse) - o.inference(dense, sparse)).max() < 5e-3
+
+
 @pytest.mark.parametrize("m_spa,n_emb,itself,optname", [(32, 26, False, "sgd"), (64, 5, True, "sgd"), (128, 26, False, "adagrad"),
                                                         (32, 31, True, "sgd"), (64, 16, False, "sgd")])
 def test_dlrm_wide_embeddings_mfma_interaction(m_spa, n_emb, itself, optname):
