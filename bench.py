@@ -130,7 +130,8 @@ def bench_dlrm(args, torch, rt, world, rank, local_rank, device, dist):
         if gp.get("launches"):
             tf = flops * K / (gp["total_ms"] * 1e-3) / 1e12
             peak = 2500.0 if args.fp16_mlp else 157.3         # MI355X_MICROARCH.md: dense fp16 MFMA / fp32 (xf32-less) matrix peak, TFLOP/s
-            extra = {"roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel" if args.fp16_mlp else "gemm_f32_kernel", "achieved": tf,
+            extra = {"roofline": {"bound": "mfma", "kernel": ("gemm16_nt_kernel + gemm16_tn_kernel + slab_reduce_kernel + head kernels (all MLP products of the step)"
+                                                              if args.fp16_mlp else "gemm_f32v_kernel"), "achieved": tf,
                                   "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
                                   "gemm_ms_per_step": gp["total_ms"] / K, "flops_per_step": flops}}
     else:

@@ -25,6 +25,7 @@ struct DenseLayer {
     bool lean = false;                  // the layer's output lives only as its fp16 copy (no fp32 store): its consumers -- the next
                                         // layer's three products and the fused activation backward -- all read fp16
     bool dw16 = false;                  // the weight gradient comes from the batch-major fp16 copies (gemm16_tn)
+    bool head = false;                  // the 1-unit last layer of the top MLP on the fused head kernels (kernels_gemm16.hip)
     float* slab = nullptr;              // split-K slices of this layer's weight gradient, [tiles][S][128 * 128]
     int slab_S = 1, slab_tiles = 0;
 };
@@ -174,6 +175,12 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
         };
         flags_of(m->bot, dense_dim);
         flags_of(m->top, m_spa + m->P);
+        const size_t nt_ = m->top.size();
+        if (nt_ >= 2 && getenv("ORX_DLRM_NO_HEAD") == nullptr) {
+            DenseLayer& H = m->top[nt_ - 1]; DenseLayer& Bl = m->top[nt_ - 2];
+            H.head = H.out == 1 && H.w16t != nullptr && Bl.w16 != nullptr && Bl.act != 2 && Bl.out % 8 == 0 && orx_head16_ok(H.in, up8(Bl.out));
+            if (H.head) Bl.lean = getenv("ORX_DLRM_NO_LEAN") == nullptr;          // nothing reads the fp32 output of the layer below the head
+        }
     }
     m->ldR = (m_spa + m->P + 3) & ~3;
     m->maxw = m->ldR;
@@ -283,7 +290,7 @@ static int ensure_buffers(orx_dlrm* m, int64_t B) {
                 orx_gemm16_tn_plan(m->ctx, D.in, D.out, (int)B, &S, &tiles, &kchunk);
                 D.slab_S = S; D.slab_tiles = tiles;
                 if (S > 1) {
-                    ORX_HIP(hipMalloc((void**)&D.slab, (size_t)tiles * S * 128 * 128 * sizeof(float)));
+                    ORX_HIP(hipMalloc((void**)&D.slab, (size_t)tiles * S * ORX_SLAB_STRIDE * sizeof(float)));
                     CHECK(orx_table_scratch(D.W));
                     SlabReduce j; j.slab = D.slab; j.C = D.W->gsum; j.ldc = D.out; j.M = D.in; j.N = D.out; j.S = S; j.ntn = (D.out + 127) / 128; j.tiles = tiles;
                     jobs.push_back(j); m->slab_max_tiles[k] = std::max(m->slab_max_tiles[k], tiles);
@@ -366,7 +373,9 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
         const bool last = l + 1 == m->top.size();
         if (f16 && have16) {            // X16 * W16T: fp16-resident operands, fp16 copy of the output for the next layer
             void* y16 = last ? nullptr : m->top_y16[l];
-            if (m->gen2 && orx_gemm16_nt_ok(ldx16, L.ld16t, L.out, L.in))
+            if (L.head)
+                CHECK(orx_launch_head_fwd(c, x16, ldx16, L.w16t, L.b->w, L.act, m->top_y[l], (int)B, L.in));
+            else if (m->gen2 && orx_gemm16_nt_ok(ldx16, L.ld16t, L.out, L.in))
                 CHECK(orx_launch_gemm16_nt(c, x16, ldx16, L.w16t, L.ld16t, L.lean ? nullptr : m->top_y[l], L.out, y16, up8(L.out), L.b->w, (int)B, L.out, L.in, L.act));
             else
             CHECK(orx_launch_gemm_f16s(c, x16, ldx16, L.w16t, L.ld16t, m->top_y[l], L.out, y16, up8(L.out), L.b->w, (int)B, L.out, L.in, L.act));
@@ -422,6 +431,18 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
         DenseLayer& D = L[l];
         CHECK(orx_table_scratch(D.W)); CHECK(orx_table_scratch(D.b));
         const bool want_dx = l > 0 || need_dx0;
+        if (D.head && l > 0 && !act_done && ins16 && (*ins16)[l] && m->g16) {
+            // the 1-unit head: activation backward, weight / bias gradient, input gradient and the activation backward of
+            // the layer below in one pass over that layer's fp16 output
+            DenseLayer& Bl = L[l - 1];
+            CHECK(orx_table_scratch(Bl.b));
+            const bool below16 = Bl.dw16 && orx_gemm16_nt_ok(Bl.out, Bl.ld16, Bl.in, Bl.out);
+            CHECK(orx_launch_head_bwd(c, (*ins16)[l], (*ld_in16)[l], D.w16t, dy, outs[l], D.act, Bl.act, D.W->gsum, D.b->gsum,
+                                      m->g16, Bl.out, below16 ? nullptr : other, ld_in[l], Bl.b->gsum, (int)B, D.in));
+            act_done = true; dy16 = m->g16; dy32 = !below16;
+            float* t = dy; dy = other; other = t;
+            continue;
+        }
         const bool s16 = D.w16 != nullptr && m->g16 != nullptr && D.out % 8 == 0 && want_dx;
         // dZ = dY * act'(Y) and gb = colsum(dZ) in one pass (unless the product above already did it).  The gradient
         // buffers are zero here (the optimizer kernels zero them behind themselves), so slab sums / split-K just add.

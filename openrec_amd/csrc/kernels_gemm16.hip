@@ -244,8 +244,10 @@ int orx_launch_gemm16_nt(orx_ctx* ctx, const void* A16, int64_t lda, const void*
     auto blocks = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     static const int force = getenv("ORX_GEMM16_TILE") ? atoi(getenv("ORX_GEMM16_TILE")) : 0;
     const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+    // (the 4-wavefront configurations want two workgroups per CU: with one, every load and barrier latency of the short K
+    // loops of the narrow layers is exposed -- a fused 8192 x 512 x 256 product took 18 us on 256 tiles of 128 x 128)
     if (force == 1 || (force == 0 && blocks(256, 128) >= cus)) return launch_nt<4, 2, 4, 4, 1>(ctx, g);
-    if (force == 2 || (force == 0 && blocks(128, 128) >= cus)) return launch_nt<2, 2, 4, 4, 2>(ctx, g);
+    if (force == 2 || (force == 0 && blocks(128, 128) >= 2 * cus)) return launch_nt<2, 2, 4, 4, 2>(ctx, g);
     return launch_nt<2, 2, 4, 2, 2>(ctx, g);
 }
 
@@ -255,6 +257,10 @@ __device__ __forceinline__ h4 lds_tr_read(const _Float16* p) {
     s4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)p);
     return __builtin_bit_cast(h4, v);
 }
+
+// one slice of one tile in the split-K workspace: 128 x 128 floats + 256 bytes, so that the S slices of a tile (read together by
+// the reduce kernel) do not all start on the same memory channel
+constexpr size_t SLAB_STRIDE = ORX_SLAB_STRIDE;
 
 struct Tn16Args {
     const _Float16* A; int64_t lda;      // [K][lda]: rows = reduction index (samples), M columns used
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_tn_kernel(Tn16Args 
     }
     const int S = gridDim.x / nt;
     if (S > 1) {
-        float* mine = g.slab + ((size_t)tile * S + bz) * (BM * BN);
+        float* mine = g.slab + ((size_t)tile * S + bz) * SLAB_STRIDE;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduce* jobs
     const int tile = blockIdx.x;
     if (tile >= j.tiles) return;
     const int by = tile / j.ntn, bx = tile - by * j.ntn;
-    const float* base = j.slab + (size_t)tile * j.S * (BM * BN);
+    const float* base = j.slab + (size_t)tile * j.S * SLAB_STRIDE;
     for (int e = threadIdx.x + 256 * blockIdx.y; e < BM * BN / 4; e += 256 * gridDim.y) {
         const int r = (e * 4) / BN, c = (e * 4) % BN;
         const int row = by * BM + r, col = bx * BN + c;
@@ -389,12 +395,13 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduce* jobs
         for (; z + 8 <= j.S; z += 8) {                       // 8 slices in flight, summed in slice order
             f32x4 w[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (size_t)(z + u) * (BM * BN) + e * 4));
+            for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (size_t)(z + u) * SLAB_STRIDE + e * 4));
 #pragma unroll
             for (int u = 0; u < 8; ++u) v += w[u];
         }
-        for (; z < j.S; ++z) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (size_t)z * (BM * BN) + e * 4));
+        for (; z < j.S; ++z) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (size_t)z * SLAB_STRIDE + e * 4));
         float* p = j.C + (int64_t)row * j.ldc + col;
+        if (col + 3 < j.N && (j.ldc & 3) == 0) { f32x4 o = *reinterpret_cast<f32x4*>(p); o += v; *reinterpret_cast<f32x4*>(p) = o; continue; }
         const float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (col + k < j.N) p[k] += o[k];
@@ -433,6 +440,7 @@ int orx_launch_gemm16_tn(orx_ctx* ctx, const void* A16, int64_t lda, const void*
 
 int orx_launch_slab_reduce(orx_ctx* ctx, const void* jobs_dev, int n_jobs, int max_tiles) {
     if (n_jobs == 0) return ORX_OK;
+    ProfScope ps(ctx, ORX_K_GEMM);                            // (part of the weight-gradient products' cost)
     ORX_LAUNCH(ctx, (slab_reduce_kernel<128, 128>), dim3((unsigned)max_tiles, 8, (unsigned)n_jobs), dim3(256), 0, (const SlabReduce*)jobs_dev);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
@@ -451,7 +459,144 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* src, int64_t l
 int orx_launch_cast16(orx_ctx* ctx, const float* src, int64_t lds_, void* dst16, int64_t ld16, int M, int N) {
     if (M == 0 || N == 0) return ORX_OK;
     int64_t g = ((int64_t)M * ld16 + 255) / 256; if (g > 8192) g = 8192;
+    ProfScope ps(ctx, ORX_K_GEMM);
     ORX_LAUNCH(ctx, cast16_kernel, dim3((unsigned)g), dim3(256), 0, src, lds_, (_Float16*)dst16, ld16, M, N);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the 1-unit head
+// The top MLP ends in one unit (dlrm.py:57-61: ln_top[-1] == 1): its three "products" are a GEMV, an outer product and a
+// weighted column sum over [B][K] -- 4 MB at K = 256 -- which the tiled kernels ran as three launches of ~15-23 us each.
+// head_fwd: pred[b] = act(b0 + sum_k X16[b][k] * w16[k]).  head_bwd, one pass over X16 (= the fp16 copy of the layer below's
+// output Y): dz[b] = dy[b] * act'(pred[b]); gb += sum dz; gW[k] += sum_b X16[b][k] * dz16[b]; and the input gradient with the
+// layer below's activation backward folded in: dZb[b][k] = dz16[b] * w16[k] * act_b'(Y[b][k]) -> fp16 (and fp32 on request),
+// gbb[k] += sum_b dZb[b][k].  Operands are rounded to fp16 where the MFMA path rounds them (dz, w, X).
+// Half a wavefront per row (lane j owns chunks j, j + 32, ... of 8 halves), HEAD_ROWS rows per workgroup, one atomic per
+// (workgroup, column) after an LDS reduction.
+constexpr int HEAD_KMAX = 1024, HEAD_J = HEAD_KMAX / 256;
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const _Float16* X, int64_t ldx, const _Float16* w, const float* bias, int act,
+                                                       float* pred, int B, int K) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
+    float s = 0.0f;
+    if (row < B) {
+        for (int c = l32; c * 8 < K; c += 32) {
+            const h8 x = *reinterpret_cast<const h8*>(X + (int64_t)row * ldx + c * 8), ww = *reinterpret_cast<const h8*>(w + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)x[e] * (float)ww[e];
+        }
+    }
+    s = group_allreduce<32>(s);
+    if (row < B && l32 == 0) {
+        float v = s + bias[0];
+        if (act == 1) v = fmaxf(v, 0.0f); else if (act == 2) v = 1.0f / (1.0f + __expf(-v));
+        pred[row] = v;
+    }
+}
+
+struct HeadBwdArgs {
+    const _Float16* X; int64_t ldx;      // [B][ldx]: input of the head = fp16 copy of the layer below's output
+    const _Float16* w;                   // [K] fp16 copy of the head's weights
+    const float* dy; const float* pred;  // [B]
+    int act, act_below;
+    float* gW; float* gb;                // head gradients (+=)
+    _Float16* dZ16; int64_t ld16;        // [B][ld16] gradient w.r.t. the layer below's pre-activation
+    float* dZ32; int64_t ld32;           // optional
+    float* gb_below;                     // [K] (+=)
+    int B, K, rows_per_block;
+};
+
+__global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
+    __shared__ float red[8][HEAD_KMAX / 8][8 + 1];             // [half-wave][chunk][e]  (padded), used twice
+    __shared__ float red_b[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l32 = lane & 31;
+    const int hw = wave * 2 + half;                            // 8 half-wavefronts, each takes every 8th row of the block's slab
+    const int r0 = blockIdx.x * a.rows_per_block, r1 = min(a.B, r0 + a.rows_per_block);
+    float gw[HEAD_J][8], gbb[HEAD_J][8];
+    h8 wv[HEAD_J];
+#pragma unroll
+    for (int j = 0; j < HEAD_J; ++j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gw[j][e] = 0.0f; gbb[j][e] = 0.0f; wv[j][e] = (_Float16)0.0f; }
+        const int c = l32 + 32 * j;
+        if (c * 8 < a.K) wv[j] = *reinterpret_cast<const h8*>(a.w + c * 8);
+    }
+    float gb = 0.0f;
+    for (int row = r0 + hw; row < r1; row += 8) {
+        const float p = a.pred[row];
+        float dz = a.dy[row];
+        dz = a.act == 1 ? (p > 0.0f ? dz : 0.0f) : (a.act == 2 ? dz * p * (1.0f - p) : dz);
+        if (l32 == 0) gb += dz;
+        const float dzh = (float)(_Float16)dz;
+#pragma unroll
+        for (int j = 0; j < HEAD_J; ++j) {
+            const int c = l32 + 32 * j;
+            if (c * 8 >= a.K) continue;
+            const h8 x = *reinterpret_cast<const h8*>(a.X + (int64_t)row * a.ldx + c * 8);
+            h8 o;
+            float o32[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y = (float)x[e];
+                gw[j][e] += y * dzh;
+                float d = dzh * (float)wv[j][e];
+                d = a.act_below == 1 ? (y > 0.0f ? d : 0.0f) : (a.act_below == 2 ? d * y * (1.0f - y) : d);
+                gbb[j][e] += d; o[e] = (_Float16)d; o32[e] = d;
+            }
+            *reinterpret_cast<h8*>(a.dZ16 + (int64_t)row * a.ld16 + c * 8) = o;
+            if (a.dZ32) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a.dZ32[(int64_t)row * a.ld32 + c * 8 + e] = o32[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int j = 0; j < HEAD_J; ++j) {
+            const int c = l32 + 32 * j;
+            if (c * 8 >= a.K) continue;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[hw][c][e] = pass == 0 ? gw[j][e] : gbb[j][e];
+        }
+        if (pass == 0 && l32 == 0) red_b[hw] = gb;
+        __syncthreads();
+        for (int k = threadIdx.x; k < a.K; k += 256) {
+            float s0 = 0.0f;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) s0 += red[h][k >> 3][k & 7];
+            unsafeAtomicAdd((pass == 0 ? a.gW : a.gb_below) + k, s0);
+        }
+        if (pass == 0 && threadIdx.x == 0) {
+            float s = 0.0f;
+            for (int h = 0; h < 8; ++h) s += red_b[h];
+            unsafeAtomicAdd(a.gb, s);
+        }
+        __syncthreads();
+    }
+}
+
+bool orx_head16_ok(int K, int64_t ldx) { return K % 8 == 0 && K >= 8 && K <= HEAD_KMAX && ldx % 8 == 0; }
+
+int orx_launch_head_fwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* bias, int act, float* pred, int B, int K) {
+    if (B == 0) return ORX_OK;
+    ProfScope ps(ctx, ORX_K_GEMM);
+    ORX_LAUNCH(ctx, head_fwd_kernel, dim3((unsigned)((B + 7) / 8)), dim3(256), 0, (const _Float16*)X16, ldx, (const _Float16*)w16, bias, act, pred, B, K);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_launch_head_bwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* dy, const float* pred, int act, int act_below,
+                        float* gW, float* gb, void* dZ16, int64_t ld16, float* dZ32, int64_t ld32, float* gb_below, int B, int K) {
+    if (B == 0) return ORX_OK;
+    ProfScope ps(ctx, ORX_K_GEMM);
+    const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+    int rows = std::max(64, (int)((B + cus - 1) / cus));           // <= one workgroup per CU, >= 64 rows each (atomics per column = blocks)
+    rows = (rows + 7) / 8 * 8;
+    HeadBwdArgs a{(const _Float16*)X16, ldx, (const _Float16*)w16, dy, pred, act, act_below, gW, gb, (_Float16*)dZ16, ld16, dZ32, ld32, gb_below, B, K, rows};
+    ORX_LAUNCH(ctx, head_bwd_kernel, dim3((unsigned)((B + rows - 1) / rows)), dim3(256), 0, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

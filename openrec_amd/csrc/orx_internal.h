@@ -391,6 +391,7 @@ bool orx_gemm16_nt_ok(int64_t lda, int64_t ldb, int N, int K);
 int orx_launch_gemm16_nt(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                          void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act,
                          const float* actY = nullptr, const void* actY16 = nullptr, int64_t ldy = 0, int act_y = 0, float* gb = nullptr);
+#define ORX_SLAB_STRIDE (128 * 128 + 64)          // floats per (tile, slice) of a split-K workspace (kernels_gemm16.hip)
 struct SlabReduce { const float* slab; float* C; int64_t ldc; int M, N, S, ntn, tiles; };
 bool orx_gemm16_tn_ok(int64_t lda, int64_t ldb, int N);
 void orx_gemm16_tn_plan(orx_ctx* ctx, int M, int N, int K, int* S_out, int* tiles_out, int* kchunk_out);
@@ -398,6 +399,10 @@ int orx_launch_gemm16_tn(orx_ctx* ctx, const void* A16, int64_t lda, const void*
                          float* slab, int M, int N, int K);
 int orx_launch_slab_reduce(orx_ctx* ctx, const void* jobs_dev, int n_jobs, int max_tiles);
 int orx_launch_cast16(orx_ctx* ctx, const float* src, int64_t lds_, void* dst16, int64_t ld16, int M, int N);
+bool orx_head16_ok(int K, int64_t ldx);
+int orx_launch_head_fwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* bias, int act, float* pred, int B, int K);
+int orx_launch_head_bwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* dy, const float* pred, int act, int act_below,
+                        float* gW, float* gb, void* dZ16, int64_t ld16, float* dZ32, int64_t ld32, float* gb_below, int B, int K);
 struct ShadowParam { const float* w; void* w16; void* w16t; int in, out, ld16, ld16t; };
 int orx_launch_dense_shadow(orx_ctx* ctx, const ShadowParam* ps_dev, int count, int64_t max_n);
 int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act);
