@@ -59,6 +59,7 @@ struct orx_dlrm {
     std::vector<void*> top_y16;         // output of top layer l (l < last), [cap][up8(out)]
     void* g16 = nullptr, *g16b = nullptr;   // dY after the activation backward, [cap][up8(maxw)], ping-pong
     ShadowParam* d_shadow = nullptr; int n_shadow = 0; int64_t shadow_max = 0;
+    const int32_t* direct_idx = nullptr;    // set by forward(): the interaction reads embedding rows through these ids (no gathered copy in Z)
     bool gen2 = false;                  // ORX_DLRM_FP16_MLP with the kernels of kernels_gemm16.hip (ORX_DLRM_GEMM_V1 = the round-1 kernels)
     SlabReduce* d_slabjobs[2] = {nullptr, nullptr}; int n_slabjobs[2] = {0, 0}, slab_max_tiles[2] = {0, 0};   // [0] bottom, [1] top MLP
     void* dense16 = nullptr; int ld_dense16 = 0;   // fp16 copy of the dense features (operand of the first bottom layer)
@@ -323,6 +324,7 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
     orx_ctx* c = m->ctx;
     const int F = m->F, d = m->m_spa;
     const int compat = (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0, itself = (m->flags & ORX_DLRM_INTERACT_ITSELF) ? 1 : 0;
+    m->direct_idx = nullptr;
     if (emb_rows != nullptr) {
         CHECK(orx_launch_copy2d(c, m->Z, (int64_t)F * d, emb_rows, (int64_t)m->n_emb * d, (int)B, m->n_emb * d));
     } else {
@@ -333,8 +335,10 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
         }
         // a table under the lazy Adam: the rows about to be read are replayed to the optimizer's step first
         if (!touched) CHECK(orx_table_touch(m->emb, idx, B * F));
-        // dlrm.py:83-85: the n_emb gathers = one gather on the combined table (dense slot skipped)
-        CHECK(orx_launch_gather(c, m->emb->w, nullptr, m->emb->rows, d, idx, B * F, m->Z, d, c->d_err, 1));
+        // dlrm.py:83-85: the n_emb gathers = one gather on the combined table (dense slot skipped) -- or none at all: the
+        // MFMA interaction kernels (forward and backward) read the rows from the table through idx
+        m->direct_idx = orx_interact_direct_ok(F, d, compat) ? idx : nullptr;
+        if (!m->direct_idx) CHECK(orx_launch_gather(c, m->emb->w, nullptr, m->emb->rows, d, idx, B * F, m->Z, d, c->d_err, 1));
     }
     const bool f16 = (m->flags & ORX_DLRM_FP16_MLP) != 0;
     if (f16) CHECK(orx_launch_dense_shadow(c, m->d_shadow, m->n_shadow, m->shadow_max));   // W changed since the last step
@@ -361,7 +365,8 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
     }
     // dlrm.py:89-92: R = concat(dense_emb, interaction)
     bool have16 = false;                                         // does the current activation have an fp16 copy?
-    CHECK(orx_launch_interact(c, true, m->Z, nullptr, F, d, compat, itself, m->R, m->P, B, m->ldR, f16 ? m->R16 : nullptr, m->ldR16, &have16));
+    CHECK(orx_launch_interact(c, true, m->Z, nullptr, F, d, compat, itself, m->R, m->P, B, m->ldR, f16 ? m->R16 : nullptr, m->ldR16, &have16,
+                              m->direct_idx ? m->emb->w : nullptr, m->direct_idx, m->direct_idx ? m->emb->rows : 0));
     if (m->gen2 && !have16) {            // (the LDS interaction kernels -- reference_compat, odd shapes -- write fp32 only)
         CHECK(orx_launch_cast16(c, m->R, m->ldR, m->R16, m->ldR16, (int)B, m->m_spa + m->P));
         have16 = true;
@@ -529,7 +534,8 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B) {
         }
     CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR, m->gen2 ? &ins16 : nullptr, &ldi16, &outs16));
     // ---- interaction backward: dZ for every slot (slot F-1 = d dense_emb)
-    CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B, m->ldR));
+    CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B, m->ldR, nullptr, 0, nullptr,
+                              m->direct_idx ? m->emb->w : nullptr, m->direct_idx, m->direct_idx ? m->emb->rows : 0));
     // ---- bottom MLP backward from dZ[:, F-1, :]
     float* dy = (dR == m->gA) ? m->gB : m->gA;
     float* other = (dy == m->gA) ? m->gB : m->gA;

@@ -672,13 +672,28 @@ __global__ __launch_bounds__(256) void interact_bwd_kernel(const float* Z, const
 // forward: G = Z Z^T on the lower triangle of 16x16 tiles (v_mfma_f32_16x16x4_f32; the B operand of tile
 // (ti, tj) is the A operand of row tile tj: both are "lane (i, q) holds Z[16 t + i][k]").  K order inside a
 // 32-wide block: step s of lane group q multiplies column 8q + s (two 16-byte loads per row and block).
-__global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(const float* Z, int F, int d, int itself, float* R, int64_t B, int ldR,
+// Where the feature rows of a sample come from: the gathered copy Z [B][F][d], or -- `emb` set -- straight from the combined
+// embedding table through the step's row ids (slot F-1, the bottom MLP's output, always lives in Z).  Reading the table
+// directly removes the gather pass: 109 MB written and read again per step at the C5 shapes.
+struct RowSrc {
+    const float* Z; const float* emb; const int32_t* idx; int64_t rows; int* err;
+    __device__ __forceinline__ const float* row(int64_t b, int f, int F, int d) const {
+        if (emb == nullptr || f == F - 1) return Z + (b * F + f) * d;
+        const int r = idx[b * F + f];
+        if ((uint32_t)r >= (uint64_t)rows) { *err = 1; return nullptr; }
+        return emb + (size_t)r * d;
+    }
+};
+
+__global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(RowSrc src, int F, int d, int itself, float* R, int64_t B, int ldR,
                                                                 _Float16* R16, int ldR16) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     const int i = lane & 15, q = lane >> 4;
-    const float* zb = Z + b * F * d;
+    const float* z0 = i < F ? src.row(b, i, F, d) : nullptr;
+    const float* z1 = 16 + i < F ? src.row(b, 16 + i, F, d) : nullptr;
+    const float* zlast = src.row(b, F - 1, F, d);
     f32x4 a00, a10, a11;
     a00.x = a00.y = a00.z = a00.w = 0.0f; a10 = a00; a11 = a00;
     for (int kb = 0; kb < d; kb += 32) {
@@ -686,8 +701,8 @@ __global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(const float* Z, 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             f32x4 z; z.x = z.y = z.z = z.w = 0.0f;
-            t0[h] = i < F ? *reinterpret_cast<const f32x4*>(zb + (int64_t)i * d + kb + 8 * q + 4 * h) : z;
-            t1[h] = 16 + i < F ? *reinterpret_cast<const f32x4*>(zb + (int64_t)(16 + i) * d + kb + 8 * q + 4 * h) : z;
+            t0[h] = z0 ? *reinterpret_cast<const f32x4*>(z0 + kb + 8 * q + 4 * h) : z;
+            t1[h] = z1 ? *reinterpret_cast<const f32x4*>(z1 + kb + 8 * q + 4 * h) : z;
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -701,7 +716,7 @@ __global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(const float* Z, 
     float* rb = R + b * ldR;
     _Float16* rh = R16 ? R16 + b * ldR16 : nullptr;
     for (int k = lane; k < d; k += 64) {
-        const float v = zb[(int64_t)(F - 1) * d + k];
+        const float v = zlast[k];
         rb[k] = v;
         if (rh) rh[k] = (_Float16)v;
     }
@@ -724,14 +739,13 @@ __global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(const float* Z, 
 // CPL = d/16 consecutive columns CPL*j .. CPL*j + CPL-1 of Z row 4 s + q (float4 loads); column tile t of the
 // MFMA grid is {CPL*j + t}, so every lane ends up with CPL consecutive columns of its output rows (float4 stores).
 template <int CPL>
-__global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(const float* Z, const float* dR, int F, int itself, float* dZ,
+__global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, const float* dR, int F, int itself, float* dZ,
                                                                 int64_t B, int ldR) {
     constexpr int d = 16 * CPL;
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     const int i = lane & 15, q = lane >> 4;
-    const float* zb = Z + b * F * d;
     const float* rb = dR + b * ldR;
     auto sval = [&](int r, int c) -> float {             // (Gs + Gs^T)[r][c]
         if (r >= F || c >= F) return 0.0f;
@@ -751,9 +765,10 @@ __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(const float* Z, 
 #pragma unroll
         for (int c4 = 0; c4 < CPL; c4 += 4) {
             f32x4 v; v.x = v.y = v.z = v.w = 0.0f;
-            if (k < F) {
-                if (CPL >= 4) v = *reinterpret_cast<const f32x4*>(zb + (int64_t)k * d + CPL * i + c4);
-                else { v.x = zb[(int64_t)k * d + CPL * i]; v.y = zb[(int64_t)k * d + CPL * i + 1]; }
+            const float* zk = k < F ? src.row(b, k, F, d) : nullptr;
+            if (zk) {
+                if (CPL >= 4) v = *reinterpret_cast<const f32x4*>(zk + CPL * i + c4);
+                else { v.x = zk[CPL * i]; v.y = zk[CPL * i + 1]; }
             }
             zr[s][c4] = v.x; if (c4 + 1 < CPL) zr[s][c4 + 1] = v.y;
             if (c4 + 2 < CPL) zr[s][c4 + 2] = v.z; if (c4 + 3 < CPL) zr[s][c4 + 3] = v.w;
@@ -790,22 +805,31 @@ __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(const float* Z, 
         }
 }
 
+// can the interaction read its embedding rows straight from the table (both passes on the MFMA kernels)?
+bool orx_interact_direct_ok(int F, int d, int compat) {
+    return !compat && F <= 32 && (d == 32 || d == 64 || d == 128 || d == 256) && getenv("ORX_INTERACT_SIMPLE") == nullptr &&
+           getenv("ORX_DLRM_NO_DIRECT") == nullptr;
+}
+
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
-                        float* out, int P, int64_t B, int ldR, void* R16, int ldR16, bool* wrote16) {
+                        float* out, int P, int64_t B, int ldR, void* R16, int ldR16, bool* wrote16,
+                        const float* emb, const int32_t* idx, int64_t emb_rows) {
     if (wrote16) *wrote16 = false;
     if (B == 0) return ORX_OK;
     const bool mfma = !compat && F <= 32 && d % 32 == 0 && ((uintptr_t)Z & 15) == 0 && getenv("ORX_INTERACT_SIMPLE") == nullptr;
     const bool bwd_ok = d == 32 || d == 64 || d == 128 || d == 256;
+    ORX_ARG(emb == nullptr || (mfma && bwd_ok), "interact: direct table rows need the MFMA kernels");
+    const RowSrc src{Z, emb, idx, emb_rows, ctx->d_err};
     if (mfma && (fwd || bwd_ok)) {
         const dim3 g((unsigned)((B + 3) / 4));
         if (fwd) {
-            ORX_LAUNCH(ctx, interact_fwd_mfma_kernel, g, dim3(256), 0, Z, F, d, itself, out, B, ldR, (_Float16*)R16, ldR16);
+            ORX_LAUNCH(ctx, interact_fwd_mfma_kernel, g, dim3(256), 0, src, F, d, itself, out, B, ldR, (_Float16*)R16, ldR16);
             if (wrote16 && R16) *wrote16 = true;
         }
-        else if (d == 32) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<2>), g, dim3(256), 0, Z, dR, F, itself, out, B, ldR);
-        else if (d == 64) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4>), g, dim3(256), 0, Z, dR, F, itself, out, B, ldR);
-        else if (d == 128) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8>), g, dim3(256), 0, Z, dR, F, itself, out, B, ldR);
-        else ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<16>), g, dim3(256), 0, Z, dR, F, itself, out, B, ldR);
+        else if (d == 32) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<2>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR);
+        else if (d == 64) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR);
+        else if (d == 128) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR);
+        else ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<16>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR);
         ORX_HIP(hipGetLastError());
         return ORX_OK;
     }
