@@ -984,34 +984,147 @@ __global__ __launch_bounds__(256) void dlrm_tiny_apply_kernel(const int32_t* idx
     for (int i = threadIdx.x; i < R * d; i += blockDim.x) acc[i] = 0.0f;
     __syncthreads();
     const int64_t b0 = (int64_t)blockIdx.y * slab, b1 = min(B, b0 + slab);
-    const int per = blockDim.x / d > 0 ? blockDim.x / d : 1;   // samples handled concurrently (d <= 256)
-    const int e = threadIdx.x % d, sub = threadIdx.x / d;
-    if (sub < per) {
-        // four samples in flight per thread: the loop is otherwise bound by one global-load latency per sample
-        for (int64_t bb = b0 + sub; bb < b1; bb += 4 * per) {
-            int r[4]; float v[4];
+    if ((d & 3) == 0 && d <= 1024) {
+        // a thread owns 4 columns: 16-byte loads, 256 / (d / 4) samples side by side, four rounds in flight -- the pass is bound
+        // by bytes in flight per CU (the scalar version kept 8 KB in flight per workgroup: 48 us for 29 MB)
+        const int tpr = d / 4, per = 256 / tpr > 0 ? 256 / tpr : 1;
+        const int e4 = (threadIdx.x % tpr) * 4, sub = threadIdx.x / tpr;
+        if (sub < per) {
+            constexpr int UN = 8;
+            for (int64_t bb = b0 + sub; bb < b1; bb += UN * per) {
+                int r[UN]; f32x4 v[UN];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int64_t x = bb + (int64_t)k * per;
-                r[k] = x < b1 ? idx[x * F + f] : -1;
-                v[k] = r[k] >= 0 ? dZ[(x * F + f) * d + e] : 0.0f;
+                for (int k = 0; k < UN; ++k) {               // unconditional loads (clamped), so that all UN are in flight together
+                    const int64_t x = bb + (int64_t)k * per, xc = x < b1 ? x : b1 - 1;
+                    r[k] = idx[xc * F + f];
+                    v[k] = *reinterpret_cast<const f32x4*>(dZ + (xc * F + f) * d + e4);
+                    if (x >= b1) r[k] = -1;
+                }
+#pragma unroll
+                for (int k = 0; k < UN; ++k)
+                    if (r[k] >= 0) {
+                        // LDS layout [row][component c][d / 4]: the lanes of one ds_add_f32 hit consecutive banks (with [row][d] they
+                        // hit every 4th: 16 banks for 64 lanes, and the pass spent 38 of its 48 us in LDS atomics)
+                        float* p = &acc[(int)(r[k] - off) * d + (e4 >> 2)];
+                        atomicAdd(p, v[k].x); atomicAdd(p + tpr, v[k].y); atomicAdd(p + 2 * tpr, v[k].z); atomicAdd(p + 3 * tpr, v[k].w);
+                    }
             }
+        }
+    } else {
+        const int per = blockDim.x / d > 0 ? blockDim.x / d : 1;   // samples handled concurrently (d <= 256)
+        const int e = threadIdx.x % d, sub = threadIdx.x / d;
+        if (sub < per) {
+            for (int64_t bb = b0 + sub; bb < b1; bb += 4 * per) {
+                int r[4]; float v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (r[k] >= 0) atomicAdd(&acc[(int)(r[k] - off) * d + e], v[k]);
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t x = bb + (int64_t)k * per;
+                    r[k] = x < b1 ? idx[x * F + f] : -1;
+                    v[k] = r[k] >= 0 ? dZ[(x * F + f) * d + e] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (r[k] >= 0) atomicAdd(&acc[(int)(r[k] - off) * d + e], v[k]);
+            }
         }
     }
     __syncthreads();
+    const bool planar = (d & 3) == 0 && d <= 1024;
     for (int i = threadIdx.x; i < R * d; i += blockDim.x) {
-        const float v = acc[i];
+        const int r = i / d, col = i - r * d;
+        const float v = planar ? acc[r * d + (col & 3) * (d >> 2) + (col >> 2)] : acc[i];
         if (v != 0.0f) unsafeAtomicAdd(W + off * d + i, -lr * v);
+    }
+}
+
+// The same sums as a one-hot product on the fp32 MFMA: sum[r][:] = sum_b [row(b) == r] * dZ[b][:], i.e. O^T dZ with O the
+// [samples][R] one-hot matrix of the slot's row ids -- exact (products with 0 / 1; fp32 accumulation in MFMA order).  LDS fp32
+// atomics turned out to be the whole cost of the LDS version: 38 of its 48 us at the C5 shapes, whatever the slab size or the
+// bank layout (7.3 M ds_add_f32 lane-ops at ~3 cycles each per CU).  One wavefront per slab of samples; A operand: lane (i, q)
+// holds [row(sample q) == 16 ti + i]; B operand: lane (j, q) owns the CPL = d / 16 consecutive columns CPL j .. of sample q's
+// gradient row (16-byte loads; MFMA column tile t = {CPL j + t}), so a lane ends with CPL consecutive columns of rows 4 q' + r.
+template <int CPL, int RT>
+__global__ __launch_bounds__(256) void dlrm_tiny_apply_mfma_kernel(const int32_t* idx, const float* dZ, const int* tiny_f, const int64_t* offset,
+                                                                   const int64_t* rows, int F, int64_t B, int slab, float lr, float* W) {
+    constexpr int d = 16 * CPL, UN = 4;
+    const int f = tiny_f[blockIdx.x];
+    const int R = (int)rows[f];
+    const int64_t off = offset[f];
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    extern __shared__ float red[];                          // [R][d]: the block's four wavefronts add their sums in turn
+    const int wave = threadIdx.x >> 6;
+    const int64_t b0 = ((int64_t)blockIdx.y * 4 + wave) * slab, b1 = min(B, b0 + slab);
+    f32x4 acc[RT][CPL];
+#pragma unroll
+    for (int ti = 0; ti < RT; ++ti)
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) { acc[ti][t].x = acc[ti][t].y = acc[ti][t].z = acc[ti][t].w = 0.0f; }
+    for (int64_t s = b0; s < b1; s += 4 * UN) {
+        int r[UN]; float z[UN][CPL];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {                       // unconditional (clamped) loads: all UN groups of 4 samples in flight
+            const int64_t x = s + 4 * u + q, xc = x < b1 ? x : b1 - 1;
+            r[u] = (int)(idx[xc * F + f] - off);
+            const float* zp = dZ + (xc * F + f) * d + CPL * i;
+            if (CPL >= 4) {
+#pragma unroll
+                for (int c4 = 0; c4 < CPL; c4 += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(zp + c4);
+                    z[u][c4] = v.x; z[u][c4 + 1] = v.y; z[u][c4 + 2] = v.z; z[u][c4 + 3] = v.w;
+                }
+            } else { z[u][0] = zp[0]; z[u][1] = zp[1]; }
+            if (x >= b1) r[u] = -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+#pragma unroll
+            for (int ti = 0; ti < RT; ++ti) {
+                if (R <= 16 * ti) continue;                      // (wave-uniform)
+                const float a = r[u] == 16 * ti + i ? 1.0f : 0.0f;
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) acc[ti][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, z[u][t], acc[ti][t], 0, 0, 0);
+            }
+        }
+    }
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int ti = 0; ti < RT; ++ti)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int g = 16 * ti + 4 * q + rr;
+                    if (g >= R) continue;
+                    float* p = red + g * d + CPL * i;
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) p[t] = (w == 0 ? 0.0f : p[t]) + acc[ti][t][rr];
+                }
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < R * d; e += 256) {
+        const float v = red[e];
+        if (v != 0.0f) unsafeAtomicAdd(W + off * d + e, -lr * v);
     }
 }
 
 int orx_launch_dlrm_tiny_apply(orx_ctx* ctx, const int32_t* idx, const float* dZ, const int* tiny_f_dev, int n_tiny, int max_rows,
                                const int64_t* offset, const int64_t* rows, int F, int d, int64_t B, float lr, float* W) {
     if (n_tiny == 0 || B == 0) return ORX_OK;
-    const int slab = 64;
+    static const int slab_env = getenv("ORX_TINY_SLAB") ? atoi(getenv("ORX_TINY_SLAB")) : 0;
+    if (max_rows <= 64 && (d == 32 || d == 64 || d == 128 || d == 256) && getenv("ORX_TINY_LDS") == nullptr) {
+        const int slab = slab_env > 0 ? slab_env : 64;                   // samples per wavefront (4 wavefronts per workgroup)
+        const dim3 g((unsigned)n_tiny, (unsigned)((B + 4 * slab - 1) / (4 * slab)));
+#define ORX_TINY_GO(CPL, RT) ORX_LAUNCH(ctx, (dlrm_tiny_apply_mfma_kernel<CPL, RT>), g, dim3(256), (size_t)max_rows * d * sizeof(float), idx, dZ, tiny_f_dev, offset, rows, F, B, slab, lr, W)
+        if (max_rows <= 32) {
+            if (d == 32) ORX_TINY_GO(2, 2); else if (d == 64) ORX_TINY_GO(4, 2); else if (d == 128) ORX_TINY_GO(8, 2); else ORX_TINY_GO(16, 2);
+        } else {
+            if (d == 32) ORX_TINY_GO(2, 4); else if (d == 64) ORX_TINY_GO(4, 4); else if (d == 128) ORX_TINY_GO(8, 4); else ORX_TINY_GO(16, 4);
+        }
+#undef ORX_TINY_GO
+        ORX_HIP(hipGetLastError());
+        return ORX_OK;
+    }
+    const int slab = slab_env > 0 ? slab_env : 128;
     ORX_LAUNCH(ctx, dlrm_tiny_apply_kernel, dim3((unsigned)n_tiny, (unsigned)((B + slab - 1) / slab)), dim3(256),
                (size_t)max_rows * d * sizeof(float), idx, dZ, tiny_f_dev, offset, rows, F, d, B, slab, lr, W);
     ORX_HIP(hipGetLastError());

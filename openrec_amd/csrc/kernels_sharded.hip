@@ -149,6 +149,30 @@ __global__ __launch_bounds__(256) void apply_rows_sgd_kernel(RowsArgs a) {
     }
 }
 
+// The same for D % 64 == 0 without a bias column: one wavefront per gradient row, lane -> columns lane, lane + 64, ... (each
+// atomic instruction covers 256 contiguous bytes, no index division), four rows in flight per wavefront.
+__global__ __launch_bounds__(256) void apply_rows_sgd_wave_kernel(RowsArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t k0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; k0 < a.n; k0 += nw * 4) {
+        int r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = k0 + u < a.n ? a.ids[k0 + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r[u] < 0) continue;
+            if ((int64_t)r[u] >= a.rows) { if (lane == 0) *a.err = 1; r[u] = -1; }
+        }
+        for (int e = lane; e < a.D; e += 64) {
+            float g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = r[u] >= 0 ? a.grads[(k0 + u) * a.g_stride + e] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (r[u] >= 0) unsafeAtomicAdd(a.W + (size_t)r[u] * a.D + e, -a.lr * g[u]);
+        }
+    }
+}
+
 // SGD with duplicate flags (computed once for all steps of a planned K-step call): a row referenced
 // once in the list is a plain float4 read-modify-write by its lane group, only duplicated rows take
 // the 64 atomics per reference.  LPR lanes per reference.
@@ -345,6 +369,10 @@ int orx_launch_apply_rows(orx_ctx* ctx, int optkind, bool use_dflag, const RowsA
             case 32: ORX_LAUNCH(ctx, (apply_rows_sgd_flagged_kernel<32>), g, dim3(256), 0, a); break;
             default: ORX_LAUNCH(ctx, (apply_rows_sgd_flagged_kernel<64>), g, dim3(256), 0, a); break;
         }
+    } else if (optkind == ORX_SGD && a.bias == nullptr && a.D % 64 == 0 && getenv("ORX_APPLY_SCALAR") == nullptr) {
+        int64_t g = (a.n + 15) / 16;
+        if (g > 16384) g = 16384;
+        ORX_LAUNCH(ctx, apply_rows_sgd_wave_kernel, dim3((unsigned)g), dim3(256), 0, a);
     } else if (optkind == ORX_SGD) {
         int64_t g = (a.n * (a.D + 1) + 255) / 256;
         if (g > 65536) g = 65536;
