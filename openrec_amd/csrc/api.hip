@@ -549,7 +549,15 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
     int64_t chunk = (int64_t)((256ull << 20) / ((size_t)3 * B * sizeof(int32_t)));
     if (staging && chunk > 256) chunk = 256;
     if (chunk < 1) chunk = 1;
+    // The scratch is sized for at least 32 steps (6 MB per step at B = 65536) whatever K is: a training loop's calls vary
+    // in length (the driver's protocol: 5 warm-up steps, then 20 timed ones; the Python step queue: whatever was queued
+    // when something observed the model), and growing a dozen buffers -- hipFree + hipMalloc each -- inside the longer
+    // call cost it ~60 us (3 us per step of a K = 20 call; DESIGN.md 4.0 had this as "the first K = 20 call after a shorter
+    // one runs longer").
+    const int64_t chunk_cap = std::max<int64_t>(std::min<int64_t>(chunk, 32), std::min<int64_t>(chunk, K));
     if (chunk > K) chunk = K;
+    const int64_t used_chunk = chunk;
+    chunk = chunk_cap;                                   // (everything below sizes buffers)
     ENSURE(c->d_partial, c->d_partial_cap, (size_t)chunk * nw * 2 * sizeof(float));
     ENSURE(c->d_loss, c->d_loss_cap, (size_t)K * 2 * sizeof(double));
     const int64_t list_stride = 2 * B;          // distinct duplicated rows <= B/2 (users) + B (items)
@@ -596,6 +604,7 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
     }
     plan->item_stride = item_stride; plan->tree_off[0] = 0; plan->tree_off[1] = (int)cap1; plan->tree_off[2] = (int)(cap1 + cap2);
 
+    chunk = used_chunk;
     plan->nw = nw; plan->chunk = chunk; plan->list_stride = list_stride; plan->Bp = Bp;
     plan->min_late = -1;
     return ORX_OK;

@@ -3,7 +3,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-marker = sys.argv[2] if len(sys.argv) > 2 else 'void gather_kernel'
+marker = sys.argv[2] if len(sys.argv) > 2 else 'dense_shadow_kernel'
 idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith(marker)]
 a, b = idx[-3], idx[-2]
 t0 = int(rows[a]['Start_Timestamp'])
