@@ -11,7 +11,9 @@ opt = rt.Optimizer.sgd(0.05, ctx=ctx)
 g = torch.Generator(device=dev); g.manual_seed(1)
 uid, pid, nid = (torch.randint(0, N, (K + W, B), device=dev, dtype=torch.int32, generator=g) for _ in range(3))
 rt.pairwise_reserve(opt, U, V, b, K, B)
-rt.pairwise_step("bpr", opt, U, V, b, uid[:W], pid[:W], nid[:W], K=W, B=B, want_loss=False)
+WK = int(os.environ.get("WARM_K", W))
+for _ in range(int(os.environ.get("WARM_REPS", 1))):
+    rt.pairwise_step("bpr", opt, U, V, b, uid[:WK], pid[:WK], nid[:WK], K=WK, B=B, want_loss=False)
 ctx.synchronize(); torch.cuda.synchronize()
 if os.environ.get("SPIN_MS"):
     x = torch.empty(64 << 20, device=dev); y = torch.empty_like(x)
