@@ -412,9 +412,11 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduce* jobs
 void orx_gemm16_tn_plan(orx_ctx* ctx, int M, int N, int K, int* S_out, int* tiles_out, int* kchunk_out) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
-    int S = std::max(1, std::min(32, (2 * cus) / tiles));           // two 4-wavefront workgroups per CU
-    int kchunk = (((K + S - 1) / S + 63) / 64) * 64;
-    S = (K + kchunk - 1) / kchunk;
+    // S depends on the SHAPE of the gradient only, never on the number of samples: the workspace and the reduce descriptors
+    // are made once per model, and a later call with fewer samples (the last batch of an epoch) must write -- and the
+    // reduce must add -- the same S slices; slices beyond the samples write zeros
+    const int S = std::max(1, std::min(32, (2 * cus) / tiles));     // two 4-wavefront workgroups per CU
+    const int kchunk = std::max(64, (((K + S - 1) / S + 63) / 64) * 64);
     *S_out = S; *tiles_out = tiles; *kchunk_out = kchunk;
 }
 

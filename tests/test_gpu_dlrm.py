@@ -169,7 +169,12 @@ def test_dlrm_fp16_mlp_mode_over_several_steps_and_shapes(cfg_name, compat):
             b[:] = rng.normal(size=b.shape).astype(np.float32) * 0.1
             m.param(nm + "_w", l).write(W); m.param(nm + "_b", l).write(b.reshape(1, -1))
     opt, oo = rt.Optimizer.sgd(0.02), orc.SGD(0.02)     # (at lr 0.2 units go borderline-dead and fp16 noise flips relu masks: 22 % seen)
-    for step in range(3):
+    B_full = B
+    for step in range(4):
+        # the batch size changes from call to call (the last batch of an epoch: tf2_examples/dlrm_criteo.py batches without
+        # drop_remainder): the split-K workspaces and their reduce descriptors are sized once, for the largest batch
+        B = (B_full, B_full // 2 + 3, B_full // 5 + 1, B_full)[step]
+        tol = 0.06 if B >= 500 else 0.15                   # (fewer samples average less of the fp16 rounding out)
         dense = np.log1p(rng.integers(0, 100, (B, 13))).astype(np.float32)
         sparse = np.stack([rng.integers(0, n, B) for n in ln_emb], 1).astype(np.int32)
         label = (rng.uniform(size=B) < 0.3).astype(np.float32)
@@ -181,8 +186,8 @@ def test_dlrm_fp16_mlp_mode_over_several_steps_and_shapes(cfg_name, compat):
             W1, b1 = o.__dict__[nm][l]
             dW, db = m.param(nm + "_w", l).read() - W0, m.param(nm + "_b", l).read().reshape(-1) - b0.reshape(-1)
             rW, rb = W1 - W0, (b1 - b0).reshape(-1)
-            assert np.abs(dW - rW).max() < 0.06 * np.abs(rW).max() + 1e-7, (step, nm, l, "W")
-            assert np.abs(db - rb).max() < 0.06 * np.abs(rb).max() + 1e-7, (step, nm, l, "b")   # (fp16 operands through up to 7 chained products)
+            assert np.abs(dW - rW).max() < tol * np.abs(rW).max() + 1e-7, (step, nm, l, "W")
+            assert np.abs(db - rb).max() < tol * np.abs(rb).max() + 1e-7, (step, nm, l, "b")   # (fp16 operands through up to 7 chained products)
             # the device keeps training from ITS parameters: re-sync so the per-step comparison stays first order
             m.param(nm + "_w", l).write(W1); m.param(nm + "_b", l).write(b1.reshape(1, -1))
         m.param("emb").write(np.concatenate(o.emb))
