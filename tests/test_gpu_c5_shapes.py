@@ -11,7 +11,7 @@ import pytest
 
 from conftest import TOL
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.fp32_tie]
 COUNTS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306, 10,
           5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
 CFG = dict(m_spa=128, ln_bot=[512, 256, 128], ln_top=[1024, 1024, 512, 256, 1], dense_dim=13)

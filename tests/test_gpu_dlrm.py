@@ -5,7 +5,7 @@ import pytest
 
 from conftest import golden_files, load_golden, rel_err, OPT_KW
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.fp32_tie]
 
 CFG = dict(m_spa=4, ln_emb=[7, 5, 11], ln_bot=[8, 4], ln_top=[16, 8, 1], dense_dim=13)
 KW = {
