@@ -9,12 +9,13 @@ output.  What is NOT a recognised composition computes on the host, without grad
 from __future__ import annotations
 
 import warnings
+import weakref
 
 import numpy as np
 
 from .latent_factor import GatheredRows
 
-_models = {}
+_models = weakref.WeakValueDictionary()     # introspection only: the strong reference lives on the user LatentFactor
 _warned = set()
 
 
@@ -47,8 +48,11 @@ def _chain(table, flush):
 def composed_model(kind, user_lf, item_lf, bias_lf, **kw):
     """the model object (step queue, tables) behind a hand-made composition of these three LatentFactors"""
     from ..recommenders._base import PairwiseRecommender, PointwiseRecommender, _StepQueue
+    # the composed model lives exactly as long as its user LatentFactor (it holds the other two alive, so their ids stay
+    # unique while it exists): a dict on the module would keep every composition's tables in HBM for the life of the process
     key = (kind, id(user_lf), id(item_lf), id(bias_lf), tuple(sorted(kw.items())))
-    m = _models.get(key)
+    owned = user_lf.__dict__.setdefault("_composed", {})
+    m = owned.get(key)
     if m is None:
         if kind == "bpr":
             class _Composed(PairwiseRecommender):
@@ -60,8 +64,15 @@ def composed_model(kind, user_lf, item_lf, bias_lf, **kw):
         m = _Composed.__new__(_Composed)
         m.user_latent_factor, m.item_latent_factor, m.item_bias = user_lf, item_lf, bias_lf
         m._queue = _StepQueue()
+        wm = weakref.ref(m)                    # (an optimizer keeps the TABLES alive; their hook must not keep the model)
+
+        def flush():
+            mm = wm()
+            if mm is not None:
+                mm.flush()
         for lf in (user_lf, item_lf, bias_lf):
-            _chain(lf.table, m.flush)
+            _chain(lf.table, flush)
+        owned[key] = m
         _models[key] = m
     return m
 

@@ -78,7 +78,7 @@ def test_reference_bpr_class_text_trains_on_the_fused_path(optk):
             out.append(step(u, p, n))
             want.append(orc.bpr_step(U, V, b, u, p, n, oo))
     assert len(_models) == n_models + 1                                  # one composed model for the five steps
-    q = next(reversed(_models.values()))._queue
+    q = next(iter(model.user_latent_factor._composed.values()))._queue
     assert len(q.steps) == 5                                             # ... which are still QUEUED: one K=5 device call follows
     for (loss, l2), (lr, l2r) in zip(out, want):
         assert abs(float(loss) - lr) <= TOL * abs(lr) and abs(float(l2) - l2r) <= TOL * abs(l2r)
@@ -96,6 +96,11 @@ def test_reference_bpr_class_text_trains_on_the_fused_path(optk):
     lr, l2r, _ = orc.bpr_forward(U, V, b, u, p, n)
     assert abs(float(loss) - lr) <= TOL * abs(lr) and abs(float(l2) - l2r) <= TOL * abs(l2r)
     assert rel_err(model.trainable_variables[0].numpy(), U) < tol
+    # the composition (and its 3 tables in HBM) dies with the model that made it
+    import gc
+    del model, step, q, out, loss, l2
+    gc.collect()
+    assert len(_models) == n_models
 
 
 def test_reference_wrmf_class_text_trains_on_the_fused_path():
