@@ -220,7 +220,9 @@ class ShardedPairwise:
         process group's own stream, so kernels enqueued before wait() overlap with the exchange."""
         if self.a2a_fn is not None or (self.world == 1 and not self.force_collectives):
             out = self._a2a(send, recv)
-            return out, (lambda: None)
+            if out is not recv:            # (a one-rank exchange is the identity: the overlapped path reads `recv`, halves side by side)
+                recv.copy_(out)
+            return recv, (lambda: None)
         work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
         return recv, work.wait
 

@@ -67,3 +67,91 @@ class OracleBackend:
         self.opt.apply(table.w, i[m], g[:, :D], key=id(table))
         if bias is not None:
             self.opt.apply(bias.w, i[m], g[:, D:D + 1], key=id(bias))
+
+
+class FastOracleBackend(OracleBackend):
+    """The DEVICE-SIDE exchange plan of the engine's K-step paths (`ShardedPairwise._steps_planned` / `_steps_overlapped`,
+    what `bench.py --gpus N` runs) restated on the CPU, contract by contract, from the kernels it stands in for
+    (openrec_amd/csrc/kernels_sharded.hip: shard_route_kernel, shard_request_kernel, shard_localize_kernel,
+    shard_grads_kernel; padding = -1, slots inside a bucket in arrival order), so that those paths run under gloo with
+    world > 1 -- the real collectives, asynchronous ones included.  No `rows_dupflags`: the engine then applies every list
+    through `apply_rows` (the optimizer's own duplicate rule), which is the path Adagrad / Adam take on the GPU too."""
+    fast = True
+
+    def stream_ctx(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def check(self):
+        pass
+
+    @staticmethod
+    def _bucket(dest, world, cap):
+        from openrec_amd.sharded import bucket_slots
+        slot, ov = bucket_slots(dest.to(torch.int64), world, cap)
+        return slot, bool(ov)
+
+    def shard_route_steps(self, uid, pid, nid, n_users, n_items, world, cap, send, counters, overflow):
+        K, B = uid.shape
+        send.fill_(-1); counters.zero_()
+        for k in range(K):
+            u = uid[k].to(torch.int64)
+            slot, ov = self._bucket(u % world, world, cap)
+            ok = slot >= 0
+            send[k, slot[ok], 0] = uid[k][ok]; send[k, slot[ok], 1] = pid[k][ok]; send[k, slot[ok], 2] = nid[k][ok]
+            counters[k] = torch.bincount(u % world, minlength=world).to(torch.int32)
+            if ov:
+                overflow.fill_(1)
+
+    def shard_request_steps(self, trip, world, cap, send_ids, slot, u_loc, counters, overflow):
+        K, T = trip.shape[0], trip.shape[1]
+        send_ids.fill_(-1); counters.zero_()
+        for k in range(K):
+            u, p, n = (trip[k, :, c].to(torch.int64) for c in range(3))
+            live = u >= 0
+            ids = torch.cat([p, n]); alive = torch.cat([live, live])
+            dest = torch.where(alive, ids % world, torch.full_like(ids, -1))
+            s, ov = self._bucket(dest, world, cap)
+            ok = s >= 0
+            send_ids[k, s[ok]] = ids[ok].to(torch.int32)
+            slot[k] = s.to(torch.int32)
+            gp, gn = s[:T], s[T:]
+            u_loc[k] = torch.where(live & (gp >= 0) & (gn >= 0), torch.div(u, world, rounding_mode="floor"), torch.full_like(u, -1)).to(torch.int32)
+            if ov:
+                overflow.fill_(1)
+
+    def shard_localize(self, ids, world, out):
+        out.copy_(torch.where(ids >= 0, torch.div(ids, world, rounding_mode="floor"), torch.full_like(ids, -1)))
+
+    def shard_grads(self, model, user, rows_in, u_loc, slot, b_global, margin, gu, send_g, accum):
+        T = u_loc.numel()
+        D = user.w.shape[1]
+        ul, sp, sn = u_loc.numpy(), slot.numpy()[:T], slot.numpy()[T:]
+        live = ul >= 0
+        g_out = send_g.numpy()
+        for s_ in (sp, sn):                                  # surviving requests of dead triplets get zero gradients
+            dead = (~live) & (s_ >= 0)
+            g_out[s_[dead]] = 0.0
+        if not live.any():
+            return
+        k = int(live.sum())
+        rows = rows_in.numpy()
+        U = user.w[ul[live]].copy()
+        P, Nn = rows[sp[live]], rows[sn[live]]
+        V = np.concatenate([P[:, :D], Nn[:, :D]]); b = np.concatenate([P[:, D], Nn[:, D]])[:, None]
+        ar = np.arange(k)
+        if model == "bpr":
+            loss, l2, _ = orc.bpr_forward(U, V, b, ar, ar, ar + k)
+            gr = orc.bpr_grads(U, V, b, ar, ar, ar + k)
+            scale = np.float32(k) / np.float32(b_global)
+            loss = loss * scale
+            for key, l2part in (("gu", U), ("gp", V[:k]), ("gn", V[k:])):
+                gr[key] = (gr[key] - l2part) * scale + l2part
+            gr["gbp"] = gr["gbp"] * scale; gr["gbn"] = gr["gbn"] * scale
+        else:
+            loss, l2, _ = orc.ucml_forward(U, V, b, ar, ar, ar + k, margin)
+            gr = orc.ucml_grads(U, V, b, ar, ar, ar + k, margin)
+        gu.numpy()[live] = gr["gu"]
+        g_out[sp[live], :D] = gr["gp"]; g_out[sp[live], D] = gr["gbp"]
+        g_out[sn[live], :D] = gr["gn"]; g_out[sn[live], D] = gr["gbn"]
+        accum += torch.tensor([float(loss), float(l2)], dtype=torch.float64)

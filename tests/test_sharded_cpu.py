@@ -97,3 +97,54 @@ def test_bucket_slots_is_a_stable_partition():
         assert (np.diff(s[idx]) == 1).all() and s[idx[0]] == k * 200
     slot, ov = bucket_slots(dest, 4, 10)
     assert bool(ov) and ((slot.numpy() >= 0).sum() == 40)
+
+
+def _run_rank_ksteps(rank, world, port, model, optk, overlap, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sharded_ref_backend import FastOracleBackend
+    from openrec_amd import sharded
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    U, V, b, steps = _global_case(model)
+    be = FastOracleBackend(optk, 0.05)
+    eng = sharded.ShardedPairwise(model, optk, U.shape[0], V.shape[0], U.shape[1], lr=0.05, rank=rank, world=world,
+                                  device=torch.device("cpu"), backend=be, slack=1.5)
+    assert eng.fast
+    eng.U.w[:] = U[rank::world]; eng.V.w[:] = V[rank::world]; eng.b.w[:] = b[rank::world]
+    B = steps[0][0].shape[0]; per = B // world
+    sl = slice(rank * per, (rank + 1) * per)
+    uid, pid, nid = (torch.from_numpy(np.stack([st[c][sl] for st in steps]).copy()) for c in range(3))    # [K, per]
+    eng.steps(uid, pid, nid, plan_chunk=2, overlap=overlap)          # chunks of 2 + 1 steps
+    eng.check()
+    assert int(eng._ovf.item()) == 0
+    loss, l2 = eng.loss_sums()
+    np.savez(out % rank, U=eng.U.w, V=eng.V.w, b=eng.b.w, loss=loss, l2=l2)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("world", [1, 2])
+@pytest.mark.parametrize("model,optk", [("bpr", "sgd"), ("bpr", "adagrad"), ("ucml", "sgd"), ("bpr", "adam")])
+def test_sharded_kstep_paths_equal_single_process(tmp_path, world, model, optk, overlap):
+    """What `bench.py --gpus N` runs -- `ShardedPairwise.steps`: the exchange plan of a chunk of steps in one all-to-all per
+    phase, and the overlapped form with two half-batches per step and ASYNCHRONOUS all-to-alls -- over real collectives with
+    two ranks (gloo).  The device kernels of the plan are restated in tests/sharded_ref_backend.py (FastOracleBackend); the
+    GPU tests hold the kernels themselves against the same oracle on a virtual cluster."""
+    out = str(tmp_path / "k%d.npz")
+    if world == 1:
+        _run_rank_ksteps(0, 1, 0, model, optk, overlap, out)
+    else:
+        mp.spawn(_run_rank_ksteps, args=(world, _free_port(), model, optk, overlap, out), nprocs=world, join=True)
+    U, V, b, steps = _global_case(model)
+    o = {"sgd": lambda: orc.SGD(0.05), "adagrad": lambda: orc.Adagrad(0.05, 0.1, 1e-7), "adam": lambda: orc.AdamTFSparse(0.05)}[optk]()
+    tl = tl2 = 0.0
+    for (u, p, n) in steps:
+        l, l2 = orc.bpr_step(U, V, b, u, p, n, o) if model == "bpr" else orc.ucml_step(U, V, b, u, p, n, o, do_censor=False)
+        tl += float(l); tl2 += float(l2)
+    for r in range(world):
+        g = np.load(out % r)
+        assert rel_err(g["U"], U[r::world]) < 1e-5 and rel_err(g["V"], V[r::world]) < 1e-5 and rel_err(g["b"], b[r::world]) < 1e-5
+        assert abs(float(g["loss"]) - tl) < 1e-5 * abs(tl) and abs(float(g["l2"]) - tl2) < 1e-5 * abs(tl2)
