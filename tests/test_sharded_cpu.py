@@ -148,3 +148,10 @@ def test_sharded_kstep_paths_equal_single_process(tmp_path, world, model, optk, 
         g = np.load(out % r)
         assert rel_err(g["U"], U[r::world]) < 1e-5 and rel_err(g["V"], V[r::world]) < 1e-5 and rel_err(g["b"], b[r::world]) < 1e-5
         assert abs(float(g["loss"]) - tl) < 1e-5 * abs(tl) and abs(float(g["l2"]) - tl2) < 1e-5 * abs(tl2)
+
+
+@pytest.mark.parametrize("model,optk,overlap", [("bpr", "sgd", True), ("bpr", "adagrad", False), ("ucml", "sgd", True)])
+def test_sharded_kstep_paths_world4(tmp_path, model, optk, overlap):
+    """four ranks: the [dest][step][slot] <-> [step][src][slot] transposes of the chunk-wide exchanges are their own inverse
+    at world 2 -- here they are not"""
+    test_sharded_kstep_paths_equal_single_process(tmp_path, 4, model, optk, overlap)
