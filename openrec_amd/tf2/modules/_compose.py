@@ -22,8 +22,8 @@ _warned = set()
 def host_fallback(what):
     if what not in _warned:
         _warned.add(what)
-        warnings.warn(f"{what}: not a composition of LatentFactor lookups this package fuses -- computed on the host from "
-                      "gathered rows, WITHOUT gradients (a tape over it cannot train)", RuntimeWarning, stacklevel=3)
+        warnings.warn(f"{what}: this call is not one of the compositions this package runs as a fused device step -- computed "
+                      "on the host, WITHOUT gradients (a tape over it cannot train)", RuntimeWarning, stacklevel=3)
 
 
 def _same_ids(a, b):

@@ -48,6 +48,13 @@ class MLP:
         return out
 
     def __call__(self, x):
+        """Forward on the host (weights read back from HBM), WITHOUT gradients: the device paths are the packaged recommenders
+        (GMF's fused pointwise step reads and updates `layers[0].kernel` in HBM; DLRM runs its MLPs inside `orx_dlrm_step`).
+        Under a GradientTape -- where the caller expects to train through it -- this says so once."""
+        from .._lazy import active_tape
+        if active_tape() is not None:
+            from ._compose import host_fallback
+            host_fallback("MLP")
         x = np.asarray(x, np.float32)
         self.build(x.shape[-1])
         for layer in self.layers:

@@ -16,6 +16,10 @@ class SecondOrderFeatureInteraction:
         self._reference_compat = reference_compat
 
     def __call__(self, inputs):
+        from .._lazy import active_tape
+        if active_tape() is not None:          # (the device path of this op lives inside the packaged DLRM's step)
+            from ._compose import host_fallback
+            host_fallback("SecondOrderFeatureInteraction")
         z = np.stack([np.asarray(x, np.float32) for x in inputs], axis=1)          # [B, F, d]
         dots = np.einsum('bfd,bgd->bfg', z, z)
         F = z.shape[1]
