@@ -155,3 +155,30 @@ class FastOracleBackend(OracleBackend):
         g_out[sp[live], :D] = gr["gp"]; g_out[sp[live], D] = gr["gbp"]
         g_out[sn[live], :D] = gr["gn"]; g_out[sn[live], D] = gr["gbn"]
         accum += torch.tensor([float(loss), float(l2)], dtype=torch.float64)
+
+
+class FlaggedOracleBackend(FastOracleBackend):
+    """... plus the SGD specialisations the GPU engine takes (kernels_sharded.hip: rows_dupflags, shard_grads_kernel<APPLY>,
+    apply_rows_sgd_flagged_kernel): duplicate flags per apply list, user rows referenced once updated by the gradient kernel
+    itself, flagged applies for the rest.  SGD only (the engine asks for flags only then)."""
+
+    def rows_dupflags(self, table, ids2d, out):
+        ids = ids2d.numpy()
+        o = out.numpy().reshape(ids.shape)
+        for k in range(ids.shape[0]):
+            live = ids[k] >= 0
+            uniq, cnt = np.unique(ids[k][live], return_counts=True)
+            dup = np.isin(ids[k], uniq[cnt > 1]) & live
+            o[k] = dup.astype(np.uint8)
+
+    def apply_rows_flagged(self, table, bias, ids, grads, dflag):
+        self.apply_rows(table, bias, ids, grads)          # scatter_add is the same sum with or without the flags
+
+    def shard_grads_sgd(self, model, user, rows_in, u_loc, slot, dup_u, b_global, margin, gu, u_apply, send_g, accum):
+        assert self.opt_kind == "sgd"
+        self.shard_grads(model, user, rows_in, u_loc, slot, b_global, margin, gu, send_g, accum)
+        ul, dup = u_loc.numpy(), dup_u.numpy() != 0
+        once = (ul >= 0) & ~dup
+        user.w[ul[once]] -= np.float32(self.lr) * gu.numpy()[once]
+        ua = u_apply.numpy()
+        ua[:] = np.where((ul >= 0) & dup, ul, -1)

@@ -102,13 +102,15 @@ def test_bucket_slots_is_a_stable_partition():
 def _run_rank_ksteps(rank, world, port, model, optk, overlap, out):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from sharded_ref_backend import FastOracleBackend
+    from sharded_ref_backend import FastOracleBackend, FlaggedOracleBackend
     from openrec_amd import sharded
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     U, V, b, steps = _global_case(model)
-    be = FastOracleBackend(optk, 0.05)
+    # SGD on the GPU takes the flagged route (duplicate flags, user rows updated by the gradient kernel); every second SGD
+    # case here does too
+    be = (FlaggedOracleBackend if optk == "sgd" and (model == "bpr") == bool(overlap) else FastOracleBackend)(optk, 0.05)
     eng = sharded.ShardedPairwise(model, optk, U.shape[0], V.shape[0], U.shape[1], lr=0.05, rank=rank, world=world,
                                   device=torch.device("cpu"), backend=be, slack=1.5)
     assert eng.fast
