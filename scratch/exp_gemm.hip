@@ -97,9 +97,9 @@ __global__ __launch_bounds__(256) void base_k(G g) {
 
 // ---------------------------------------------------------------- pipelined kernel
 // WM x WN wavefronts, each TM x TN tiles of 16x16; BK halves per stage; DBUF: two LDS stages, one barrier per K step
-template <int WM, int WN, int TM, int TN, int BK, int DBUF, int NOEPI, int MINB, int REMAP = 0>
+template <int WM, int WN, int TM, int TN, int BK, int DBUF, int NOEPI, int MINB, int REMAP = 0, int LDPAD = 8, int WMAP = 0>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void pipe_k(G g) {
-  constexpr int BM = WM * TM * 16, BN = WN * TN * 16, LD = BK + 8, NT = 64 * WM * WN;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16, LD = BK + LDPAD, NT = 64 * WM * WN;
   constexpr int CPR = BK / 8;                                  // 16-byte chunks per tile row
   constexpr int NA = BM * CPR / NT, NB = BN * CPR / NT;        // chunks per thread
   static_assert(BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile/thread mismatch");
@@ -127,20 +127,20 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void pipe_k(G g) {
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int c = threadIdx.x + NT * i, row = c / CPR, k = k0 + (c % CPR) * 8;
+      const int c = threadIdx.x + NT * i, row = WMAP ? c % BM : c / CPR, k = k0 + (WMAP ? c / BM : c % CPR) * 8;
       ra[i] = (bm + row < g.M && k < g.lda) ? *reinterpret_cast<const h8*>(g.A + (int64_t)(bm + row) * g.lda + k) : zero;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int c = threadIdx.x + NT * i, row = c / CPR, k = k0 + (c % CPR) * 8;
+      const int c = threadIdx.x + NT * i, row = WMAP ? c % BN : c / CPR, k = k0 + (WMAP ? c / BN : c % CPR) * 8;
       rb[i] = (bn + row < g.N && k < g.ldb) ? *reinterpret_cast<const h8*>(g.B + (int64_t)(bn + row) * g.ldb + k) : zero;
     }
   };
   auto lstore = [&](_Float16* S) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) { const int c = threadIdx.x + NT * i; *reinterpret_cast<h8*>(S + (c / CPR) * LD + (c % CPR) * 8) = ra[i]; }
+    for (int i = 0; i < NA; ++i) { const int c = threadIdx.x + NT * i; *reinterpret_cast<h8*>(S + (WMAP ? c % BM : c / CPR) * LD + (WMAP ? c / BM : c % CPR) * 8) = ra[i]; }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) { const int c = threadIdx.x + NT * i; *reinterpret_cast<h8*>(S + (BM + c / CPR) * LD + (c % CPR) * 8) = rb[i]; }
+    for (int i = 0; i < NB; ++i) { const int c = threadIdx.x + NT * i; *reinterpret_cast<h8*>(S + (BM + (WMAP ? c % BN : c / CPR)) * LD + (WMAP ? c / BN : c % CPR) * 8) = rb[i]; }
   };
   auto compute = [&](const _Float16* S) {
 #pragma unroll
@@ -428,6 +428,17 @@ int main(int argc, char** argv) {
     CK(hipMemset(C, 0, (size_t)M * N * 4)); CK(hipMemset(C16, 0, (size_t)M * N * 2));
   };
   auto noepi = [&](const char* name, float us) { printf("%-34s %8.2f us  %7.1f TFLOP/s   (no epilogue)\n", name, us, 2.0 * M * N * K / us * 1e-6); };
+  const bool lds_only = argc > 6 && !strcmp(argv[6], "lds");
+  if (lds_only) {
+#define RUNL(PAD, WMAP_, NOEPI, NAME) do { constexpr int BM_ = 256, BN_ = 128; const size_t sh = (size_t)2 * (BM_ + BN_) * (64 + PAD) * 2; \
+    auto kern = pipe_k<4, 2, 4, 4, 64, 1, NOEPI, 1, 1, PAD, WMAP_>; \
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
+    float us = timeit([&] { hipLaunchKernelGGL(kern, dim3((N + BN_ - 1) / BN_, (M + BM_ - 1) / BM_), dim3(512), sh, 0, g); }); \
+    CK(hipGetLastError()); if (NOEPI) noepi(NAME, us); else check(NAME, us); } while (0)
+    RUNL(8, 0, 1, "256x128 pad8 (current) NOEPI"); RUNL(16, 0, 1, "256x128 pad16 NOEPI"); RUNL(24, 0, 1, "256x128 pad24 NOEPI"); RUNL(40, 0, 1, "256x128 pad40 NOEPI");
+    RUNL(8, 1, 1, "256x128 pad8 rowwise-writes NOEPI"); RUNL(8, 0, 0, "256x128 pad8 (current)"); RUNL(24, 0, 0, "256x128 pad24"); RUNL(8, 1, 0, "256x128 pad8 rowwise-writes");
+    return 0;
+  }
   check("base 128x128x32", timeit([&] { base_k<0><<<dim3((N + 127) / 128, (M + 127) / 128), 256>>>(g); }));
   noepi("base 128x128x32 NOEPI", timeit([&] { base_k<1><<<dim3((N + 127) / 128, (M + 127) / 128), 256>>>(g); }));
 #define RUN(WM, WN, TM, TN, BK, DB, NOEPI, MINB, NAME) RUNR(WM, WN, TM, TN, BK, DB, NOEPI, MINB, 0, NAME)
