@@ -40,4 +40,8 @@ if [ "$WHAT" = "all" ]; then
   (cd $REPO && python scripts/bench_score.py > $OUT/${TAG}_score_bench.json 2> /dev/null)
 fi
 cd $REPO
+if [ "$WHAT" = "all" ]; then
+  bash scripts/pmc_dlrm.sh $TAG > /dev/null 2>&1            # MFMA-busy / LDS-conflict counters of the DLRM fp16 step -> <tag>_dlrm_pmc.csv
+  [ -x scratch/copy_bw ] && (cd scratch && timeout 120 ./copy_bw > $OUT/${TAG}_copy_bw.log 2>&1)   # the streaming-copy yardstick
+fi
 python scripts/summarize_profiles.py $TAG
