@@ -238,7 +238,7 @@ int orx_sampler_pairwise(orx_sampler* s, uint64_t seed, int64_t first, int64_t n
  *                        reference).  Counter-based: any window can be regenerated. */
 int orx_sampler_stratified(orx_sampler* s, uint64_t seed, int64_t first, int64_t n, float pos_ratio,
                            int32_t* uid_dev, int32_t* iid_dev, float* label_dev);
-int orx_sampler_per_pos_stratified(orx_sampler* s, uint64_t seed, int64_t first, int64_t n, float pos_ratio,
+int orx_sampler_per_pos_stratified(orx_sampler* s, uint64_t seed, int64_t first, int64_t n, double pos_ratio,
                                    int32_t* uid_dev, int32_t* iid_dev, float* label_dev);
 
 /* ---- DLRM (recommenders/dlrm.py:6-100, modules/multi_layer_perceptron.py:5-18,

@@ -69,7 +69,7 @@ SIGNATURES = {
     "orx_sampler_destroy": (c_int, [_p]),
     "orx_sampler_pairwise": (c_int, [_p, c_uint64, c_int64, c_int64, _ip, _ip, _ip]),
     "orx_sampler_stratified": (c_int, [_p, c_uint64, c_int64, c_int64, c_float, _ip, _ip, _p]),
-    "orx_sampler_per_pos_stratified": (c_int, [_p, c_uint64, c_int64, c_int64, c_float, _ip, _ip, _p]),
+    "orx_sampler_per_pos_stratified": (c_int, [_p, c_uint64, c_int64, c_int64, c_double, _ip, _ip, _p]),
     "orx_dlrm_create": (c_int, [_p, c_int32, c_int32, _p, c_int32, _p, c_int32, _p, c_int32, c_int, c_float, c_uint64, _pp]),
     "orx_dlrm_destroy": (c_int, [_p]),
     "orx_dlrm_param": (c_int, [_p, c_int, c_int, _pp]),

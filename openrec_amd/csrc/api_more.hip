@@ -343,6 +343,36 @@ int orx_adam_rows_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const int32_t*
     return orx_launch_adam_rows(ctx, true, a, n / 2 + 1);
 }
 
+// the same two operations on a SORTED id list (kernels_rowsort.hip): distinct rows are the heads of the runs, a row's
+// gradient rows are summed in position order -- no duplicate flags, no gsum, no atomics.  step: the caller has advanced opt->t.
+int orx_adam_rows_sorted(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride, bool step) {
+    if (n == 0) return ORX_OK;
+    AdamRowsArgs a;
+    if (!step) {
+        if (opt->t == 0) return ORX_OK;
+        if (t->lazy != opt) return orx_table_sync(t);
+        CHECK(adam_rows_args(ctx, opt, t, opt->t, &a));
+        a.T = (int)opt->t;
+        return orx_csr_adam(ctx, false, a, t, sorted, n);
+    }
+    ORX_ARG(opt->t >= 1, "adam_rows_sorted: the step counter has not been advanced");
+    CHECK(adam_rows_args(ctx, opt, t, opt->t - 1, &a));
+    a.grads = grads; a.g_stride = g_stride; a.T = (int)opt->t; a.lr_T = opt->h_lrt[(size_t)opt->t];
+    return orx_csr_adam(ctx, true, a, t, sorted, n);
+}
+
+// TF-2.0 sparse Adam in its literal form (ORX_ADAM_DENSE): summed gradient rows into gsum + a dense-decay sweep of the whole table
+int orx_adam_dense_sorted(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride) {
+    CHECK(orx_table_scratch(t));
+    OptSlots st;
+    CHECK(orx_opt_slots(opt, t, &st));
+    CHECK(orx_csr_accum(ctx, t, sorted, n, grads, g_stride));
+    const double b1 = opt->p0, b2 = opt->p1;
+    const double tt = (double)(opt->t > 0 ? opt->t : 1);
+    const float lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, tt)) / (1.0 - std::pow(b1, tt)));
+    return orx_launch_adam_sweep(ctx, t->w, st.s0, st.s1, t->gsum, t->rows * t->dim, lr_t, opt->p0, opt->p1, opt->p2);
+}
+
 // rows about to be read by a forward pass: replayed to the lazy optimizer's step (no-op for a table that is current)
 int orx_table_touch(orx_table* t, const int32_t* ids, int64_t n) {
     if (t == nullptr || t->lazy == nullptr) return ORX_OK;
@@ -400,6 +430,15 @@ extern "C" int orx_apply_rows(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_tabl
     ORX_ARG(!bias || (bias->dim == 1 && bias->rows == t->rows), "orx_apply_rows: bias must be [%lld, 1]", (long long)t->rows);
     if (n == 0) return ORX_OK;
     ORX_HIP(hipSetDevice(ctx->device));
+    if (bias == nullptr && t->dim <= 256 && getenv("ORX_ROWS_ATOMICS") == nullptr) {
+        // the deterministic path (kernels_rowsort.hip): sort the (row, position) pairs, sum every row's gradients in position
+        // order, apply the rule once per distinct row
+        const uint2* sorted = nullptr;
+        CHECK(orx_rows_sort(ctx, ids, 1, n, n, t->rows, &sorted));
+        if (lazy) return orx_adam_rows_sorted(ctx, opt, t, sorted, n, grads, g_stride, true);
+        if (opt->kind == ORX_ADAM) return orx_adam_dense_sorted(ctx, opt, t, sorted, n, grads, g_stride);
+        return orx_csr_apply(ctx, opt, t, sorted, n, grads, g_stride);
+    }
     RowsArgs a;
     memset(&a, 0, sizeof(a));
     a.W = t->w; a.bias = bias ? bias->w : nullptr;
@@ -773,11 +812,13 @@ extern "C" int orx_sampler_stratified(orx_sampler* s, uint64_t seed, int64_t fir
     return orx_launch_sample_stratified(s->ctx, a, pos_ratio, label_dev, s->d_blockcnt, s->d_blockbase, s->d_counter);
 }
 
-extern "C" int orx_sampler_per_pos_stratified(orx_sampler* s, uint64_t seed, int64_t first, int64_t n, float pos_ratio,
+extern "C" int orx_sampler_per_pos_stratified(orx_sampler* s, uint64_t seed, int64_t first, int64_t n, double pos_ratio,
                                               int32_t* uid_dev, int32_t* iid_dev, float* label_dev) {
     ORX_ARG(s && uid_dev && iid_dev && label_dev && first >= 0 && n >= 0, "orx_sampler_per_pos_stratified: bad argument");
-    ORX_ARG(pos_ratio > 0.f && pos_ratio <= 1.f, "orx_sampler_per_pos_stratified: pos_ratio must lie in (0, 1]");
-    const int nneg = (int)((1.0f - pos_ratio) / pos_ratio);          // dataset.py:40
+    ORX_ARG(pos_ratio > 0.0 && pos_ratio <= 1.0, "orx_sampler_per_pos_stratified: pos_ratio must lie in (0, 1]");
+    // dataset.py:40 computes int((1 - pos_ratio) / pos_ratio) in Python doubles; in fp32 the quotient lands on the other side of
+    // an integer for common ratios (0.05: 19 instead of 18; 1/3: 1 instead of 2), i.e. another group size than the reference's
+    const int nneg = (int)((1.0 - pos_ratio) / pos_ratio);
     ORX_ARG(nneg + 1 <= s->total_items, "orx_sampler_per_pos_stratified: %d negatives per positive need more than %lld items "
             "(random.sample would raise ValueError)", nneg, (long long)s->total_items);
     ORX_HIP(hipSetDevice(s->ctx->device));

@@ -28,6 +28,8 @@ struct DenseLayer {
     bool head = false;                  // the 1-unit last layer of the top MLP on the fused head kernels (kernels_gemm16.hip)
     float* slab = nullptr;              // split-K slices of this layer's weight gradient, [tiles][S][128 * 128]
     int slab_S = 1, slab_tiles = 0;
+    float* gbpart = nullptr;            // bias-gradient partial rows [row blocks][out] (ColPart), carved from orx_dlrm::colpart
+    float* gwpart = nullptr;            // the head layer: weight-gradient partial rows [row blocks][in]
 };
 
 static inline int up8(int x) { return (x + 7) & ~7; }
@@ -64,6 +66,7 @@ struct orx_dlrm {
     SlabReduce* d_slabjobs[2] = {nullptr, nullptr}; int n_slabjobs[2] = {0, 0}, slab_max_tiles[2] = {0, 0};   // [0] bottom, [1] top MLP
     void* dense16 = nullptr; int ld_dense16 = 0;   // fp16 copy of the dense features (operand of the first bottom layer)
     std::vector<void*> bot_y16;         // output of bottom layer l (l < last), [cap][up8(out)]
+    float* colpart = nullptr;           // pool of the layers' partial rows
     int32_t* d_idx_all = nullptr; int64_t idx_all_cap = 0;          // combined row ids of a chunk of steps (planned sparse apply)
     int32_t* d_sparse_all = nullptr; int64_t sparse_all_cap = 0;
     DenseParam* d_params = nullptr;     // descriptors of the dense parameters for the multi-tensor optimizer launch
@@ -197,6 +200,7 @@ static void free_buffers(orx_dlrm* m) {
     for (auto& D : m->bot) { hipFree(D.slab); D.slab = nullptr; }
     for (int k = 0; k < 2; ++k) { hipFree(m->d_slabjobs[k]); m->d_slabjobs[k] = nullptr; m->n_slabjobs[k] = 0; m->slab_max_tiles[k] = 0; }
     hipFree(m->dense16); m->dense16 = nullptr;
+    hipFree(m->colpart); m->colpart = nullptr;
     for (void* p : m->bot_y16) hipFree(p);
     m->bot_y16.clear();
     for (void* p : m->top_y16) hipFree(p);
@@ -259,6 +263,19 @@ static int ensure_buffers(orx_dlrm* m, int64_t B) {
     }
     for (size_t l = 0; l < m->top.size(); ++l) {
         float* p; ORX_HIP(hipMalloc((void**)&p, sizeof(float) * B * m->top[l].out)); m->top_y.push_back(p);
+    }
+    {   // partial rows of the column sums: at most one per 32 samples (act_bwd_colsum's short slabs)
+        const size_t maxP = (size_t)B / 32 + 2;
+        size_t total = 0;
+        for (int k = 0; k < 2; ++k) for (auto& D : (k == 0 ? m->bot : m->top)) total += maxP * (size_t)(D.out + (D.head ? D.in : 0));
+        ORX_HIP(hipMalloc((void**)&m->colpart, total * sizeof(float)));
+        float* p = m->colpart;
+        for (int k = 0; k < 2; ++k)
+            for (auto& D : (k == 0 ? m->bot : m->top)) {
+                D.gbpart = p; p += maxP * D.out;
+                D.gwpart = nullptr;
+                if (D.head) { D.gwpart = p; p += maxP * D.in; }
+            }
     }
     if (m->flags & ORX_DLRM_FP16_MLP) {
         m->ldR16 = up8(m->m_spa + m->P);
@@ -360,6 +377,11 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
             ORX_ARG(l == 0 || !m->bot[l - 1].lean, "dlrm forward: bottom layer %d has no fp32 input", (int)l);
             CHECK(mlp_gemm(m, x, ldx, 1, L.W->w, L.out, 1, y, ldy, L.b->w, (int)B, L.out, L.in, L.act));
             bx16 = nullptr;
+            if (bot16 && !last) {       // a layer off the fp16 kernels (width < 32, or fewer than 8 inputs): the layers above and this
+                                        // layer's consumers in the backward pass (dw16) still read the fp16 copy of its output
+                CHECK(orx_launch_cast16(c, y, ldy, m->bot_y16[l], up8(L.out), (int)B, L.out));
+                bx16 = m->bot_y16[l]; ldbx16 = up8(L.out);
+            }
         }
         x = y; ldx = ldy;
     }
@@ -432,6 +454,9 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
     void* dy16 = nullptr;               // fp16 copy of the current dy (g16 / g16b ping-pong)
     bool dy32 = true;                   // does `dy` hold the fp32 gradient (false: only dy16 is valid)
     int slabs = 0;
+    std::vector<ColJob> coljobs;        // bias gradients (and the head's weight gradient) leave as partial rows per row block
+    auto colpart_of = [&](float* parts) { ColPart cp; cp.parts = parts; return cp; };
+    auto add_job = [&](const ColPart& cp, float* out, int N) { ColJob j; j.parts = cp.parts; j.out = out; j.N = N; j.P = cp.P; coljobs.push_back(j); };
     for (int l = (int)L.size() - 1; l >= 0; --l) {
         DenseLayer& D = L[l];
         CHECK(orx_table_scratch(D.W)); CHECK(orx_table_scratch(D.b));
@@ -442,8 +467,10 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
             DenseLayer& Bl = L[l - 1];
             CHECK(orx_table_scratch(Bl.b));
             const bool below16 = Bl.dw16 && orx_gemm16_nt_ok(Bl.out, Bl.ld16, Bl.in, Bl.out);
-            CHECK(orx_launch_head_bwd(c, (*ins16)[l], (*ld_in16)[l], D.w16t, dy, outs[l], D.act, Bl.act, D.W->gsum, D.b->gsum,
-                                      m->g16, Bl.out, below16 ? nullptr : other, ld_in[l], Bl.b->gsum, (int)B, D.in));
+            ColPart pW = colpart_of(D.gwpart), pb = colpart_of(D.gbpart), pbb = colpart_of(Bl.gbpart);
+            CHECK(orx_launch_head_bwd(c, (*ins16)[l], (*ld_in16)[l], D.w16t, dy, outs[l], D.act, Bl.act, &pW, &pb,
+                                      m->g16, Bl.out, below16 ? nullptr : other, ld_in[l], &pbb, (int)B, D.in));
+            add_job(pW, D.W->gsum, D.in); add_job(pb, D.b->gsum, 1); add_job(pbb, Bl.b->gsum, Bl.out);
             act_done = true; dy16 = m->g16; dy32 = !below16;
             float* t = dy; dy = other; other = t;
             continue;
@@ -454,7 +481,9 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
         if (!act_done) {
             ORX_ARG(dy32, "dlrm backward: fp32 gradient missing for layer %d", l);
             dy16 = (s16 || (D.dw16 && m->g16 != nullptr)) ? m->g16 : nullptr;
-            CHECK(orx_launch_act_bwd_colsum(c, dy, outs[l], ld_out[l], (int)B, D.out, D.act, D.b->gsum, dy16, D.out));
+            ColPart pb = colpart_of(D.gbpart);
+            CHECK(orx_launch_act_bwd_colsum(c, dy, outs[l], ld_out[l], (int)B, D.out, D.act, &pb, dy16, D.out));
+            add_job(pb, D.b->gsum, D.out);
         }
         act_done = false;
         // gW [in, out] = X^T * dZ
@@ -481,14 +510,18 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
                                                                           : orx_gemm16_nt_ok(L[l - 1].out, L[l - 1].ld16, L[l - 1].in, L[l - 1].out));
                         const bool y16 = L[l - 1].lean;
                         ORX_ARG(!y16 || (outs16 && (*outs16)[l - 1]), "dlrm backward: fp16 activation missing for layer %d", l - 1);
+                        ColPart pbb = colpart_of(L[l - 1].gbpart);
                         CHECK(orx_launch_gemm16_nt(c, dy16, D.out, D.w16, D.ld16, below16 ? nullptr : other, ld_in[l], next16, L[l - 1].out,
                                                    nullptr, (int)B, D.in, D.out, 0, y16 ? nullptr : outs[l - 1], y16 ? (*outs16)[l - 1] : nullptr,
-                                                   y16 ? (int64_t)up8(L[l - 1].out) : ld_out[l - 1], L[l - 1].act, L[l - 1].b->gsum));
+                                                   y16 ? (int64_t)up8(L[l - 1].out) : ld_out[l - 1], L[l - 1].act, &pbb));
+                        add_job(pbb, L[l - 1].b->gsum, L[l - 1].out);
                         dy16 = next16; dy32 = !below16;
                     } else {
                         ORX_ARG(!L[l - 1].lean, "dlrm backward: layer %d has no fp32 activation", l - 1);
+                        ColPart pbb = colpart_of(L[l - 1].gbpart);
                         CHECK(orx_launch_gemm_f16s(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], (l - 1 > 0 || need_dx0) ? next16 : nullptr, L[l - 1].out,
-                                                   nullptr, (int)B, D.in, D.out, 0, outs[l - 1], ld_out[l - 1], L[l - 1].act, L[l - 1].b->gsum));
+                                                   nullptr, (int)B, D.in, D.out, 0, outs[l - 1], ld_out[l - 1], L[l - 1].act, &pbb));
+                        add_job(pbb, L[l - 1].b->gsum, L[l - 1].out);
                         dy16 = (l - 1 > 0 || need_dx0) ? next16 : nullptr; dy32 = true;
                     }
                     act_done = true;
@@ -504,6 +537,7 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
             float* t = dy; dy = other; other = t;
         }
     }
+    CHECK(orx_launch_colparts_reduce(c, coljobs.data(), (int)coljobs.size()));
     if (slabs > 0) {
         ORX_ARG(slabs == m->n_slabjobs[which], "dlrm backward: %d of %d split-K weight gradients were produced", slabs, m->n_slabjobs[which]);
         CHECK(orx_launch_slab_reduce(c, m->d_slabjobs[which], m->n_slabjobs[which], m->slab_max_tiles[which]));
@@ -582,23 +616,26 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         ORX_HIP(hipMalloc((void**)&m->d_loss, sizeof(double) * K)); m->loss_cap = K;
     }
     const int F = m->F, d = m->m_spa;
-    // Sparse optimizer with a plan: the row ids of all K steps are known up front, so duplicate roles, staging plan
-    // and reduction tree are made once per (up to 64-step) chunk and every step applies its rows without atomics
-    // (orx_apply_rows_planned_step).  SGD / Adagrad on float4 dims (Adam: the lazy rule below).  The plan costs one
-    // dedup workgroup per 425 984-row range and step, each streaming all B*F ids: right for combined tables of a few
-    // ranges, wrong for Criteo's 33.8 M rows (80 ranges: +120 us per step, measured) -- those keep the atomics path
-    // with the LDS sums for the tiny tables.
-    const bool planned = m->emb != nullptr && (opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD) && orx_fused_can_inline_apply(d) &&
+    // Sparse optimizer: the row ids of all K steps are known up front, so the (row, position) pairs of every step's id list
+    // are SORTED once per chunk of steps (kernels_rowsort.hip) and each step applies its gradient rows as segmented sums in
+    // position order -- no fp32 atomics, no arrival-order ranks: a step is bit-reproducible, whatever the duplicate
+    // structure (Criteo has tables of 3 rows next to tables of 10 M).  ORX_ROWS_ATOMICS=1 keeps the round-2 paths (plan with
+    // arrival-order staging / LDS sums for the tiny tables / scatter-add atomics) for A/B measurements.
+    const bool atomics = getenv("ORX_ROWS_ATOMICS") != nullptr || d > 256;
+    const bool sorted_apply = m->emb != nullptr && !atomics;
+    const bool planned = atomics && m->emb != nullptr && (opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD) && orx_fused_can_inline_apply(d) &&
                          orx_dedup_buckets(m->emb->rows) <= 8 && getenv("ORX_DLRM_NO_PLAN") == nullptr;
-    // steps per plan: what orx_exact_buffers accepts as one chunk for B*F ids per step
-    const int64_t PC = std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)((256ull << 20) / ((size_t)3 * B * F * sizeof(int32_t)))));
+    // steps per plan / sort: what orx_exact_buffers accepts as one chunk for B*F ids per step; <= 8 M sorted entries
+    const int64_t PC = sorted_apply ? std::max<int64_t>(1, std::min<int64_t>(64, (8LL << 20) / (B * F)))
+                                    : std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)((256ull << 20) / ((size_t)3 * B * F * sizeof(int32_t)))));
     RowsPlan rp;
+    const uint2* sorted = nullptr;
     const int32_t* sparse_dev = sparse;
     const bool lazy_adam = m->emb != nullptr && orx_adam_rows_lazy(opt, m->emb);
     { orx_table* mine[1] = {m->emb}; CHECK(orx_opt_isolate(opt, mine, m->emb ? 1 : 0)); }   // (a shared optimizer: api.hip orx_opt_isolate)
     ColWindows cw;
     if (getenv("ORX_DLRM_NO_COLWIN") == nullptr) { cw.F = F; cw.win = m->d_colwin; }
-    if (planned) {
+    if (planned || sorted_apply) {
         const int64_t kp = std::min<int64_t>(K, PC);
         if (m->idx_all_cap < kp * B * F) {
             if (m->d_idx_all) ORX_HIP(hipFree(m->d_idx_all));
@@ -613,23 +650,29 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
             sparse_dev = m->d_sparse_all;
         }
     }
+    if (sorted_apply && !lazy_adam) CHECK(orx_table_sync(m->emb));
     for (int64_t s = 0; s < K; ++s) {
-        if (planned && s % PC == 0) {
+        if ((planned || sorted_apply) && s % PC == 0) {
             const int64_t kp = std::min<int64_t>(K - s, PC);
             CHECK(orx_launch_dlrm_ids(c, sparse_dev + s * B * m->n_emb, m->d_offset, m->d_rows, m->n_emb, kp * B, m->d_idx_all));
-            CHECK(orx_apply_rows_plan(c, m->emb, m->d_idx_all, kp, B * F, B * F, &rp));
+            if (planned) CHECK(orx_apply_rows_plan(c, m->emb, m->d_idx_all, kp, B * F, B * F, &rp));
+            else CHECK(orx_rows_sort(c, m->d_idx_all, kp, B * F, B * F, m->emb->rows, &sorted));
         }
-        const int32_t* idx_s = planned ? m->d_idx_all + (s % PC) * B * F : nullptr;
+        const int32_t* idx_s = (planned || sorted_apply) ? m->d_idx_all + (s % PC) * B * F : nullptr;
+        const uint2* sorted_s = sorted_apply ? sorted + (s % PC) * B * F : nullptr;
         Batch bt;
         CHECK(stage(m, dense + s * B * m->dense_dim, sparse + s * B * m->n_emb, label + s * B, B, flags, &bt));
         // lazy Adam: the rows of this batch are replayed to the current step before the forward reads
         // them; the duplicate analysis of the id list is shared with the apply below
         bool deduped = false;
         if (lazy_adam) {
-            CHECK(orx_launch_dlrm_ids(c, bt.sparse, m->d_offset, m->d_rows, m->n_emb, B, m->d_idx));
-            idx_s = m->d_idx;
+            if (!sorted_apply) {
+                CHECK(orx_launch_dlrm_ids(c, bt.sparse, m->d_offset, m->d_rows, m->n_emb, B, m->d_idx));
+                idx_s = m->d_idx;
+            }
             if (m->emb->lazy == opt && opt->t > 0) {
-                CHECK(orx_adam_rows_touch(c, opt, m->emb, idx_s, B * F, false, cw));
+                if (sorted_apply) CHECK(orx_adam_rows_sorted(c, opt, m->emb, sorted_s, B * F, nullptr, 0, false));
+                else CHECK(orx_adam_rows_touch(c, opt, m->emb, idx_s, B * F, false, cw));
                 deduped = getenv("ORX_DLRM_NO_SHARED_DEDUP") == nullptr;
             } else {
                 CHECK(orx_table_sync(m->emb));
@@ -648,7 +691,11 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
             lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, (double)opt->t)) / (1.0 - std::pow(b1, (double)opt->t)));
         }
         // sparse: per-occurrence rows dZ[b, f, :] onto the combined table (dense slot has id -1)
-        if (planned) {
+        if (sorted_apply) {
+            if (lazy_adam) CHECK(orx_adam_rows_sorted(c, opt, m->emb, sorted_s, B * F, m->dZ, d, true));
+            else if (opt->kind == ORX_ADAM) CHECK(orx_adam_dense_sorted(c, opt, m->emb, sorted_s, B * F, m->dZ, d));
+            else CHECK(orx_csr_apply(c, opt, m->emb, sorted_s, B * F, m->dZ, d));
+        } else if (planned) {
             CHECK(orx_apply_rows_planned_step(c, opt, m->emb, nullptr, rp, s % PC, idx_s, m->dZ, d));
         } else if (lazy_adam) {
             CHECK(orx_adam_rows_apply(c, opt, m->emb, idx_s, B * F, m->dZ, d, deduped, cw));

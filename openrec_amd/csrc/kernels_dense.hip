@@ -20,7 +20,8 @@ struct GemmArgs {
     const float* bias;
     int M, N, K;
     int act;                 // 0 none, 1 relu, 2 sigmoid
-    int kchunk;              // split-K (fp16 kernel): K range per blockIdx.z, partial tiles combine with atomics
+    int kchunk;              // split-K: K range per blockIdx.z; the partial products go to ws [splits][M][N] (plain stores) and
+    float* ws;               // splitk_reduce_kernel adds them in split order (no atomics: the sum is reproducible)
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int vec_a, in
                 const int col = bn + wn + ni * 16 + (lane & 15);
                 if (row < g.M && col < g.N) {
                     float v = acc[mi][ni][r];
-                    if (gridDim.z > 1) { unsafeAtomicAdd(g.C + (int64_t)row * g.ldc + col, v); continue; }
+                    if (gridDim.z > 1) { g.ws[((int64_t)blockIdx.z * g.M + row) * g.N + col] = v; continue; }
                     if (g.bias) v += g.bias[col];
                     if (g.act == 1) v = fmaxf(v, 0.0f);
                     else if (g.act == 2) v = 1.0f / (1.0f + __expf(-v));
@@ -281,13 +282,34 @@ __global__ __launch_bounds__(256) void gemm_f32v_kernel(GemmArgs g, int vec_a, i
                 const int col = bn + wn + ni * 16 + (lane & 15);
                 if (row < g.M && col < g.N) {
                     float v = acc[mi][ni][r];
-                    if (gridDim.z > 1) { unsafeAtomicAdd(g.C + (int64_t)row * g.ldc + col, v); continue; }
+                    if (gridDim.z > 1) { g.ws[((int64_t)blockIdx.z * g.M + row) * g.N + col] = v; continue; }
                     if (g.bias) v += g.bias[col];
                     if (g.act == 1) v = fmaxf(v, 0.0f);
                     else if (g.act == 2) v = 1.0f / (1.0f + __expf(-v));
                     g.C[(int64_t)row * g.ldc + col] = v;
                 }
             }
+}
+
+// C[M][N] = sum over the splits of ws [splits][M][N], in split order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* C, int64_t ldc, int M, int N, int splits) {
+    const int64_t total = (int64_t)M * N, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        float v = 0.0f;
+        int z = 0;
+        for (; z + 4 <= splits; z += 4) {
+            const float w0 = ws[(int64_t)z * total + i], w1 = ws[(int64_t)(z + 1) * total + i], w2 = ws[(int64_t)(z + 2) * total + i], w3 = ws[(int64_t)(z + 3) * total + i];
+            v += w0; v += w1; v += w2; v += w3;
+        }
+        for (; z < splits; ++z) v += ws[(int64_t)z * total + i];
+        C[(i / N) * ldc + (i % N)] = v;
+    }
+}
+
+static int splitk_finish(orx_ctx* ctx, const GemmArgs& g, int splits) {
+    int64_t gx = ((int64_t)g.M * g.N + 255) / 256; if (gx > 4096) gx = 4096;
+    ORX_LAUNCH(ctx, splitk_reduce_kernel, dim3((unsigned)gx), dim3(256), 0, (const float*)g.ws, g.C, g.ldc, g.M, g.N, splits);
+    return ORX_OK;
 }
 
 // ---- fp16-resident operands ("shadows") -------------------------------------------------------------
@@ -308,7 +330,7 @@ struct Gemm16Args {
     // fused activation backward of the layer BELOW (input-gradient product dX = dZ * W^T): the epilogue turns dX into
     // that layer's dZ = dX * act'(Y), adds its column sums to the bias gradient gb (zero before) -- the separate
     // act_bwd_colsum pass over [batch, width] disappears
-    const float* actY; int64_t ldy; int act_y; float* gb;
+    const float* actY; int64_t ldy; int act_y; float* gb;      // gb: partial column sums [row blocks of 128][N] (plain stores)
 };
 
 struct TileLoader16 {
@@ -336,6 +358,7 @@ __global__ __launch_bounds__(256) void gemm_f16s_kernel(Gemm16Args g) {
     constexpr int BM = 128, BN = 128, BK = 32, LD = BK + 8;
     __shared__ __attribute__((aligned(16))) _Float16 As[BM * LD];
     __shared__ __attribute__((aligned(16))) _Float16 Bs[BN * LD];
+    __shared__ float colred[2][BN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -393,15 +416,22 @@ __global__ __launch_bounds__(256) void gemm_f16s_kernel(Gemm16Args g) {
         if (g.gb) {                                      // the 4 lane groups hold different rows of the same column
             csum += __shfl_xor(csum, 16);
             csum += __shfl_xor(csum, 32);
-            if (lane < 16 && col < g.N) unsafeAtomicAdd(g.gb + col, csum);
+            if (lane < 16) colred[wave >> 1][wn + ni * 16 + lane] = csum;
         }
+    }
+    if (g.gb) {                                          // the two wavefronts that share the columns, then one plain store per column
+        __syncthreads();
+        for (int cidx = threadIdx.x; cidx < BN; cidx += 256)
+            if (bn + cidx < g.N) g.gb[(int64_t)blockIdx.y * g.N + bn + cidx] = colred[0][cidx] + colred[1][cidx];
     }
 }
 
 int orx_launch_gemm_f16s(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                          void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act,
-                         const float* actY, int64_t ldy, int act_y, float* gb) {
+                         const float* actY, int64_t ldy, int act_y, ColPart* gbp) {
     if (M == 0 || N == 0) return ORX_OK;
+    float* gb = gbp ? gbp->parts : nullptr;
+    if (gbp) gbp->P = (M + 127) / 128;
     ORX_ARG(lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)A16 | (uintptr_t)B16) & 15) == 0, "gemm_f16s: operands need 16-byte rows");
     ProfScope ps(ctx, ORX_K_GEMM);
     Gemm16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, (_Float16*)C16, ldc16, bias, M, N, K, act, actY, ldy, act_y, gb};
@@ -457,9 +487,9 @@ int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, 
                         float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero) {
     if (M == 0 || N == 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_GEMM);
-    GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0};
+    GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0, nullptr};
     // split-K when the output has too few tiles to fill the chip (the X^T*dY weight-gradient products:
-    // small M x N, K = batch); partial tiles are combined with fp32 atomics into a zeroed output
+    // small M x N, K = batch); the partial products leave through a workspace and are added in split order
     const int tiles = ((N + 127) / 128) * ((M + 127) / 128);
     int splits = 1;
     if (bias == nullptr && act == 0 && ldc == N && tiles < 256 && K >= 256) {
@@ -470,7 +500,11 @@ int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, 
     }
     g.kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
     splits = (K + g.kchunk - 1) / g.kchunk;
-    if (splits > 1 && !c_zero) ORX_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * ldc, ctx->stream));
+    (void)c_zero;
+    if (splits > 1) {
+        if (orx_ensure((void**)&ctx->d_splitk, &ctx->d_splitk_cap, sizeof(float) * (size_t)splits * M * N) != ORX_OK) return ORX_ERR_OOM;
+        g.ws = ctx->d_splitk;
+    }
     const dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)splits);
     const bool akc = sa1 == 1, bnc = sb1 == 1;
     ORX_ARG((akc || sa0 == 1) && (bnc || sb0 == 1), "gemm_f16: every operand needs one unit stride");
@@ -481,6 +515,7 @@ int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, 
     else if (akc) ORX_LAUNCH(ctx, (gemm_f16_kernel<true, false>), grid, dim3(256), 0, g, va, vb);
     else if (bnc) ORX_LAUNCH(ctx, (gemm_f16_kernel<false, true>), grid, dim3(256), 0, g, va, vb);
     else ORX_LAUNCH(ctx, (gemm_f16_kernel<false, false>), grid, dim3(256), 0, g, va, vb);
+    if (splits > 1) splitk_finish(ctx, g, splits);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -489,15 +524,20 @@ int orx_launch_gemm(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, cons
                     float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero) {
     if (M == 0 || N == 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_GEMM);
-    GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0};
+    GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0, nullptr};
+    (void)c_zero;
     if ((sa1 == 1 || sa0 == 1) && (sb1 == 1 || sb0 == 1) && getenv("ORX_GEMM_F32_SIMPLE") == nullptr) {
         dim3 grid; int va, vb; bool akc, bnc;
         const int splits = gemm_plan(A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, &g, &grid, &va, &vb, &akc, &bnc);
-        if (splits > 1 && !c_zero) ORX_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * ldc, ctx->stream));
+        if (splits > 1) {
+            if (orx_ensure((void**)&ctx->d_splitk, &ctx->d_splitk_cap, sizeof(float) * (size_t)splits * M * N) != ORX_OK) return ORX_ERR_OOM;
+            g.ws = ctx->d_splitk;
+        }
         if (akc && bnc) ORX_LAUNCH(ctx, (gemm_f32v_kernel<true, true>), grid, dim3(256), 0, g, va, vb);
         else if (akc) ORX_LAUNCH(ctx, (gemm_f32v_kernel<true, false>), grid, dim3(256), 0, g, va, vb);
         else if (bnc) ORX_LAUNCH(ctx, (gemm_f32v_kernel<false, true>), grid, dim3(256), 0, g, va, vb);
         else ORX_LAUNCH(ctx, (gemm_f32v_kernel<false, false>), grid, dim3(256), 0, g, va, vb);
+        if (splits > 1) splitk_finish(ctx, g, splits);
         ORX_HIP(hipGetLastError());
         return ORX_OK;
     }
@@ -528,8 +568,8 @@ int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int
     return ORX_OK;
 }
 
-// dZ = dY * act'(Y) in place AND gb[c] += sum_r dZ[r, c] in the same pass (the bias gradient; gb must be zero:
-// the dense optimizer kernels leave every gradient buffer zeroed).  grid = (columns / 64, row slabs of 256).
+// dZ = dY * act'(Y) in place AND the column sums of dZ (the bias gradient) of every row slab in the same pass:
+// parts[slab][c], plain stores; colparts_reduce_kernel adds the slabs in order.  grid = (columns / 64, row slabs).
 __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb,
                                                              _Float16* d16, int64_t ld16, int slab) {
     __shared__ float sh[4][64];
@@ -550,35 +590,45 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* dY, const fl
     }
     sh[part][threadIdx.x & 63] = s;
     __syncthreads();
-    if (part == 0 && c < N) unsafeAtomicAdd(gb + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (part == 0 && c < N) gb[(int64_t)blockIdx.y * N + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
-int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb, void* d16, int64_t ld16) {
+int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, ColPart* gbp, void* d16, int64_t ld16) {
     if (M == 0 || N == 0) return ORX_OK;
     const int slab = (int64_t)M * N >= (4 << 20) ? 256 : 32;          // small layers: more, shorter slabs (the pass is latency-bound)
+    float* gb = gbp->parts;
+    gbp->P = (M + slab - 1) / slab;
     ORX_LAUNCH(ctx, act_bwd_colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + slab - 1) / slab)), dim3(256), 0, dY, Y, ldy, M, N, act, gb,
                (_Float16*)d16, ld16, slab);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
 
-// out[c] = sum_r X[r, c]   (bias gradient).  grid = (columns / 64, row slabs of 256); the slabs
-// combine with one fp32 atomic per (slab, column) into the zeroed output.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* X, int M, int N, float* out) {
-    __shared__ float sh[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int part = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * 256, r1 = min(M, r0 + 256);
+// out[c] = sum over the P row blocks of parts[p][c], in block order: the second stage of every bias-gradient column sum
+// (act_bwd_colsum_kernel, the fused epilogues of the fp16 products, the head kernel).  One launch serves all layers of an
+// MLP backward: grid = (columns / 256, jobs).
+__global__ __launch_bounds__(256) void colparts_reduce_kernel(ColJobs jobs) {
+    const ColJob j = jobs.j[blockIdx.y];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= j.N) return;
     float s = 0.0f;
-    if (c < N) for (int r = r0 + part; r < r1; r += 4) s += X[(int64_t)r * N + c];
-    sh[part][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (part == 0 && c < N) unsafeAtomicAdd(out + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    int p = 0;
+    for (; p + 4 <= j.P; p += 4) {
+        const float a0 = j.parts[(int64_t)p * j.N + c], a1 = j.parts[(int64_t)(p + 1) * j.N + c], a2 = j.parts[(int64_t)(p + 2) * j.N + c], a3 = j.parts[(int64_t)(p + 3) * j.N + c];
+        s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; p < j.P; ++p) s += j.parts[(int64_t)p * j.N + c];
+    j.out[c] = s;
 }
 
-int orx_launch_colsum(orx_ctx* ctx, const float* X, int M, int N, float* out) {
-    ORX_HIP(hipMemsetAsync(out, 0, sizeof(float) * N, ctx->stream));
-    ORX_LAUNCH(ctx, colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 255) / 256)), dim3(256), 0, X, M, N, out);
+int orx_launch_colparts_reduce(orx_ctx* ctx, const ColJob* jobs, int n) {
+    for (int base = 0; base < n; base += ORX_COLJOBS_MAX) {
+        ColJobs cj;
+        const int cnt = n - base < ORX_COLJOBS_MAX ? n - base : ORX_COLJOBS_MAX;
+        int maxN = 1;
+        for (int i = 0; i < cnt; ++i) { cj.j[i] = jobs[base + i]; if (cj.j[i].N > maxN) maxN = cj.j[i].N; }
+        ORX_LAUNCH(ctx, colparts_reduce_kernel, dim3((unsigned)((maxN + 255) / 256), (unsigned)cnt), dim3(256), 0, cj);
+    }
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

@@ -197,8 +197,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_kernel(Nt16Args 
     }
     if (g.gb) {
         // column sums: over the 16 rows of a lane group (DPP), over the block's WM wavefronts through LDS (the stages are
-        // free now), then ONE atomic per (workgroup, column): same-address atomics from all row blocks serialize in L2, a
-        // per-wavefront atomic made the fused product of a 8192 x 512 x 256 layer take 42 us instead of ~15
+        // free now), then ONE plain store per (workgroup, column) into the row block's partial row: colparts_reduce_kernel adds
+        // the row blocks in order (atomics would make the sum depend on arrival order)
         float* red = reinterpret_cast<float*>(lds16);           // [WM][BN]
 #pragma unroll
         for (int np = 0; np < TN / 2; ++np)
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_kernel(Nt16Args 
             float s = 0.0f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) s += red[w * BN + cidx];
-            if (bn + cidx < g.N) unsafeAtomicAdd(g.gb + bn + cidx, s);
+            if (bn + cidx < g.N) g.gb[(int64_t)(bm / BM) * g.N + bn + cidx] = s;
         }
     }
 }
@@ -234,8 +234,9 @@ bool orx_gemm16_nt_ok(int64_t lda, int64_t ldb, int N, int K) { return lda % 8 =
 
 int orx_launch_gemm16_nt(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                          void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act,
-                         const float* actY, const void* actY16, int64_t ldy, int act_y, float* gb) {
+                         const float* actY, const void* actY16, int64_t ldy, int act_y, ColPart* gbp) {
     if (M == 0 || N == 0) return ORX_OK;
+    float* gb = gbp ? gbp->parts : nullptr;
     ORX_ARG(lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)A16 | (uintptr_t)B16) & 15) == 0, "gemm16_nt: operands need 16-byte rows");
     ProfScope ps(ctx, ORX_K_GEMM);
     Nt16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, (_Float16*)C16, ldc16, bias, M, N, K, act,
@@ -246,7 +247,8 @@ int orx_launch_gemm16_nt(orx_ctx* ctx, const void* A16, int64_t lda, const void*
     const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
     // (the 4-wavefront configurations want two workgroups per CU: with one, every load and barrier latency of the short K
     // loops of the narrow layers is exposed -- a fused 8192 x 512 x 256 product took 18 us on 256 tiles of 128 x 128)
-    if (force == 1 || (force == 0 && blocks(256, 128) >= cus)) return launch_nt<4, 2, 4, 4, 1>(ctx, g);
+    if (force == 1 || (force == 0 && blocks(256, 128) >= cus)) { if (gbp) gbp->P = (M + 255) / 256; return launch_nt<4, 2, 4, 4, 1>(ctx, g); }
+    if (gbp) gbp->P = (M + 127) / 128;
     if (force == 2 || (force == 0 && blocks(128, 128) >= 2 * cus)) return launch_nt<2, 2, 4, 4, 2>(ctx, g);
     return launch_nt<2, 2, 4, 2, 2>(ctx, g);
 }
@@ -503,10 +505,10 @@ struct HeadBwdArgs {
     const _Float16* w;                   // [K] fp16 copy of the head's weights
     const float* dy; const float* pred;  // [B]
     int act, act_below;
-    float* gW; float* gb;                // head gradients (+=)
+    float* gW; float* gb;                // head gradients: partial sums per workgroup, [blocks][K] and [blocks]
     _Float16* dZ16; int64_t ld16;        // [B][ld16] gradient w.r.t. the layer below's pre-activation
     float* dZ32; int64_t ld32;           // optional
-    float* gb_below;                     // [K] (+=)
+    float* gb_below;                     // [blocks][K] partial sums
     int B, K, rows_per_block;
 };
 
@@ -569,12 +571,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
             float s0 = 0.0f;
 #pragma unroll
             for (int h = 0; h < 8; ++h) s0 += red[h][k >> 3][k & 7];
-            unsafeAtomicAdd((pass == 0 ? a.gW : a.gb_below) + k, s0);
+            (pass == 0 ? a.gW : a.gb_below)[(int64_t)blockIdx.x * a.K + k] = s0;
         }
         if (pass == 0 && threadIdx.x == 0) {
             float s = 0.0f;
             for (int h = 0; h < 8; ++h) s += red_b[h];
-            unsafeAtomicAdd(a.gb, s);
+            a.gb[blockIdx.x] = s;
         }
         __syncthreads();
     }
@@ -591,13 +593,14 @@ int orx_launch_head_fwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* 
 }
 
 int orx_launch_head_bwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* dy, const float* pred, int act, int act_below,
-                        float* gW, float* gb, void* dZ16, int64_t ld16, float* dZ32, int64_t ld32, float* gb_below, int B, int K) {
+                        ColPart* gW, ColPart* gb, void* dZ16, int64_t ld16, float* dZ32, int64_t ld32, ColPart* gb_below, int B, int K) {
     if (B == 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_GEMM);
     const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
-    int rows = std::max(64, (int)((B + cus - 1) / cus));           // <= one workgroup per CU, >= 64 rows each (atomics per column = blocks)
+    int rows = std::max(64, (int)((B + cus - 1) / cus));           // <= one workgroup per CU, >= 64 rows each (partial rows = blocks)
     rows = (rows + 7) / 8 * 8;
-    HeadBwdArgs a{(const _Float16*)X16, ldx, (const _Float16*)w16, dy, pred, act, act_below, gW, gb, (_Float16*)dZ16, ld16, dZ32, ld32, gb_below, B, K, rows};
+    gW->P = gb->P = gb_below->P = (B + rows - 1) / rows;
+    HeadBwdArgs a{(const _Float16*)X16, ldx, (const _Float16*)w16, dy, pred, act, act_below, gW->parts, gb->parts, (_Float16*)dZ16, ld16, dZ32, ld32, gb_below->parts, B, K, rows};
     ORX_LAUNCH(ctx, head_bwd_kernel, dim3((unsigned)((B + rows - 1) / rows)), dim3(256), 0, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;

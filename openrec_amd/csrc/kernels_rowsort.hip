@@ -1,0 +1,350 @@
+// Deterministic application of per-occurrence gradient rows to an embedding table (the IndexedSlices of
+// tf2_examples/dlrm_criteo.py:44-47 / bpr_citeulike.py:35-38 as Keras applies them: SGD scatter-add of every occurrence,
+// Adagrad / Adam on the SUM of a row's occurrences -- SURVEY.md A.3-A.5).
+//
+//   1. stable LSD radix sort of (row id, position) pairs, K id lists at once (all steps of a K-step call are sorted before
+//      the first of them runs: the ids are known up front);
+//   2. one wavefront per 64 consecutive sorted entries sums the gradient rows of every run of equal ids IN POSITION ORDER and
+//      applies the optimizer rule once per distinct row; runs that cross a 64-entry boundary leave partial sums that a second
+//      launch adds in block order.
+//
+// No fp32 atomics and no arrival-order ranks anywhere: the result is a function of the inputs alone (bit-identical from run
+// to run), whatever the duplicate structure -- tables of 3 rows with thousands of references per row and tables of 10 M rows
+// take the same path.  HBM-bound: the gradient rows are read once, every distinct table row is read and written once.
+#include <cstring>
+
+#include "orx_device.h"
+
+namespace {
+
+constexpr int SORT_WAVES = 4, SORT_ROUNDS = 8, SORT_TILE = 64 * SORT_WAVES * SORT_ROUNDS;     // 2048 keys per workgroup
+constexpr int SORT_MAXBITS = 9;
+constexpr uint32_t KEY_NONE = 0xffffffffu;
+
+struct SortArgs {
+    const int32_t* ids; int64_t id_stride;     // first pass: list k at ids + k * id_stride (NULL: read `in`)
+    const uint2* in; uint2* out;               // [K][n] (key, position)
+    int* hist;                                 // [K][nbins][nblk]
+    int64_t n; int nblk; uint32_t sentinel;    // sentinel = table rows: key of padding (id < 0) and out-of-range ids, sorts last
+    int shift, bits;
+    int* err;
+};
+
+__device__ __forceinline__ uint2 sort_load(const SortArgs& a, int64_t k, int64_t i) {
+    if (a.ids != nullptr) {
+        const int id = a.ids[k * a.id_stride + i];
+        uint32_t key = (uint32_t)id;
+        if (id < 0) key = a.sentinel;
+        else if (key >= a.sentinel) { *a.err = 1; key = a.sentinel; }
+        return make_uint2(key, (uint32_t)i);
+    }
+    return a.in[k * a.n + i];
+}
+
+__global__ __launch_bounds__(256) void sort_hist_kernel(SortArgs a) {
+    __shared__ int h[1 << SORT_MAXBITS];
+    const int nbins = 1 << a.bits;
+    for (int d = threadIdx.x; d < nbins; d += 256) h[d] = 0;
+    __syncthreads();
+    const int64_t k = blockIdx.y, t0 = (int64_t)blockIdx.x * SORT_TILE;
+    for (int r = 0; r < SORT_TILE / 256; ++r) {
+        const int64_t i = t0 + r * 256 + threadIdx.x;
+        if (i < a.n) atomicAdd(&h[(sort_load(a, k, i).x >> a.shift) & (nbins - 1)], 1);      // (integer counts: order-free)
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < nbins; d += 256) a.hist[((int64_t)k * nbins + d) * a.nblk + blockIdx.x] = h[d];
+}
+
+// exclusive prefix over the (digit-major) counts of one list
+__global__ __launch_bounds__(1024) void sort_scan_kernel(int* hist, int64_t per_list) {
+    __shared__ int sh[1024];
+    int* p = hist + (int64_t)blockIdx.x * per_list;
+    const int64_t chunk = (per_list + 1023) / 1024, lo = threadIdx.x * chunk, hi = lo + chunk < per_list ? lo + chunk : per_list;
+    int s = 0;
+    for (int64_t i = lo; i < hi; ++i) s += p[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = sh[threadIdx.x] - s;
+    for (int64_t i = lo; i < hi; ++i) { const int c = p[i]; p[i] = run; run += c; }
+}
+
+// Stable scatter: entry i of the tile belongs to wavefront (i / 512), round (i / 64) % 8, lane i % 64.  Equal digits keep
+// their order: inside a round by lane (ballot match + popcount of the lower lanes), across rounds and wavefronts by an
+// exclusive prefix over the per-(wavefront, round) counts, across workgroups by the scanned histogram.
+__global__ __launch_bounds__(256) void sort_scatter_kernel(SortArgs a) {
+    extern __shared__ unsigned short cnt[];                  // [WAVES * ROUNDS][nbins] counts, then prefixes (<= 2048)
+    __shared__ int goff[1 << SORT_MAXBITS];
+    const int nbins = 1 << a.bits;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t k = blockIdx.y, t0 = (int64_t)blockIdx.x * SORT_TILE;
+    for (int e = threadIdx.x; e < SORT_WAVES * SORT_ROUNDS * nbins; e += 256) cnt[e] = 0;
+    for (int d = threadIdx.x; d < nbins; d += 256) goff[d] = a.hist[((int64_t)k * nbins + d) * a.nblk + blockIdx.x];
+    __syncthreads();
+    uint2 kv[SORT_ROUNDS]; int rank[SORT_ROUNDS];
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+        const int64_t i = t0 + (wave * SORT_ROUNDS + r) * 64 + lane;
+        const bool valid = i < a.n;
+        kv[r] = valid ? sort_load(a, k, i) : make_uint2(0u, 0u);
+        const int digit = (kv[r].x >> a.shift) & (nbins - 1);
+        unsigned long long m = __ballot(valid);
+        for (int b = 0; b < a.bits; ++b) {
+            const bool bit = (digit >> b) & 1;
+            const unsigned long long bal = __ballot(valid && bit);
+            m &= bit ? bal : ~bal;
+        }
+        rank[r] = valid ? __popcll(m & below) : -1;
+        if (valid && rank[r] == 0) cnt[(wave * SORT_ROUNDS + r) * nbins + digit] = (unsigned short)__popcll(m);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < nbins; d += 256) {
+        int run = 0;
+        for (int wr = 0; wr < SORT_WAVES * SORT_ROUNDS; ++wr) { const int c = cnt[wr * nbins + d]; cnt[wr * nbins + d] = (unsigned short)run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+        if (rank[r] < 0) continue;
+        const int digit = (kv[r].x >> a.shift) & (nbins - 1);
+        a.out[k * a.n + goff[digit] + cnt[(wave * SORT_ROUNDS + r) * nbins + digit] + rank[r]] = kv[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ segmented sums + rule
+enum { CSR_SGD = 0, CSR_ADAGRAD = 1, CSR_ADAM = 2, CSR_ACCUM = 3 };
+
+struct CsrArgs {
+    const uint2* sorted; int64_t n; uint32_t rows; int D;
+    const float* grads; int64_t g_stride;
+    float* W; float* A; float* V; int* last; float* G;      // table; Adagrad acc / Adam m; Adam v; lazy stamps; gsum (ACCUM)
+    float lr, eps, b1, b2, lr_T; const float* lrt; int T, newton;
+    float* part_lo; float* part_hi;                          // [blocks][Dp]: sums of the runs open at a block's start / end
+    int Dp;
+};
+
+// the optimizer rule on row `row` with the summed gradient s[e] of column lane + 64 e
+template <int NE, int MODE>
+__device__ __forceinline__ void csr_rule(const CsrArgs& a, uint32_t row, const float (&s)[NE], int lane) {
+    int from = 0;
+    if (MODE == CSR_ADAM) from = __builtin_amdgcn_readfirstlane(a.last[row]);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int col = lane + 64 * e;
+        if (col >= a.D) continue;
+        const size_t i = (size_t)row * a.D + col;
+        if (MODE == CSR_SGD) a.W[i] = a.W[i] - a.lr * s[e];
+        else if (MODE == CSR_ADAGRAD) opt_apply1<ORX_ADAGRAD>(a.W + i, a.A + i, a.W[i], s[e], a.lr, a.eps);
+        else if (MODE == CSR_ACCUM) a.G[i] += s[e];
+        else {
+            float w = a.W[i], m = a.A[i], v = a.V[i];
+            adam_replay1<true>(w, m, v, from, a.T - 1, a.lrt, a.b1, a.b2, a.eps, a.newton != 0);
+            adam_elem(w, m, v, s[e], a.lr_T, a.b1, a.b2, a.eps);
+            a.W[i] = w; a.A[i] = m; a.V[i] = v;
+        }
+    }
+    if (MODE == CSR_ADAM && lane == 0) a.last[row] = a.T;
+}
+
+template <int NE, int MODE>
+__global__ __launch_bounds__(256) void csr_apply_kernel(CsrArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), i0 = b * 64;
+    if (i0 >= a.n) return;
+    const int cnt = (int)(a.n - i0 < 64 ? a.n - i0 : 64);
+    const uint2 mine = lane < cnt ? a.sorted[i0 + lane] : make_uint2(KEY_NONE, 0u);
+    const uint32_t prevk = b > 0 ? a.sorted[i0 - 1].x : KEY_NONE, nextk = i0 + 64 < a.n ? a.sorted[i0 + 64].x : KEY_NONE;
+    float acc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[e] = 0.0f;
+    uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, 0);
+    int seg0 = 0;
+    auto flush = [&](int end) {
+        if (cur >= a.rows) return;                           // padding / out-of-range ids (sorted last)
+        const bool open_lo = seg0 == 0 && prevk == cur, open_hi = end == 64 && nextk == cur;
+        if (!open_lo && !open_hi) { csr_rule<NE, MODE>(a, cur, acc, lane); return; }
+        float* p = (open_lo ? a.part_lo : a.part_hi) + (size_t)b * a.Dp;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) if (lane + 64 * e < a.D) p[lane + 64 * e] = acc[e];
+    };
+    constexpr int UN = 8;
+    for (int j0 = 0; j0 < cnt; j0 += UN) {
+        uint32_t kj[UN]; float g[UN][NE];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {                       // UN gradient rows in flight
+            const int j = j0 + u < cnt ? j0 + u : cnt - 1;
+            kj[u] = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, j);
+            const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, j);
+            const float* gp = a.grads + (size_t)pj * a.g_stride;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) g[u][e] = (kj[u] < a.rows && lane + 64 * e < a.D) ? gp[lane + 64 * e] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (j0 + u >= cnt) break;
+            if (kj[u] != cur) {
+                flush(j0 + u);
+                cur = kj[u]; seg0 = j0 + u;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) acc[e] = 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) acc[e] += g[u][e];
+        }
+    }
+    flush(cnt);
+}
+
+// runs that cross block boundaries: the wavefront of the block a run STARTS in adds the partial sums in block order
+template <int NE, int MODE>
+__global__ __launch_bounds__(256) void csr_finish_kernel(CsrArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), i0 = b * 64;
+    if (i0 + 64 >= a.n) return;                              // the last block's runs end in it
+    const uint32_t row = a.sorted[i0 + 63].x;
+    if (row >= a.rows || a.sorted[i0 + 64].x != row) return;           // the block's last run ends here
+    if (a.sorted[i0].x == row && b > 0 && a.sorted[i0 - 1].x == row) return;   // ... or started in an earlier block
+    float s[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) s[e] = lane + 64 * e < a.D ? a.part_hi[(size_t)b * a.Dp + lane + 64 * e] : 0.0f;
+    for (int64_t c = b + 1;; ++c) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) if (lane + 64 * e < a.D) s[e] += a.part_lo[(size_t)c * a.Dp + lane + 64 * e];
+        const int64_t nx = (c + 1) * 64;
+        if (nx >= a.n || a.sorted[nx].x != row) break;
+    }
+    csr_rule<NE, MODE>(a, row, s, lane);
+}
+
+// lazy Adam: every distinct row of the list is replayed to step T before a forward pass reads it
+__global__ __launch_bounds__(256) void csr_touch_kernel(CsrArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.n) return;
+    const uint32_t row = a.sorted[i].x;
+    if (row >= a.rows || (i > 0 && a.sorted[i - 1].x == row)) return;
+    const int from = __builtin_amdgcn_readfirstlane(a.last[row]);
+    if (from >= a.T) return;
+    for (int col = lane; col < a.D; col += 64) {
+        const size_t k = (size_t)row * a.D + col;
+        float w = a.W[k], m = a.A[k], v = a.V[k];
+        adam_replay1<true>(w, m, v, from, a.T, a.lrt, a.b1, a.b2, a.eps, a.newton != 0);
+        a.W[k] = w; a.A[k] = m; a.V[k] = v;
+    }
+    if (lane == 0) a.last[row] = a.T;
+}
+
+template <int MODE>
+int launch_csr(orx_ctx* ctx, const CsrArgs& a) {
+    const int64_t nblk = (a.n + 63) / 64;
+    const dim3 g((unsigned)((nblk + 3) / 4));
+    const int ne = (a.D + 63) / 64;
+#define ORX_CSR_GO(NE)                                                                  \
+    do {                                                                                \
+        ORX_LAUNCH(ctx, (csr_apply_kernel<NE, MODE>), g, dim3(256), 0, a);              \
+        ORX_LAUNCH(ctx, (csr_finish_kernel<NE, MODE>), g, dim3(256), 0, a);             \
+    } while (0)
+    switch (ne) {
+        case 1: ORX_CSR_GO(1); break;
+        case 2: ORX_CSR_GO(2); break;
+        case 3: ORX_CSR_GO(3); break;
+        default: ORX_CSR_GO(4); break;
+    }
+#undef ORX_CSR_GO
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+}  // namespace
+
+static inline int bit_width_u64(uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
+
+// sorted (row, position) pairs of K id lists of n ids each; `out` points into the context's sort buffers (valid until the
+// next orx_rows_sort on this context)
+int orx_rows_sort(orx_ctx* ctx, const int32_t* ids, int64_t K, int64_t n, int64_t id_stride, int64_t rows, const uint2** out) {
+    ORX_ARG(rows > 0 && rows < (1LL << 31) && n < (1LL << 31), "rows_sort: tables of up to 2^31 - 1 rows, lists of up to 2^31 - 1 ids");
+    *out = nullptr;
+    if (K == 0 || n == 0) return ORX_OK;
+    const int total_bits = bit_width_u64((uint64_t)rows);                 // the sentinel `rows` must be representable
+    const int passes = (total_bits + SORT_MAXBITS - 1) / SORT_MAXBITS;
+    const int bits = (total_bits + passes - 1) / passes;
+    const int nblk = (int)((n + SORT_TILE - 1) / SORT_TILE), nbins = 1 << bits;
+    if (orx_ensure((void**)&ctx->d_sort[0], &ctx->d_sort_cap[0], (size_t)K * n * sizeof(uint2)) != ORX_OK) return ORX_ERR_OOM;
+    if (orx_ensure((void**)&ctx->d_sort[1], &ctx->d_sort_cap[1], (size_t)K * n * sizeof(uint2)) != ORX_OK) return ORX_ERR_OOM;
+    if (orx_ensure((void**)&ctx->d_sort_hist, &ctx->d_sort_hist_cap, (size_t)K * nbins * nblk * sizeof(int)) != ORX_OK) return ORX_ERR_OOM;
+    ProfScope ps(ctx, ORX_K_DEDUP);
+    SortArgs a;
+    a.id_stride = id_stride; a.hist = ctx->d_sort_hist; a.n = n; a.nblk = nblk; a.sentinel = (uint32_t)rows; a.bits = bits; a.err = ctx->d_err;
+    int src = 1;                                                           // (first pass reads the ids)
+    for (int p = 0; p < passes; ++p) {
+        a.ids = p == 0 ? ids : nullptr;
+        a.in = ctx->d_sort[src]; a.out = ctx->d_sort[src ^ 1]; a.shift = p * bits;
+        const dim3 g((unsigned)nblk, (unsigned)K);
+        ORX_LAUNCH(ctx, sort_hist_kernel, g, dim3(256), 0, a);
+        ORX_LAUNCH(ctx, sort_scan_kernel, dim3((unsigned)K), dim3(1024), 0, a.hist, (int64_t)nbins * nblk);
+        ORX_LAUNCH(ctx, sort_scatter_kernel, g, dim3(256), (size_t)SORT_WAVES * SORT_ROUNDS * nbins * sizeof(unsigned short), a);
+        src ^= 1;
+    }
+    ORX_HIP(hipGetLastError());
+    *out = ctx->d_sort[src];
+    return ORX_OK;
+}
+
+static int csr_args(orx_ctx* ctx, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride, CsrArgs* a) {
+    memset(a, 0, sizeof(*a));
+    ORX_ARG(t->dim <= 256, "rows apply: dims up to 256 (got %d)", t->dim);
+    a->sorted = sorted; a->n = n; a->rows = (uint32_t)t->rows; a->D = t->dim; a->grads = grads; a->g_stride = g_stride; a->W = t->w;
+    a->Dp = (t->dim + 3) & ~3;
+    const size_t bytes = (size_t)((n + 63) / 64) * a->Dp * sizeof(float);
+    if (orx_ensure((void**)&ctx->d_csr_part[0], &ctx->d_csr_part_cap[0], bytes) != ORX_OK) return ORX_ERR_OOM;
+    if (orx_ensure((void**)&ctx->d_csr_part[1], &ctx->d_csr_part_cap[1], bytes) != ORX_OK) return ORX_ERR_OOM;
+    a->part_lo = ctx->d_csr_part[0]; a->part_hi = ctx->d_csr_part[1];
+    return ORX_OK;
+}
+
+// SGD / Adagrad on the sorted list (one step)
+int orx_csr_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride) {
+    if (n == 0) return ORX_OK;
+    ORX_ARG(opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD, "csr_apply: SGD / Adagrad (Adam: orx_csr_adam_apply)");
+    ProfScope ps(ctx, ORX_K_DUPAPPLY);
+    CsrArgs a;
+    if (int rc = csr_args(ctx, t, sorted, n, grads, g_stride, &a)) return rc;
+    a.lr = opt->lr;
+    if (opt->kind == ORX_ADAGRAD) {
+        OptSlots st;
+        if (int rc = orx_opt_slots(opt, t, &st)) return rc;
+        a.A = st.s0; a.eps = opt->p1;
+        return launch_csr<CSR_ADAGRAD>(ctx, a);
+    }
+    return launch_csr<CSR_SGD>(ctx, a);
+}
+
+// gsum[row] += sum of the row's gradient rows (the whole-table-sweep form of TF-2.0 Adam follows with its sweep)
+int orx_csr_accum(orx_ctx* ctx, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride) {
+    if (n == 0) return ORX_OK;
+    ProfScope ps(ctx, ORX_K_DUPAPPLY);
+    CsrArgs a;
+    if (int rc = csr_args(ctx, t, sorted, n, grads, g_stride, &a)) return rc;
+    if (int rc = orx_table_scratch(t)) return rc;
+    a.G = t->gsum;
+    return launch_csr<CSR_ACCUM>(ctx, a);
+}
+
+// lazy TF-2.0 Adam on the sorted list: touch (replay the distinct rows to step T) / step T
+int orx_csr_adam(orx_ctx* ctx, bool step, const AdamRowsArgs& r, orx_table* t, const uint2* sorted, int64_t n) {
+    if (n == 0) return ORX_OK;
+    ProfScope ps(ctx, ORX_K_DUPAPPLY);
+    CsrArgs a;
+    if (int rc = csr_args(ctx, t, sorted, n, r.grads, r.g_stride, &a)) return rc;
+    a.A = r.M; a.V = r.V; a.last = r.last; a.lrt = r.lrt; a.lr_T = r.lr_T; a.b1 = r.b1; a.b2 = r.b2; a.eps = r.eps; a.T = r.T; a.newton = r.newton;
+    if (step) return launch_csr<CSR_ADAM>(ctx, a);
+    ORX_LAUNCH(ctx, csr_touch_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, a);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}

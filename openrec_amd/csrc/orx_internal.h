@@ -83,6 +83,12 @@ struct orx_ctx {
     double* d_loss = nullptr;  size_t d_loss_cap = 0;       // [K][2] step results
     float* d_tmp = nullptr;    size_t d_tmp_cap = 0;        // misc fp32 scratch
     float* d_wpart = nullptr;  size_t d_wpart_cap = 0;      // [nwaves][D] dense-kernel gradient partials
+    // deterministic row apply (kernels_rowsort.hip): ping-pong buffers of the radix sort, its histograms, partial sums of runs
+    // that cross a 64-entry block
+    uint2* d_sort[2] = {nullptr, nullptr}; size_t d_sort_cap[2] = {0, 0};
+    int* d_sort_hist = nullptr; size_t d_sort_hist_cap = 0;
+    float* d_csr_part[2] = {nullptr, nullptr}; size_t d_csr_part_cap[2] = {0, 0};
+    float* d_splitk = nullptr; size_t d_splitk_cap = 0;     // [splits][M][N] partial products of a split-K fp32 product
     bool prof = false;
     ProfSlot prof_slot[ORX_K_NUM];
     hipEvent_t cur_e0 = nullptr, cur_e1 = nullptr;   // events of the launch being profiled (or null)
@@ -380,17 +386,24 @@ int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, 
 struct DenseParam { float* w; float* acc; float* acc2; float* g; int64_t n; };
 int orx_launch_dense_apply_multi(orx_ctx* ctx, const DenseParam* ps_dev, int count, int64_t max_n, int optkind, float lr, float eps,
                                  float b1 = 0.f, float b2 = 0.f);
-int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb,
+// Column sums (bias gradients) leave their producers as one partial row per row block -- parts[p * N + c], plain stores --
+// and one colparts_reduce launch per MLP backward adds the blocks in order: no fp32 atomics, reproducible sums.
+struct ColPart { float* parts = nullptr; int P = 0; };        // in: the workspace; out: row blocks written
+struct ColJob { const float* parts; float* out; int N, P; };
+constexpr int ORX_COLJOBS_MAX = 24;
+struct ColJobs { ColJob j[ORX_COLJOBS_MAX]; };
+int orx_launch_colparts_reduce(orx_ctx* ctx, const ColJob* jobs, int n);
+int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, ColPart* gb,
                               void* d16 = nullptr, int64_t ld16 = 0);
 int orx_launch_gemm_f16s(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                          void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act,
-                         const float* actY = nullptr, int64_t ldy = 0, int act_y = 0, float* gb = nullptr);
+                         const float* actY = nullptr, int64_t ldy = 0, int act_y = 0, ColPart* gb = nullptr);
 // second-generation fp16 products (kernels_gemm16.hip): C = A16 * B16^T on K-contiguous fp16 operands with the fused epilogues,
 // and the weight gradient C += A16^T * B16 from batch-major fp16 copies (split-K through fp32 slabs + one reduce launch)
 bool orx_gemm16_nt_ok(int64_t lda, int64_t ldb, int N, int K);
 int orx_launch_gemm16_nt(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                          void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act,
-                         const float* actY = nullptr, const void* actY16 = nullptr, int64_t ldy = 0, int act_y = 0, float* gb = nullptr);
+                         const float* actY = nullptr, const void* actY16 = nullptr, int64_t ldy = 0, int act_y = 0, ColPart* gb = nullptr);
 #define ORX_SLAB_STRIDE (128 * 128 + 64)          // floats per (tile, slice) of a split-K workspace (kernels_gemm16.hip)
 struct SlabReduce { const float* slab; float* C; int64_t ldc; int M, N, S, ntn, tiles; };
 bool orx_gemm16_tn_ok(int64_t lda, int64_t ldb, int N);
@@ -402,11 +415,10 @@ int orx_launch_cast16(orx_ctx* ctx, const float* src, int64_t lds_, void* dst16,
 bool orx_head16_ok(int K, int64_t ldx);
 int orx_launch_head_fwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* bias, int act, float* pred, int B, int K);
 int orx_launch_head_bwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* dy, const float* pred, int act, int act_below,
-                        float* gW, float* gb, void* dZ16, int64_t ld16, float* dZ32, int64_t ld32, float* gb_below, int B, int K);
+                        ColPart* gW, ColPart* gb, void* dZ16, int64_t ld16, float* dZ32, int64_t ld32, ColPart* gb_below, int B, int K);
 struct ShadowParam { const float* w; void* w16; void* w16t; int in, out, ld16, ld16t; };
 int orx_launch_dense_shadow(orx_ctx* ctx, const ShadowParam* ps_dev, int count, int64_t max_n);
 int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act);
-int orx_launch_colsum(orx_ctx* ctx, const float* X, int M, int N, float* out);
 int orx_launch_copy2d(orx_ctx* ctx, float* dst, int64_t ldd, const float* src, int64_t lds_, int M, int N);
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
                         float* out, int P, int64_t B, int ldR, void* R16 = nullptr, int ldR16 = 0, bool* wrote16 = nullptr,
@@ -420,6 +432,14 @@ int orx_launch_dlrm_mask_tiny(orx_ctx* ctx, const int32_t* idx, const unsigned c
 int orx_launch_dlrm_ids(orx_ctx* ctx, const int32_t* sparse, const int64_t* offset, const int64_t* rows, int nf, int64_t B,
                         int32_t* idx);
 int orx_launch_rows_accum(orx_ctx* ctx, float* G, const int32_t* ids, const float* grads, int64_t g_stride, int64_t n, int D, int64_t rows);
+
+// kernels_rowsort.hip: deterministic apply of per-occurrence gradient rows (stable sort by row + segmented sums in position order)
+int orx_rows_sort(orx_ctx* ctx, const int32_t* ids, int64_t K, int64_t n, int64_t id_stride, int64_t rows, const uint2** sorted);
+int orx_csr_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride);
+int orx_csr_accum(orx_ctx* ctx, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride);
+int orx_csr_adam(orx_ctx* ctx, bool step, const AdamRowsArgs& r, orx_table* t, const uint2* sorted, int64_t n);
+int orx_adam_rows_sorted(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride, bool step);
+int orx_adam_dense_sorted(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride);
 
 // device-side exchange plan of the sharded step (kernels_sharded.hip)
 struct RouteArgs {

@@ -15,6 +15,16 @@ Z Z^T, lines 23-27/32 select the strictly UPPER triangle, so every selected
 element is 0 (only the diagonal survives with self_interaction) and the
 embedding tables receive zero gradients.  `reference_compat=False` is the
 evidently intended strictly-lower-triangle pairwise dot product.
+
+`operand_dtype=np.float16` restates the library's ORX_DLRM_FP16_MLP mode (north_star: "dense top-MLP on fp16 MFMA"): every
+MLP product -- X W, dZ W^T, X^T dZ -- rounds BOTH operands to fp16 once and accumulates in `dtype`; biases, activations,
+bias gradients (column sums of the unrounded dZ), the feature interaction, the loss and the optimizer stay in `dtype`.
+
+`tie_margin` reports how close a sample comes to a discontinuity of the network (a relu pre-activation near zero, the
+prediction near a clipping threshold): two correct fp32 implementations that add the same terms in a different order can
+land on different sides of it, and the sample's share of every gradient below then differs at first order.  Parity tests
+draw their batches so that no sample lies within summation noise of such a point (tests/dlrm_util.py), and hold everything
+else to 1e-5.
 """
 from __future__ import annotations
 
@@ -44,9 +54,10 @@ def interaction_pairs(F, self_interaction, reference_compat):
 class DLRMOracle:
     def __init__(self, m_spa, ln_emb, ln_bot, ln_top, dense_dim, arch_interaction_itself=False,
                  sigmoid_bot=False, sigmoid_top=True, loss_func="mse", loss_threshold=0.0,
-                 reference_compat=True, dtype=np.float32, seed=0):
+                 reference_compat=True, dtype=np.float32, seed=0, operand_dtype=None):
         rng = np.random.default_rng(seed)
         self.dt = np.dtype(dtype)
+        self.op_dt = None if operand_dtype is None else np.dtype(operand_dtype)
         self.m_spa, self.ln_emb = m_spa, list(ln_emb)
         self.emb = [rng.uniform(-0.05, 0.05, (n, m_spa)).astype(dtype) for n in ln_emb]   # dlrm.py:32-33
         self.bot, d = [], dense_dim
@@ -72,18 +83,27 @@ class DLRMOracle:
             return orc._sigmoid(x)
         return x
 
-    def _mlp(self, x, layers, acts):
+    def _op(self, a):
+        """operand of an MLP product: rounded to `operand_dtype` once (fp16 mode), kept in `dtype` otherwise"""
+        return a if self.op_dt is None else a.astype(self.op_dt).astype(self.dt)
+
+    def _mlp(self, x, layers, acts, margins=None):
         outs = [x]
         for (W, b), a in zip(layers, acts):
-            x = self._act(x @ W + b, a)
+            xo, Wo = self._op(x), self._op(W)
+            z = xo @ Wo + b
+            if margins is not None and a == "relu":          # |z| against the sum of the magnitudes it was added up from
+                S = np.abs(xo) @ np.abs(Wo) + np.abs(b) + np.finfo(self.dt).tiny
+                margins.append((np.abs(z) / S).min(axis=1))
+            x = self._act(z, a)
             outs.append(x)
         return outs
 
-    def forward(self, dense, sparse, emb_rows=None):
+    def forward(self, dense, sparse, emb_rows=None, margins=None):
         """emb_rows [B, n_emb, d]: embedding vectors handed in instead of looked up (the hybrid-parallel
         step of openrec_amd/sharded_dlrm.py exchanges them between ranks first)."""
         dense = dense.astype(self.dt)
-        bot = self._mlp(dense, self.bot, self.bot_act)                                  # dlrm.py:87
+        bot = self._mlp(dense, self.bot, self.bot_act, margins)                         # dlrm.py:87
         if emb_rows is not None:
             vecs = [emb_rows[:, f, :].astype(self.dt) for f in range(emb_rows.shape[1])] + [bot[-1]]
         else:
@@ -94,17 +114,26 @@ class DLRMOracle:
             dots = np.tril(dots)                                                        # interaction.py:21
         inter = dots[:, self.I, self.J]
         R = np.concatenate([bot[-1], inter], 1)                                         # dlrm.py:90-92
-        top = self._mlp(R, self.top, self.top_act)
+        top = self._mlp(R, self.top, self.top_act, margins)
         p = top[-1]
         clip_mask = np.ones_like(p)
         if 0.0 < self.thr < 1.0:                                                        # dlrm.py:97-98
             lo, hi = self.dt.type(self.thr), self.dt.type(1.0 - self.thr)
+            if margins is not None:
+                margins.append(np.minimum(np.abs(p - lo), np.abs(p - hi)).reshape(-1))
             clip_mask = ((p >= lo) & (p <= hi)).astype(self.dt)
             p = np.clip(p, lo, hi)
         return dict(bot=bot, Z=Z, R=R, top=top, pred=p.reshape(-1), clip_mask=clip_mask.reshape(-1))
 
     def inference(self, dense, sparse):
         return self.forward(dense, sparse)["pred"]
+
+    def tie_margin(self, dense, sparse, emb_rows=None):
+        """[B]: the smallest relative distance of any relu pre-activation of the sample from zero, |z| / (|x| |W| + |b|)
+        (and of the prediction from a clipping threshold)"""
+        margins = []
+        self.forward(dense, sparse, emb_rows, margins)
+        return np.min(np.stack(margins, 0), axis=0) if margins else np.full(dense.shape[0], np.inf)
 
     # ----------------------------------------------------------- loss + backward
     def loss_and_grads(self, dense, sparse, label, emb_rows=None, global_batch=None):
@@ -152,8 +181,9 @@ class DLRMOracle:
                 dz = dy * y * (1 - y)
             else:
                 dz = dy
-            grads[l] = (outs[l].T @ dz, dz.sum(0))
-            dy = dz @ layers[l][0].T
+            dzo = self._op(dz)
+            grads[l] = (self._op(outs[l]).T @ dzo, dz.sum(0))
+            dy = dzo @ self._op(layers[l][0]).T
         return grads, dy
 
     # ------------------------------------------------------------------- step

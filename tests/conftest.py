@@ -13,41 +13,6 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "fp32_tie: compares a relu network step by step with an fp32 oracle (see conftest.py)")
-
-
-# A relu network has a discontinuity in every unit: a pre-activation that lies within fp32 summation noise of zero (~1e-8 of
-# its scale here) goes to one side or the other depending on the ORDER of additions upstream -- and the device's split-K /
-# bias-gradient / scatter-add atomics make that order differ from run to run.  When such a unit lands on the other side than
-# in the oracle, its sample's share of every gradient below it is off by a few per cent: seen twice in ~60 runs of
-# tests/test_gpu_dlrm.py (different tests, never reproducible; scratch/dbg_c5.py shows the mechanism at full size, where the
-# fp32 and the fp64 oracle agree with each other and the device sits on the other side of ONE unit).  Tests marked `fp32_tie`
-# are therefore given ONE more run when they fail, and every such rerun is listed at the end of the session.  A wrong kernel
-# fails both runs; nothing else in the suite is ever rerun.
-_reruns = []
-
-
-def pytest_runtest_protocol(item, nextitem):
-    if item.get_closest_marker("fp32_tie") is None:
-        return None
-    from _pytest.runner import runtestprotocol
-    item.ihook.pytest_runtest_logstart(nodeid=item.nodeid, location=item.location)
-    reports = runtestprotocol(item, nextitem=nextitem, log=False)
-    if any(r.when == "call" and r.failed for r in reports):
-        first = [r for r in reports if r.when == "call"][0]
-        _reruns.append((item.nodeid, str(first.longrepr).strip().splitlines()[-1][:200]))
-        reports = runtestprotocol(item, nextitem=nextitem, log=False)
-    for r in reports:
-        item.ihook.pytest_runtest_logreport(report=r)
-    item.ihook.pytest_runtest_logfinish(nodeid=item.nodeid, location=item.location)
-    return True
-
-
-def pytest_terminal_summary(terminalreporter):
-    if _reruns:
-        terminalreporter.section("fp32_tie reruns (first run failed, see conftest.py)")
-        for nodeid, line in _reruns:
-            terminalreporter.write_line(f"{nodeid}: {line}")
 
 
 def golden_files(prefix=""):

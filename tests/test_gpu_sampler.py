@@ -123,3 +123,26 @@ def test_device_pointwise_samplers_follow_the_reference_generators():
     U = rt.Table(NU, 64).init_uniform(seed=1); V = rt.Table(NI, 64).init_uniform(seed=2); b = rt.Table(NI, 1).init_uniform(seed=3)
     loss, _ = rt.pointwise_step("wrmf", rt.Optimizer.sgd(0.01), U, V, b, None, u[:K * B], i[:K * B], lab[:K * B], K=K, B=B)
     assert np.isfinite(loss).all() and loss[0] > 0
+
+
+@pytest.mark.parametrize("ratio", [0.05, 1.0 / 3.0, 1.0 / 6.0, 1.0 / 11.0, 0.5, 0.2])
+def test_per_pos_group_size_is_the_python_double_quotient(ratio):
+    """dataset.py:40: num_negative_per_positive = int((1 - pos_ratio) / pos_ratio) in Python doubles.  In fp32 the quotient
+    lands on the other side of an integer for common ratios (0.05 -> 19 instead of 18, 1/3 -> 1 instead of 2, 1/6 -> 4
+    instead of 5, 1/11 -> 9 instead of 10): the device sampler must emit the reference's group size and label mix."""
+    import torch
+    from openrec_amd import runtime as rt
+    import sampler_stats as ss
+    g, raw, NU, NI, _ = ss.load()
+    sm = rt.DeviceSampler(raw, NU, NI)
+    nneg = int((1 - ratio) / ratio)
+    assert nneg + 1 <= NI
+    grp = 1 + nneg
+    n = 50 * grp
+    dev = torch.device("cuda", 0)
+    u = torch.empty(n, dtype=torch.int32, device=dev); i = torch.empty_like(u); lab = torch.empty(n, dtype=torch.float32, device=dev)
+    sm.per_pos_stratified_pointwise(3, 0, n, ratio, u, i, lab); sm.ctx.synchronize()
+    L = lab.cpu().numpy().reshape(-1, grp)
+    assert (L[:, 0] == 1.0).all() and (L[:, 1:] == 0.0).all()
+    U = u.cpu().numpy().reshape(-1, grp)
+    assert (U == U[:, :1]).all()

@@ -9,7 +9,7 @@ import pytest
 
 from conftest import rel_err
 
-pytestmark = [pytest.mark.gpu, pytest.mark.fp32_tie]
+pytestmark = pytest.mark.gpu
 
 CFG = dict(m_spa=16, ln_emb=[1000, 37, 5000, 3, 250], ln_bot=[64, 16], ln_top=[128, 64, 1], dense_dim=13)
 
