@@ -329,9 +329,21 @@ struct Batch { const float* dense; const int32_t* sparse; const float* label; };
 
 // MLP product: exact fp32 MFMA, or fp16 MFMA in the performance mode
 static int mlp_gemm(orx_dlrm* m, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
-                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero = false) {
-    if (m->flags & ORX_DLRM_FP16_MLP) return orx_launch_gemm_f16(m->ctx, A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, c_zero);
-    return orx_launch_gemm(m->ctx, A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, c_zero);
+                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero = false, float out_scale = 1.0f) {
+    if (m->flags & ORX_DLRM_FP16_MLP) return orx_launch_gemm_f16(m->ctx, A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, c_zero, out_scale);
+    return orx_launch_gemm(m->ctx, A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, c_zero, out_scale);
+}
+
+// fp16 mode: the backward pass carries S * gradient, S a power of two of the order of the batch the loss mean runs over (the
+// loss kernel multiplies dLoss/dPred by it), so that the fp16 copies of the gradients sit in fp16's NORMAL range: dLoss/dPred
+// is O(1 / B), 1e-5 at the C5 batch, where fp16 is subnormal and holds 2 to 7 bits.  Every fp32 sink divides by S again --
+// exact both ways: weight gradients (slab reduce / product epilogue), bias gradients (partial-row reduce), the interaction's
+// embedding gradients.  The exact fp32 mode runs with S = 1.
+static float loss_scale(const orx_dlrm* m, int64_t n_mean) {
+    if (!(m->flags & ORX_DLRM_FP16_MLP) || getenv("ORX_DLRM_NO_LOSS_SCALE") != nullptr) return 1.0f;
+    float s = 1.0f;
+    while (s < (float)n_mean && s < 32768.0f) s *= 2.0f;
+    return s;
 }
 
 // forward of one batch; leaves every activation in the model's buffers.  emb_rows != NULL: the
@@ -445,7 +457,7 @@ static int dense_apply_all(orx_dlrm* m, orx_opt* opt, float lr_t = 0.f) {
 // ins16 / outs16 (top MLP in fp16 mode, else NULL): the fp16 copies of every layer's input and output.
 static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vector<const float*>& ins, const std::vector<int64_t>& ld_in,
                         const std::vector<const float*>& outs, const std::vector<int64_t>& ld_out,
-                        float* dy, float* other, int64_t B, bool need_dx0, float** dx_out,
+                        float* dy, float* other, int64_t B, bool need_dx0, float** dx_out, float gscale,
                         const std::vector<const void*>* ins16 = nullptr, const std::vector<int64_t>* ld_in16 = nullptr,
                         const std::vector<const void*>* outs16 = nullptr) {
     orx_ctx* c = m->ctx;
@@ -456,7 +468,8 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
     int slabs = 0;
     std::vector<ColJob> coljobs;        // bias gradients (and the head's weight gradient) leave as partial rows per row block
     auto colpart_of = [&](float* parts) { ColPart cp; cp.parts = parts; return cp; };
-    auto add_job = [&](const ColPart& cp, float* out, int N) { ColJob j; j.parts = cp.parts; j.out = out; j.N = N; j.P = cp.P; coljobs.push_back(j); };
+    const float inv_scale = 1.0f / gscale;                  // dy and everything derived from it carries the loss scale
+    auto add_job = [&](const ColPart& cp, float* out, int N) { ColJob j; j.parts = cp.parts; j.out = out; j.N = N; j.P = cp.P; j.scale = inv_scale; coljobs.push_back(j); };
     for (int l = (int)L.size() - 1; l >= 0; --l) {
         DenseLayer& D = L[l];
         CHECK(orx_table_scratch(D.W)); CHECK(orx_table_scratch(D.b));
@@ -489,11 +502,11 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
         // gW [in, out] = X^T * dZ
         if (D.dw16) {
             ORX_ARG(dy16 != nullptr && ins16 && (*ins16)[l], "dlrm backward: fp16 operands missing for layer %d", l);
-            CHECK(orx_launch_gemm16_tn(c, (*ins16)[l], (*ld_in16)[l], dy16, D.out, D.W->gsum, D.out, D.slab, D.in, D.out, (int)B));
+            CHECK(orx_launch_gemm16_tn(c, (*ins16)[l], (*ld_in16)[l], dy16, D.out, D.W->gsum, D.out, D.slab, D.in, D.out, (int)B, inv_scale));
             if (D.slab_S > 1) ++slabs;
         } else {
             ORX_ARG(dy32, "dlrm backward: fp32 gradient missing for layer %d", l);
-            CHECK(mlp_gemm(m, ins[l], 1, ld_in[l], dy, D.out, 1, D.W->gsum, D.out, nullptr, D.in, D.out, (int)B, 0, true));
+            CHECK(mlp_gemm(m, ins[l], 1, ld_in[l], dy, D.out, 1, D.W->gsum, D.out, nullptr, D.in, D.out, (int)B, 0, true, inv_scale));
         }
         if (want_dx) {
             // dX [B, in] = dZ * W^T  (fp16-resident operands where they exist: dZ16, W16).  With a layer below, the
@@ -540,7 +553,7 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
     CHECK(orx_launch_colparts_reduce(c, coljobs.data(), (int)coljobs.size()));
     if (slabs > 0) {
         ORX_ARG(slabs == m->n_slabjobs[which], "dlrm backward: %d of %d split-K weight gradients were produced", slabs, m->n_slabjobs[which]);
-        CHECK(orx_launch_slab_reduce(c, m->d_slabjobs[which], m->n_slabjobs[which], m->slab_max_tiles[which]));
+        CHECK(orx_launch_slab_reduce(c, m->d_slabjobs[which], m->n_slabjobs[which], m->slab_max_tiles[which], inv_scale));
     }
     *dx_out = dy;
     return ORX_OK;
@@ -548,7 +561,7 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
 
 // backward of the batch whose activations `forward` left behind; m->gA holds dLoss/dPred.
 // Leaves dZ [B, F, d] (slot F-1 = d dense_emb) and every dense gradient in its table's gsum.
-static int backward(orx_dlrm* m, const Batch& bt, int64_t B) {
+static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale) {
     orx_ctx* c = m->ctx;
     const int F = m->F, d = m->m_spa;
     const int compat = (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0, itself = (m->flags & ORX_DLRM_INTERACT_ITSELF) ? 1 : 0;
@@ -566,14 +579,15 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B) {
             ins16.push_back(l == 0 ? m->R16 : m->top_y16[l - 1]); ldi16.push_back(l == 0 ? m->ldR16 : up8(m->top[l - 1].out));
             outs16.push_back(l + 1 < m->top.size() ? m->top_y16[l] : nullptr);
         }
-    CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR, m->gen2 ? &ins16 : nullptr, &ldi16, &outs16));
+    CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR, gscale, m->gen2 ? &ins16 : nullptr, &ldi16, &outs16));
     // ---- interaction backward: dZ for every slot (slot F-1 = d dense_emb)
+    // (dR carries the loss scale; dZ -- the embedding rows' gradients -- leaves unscaled)
     CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B, m->ldR, nullptr, 0, nullptr,
-                              m->direct_idx ? m->emb->w : nullptr, m->direct_idx, m->direct_idx ? m->emb->rows : 0));
+                              m->direct_idx ? m->emb->w : nullptr, m->direct_idx, m->direct_idx ? m->emb->rows : 0, 1.0f / gscale));
     // ---- bottom MLP backward from dZ[:, F-1, :]
     float* dy = (dR == m->gA) ? m->gB : m->gA;
     float* other = (dy == m->gA) ? m->gB : m->gA;
-    CHECK(orx_launch_copy2d(c, dy, d, m->dZ + (size_t)(F - 1) * d, (int64_t)F * d, (int)B, d));
+    CHECK(orx_launch_copy2d(c, dy, d, m->dZ + (size_t)(F - 1) * d, (int64_t)F * d, (int)B, d, gscale));
     ins.clear(); outs.clear(); ldi.clear(); ldo.clear();
     for (size_t l = 0; l < m->bot.size(); ++l) {
         const bool last = l + 1 == m->bot.size();
@@ -588,7 +602,7 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B) {
             ins16.push_back(l == 0 ? m->dense16 : m->bot_y16[l - 1]); ldi16.push_back(l == 0 ? m->ld_dense16 : up8(m->bot[l - 1].out));
             outs16.push_back(l + 1 < m->bot.size() ? m->bot_y16[l] : nullptr);
         }
-    CHECK(mlp_backward(m, m->bot, ins, ldi, outs, ldo, dy, other, B, false, &dx0, bot16 ? &ins16 : nullptr, &ldi16, &outs16));
+    CHECK(mlp_backward(m, m->bot, ins, ldi, outs, ldo, dy, other, B, false, &dx0, gscale, bot16 ? &ins16 : nullptr, &ldi16, &outs16));
     }
     return ORX_OK;
 }
@@ -681,8 +695,9 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         CHECK(forward(m, bt, B, nullptr, idx_s, lazy_adam));
         float* pred = m->top_y.back();
         // loss + dLoss/dP  (dlrm.py:72-73, :97-98)
-        CHECK(orx_launch_dlrm_loss(c, pred, bt.label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, m->d_loss + s));
-        CHECK(backward(m, bt, B));
+        const float gscale = loss_scale(m, B);
+        CHECK(orx_launch_dlrm_loss(c, pred, bt.label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, m->d_loss + s, 0, 0, gscale));
+        CHECK(backward(m, bt, B, gscale));
         // ---- optimizer: one step counter for all variables (Keras `iterations`)
         opt->t += 1;
         float lr_t = 0.f;
@@ -761,9 +776,10 @@ extern "C" int orx_dlrm_grads(orx_dlrm* m, const float* dense, const float* emb_
     CHECK(ensure_buffers(m, B));
     Batch bt; bt.dense = dense; bt.sparse = nullptr; bt.label = label;
     CHECK(forward(m, bt, B, emb_rows));
+    const float gscale = loss_scale(m, global_B);
     CHECK(orx_launch_dlrm_loss(c, m->top_y.back(), label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, loss_accum,
-                               global_B, 1));
-    CHECK(backward(m, bt, B));
+                               global_B, 1, gscale));
+    CHECK(backward(m, bt, B, gscale));
     m->grads_pending = true;
     const int d = m->m_spa;
     return orx_launch_copy2d(c, emb_grads, (int64_t)m->n_emb * d, m->dZ, (int64_t)m->F * d, (int)B, m->n_emb * d);

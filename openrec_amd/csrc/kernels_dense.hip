@@ -22,6 +22,7 @@ struct GemmArgs {
     int act;                 // 0 none, 1 relu, 2 sigmoid
     int kchunk;              // split-K: K range per blockIdx.z; the partial products go to ws [splits][M][N] (plain stores) and
     float* ws;               // splitk_reduce_kernel adds them in split order (no atomics: the sum is reproducible)
+    float out_scale;         // the product is multiplied by this (1 / loss scale of the fp16 mode's weight gradients; else 1)
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                 const int row = bm + wm + mi * 16 + (lane >> 4) * 4 + r;
                 const int col = bn + wn + ni * 16 + (lane & 15);
                 if (row < g.M && col < g.N) {
-                    float v = acc[mi][ni][r];
+                    float v = acc[mi][ni][r] * g.out_scale;
                     if (g.bias) v += g.bias[col];
                     if (g.act == 1) v = fmaxf(v, 0.0f);
                     else if (g.act == 2) v = 1.0f / (1.0f + __expf(-v));
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int vec_a, in
                 const int row = bm + wm + mi * 16 + (lane >> 4) * 4 + r;
                 const int col = bn + wn + ni * 16 + (lane & 15);
                 if (row < g.M && col < g.N) {
-                    float v = acc[mi][ni][r];
+                    float v = acc[mi][ni][r] * g.out_scale;
                     if (gridDim.z > 1) { g.ws[((int64_t)blockIdx.z * g.M + row) * g.N + col] = v; continue; }
                     if (g.bias) v += g.bias[col];
                     if (g.act == 1) v = fmaxf(v, 0.0f);
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm_f32v_kernel(GemmArgs g, int vec_a, i
                 const int row = bm + wm + mi * 16 + (lane >> 4) * 4 + r;
                 const int col = bn + wn + ni * 16 + (lane & 15);
                 if (row < g.M && col < g.N) {
-                    float v = acc[mi][ni][r];
+                    float v = acc[mi][ni][r] * g.out_scale;
                     if (gridDim.z > 1) { g.ws[((int64_t)blockIdx.z * g.M + row) * g.N + col] = v; continue; }
                     if (g.bias) v += g.bias[col];
                     if (g.act == 1) v = fmaxf(v, 0.0f);
@@ -484,10 +485,10 @@ static int gemm_plan(const float* A, int64_t sa0, int64_t sa1, const float* B, i
 }
 
 int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
-                        float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero) {
+                        float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero, float out_scale) {
     if (M == 0 || N == 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_GEMM);
-    GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0, nullptr};
+    GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0, nullptr, out_scale};
     // split-K when the output has too few tiles to fill the chip (the X^T*dY weight-gradient products:
     // small M x N, K = batch); the partial products leave through a workspace and are added in split order
     const int tiles = ((N + 127) / 128) * ((M + 127) / 128);
@@ -521,10 +522,10 @@ int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, 
 }
 
 int orx_launch_gemm(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
-                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero) {
+                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero, float out_scale) {
     if (M == 0 || N == 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_GEMM);
-    GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0, nullptr};
+    GemmArgs g{A, sa0, sa1, B, sb0, sb1, C, ldc, bias, M, N, K, act, 0, nullptr, out_scale};
     (void)c_zero;
     if ((sa1 == 1 || sa0 == 1) && (sb1 == 1 || sb0 == 1) && getenv("ORX_GEMM_F32_SIMPLE") == nullptr) {
         dim3 grid; int va, vb; bool akc, bnc;
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(256) void colparts_reduce_kernel(ColJobs jobs) {
         s += a0; s += a1; s += a2; s += a3;
     }
     for (; p < j.P; ++p) s += j.parts[(int64_t)p * j.N + c];
-    j.out[c] = s;
+    j.out[c] = s * j.scale;
 }
 
 int orx_launch_colparts_reduce(orx_ctx* ctx, const ColJob* jobs, int n) {
@@ -634,19 +635,19 @@ int orx_launch_colparts_reduce(orx_ctx* ctx, const ColJob* jobs, int n) {
 }
 
 // strided copy: dst[r, 0:n] = src[r*lds + 0:n]
-__global__ void copy2d_kernel(float* dst, int64_t ldd, const float* src, int64_t lds_, int M, int N) {
+__global__ void copy2d_kernel(float* dst, int64_t ldd, const float* src, int64_t lds_, int M, int N, float scale) {
     const int64_t total = (int64_t)M * N;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int64_t r = i / N; const int c = (int)(i - r * N);
-        dst[r * ldd + c] = src[r * lds_ + c];
+        dst[r * ldd + c] = src[r * lds_ + c] * scale;
     }
 }
 
-int orx_launch_copy2d(orx_ctx* ctx, float* dst, int64_t ldd, const float* src, int64_t lds_, int M, int N) {
+int orx_launch_copy2d(orx_ctx* ctx, float* dst, int64_t ldd, const float* src, int64_t lds_, int M, int N, float scale) {
     if (M == 0 || N == 0) return ORX_OK;
     int64_t g = ((int64_t)M * N + 255) / 256; if (g > 8192) g = 8192;
-    ORX_LAUNCH(ctx, copy2d_kernel, dim3((unsigned)g), dim3(256), 0, dst, ldd, src, lds_, M, N);
+    ORX_LAUNCH(ctx, copy2d_kernel, dim3((unsigned)g), dim3(256), 0, dst, ldd, src, lds_, M, N, scale);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(256) void interact_fwd_kernel(const float* Z, int F
 
 // dZ [B, F, d] from dR [B, d + P]
 __global__ __launch_bounds__(256) void interact_bwd_kernel(const float* Z, const float* dR, int F, int d, int compat,
-                                                           int itself, float* dZ, int P, int64_t B, int ldR) {
+                                                           int itself, float* dZ, int P, int64_t B, int ldR, float scale) {
     extern __shared__ float sm[];            // zs [F][d + 1], gs [F][F]
     const int zd = d + 1;
     float* zs = sm;
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(256) void interact_bwd_kernel(const float* Z, const
         const int i = e / d, k = e % d;
         float acc = (i == F - 1) ? rb[k] : 0.0f;
         for (int j = 0; j < F; ++j) acc += (gs[i * F + j] + gs[j * F + i]) * zs[j * zd + k];  // d(z_i.z_j): both orders
-        dZ[b * F * d + e] = acc;
+        dZ[b * F * d + e] = acc * scale;
     }
 }
 
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(RowSrc src, int 
 // MFMA grid is {CPL*j + t}, so every lane ends up with CPL consecutive columns of its output rows (float4 stores).
 template <int CPL>
 __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, const float* dR, int F, int itself, float* dZ,
-                                                                int64_t B, int ldR) {
+                                                                int64_t B, int ldR, float scale) {
     constexpr int d = 16 * CPL;
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -845,7 +846,7 @@ __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, cons
             float* out = dZ + (b * F + g) * d + CPL * i;
             float o[CPL];
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) o[t] = acc[ti][t][r] + (g == F - 1 ? rb[CPL * i + t] : 0.0f);
+            for (int t = 0; t < CPL; ++t) o[t] = (acc[ti][t][r] + (g == F - 1 ? rb[CPL * i + t] : 0.0f)) * scale;
             if (CPL >= 4) {
 #pragma unroll
                 for (int t = 0; t < CPL; t += 4) { f32x4 v; v.x = o[t]; v.y = o[t + 1]; v.z = o[t + 2]; v.w = o[t + 3]; *reinterpret_cast<f32x4*>(out + t) = v; }
@@ -863,7 +864,7 @@ bool orx_interact_direct_ok(int F, int d, int compat) {
 
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
                         float* out, int P, int64_t B, int ldR, void* R16, int ldR16, bool* wrote16,
-                        const float* emb, const int32_t* idx, int64_t emb_rows) {
+                        const float* emb, const int32_t* idx, int64_t emb_rows, float scale) {
     if (wrote16) *wrote16 = false;
     if (B == 0) return ORX_OK;
     const bool mfma = !compat && F <= 32 && d % 32 == 0 && ((uintptr_t)Z & 15) == 0 && getenv("ORX_INTERACT_SIMPLE") == nullptr;
@@ -876,15 +877,15 @@ int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR,
             ORX_LAUNCH(ctx, interact_fwd_mfma_kernel, g, dim3(256), 0, src, F, d, itself, out, B, ldR, (_Float16*)R16, ldR16);
             if (wrote16 && R16) *wrote16 = true;
         }
-        else if (d == 32) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<2>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR);
-        else if (d == 64) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR);
-        else if (d == 128) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR);
-        else ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<16>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR);
+        else if (d == 32) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<2>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
+        else if (d == 64) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
+        else if (d == 128) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
+        else ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<16>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
         ORX_HIP(hipGetLastError());
         return ORX_OK;
     }
     if (fwd) ORX_LAUNCH(ctx, interact_fwd_kernel, dim3((unsigned)B), dim3(256), (size_t)F * (d + 1) * sizeof(float), Z, F, d, compat, itself, out, P, B, ldR);
-    else ORX_LAUNCH(ctx, interact_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(F * (d + 1) + F * F) * sizeof(float), Z, dR, F, d, compat, itself, out, P, B, ldR);
+    else ORX_LAUNCH(ctx, interact_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(F * (d + 1) + F * F) * sizeof(float), Z, dR, F, d, compat, itself, out, P, B, ldR, scale);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -894,7 +895,7 @@ int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR,
 // n_mean: the batch the loss mean runs over (= B, or the global batch of a data-parallel step);
 // accumulate: add this launch's share to *loss_out instead of overwriting it
 __global__ __launch_bounds__(1024) void dlrm_loss_kernel(float* P, const float* y, int64_t B, int bce, float thr,
-                                                         float* dP, double* loss_out, int64_t n_mean, int accumulate) {
+                                                         float* dP, double* loss_out, int64_t n_mean, int accumulate, float gscale) {
     __shared__ double sh[16];
     double s = 0.0;
     const float invB = 1.0f / (float)n_mean;
@@ -919,7 +920,7 @@ __global__ __launch_bounds__(1024) void dlrm_loss_kernel(float* P, const float* 
             const float inside = (p >= eps && p <= 1.0f - eps) ? 1.0f : 0.0f;
             g = -(t / (pc + eps) - (1.0f - t) / (1.0f - pc + eps)) * inside * invB;
         }
-        if (dP) dP[i] = g * mask;
+        if (dP) dP[i] = g * mask * gscale;           // (gscale: the fp16 mode's loss scale, a power of two)
     }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
@@ -933,8 +934,8 @@ __global__ __launch_bounds__(1024) void dlrm_loss_kernel(float* P, const float* 
 }
 
 int orx_launch_dlrm_loss(orx_ctx* ctx, float* P, const float* y, int64_t B, int bce, float thr, float* dP, double* loss_out,
-                         int64_t n_mean, int accumulate) {
-    ORX_LAUNCH(ctx, dlrm_loss_kernel, dim3(1), dim3(1024), 0, P, y, B, bce, thr, dP, loss_out, n_mean > 0 ? n_mean : B, accumulate);
+                         int64_t n_mean, int accumulate, float gscale) {
+    ORX_LAUNCH(ctx, dlrm_loss_kernel, dim3(1), dim3(1024), 0, P, y, B, bce, thr, dP, loss_out, n_mean > 0 ? n_mean : B, accumulate, gscale);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

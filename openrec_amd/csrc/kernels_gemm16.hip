@@ -270,6 +270,7 @@ struct Tn16Args {
     float* C; int64_t ldc;               // S == 1: C += tile
     float* slab;                         // S > 1: [tile][S][BM * BN]
     int M, N, K, kchunk;
+    float out_scale;                     // S == 1: C += out_scale * tile (the slabs are scaled by slab_reduce_kernel)
 };
 
 // k order inside a 32-deep MFMA step: lane group q holds rows 4q .. 4q + 3 and 16 + 4q .. 16 + 4q + 3 of the stage (the same
@@ -375,14 +376,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_tn_kernel(Tn16Args 
             if (row >= g.M) continue;
             const float v[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (col + e < g.N) g.C[(int64_t)row * g.ldc + col + e] += v[e];
+            for (int e = 0; e < 4; ++e) if (col + e < g.N) g.C[(int64_t)row * g.ldc + col + e] += v[e] * g.out_scale;
         }
     }
 }
 
 // C += sum over the S slices of every tile; one launch serves all layers of an MLP backward.  grid = (max tiles, 8 parts, layers)
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduce* jobs) {
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduce* jobs, float out_scale) {
     const SlabReduce j = jobs[blockIdx.z];
     const int tile = blockIdx.x;
     if (tile >= j.tiles) return;
@@ -402,6 +403,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduce* jobs
             for (int u = 0; u < 8; ++u) v += w[u];
         }
         for (; z < j.S; ++z) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (size_t)z * SLAB_STRIDE + e * 4));
+        v *= out_scale;
         float* p = j.C + (int64_t)row * j.ldc + col;
         if (col + 3 < j.N && (j.ldc & 3) == 0) { f32x4 o = *reinterpret_cast<f32x4*>(p); o += v; *reinterpret_cast<f32x4*>(p) = o; continue; }
         const float o[4] = {v.x, v.y, v.z, v.w};
@@ -425,14 +427,14 @@ void orx_gemm16_tn_plan(orx_ctx* ctx, int M, int N, int K, int* S_out, int* tile
 bool orx_gemm16_tn_ok(int64_t lda, int64_t ldb, int N) { return lda % 8 == 0 && ldb % 8 == 0 && N % 8 == 0; }
 
 int orx_launch_gemm16_tn(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
-                         float* slab, int M, int N, int K) {
+                         float* slab, int M, int N, int K, float out_scale) {
     if (M == 0 || N == 0 || K == 0) return ORX_OK;
     ORX_ARG(lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)A16 | (uintptr_t)B16) & 15) == 0, "gemm16_tn: operands need 16-byte rows");
     ProfScope ps(ctx, ORX_K_GEMM);
     int S, tiles, kchunk;
     orx_gemm16_tn_plan(ctx, M, N, K, &S, &tiles, &kchunk);
     ORX_ARG(S == 1 || slab != nullptr, "gemm16_tn: split-K needs a slab workspace");
-    Tn16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, slab, M, N, K, kchunk};
+    Tn16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, slab, M, N, K, kchunk, out_scale};
     constexpr size_t shm = (size_t)2 * 64 * (128 + 16 + 128 + 16) * 2;
     auto kern = gemm16_tn_kernel<2, 2, 4, 4, 2>;
     static bool attr = false;
@@ -442,10 +444,10 @@ int orx_launch_gemm16_tn(orx_ctx* ctx, const void* A16, int64_t lda, const void*
     return ORX_OK;
 }
 
-int orx_launch_slab_reduce(orx_ctx* ctx, const void* jobs_dev, int n_jobs, int max_tiles) {
+int orx_launch_slab_reduce(orx_ctx* ctx, const void* jobs_dev, int n_jobs, int max_tiles, float out_scale) {
     if (n_jobs == 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_GEMM);                            // (part of the weight-gradient products' cost)
-    ORX_LAUNCH(ctx, (slab_reduce_kernel<128, 128>), dim3((unsigned)max_tiles, 8, (unsigned)n_jobs), dim3(256), 0, (const SlabReduce*)jobs_dev);
+    ORX_LAUNCH(ctx, (slab_reduce_kernel<128, 128>), dim3((unsigned)max_tiles, 8, (unsigned)n_jobs), dim3(256), 0, (const SlabReduce*)jobs_dev, out_scale);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

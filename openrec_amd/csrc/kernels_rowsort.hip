@@ -25,6 +25,7 @@ struct SortArgs {
     const int32_t* ids; int64_t id_stride;     // first pass: list k at ids + k * id_stride (NULL: read `in`)
     const uint2* in; uint2* out;               // [K][n] (key, position)
     int* hist;                                 // [K][nbins][nblk]
+    int* binbase;                              // [K][nbins] first output position of a digit (after the scans)
     int64_t n; int nblk; uint32_t sentinel;    // sentinel = table rows: key of padding (id < 0) and out-of-range ids, sorts last
     int shift, bits;
     int* err;
@@ -55,23 +56,38 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(SortArgs a) {
     for (int d = threadIdx.x; d < nbins; d += 256) a.hist[((int64_t)k * nbins + d) * a.nblk + blockIdx.x] = h[d];
 }
 
-// exclusive prefix over the (digit-major) counts of one list
-__global__ __launch_bounds__(1024) void sort_scan_kernel(int* hist, int64_t per_list) {
-    __shared__ int sh[1024];
-    int* p = hist + (int64_t)blockIdx.x * per_list;
-    const int64_t chunk = (per_list + 1023) / 1024, lo = threadIdx.x * chunk, hi = lo + chunk < per_list ? lo + chunk : per_list;
-    int s = 0;
-    for (int64_t i = lo; i < hi; ++i) s += p[i];
-    sh[threadIdx.x] = s;
+// Exclusive prefix over the (digit-major) counts of every list, in two small launches: one wavefront per (list, digit) scans
+// that digit's per-workgroup counts in place and leaves the digit's total; one workgroup per list scans the totals.
+__global__ __launch_bounds__(256) void sort_scan_blocks_kernel(int* hist, int* bintotal, int nblk, int64_t nrows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // (list, digit)
+    if (row >= nrows) return;
+    int* p = hist + row * nblk;
+    int carry = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 64) {
+        const int c = b0 + lane < nblk ? p[b0 + lane] : 0;
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        if (b0 + lane < nblk) p[b0 + lane] = carry + incl - c;
+        carry += __shfl(incl, 63);
+    }
+    if (lane == 0) bintotal[row] = carry;
+}
+
+__global__ __launch_bounds__(512) void sort_scan_bins_kernel(int* bintotal, int nbins) {
+    __shared__ int sh[1 << SORT_MAXBITS];
+    int* p = bintotal + (int64_t)blockIdx.x * nbins;
+    const int c = (int)threadIdx.x < nbins ? p[threadIdx.x] : 0;
+    sh[threadIdx.x] = c;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+    for (int off = 1; off < 512; off <<= 1) {
+        const int v = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
         __syncthreads();
         sh[threadIdx.x] += v;
         __syncthreads();
     }
-    int run = sh[threadIdx.x] - s;
-    for (int64_t i = lo; i < hi; ++i) { const int c = p[i]; p[i] = run; run += c; }
+    if ((int)threadIdx.x < nbins) p[threadIdx.x] = sh[threadIdx.x] - c;
 }
 
 // Stable scatter: entry i of the tile belongs to wavefront (i / 512), round (i / 64) % 8, lane i % 64.  Equal digits keep
@@ -84,7 +100,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(SortArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t k = blockIdx.y, t0 = (int64_t)blockIdx.x * SORT_TILE;
     for (int e = threadIdx.x; e < SORT_WAVES * SORT_ROUNDS * nbins; e += 256) cnt[e] = 0;
-    for (int d = threadIdx.x; d < nbins; d += 256) goff[d] = a.hist[((int64_t)k * nbins + d) * a.nblk + blockIdx.x];
+    for (int d = threadIdx.x; d < nbins; d += 256) goff[d] = a.binbase[(int64_t)k * nbins + d] + a.hist[((int64_t)k * nbins + d) * a.nblk + blockIdx.x];
     __syncthreads();
     uint2 kv[SORT_ROUNDS]; int rank[SORT_ROUNDS];
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -129,21 +145,47 @@ struct CsrArgs {
     int Dp;
 };
 
+// the row's state, loaded together with the gradient rows (no dependent round trip when the rule is applied)
+template <int NE, int MODE>
+struct RowState {
+    float w[NE], a[NE], v[NE]; int last;
+    __device__ __forceinline__ void load(const CsrArgs& c, uint32_t row, int lane) {
+        const bool live = row < c.rows;
+        last = 0;
+        if (MODE == CSR_ADAM) last = live ? c.last[row] : 0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int col = lane + 64 * e;
+            const size_t i = (size_t)row * c.D + col;
+            const bool ok = live && col < c.D;
+            w[e] = a[e] = v[e] = 0.0f;
+            if (MODE == CSR_ACCUM) { if (ok) w[e] = c.G[i]; continue; }
+            if (ok) w[e] = c.W[i];
+            if (MODE == CSR_ADAGRAD || MODE == CSR_ADAM) { if (ok) a[e] = c.A[i]; }
+            if (MODE == CSR_ADAM) { if (ok) v[e] = c.V[i]; }
+        }
+    }
+};
+
 // the optimizer rule on row `row` with the summed gradient s[e] of column lane + 64 e
 template <int NE, int MODE>
-__device__ __forceinline__ void csr_rule(const CsrArgs& a, uint32_t row, const float (&s)[NE], int lane) {
+__device__ __forceinline__ void csr_rule(const CsrArgs& a, uint32_t row, const float (&s)[NE], const RowState<NE, MODE>& st, int lane) {
     int from = 0;
-    if (MODE == CSR_ADAM) from = __builtin_amdgcn_readfirstlane(a.last[row]);
+    if (MODE == CSR_ADAM) from = __builtin_amdgcn_readfirstlane(st.last);
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int col = lane + 64 * e;
         if (col >= a.D) continue;
         const size_t i = (size_t)row * a.D + col;
-        if (MODE == CSR_SGD) a.W[i] = a.W[i] - a.lr * s[e];
-        else if (MODE == CSR_ADAGRAD) opt_apply1<ORX_ADAGRAD>(a.W + i, a.A + i, a.W[i], s[e], a.lr, a.eps);
-        else if (MODE == CSR_ACCUM) a.G[i] += s[e];
+        if (MODE == CSR_SGD) a.W[i] = st.w[e] - a.lr * s[e];
+        else if (MODE == CSR_ADAGRAD) {
+            const float acc = st.a[e] + s[e] * s[e];
+            a.A[i] = acc;
+            a.W[i] = st.w[e] - a.lr * s[e] / (sqrtf(acc) + a.eps);
+        }
+        else if (MODE == CSR_ACCUM) a.G[i] = st.w[e] + s[e];
         else {
-            float w = a.W[i], m = a.A[i], v = a.V[i];
+            float w = st.w[e], m = st.a[e], v = st.v[e];
             adam_replay1<true>(w, m, v, from, a.T - 1, a.lrt, a.b1, a.b2, a.eps, a.newton != 0);
             adam_elem(w, m, v, s[e], a.lr_T, a.b1, a.b2, a.eps);
             a.W[i] = w; a.A[i] = m; a.V[i] = v;
@@ -163,34 +205,38 @@ __global__ __launch_bounds__(256) void csr_apply_kernel(CsrArgs a) {
     float acc[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) acc[e] = 0.0f;
-    uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, 0);
+    uint32_t cur = KEY_NONE;
     int seg0 = 0;
+    RowState<NE, MODE> st_cur;
     auto flush = [&](int end) {
-        if (cur >= a.rows) return;                           // padding / out-of-range ids (sorted last)
+        if (cur >= a.rows) return;                           // padding / out-of-range ids (sorted last); nothing before the first entry
         const bool open_lo = seg0 == 0 && prevk == cur, open_hi = end == 64 && nextk == cur;
-        if (!open_lo && !open_hi) { csr_rule<NE, MODE>(a, cur, acc, lane); return; }
+        if (!open_lo && !open_hi) { csr_rule<NE, MODE>(a, cur, acc, st_cur, lane); return; }
         float* p = (open_lo ? a.part_lo : a.part_hi) + (size_t)b * a.Dp;
 #pragma unroll
         for (int e = 0; e < NE; ++e) if (lane + 64 * e < a.D) p[lane + 64 * e] = acc[e];
     };
     constexpr int UN = 8;
     for (int j0 = 0; j0 < cnt; j0 += UN) {
-        uint32_t kj[UN]; float g[UN][NE];
+        uint32_t kj[UN]; float g[UN][NE]; RowState<NE, MODE> st[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {                       // UN gradient rows in flight
+        for (int u = 0; u < UN; ++u) {                       // UN gradient rows and the table rows they belong to in flight
             const int j = j0 + u < cnt ? j0 + u : cnt - 1;
             kj[u] = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, j);
             const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, j);
             const float* gp = a.grads + (size_t)pj * a.g_stride;
 #pragma unroll
             for (int e = 0; e < NE; ++e) g[u][e] = (kj[u] < a.rows && lane + 64 * e < a.D) ? gp[lane + 64 * e] : 0.0f;
+            // (only the entry that starts a run uses its table row; the others re-read a line the run's head just fetched)
+            const uint32_t before = j > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)mine.x, j - 1) : KEY_NONE;
+            if (j0 + u < cnt && kj[u] != before) st[u].load(a, kj[u], lane);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             if (j0 + u >= cnt) break;
-            if (kj[u] != cur) {
-                flush(j0 + u);
-                cur = kj[u]; seg0 = j0 + u;
+            if (kj[u] != cur || j0 + u == 0) {
+                if (j0 + u > 0) flush(j0 + u);
+                cur = kj[u]; seg0 = j0 + u; st_cur = st[u];
 #pragma unroll
                 for (int e = 0; e < NE; ++e) acc[e] = 0.0f;
             }
@@ -219,7 +265,9 @@ __global__ __launch_bounds__(256) void csr_finish_kernel(CsrArgs a) {
         const int64_t nx = (c + 1) * 64;
         if (nx >= a.n || a.sorted[nx].x != row) break;
     }
-    csr_rule<NE, MODE>(a, row, s, lane);
+    RowState<NE, MODE> st;
+    st.load(a, row, lane);
+    csr_rule<NE, MODE>(a, row, s, st, lane);
 }
 
 // lazy Adam: every distinct row of the list is replayed to step T before a forward pass reads it
@@ -277,17 +325,18 @@ int orx_rows_sort(orx_ctx* ctx, const int32_t* ids, int64_t K, int64_t n, int64_
     const int nblk = (int)((n + SORT_TILE - 1) / SORT_TILE), nbins = 1 << bits;
     if (orx_ensure((void**)&ctx->d_sort[0], &ctx->d_sort_cap[0], (size_t)K * n * sizeof(uint2)) != ORX_OK) return ORX_ERR_OOM;
     if (orx_ensure((void**)&ctx->d_sort[1], &ctx->d_sort_cap[1], (size_t)K * n * sizeof(uint2)) != ORX_OK) return ORX_ERR_OOM;
-    if (orx_ensure((void**)&ctx->d_sort_hist, &ctx->d_sort_hist_cap, (size_t)K * nbins * nblk * sizeof(int)) != ORX_OK) return ORX_ERR_OOM;
+    if (orx_ensure((void**)&ctx->d_sort_hist, &ctx->d_sort_hist_cap, (size_t)K * nbins * (nblk + 1) * sizeof(int)) != ORX_OK) return ORX_ERR_OOM;
     ProfScope ps(ctx, ORX_K_DEDUP);
     SortArgs a;
-    a.id_stride = id_stride; a.hist = ctx->d_sort_hist; a.n = n; a.nblk = nblk; a.sentinel = (uint32_t)rows; a.bits = bits; a.err = ctx->d_err;
+    a.id_stride = id_stride; a.hist = ctx->d_sort_hist; a.binbase = ctx->d_sort_hist + (size_t)K * nbins * nblk; a.n = n; a.nblk = nblk; a.sentinel = (uint32_t)rows; a.bits = bits; a.err = ctx->d_err;
     int src = 1;                                                           // (first pass reads the ids)
     for (int p = 0; p < passes; ++p) {
         a.ids = p == 0 ? ids : nullptr;
         a.in = ctx->d_sort[src]; a.out = ctx->d_sort[src ^ 1]; a.shift = p * bits;
         const dim3 g((unsigned)nblk, (unsigned)K);
         ORX_LAUNCH(ctx, sort_hist_kernel, g, dim3(256), 0, a);
-        ORX_LAUNCH(ctx, sort_scan_kernel, dim3((unsigned)K), dim3(1024), 0, a.hist, (int64_t)nbins * nblk);
+        ORX_LAUNCH(ctx, sort_scan_blocks_kernel, dim3((unsigned)((K * nbins + 3) / 4)), dim3(256), 0, a.hist, a.binbase, nblk, (int64_t)K * nbins);
+        ORX_LAUNCH(ctx, sort_scan_bins_kernel, dim3((unsigned)K), dim3(512), 0, a.binbase, nbins);
         ORX_LAUNCH(ctx, sort_scatter_kernel, g, dim3(256), (size_t)SORT_WAVES * SORT_ROUNDS * nbins * sizeof(unsigned short), a);
         src ^= 1;
     }

@@ -380,16 +380,16 @@ int orx_launch_adam_sweep(orx_ctx* ctx, float* w, float* m, float* v, float* gsu
 
 // kernels_dense.hip (DLRM dense side)
 int orx_launch_gemm(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
-                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero = false);
+                    float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero = false, float out_scale = 1.0f);
 int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1,
-                        float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero = false);
+                        float* C, int64_t ldc, const float* bias, int M, int N, int K, int act, bool c_zero = false, float out_scale = 1.0f);
 struct DenseParam { float* w; float* acc; float* acc2; float* g; int64_t n; };
 int orx_launch_dense_apply_multi(orx_ctx* ctx, const DenseParam* ps_dev, int count, int64_t max_n, int optkind, float lr, float eps,
                                  float b1 = 0.f, float b2 = 0.f);
 // Column sums (bias gradients) leave their producers as one partial row per row block -- parts[p * N + c], plain stores --
 // and one colparts_reduce launch per MLP backward adds the blocks in order: no fp32 atomics, reproducible sums.
 struct ColPart { float* parts = nullptr; int P = 0; };        // in: the workspace; out: row blocks written
-struct ColJob { const float* parts; float* out; int N, P; };
+struct ColJob { const float* parts; float* out; int N, P; float scale; };     // out = scale * sum of the partial rows
 constexpr int ORX_COLJOBS_MAX = 24;
 struct ColJobs { ColJob j[ORX_COLJOBS_MAX]; };
 int orx_launch_colparts_reduce(orx_ctx* ctx, const ColJob* jobs, int n);
@@ -409,8 +409,8 @@ struct SlabReduce { const float* slab; float* C; int64_t ldc; int M, N, S, ntn, 
 bool orx_gemm16_tn_ok(int64_t lda, int64_t ldb, int N);
 void orx_gemm16_tn_plan(orx_ctx* ctx, int M, int N, int K, int* S_out, int* tiles_out, int* kchunk_out);
 int orx_launch_gemm16_tn(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
-                         float* slab, int M, int N, int K);
-int orx_launch_slab_reduce(orx_ctx* ctx, const void* jobs_dev, int n_jobs, int max_tiles);
+                         float* slab, int M, int N, int K, float out_scale = 1.0f);
+int orx_launch_slab_reduce(orx_ctx* ctx, const void* jobs_dev, int n_jobs, int max_tiles, float out_scale = 1.0f);
 int orx_launch_cast16(orx_ctx* ctx, const float* src, int64_t lds_, void* dst16, int64_t ld16, int M, int N);
 bool orx_head16_ok(int K, int64_t ldx);
 int orx_launch_head_fwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* bias, int act, float* pred, int B, int K);
@@ -419,13 +419,13 @@ int orx_launch_head_bwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* 
 struct ShadowParam { const float* w; void* w16; void* w16t; int in, out, ld16, ld16t; };
 int orx_launch_dense_shadow(orx_ctx* ctx, const ShadowParam* ps_dev, int count, int64_t max_n);
 int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act);
-int orx_launch_copy2d(orx_ctx* ctx, float* dst, int64_t ldd, const float* src, int64_t lds_, int M, int N);
+int orx_launch_copy2d(orx_ctx* ctx, float* dst, int64_t ldd, const float* src, int64_t lds_, int M, int N, float scale = 1.0f);
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
                         float* out, int P, int64_t B, int ldR, void* R16 = nullptr, int ldR16 = 0, bool* wrote16 = nullptr,
-                        const float* emb = nullptr, const int32_t* idx = nullptr, int64_t emb_rows = 0);
+                        const float* emb = nullptr, const int32_t* idx = nullptr, int64_t emb_rows = 0, float scale = 1.0f);
 bool orx_interact_direct_ok(int F, int d, int compat);
 int orx_launch_dlrm_loss(orx_ctx* ctx, float* P, const float* y, int64_t B, int bce, float thr, float* dP, double* loss_out,
-                         int64_t n_mean = 0, int accumulate = 0);
+                         int64_t n_mean = 0, int accumulate = 0, float gscale = 1.0f);
 int orx_launch_dlrm_tiny_apply(orx_ctx* ctx, const int32_t* idx, const float* dZ, const int* tiny_f_dev, int n_tiny, int max_rows,
                                const int64_t* offset, const int64_t* rows, int F, int d, int64_t B, float lr, float* W);
 int orx_launch_dlrm_mask_tiny(orx_ctx* ctx, const int32_t* idx, const unsigned char* is_tiny_dev, int F, int64_t total, int32_t* out);

@@ -19,6 +19,9 @@ evidently intended strictly-lower-triangle pairwise dot product.
 `operand_dtype=np.float16` restates the library's ORX_DLRM_FP16_MLP mode (north_star: "dense top-MLP on fp16 MFMA"): every
 MLP product -- X W, dZ W^T, X^T dZ -- rounds BOTH operands to fp16 once and accumulates in `dtype`; biases, activations,
 bias gradients (column sums of the unrounded dZ), the feature interaction, the loss and the optimizer stay in `dtype`.
+The gradients are rounded under a static LOSS SCALE, as the library does (csrc/dlrm.hip: loss_scale): S = the power of two
+>= the batch the loss mean runs over (at most 2^15); fp16(S dZ) / S -- dLoss/dPred is O(1 / B), which at B = 8192 lies in
+fp16's subnormal range.
 
 `tie_margin` reports how close a sample comes to a discontinuity of the network (a relu pre-activation near zero, the
 prediction near a clipping threshold): two correct fp32 implementations that add the same terms in a different order can
@@ -73,6 +76,7 @@ class DLRMOracle:
         self.bot_act = ["relu"] * (len(ln_bot) - 1) + ["sigmoid" if sigmoid_bot else "relu"]   # dlrm.py:34-35
         self.top_act = ["relu"] * (len(ln_top) - 1) + ["sigmoid" if sigmoid_top else "relu"]   # dlrm.py:36-37
         self.loss_func, self.thr = loss_func, loss_threshold
+        self._gscale = self.dt.type(1.0)
 
     # ------------------------------------------------------------------ forward
     @staticmethod
@@ -87,23 +91,49 @@ class DLRMOracle:
         """operand of an MLP product: rounded to `operand_dtype` once (fp16 mode), kept in `dtype` otherwise"""
         return a if self.op_dt is None else a.astype(self.op_dt).astype(self.dt)
 
-    def _mlp(self, x, layers, acts, margins=None):
+    def _mlp(self, x, layers, acts, probe=None, x_noise=None):
+        """probe (dict, optional) collects what tie_margin / fp16_flip_risk report; x_noise: absolute uncertainty of the
+        input activations between two correct implementations (None: the inputs are given data, identical on both sides)"""
         outs = [x]
         for (W, b), a in zip(layers, acts):
             xo, Wo = self._op(x), self._op(W)
             z = xo @ Wo + b
-            if margins is not None and a == "relu":          # |z| against the sum of the magnitudes it was added up from
-                S = np.abs(xo) @ np.abs(Wo) + np.abs(b) + np.finfo(self.dt).tiny
-                margins.append((np.abs(z) / S).min(axis=1))
+            S = None
+            if probe is not None:
+                S = np.abs(xo) @ np.abs(Wo) + np.abs(b) + np.finfo(self.dt).tiny      # the magnitudes z was added up from
+                move = None
+                if self.op_dt is not None and x_noise is not None:
+                    move = self._flip_move(x, xo, Wo, x_noise)
+                if a == "relu":
+                    probe["margin"].append((np.abs(z) / S).min(axis=1))
+                    if move is not None:
+                        probe["risky"] |= (np.abs(z) < move + probe["delta"] * S).any(axis=1)
             x = self._act(z, a)
+            if probe is not None:       # what the next layer's inputs may differ by: the summation noise of this layer.  (The doubtful
+                # roundings themselves are NOT passed on as certain movement: taken as certain and coherent they mark every sample
+                # within three layers, while in fact a handful per step come true -- tests/test_gpu_dlrm.py budgets for those.)
+                x_noise = probe["kappa"] * S * (1.0 if a != "sigmoid" else 0.25)
             outs.append(x)
+        if probe is not None:
+            probe["out_noise"] = x_noise
         return outs
 
-    def forward(self, dense, sparse, emb_rows=None, margins=None):
+    def _flip_move(self, x, xo, Wo, x_noise):
+        """fp16 mode, [B, units]: how far the input activations that another correct implementation may round to the
+        neighbouring fp16 value (they sit within the implementations' disagreement `x_noise` of a rounding boundary) can move
+        each pre-activation of this layer.  Each such operand moves z_j by one fp16 ulp of x_k times |W_kj|; all of a sample's
+        doubtful operands are taken to move together (a 1024-term product has several).  A relu unit closer to zero than
+        that may come out on the other side there; the next layer inherits the movement as input uncertainty."""
+        ulp = np.spacing(np.abs(xo).astype(self.op_dt)).astype(self.dt)
+        dist = 0.5 * ulp - np.abs(x - xo)                       # distance of the unrounded activation from the rounding boundary
+        doubt = np.where((dist < x_noise) & (np.abs(x) > 0), ulp, 0.0)
+        return doubt @ np.abs(Wo)
+
+    def forward(self, dense, sparse, emb_rows=None, probe=None):
         """emb_rows [B, n_emb, d]: embedding vectors handed in instead of looked up (the hybrid-parallel
         step of openrec_amd/sharded_dlrm.py exchanges them between ranks first)."""
         dense = dense.astype(self.dt)
-        bot = self._mlp(dense, self.bot, self.bot_act, margins)                         # dlrm.py:87
+        bot = self._mlp(dense, self.bot, self.bot_act, probe, None)                     # dlrm.py:87
         if emb_rows is not None:
             vecs = [emb_rows[:, f, :].astype(self.dt) for f in range(emb_rows.shape[1])] + [bot[-1]]
         else:
@@ -114,13 +144,18 @@ class DLRMOracle:
             dots = np.tril(dots)                                                        # interaction.py:21
         inter = dots[:, self.I, self.J]
         R = np.concatenate([bot[-1], inter], 1)                                         # dlrm.py:90-92
-        top = self._mlp(R, self.top, self.top_act, margins)
+        R_noise = None
+        if probe is not None:       # the interaction's outputs are fp32 dot products of the (fp32) feature rows
+            aZ = np.abs(Z)
+            Sd = np.einsum("bfd,bgd->bfg", aZ, aZ)[:, self.I, self.J]
+            R_noise = np.concatenate([probe["out_noise"] if probe["out_noise"] is not None else np.zeros_like(bot[-1]), probe["kappa"] * Sd], 1)
+        top = self._mlp(R, self.top, self.top_act, probe, R_noise)
         p = top[-1]
         clip_mask = np.ones_like(p)
         if 0.0 < self.thr < 1.0:                                                        # dlrm.py:97-98
             lo, hi = self.dt.type(self.thr), self.dt.type(1.0 - self.thr)
-            if margins is not None:
-                margins.append(np.minimum(np.abs(p - lo), np.abs(p - hi)).reshape(-1))
+            if probe is not None:
+                probe["margin"].append(np.minimum(np.abs(p - lo), np.abs(p - hi)).reshape(-1))
             clip_mask = ((p >= lo) & (p <= hi)).astype(self.dt)
             p = np.clip(p, lo, hi)
         return dict(bot=bot, Z=Z, R=R, top=top, pred=p.reshape(-1), clip_mask=clip_mask.reshape(-1))
@@ -128,12 +163,15 @@ class DLRMOracle:
     def inference(self, dense, sparse):
         return self.forward(dense, sparse)["pred"]
 
-    def tie_margin(self, dense, sparse, emb_rows=None):
+    def tie_margin(self, dense, sparse, emb_rows=None, kappa=2e-7, delta=1e-6):
         """[B]: the smallest relative distance of any relu pre-activation of the sample from zero, |z| / (|x| |W| + |b|)
-        (and of the prediction from a clipping threshold)"""
-        margins = []
-        self.forward(dense, sparse, emb_rows, margins)
-        return np.min(np.stack(margins, 0), axis=0) if margins else np.full(dense.shape[0], np.inf)
+        (and of the prediction from a clipping threshold).  fp16 mode: -1 for samples where an fp16 rounding of a hidden
+        activation that two correct implementations may resolve differently could flip a relu unit (_flip_move; `kappa`
+        = the relative disagreement of fp32 dot products, in units of the summed magnitudes)."""
+        probe = dict(margin=[], risky=np.zeros(dense.shape[0], bool), kappa=kappa, delta=delta, out_noise=None)
+        self.forward(dense, sparse, emb_rows, probe)
+        m = np.min(np.stack(probe["margin"], 0), axis=0) if probe["margin"] else np.full(dense.shape[0], np.inf)
+        return np.where(probe["risky"], -1.0, m)
 
     # ----------------------------------------------------------- loss + backward
     def loss_and_grads(self, dense, sparse, label, emb_rows=None, global_batch=None):
@@ -152,6 +190,11 @@ class DLRMOracle:
             inside = ((p >= eps) & (p <= 1 - eps)).astype(self.dt)
             dp = -(y / (pc + eps) - (1 - y) / (1 - pc + eps)) * inside / self.dt.type(B)
         dp = (dp * c["clip_mask"]).reshape(-1, 1)
+        S = 1.0
+        if self.op_dt is not None:
+            while S < B and S < 32768.0:
+                S *= 2.0
+        self._gscale = self.dt.type(S)
         g_top, dR = self._mlp_backward(c["top"], self.top, self.top_act, dp)
         d = self.m_spa
         dZ = np.zeros_like(c["Z"])
@@ -181,7 +224,7 @@ class DLRMOracle:
                 dz = dy * y * (1 - y)
             else:
                 dz = dy
-            dzo = self._op(dz)
+            dzo = self._op(dz * self._gscale) / self._gscale
             grads[l] = (self._op(outs[l]).T @ dzo, dz.sum(0))
             dy = dzo @ self._op(layers[l][0]).T
         return grads, dy

