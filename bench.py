@@ -174,6 +174,80 @@ def bench_dlrm(args, torch, rt, world, rank, local_rank, device, dist):
         dist.destroy_process_group()
 
 
+def secondary_pairwise(torch, rt, ctx, device, model, dim, opt_name, censor, K, W, batch=65536, users=1_000_000, items=1_000_000):
+    """one more pairwise workload after the headline run (same protocol: W warm-up steps in two calls, K timed steps in one call,
+    then the same K steps again with dispatch-attached events for the kernel time)"""
+    lr = 0.05
+    U = rt.Table(users, dim, ctx).init_uniform(seed=0); V = rt.Table(items, dim, ctx).init_uniform(seed=1); b = rt.Table(items, 1, ctx).init_uniform(seed=2)
+    opt = {"sgd": lambda: rt.Optimizer.sgd(lr, ctx=ctx), "adagrad": lambda: rt.Optimizer.adagrad(lr, ctx=ctx)}[opt_name]()
+    uid, pid, nid = make_ids(torch, users, items, K + W, batch, 4321, device)
+    torch.cuda.synchronize()
+    run = lambda first, count: rt.pairwise_step(model, opt, U, V, b, uid[first:first + count], pid[first:first + count], nid[first:first + count],
+                                                K=count, B=batch, margin=0.5, want_loss=False, censor=censor)
+    rt.pairwise_reserve(opt, U, V, b, max(K, W, 1), batch)
+    w1 = W - W // 2
+    run(0, w1)
+    if W // 2:
+        run(w1, W // 2)
+    ctx.synchronize(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(W, K)
+    ctx.synchronize(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.prof_reset(); ctx.prof_enable(True)
+    run(W, K)
+    ctx.prof_enable(False)
+    fused = ctx.prof_get().get("fused", {})
+    bpt = alg_bytes_per_triplet(dim, opt_name, model)
+    out = {"workload": f"{model} dim={dim} {users}x{items} table, batch={batch}, {opt_name}, exact TF duplicate semantics"
+                       f"{', censor after each step' if censor else ''}",
+           "value": K * batch / dt, "unit": "triplets/s", "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3}
+    if fused.get("launches"):
+        dur = fused["total_ms"] / fused["launches"] * 1e-3
+        out["roofline"] = {"bound": "hbm", "kernel": "fused_kernel", "kernel_us": dur * 1e6, "bytes_per_triplet": bpt,
+                           "achieved": batch * bpt / dur / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": batch * bpt / dur / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
+def secondary_dlrm(torch, rt, ctx, device, fp16, K, W, B=8192):
+    """C5 on one GPU after the headline run: orx_dlrm_step on batches resident in HBM (see bench_dlrm for the full version)"""
+    cfg = dict(m_spa=128, ln_emb=CRITEO_KAGGLE_COUNTS, ln_bot=[512, 256, 128], ln_top=[1024, 1024, 512, 256, 1], dense_dim=13, reference_compat=False)
+    g = torch.Generator(device=device); g.manual_seed(99)
+    n = (K + W) * B
+    dense = torch.log1p(torch.randint(0, 100, (n, 13), device=device, generator=g).float()).contiguous()
+    sparse = torch.stack([torch.randint(0, c, (n,), device=device, generator=g, dtype=torch.int32) for c in CRITEO_KAGGLE_COUNTS], 1).contiguous()
+    label = (torch.rand((n,), device=device, generator=g) < 0.25).float().contiguous()
+    m = rt.DLRMModel(ctx=ctx, fp16_mlp=fp16, **cfg)
+    opt = rt.Optimizer.sgd(0.01, ctx=ctx)
+    es = lambda t: t.element_size()
+    run = lambda first, count: m.step_device(opt, dense.data_ptr() + first * B * 13 * es(dense), sparse.data_ptr() + first * B * 26 * es(sparse),
+                                             label.data_ptr() + first * B * es(label), count, B)
+    torch.cuda.synchronize()
+    run(0, W - W // 2)
+    if W // 2:
+        run(W - W // 2, W // 2)
+    ctx.synchronize(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(W, K)
+    ctx.synchronize(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.prof_reset(); ctx.prof_enable(True)
+    run(W, K)
+    ctx.prof_enable(False)
+    gp = ctx.prof_get().get("gemm", {})
+    dims = list(zip([13] + cfg["ln_bot"][:-1], cfg["ln_bot"])) + list(zip([128 + 27 * 26 // 2] + cfg["ln_top"][:-1], cfg["ln_top"]))
+    flops = sum(2.0 * B * i * o * (2 if k == 0 else 3) for k, (i, o) in enumerate(dims))
+    out = {"workload": f"dlrm 26 Criteo-Kaggle tables (33.8 M rows x 128), bottom 13-512-256-128, top 479-1024-1024-512-256-1, batch={B}, sgd, "
+                       f"{'fp16 MFMA MLP products (fp32 master weights, accumulation, embeddings)' if fp16 else 'fp32'}",
+           "value": K * B / dt, "unit": "samples/s", "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3}
+    if gp.get("launches"):
+        tf = flops * K / (gp["total_ms"] * 1e-3) / 1e12
+        peak = 2500.0 if fp16 else 157.3
+        out["roofline"] = {"bound": "mfma", "kernel": "all MLP products of the step (gemm16_nt / gemm16_tn / slab_reduce / head kernels)" if fp16 else "gemm_f32v_kernel",
+                           "kernel_us": gp["total_ms"] / K * 1e3, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "flops_per_step": flops}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,6 +270,8 @@ def main():
                          "reported for DESIGN.md, never the headline")
     ap.add_argument("--censor", action="store_true",
                     help="UCML: LatentFactor.censor of the touched rows after every step (ucml.py:44-48)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the \"secondary\" block of the headline line (C3 = UCML D=128 + censor, C5 = DLRM with fp16 MLP products)")
     args = ap.parse_args()
 
     import torch
@@ -354,6 +430,21 @@ def main():
                                                     for k, v in prof.items() if v.get("launches") and k not in ("fused", "pointwise")}}
         if losses is not None:
             out["loss_first_last"] = [float(losses[0][0]), float(losses[0][-1])]
+        headline = (args.model, args.dim, args.users, args.items, args.batch, args.opt, args.zipf, args.hogwild, args.host_ids, args.censor) == \
+                   ("bpr", 64, 1_000_000, 1_000_000, 65536, "sgd", 0.0, False, False, False)
+        if world == 1 and not args.sharded and headline and not args.no_secondary:
+            # BASELINE.json configs[2] and configs[4] at the same protocol, after the timed C2 region (the headline tables are
+            # released first); a failure here must never hide the headline
+            sec = {}
+            del U, V, b, uid, pid, nid
+            torch.cuda.empty_cache()
+            for key, fn in (("c3", lambda: secondary_pairwise(torch, rt, ctx, device, "ucml", 128, "sgd", True, 20, 10)),
+                            ("c5_fp16", lambda: secondary_dlrm(torch, rt, ctx, device, True, 20, 10))):
+                try:
+                    sec[key] = fn()
+                except Exception as e:
+                    sec[key] = {"error": repr(e)}
+            out["secondary"] = sec
         if world == 1 and not args.sharded and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args)

@@ -19,30 +19,38 @@ def _tables(NU, NI, D, seed):
     return U, V, b
 
 
-@pytest.mark.parametrize("model,D,optname", [("bpr", 64, "sgd"), ("ucml", 128, "sgd"), ("bpr", 64, "adagrad")])
-def test_full_size_steps_match_the_c_oracle(model, D, optname):
+@pytest.mark.parametrize("model,D,optname,censor", [("bpr", 64, "sgd", False), ("ucml", 128, "sgd", False), ("bpr", 64, "adagrad", False),
+                                                    ("ucml", 128, "sgd", True)])
+def test_full_size_steps_match_the_c_oracle(model, D, optname, censor):
+    """censor=True is BASELINE configs[2] as SURVEY.md 8(d) quotes it: UCML D=128 with censor_vec after every step (ucml.py:44-48:
+    LatentFactor.censor on the user ids, the p-item ids, the n-item ids; latent_factor.py:17-23) -- on the device the censor is
+    fused into the write-back of the step's rows, items referenced as positive AND negative are censored twice."""
     from openrec_amd import runtime as rt
     from oracle import c_oracle
     NU = NI = 1_000_000
     B, K = 65536, 3
     U, V, b = _tables(NU, NI, D, 1)
+    if censor:      # rows on both sides of min_norm = 0.1: U(-.05, .05)^128 has norm 0.33 (censored to 1), a tenth of the rows stays below 0.1
+        U[::10] *= 0.2; V[::10] *= 0.2
     rng = np.random.default_rng(2)
     uid = rng.integers(0, NU, (K, B)).astype(np.int32); pid = rng.integers(0, NI, (K, B)).astype(np.int32)
     nid = rng.integers(0, NI, (K, B)).astype(np.int32)
     tU = rt.Table(NU, D).write(U); tV = rt.Table(NI, D).write(V); tb = rt.Table(NI, 1).write(b)
     opt = rt.Optimizer.sgd(0.05) if optname == "sgd" else rt.Optimizer.adagrad(0.05)
     U0, V0, b0 = U.copy(), V.copy(), b.copy()
-    loss, l2 = rt.pairwise_step(model, opt, tU, tV, tb, uid, pid, nid, K=K, B=B, margin=0.5)
+    loss, l2 = rt.pairwise_step(model, opt, tU, tV, tb, uid, pid, nid, K=K, B=B, margin=0.5, censor=censor)
     cpu = c_oracle.PairwiseCPU(model, optname, U, V, b, lr=0.05)
     for s in range(K):
         lw, l2w = cpu.step(uid[s], pid[s], nid[s])
         assert abs(loss[s] - lw) <= 1e-5 * abs(lw) and abs(l2[s] - l2w) <= 1e-5 * abs(l2w)
+        if censor:                                            # ucml.py:46-48, in the reference's order
+            c_oracle.censor(U, uid[s]); c_oracle.censor(V, pid[s]); c_oracle.censor(V, nid[s])
     gU, gV, gb = tU.read(), tV.read(), tb.read()
     for got, want in ((gU, U), (gV, V), (gb, b)):
         assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
     # the UPDATE of every element (a bound on the table cannot see the loss gradient at this batch size: conftest.delta_check)
     for name, w0, got, want in (("user", U0, gU, U), ("item", V0, gV, V), ("item_bias", b0, gb, b)):
-        coef = delta_check(w0, got, want, steps=K, what=f"{model} {optname} {name}")
+        coef = delta_check(w0, got, want, steps=K * (3 if censor else 1), what=f"{model} {optname} {name}")   # (a censor = a norm + a divide: two more roundings)
         assert abs(coef - 1.0) <= 1e-4, (name, coef)
     # rows outside every id list keep their exact bits
     untouched_u = np.ones(NU, bool); untouched_u[uid.reshape(-1)] = False
