@@ -107,6 +107,8 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipFree(c->d_sort[0]); hipFree(c->d_sort[1]); hipFree(c->d_sort_hist); hipFree(c->d_csr_part[0]); hipFree(c->d_csr_part[1]); hipFree(c->d_splitk);
     if (c->h_plan) hipHostFree(c->h_plan);
     if (c->plan_ev) hipEventDestroy(c->plan_ev);
+    for (int k = 0; k < 2; ++k) { if (c->pipe_cnt[k]) hipEventDestroy(c->pipe_cnt[k]); if (c->pipe_done[k]) hipEventDestroy(c->pipe_done[k]); }
+    if (c->plan_stream) hipStreamDestroy(c->plan_stream);
     if (c->wait_ev) hipEventDestroy(c->wait_ev);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -578,6 +580,15 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
                 c->h_plan_cap = (size_t)chunk * 9 * sizeof(int);
             }
             if (!c->plan_ev) ORX_HIP(hipEventCreateWithFlags(&c->plan_ev, hipEventDisableTiming));
+            if (!c->plan_stream) {                          // the plan pipeline's stream and events (orx_pairwise_step)
+                int lo_p = 0, hi_p = 0;
+                ORX_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+                ORX_HIP(hipStreamCreateWithPriority(&c->plan_stream, hipStreamNonBlocking, hi_p));
+                for (int k = 0; k < 2; ++k) {
+                    ORX_HIP(hipEventCreateWithFlags(&c->pipe_cnt[k], hipEventDisableTiming));
+                    ORX_HIP(hipEventCreateWithFlags(&c->pipe_done[k], hipEventDisableTiming));
+                }
+            }
         } else {
             if (role_bits) ENSURE(c->d_roles, c->d_roles_cap, (size_t)chunk * 3 * Bp);
             if (inline_apply) ENSURE(c->d_dupbits, c->d_dupbits_cap, (size_t)chunk * nb_total * orx_dedup_words() * sizeof(unsigned int));
@@ -611,69 +622,31 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
     return ORX_OK;
 }
 
-// The plan of a chunk of kc steps of an exact step (pairwise: three id lists per step; pointwise: two, nN = 0):
-// duplicate detection, roles, staging plan, and the host-side decisions read back from it.
-int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,
-                 int64_t nU, int64_t nP, int64_t nN, int64_t kc, int64_t B, bool role_bits, bool inline_apply, bool staging,
-                 const PairPlan& plan, ExactChunk* out, const std::function<int()>* while_waiting) {
-    *out = ExactChunk();
-    // duplicate detection for every step of the chunk, on the id arrays alone
-    DedupArgs d;
+// DedupArgs of steps i0 .. of the chunk's plan arrays
+static void plan_dedup_args(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,
+                            int64_t nU, int64_t nP, int64_t nN, int64_t B, bool role_bits, bool inline_apply, bool staging,
+                            const PairPlan& plan, int64_t i0, DedupArgs* out) {
+    DedupArgs& d = *out;
     memset(&d, 0, sizeof(d));
     d.uid = uid; d.pid = pid; d.nid = nid; d.id_stride = ds;
-    d.dflag = nullptr; d.ids_out = c->d_ids2; d.dlist = c->d_dlist; d.dcount = c->d_dcount;
+    d.dflag = nullptr; d.ids_out = c->d_ids2 + (size_t)i0 * 3 * plan.Bp; d.dlist = c->d_dlist + (size_t)i0 * plan.list_stride; d.dcount = c->d_dcount + i0;
     d.roles = role_bits ? c->d_roles : nullptr;
     d.dupbits = inline_apply ? c->d_dupbits : nullptr;
     d.flag_stride = 3 * plan.Bp; d.role_stride = plan.Bp; d.list_stride = plan.list_stride;
     d.nU = nU; d.nP = nP; d.nN = nN; d.NU = U->rows; d.NI = V->rows;
     d.nbu = orx_dedup_buckets(U->rows); d.nbi = orx_dedup_buckets(V->rows);
     d.min_late = plan.min_late;
-    const bool v2 = orx_plan_v2(role_bits);
-    if (!v2) ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));     // (the bucketed plan zeroes its counters itself)
-    d.alloc = c->d_alloc;
+    d.alloc = c->d_alloc ? c->d_alloc + 8 * i0 : nullptr;
     if (staging) {
-        d.refinfo = c->d_refinfo; d.tricnt = c->d_tricnt; d.segstart = c->d_segstart;
-        d.dseg = c->d_dseg; d.dcnt = c->d_dcnt; d.items = c->d_chunks;
+        d.refinfo = c->d_refinfo + (size_t)i0 * 3 * plan.Bp; d.tricnt = c->d_tricnt + (size_t)i0 * B; d.segstart = c->d_segstart + (size_t)i0 * B;
+        d.dseg = c->d_dseg + (size_t)i0 * plan.list_stride; d.dcnt = c->d_dcnt + (size_t)i0 * plan.list_stride; d.items = c->d_chunks + (size_t)i0 * plan.item_stride;
         d.tri_stride = B; d.item_stride = plan.item_stride;
         for (int l = 0; l < 3; ++l) d.tree_off[l] = plan.tree_off[l];
-        if (!v2) ORX_HIP(hipMemsetAsync(c->d_tricnt, 0, (size_t)kc * B * sizeof(int), c->stream));
-        if (!v2) ORX_HIP(hipMemsetAsync(c->d_alloc, 0, (size_t)kc * 8 * sizeof(int), c->stream));
     }
-    std::vector<int> dc_v1, al_v1, dc_v2;
-    const int* dc = nullptr;            // duplicated rows per step
-    const int* al = nullptr;            // staging allocators per step
-    if (v2) {
-        // bucketed plan; ONE read-back of the per-step counters into pinned memory, and the urgent marks are made while
-        // the host waits for it (the fused kernel ignores them in a launch without apply blocks)
-        d.roles = nullptr; d.dupbits = nullptr;
-        CHECK(orx_launch_plan(c, d, kc, inline_apply));
-        ORX_HIP(hipMemcpyAsync(c->h_plan, c->d_alloc, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // ([5] = duplicated rows)
-        ORX_HIP(hipEventRecord(c->plan_ev, c->stream));
-        if (inline_apply) CHECK(orx_launch_plan_urgent(c, d, kc));
-        // work that does not depend on the counters goes to the device before the host blocks on them (the first fused launch
-        // of the chunk: the device would otherwise idle through the host's wake-up and the first launch's latency)
-        if (while_waiting && *while_waiting) CHECK((*while_waiting)());
-        ORX_HIP(hipEventSynchronize(c->plan_ev));
-        dc_v2.resize((size_t)kc);
-        int big = 0;
-        for (int64_t i = 0; i < kc; ++i) { dc_v2[i] = c->h_plan[8 * i + 5]; big = std::max(big, c->h_plan[8 * i + 6]); }
-        c->plan_big = big > 16384;          // ([6] = the step's largest bucket, if above 8 k references)
-        dc = dc_v2.data(); al = c->h_plan;
-    } else {
-        CHECK(orx_launch_dedup(c, d, kc));
-        if (inline_apply) {
-            dc_v1.resize((size_t)kc);
-            ORX_HIP(hipMemcpyAsync(dc_v1.data(), c->d_dcount, dc_v1.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            ORX_HIP(hipStreamSynchronize(c->stream));
-            dc = dc_v1.data();
-        }
-        if (staging) {
-            al_v1.resize((size_t)kc * 8);
-            ORX_HIP(hipMemcpyAsync(al_v1.data(), c->d_alloc, al_v1.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            ORX_HIP(hipStreamSynchronize(c->stream));
-            al = al_v1.data();
-        }
-    }
+}
+
+// host-side decisions from the per-step counters of steps i0 .. i0 + kc - 1: dc = duplicated rows per step, al = allocators [8] per step
+static void plan_decide(int64_t kc, int64_t B, bool inline_apply, bool staging, const int* dc, const int* al, ExactChunk* out) {
     if (inline_apply) {
         // The in-launch apply hides the duplicate apply behind the next step while few references have
         // to wait for it (the headline: ~0.16 B duplicated rows per step, 34 vs 39 us).  With many
@@ -699,7 +672,71 @@ int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
         // without the segment bookkeeping are launched
         out->use_stage = max_staged > 0;
     }
-    if (!v2 && inline_apply && !out->hot && !out->dense_dups) CHECK(orx_launch_urgent(c, d, kc));
+}
+
+int orx_exact_plan_issue(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,
+                         int64_t nU, int64_t nP, int64_t nN, int64_t kc, int64_t B, bool inline_apply, bool staging,
+                         const PairPlan& plan, int64_t i0, hipEvent_t counters, const std::function<int()>* after_readback) {
+    DedupArgs d;
+    plan_dedup_args(c, U, V, uid, pid, nid, ds, nU, nP, nN, B, true, inline_apply, staging, plan, i0, &d);
+    // bucketed plan; ONE read-back of the per-step counters into pinned memory, and the urgent marks are made while
+    // the host waits for it (the fused kernel ignores them in a launch without apply blocks)
+    d.roles = nullptr; d.dupbits = nullptr;
+    CHECK(orx_launch_plan(c, d, kc, inline_apply, i0));
+    ORX_HIP(hipMemcpyAsync(c->h_plan + 8 * i0, c->d_alloc + 8 * i0, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // ([5] = duplicated rows)
+    ORX_HIP(hipEventRecord(counters, c->stream));
+    // step 0 of a chunk carries no apply blocks and needs no urgent marks: it may go out before them
+    if (after_readback && *after_readback) CHECK((*after_readback)());
+    if (inline_apply) CHECK(orx_launch_plan_urgent(c, d, kc, i0));
+    return ORX_OK;
+}
+
+int orx_exact_plan_finish(orx_ctx* c, int64_t kc, int64_t B, bool inline_apply, bool staging, int64_t i0, hipEvent_t counters, ExactChunk* out) {
+    *out = ExactChunk();
+    ORX_HIP(hipEventSynchronize(counters));
+    std::vector<int> dcv((size_t)kc);
+    int big = 0;
+    const int* hp = c->h_plan + 8 * i0;
+    for (int64_t i = 0; i < kc; ++i) { dcv[i] = hp[8 * i + 5]; big = std::max(big, hp[8 * i + 6]); }
+    c->plan_big = big > 16384;          // ([6] = the step's largest bucket, if above 8 k references)
+    plan_decide(kc, B, inline_apply, staging, dcv.data(), hp, out);
+    return ORX_OK;
+}
+
+// The plan of a chunk of kc steps of an exact step (pairwise: three id lists per step; pointwise: two, nN = 0):
+// duplicate detection, roles, staging plan, and the host-side decisions read back from it.
+int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,
+                 int64_t nU, int64_t nP, int64_t nN, int64_t kc, int64_t B, bool role_bits, bool inline_apply, bool staging,
+                 const PairPlan& plan, ExactChunk* out, const std::function<int()>* while_waiting) {
+    *out = ExactChunk();
+    if (orx_plan_v2(role_bits)) {
+        // work that does not depend on the counters goes to the device before the host blocks on them (the first fused launch
+        // of the chunk: the device would otherwise idle through the host's wake-up and the first launch's latency)
+        CHECK(orx_exact_plan_issue(c, U, V, uid, pid, nid, ds, nU, nP, nN, kc, B, inline_apply, staging, plan, 0, c->plan_ev, while_waiting));
+        return orx_exact_plan_finish(c, kc, B, inline_apply, staging, 0, c->plan_ev, out);
+    }
+    // duplicate detection for every step of the chunk, on the id arrays alone
+    DedupArgs d;
+    plan_dedup_args(c, U, V, uid, pid, nid, ds, nU, nP, nN, B, role_bits, inline_apply, staging, plan, 0, &d);
+    ORX_HIP(hipMemsetAsync(c->d_dcount, 0, (size_t)kc * sizeof(int), c->stream));     // (the bucketed plan zeroes its counters itself)
+    if (staging) {
+        ORX_HIP(hipMemsetAsync(c->d_tricnt, 0, (size_t)kc * B * sizeof(int), c->stream));
+        ORX_HIP(hipMemsetAsync(c->d_alloc, 0, (size_t)kc * 8 * sizeof(int), c->stream));
+    }
+    std::vector<int> dc_v1, al_v1;
+    CHECK(orx_launch_dedup(c, d, kc));
+    if (inline_apply) {
+        dc_v1.resize((size_t)kc);
+        ORX_HIP(hipMemcpyAsync(dc_v1.data(), c->d_dcount, dc_v1.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        ORX_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (staging) {
+        al_v1.resize((size_t)kc * 8);
+        ORX_HIP(hipMemcpyAsync(al_v1.data(), c->d_alloc, al_v1.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        ORX_HIP(hipStreamSynchronize(c->stream));
+    }
+    plan_decide(kc, B, inline_apply, staging, dc_v1.data(), al_v1.data(), out);
+    if (inline_apply && !out->hot && !out->dense_dups) CHECK(orx_launch_urgent(c, d, kc));
     return ORX_OK;
 }
 
@@ -831,8 +868,6 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
 
     for (int64_t s0 = 0; s0 < K; s0 += chunk) {
         const int64_t kc = (K - s0 < chunk) ? (K - s0) : chunk;
-        bool hot = false, use_stage = false, dense_dups = false;
-        int tree_levels = 0;
         // arguments of step i of the chunk, and its fused launch
         auto launch_step = [&](int64_t i, bool stage_views, bool with_apply) -> int {
             const int64_t s = s0 + i;
@@ -856,18 +891,55 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             return orx_launch_fused(c, model, opt->kind, mode, a);
         };
         bool first_launched = false;
+        // ---- the plan of the chunk, optionally in PIECES (bucketed plan, in-launch apply): piece 0 (6 steps) is planned on the step
+        // stream, every later piece (4x the previous one) on a second stream while the steps of the piece before it run -- the fused
+        // launches of a K-step call then start ~45 us after the call instead of after the plan of all K steps (110 us at K = 20,
+        // 620 us at K = 200).  The pieces share the chunk's plan arrays, so the in-launch apply runs across their boundaries.
+        std::vector<int64_t> pc_lo, pc_hi;                   // piece j = steps [pc_lo[j], pc_hi[j]) of the chunk
+        std::vector<ExactChunk> pck;
+        const bool v2 = mode == MODE_EXACT && orx_plan_v2(role_bits);
+        // MEASURED AND LEFT OFF (profiles/r3_plan_pipeline.txt; ORX_PLAN_PIPE=1 turns it on): what runs beside the fused kernels takes
+        // from them what it gets.  K = 20: 41.5 / 40.5 us per step with the pipeline against 39.2 without (fused launch 32.5 against
+        // 30.8 us); K = 40: 37.9 / 36.9; K = 64: 37.2 / 36.3; K = 200: 34.3 / 33.7 -- the same verdict as round 2's chunk-level overlap.
+        const bool pipe = v2 && inline_apply && !censor && kc > 8 && getenv("ORX_PLAN_PIPE") != nullptr;
         if (mode == MODE_EXACT) {
-            ExactChunk ck;
+            if (pipe) {
+                for (int64_t lo = 0, sz = 6; lo < kc; lo += sz, sz *= 4) {
+                    int64_t hi = std::min<int64_t>(kc, lo + sz);
+                    if (kc - hi < 3) hi = kc;                // (no 1-2 step tail piece)
+                    pc_lo.push_back(lo); pc_hi.push_back(hi);
+                    if (hi == kc) break;
+                }
+            } else {
+                pc_lo.push_back(0); pc_hi.push_back(kc);
+            }
+            pck.resize(pc_lo.size());
             // With the bucketed plan the chunk's FIRST fused launch goes out before the host waits for the plan's counters:
             // step 0 never carries apply blocks, and the kernel built with the staging bookkeeping is right whether or not
             // any range made a staging plan (references without one carry (-1, 0) and use atomics).
             const std::function<int()> early = [&]() -> int { first_launched = true; return launch_step(0, staging, false); };
-            const bool can_early = orx_plan_v2(role_bits) && !censor && getenv("ORX_PLAN_NO_EARLY") == nullptr;
-            CHECK(orx_exact_plan_chunk(c, U, V, du + s0 * ds, dp + s0 * ds, dn + s0 * ds, ds, B, B, B, kc, B, role_bits, inline_apply, staging,
-                                       plan, &ck, can_early ? &early : nullptr));
-            hot = ck.hot; use_stage = ck.use_stage; dense_dups = ck.dense_dups; tree_levels = ck.tree_levels;
+            const bool can_early = v2 && !censor && getenv("ORX_PLAN_NO_EARLY") == nullptr;
+            if (pipe) {
+                CHECK(orx_exact_plan_issue(c, U, V, du + s0 * ds, dp + s0 * ds, dn + s0 * ds, ds, B, B, B, pc_hi[0], B, inline_apply, staging, plan, 0,
+                                           c->plan_ev, can_early ? &early : nullptr));
+                CHECK(orx_exact_plan_finish(c, pc_hi[0], B, inline_apply, staging, 0, c->plan_ev, &pck[0]));
+            } else {
+                CHECK(orx_exact_plan_chunk(c, U, V, du + s0 * ds, dp + s0 * ds, dn + s0 * ds, ds, B, B, B, kc, B, role_bits, inline_apply, staging,
+                                           plan, &pck[0], can_early ? &early : nullptr));
+            }
         }
-        const bool inl = inline_apply && !hot && !dense_dups;
+        // enqueue the plan of piece j (>= 1) on the plan stream; it starts once the device has passed `after`
+        auto issue_piece = [&](size_t j, hipEvent_t after) -> int {
+            hipStream_t main_stream = c->stream;
+            ORX_HIP(hipStreamWaitEvent(c->plan_stream, after, 0));
+            c->stream = c->plan_stream;
+            const int64_t lo = pc_lo[j], n = pc_hi[j] - lo;
+            const int rc = orx_exact_plan_issue(c, U, V, du + (s0 + lo) * ds, dp + (s0 + lo) * ds, dn + (s0 + lo) * ds, ds, B, B, B, n, B,
+                                                inline_apply, staging, plan, lo, c->pipe_cnt[j & 1], nullptr);
+            if (rc == ORX_OK) { const hipError_t e = hipEventRecord(c->pipe_done[j & 1], c->plan_stream); if (e != hipSuccess) { c->stream = main_stream; ORX_HIP(e); } }
+            c->stream = main_stream;
+            return rc;
+        };
         if (censor) {
             // one elected reference per distinct row of each of the three id lists, for every step of the chunk
             ENSURE(c->d_cflag, c->d_cflag_cap, (size_t)3 * kc * B);
@@ -882,25 +954,48 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
                 CHECK(orx_launch_dedup(c, d, kc));
             }
         }
-        for (int64_t i = 0; i < kc; ++i) {
-            const int64_t s = s0 + i;
-            if (!(i == 0 && first_launched)) CHECK(launch_step(i, use_stage, inl));
-            for (int l = 0; l < tree_levels; ++l) CHECK(orx_launch_hot_reduce(c, a, l));
-            if (mode == MODE_EXACT && (!inl || i == kc - 1)) CHECK(orx_launch_dup_apply(c, opt->kind, a));
-            if (mode == MODE_ACCUM) {   // Adam: dense-decay sweep of TF 2.0 over the whole tables
-                opt->t += 1;
-                const double b1 = opt->p0, b2 = opt->p1;
-                const float lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, (double)opt->t)) / (1.0 - std::pow(b1, (double)opt->t)));
-                CHECK(orx_launch_adam_sweep(c, U->w, sU.s0, sU.s1, U->gsum, U->rows * U->dim, lr_t, opt->p0, opt->p1, opt->p2));
-                CHECK(orx_launch_adam_sweep(c, V->w, sV.s0, sV.s1, V->gsum, V->rows * V->dim, lr_t, opt->p0, opt->p1, opt->p2));
-                CHECK(orx_launch_adam_sweep(c, b->w, sb.s0, sb.s1, b->gsum, b->rows, lr_t, opt->p0, opt->p1, opt->p2));
-            }
-            if (censor) {                   // ucml.py:44-48: users and pos items (two tables), then neg items
-                const unsigned char* fu = c->d_cflag + (size_t)i * B;
-                const unsigned char* fp = c->d_cflag + (size_t)(kc + i) * B;
-                const unsigned char* fn = c->d_cflag + (size_t)(2 * kc + i) * B;
-                CHECK(orx_launch_censor2(c, U->w, fu, U->rows, du + s * ds, B, V->w, fp, V->rows, dp + s * ds, B, U->dim, 0.1f));
-                CHECK(orx_launch_censor2(c, V->w, fn, V->rows, dn + s * ds, B, nullptr, nullptr, 0, nullptr, 0, U->dim, 0.1f));
+        // per piece: may the duplicated rows of its steps be applied by the NEXT step's launch?
+        auto piece_inl = [&](size_t j) { return inline_apply && !pck[j].hot && !pck[j].dense_dups; };
+        const size_t npc = mode == MODE_EXACT ? pc_lo.size() : 1;
+        for (size_t j = 0; j < npc; ++j) {
+            const int64_t lo = mode == MODE_EXACT ? pc_lo[j] : 0, hi = mode == MODE_EXACT ? pc_hi[j] : kc;
+            // (piece 1 may start behind piece 0's counters: plan_ev sits behind its plan kernels, ahead of step 0 and the urgent marks)
+            if (j + 1 < npc) CHECK(issue_piece(j + 1, j == 0 ? c->plan_ev : c->pipe_done[j & 1]));
+            if (j > 0) ORX_HIP(hipStreamWaitEvent(c->stream, c->pipe_done[j & 1], 0));      // the step stream takes up this piece's steps behind its plan
+            const bool inl_j = mode == MODE_EXACT && piece_inl(j);
+            const int tree_levels = mode == MODE_EXACT ? pck[j].tree_levels : 0;
+            for (int64_t i = lo; i < hi; ++i) {
+                const int64_t s = s0 + i;
+                bool inl_next = inl_j;                         // is step i + 1 launched with apply blocks for step i's rows?
+                if (i == hi - 1 && j + 1 < npc) {
+                    // the last step of a piece: the next piece's counters decide (its plan has had the whole piece to finish)
+                    CHECK(orx_exact_plan_finish(c, pc_hi[j + 1] - pc_lo[j + 1], B, inline_apply, staging, pc_lo[j + 1], c->pipe_cnt[(j + 1) & 1], &pck[j + 1]));
+                    inl_next = inl_j && piece_inl(j + 1);
+                }
+                const bool defer = mode == MODE_EXACT && inl_next && i < kc - 1;      // step i's duplicated rows wait for launch i + 1
+                if (!(i == 0 && first_launched)) {
+                    const bool prev_deferred = i > 0 && (i > lo ? inl_j : (j > 0 && piece_inl(j - 1) && inl_j));
+                    // (a step reads the staging segments of the step before it: the views cover both pieces' plans)
+                    const bool sv = mode == MODE_EXACT && (pck[j].use_stage || (i == lo && j > 0 && pck[j - 1].use_stage));
+                    CHECK(launch_step(i, sv, prev_deferred));
+                }
+                for (int l = 0; l < tree_levels; ++l) CHECK(orx_launch_hot_reduce(c, a, l));
+                if (mode == MODE_EXACT && !defer) CHECK(orx_launch_dup_apply(c, opt->kind, a));
+                if (mode == MODE_ACCUM) {   // Adam: dense-decay sweep of TF 2.0 over the whole tables
+                    opt->t += 1;
+                    const double b1 = opt->p0, b2 = opt->p1;
+                    const float lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, (double)opt->t)) / (1.0 - std::pow(b1, (double)opt->t)));
+                    CHECK(orx_launch_adam_sweep(c, U->w, sU.s0, sU.s1, U->gsum, U->rows * U->dim, lr_t, opt->p0, opt->p1, opt->p2));
+                    CHECK(orx_launch_adam_sweep(c, V->w, sV.s0, sV.s1, V->gsum, V->rows * V->dim, lr_t, opt->p0, opt->p1, opt->p2));
+                    CHECK(orx_launch_adam_sweep(c, b->w, sb.s0, sb.s1, b->gsum, b->rows, lr_t, opt->p0, opt->p1, opt->p2));
+                }
+                if (censor) {                   // ucml.py:44-48: users and pos items (two tables), then neg items
+                    const unsigned char* fu = c->d_cflag + (size_t)i * B;
+                    const unsigned char* fp = c->d_cflag + (size_t)(kc + i) * B;
+                    const unsigned char* fn = c->d_cflag + (size_t)(2 * kc + i) * B;
+                    CHECK(orx_launch_censor2(c, U->w, fu, U->rows, du + s * ds, B, V->w, fp, V->rows, dp + s * ds, B, U->dim, 0.1f));
+                    CHECK(orx_launch_censor2(c, V->w, fn, V->rows, dn + s * ds, B, nullptr, nullptr, 0, nullptr, 0, U->dim, 0.1f));
+                }
             }
         }
         ReduceArgs r;

@@ -428,10 +428,16 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(ReduceArgs a) {
     __shared__ double sh[2][16];
     const float* part = a.partial + (size_t)blockIdx.x * a.nwaves * 2;
     double s0 = 0.0, s1 = 0.0;
-    for (int i = threadIdx.x; i < a.nwaves; i += blockDim.x) {
-        const float2 v = *reinterpret_cast<const float2*>(part + 2 * i);
-        s0 += (double)v.x;
-        s1 += (double)v.y;
+    constexpr int UN = 8;                                    // 8 independent loads in flight per thread (the pass is latency-bound)
+    for (int i0 = threadIdx.x; i0 < a.nwaves; i0 += UN * blockDim.x) {
+        float2 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + u * blockDim.x;
+            v[u] = i < a.nwaves ? *reinterpret_cast<const float2*>(part + 2 * i) : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; }
     }
     for (int off = 32; off > 0; off >>= 1) {
         s0 += __shfl_xor(s0, off);

@@ -42,6 +42,7 @@ struct PlanArgs {
     int64_t nref;
     unsigned int* dupbits;     // [K][nb][words] "seen twice" bitmaps for plan_urgent_kernel, or NULL
     int min_late;              // staging plan in ranges with at least this many third-or-later references (< 0: max(64, n / 512))
+    int s_first;               // plan_urgent_kernel: first step to mark (1, or 0 when the plan's step 0 has a predecessor in the same arrays)
 };
 
 // reference j of the step (users, then pos items, then neg items): id, table, position in ids_out / refinfo
@@ -351,13 +352,13 @@ __global__ __launch_bounds__(T) void plan_urgent_kernel(PlanArgs a) {
     const int W = (1 << a.shift) >> 5;
     const int nb = a.nru + a.nri;
     const int b = blockIdx.x;
-    const int64_t s = 1 + blockIdx.y;
+    const int64_t s = a.s_first + blockIdx.y;
     const int* cnt = a.bcnt + s * (3 * nb + 1) + 2 * nb;
     const int lo = cnt[b], n = cnt[b + 1] - lo;
     if (n == 0) return;
     const int prev_n = cnt[b + 1 - (3 * nb + 1)] - cnt[b - (3 * nb + 1)];
     if (prev_n < 2) return;                             // no duplicated row without two references
-    const unsigned int* prev = a.dupbits + ((size_t)(s - 1) * nb + b) * W;
+    const unsigned int* prev = a.dupbits + ((s - 1) * nb + b) * (int64_t)W;
     for (int w = threadIdx.x; w < W; w += T) pl_lds[w] = prev[w];
     __syncthreads();
     const int lg = b < a.nru ? a.lgu : a.lgi;
@@ -421,7 +422,9 @@ int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t B, int64_t NU, int64_t N
 }
 
 // The plan of kc steps.  `d` is filled as for orx_launch_dedup (dupbits non-NULL: the bitmaps for orx_plan_urgent are kept).
-int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupbits) {
+// step0: the steps are number step0 .. step0 + kc - 1 of the chunk whose plan arrays the context holds (`d` already points at
+// step step0 of every per-step array): a chunk is planned in pieces, each while the previous piece's steps run.
+int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupbits, int64_t step0) {
     ProfScope ps(ctx, ORX_K_DEDUP);
     PlanArgs a;
     a.d = d;
@@ -429,9 +432,11 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
     const int nb = a.nru + a.nri;
     if (nb == 0 || a.nref == 0 || kc == 0) return ORX_OK;
     ORX_ARG(a.nref < (1LL << 30) && kc < 65536, "plan: too many references per step (%lld) or steps (%lld)", (long long)a.nref, (long long)kc);
-    { const int rc = plan_ensure(ctx, kc, a, keep_dupbits); if (rc != ORX_OK) return rc; }     // (a no-op after a reserve)
-    a.bcnt = ctx->d_pl_cnt; a.list = ctx->d_pl_list;
-    a.dupbits = keep_dupbits ? ctx->d_dupbits : nullptr;
+    { const int rc = plan_ensure(ctx, step0 + kc, a, keep_dupbits); if (rc != ORX_OK) return rc; }     // (a no-op after a reserve)
+    const size_t words = (size_t)nb * ((1u << a.shift) >> 5);
+    a.bcnt = ctx->d_pl_cnt + step0 * (3 * nb + 1); a.list = ctx->d_pl_list + step0 * a.nref;
+    a.dupbits = keep_dupbits ? ctx->d_dupbits + step0 * words : nullptr;
+    a.s_first = 1;
     const char* ml = getenv("ORX_PLAN_MIN_LATE");      // experiments
     a.min_late = ml ? atoi(ml) : d.min_late;
     ORX_HIP(hipMemsetAsync(a.bcnt, 0, (size_t)kc * (3 * nb + 1) * sizeof(int), ctx->stream));
@@ -457,16 +462,20 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
     return ORX_OK;
 }
 
-int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc) {
+int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc, int64_t step0) {
     ProfScope ps(ctx, ORX_K_DEDUP);
-    if (kc < 2) return ORX_OK;
+    const int first = step0 > 0 ? 0 : 1;                // (step 0 of a chunk has no predecessor)
+    if (kc - first < 1) return ORX_OK;
     PlanArgs a;
     a.d = d;
     plan_geometry(d, &a);
-    a.bcnt = ctx->d_pl_cnt; a.list = ctx->d_pl_list; a.dupbits = ctx->d_dupbits; a.min_late = -1;
+    const int nb = a.nru + a.nri;
+    const size_t words = (size_t)nb * ((1u << a.shift) >> 5);
+    a.bcnt = ctx->d_pl_cnt + step0 * (3 * nb + 1); a.list = ctx->d_pl_list + step0 * a.nref; a.dupbits = ctx->d_dupbits + step0 * words; a.min_late = -1;
+    a.s_first = first;
     const int W = (1 << a.shift) >> 5;
-    if (ctx->plan_big) ORX_LAUNCH(ctx, plan_urgent_kernel<1024>, dim3((unsigned)(a.nru + a.nri), (unsigned)(kc - 1)), dim3(1024), (size_t)W * 4, a);
-    else ORX_LAUNCH(ctx, plan_urgent_kernel<256>, dim3((unsigned)(a.nru + a.nri), (unsigned)(kc - 1)), dim3(256), (size_t)W * 4, a);
+    if (ctx->plan_big) ORX_LAUNCH(ctx, plan_urgent_kernel<1024>, dim3((unsigned)(a.nru + a.nri), (unsigned)(kc - first)), dim3(1024), (size_t)W * 4, a);
+    else ORX_LAUNCH(ctx, plan_urgent_kernel<256>, dim3((unsigned)(a.nru + a.nri), (unsigned)(kc - first)), dim3(256), (size_t)W * 4, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

@@ -62,6 +62,10 @@ struct orx_ctx {
     int* h_plan = nullptr;                                       // pinned host mirror of the per-step plan counters
     size_t h_plan_cap = 0;
     hipEvent_t plan_ev = nullptr;                                // "plan counters have arrived on the host"
+    // plan pipeline (api.hip): the pieces of a chunk after the first are planned on a second stream while the previous piece's
+    // steps run; per piece parity: counters on the host / plan complete on the device
+    hipStream_t plan_stream = nullptr;
+    hipEvent_t pipe_cnt[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr};
     hipEvent_t wait_ev = nullptr;                                // orx_ctx_wait_stream
     int epoch = 0;                                               // step epoch: tags ready flags and censor side marks
     int epoch_gen = 0;                                           // bumped when `epoch` wraps (tables then clear their tags)
@@ -336,6 +340,12 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
 int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,
                          int64_t nU, int64_t nP, int64_t nN, int64_t kc, int64_t B, bool role_bits, bool inline_apply, bool staging,
                          const PairPlan& plan, ExactChunk* out, const std::function<int()>* while_waiting = nullptr);
+// the same in two halves, for steps i0 .. i0 + kc - 1 of the chunk's plan arrays (bucketed plan only): issue enqueues the plan on the
+// context's CURRENT stream and records `counters` after the read-back of the per-step counters; finish waits for it on the host
+int orx_exact_plan_issue(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,
+                         int64_t nU, int64_t nP, int64_t nN, int64_t kc, int64_t B, bool inline_apply, bool staging,
+                         const PairPlan& plan, int64_t i0, hipEvent_t counters, const std::function<int()>* after_readback = nullptr);
+int orx_exact_plan_finish(orx_ctx* c, int64_t kc, int64_t B, bool inline_apply, bool staging, int64_t i0, hipEvent_t counters, ExactChunk* out);
 void orx_exact_step_views(orx_ctx* c, const PairPlan& plan, int64_t i, int64_t B, int D, bool use_stage, PairArgs* a);
 int orx_launch_rows_planned(orx_ctx* ctx, int optkind, const RowsArgs& a);
 // K id lists of n local rows each (ids [K][n], < 0 = padding) against ONE table: plan once (duplicate roles, staging
@@ -349,8 +359,8 @@ int orx_launch_urgent(orx_ctx* ctx, const DedupArgs& a, int64_t K);
 // bucketed plan (kernels_plan.hip): same outputs as orx_launch_dedup (+ orx_launch_urgent) with `d` filled the same way
 bool orx_plan_v2(bool role_bits);
 int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t B, int64_t NU, int64_t NI, bool want_dupbits);
-int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupbits);
-int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc);
+int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupbits, int64_t step0 = 0);
+int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc, int64_t step0 = 0);
 int orx_fused_can_inline_apply(int D);
 int orx_dedup_words(void);
 int orx_launch_loss_reduce(orx_ctx* ctx, const ReduceArgs& a, int64_t K);
