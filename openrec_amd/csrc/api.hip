@@ -230,6 +230,7 @@ int orx_table_side(orx_table* t) {
 extern "C" int orx_table_init_uniform(orx_table* t, float lo, float hi, uint64_t seed) {
     if (t) CHECK(orx_table_sync(t));
     ORX_ARG(t, "orx_table_init_uniform: NULL table");
+    t->version += 1;
     ORX_HIP(hipSetDevice(t->ctx->device));
     return orx_launch_init_uniform(t->ctx, t->w, t->rows * t->dim, lo, hi, seed);
 }
@@ -237,6 +238,7 @@ extern "C" int orx_table_init_uniform(orx_table* t, float lo, float hi, uint64_t
 extern "C" int orx_table_fill(orx_table* t, float value) {
     if (t) CHECK(orx_table_sync(t));
     ORX_ARG(t, "orx_table_fill: NULL table");
+    t->version += 1;
     ORX_HIP(hipSetDevice(t->ctx->device));
     return orx_launch_fill(t->ctx, t->w, t->rows * t->dim, value);
 }
@@ -265,6 +267,7 @@ extern "C" int orx_table_read(orx_table* t, int64_t row0, int64_t nrows, float* 
 extern "C" int orx_table_write(orx_table* t, int64_t row0, int64_t nrows, const float* host_src) {
     if (t) CHECK(orx_table_sync(t));
     ORX_ARG(t, "orx_table_write: NULL table");
+    t->version += 1;
     return rows_copy(t->ctx, t->w, t->rows, t->dim, row0, nrows, (float*)host_src, false);
 }
 

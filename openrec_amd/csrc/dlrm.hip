@@ -28,6 +28,7 @@ struct DenseLayer {
     bool head = false;                  // the 1-unit last layer of the top MLP on the fused head kernels (kernels_gemm16.hip)
     float* slab = nullptr;              // split-K slices of this layer's weight gradient, [tiles][S][128 * 128]
     int slab_S = 1, slab_tiles = 0;
+    uint64_t shadow_version = ~0ull;    // W->version the fp16 copies were made from
     float* gbpart = nullptr;            // bias-gradient partial rows [row blocks][out] (ColPart), carved from orx_dlrm::colpart
     float* gwpart = nullptr;            // the head layer: weight-gradient partial rows [row blocks][in]
 };
@@ -71,6 +72,8 @@ struct orx_dlrm {
     int32_t* d_sparse_all = nullptr; int64_t sparse_all_cap = 0;
     DenseParam* d_params = nullptr;     // descriptors of the dense parameters for the multi-tensor optimizer launch
     orx_opt* params_opt = nullptr;
+    DenseFused* d_fused = nullptr;      // ... and for the fused launch of the fp16 mode (slab reduce + rule + fp16 copies)
+    orx_opt* fused_opt = nullptr; int fused_tiles = 0; DenseFusedTiles fused_tt;
     bool grads_pending = false;         // orx_dlrm_grads ran, orx_dlrm_dense_apply not yet
     double* d_loss = nullptr;           // [Kcap]
     int64_t loss_cap = 0;
@@ -201,6 +204,7 @@ static void free_buffers(orx_dlrm* m) {
     for (int k = 0; k < 2; ++k) { hipFree(m->d_slabjobs[k]); m->d_slabjobs[k] = nullptr; m->n_slabjobs[k] = 0; m->slab_max_tiles[k] = 0; }
     hipFree(m->dense16); m->dense16 = nullptr;
     hipFree(m->colpart); m->colpart = nullptr;
+    m->fused_opt = nullptr;              // (the fused optimizer's descriptors point at the split-K workspaces)
     for (void* p : m->bot_y16) hipFree(p);
     m->bot_y16.clear();
     for (void* p : m->top_y16) hipFree(p);
@@ -220,7 +224,7 @@ extern "C" int orx_dlrm_destroy(orx_dlrm* m) {
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     free_buffers(m);
-    hipFree(m->d_offset); hipFree(m->d_colwin); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params); hipFree(m->d_idx_all); hipFree(m->d_sparse_all); hipFree(m->d_tiny_f); hipFree(m->d_is_tiny);
+    hipFree(m->d_offset); hipFree(m->d_colwin); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params); hipFree(m->d_fused); hipFree(m->d_idx_all); hipFree(m->d_sparse_all); hipFree(m->d_tiny_f); hipFree(m->d_is_tiny);
     orx_table_destroy(m->emb);
     for (auto& d : m->bot) { orx_table_destroy(d.W); orx_table_destroy(d.b); hipFree(d.w16); hipFree(d.w16t); }
     for (auto& d : m->top) { orx_table_destroy(d.W); orx_table_destroy(d.b); hipFree(d.w16); hipFree(d.w16t); }
@@ -370,7 +374,14 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
         if (!m->direct_idx) CHECK(orx_launch_gather(c, m->emb->w, nullptr, m->emb->rows, d, idx, B * F, m->Z, d, c->d_err, 1));
     }
     const bool f16 = (m->flags & ORX_DLRM_FP16_MLP) != 0;
-    if (f16) CHECK(orx_launch_dense_shadow(c, m->d_shadow, m->n_shadow, m->shadow_max));   // W changed since the last step
+    if (f16) {       // fp16 copies of the dense kernels: written by the fused optimizer launch; refreshed here when something else wrote a kernel
+        bool stale = false;
+        for (int k = 0; k < 2; ++k) for (auto& D : (k == 0 ? m->bot : m->top)) if (D.w16 != nullptr && D.shadow_version != D.W->version) stale = true;
+        if (stale) {
+            CHECK(orx_launch_dense_shadow(c, m->d_shadow, m->n_shadow, m->shadow_max));
+            for (int k = 0; k < 2; ++k) for (auto& D : (k == 0 ? m->bot : m->top)) D.shadow_version = D.W->version;
+        }
+    }
     // dlrm.py:87: bottom MLP; its last layer writes straight into slot F-1 of Z
     const float* x = bt.dense; int64_t ldx = m->dense_dim;
     const bool bot16 = m->gen2 && m->dense16 != nullptr;
@@ -428,9 +439,45 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
     return ORX_OK;
 }
 
-// SGD / Adagrad / Adam (lr_t of the step) on every dense parameter in one launch (gradients in the tables' gsum)
-static int dense_apply_all(orx_dlrm* m, orx_opt* opt, float lr_t = 0.f) {
+// SGD / Adagrad / Adam (lr_t of the step) on every dense parameter in one launch (gradients in the tables' gsum).
+// fused (fp16 mode, orx_dlrm_step): the launch also adds the split-K slices of the weight gradients that mlp_backward left in
+// the slab workspaces (no slab_reduce launches) and writes the fp16 copies of the new kernels (no dense_shadow launch).
+static int dense_apply_all(orx_dlrm* m, orx_opt* opt, float lr_t = 0.f, bool fused = false, float slab_scale = 1.0f) {
     orx_ctx* c = m->ctx;
+    if (fused) {
+        if (m->fused_opt != opt) {
+            std::vector<DenseFused> h;
+            int tiles = 0;
+            auto add = [&](orx_table* t, DenseLayer* D) -> int {
+                OptSlots s;
+                CHECK(orx_opt_slots(opt, t, &s));
+                CHECK(orx_table_scratch(t));
+                DenseFused p;
+                memset(&p, 0, sizeof(p));
+                p.w = t->w; p.acc = s.s0; p.acc2 = s.s1; p.g = t->gsum; p.rows = (int)t->rows; p.cols = t->dim;
+                if (D != nullptr) {
+                    if (D->dw16 && D->slab_S > 1) { p.slab = D->slab; p.S = D->slab_S; p.ntn = (D->out + 127) / 128; }
+                    p.w16 = D->w16; p.w16t = D->w16t; p.ld16 = D->ld16; p.ld16t = D->ld16t;
+                }
+                p.tile0 = tiles; p.tiles_x = (p.cols + 63) / 64;
+                tiles += p.tiles_x * ((p.rows + 15) / 16);        // (16 x 64 tiles: kernels_dense.hip DF_ROWS)
+                h.push_back(p);
+                return ORX_OK;
+            };
+            for (int k = 0; k < 2; ++k) for (auto& D : (k == 0 ? m->bot : m->top)) { CHECK(add(D.W, &D)); CHECK(add(D.b, nullptr)); }
+            if (!m->d_fused) ORX_HIP(hipMalloc((void**)&m->d_fused, h.size() * sizeof(DenseFused)));
+            ORX_HIP(hipMemcpyAsync(m->d_fused, h.data(), h.size() * sizeof(DenseFused), hipMemcpyHostToDevice, c->stream));
+            ORX_HIP(hipStreamSynchronize(c->stream));
+            ORX_ARG(h.size() <= 48, "dlrm: more than 24 dense layers");
+            m->fused_tt.count = (int)h.size();
+            for (size_t i = 0; i < h.size(); ++i) m->fused_tt.tile0[i] = h[i].tile0;
+            m->fused_opt = opt; m->fused_tiles = tiles;
+        }
+        if (opt->kind == ORX_ADAM) CHECK(orx_launch_dense_apply_fused(c, m->d_fused, m->fused_tt, m->fused_tiles, ORX_ADAM, lr_t, opt->p2, opt->p0, opt->p1, slab_scale));
+        else CHECK(orx_launch_dense_apply_fused(c, m->d_fused, m->fused_tt, m->fused_tiles, opt->kind, opt->lr, opt->p1, 0.f, 0.f, slab_scale));
+        for (int k = 0; k < 2; ++k) for (auto& D : (k == 0 ? m->bot : m->top)) { D.W->version += 1; D.b->version += 1; D.shadow_version = D.W->version; }
+        return ORX_OK;
+    }
     std::vector<DenseParam> h;
     int64_t max_n = 0;
     auto add = [&](orx_table* t) -> int {
@@ -439,6 +486,7 @@ static int dense_apply_all(orx_dlrm* m, orx_opt* opt, float lr_t = 0.f) {
         CHECK(orx_table_scratch(t));
         DenseParam p; p.w = t->w; p.acc = s.s0; p.acc2 = s.s1; p.g = t->gsum; p.n = t->rows * t->dim;
         h.push_back(p); max_n = std::max(max_n, p.n);
+        t->version += 1;
         return ORX_OK;
     };
     for (auto& D : m->bot) { CHECK(add(D.W)); CHECK(add(D.b)); }
@@ -457,7 +505,7 @@ static int dense_apply_all(orx_dlrm* m, orx_opt* opt, float lr_t = 0.f) {
 // ins16 / outs16 (top MLP in fp16 mode, else NULL): the fp16 copies of every layer's input and output.
 static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vector<const float*>& ins, const std::vector<int64_t>& ld_in,
                         const std::vector<const float*>& outs, const std::vector<int64_t>& ld_out,
-                        float* dy, float* other, int64_t B, bool need_dx0, float** dx_out, float gscale,
+                        float* dy, float* other, int64_t B, bool need_dx0, float** dx_out, float gscale, bool defer_slabs,
                         const std::vector<const void*>* ins16 = nullptr, const std::vector<int64_t>* ld_in16 = nullptr,
                         const std::vector<const void*>* outs16 = nullptr) {
     orx_ctx* c = m->ctx;
@@ -502,6 +550,8 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
         // gW [in, out] = X^T * dZ
         if (D.dw16) {
             ORX_ARG(dy16 != nullptr && ins16 && (*ins16)[l], "dlrm backward: fp16 operands missing for layer %d", l);
+            // (tried: these products on a second stream beside the input-gradient chain -- they only feed the optimizer.  The step
+            // went from 0.6125 to 0.628 ms: side by side the products slow each other down by more than the overlap gains.)
             CHECK(orx_launch_gemm16_tn(c, (*ins16)[l], (*ld_in16)[l], dy16, D.out, D.W->gsum, D.out, D.slab, D.in, D.out, (int)B, inv_scale));
             if (D.slab_S > 1) ++slabs;
         } else {
@@ -553,7 +603,8 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
     CHECK(orx_launch_colparts_reduce(c, coljobs.data(), (int)coljobs.size()));
     if (slabs > 0) {
         ORX_ARG(slabs == m->n_slabjobs[which], "dlrm backward: %d of %d split-K weight gradients were produced", slabs, m->n_slabjobs[which]);
-        CHECK(orx_launch_slab_reduce(c, m->d_slabjobs[which], m->n_slabjobs[which], m->slab_max_tiles[which], inv_scale));
+        // (deferred: the fused optimizer launch adds the slices itself -- orx_dlrm_step in fp16 mode)
+        if (!defer_slabs) CHECK(orx_launch_slab_reduce(c, m->d_slabjobs[which], m->n_slabjobs[which], m->slab_max_tiles[which], inv_scale));
     }
     *dx_out = dy;
     return ORX_OK;
@@ -561,7 +612,7 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
 
 // backward of the batch whose activations `forward` left behind; m->gA holds dLoss/dPred.
 // Leaves dZ [B, F, d] (slot F-1 = d dense_emb) and every dense gradient in its table's gsum.
-static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale) {
+static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale, bool defer_slabs = false) {
     orx_ctx* c = m->ctx;
     const int F = m->F, d = m->m_spa;
     const int compat = (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0, itself = (m->flags & ORX_DLRM_INTERACT_ITSELF) ? 1 : 0;
@@ -579,7 +630,7 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale) {
             ins16.push_back(l == 0 ? m->R16 : m->top_y16[l - 1]); ldi16.push_back(l == 0 ? m->ldR16 : up8(m->top[l - 1].out));
             outs16.push_back(l + 1 < m->top.size() ? m->top_y16[l] : nullptr);
         }
-    CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR, gscale, m->gen2 ? &ins16 : nullptr, &ldi16, &outs16));
+    CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR, gscale, defer_slabs, m->gen2 ? &ins16 : nullptr, &ldi16, &outs16));
     // ---- interaction backward: dZ for every slot (slot F-1 = d dense_emb)
     // (dR carries the loss scale; dZ -- the embedding rows' gradients -- leaves unscaled)
     CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B, m->ldR, nullptr, 0, nullptr,
@@ -602,7 +653,7 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale) {
             ins16.push_back(l == 0 ? m->dense16 : m->bot_y16[l - 1]); ldi16.push_back(l == 0 ? m->ld_dense16 : up8(m->bot[l - 1].out));
             outs16.push_back(l + 1 < m->bot.size() ? m->bot_y16[l] : nullptr);
         }
-    CHECK(mlp_backward(m, m->bot, ins, ldi, outs, ldo, dy, other, B, false, &dx0, gscale, bot16 ? &ins16 : nullptr, &ldi16, &outs16));
+    CHECK(mlp_backward(m, m->bot, ins, ldi, outs, ldo, dy, other, B, false, &dx0, gscale, defer_slabs, bot16 ? &ins16 : nullptr, &ldi16, &outs16));
     }
     return ORX_OK;
 }
@@ -697,7 +748,8 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         // loss + dLoss/dP  (dlrm.py:72-73, :97-98)
         const float gscale = loss_scale(m, B);
         CHECK(orx_launch_dlrm_loss(c, pred, bt.label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, m->d_loss + s, 0, 0, gscale));
-        CHECK(backward(m, bt, B, gscale));
+        const bool fuse_dense = m->gen2 && getenv("ORX_DLRM_NO_FUSED_DENSE") == nullptr;
+        CHECK(backward(m, bt, B, gscale, fuse_dense));
         // ---- optimizer: one step counter for all variables (Keras `iterations`)
         opt->t += 1;
         float lr_t = 0.f;
@@ -726,7 +778,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         } else {
             CHECK(orx_apply_rows(c, opt, m->emb, nullptr, m->d_idx, B * F, m->dZ, d));
         }
-        CHECK(dense_apply_all(m, opt, lr_t));
+        CHECK(dense_apply_all(m, opt, lr_t, fuse_dense, 1.0f / gscale));
     }
     if (loss_out) {
         std::vector<double> h((size_t)K);

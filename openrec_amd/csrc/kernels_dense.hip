@@ -609,17 +609,28 @@ int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t l
 // (act_bwd_colsum_kernel, the fused epilogues of the fp16 products, the head kernel).  One launch serves all layers of an
 // MLP backward: grid = (columns / 256, jobs).
 __global__ __launch_bounds__(256) void colparts_reduce_kernel(ColJobs jobs) {
+    // 64 columns per workgroup; the P partial rows in four contiguous segments (one per wavefront, 8 loads in flight), combined in
+    // segment order: the summation order is a function of P alone
+    __shared__ float seg[4][64];
     const ColJob j = jobs.j[blockIdx.y];
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= j.N) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    if (blockIdx.x * 64 >= j.N) return;
+    const int per = (j.P + 3) / 4, p0 = w * per, p1 = p0 + per < j.P ? p0 + per : j.P;
     float s = 0.0f;
-    int p = 0;
-    for (; p + 4 <= j.P; p += 4) {
-        const float a0 = j.parts[(int64_t)p * j.N + c], a1 = j.parts[(int64_t)(p + 1) * j.N + c], a2 = j.parts[(int64_t)(p + 2) * j.N + c], a3 = j.parts[(int64_t)(p + 3) * j.N + c];
-        s += a0; s += a1; s += a2; s += a3;
+    if (c < j.N) {
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = j.parts[(int64_t)(p + u) * j.N + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += a[u];
+        }
+        for (; p < p1; ++p) s += j.parts[(int64_t)p * j.N + c];
     }
-    for (; p < j.P; ++p) s += j.parts[(int64_t)p * j.N + c];
-    j.out[c] = s * j.scale;
+    seg[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < j.N) j.out[c] = (((seg[0][threadIdx.x] + seg[1][threadIdx.x]) + seg[2][threadIdx.x]) + seg[3][threadIdx.x]) * j.scale;
 }
 
 int orx_launch_colparts_reduce(orx_ctx* ctx, const ColJob* jobs, int n) {
@@ -628,7 +639,7 @@ int orx_launch_colparts_reduce(orx_ctx* ctx, const ColJob* jobs, int n) {
         const int cnt = n - base < ORX_COLJOBS_MAX ? n - base : ORX_COLJOBS_MAX;
         int maxN = 1;
         for (int i = 0; i < cnt; ++i) { cj.j[i] = jobs[base + i]; if (cj.j[i].N > maxN) maxN = cj.j[i].N; }
-        ORX_LAUNCH(ctx, colparts_reduce_kernel, dim3((unsigned)((maxN + 255) / 256), (unsigned)cnt), dim3(256), 0, cj);
+        ORX_LAUNCH(ctx, colparts_reduce_kernel, dim3((unsigned)((maxN + 63) / 64), (unsigned)cnt), dim3(256), 0, cj);
     }
     ORX_HIP(hipGetLastError());
     return ORX_OK;
@@ -789,12 +800,17 @@ __global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(RowSrc src, int 
 // A operand: lane (i, q) holds S[16 ti + i][4 s + q], built straight from dR.  B operand: lane (j, q) owns the
 // CPL = d/16 consecutive columns CPL*j .. CPL*j + CPL-1 of Z row 4 s + q (float4 loads); column tile t of the
 // MFMA grid is {CPL*j + t}, so every lane ends up with CPL consecutive columns of its output rows (float4 stores).
-template <int CPL>
+// SPLIT wavefronts may share a sample, each taking d / SPLIT of the columns.  Measured at d = 128, B = 8192: two wavefronts of 64
+// columns (16 384 wavefronts of ~90 VGPRs) are SLOWER than one of 128 (8192 of ~170): step 0.6285 against 0.6125 ms -- every
+// wavefront re-reads the sample's dR and the 256-byte half rows lose the 512-byte bursts.  No launch uses SPLIT > 1.
+template <int CPL, int SPLIT>
 __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, const float* dR, int F, int itself, float* dZ,
                                                                 int64_t B, int ldR, float scale) {
-    constexpr int d = 16 * CPL;
+    constexpr int d = 16 * CPL * SPLIT;
     const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t b = wv / SPLIT;
+    const int coff = (int)(wv % SPLIT) * 16 * CPL;          // first column of this wavefront's share
     if (b >= B) return;
     const int i = lane & 15, q = lane >> 4;
     const float* rb = dR + b * ldR;
@@ -818,8 +834,8 @@ __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, cons
             f32x4 v; v.x = v.y = v.z = v.w = 0.0f;
             const float* zk = k < F ? src.row(b, k, F, d) : nullptr;
             if (zk) {
-                if (CPL >= 4) v = *reinterpret_cast<const f32x4*>(zk + CPL * i + c4);
-                else { v.x = zk[CPL * i]; v.y = zk[CPL * i + 1]; }
+                if (CPL >= 4) v = *reinterpret_cast<const f32x4*>(zk + coff + CPL * i + c4);
+                else { v.x = zk[coff + CPL * i]; v.y = zk[coff + CPL * i + 1]; }
             }
             zr[s][c4] = v.x; if (c4 + 1 < CPL) zr[s][c4 + 1] = v.y;
             if (c4 + 2 < CPL) zr[s][c4 + 2] = v.z; if (c4 + 3 < CPL) zr[s][c4 + 3] = v.w;
@@ -843,10 +859,10 @@ __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, cons
         for (int r = 0; r < 4; ++r) {
             const int g = 16 * ti + q * 4 + r;
             if (g >= F) continue;
-            float* out = dZ + (b * F + g) * d + CPL * i;
+            float* out = dZ + (b * F + g) * d + coff + CPL * i;
             float o[CPL];
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) o[t] = (acc[ti][t][r] + (g == F - 1 ? rb[CPL * i + t] : 0.0f)) * scale;
+            for (int t = 0; t < CPL; ++t) o[t] = (acc[ti][t][r] + (g == F - 1 ? rb[coff + CPL * i + t] : 0.0f)) * scale;
             if (CPL >= 4) {
 #pragma unroll
                 for (int t = 0; t < CPL; t += 4) { f32x4 v; v.x = o[t]; v.y = o[t + 1]; v.z = o[t + 2]; v.w = o[t + 3]; *reinterpret_cast<f32x4*>(out + t) = v; }
@@ -877,10 +893,10 @@ int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR,
             ORX_LAUNCH(ctx, interact_fwd_mfma_kernel, g, dim3(256), 0, src, F, d, itself, out, B, ldR, (_Float16*)R16, ldR16);
             if (wrote16 && R16) *wrote16 = true;
         }
-        else if (d == 32) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<2>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
-        else if (d == 64) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
-        else if (d == 128) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
-        else ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<16>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
+        else if (d == 32) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<2, 1>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
+        else if (d == 64) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4, 1>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
+        else if (d == 128) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8, 1>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
+        else ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<16, 1>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
         ORX_HIP(hipGetLastError());
         return ORX_OK;
     }
@@ -1016,6 +1032,102 @@ int orx_launch_dense_apply_multi(orx_ctx* ctx, const DenseParam* ps_dev, int cou
     if (count == 0) return ORX_OK;
     int64_t gx = (max_n + 255) / 256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
     ORX_LAUNCH(ctx, dense_apply_multi_kernel, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, ps_dev, optkind, lr, eps, b1, b2);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// One 16 x 64 tile of one dense parameter per workgroup (thread = 4 consecutive columns of one row; ~2400 workgroups for the C5 MLPs:
+// 64 x 64 tiles gave 600 and a launch of 96 us, latency-bound): gradient = g + slab_scale * (sum of the S split-K slices, in slice
+// order, 8 in flight), the optimizer rule, g re-zeroed, and the fp16 copies of the new weights -- w16 row-major straight from the
+// registers, w16t through an LDS transpose.
+constexpr int DF_ROWS = 16;
+__global__ __launch_bounds__(256) void dense_apply_fused_kernel(const DenseFused* ps, DenseFusedTiles tt, int optkind, float lr, float eps, float b1, float b2,
+                                                                float slab_scale) {
+    __shared__ _Float16 tr[DF_ROWS][64 + 2];
+    int pi = 0;                                              // (the tile table travels in the kernel arguments: scalar loads, no dependent memory chain)
+    while (pi + 1 < tt.count && (int)blockIdx.x >= tt.tile0[pi + 1]) ++pi;
+    const DenseFused p = ps[pi];
+    const int t = blockIdx.x - p.tile0;
+    const int r0 = (t / p.tiles_x) * DF_ROWS, c0 = (t % p.tiles_x) * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const bool vec = (p.cols & 3) == 0;
+    const int row = r0 + ty, col = c0 + 4 * tx;
+    const int nv = col < p.cols ? (p.cols - col < 4 ? p.cols - col : 4) : 0;
+    const bool live = row < p.rows && nv > 0;
+    float gi[4] = {0.f, 0.f, 0.f, 0.f}, wv[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t i = (int64_t)row * p.cols + col;
+    if (live) {
+        if (vec) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.g + i), w4 = *reinterpret_cast<const f32x4*>(p.w + i);
+            gi[0] = g4.x; gi[1] = g4.y; gi[2] = g4.z; gi[3] = g4.w; wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
+            if (optkind != ORX_SGD) { const f32x4 q = *reinterpret_cast<const f32x4*>(p.acc + i); a1[0] = q.x; a1[1] = q.y; a1[2] = q.z; a1[3] = q.w; }
+            if (optkind == ORX_ADAM) { const f32x4 q = *reinterpret_cast<const f32x4*>(p.acc2 + i); a2[0] = q.x; a2[1] = q.y; a2[2] = q.z; a2[3] = q.w; }
+        } else {
+            for (int e = 0; e < nv; ++e) { gi[e] = p.g[i + e]; wv[e] = p.w[i + e]; if (optkind != ORX_SGD) a1[e] = p.acc[i + e]; if (optkind == ORX_ADAM) a2[e] = p.acc2[i + e]; }
+        }
+        if (p.slab != nullptr) {           // the gradient's split-K slices: tile (row / 128, col / 128), 128 x 128 floats per slice, slice order
+            const float* base = p.slab + ((size_t)((row >> 7) * p.ntn + (col >> 7)) * p.S) * ORX_SLAB_STRIDE + (row & 127) * 128 + (col & 127);
+            float sv[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int z0 = 0; z0 < p.S; z0 += 8) {
+                f32x4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    q[u].x = q[u].y = q[u].z = q[u].w = 0.f;
+                    if (z0 + u < p.S) {
+                        const float* sp = base + (size_t)(z0 + u) * ORX_SLAB_STRIDE;
+                        if (vec) q[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp));
+                        else { q[u].x = sp[0]; if (nv > 1) q[u].y = sp[1]; if (nv > 2) q[u].z = sp[2]; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { sv[0] += q[u].x; sv[1] += q[u].y; sv[2] += q[u].z; sv[3] += q[u].w; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gi[e] += sv[e] * slab_scale;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (optkind == ORX_ADAM) adam_elem(wv[e], a1[e], a2[e], gi[e], lr, b1, b2, eps);
+            else if (optkind == ORX_ADAGRAD) { a1[e] += gi[e] * gi[e]; wv[e] -= lr * gi[e] / (sqrtf(a1[e]) + eps); }
+            else wv[e] -= lr * gi[e];
+        }
+        if (vec) {
+            f32x4 o; o.x = wv[0]; o.y = wv[1]; o.z = wv[2]; o.w = wv[3];
+            *reinterpret_cast<f32x4*>(p.w + i) = o;
+            f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(p.g + i) = z4;
+            if (optkind != ORX_SGD) { f32x4 q; q.x = a1[0]; q.y = a1[1]; q.z = a1[2]; q.w = a1[3]; *reinterpret_cast<f32x4*>(p.acc + i) = q; }
+            if (optkind == ORX_ADAM) { f32x4 q; q.x = a2[0]; q.y = a2[1]; q.z = a2[2]; q.w = a2[3]; *reinterpret_cast<f32x4*>(p.acc2 + i) = q; }
+        } else {
+            for (int e = 0; e < nv; ++e) { p.w[i + e] = wv[e]; p.g[i + e] = 0.0f; if (optkind != ORX_SGD) p.acc[i + e] = a1[e]; if (optkind == ORX_ADAM) p.acc2[i + e] = a2[e]; }
+        }
+        if (p.w16 != nullptr) {
+            _Float16* q = (_Float16*)p.w16 + (int64_t)row * p.ld16 + col;
+            if (vec) { h4 h; h[0] = (_Float16)wv[0]; h[1] = (_Float16)wv[1]; h[2] = (_Float16)wv[2]; h[3] = (_Float16)wv[3]; *reinterpret_cast<h4*>(q) = h; }
+            else for (int e = 0; e < nv; ++e) q[e] = (_Float16)wv[e];
+        }
+    }
+    if (p.w16t == nullptr) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tr[ty][4 * tx + e] = (_Float16)(live && e < nv ? wv[e] : 0.0f);
+    __syncthreads();
+    // w16t [cols][ld16t]: thread = column c0 + t / 4, 4 consecutive rows r0 + 4 (t % 4) ..
+    const int c = threadIdx.x >> 2, rb = (threadIdx.x & 3) * 4;
+    if (c0 + c < p.cols) {
+        _Float16* q = (_Float16*)p.w16t + (int64_t)(c0 + c) * p.ld16t + r0 + rb;
+        if (r0 + rb + 3 < p.rows && (p.ld16t & 3) == 0) {
+            h4 h; h[0] = tr[rb][c]; h[1] = tr[rb + 1][c]; h[2] = tr[rb + 2][c]; h[3] = tr[rb + 3][c];
+            *reinterpret_cast<h4*>(q) = h;
+        } else {
+            for (int e = 0; e < 4; ++e) if (r0 + rb + e < p.rows) q[e] = tr[rb + e][c];
+        }
+    }
+}
+
+int orx_launch_dense_apply_fused(orx_ctx* ctx, const DenseFused* ps_dev, const DenseFusedTiles& tt, int total_tiles, int optkind, float lr, float eps,
+                                 float b1, float b2, float slab_scale) {
+    if (tt.count == 0 || total_tiles == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, dense_apply_fused_kernel, dim3((unsigned)total_tiles), dim3(256), 0, ps_dev, tt, optkind, lr, eps, b1, b2, slab_scale);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

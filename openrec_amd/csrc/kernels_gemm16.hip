@@ -38,9 +38,12 @@ struct Nt16Args {
 // (b % 8) * (n / 8) + b / 8 hands every XCD a contiguous run of the row-major tile list
 __device__ __forceinline__ int xcd_slot(int b, int n) { return (n & 7) ? b : (b & 7) * (n >> 3) + (b >> 3); }
 
-template <int WM, int WN, int TM, int TN, int MINB>
+// PAD: halves of padding per LDS tile row.  8 (144-byte rows) leaves 36 % of the LDS-active cycles in bank conflicts
+// (profiles/r2_dlrm_fp16_pmc_mfma_lds.csv); 16 (160-byte rows) removes them: main loop 21.1 -> 20.0 us on 8192 x 1024 x 1024
+// (profiles/r2_exp_gemm_lds_pitch.log).  The 128 x 128 configuration keeps 8: two workgroups of it must share a CU's 160 KB.
+template <int WM, int WN, int TM, int TN, int MINB, int PAD>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_kernel(Nt16Args g) {
-    constexpr int BK = 64, BM = WM * TM * 16, BN = WN * TN * 16, LD = BK + 8, NT = 64 * WM * WN;
+    constexpr int BK = 64, BM = WM * TM * 16, BN = WN * TN * 16, LD = BK + PAD, NT = 64 * WM * WN;
     constexpr int CPR = BK / 8;                                  // 16-byte chunks per tile row
     constexpr int NA = BM * CPR / NT, NB = BN * CPR / NT;
     static_assert(BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile / thread mismatch");
@@ -217,11 +220,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_kernel(Nt16Args 
     }
 }
 
-template <int WM, int WN, int TM, int TN, int MINB>
+template <int WM, int WN, int TM, int TN, int MINB, int PAD>
 static int launch_nt(orx_ctx* ctx, const Nt16Args& g) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    constexpr size_t shm = (size_t)2 * (BM + BN) * 72 * 2;
-    auto kern = gemm16_nt_kernel<WM, WN, TM, TN, MINB>;
+    constexpr size_t shm = (size_t)2 * (BM + BN) * (64 + PAD) * 2;
+    auto kern = gemm16_nt_kernel<WM, WN, TM, TN, MINB, PAD>;
     static bool attr = false;
     if (!attr) { ORX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); attr = true; }
     const unsigned nb = (unsigned)(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN));
@@ -247,10 +250,10 @@ int orx_launch_gemm16_nt(orx_ctx* ctx, const void* A16, int64_t lda, const void*
     const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
     // (the 4-wavefront configurations want two workgroups per CU: with one, every load and barrier latency of the short K
     // loops of the narrow layers is exposed -- a fused 8192 x 512 x 256 product took 18 us on 256 tiles of 128 x 128)
-    if (force == 1 || (force == 0 && blocks(256, 128) >= cus)) { if (gbp) gbp->P = (M + 255) / 256; return launch_nt<4, 2, 4, 4, 1>(ctx, g); }
+    if (force == 1 || (force == 0 && blocks(256, 128) >= cus)) { if (gbp) gbp->P = (M + 255) / 256; return launch_nt<4, 2, 4, 4, 1, 16>(ctx, g); }
     if (gbp) gbp->P = (M + 127) / 128;
-    if (force == 2 || (force == 0 && blocks(128, 128) >= 2 * cus)) return launch_nt<2, 2, 4, 4, 2>(ctx, g);
-    return launch_nt<2, 2, 4, 2, 2>(ctx, g);
+    if (force == 2 || (force == 0 && blocks(128, 128) >= 2 * cus)) return launch_nt<2, 2, 4, 4, 2, 8>(ctx, g);
+    return launch_nt<2, 2, 4, 2, 2, 16>(ctx, g);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient

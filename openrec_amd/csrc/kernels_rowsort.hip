@@ -256,14 +256,30 @@ __global__ __launch_bounds__(256) void csr_finish_kernel(CsrArgs a) {
     const uint32_t row = a.sorted[i0 + 63].x;
     if (row >= a.rows || a.sorted[i0 + 64].x != row) return;           // the block's last run ends here
     if (a.sorted[i0].x == row && b > 0 && a.sorted[i0 - 1].x == row) return;   // ... or started in an earlier block
+    // how many blocks the run continues into: lane l looks at the first key of block b + 2 + l (64 blocks per round)
+    int64_t last = b + 1;                                    // the last block that holds a piece of the run
+    for (;;) {
+        const int64_t nx = (last + 1 + lane) * 64;
+        const bool cont = nx < a.n && a.sorted[nx].x == row;
+        const unsigned long long m = __ballot(cont);
+        const int run = m == ~0ull ? 64 : __builtin_ctzll(~m);         // consecutive continuing blocks
+        last += run;
+        if (run < 64) break;
+    }
     float s[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) s[e] = lane + 64 * e < a.D ? a.part_hi[(size_t)b * a.Dp + lane + 64 * e] : 0.0f;
-    for (int64_t c = b + 1;; ++c) {
+    constexpr int UN = 8;
+    for (int64_t c0 = b + 1; c0 <= last; c0 += UN) {         // UN partial rows in flight, added in block order
+        float q[UN][NE];
 #pragma unroll
-        for (int e = 0; e < NE; ++e) if (lane + 64 * e < a.D) s[e] += a.part_lo[(size_t)c * a.Dp + lane + 64 * e];
-        const int64_t nx = (c + 1) * 64;
-        if (nx >= a.n || a.sorted[nx].x != row) break;
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) q[u][e] = (c0 + u <= last && lane + 64 * e < a.D) ? a.part_lo[(size_t)(c0 + u) * a.Dp + lane + 64 * e] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) if (c0 + u <= last) s[e] += q[u][e];
     }
     RowState<NE, MODE> st;
     st.load(a, row, lane);

@@ -112,6 +112,8 @@ struct orx_table {
     int tag_gen = 0;                  // ctx->epoch_gen the ready / side tags belong to
     int* side = nullptr;              // [rows][2] fused censor: last epoch with a duplicated pos / neg reference
     struct orx_opt* lazy = nullptr;   // lazily-applied Adam: rows are caught up on demand (orx_table_sync flushes)
+    uint64_t version = 0;             // bumped by every host-side write / fill / init and by the dense optimizer kernels: derived copies
+                                      // (the fp16 copies of the DLRM kernels) know when they are stale
 };
 
 struct OptSlots {
@@ -396,6 +398,18 @@ int orx_launch_gemm_f16(orx_ctx* ctx, const float* A, int64_t sa0, int64_t sa1, 
 struct DenseParam { float* w; float* acc; float* acc2; float* g; int64_t n; };
 int orx_launch_dense_apply_multi(orx_ctx* ctx, const DenseParam* ps_dev, int count, int64_t max_n, int optkind, float lr, float eps,
                                  float b1 = 0.f, float b2 = 0.f);
+// the same rule in 64 x 64 tiles, with the rest of a dense parameter's per-step work folded in: the split-K slices of its gradient
+// (kernels_gemm16.hip) are added on the way in (slice order; times slab_scale = 1 / loss scale), the fp16 copies of the new weights
+// (w16 [rows][ld16], w16t [cols][ld16t], transposed through LDS) are written on the way out
+struct DenseFused {
+    float* w; float* acc; float* acc2; float* g; int rows, cols;
+    const float* slab; int S, ntn;                 // NULL: the gradient is g alone
+    void* w16; void* w16t; int ld16, ld16t;        // NULL: no fp16 copies
+    int tile0, tiles_x;                            // first tile of this parameter in the launch's flat tile list; tiles per tile row
+};
+struct DenseFusedTiles { int count; int tile0[48]; };       // first tile of every parameter (kernel argument)
+int orx_launch_dense_apply_fused(orx_ctx* ctx, const DenseFused* ps_dev, const DenseFusedTiles& tt, int total_tiles, int optkind, float lr, float eps,
+                                 float b1, float b2, float slab_scale);
 // Column sums (bias gradients) leave their producers as one partial row per row block -- parts[p * N + c], plain stores --
 // and one colparts_reduce launch per MLP backward adds the blocks in order: no fp32 atomics, reproducible sums.
 struct ColPart { float* parts = nullptr; int P = 0; };        // in: the workspace; out: row blocks written
