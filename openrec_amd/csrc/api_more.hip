@@ -86,13 +86,16 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     // atomics for every duplicate.
     const bool role_bits = mode == MODE_EXACT && orx_fused_can_inline_apply(D) && U->rows < (1LL << 28) && V->rows < (1LL << 28) && !(fb & 1);
     const bool staging = role_bits && !(fb & 8);
+    // the previous step's duplicated rows are applied by extra blocks of the next step's launch, as in the pairwise step
+    // (WRMF 27.1 -> see DESIGN 4.4; fb bit 2: separate dup_apply launches)
+    const bool inline_apply = role_bits && K > 1 && orx_plan_v2(true) && !(fb & 2);
     PairPlan plan;
     memset(&plan, 0, sizeof(plan));
     if (role_bits) {
         CHECK(orx_table_scratch(U, true)); CHECK(orx_table_scratch(V, true)); CHECK(orx_table_scratch(b, true));
         const int nb_total = orx_dedup_buckets(U->rows) + orx_dedup_buckets(V->rows);
         const size_t part_cap = c->d_partial_cap;       // orx_exact_buffers sizes d_partial for its own use: keep ours
-        CHECK(orx_exact_buffers(c, U, V, K, B, mode, true, false, staging, nb_total, nslot, &plan));
+        CHECK(orx_exact_buffers(c, U, V, K, B, mode, true, inline_apply, staging, nb_total, nslot, &plan));
         if (opt->kind == ORX_ADAM) plan.min_late = 1;      // Adam: fixed summation order for every row referenced >= 3 times (api.hip)
         (void)part_cap;
         ENSURE(c->d_partial, c->d_partial_cap, (size_t)K * nslot * 2 * sizeof(float));
@@ -119,11 +122,20 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     a.lr = opt->lr; a.eps = opt->kind == ORX_ADAGRAD ? opt->p1 : 0.f;
     a.invB = 1.0f / (float)B; a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f; a.a_w = a_w; a.b_w = b_w;
     a.wpartial = c->d_wpart; a.err = c->d_err;
-    if (role_bits) { a.role_bits = 1; a.gU2 = U->gsum2; a.gV2 = V->gsum2; a.gb2 = b->gsum2; }
-    PairArgs pa;                                 // view of the same tables for dup_apply_kernel / hot_reduce_kernel
+    if (role_bits) { a.role_bits = 1; a.gU2 = U->gsum2; a.gV2 = V->gsum2; a.gb2 = b->gsum2; a.readyU = U->ready; a.readyV = V->ready; }
+    PairArgs pa;                                 // view of the same tables for dup_apply_kernel / hot_reduce_kernel / the in-launch apply
     memset(&pa, 0, sizeof(pa));
     pa.U = U->w; pa.V = V->w; pa.b = b->w; pa.gU = U->gsum; pa.gV = V->gsum; pa.gb = b->gsum;
-    if (role_bits) { pa.gU2 = U->gsum2; pa.gV2 = V->gsum2; pa.gb2 = b->gsum2; pa.role_bits = 1; }
+    if (role_bits) { pa.gU2 = U->gsum2; pa.gV2 = V->gsum2; pa.gb2 = b->gsum2; pa.role_bits = 1; pa.readyU = U->ready; pa.readyV = V->ready; }
+    // epochs tag the ready flags: one per step; on wrap-around the tables clear theirs (as orx_pairwise_step does)
+    if ((int64_t)c->epoch + K + 16 > 0x7fffffff) { c->epoch = 0; c->epoch_gen += 1; }
+    for (orx_table* t : {U, V}) {
+        if (t->tag_gen != c->epoch_gen) {
+            if (t->ready) ORX_HIP(hipMemsetAsync(t->ready, 0, (size_t)t->rows * sizeof(int), c->stream));
+            if (t->side) ORX_HIP(hipMemsetAsync(t->side, 0, (size_t)t->rows * 2 * sizeof(int), c->stream));
+            t->tag_gen = c->epoch_gen;
+        }
+    }
     pa.aU = sU.s0; pa.aV = sV.s0; pa.ab = sb.s0; pa.B = B; pa.D = D; pa.lr = a.lr; pa.eps = a.eps;
     if (lazy_adam) {
         a.a2U = pa.a2U = sU.s1; a.a2V = pa.a2V = sV.s1; a.a2b = pa.a2b = sb.s1;
@@ -139,7 +151,8 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     for (int64_t s0 = 0; s0 < K; s0 += chunk) {
     const int64_t kc = (K - s0 < chunk) ? (K - s0) : chunk;
     ExactChunk ck;
-    if (role_bits) CHECK(orx_exact_plan_chunk(c, U, V, du + s0 * ds, di + s0 * ds, di + s0 * ds, ds, B, B, 0, kc, B, true, false, staging, plan, &ck));
+    if (role_bits) CHECK(orx_exact_plan_chunk(c, U, V, du + s0 * ds, di + s0 * ds, di + s0 * ds, ds, B, B, 0, kc, B, true, inline_apply, staging, plan, &ck));
+    const bool inl = inline_apply && !ck.hot && !ck.dense_dups;      // (many duplicated rows / reduction-tree levels: separate launches, api.hip)
     for (int64_t i = 0; i < kc; ++i) {
         const int64_t s = s0 + i;
         a.label = dl + s * ds;
@@ -154,10 +167,20 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
             pa.dlist = c->d_dlist + (size_t)s * list_stride; pa.dcount = c->d_dcount + s;
         }
         if (lazy_adam) { opt->t += 1; a.step_t = pa.step_t = (int)opt->t; }
+        a.n_apply_blocks = 0;
+        if (role_bits) {
+            a.epoch = pa.epoch = ++c->epoch;
+            if (inl && i > 0) {                  // this launch also applies the duplicated rows of step i-1
+                pa.n_apply_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(16, (B / 4) / (1024 / D) + 1));
+                pa.prev_dlist = c->d_dlist + (size_t)(i - 1) * plan.list_stride; pa.prev_dcount = c->d_dcount + (i - 1);
+                a.n_apply_blocks = pa.n_apply_blocks;
+                a.ap = pa;
+            }
+        }
         CHECK(orx_launch_point_fused(c, model, opt->kind, mode, a));
         if (mode == MODE_EXACT) {
             for (int l = 0; l < ck.tree_levels; ++l) CHECK(orx_launch_hot_reduce(c, pa, l));
-            CHECK(orx_launch_dup_apply(c, opt->kind, pa));
+            if (!inl || i == kc - 1) CHECK(orx_launch_dup_apply(c, opt->kind, pa));
         }
         float lr_t = lazy_adam ? opt->h_lrt[(size_t)opt->t] : 0.f;
         if (mode == MODE_ACCUM) {

@@ -11,7 +11,7 @@
 // gsum and are finished by dup_apply_kernel.  GMF's dense kernel gradient
 // (a [D] vector summed over the batch) leaves the fused kernel as one partial per
 // wavefront and is reduced + applied by dense_apply_kernel.
-#include "orx_device.h"
+#include "orx_apply_device.h"
 
 // per-sample loss term and d(loss)/d(score)
 template <int MODEL>
@@ -36,8 +36,14 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
-    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
+    const int nab = MODE == MODE_EXACT ? a.n_apply_blocks : 0;
+    if (MODE == MODE_EXACT && (int)blockIdx.x < nab) {          // apply role (block-uniform): step s-1's duplicated rows
+        if (a.ap.prev_dcnt != nullptr) inline_apply<LPR, OPT, false, true>(a.ap);
+        else inline_apply<LPR, OPT, false, false>(a.ap);
+        return;
+    }
+    const int64_t wave_global = (int64_t)(blockIdx.x - nab) * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)(gridDim.x - nab) * 4 * TPW;
     float loss_acc = 0.0f, sq_acc = 0.0f;
     f4 wv; wv.x = wv.y = wv.z = wv.w = 1.0f;
     if (MODEL == ORX_GMF) wv = *reinterpret_cast<const f4*>(a.w + 4 * sub);
@@ -47,10 +53,12 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
         const float y = a.label[t];
         int du = 0, di = 0;
         int ku = 2, ki = 2;                     // duplicate role: 0 / 1 = plain store into scratch row 1 / 2, 2 = staged or atomics
+        int urgent = 0;
         if (MODE == MODE_EXACT) {
             if (a.role_bits) {                  // ids rewritten by dedup_kernel
                 du = (uint32_t)u >> 31; di = (uint32_t)i >> 31;
                 ku = ((uint32_t)u >> 29) & 3; ki = ((uint32_t)i >> 29) & 3;
+                urgent = (((uint32_t)u >> 28) & 1) | (((uint32_t)i >> 27) & 2);
                 u &= 0x0fffffff; i &= 0x0fffffff;
             } else {
                 du = a.dflag[t]; di = a.dflag[a.B + t];
@@ -58,6 +66,13 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
         }
         if (MODE == MODE_ACCUM) { du = di = 1; }
         if (!(id_ok(u, a.NU) & id_ok(i, a.NI))) { if (sub == 0) *a.err = 1; continue; }
+        if (MODE == MODE_EXACT && urgent && nab) {      // a row of this sample is being updated by an apply block of this launch
+            if (sub == 0) {
+                if (urgent & 1) wait_ready(a.readyU + u, a.epoch);
+                if (urgent & 2) wait_ready(a.readyV + i, a.epoch);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         float* Up = a.U + (size_t)u * D + 4 * sub;
         float* Ip = a.V + (size_t)i * D + 4 * sub;
         f4 ru = *reinterpret_cast<const f4*>(Up);
@@ -373,7 +388,7 @@ static void launch_point_adam(int lpr, dim3 g, orx_ctx* c, const PointArgs& a) {
 int orx_launch_point_fused(orx_ctx* ctx, int model, int optkind, int mode, const PointArgs& a) {
     ProfScope ps(ctx, ORX_K_POINT);
     const int lpr = lpr_for_dim_p(a.D);
-    const dim3 g((unsigned)point_grid(a.D, a.B));
+    const dim3 g((unsigned)(point_grid(a.D, a.B) + (mode == MODE_EXACT && lpr != 0 ? a.n_apply_blocks : 0)));
     if (optkind == ORX_ADAM && mode == MODE_EXACT) {
         ORX_ARG(lpr != 0 && a.lrt != nullptr && a.role_bits, "point_fused: the lazy Adam path needs a float4 dim and the exact-step plan");
         if (model == ORX_GMF) launch_point_adam<ORX_GMF>(lpr, g, ctx, a);

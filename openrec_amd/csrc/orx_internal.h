@@ -316,6 +316,11 @@ struct PointArgs {
     // lazy TF-2.0 Adam: second slots, per-row step stamps (the bias shares its item row's), lr_t table
     float* a2U; float* a2V; float* a2b; int* lastU; int* lastV; int* lastb;
     const float* lrt; float b1; float b2; int step_t; int newton;
+    // in-launch application of the PREVIOUS step's duplicated rows, as in the pairwise step (n_apply_blocks == 0: off): the first
+    // blocks of the launch run inline_apply on `ap` (the tables seen as a pairwise step sees them, prev_* = step s-1's lists);
+    // references marked urgent (bit 28 of the rewritten ids) wait for their row's ready flag
+    int n_apply_blocks; int epoch; const int* readyU; const int* readyV;
+    PairArgs ap;
 };
 
 int orx_launch_point_fused(orx_ctx* ctx, int model, int optkind, int mode, const PointArgs& a);
