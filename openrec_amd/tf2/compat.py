@@ -346,9 +346,29 @@ def matmul(a, b, transpose_a=False, transpose_b=False):
 
 def reshape(x, shape):
     from .modules.latent_factor import Variable
+    from .modules._expr import Expr
     if isinstance(x, Variable):
         return _Flat(x, shape)
+    if isinstance(x, Expr):
+        return Expr("reshape", x, shape=shape)
     return np.asarray(x).reshape(shape)
+
+
+def _expr_ops():
+    from .modules import _expr
+    return _expr
+
+
+def _square(x): return _expr_ops().square(x)
+def _reduce_sum(x, axis=None, keepdims=False): return _expr_ops().reduce_sum(x, axis=axis, keepdims=keepdims)
+def _maximum(a, b): return _expr_ops().maximum(a, b)
+def _expand_dims(x, axis): return _expr_ops().expand_dims(x, axis)
+def _squeeze(x, axis=None): return _expr_ops().squeeze(x, axis=axis)
+
+
+class _BCE:
+    def __new__(cls, *a, **k):
+        return _expr_ops().BinaryCrossentropy(*a, **k)
 
 
 def _l2_loss(x):
@@ -357,12 +377,15 @@ def _l2_loss(x):
 
 
 optimizers = types.SimpleNamespace(SGD=SGD, Adagrad=Adagrad, Adam=Adam)
-keras = types.SimpleNamespace(optimizers=optimizers, metrics=types.SimpleNamespace(Mean=Mean, AUC=AUC), Model=Model)
+losses = types.SimpleNamespace(BinaryCrossentropy=_BCE)
+keras = types.SimpleNamespace(optimizers=optimizers, metrics=types.SimpleNamespace(Mean=Mean, AUC=AUC), Model=Model, losses=losses)
+math = types.SimpleNamespace(square=_square, reduce_sum=_reduce_sum, maximum=_maximum)
 data = types.SimpleNamespace(Dataset=TensorSliceDataset)
 nn = types.SimpleNamespace(l2_loss=_l2_loss)
 linalg = types.SimpleNamespace(matmul=matmul)
 tf = types.SimpleNamespace(function=function, GradientTape=GradientTape, constant=constant, keras=keras, data=data, nn=nn,
-                           linalg=linalg, matmul=matmul, reshape=reshape, int32=int32, float32=float32, bool=bool_)
+                           linalg=linalg, matmul=matmul, reshape=reshape, int32=int32, float32=float32, bool=bool_,
+                           math=math, reduce_sum=_reduce_sum, maximum=_maximum, square=_square, expand_dims=_expand_dims, squeeze=_squeeze)
 
 
 def install():
@@ -380,7 +403,7 @@ def install():
     for k, v in vars(tf).items():
         setattr(mod, k, v)
     kmod = types.ModuleType("tensorflow.keras")
-    kmod.optimizers, kmod.metrics, kmod.Model = optimizers, keras.metrics, Model
+    kmod.optimizers, kmod.metrics, kmod.Model, kmod.losses = optimizers, keras.metrics, Model, losses
     omod = types.ModuleType("tensorflow.keras.optimizers")
     omod.SGD, omod.Adagrad, omod.Adam = SGD, Adagrad, Adam
     mmod = types.ModuleType("tensorflow.keras.metrics")

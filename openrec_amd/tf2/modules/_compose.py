@@ -50,13 +50,25 @@ def composed_model(kind, user_lf, item_lf, bias_lf, **kw):
     from ..recommenders._base import PairwiseRecommender, PointwiseRecommender, _StepQueue
     # the composed model lives exactly as long as its user LatentFactor (it holds the other two alive, so their ids stay
     # unique while it exists): a dict on the module would keep every composition's tables in HBM for the life of the process
-    key = (kind, id(user_lf), id(item_lf), id(bias_lf), tuple(sorted(kw.items())))
+    mlp = kw.pop("mlp", None)
+    key = (kind, id(user_lf), id(item_lf), id(bias_lf), id(mlp), tuple(sorted(kw.items())))
     owned = user_lf.__dict__.setdefault("_composed", {})
     m = owned.get(key)
     if m is None:
         if kind == "bpr":
             class _Composed(PairwiseRecommender):
                 _model = "bpr"
+        elif kind == "ucml":
+            class _Composed(PairwiseRecommender):
+                _model = "ucml"
+                _score_kind = "l2"
+                margin = float(kw["margin"])
+        elif kind == "gmf":
+            class _Composed(PointwiseRecommender):
+                _score_kind = "gmf"
+
+                def _point_args(self):
+                    return "gmf", self.mlp.layers[0].kernel, {}
         else:
             class _Composed(PointwiseRecommender):
                 def _point_args(self):
@@ -72,15 +84,141 @@ def composed_model(kind, user_lf, item_lf, bias_lf, **kw):
                 mm.flush()
         for lf in (user_lf, item_lf, bias_lf):
             _chain(lf.table, flush)
+        if mlp is not None:
+            m.mlp = mlp
+            _chain(mlp.layers[0].kernel, flush)
         owned[key] = m
         _models[key] = m
     return m
 
 
-def _tag(step, rows):
+def _tag(step, rows, params=()):
     step.l2_rows = rows
+    step.l2_params = tuple(params)
     for r in rows:
         r._l2_step = step
+
+
+# ---- compositions spelled out in raw ops (modules/_expr.py) ------------------------------------------------------------
+def _node(e, op, n=None):
+    from ._expr import Expr
+    return isinstance(e, Expr) and e.op == op and (n is None or len(e.args) == n)
+
+
+def _sq_dist(e, keepdims):
+    """reduce_sum(square(a - b), axis=-1, keepdims) -> (a, b)"""
+    if not (_node(e, "reduce_sum", 1) and e.kw.get("axis") in (-1,) and bool(e.kw.get("keepdims")) == keepdims):
+        return None
+    sq = e.args[0]
+    if not (_node(sq, "square", 1) and _node(sq.args[0], "sub", 2)):
+        return None
+    return sq.args[0].args
+
+
+def _ucml_score(e):
+    """(-|u - v|^2) + bias  (ucml.py:35-36)  -> (u rows, item rows, bias rows)"""
+    if not _node(e, "add", 2):
+        return None
+    a, b = e.args
+    if isinstance(a, GatheredRows):
+        a, b = b, a
+    if not (_node(a, "neg", 1) and isinstance(b, GatheredRows)):
+        return None
+    d = _sq_dist(a.args[0], True)
+    if d is None or not all(isinstance(x, GatheredRows) for x in d):
+        return None
+    return d[0], d[1], b
+
+
+def try_ucml_loss(e):
+    """tf.reduce_sum(tf.maximum(margin - (pos_score - neg_score), 0))  (ucml.py:37-39) -> the fused UCML step's loss, or None"""
+    mx = e.args[0]
+    if not _node(mx, "maximum", 2):
+        return None
+    h, zero = mx.args
+    if not (np.isscalar(zero) and float(zero) == 0.0 and _node(h, "sub", 2) and np.isscalar(h.args[0]) and _node(h.args[1], "sub", 2)):
+        return None
+    pos, neg = _ucml_score(h.args[1].args[0]), _ucml_score(h.args[1].args[1])
+    if pos is None or neg is None:
+        return None
+    (u1, p, bp), (u2, n, bn) = pos, neg
+    U, V, b = u1.factor, p.factor, bp.factor
+    if u2 is not u1 and not (u2.factor is U and _same_ids(u1.ids, u2.ids)):
+        return None
+    if n.factor is not V or bn.factor is not b or b.dim != 1 or U.dim != V.dim or b.num_instances != V.num_instances:
+        return None
+    if not (_same_ids(p.ids, bp.ids) and _same_ids(n.ids, bn.ids)):
+        return None
+    out = composed_model("ucml", U, V, b, margin=float(h.args[0]))(u1.ids, p.ids, n.ids)
+    _tag(out[0]._step, (u1, p, n))
+    return out[0]
+
+
+def _gmf_logit(e):
+    """reshape(mlp(u * i) + b, [-1])  (gmf.py:28) -> (mlp, u rows, item rows, bias rows)"""
+    if _node(e, "reshape", 1):
+        e = e.args[0]
+    if not _node(e, "add", 2):
+        return None
+    a, b = e.args
+    if isinstance(a, GatheredRows):
+        a, b = b, a
+    if not (_node(a, "dense1", 2) and isinstance(b, GatheredRows) and _node(a.args[1], "mul", 2)):
+        return None
+    u, i = a.args[1].args
+    if not (isinstance(u, GatheredRows) and isinstance(i, GatheredRows)):
+        return None
+    return a.args[0], u, i, b
+
+
+def try_gmf_loss(label, logit):
+    """BinaryCrossentropy(from_logits=True)(label, reshape(mlp(u * i) + b_i))  (gmf.py:28-29) -> the fused GMF step's loss, or None"""
+    g = _gmf_logit(logit)
+    if g is None:
+        return None
+    mlp, u, i, b = g
+    U, V, bb = u.factor, i.factor, b.factor
+    if bb.dim != 1 or U.dim != V.dim or bb.num_instances != V.num_instances or not _same_ids(i.ids, b.ids):
+        return None
+    out = composed_model("gmf", U, V, bb, mlp=mlp)(u.ids, i.ids, label)
+    _tag(out[0]._step, (u, i), params=(mlp.layers[0].kernel,))
+    return out[0]
+
+
+def try_all_item_scores(e):
+    """the two inference compositions that end in `+ tf.reshape(item_bias.variables[0], [-1])`:
+    ucml.py:50-53  -reduce_sum(square(expand_dims(user_vec, 1) - V), -1)   and   gmf.py:36-41  squeeze(mlp(expand_dims(user_vec, 1) * V), -1)"""
+    from ... import runtime as rt
+    from .latent_factor import Variable
+    from ._expr import Expr
+
+    def flat_var(x):            # tf.reshape(variable, [-1]) (compat._Flat); never touches a lookup (that would gather it)
+        return None if isinstance(x, (GatheredRows, Expr, Variable)) or np.isscalar(x) or isinstance(x, np.ndarray) else getattr(x, "flat_of", None)
+    a, b = e.args
+    bias = flat_var(b) or flat_var(a)
+    body = a if flat_var(b) is not None else b
+    if not isinstance(bias, Variable) or bias.table.dim != 1:
+        return None
+
+    def user_and_items(x, y):
+        if _node(x, "expand_dims", 1) and x.kw.get("axis") == 1 and isinstance(x.args[0], GatheredRows) and isinstance(y, Variable):
+            return x.args[0], y
+        return None
+    kind = w = ui = None
+    if _node(body, "neg", 1):
+        d = _sq_dist(body.args[0], False)
+        ui = user_and_items(*d) if d is not None else None
+        kind = "l2"
+    elif _node(body, "squeeze", 1) and _node(body.args[0], "dense1", 2) and _node(body.args[0].args[1], "mul", 2):
+        ui = user_and_items(*body.args[0].args[1].args)
+        kind, w = "gmf", body.args[0].args[0].layers[0].kernel
+    if ui is None:
+        return None
+    rows, item_var = ui
+    if item_var.table.rows != bias.table.rows or rows.factor.dim != item_var.table.dim:
+        return None
+    from ..compat import HostTensor
+    return HostTensor(rt.score_all_items(kind, rows.factor.table, item_var.table, bias.table, rows.flat_ids(), w=w))
 
 
 def pairwise_step_of(user_vec, p_item_vec, n_item_vec, p_item_bias, n_item_bias):
@@ -116,23 +254,24 @@ class L2Sum:
     """`tf.nn.l2_loss(rows) + tf.nn.l2_loss(rows) + ...` of looked-up vectors: the second output of the fused step whose
     lookups they are (bpr.py:35, wrmf.py:32), a host sum otherwise"""
 
-    def __init__(self, rows, extra=0.0):
-        self.rows, self.extra = list(rows), extra
+    def __init__(self, rows, extra=0.0, params=()):
+        self.rows, self.extra, self.params = list(rows), extra, list(params)      # params: dense kernels (gmf.py:32: the mlp's variables)
         self._step = None
 
     def __add__(self, other):
         if isinstance(other, L2Sum):
-            return L2Sum(self.rows + other.rows, self.extra + other.extra)
-        return L2Sum(self.rows, self.extra + float(other))
+            return L2Sum(self.rows + other.rows, self.extra + other.extra, self.params + other.params)
+        return L2Sum(self.rows, self.extra + float(other), self.params)
 
     __radd__ = __add__
 
     def resolve(self):
         """the recorded step whose l2 term this is: the lookups of ONE loss-module call, each once, nothing added"""
-        if self._step is None and self.extra == 0.0:
+        if self._step is None and self.extra == 0.0 and self.rows:
             st = getattr(self.rows[0], "_l2_step", None)
-            want = getattr(st, "l2_rows", ())
-            if st is not None and len(want) == len(self.rows) and all(any(r is w for r in self.rows) for w in want):
+            want, wantp = getattr(st, "l2_rows", ()), getattr(st, "l2_params", ())
+            if st is not None and len(want) == len(self.rows) and all(any(r is w for r in self.rows) for w in want) \
+                    and len(wantp) == len(self.params) and all(any(p is w for p in self.params) for w in wantp):
                 self._step = st
         return self._step
 
@@ -140,7 +279,8 @@ class L2Sum:
         st = self.resolve()
         if st is not None:
             return np.float32(st.forward()[1])
-        return np.float32(sum(0.5 * float((np.asarray(r, np.float64) ** 2).sum()) for r in self.rows) + self.extra)
+        return np.float32(sum(0.5 * float((np.asarray(r, np.float64) ** 2).sum()) for r in self.rows)
+                          + sum(0.5 * float((p.read().astype(np.float64) ** 2).sum()) for p in self.params) + self.extra)
 
     def __float__(self):
         return float(self.numpy())
@@ -157,4 +297,7 @@ def l2_loss(x):
     """tf.nn.l2_loss: sum(x ** 2) / 2"""
     if isinstance(x, GatheredRows):
         return L2Sum([x])
+    from .latent_factor import Variable
+    if isinstance(x, Variable):
+        return L2Sum([], params=[x.table])
     return np.float32(0.5 * float((np.asarray(x, np.float64) ** 2).sum()))

@@ -1,0 +1,153 @@
+"""Lazy arithmetic on looked-up rows, so that the reference's recommenders that spell their score out in raw TensorFlow ops
+stay on the device path:
+
+  ucml.py:29-40   tf.math.square(user_vec - item_vec) -> tf.math.reduce_sum(..., axis=-1, keepdims=True) -> (-d) + bias ->
+                  pos - neg -> tf.maximum(margin - diff, 0) -> tf.reduce_sum          = the fused UCML step (hinge sum)
+  ucml.py:50-53   -reduce_sum(square(expand_dims(user_vec, 1) - V), -1) + reshape(b)  = the all-item L2 scorer
+  gmf.py:28-30    mlp(user_vec * item_vec) + item_bias -> reshape -> BinaryCrossentropy(from_logits=True)
+                                                                                      = the fused GMF step
+  gmf.py:36-41    squeeze(mlp(expand_dims(user_vec, 1) * V), -1) + reshape(b)         = the all-item GMF scorer
+
+An `Expr` is a small tree over `GatheredRows` / variables / constants.  The ops that END one of these compositions
+(`tf.reduce_sum`, the BCE loss object, `+ tf.reshape(bias, [-1])`) match the tree against the reference's text and record
+the fused step (modules/_compose.py); a tree that matches nothing evaluates on the host as a plain array -- without
+gradients, and says so once under a tape."""
+from __future__ import annotations
+
+import numpy as np
+
+from .latent_factor import GatheredRows, Variable
+
+
+def is_lazy(x):
+    if isinstance(x, (Expr, GatheredRows, Variable)):
+        return True
+    if np.isscalar(x) or isinstance(x, np.ndarray):
+        return False
+    return getattr(x, "flat_of", None) is not None
+
+
+def host(x):
+    """the value of a tree node as a host array"""
+    if isinstance(x, Expr):
+        return x.numpy()
+    if isinstance(x, Variable):
+        return x.numpy()
+    return np.asarray(x)
+
+
+class Expr:
+    __array_priority__ = 200.0
+
+    def __init__(self, op, *args, **kw):
+        self.op, self.args, self.kw = op, args, kw
+        self._host = None
+
+    # ---- arithmetic builds the tree; `+` also ends the two inference compositions
+    def __add__(self, o):
+        from ._compose import try_all_item_scores
+        e = Expr("add", self, o)
+        r = try_all_item_scores(e)
+        return e if r is None else r
+
+    def __radd__(self, o):
+        from ._compose import try_all_item_scores
+        e = Expr("add", o, self)
+        r = try_all_item_scores(e)
+        return e if r is None else r
+
+    def __sub__(self, o): return Expr("sub", self, o)
+    def __rsub__(self, o): return Expr("sub", o, self)
+    def __mul__(self, o): return Expr("mul", self, o)
+    def __rmul__(self, o): return Expr("mul", o, self)
+    def __neg__(self): return Expr("neg", self)
+
+    # ---- anything that looks at the values gets the host array
+    def numpy(self):
+        if self._host is None:
+            from .._lazy import active_tape
+            if active_tape() is not None:
+                from ._compose import host_fallback
+                host_fallback("arithmetic on looked-up rows")
+            a = [host(x) for x in self.args]
+            op, kw = self.op, self.kw
+            if op == "add": v = a[0] + a[1]
+            elif op == "sub": v = a[0] - a[1]
+            elif op == "mul": v = a[0] * a[1]
+            elif op == "neg": v = -a[0]
+            elif op == "square": v = np.square(a[0])
+            elif op == "reduce_sum": v = np.sum(a[0], axis=kw.get("axis"), keepdims=kw.get("keepdims", False), dtype=np.float32)
+            elif op == "maximum": v = np.maximum(a[0], a[1])
+            elif op == "expand_dims": v = np.expand_dims(a[0], kw["axis"])
+            elif op == "squeeze": v = np.squeeze(a[0], axis=kw.get("axis"))
+            elif op == "reshape": v = np.reshape(a[0], kw["shape"])
+            elif op == "dense1": v = a[1] @ self.args[0].layers[0].kernel.read()
+            else: raise NotImplementedError(op)
+            self._host = np.asarray(v, np.float32)
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def __float__(self):
+        return float(self.numpy())
+
+    @property
+    def shape(self):
+        return self.numpy().shape
+
+    def __getitem__(self, k):
+        return self.numpy()[k]
+
+    def __repr__(self):
+        return f"<Expr {self.op}>"
+
+
+# ------------------------------------------------------------------ the TensorFlow ops that build / end a tree
+def square(x):
+    return Expr("square", x) if is_lazy(x) else np.square(np.asarray(x))
+
+
+def reduce_sum(x, axis=None, keepdims=False):
+    if not is_lazy(x):
+        return np.sum(np.asarray(x), axis=axis, keepdims=keepdims)
+    e = Expr("reduce_sum", x, axis=axis, keepdims=keepdims)
+    if axis is None:
+        from ._compose import try_ucml_loss
+        r = try_ucml_loss(e)
+        if r is not None:
+            return r
+    return e
+
+
+def maximum(a, b):
+    return Expr("maximum", a, b) if (is_lazy(a) or is_lazy(b)) else np.maximum(np.asarray(a), np.asarray(b))
+
+
+def expand_dims(x, axis):
+    return Expr("expand_dims", x, axis=axis) if is_lazy(x) else np.expand_dims(np.asarray(x), axis)
+
+
+def squeeze(x, axis=None):
+    return Expr("squeeze", x, axis=axis) if is_lazy(x) else np.squeeze(np.asarray(x), axis=axis)
+
+
+class BinaryCrossentropy:
+    """tf.keras.losses.BinaryCrossentropy as gmf.py:20 makes it (from_logits=True, mean over the batch)"""
+
+    def __init__(self, from_logits=False, **_):
+        self.from_logits = from_logits
+
+    def __call__(self, y_true, y_pred, sample_weight=None):
+        if isinstance(y_pred, Expr) and self.from_logits and sample_weight is None:
+            from ._compose import try_gmf_loss
+            r = try_gmf_loss(y_true, y_pred)
+            if r is not None:
+                return r
+        y, x = np.asarray(y_true, np.float32).reshape(-1), host(y_pred).reshape(-1).astype(np.float32)
+        if self.from_logits:
+            return np.float32(np.mean(np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))))
+        eps = 1e-7
+        p = np.clip(x, eps, 1 - eps)
+        return np.float32(np.mean(-(y * np.log(p + eps) + (1 - y) * np.log(1 - p + eps))))

@@ -85,16 +85,26 @@ class GatheredRows:
             raise AttributeError(name)
         return getattr(self.numpy(), name)
 
-    def _bin(op):
+    def _bin(op, name=None):
+        # with another lookup / variable / lazy expression the operation stays symbolic (modules/_expr.py: ucml.py:29-32 and
+        # gmf.py:28 spell their scores out in raw ops); with a number or an array it is the host array's
         def f(self, other):
+            if name is not None:
+                from ._expr import Expr, is_lazy
+                if is_lazy(other):
+                    return Expr(name, self, other)
             return op(self.numpy(), np.asarray(other))
         def r(self, other):
+            if name is not None:
+                from ._expr import Expr, is_lazy
+                if is_lazy(other):
+                    return Expr(name, other, self)
             return op(np.asarray(other), self.numpy())
         return f, r
 
-    __add__, __radd__ = _bin(np.add)
-    __sub__, __rsub__ = _bin(np.subtract)
-    __mul__, __rmul__ = _bin(np.multiply)
+    __add__, __radd__ = _bin(np.add, "add")
+    __sub__, __rsub__ = _bin(np.subtract, "sub")
+    __mul__, __rmul__ = _bin(np.multiply, "mul")
     __truediv__, __rtruediv__ = _bin(np.true_divide)
     __matmul__, __rmatmul__ = _bin(np.matmul)
     del _bin

@@ -51,6 +51,16 @@ class MLP:
         """Forward on the host (weights read back from HBM), WITHOUT gradients: the device paths are the packaged recommenders
         (GMF's fused pointwise step reads and updates `layers[0].kernel` in HBM; DLRM runs its MLPs inside `orx_dlrm_step`).
         Under a GradientTape -- where the caller expects to train through it -- this says so once."""
+        from ._expr import Expr
+        if isinstance(x, Expr) and x.op == "mul" and len(self.layers) == 1 and self.layers[0].units == 1 and not self.layers[0].use_bias \
+                and self.layers[0].activation is None:
+            # gmf.py:28 / :39: Dense(1, no bias) of (user rows * item rows): the fused GMF step / scorer reads this kernel in HBM
+            from .latent_factor import GatheredRows
+            rows = [a for a in x.args if isinstance(a, GatheredRows)] + [a.args[0] for a in x.args if isinstance(a, Expr) and a.op == "expand_dims"
+                                                                          and isinstance(a.args[0], GatheredRows)]
+            if rows:
+                self.build(rows[0].factor.dim, rows[0].factor.table.ctx)
+                return Expr("dense1", self, x)
         from .._lazy import active_tape
         if active_tape() is not None:
             from ._compose import host_fallback

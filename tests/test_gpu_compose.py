@@ -127,6 +127,75 @@ def test_reference_wrmf_class_text_trains_on_the_fused_path():
     assert rel_err(np.asarray(pred), orc.bpr_inference(U, V, b, np.arange(8))) < 1e-4
 
 
+@pytest.mark.parametrize("optk", ["sgd", "adagrad"])
+def test_reference_ucml_class_text_trains_on_the_fused_path(optk):
+    """ucml.py:21-42 spells its score out in raw ops (tf.math.square(user_vec - item_vec) -> reduce_sum -> hinge): the lazy
+    expression tree of modules/_expr.py must match it onto the fused UCML step, censor_vec (ucml.py:44-48) included."""
+    from openrec_amd.tf2.compat import optimizers
+    from oracle import numpy_oracle as orc
+    UCML = _ref_class("ucml.py", "UCML")
+    NU, NI, D, B = 600, 800, 32, 1024
+    model = UCML(dim_user_embed=D, dim_item_embed=D, total_users=NU, total_items=NI, margin=0.7)
+    opt, oo = {"sgd": (optimizers.SGD(0.05), orc.SGD(0.05)), "adagrad": (optimizers.Adagrad(0.05), orc.Adagrad(0.05))}[optk]
+    step = _train_step(model, opt)
+    U, V, b = (v.numpy() for v in model.trainable_variables)
+    U0 = U.copy()
+    rng = np.random.default_rng(8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                   # a host fallback would warn
+        for it in range(4):
+            u, p, n = (rng.integers(0, hi, B).astype(np.int32) for hi in (NU, NI, NI))
+            loss, l2 = step(u, p, n)
+            model.censor_vec(u, p, n)
+            lr, l2r = orc.ucml_step(U, V, b, u, p, n, oo, margin=0.7, do_censor=True)
+            assert abs(float(loss) - lr) <= TOL * abs(lr) and abs(float(l2) - l2r) <= TOL * abs(l2r), it
+        Ud, Vd, bd = (v.numpy() for v in model.trainable_variables)
+        assert rel_err(Ud, U) < TOL and rel_err(Vd, V) < TOL and rel_err(bd, b) < TOL
+        assert np.abs(Ud - U0).max() > 1e-4
+        # inference (ucml.py:50-53): -reduce_sum(square(expand_dims(user_vec, 1) - V), -1) + reshape(b): the device L2 scorer
+        pred = model.inference(np.arange(16, dtype=np.int32))
+    assert pred.shape == (16, NI) and rel_err(np.asarray(pred), orc.ucml_inference(U, V, b, np.arange(16))) < 1e-4
+
+
+def test_reference_gmf_class_text_trains_on_the_fused_path():
+    """gmf.py:22-34: MLP([1], no bias) of (user_vec * item_vec) + item_bias -> Keras BCE with logits; l2 over the lookups and the
+    Dense kernel.  The composition must run as the fused GMF step (the kernel is a device-resident dense parameter)."""
+    from openrec_amd.tf2.compat import optimizers
+    from oracle import numpy_oracle as orc
+    GMF = _ref_class("gmf.py", "GMF")
+    NU, NI, D, B = 500, 700, 32, 2048
+    model = GMF(dim_user_embed=D, dim_item_embed=D, total_users=NU, total_items=NI)
+    opt, oo = optimizers.SGD(0.05), orc.SGD(0.05)
+    step = _train_step(model, opt)
+    rng = np.random.default_rng(9)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                   # a host fallback would warn
+        # an eager call builds the Dense kernel (Keras builds on first use) and is forward-only
+        u, i = rng.integers(0, NU, B).astype(np.int32), rng.integers(0, NI, B).astype(np.int32)
+        lab = (rng.random(B) < 0.4).astype(np.float32)
+        loss, l2 = model(u, i, lab)
+        names = [v.name for v in model.trainable_variables]
+        assert len(names) == 4 and names[:3] == ["user_latent_factor/embeddings", "item_latent_factor/embeddings", "item_bias/embeddings"]
+        U, V, b, w = (v.numpy() for v in model.trainable_variables)
+        assert w.shape == (D, 1)
+        lr, l2r = orc.gmf_forward(U, V, b, w, u, i, lab)[:2]
+        assert abs(float(loss) - lr) <= TOL * abs(lr) and abs(float(l2) - l2r) <= TOL * abs(l2r)
+        W0 = w.copy()
+        for it in range(4):
+            u, i = rng.integers(0, NU, B).astype(np.int32), rng.integers(0, NI, B).astype(np.int32)
+            lab = (rng.random(B) < 0.4).astype(np.float32)
+            loss, l2 = step(u, i, lab)
+            lr, l2r = orc.gmf_step(U, V, b, w, u, i, lab, oo)
+            assert abs(float(loss) - lr) <= TOL * abs(lr) and abs(float(l2) - l2r) <= TOL * abs(l2r), it
+        Ud, Vd, bd, wd = (v.numpy() for v in model.trainable_variables)
+        assert rel_err(Ud, U) < TOL and rel_err(Vd, V) < TOL and rel_err(bd, b) < TOL and rel_err(wd, w) < TOL
+        assert np.abs(wd - W0).max() > 1e-5                              # the Dense kernel trained
+        # inference (gmf.py:36-41): squeeze(mlp(expand_dims(user_vec, 1) * V), -1) + reshape(b): the device GMF scorer
+        pred = model.inference(np.arange(8, dtype=np.int32))
+    want = (U[:8, None, :] * V[None, :, :]) @ w.reshape(-1) + b.reshape(-1)
+    assert pred.shape == (8, NI) and rel_err(np.asarray(pred), want) < 1e-4
+
+
 def test_loss_only_objective_and_host_uses_of_a_lookup():
     """tape.gradient(loss) alone (no l2 term) is the fused step with no_l2; a lookup used as data is the table's rows"""
     from openrec_amd.tf2.compat import tf, optimizers
