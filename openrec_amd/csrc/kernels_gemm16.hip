@@ -225,8 +225,7 @@ static int launch_nt(orx_ctx* ctx, const Nt16Args& g) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr size_t shm = (size_t)2 * (BM + BN) * (64 + PAD) * 2;
     auto kern = gemm16_nt_kernel<WM, WN, TM, TN, MINB, PAD>;
-    static bool attr = false;
-    if (!attr) { ORX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); attr = true; }
+    ORX_ONCE_PER_DEVICE(ctx, ORX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)));
     const unsigned nb = (unsigned)(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN));
     ORX_LAUNCH(ctx, kern, dim3(nb), dim3(64 * WM * WN), shm, g);
     ORX_HIP(hipGetLastError());
@@ -440,8 +439,7 @@ int orx_launch_gemm16_tn(orx_ctx* ctx, const void* A16, int64_t lda, const void*
     Tn16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, slab, M, N, K, kchunk, out_scale};
     constexpr size_t shm = (size_t)2 * 64 * (128 + 16 + 128 + 16) * 2;
     auto kern = gemm16_tn_kernel<2, 2, 4, 4, 2>;
-    static bool attr = false;
-    if (!attr) { ORX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); attr = true; }
+    ORX_ONCE_PER_DEVICE(ctx, ORX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)));
     ORX_LAUNCH(ctx, kern, dim3((unsigned)(tiles * S)), dim3(256), shm, g);
     ORX_HIP(hipGetLastError());
     return ORX_OK;

@@ -373,11 +373,7 @@ int orx_launch_dedup(orx_ctx* ctx, const DedupArgs& a, int64_t K) {
     const int64_t g = K * (a.nbu + a.nbi);
     if (g == 0) return ORX_OK;
     ORX_ARG(g < (1LL << 31), "dedup: grid too large (K=%lld, buckets=%d)", (long long)K, a.nbu + a.nbi);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ORX_HIP(hipFuncSetAttribute((const void*)dedup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DD_LDS_BYTES));
-        attr_set = true;
-    }
+    ORX_ONCE_PER_DEVICE(ctx, ORX_HIP(hipFuncSetAttribute((const void*)dedup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DD_LDS_BYTES)));
     ORX_LAUNCH(ctx, dedup_kernel, dim3((unsigned)g), dim3(DD_THREADS), DD_LDS_BYTES, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;

@@ -442,14 +442,10 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
     ORX_HIP(hipMemsetAsync(a.bcnt, 0, (size_t)kc * (3 * nb + 1) * sizeof(int), ctx->stream));
     const dim3 gp((unsigned)((a.nref + PL_CHUNK - 1) / PL_CHUNK), (unsigned)kc);
     const size_t hist_bytes = (size_t)(3 * nb + 1) * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ORX_HIP(hipFuncSetAttribute((const void*)plan_part_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        ORX_HIP(hipFuncSetAttribute((const void*)plan_part_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        ORX_HIP(hipFuncSetAttribute((const void*)plan_range_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-        ORX_HIP(hipFuncSetAttribute((const void*)plan_range_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-        attr_set = true;
-    }
+    ORX_ONCE_PER_DEVICE(ctx, ORX_HIP(hipFuncSetAttribute((const void*)plan_part_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)));
+    ORX_ONCE_PER_DEVICE(ctx, ORX_HIP(hipFuncSetAttribute((const void*)plan_part_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)));
+    ORX_ONCE_PER_DEVICE(ctx, ORX_HIP(hipFuncSetAttribute((const void*)plan_range_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)));
+    ORX_ONCE_PER_DEVICE(ctx, ORX_HIP(hipFuncSetAttribute((const void*)plan_range_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)));
     ORX_LAUNCH(ctx, (plan_part_kernel<false>), gp, dim3(PL_THREADS), hist_bytes, a);
     ORX_LAUNCH(ctx, (plan_part_kernel<true>), gp, dim3(PL_THREADS), hist_bytes, a);
     const int W = (1 << a.shift) >> 5;

@@ -201,8 +201,7 @@ int orx_launch_score_mfma(orx_ctx* ctx, const float* U, const float* V, const fl
     const size_t lds = ((size_t)(64 * UW + 2 * TI) * pitch + 64 * UW + 4 * TI) * sizeof(float);
     const dim3 g((unsigned)((NI + chunk - 1) / chunk), (unsigned)nqt);
 #define ORX_SC(K, N, W, B) do { \
-        static bool attr = false; \
-        if (!attr) { ORX_HIP(hipFuncSetAttribute((const void*)score_mfma_kernel<K, N, W, B>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr = true; } \
+        ORX_ONCE_PER_DEVICE(ctx, ORX_HIP(hipFuncSetAttribute((const void*)score_mfma_kernel<K, N, W, B>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024))); \
         ORX_LAUNCH(ctx, (score_mfma_kernel<K, N, W, B>), g, dim3(256), lds, a); } while (0)
 #define ORX_SCW(K, B) do { if (UW == 2) ORX_SC(K, 4, 2, B); else ORX_SC(K, 4, 1, B); } while (0)
 #define ORX_SCK(K) do { switch (KB) { case 1: ORX_SCW(K, 1); break; case 2: ORX_SCW(K, 2); break; case 4: ORX_SCW(K, 4); break; \

@@ -161,6 +161,14 @@ struct ProfScope {
     ~ProfScope() { if (c->prof) orx_prof_end(c, k); }
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one bit per device ordinal, per call site
+#define ORX_ONCE_PER_DEVICE(ctx, stmt)                                                  \
+    do {                                                                               \
+        static unsigned long long _done = 0ull;                                        \
+        const unsigned long long _bit = 1ull << ((ctx)->device & 63);                  \
+        if (!(_done & _bit)) { stmt; _done |= _bit; }                                  \
+    } while (0)
+
 #define ORX_LAUNCH(ctx, kernel, grid, block, shm, ...)                                 \
     hipExtLaunchKernelGGL(kernel, grid, block, shm, (ctx)->stream, (ctx)->cur_e0, (ctx)->cur_e1, 0, __VA_ARGS__)
 

@@ -122,6 +122,9 @@ class GradientTape:
             if isinstance(t, L2Sum):
                 st = t.resolve()
                 if st is None or st not in self.steps:
+                    if getattr(t, "scale", 1.0) != 1.0:
+                        raise NotImplementedError(f"tape.gradient: the l2 term is scaled by {t.scale:g}; the fused step takes tf.nn.l2_loss of its "
+                                                  "lookups with weight 1 (the reference's objective, bpr.py:35-37) or not at all (differentiate `loss` alone)")
                     raise NotImplementedError("tape.gradient: this l2 term is not the l2_loss of one recorded step's lookups "
                                               "(bpr.py:35 / wrmf.py:32 sum tf.nn.l2_loss over exactly the looked-up vectors)")
                 flat[i] = LazyScalar(st, 1)

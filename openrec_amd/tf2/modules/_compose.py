@@ -99,6 +99,11 @@ def _tag(step, rows, params=()):
         r._l2_step = step
 
 
+def _consume(*rows):
+    for r in rows:
+        r.consumed()
+
+
 # ---- compositions spelled out in raw ops (modules/_expr.py) ------------------------------------------------------------
 def _node(e, op, n=None):
     from ._expr import Expr
@@ -149,6 +154,7 @@ def try_ucml_loss(e):
         return None
     if not (_same_ids(p.ids, bp.ids) and _same_ids(n.ids, bn.ids)):
         return None
+    _consume(u1, u2, p, n, bp, bn)
     out = composed_model("ucml", U, V, b, margin=float(h.args[0]))(u1.ids, p.ids, n.ids)
     _tag(out[0]._step, (u1, p, n))
     return out[0]
@@ -180,6 +186,7 @@ def try_gmf_loss(label, logit):
     U, V, bb = u.factor, i.factor, b.factor
     if bb.dim != 1 or U.dim != V.dim or bb.num_instances != V.num_instances or not _same_ids(i.ids, b.ids):
         return None
+    _consume(u, i, b)
     out = composed_model("gmf", U, V, bb, mlp=mlp)(u.ids, i.ids, label)
     _tag(out[0]._step, (u, i), params=(mlp.layers[0].kernel,))
     return out[0]
@@ -233,6 +240,7 @@ def pairwise_step_of(user_vec, p_item_vec, n_item_vec, p_item_bias, n_item_bias)
         return None
     if len(np.shape(user_vec.ids) if not hasattr(user_vec.ids, "shape") else user_vec.ids.shape) != 1:
         return None
+    _consume(*rows)
     out = composed_model("bpr", U, V, b)(user_vec.ids, p_item_vec.ids, n_item_vec.ids)
     _tag(out[0]._step, (user_vec, p_item_vec, n_item_vec))
     return out
@@ -245,6 +253,7 @@ def pointwise_step_of(user_vec, item_vec, item_bias, label, a, b):
     U, V, bb = user_vec.factor, item_vec.factor, item_bias.factor
     if bb.dim != 1 or U.dim != V.dim or bb.num_instances != V.num_instances or not _same_ids(item_vec.ids, item_bias.ids):
         return None
+    _consume(*rows)
     out = composed_model("wrmf", U, V, bb, a=float(a), b=float(b))(user_vec.ids, item_vec.ids, label)
     _tag(out[0]._step, (user_vec, item_vec))
     return out
@@ -265,9 +274,18 @@ class L2Sum:
 
     __radd__ = __add__
 
+    def __mul__(self, k):
+        """`l2_reg * tf.nn.l2_loss(vec)`: the value is right, but the fused step takes the l2 term with weight 1 (bpr.py:35-37 sums it
+        unscaled into the objective) or not at all -- tape.gradient says so instead of training with another weight"""
+        out = L2Sum(self.rows, self.extra * float(k), self.params)
+        out.scale = getattr(self, "scale", 1.0) * float(k)
+        return out
+
+    __rmul__ = __mul__
+
     def resolve(self):
         """the recorded step whose l2 term this is: the lookups of ONE loss-module call, each once, nothing added"""
-        if self._step is None and self.extra == 0.0 and self.rows:
+        if self._step is None and self.extra == 0.0 and self.rows and getattr(self, "scale", 1.0) == 1.0:
             st = getattr(self.rows[0], "_l2_step", None)
             want, wantp = getattr(st, "l2_rows", ()), getattr(st, "l2_params", ())
             if st is not None and len(want) == len(self.rows) and all(any(r is w for r in self.rows) for w in want) \
@@ -279,8 +297,8 @@ class L2Sum:
         st = self.resolve()
         if st is not None:
             return np.float32(st.forward()[1])
-        return np.float32(sum(0.5 * float((np.asarray(r, np.float64) ** 2).sum()) for r in self.rows)
-                          + sum(0.5 * float((p.read().astype(np.float64) ** 2).sum()) for p in self.params) + self.extra)
+        return np.float32(getattr(self, "scale", 1.0) * (sum(0.5 * float((np.asarray(r, np.float64) ** 2).sum()) for r in self.rows)
+                                                         + sum(0.5 * float((p.read().astype(np.float64) ** 2).sum()) for p in self.params)) + self.extra)
 
     def __float__(self):
         return float(self.numpy())

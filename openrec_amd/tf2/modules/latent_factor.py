@@ -48,6 +48,7 @@ class GatheredRows:
         self.ids = ids
         self._host = None
         self._l2_step = None
+        factor._pending.add(self)          # TF gathers at call time: see LatentFactor.snapshot_pending
 
     def flat_ids(self):
         i = self.ids
@@ -68,7 +69,12 @@ class GatheredRows:
             if getattr(i, "is_cuda", False):
                 i = i.cpu().numpy()
             self._host = self.factor.table.gather(np.asarray(i).reshape(-1)).reshape(self.shape)
+            self.factor._pending.discard(self)
         return self._host
+
+    def consumed(self):
+        """a loss module turned this lookup into (part of) a fused step: nothing will ever look at its rows on the host"""
+        self.factor._pending.discard(self)
 
     def __array__(self, dtype=None, copy=None):
         a = self.numpy()
@@ -129,6 +135,8 @@ class LatentFactor:
                 seed = _seed_counter[0]
             self.table.init_uniform(-0.05, 0.05, seed)  # Keras 'uniform'      (latent_factor.py:10-11)
         self._var = Variable(self.table, (name or "latent_factor") + "/embeddings")
+        import weakref
+        self._pending = weakref.WeakSet()              # lookups nobody has looked at yet
 
     @property
     def variables(self):
@@ -142,6 +150,16 @@ class LatentFactor:
         return GatheredRows(self, ids)
 
     call = __call__
+
+    def snapshot_pending(self):
+        """Gather every lookup that is still lazy NOW: called when a train step on this table is recorded.  TensorFlow gathers at
+        call time, so `v = lf(ids); train_step(...); np.asarray(v)` must give the PRE-step rows; lookups that a loss module
+        consumed (the five of bpr.py:23-27 ...) are not among them, so the fused path gathers nothing."""
+        for r in list(self._pending):
+            try:
+                r.numpy()
+            except IndexError:
+                self._pending.discard(r)                 # (raised again when somebody looks at it)
 
     def censor(self, censor_id):
         """latent_factor.py:17-23: rows of the DISTINCT ids are divided by max(norm, 0.1)."""

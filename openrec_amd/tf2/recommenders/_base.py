@@ -143,6 +143,8 @@ class Recommender:
                                uid=_ids(user_id))
 
     def _record(self, run_forward, run_train):
+        for lf in (self.user_latent_factor, self.item_latent_factor, self.item_bias):
+            lf.snapshot_pending()               # lookups made before this step see the rows as they are now (TF gathers at call time)
         step = PendingStep(self, run_forward, run_train)
         tape = active_tape()
         if tape is not None:
