@@ -203,6 +203,10 @@ int orx_pointwise_loss(orx_ctx* ctx, int model,
 int orx_score_all_items(orx_ctx* ctx, int kind, orx_table* user, orx_table* item, orx_table* bias, orx_table* w,
                         const int32_t* uid, int64_t n, float* out);
 
+/* orx_score_all_items with the scores left on the device: out_dev device float[n * item_rows]. */
+int orx_score_all_items_device(orx_ctx* ctx, int kind, orx_table* user, orx_table* item, orx_table* bias, orx_table* w,
+                               const int32_t* uid, int64_t n, float* out_dev);
+
 /* Ranking metrics of the evaluation step (openrec/tf2/metrics/ranking_metrics.py:8-69; eval_step in
  * tf2_examples/bpr_citeulike.py:41-46).  For each of n users: scores over ALL items (computed on the
  * device like orx_score_all_items when pred == NULL, else taken from the host array pred[n*items]),
@@ -212,6 +216,16 @@ int orx_rank_metrics(orx_ctx* ctx, int kind, orx_table* user, orx_table* item, o
                      const int32_t* uid, const float* pred, const uint8_t* pos_mask, const uint8_t* excl_mask,
                      int64_t n, int64_t items, const float* at, int32_t nat,
                      float* auc, float* ndcg, float* recall);
+
+/* The same metrics with the two masks as CSR item lists over the call's n users (the form the reference's Dataset holds them
+ * in before openrec/tf2/data/dataset.py:60-82 _evaluation_generator densifies them): pos_ptr / excl_ptr host int64[n + 1]
+ * starting at 0, pos_items / excl_items host int32, each user's list a set (a repeated positive is an error, an id outside
+ * [0, items) an index error).  2 x n x items mask bytes become the lists; results equal orx_rank_metrics on the dense masks.
+ * pred_on_device != 0: pred is device memory (what orx_score_all_items_device wrote). */
+int orx_rank_metrics_csr(orx_ctx* ctx, int kind, orx_table* user, orx_table* item, orx_table* bias, orx_table* w,
+                         const int32_t* uid, const float* pred, int32_t pred_on_device, int64_t n, int64_t items,
+                         const int64_t* pos_ptr, const int32_t* pos_items, const int64_t* excl_ptr, const int32_t* excl_items,
+                         const float* at, int32_t nat, float* auc, float* ndcg, float* recall);
 
 /* ---- on-device triplet sampler: the producer of the train step
  * (openrec/tf2/data/dataset.py:7-16 _pairwise_generator; utils.py:82-87, 102-116).

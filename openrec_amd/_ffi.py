@@ -64,7 +64,9 @@ SIGNATURES = {
                                    c_float, c_float, c_int, _fp, _fp]),
     "orx_pointwise_loss": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, _ip, _fp, c_int64, c_float, c_float, c_int, _fp, _fp]),
     "orx_score_all_items": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, c_int64, _fp]),
+    "orx_score_all_items_device": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, c_int64, _fp]),
     "orx_rank_metrics": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, _fp, _p, _p, c_int64, c_int64, _fp, c_int32, _fp, _fp, _fp]),
+    "orx_rank_metrics_csr": (c_int, [_p, c_int, _p, _p, _p, _p, _ip, _fp, c_int32, c_int64, c_int64, _p, _p, _p, _p, _fp, c_int32, _fp, _fp, _fp]),
     "orx_sampler_create": (c_int, [_p, _ip, _ip, c_int64, _p, _ip, c_int64, c_int64, _pp]),
     "orx_sampler_destroy": (c_int, [_p]),
     "orx_sampler_pairwise": (c_int, [_p, c_uint64, c_int64, c_int64, _ip, _ip, _ip]),

@@ -101,7 +101,7 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_cflag); hipFree(c->d_dupbits); hipFree(c->d_dlist);
+    hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_evalbits); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_cflag); hipFree(c->d_dupbits); hipFree(c->d_dlist);
     hipFree(c->d_dcount); hipFree(c->d_refinfo); hipFree(c->d_tricnt); hipFree(c->d_segstart); hipFree(c->d_alloc); hipFree(c->d_dseg); hipFree(c->d_dcnt); hipFree(c->d_chunks); hipFree(c->d_part); hipFree(c->d_partb); hipFree(c->d_stage); hipFree(c->d_stageb); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
     hipFree(c->d_wpart); hipFree(c->d_pl_cnt); hipFree(c->d_pl_list);
     hipFree(c->d_sort[0]); hipFree(c->d_sort[1]); hipFree(c->d_sort_hist); hipFree(c->d_csr_part[0]); hipFree(c->d_csr_part[1]); hipFree(c->d_splitk);

@@ -1,5 +1,6 @@
 // C-ABI entry points of the sharded building blocks (and, for now, the
 // not-yet-built pointwise step).
+#include <vector>
 #include <cmath>
 #include <cstring>
 
@@ -261,6 +262,26 @@ extern "C" int orx_score_all_items(orx_ctx* c, int kind, orx_table* U, orx_table
     CHECK(stage_ids(c, uid, n, 0));
     CHECK(orx_launch_score_all(c, U->w, V->w, b->w, w ? w->w : nullptr, c->d_ids, n, U->rows, V->rows, U->dim, kind, c->d_tmp));
     ORX_HIP(hipMemcpyAsync(out, c->d_tmp, (size_t)n * V->rows * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return orx_check_index_error(c);
+}
+
+// the same scores left in device memory (out_dev [n, item_rows] fp32): what the metrics of the evaluation step read
+extern "C" int orx_score_all_items_device(orx_ctx* c, int kind, orx_table* U, orx_table* V, orx_table* b, orx_table* w,
+                                          const int32_t* uid, int64_t n, float* out_dev) {
+    if (U) CHECK(orx_table_sync(U));
+    if (V) CHECK(orx_table_sync(V));
+    if (b) CHECK(orx_table_sync(b));
+    if (w) CHECK(orx_table_sync(w));
+    ORX_ARG(c && U && V && b && (n == 0 || (uid && out_dev)), "orx_score_all_items_device: NULL argument");
+    ORX_ARG(kind >= 0 && kind <= 2, "orx_score_all_items_device: unknown kind %d", kind);
+    ORX_ARG(U->dim == V->dim && b->rows == V->rows && b->dim == 1, "orx_score_all_items_device: table shapes do not match");
+    ORX_ARG(kind != 2 || (w && w->rows == U->dim && w->dim == 1), "orx_score_all_items_device: GMF needs w [D, 1]");
+    ORX_ARG(U->dim <= 1024, "orx_score_all_items_device: dim too large for the LDS user tile");
+    if (n == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(c->device));
+    ENSURE(c->d_ids, c->d_ids_cap, (size_t)n * sizeof(int32_t));
+    CHECK(stage_ids(c, uid, n, 0));
+    CHECK(orx_launch_score_all(c, U->w, V->w, b->w, w ? w->w : nullptr, c->d_ids, n, U->rows, V->rows, U->dim, kind, out_dev));
     return orx_check_index_error(c);
 }
 
@@ -748,6 +769,107 @@ extern "C" int orx_rank_metrics(orx_ctx* c, int kind, orx_table* U, orx_table* V
         return ORX_ERR_ARG;
     }
     return orx_check_index_error(c);
+}
+
+// The same metrics with the masks as CSR lists over the call's users (pos_ptr / excl_ptr: host int64[n + 1] starting at 0).
+extern "C" int orx_rank_metrics_csr(orx_ctx* c, int kind, orx_table* U, orx_table* V, orx_table* b, orx_table* w,
+                                    const int32_t* uid, const float* pred, int32_t pred_on_device, int64_t n, int64_t items,
+                                    const int64_t* pos_ptr, const int32_t* pos_items, const int64_t* excl_ptr, const int32_t* excl_items,
+                                    const float* at, int32_t nat, float* auc, float* ndcg, float* recall) {
+    if (U) CHECK(orx_table_sync(U));
+    if (V) CHECK(orx_table_sync(V));
+    if (b) CHECK(orx_table_sync(b));
+    if (w) CHECK(orx_table_sync(w));
+    ORX_ARG(c && pos_ptr && excl_ptr && at && n >= 0 && items > 0, "orx_rank_metrics_csr: NULL argument");
+    ORX_ARG(nat >= 1 && nat <= 16, "orx_rank_metrics_csr: nat must be in [1, 16]");
+    ORX_ARG(pred || (U && V && b && uid), "orx_rank_metrics_csr: need either pred or tables + user ids");
+    ORX_ARG(pred || V->rows == items, "orx_rank_metrics_csr: items must equal the item table's rows");
+    if (n == 0) return ORX_OK;
+    ORX_ARG(pos_ptr[0] == 0 && excl_ptr[0] == 0, "orx_rank_metrics_csr: the lists start at offset 0");
+    int64_t max_pos = 0;
+    for (int64_t q = 0; q < n; ++q) {
+        const int64_t lp = pos_ptr[q + 1] - pos_ptr[q], le = excl_ptr[q + 1] - excl_ptr[q];
+        ORX_ARG(lp >= 0 && le >= 0, "orx_rank_metrics_csr: offsets must not decrease");
+        if (lp > max_pos) max_pos = lp;
+    }
+    const int64_t npos = pos_ptr[n], nexcl = excl_ptr[n];
+    ORX_ARG((npos == 0 || pos_items) && (nexcl == 0 || excl_items), "orx_rank_metrics_csr: NULL item list");
+    ORX_HIP(hipSetDevice(c->device));
+    const size_t cells = (size_t)n * items;
+    const int64_t W = (items + 31) / 32;
+    const bool dev_pred = pred && pred_on_device;
+    const int S = orx_rank_csr_segments(n, items);
+    // one upload: pos_ptr [n+1] | excl_ptr [n+1] (int64) | pos_items | excl_items (int32) | at [16] (float)
+    const size_t up_bytes = 2 * (size_t)(n + 1) * 8 + ((size_t)npos + nexcl + 16) * 4;
+    // one download: auc [n] | ndcg [n nat] | recall [n nat] | error flag
+    const size_t nout = (size_t)n * (1 + 2 * nat) + 1;
+    static thread_local std::vector<char> pack;
+    pack.resize(up_bytes > nout * 4 ? up_bytes : nout * 4);
+    {
+        char* h = pack.data();
+        memcpy(h, pos_ptr, 8 * (size_t)(n + 1)); h += 8 * (size_t)(n + 1);
+        memcpy(h, excl_ptr, 8 * (size_t)(n + 1)); h += 8 * (size_t)(n + 1);
+        if (npos) memcpy(h, pos_items, 4 * (size_t)npos);
+        h += 4 * (size_t)npos;
+        if (nexcl) memcpy(h, excl_items, 4 * (size_t)nexcl);
+        h += 4 * (size_t)nexcl;
+        memset(h, 0, 64); memcpy(h, at, sizeof(float) * nat);
+    }
+    // d_dflag: the upload | partials [n S 136] | n_eval [n] | results [nout];  d_evalbits: the two bitmaps [2 n W], all zero between calls
+    const size_t bytes = up_bytes + ((size_t)n * S * 136 + n + nout) * 4;
+    ENSURE(c->d_dflag, c->d_dflag_cap, bytes);
+    const size_t bit_bytes = 2 * (size_t)n * W * 4;
+    if (bit_bytes > c->d_evalbits_cap) {
+        if (c->d_evalbits) ORX_HIP(hipFree(c->d_evalbits));
+        c->d_evalbits = nullptr; c->d_evalbits_cap = 0;
+        ORX_HIP(hipMalloc((void**)&c->d_evalbits, bit_bytes));
+        c->d_evalbits_cap = bit_bytes;
+        ORX_HIP(hipMemsetAsync(c->d_evalbits, 0, bit_bytes, c->stream));
+    }
+    if (!dev_pred) ENSURE(c->d_tmp, c->d_tmp_cap, cells * sizeof(float));
+    float* d_pred = dev_pred ? const_cast<float*>(pred) : c->d_tmp;
+    int64_t* d_pp = (int64_t*)c->d_dflag; int64_t* d_ep = d_pp + (n + 1);
+    int32_t* d_pi = (int32_t*)(d_ep + (n + 1)); int32_t* d_ei = d_pi + npos;
+    float* d_at = (float*)(d_ei + nexcl);
+    unsigned* d_part = (unsigned*)(d_at + 16); int* d_neval = (int*)(d_part + (size_t)n * S * 136);
+    float* d_auc = (float*)(d_neval + n); float* d_ndcg = d_auc + n; float* d_rec = d_ndcg + (size_t)n * nat;
+    int* d_flag = (int*)(d_rec + (size_t)n * nat);
+    ORX_HIP(hipMemcpyAsync(c->d_dflag, pack.data(), up_bytes, hipMemcpyHostToDevice, c->stream));
+    EvalCsrArgs a;
+    a.pred = d_pred; a.pbits = c->d_evalbits; a.ebits = c->d_evalbits + (size_t)n * W; a.pos_ptr = d_pp; a.pos_items = d_pi;
+    a.excl_ptr = d_ep; a.excl_items = d_ei; a.NI = items; a.W = W; a.at = d_at; a.nat = nat;
+    a.auc = d_auc; a.ndcg = d_ndcg; a.recall = d_rec; a.err = c->d_err; a.part = d_part; a.neval = d_neval; a.S = S;
+    a.flag_out = d_flag; a.q0 = 0;
+    CHECK(orx_launch_mask_bits(c, a, n, 0));
+    if (dev_pred || pred) {
+        if (!dev_pred) ORX_HIP(hipMemcpyAsync(d_pred, pred, cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        CHECK(orx_launch_rank_sweeps(c, a, 0, n, max_pos));
+    } else {
+        ORX_ARG(kind >= 0 && kind <= 2 && U->dim == V->dim && U->dim <= 1024, "orx_rank_metrics_csr: bad scorer arguments");
+        ENSURE(c->d_ids, c->d_ids_cap, (size_t)n * sizeof(int32_t));
+        CHECK(stage_ids(c, uid, n, 0));
+        // (scoring and sweeping slices of the batch on two streams -- a write stream beside a read stream -- was measured and is
+        // slower at every slice count: profiles/r3_eval_notes.txt)
+        CHECK(orx_launch_score_all(c, U->w, V->w, b->w, w ? w->w : nullptr, c->d_ids, n, U->rows, V->rows, U->dim, kind, d_pred));
+        CHECK(orx_launch_rank_sweeps(c, a, 0, n, max_pos));
+    }
+    CHECK(orx_launch_mask_bits(c, a, n, 1));
+    ORX_HIP(hipMemcpyAsync(pack.data(), d_auc, nout * 4, hipMemcpyDeviceToHost, c->stream));
+    ORX_HIP(hipStreamSynchronize(c->stream));
+    const float* r = (const float*)pack.data();
+    if (auc) memcpy(auc, r, sizeof(float) * n);
+    if (ndcg) memcpy(ndcg, r + n, sizeof(float) * n * nat);
+    if (recall) memcpy(recall, r + n + (size_t)n * nat, sizeof(float) * n * nat);
+    int flag; memcpy(&flag, r + nout - 1, sizeof(int));
+    if (flag == 3) {
+        orx_set_error("orx_rank_metrics_csr: a user's positive list repeats an item (the lists are sets)");
+        return ORX_ERR_ARG;
+    }
+    if (flag) {
+        orx_set_error("id out of range: an index in the batch is < 0 or >= the table's row count");
+        return ORX_ERR_INDEX;
+    }
+    return ORX_OK;
 }
 
 // ------------------------------------------------------------- device sampler ---

@@ -50,6 +50,7 @@ struct orx_ctx {
     // staging buffers (grown on demand)
     int32_t* d_ids = nullptr;  size_t d_ids_cap = 0;       // host-id upload
     float* d_lab = nullptr;    size_t d_lab_cap = 0;
+    unsigned* d_evalbits = nullptr; size_t d_evalbits_cap = 0;  // evaluation bitmaps (orx_rank_metrics_csr): all zero between calls
     unsigned char* d_dflag = nullptr; size_t d_dflag_cap = 0;   // [K][2B] duplicate flags (pointwise, censor)
     int32_t* d_ids2 = nullptr; size_t d_ids2_cap = 0;            // [K][3B] ids with the duplicate flag in bit 31
     unsigned char* d_roles = nullptr; size_t d_roles_cap = 0;    // [K][3B] dedup scratch
@@ -534,6 +535,21 @@ struct EvalArgs {
     int* err;
 };
 int orx_launch_rank_metrics(orx_ctx* ctx, const EvalArgs& a, int64_t n);
+struct EvalCsrArgs {
+    const float* pred;            // [n, NI]
+    unsigned* pbits; unsigned* ebits;                 // [n, W] bitmaps built from the lists (ebits = pbits + n W)
+    const int64_t* pos_ptr; const int32_t* pos_items; // CSR over the n users of the call
+    const int64_t* excl_ptr; const int32_t* excl_items;
+    int64_t NI, W;
+    const float* at; int nat;
+    float* auc; float* ndcg; float* recall;
+    unsigned* part; int* neval; int S; int* flag_out;
+    int64_t q0;                                       // first user of this launch (slices of the batch)                // per-(user, segment) partial counts [n][S][136]; evaluated items per user
+    int* err;
+};
+int orx_rank_csr_segments(int64_t n, int64_t NI);
+int orx_launch_mask_bits(orx_ctx* ctx, const EvalCsrArgs& a, int64_t n, int clear);
+int orx_launch_rank_sweeps(orx_ctx* ctx, const EvalCsrArgs& a, int64_t q0, int64_t nq, int64_t max_pos);
 
 // kernels_sampler.hip (on-device triplet sampler)
 struct SamplerArgs {

@@ -322,14 +322,101 @@ def pointwise_loss(model, user, item, bias, w, uid, iid, label, a=1.0, b_w=1.0):
     return float(loss[0]), float(l2[0])
 
 
-def score_all_items(kind, user, item, bias, uid, w=None):
-    """Recommender.inference: scores of the given users against ALL items -> [n, item_rows]."""
+class _HostView(np.lib.mixins.NDArrayOperatorsMixin):
+    """An array kept in another form (device memory, item lists) that turns into its NumPy value when someone looks:
+    `np.asarray(x)`, `x.numpy()`, indexing, arithmetic and any ndarray attribute all go through `_dense()`."""
+    _host = None
+
+    def numpy(self):
+        if self._host is None:
+            self._host = self._dense()
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        return getattr(ufunc, method)(*[x.numpy() if isinstance(x, _HostView) else x for x in inputs], **kw)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, i):
+        return self.numpy()[i]
+
+    def __iter__(self):
+        return iter(self.numpy())
+
+    def __getattr__(self, name):                       # (only reached for what the class does not define)
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self.numpy(), name)
+
+    ndim = 2
+
+
+class DeviceScores(_HostView):
+    """[n, items] fp32 scores of `Recommender.inference` held in device memory (a torch tensor).  The metrics read them there;
+    the host copy (4 bytes x n x items over PCIe) is made only if the script looks at the values."""
+    dtype = np.dtype(np.float32)
+
+    def __init__(self, ctx, tensor):
+        self.ctx, self.tensor, self.shape = ctx, tensor, tuple(tensor.shape)
+
+    def _dense(self):
+        return self.tensor.cpu().numpy()
+
+
+class SparseMask(_HostView):
+    """A batch of boolean item masks [n, items] as one sorted list of distinct items per row (CSR): what
+    `Dataset.evaluation` hands out instead of the dense rows of openrec/tf2/data/dataset.py:60-82.  Dense on demand."""
+    dtype = np.dtype(bool)
+
+    def __init__(self, ptr, items, n_items):
+        self.ptr = np.ascontiguousarray(ptr, np.int64); self.items = np.ascontiguousarray(items, np.int32)
+        self.shape = (self.ptr.size - 1, int(n_items))
+
+    @classmethod
+    def from_lists(cls, lists, n_items):
+        rows = [np.unique(np.asarray(r, np.int64)) for r in lists]
+        for r in rows:
+            if r.size and (r[0] < 0 or r[-1] >= n_items):
+                raise IndexError(f"item id outside [0, {n_items})")
+        ptr = np.zeros(len(rows) + 1, np.int64); np.cumsum([r.size for r in rows], out=ptr[1:])
+        return cls(ptr, np.concatenate(rows).astype(np.int32) if rows else np.zeros(0, np.int32), n_items)
+
+    @classmethod
+    def from_dense(cls, mask):
+        m = np.asarray(mask).astype(bool)
+        r, c = np.nonzero(m)
+        ptr = np.zeros(m.shape[0] + 1, np.int64); np.cumsum(np.bincount(r, minlength=m.shape[0]), out=ptr[1:])
+        return cls(ptr, c.astype(np.int32), m.shape[1])
+
+    def row(self, q):
+        return self.items[self.ptr[q]:self.ptr[q + 1]]
+
+    def _dense(self):
+        m = np.zeros(self.shape, bool)
+        m[np.repeat(np.arange(self.shape[0]), np.diff(self.ptr)), self.items] = True
+        return m
+
+
+def score_all_items(kind, user, item, bias, uid, w=None, device=False):
+    """Recommender.inference: scores of the given users against ALL items -> [n, item_rows] (host array, or with
+    `device=True` a DeviceScores that stays in HBM until someone reads it)."""
     lib = user.ctx._lib
     ptr, n, dev, keep = _ids_arg(uid)
     if dev:
         raise ValueError("score_all_items takes host ids")
-    out = np.empty((n, item.rows), np.float32)
     k = {"dot": 0, "l2": 1, "gmf": 2}[kind]
+    if device:
+        import torch
+        out = torch.empty((n, item.rows), dtype=torch.float32, device=torch.device("cuda", user.ctx.device))
+        check(lib.orx_score_all_items_device(user.ctx._h, k, user._h, item._h, bias._h, w._h if w is not None else None,
+                                             ptr, n, out.data_ptr()))
+        return DeviceScores(user.ctx, out)
+    out = np.empty((n, item.rows), np.float32)
     check(lib.orx_score_all_items(user.ctx._h, k, user._h, item._h, bias._h, w._h if w is not None else None,
                                   ptr, n, out.ctypes.data))
     return out
@@ -455,6 +542,33 @@ def rank_metrics(pos_mask, excl_mask, at, pred=None, kind=None, user=None, item=
         check(c._lib.orx_rank_metrics(c._h, k, user._h, item._h, bias._h, w._h if w is not None else None, ptr, None,
                                       pos.ctypes.data, excl.ctypes.data, n, items, atv.ctypes.data, atv.size,
                                       auc.ctypes.data, ndcg.ctypes.data, rec.ctypes.data))
+    return dict(auc=auc, ndcg=ndcg, recall=rec)
+
+
+def rank_metrics_csr(pos, excl, at, pred=None, kind=None, user=None, item=None, bias=None, w=None, uid=None, ctx=None):
+    """`rank_metrics` with the masks as SparseMask (item lists): nothing of size n x items crosses PCIe when the scores are
+    on the device (`pred` a DeviceScores, or None with the tables + user ids)."""
+    assert isinstance(pos, SparseMask) and isinstance(excl, SparseMask) and pos.shape == excl.shape
+    n, items = pos.shape
+    atv = np.ascontiguousarray(at, np.float32).reshape(-1)
+    c = ctx or (user.ctx if user is not None else (pred.ctx if isinstance(pred, DeviceScores) else default_context()))
+    auc = np.empty(n, np.float32); ndcg = np.empty((n, atv.size), np.float32); rec = np.empty((n, atv.size), np.float32)
+    tail = (n, items, pos.ptr.ctypes.data, pos.items.ctypes.data, excl.ptr.ctypes.data, excl.items.ctypes.data,
+            atv.ctypes.data, atv.size, auc.ctypes.data, ndcg.ctypes.data, rec.ctypes.data)
+    if pred is not None:
+        if isinstance(pred, DeviceScores):
+            assert pred.shape == (n, items)
+            head = (pred.tensor.data_ptr(), 1)
+        else:
+            pr = np.ascontiguousarray(pred, np.float32)
+            assert pr.shape == (n, items)
+            head = (pr.ctypes.data, 0)
+        check(c._lib.orx_rank_metrics_csr(c._h, 0, None, None, None, None, None, *head, *tail))
+    else:
+        ptr, nn, dev, keep = _ids_arg(uid)
+        assert nn == n and not dev
+        k = {"dot": 0, "l2": 1, "gmf": 2}[kind]
+        check(c._lib.orx_rank_metrics_csr(c._h, k, user._h, item._h, bias._h, w._h if w is not None else None, ptr, None, 0, *tail))
     return dict(auc=auc, ndcg=ndcg, recall=rec)
 
 

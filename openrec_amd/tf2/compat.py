@@ -299,7 +299,7 @@ class _AllItemScores:
         bias = getattr(other, "flat_of", None)
         if isinstance(bias, Variable) and bias.table.dim == 1 and bias.table.rows == self.item_var.table.rows:
             ids = self.rows.flat_ids()
-            return HostTensor(rt.score_all_items("dot", self.rows.factor.table, self.item_var.table, bias.table, ids))
+            return rt.score_all_items("dot", self.rows.factor.table, self.item_var.table, bias.table, ids, device=True)
         return HostTensor(np.asarray(self) + np.asarray(other))
 
     __radd__ = __add__

@@ -197,7 +197,7 @@ class _BatchIterator:
                 break
         if n == 0:
             return None
-        return {k: np.asarray(c, dtype=d) for k, c, d in zip(self.keys, cols, self.dtypes)}
+        return {k: d(c) if callable(d) and not isinstance(d, type) else np.asarray(c, dtype=d) for k, c, d in zip(self.keys, cols, self.dtypes)}
 
     def _produce(self, gen):
         while True:
@@ -248,20 +248,27 @@ class Dataset:
                               ("user_id", "item_id", "label"), (np.int32, np.int32, np.float32), batch_size, take)
 
     def evaluation(self, batch_size, excl_datasets=[]):
+        """dataset.py:60-82 / :161-176.  The masks of a batch are `SparseMask` objects (one sorted item list per user -- what
+        the index holds; the metrics take them as lists and `np.asarray(mask)` gives the reference's dense bool rows).  With
+        explicit negatives the exclusion mask is "everything but the labelled items" and stays a dense array."""
+        from ...runtime import SparseMask
         ix = self.datastore
+        dense_excl = ix.contain_negatives()
 
         def gen():
             for u in ix.warm_users():
-                pos = np.zeros(ix.total_items, bool)
-                pos[ix.positive_items(u)] = True
-                if ix.contain_negatives():
+                pos = np.unique(np.asarray(ix.positive_items(u), np.int64))
+                if dense_excl:
                     excl = np.ones(ix.total_items, bool)
-                    excl[ix.positive_items(u)] = False
+                    excl[pos] = False
                     excl[ix.negative_items(u)] = False
+                    for d in excl_datasets:
+                        excl[d.datastore.positive_items(u)] = True
                 else:
-                    excl = np.zeros(ix.total_items, bool)
-                for d in excl_datasets:
-                    excl[d.datastore.positive_items(u)] = True
+                    excl = [x for d in excl_datasets for x in d.datastore.positive_items(u)]
                 yield u, pos, excl
 
-        return _BatchIterator([gen()], ("user_id", "pos_mask", "excl_mask"), (np.int32, bool, bool), batch_size, None)
+        def lists(rows):
+            return SparseMask.from_lists(rows, ix.total_items)
+        return _BatchIterator([gen()], ("user_id", "pos_mask", "excl_mask"),
+                              (np.int32, lists, bool if dense_excl else lists), batch_size, None)

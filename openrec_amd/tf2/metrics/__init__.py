@@ -13,16 +13,24 @@ def _host(x, dtype):
     return np.ascontiguousarray(x, dtype=dtype)
 
 
+def _rank(pos_mask, pred, excl_mask, at):
+    """Item-list masks (what `Dataset.evaluation` yields) go to the device as lists, and scores that `inference` left in
+    device memory are read there; dense masks / host scores take the byte-mask entry point."""
+    if isinstance(pos_mask, rt.SparseMask) and isinstance(excl_mask, rt.SparseMask):
+        return rt.rank_metrics_csr(pos_mask, excl_mask, at, pred=pred if isinstance(pred, rt.DeviceScores) else _host(pred, np.float32))
+    return rt.rank_metrics(_host(pos_mask, np.uint8), _host(excl_mask, np.uint8), at, pred=_host(pred, np.float32))
+
+
 def AUC(pos_mask, pred, excl_mask):
-    return rt.rank_metrics(_host(pos_mask, np.uint8), _host(excl_mask, np.uint8), [1.0], pred=_host(pred, np.float32))["auc"]
+    return _rank(pos_mask, pred, excl_mask, [1.0])["auc"]
 
 
 def NDCG(pos_mask, pred, excl_mask, at=[100]):
-    return rt.rank_metrics(_host(pos_mask, np.uint8), _host(excl_mask, np.uint8), at, pred=_host(pred, np.float32))["ndcg"]
+    return _rank(pos_mask, pred, excl_mask, at)["ndcg"]
 
 
 def Recall(pos_mask, pred, excl_mask, at=[100]):
-    return rt.rank_metrics(_host(pos_mask, np.uint8), _host(excl_mask, np.uint8), at, pred=_host(pred, np.float32))["recall"]
+    return _rank(pos_mask, pred, excl_mask, at)["recall"]
 
 
 class DictMean:

@@ -224,8 +224,7 @@ def try_all_item_scores(e):
     rows, item_var = ui
     if item_var.table.rows != bias.table.rows or rows.factor.dim != item_var.table.dim:
         return None
-    from ..compat import HostTensor
-    return HostTensor(rt.score_all_items(kind, rows.factor.table, item_var.table, bias.table, rows.flat_ids(), w=w))
+    return rt.score_all_items(kind, rows.factor.table, item_var.table, bias.table, rows.flat_ids(), w=w, device=True)
 
 
 def pairwise_step_of(user_vec, p_item_vec, n_item_vec, p_item_bias, n_item_bias):

@@ -136,11 +136,15 @@ class Recommender:
 
     def evaluate(self, user_id, pos_mask, excl_mask, at=(100,)):
         """Beyond the reference API: `eval_step` of tf2_examples/bpr_citeulike.py:41-46 as one device call
-        (all-item scores + AUC / NDCG / Recall; the [B, n_items] score matrix never reaches the host)."""
+        (all-item scores + AUC / NDCG / Recall; the [B, n_items] score matrix never reaches the host).  The masks as
+        `Dataset.evaluation` yields them (item lists, `rt.SparseMask`) go over as lists; dense masks are accepted too
+        (both as lists when they are sparse enough to be worth the host-side nonzero)."""
         U, V, b = self._tables()
         w = self.mlp.layers[0].kernel if self._score_kind == "gmf" else None
-        return rt.rank_metrics(pos_mask, excl_mask, list(at), kind=self._score_kind, user=U, item=V, bias=b, w=w,
-                               uid=_ids(user_id))
+        kw = dict(kind=self._score_kind, user=U, item=V, bias=b, w=w, uid=_ids(user_id))
+        if isinstance(pos_mask, rt.SparseMask) and isinstance(excl_mask, rt.SparseMask):
+            return rt.rank_metrics_csr(pos_mask, excl_mask, list(at), **kw)
+        return rt.rank_metrics(pos_mask, excl_mask, list(at), **kw)
 
     def _record(self, run_forward, run_train):
         for lf in (self.user_latent_factor, self.item_latent_factor, self.item_bias):

@@ -17,4 +17,4 @@ class BPR(PairwiseRecommender):
     def inference(self, user_id):
         """bpr.py:39-43:  U[user_id] @ V^T + b  -> [B, total_items]."""
         U, V, b = self._tables()
-        return rt.score_all_items("dot", U, V, b, _ids(user_id))
+        return rt.score_all_items("dot", U, V, b, _ids(user_id), device=True)

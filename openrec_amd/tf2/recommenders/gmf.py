@@ -23,4 +23,4 @@ class GMF(PointwiseRecommender):
     def inference(self, user_id):
         """gmf.py:36-41:  sum_d w_d u_d V_d + b."""
         U, V, b = self._tables()
-        return rt.score_all_items("gmf", U, V, b, _ids(user_id), w=self.mlp.layers[0].kernel)
+        return rt.score_all_items("gmf", U, V, b, _ids(user_id), w=self.mlp.layers[0].kernel, device=True)

@@ -24,4 +24,4 @@ class UCML(PairwiseRecommender):
     def inference(self, user_id):
         """ucml.py:50-53:  -||U[user] - V||^2 + b  -> [B, total_items]."""
         U, V, b = self._tables()
-        return rt.score_all_items("l2", U, V, b, _ids(user_id))
+        return rt.score_all_items("l2", U, V, b, _ids(user_id), device=True)

@@ -19,4 +19,4 @@ class WRMF(PointwiseRecommender):
     def inference(self, user_id):
         """wrmf.py:36-40:  U[user_id] @ V^T + b."""
         U, V, b = self._tables()
-        return rt.score_all_items("dot", U, V, b, _ids(user_id))
+        return rt.score_all_items("dot", U, V, b, _ids(user_id), device=True)

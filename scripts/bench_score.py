@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--kind", default="dot")
     ap.add_argument("--simple", action="store_true", help="the round-1 VALU kernel (ORX_SCORE_SIMPLE)")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--evaluate", action="store_true", help="also time the evaluation step end to end (scores + AUC + Recall)")
+    ap.add_argument("--pos", type=int, default=10); ap.add_argument("--excl", type=int, default=200)
     args = ap.parse_args()
     if args.simple:
         os.environ["ORX_SCORE_SIMPLE"] = "1"
@@ -42,7 +44,28 @@ def main():
     us = p["total_ms"] / p["launches"] * 1e3
     pairs = args.users * args.items
     alg = pairs * 4 + args.items * (args.dim + 1) * 4 + args.users * args.dim * 4
-    print(json.dumps({"metric": "all-item scoring, user-item pairs/s", "value": pairs / (us * 1e-6), "kernel_us": us,
+    ev = None
+    if args.evaluate:
+        # eval_step end to end (tf2_examples/bpr_citeulike.py:41-46): scores + AUC + Recall@{50,100} for `users` users, the
+        # masks as item lists (`--pos` positives, `--excl` excluded items per user), wall clock of the host call
+        rng = np.random.default_rng(1)
+        pos = rt.SparseMask.from_lists([rng.choice(args.items, args.pos, replace=False) for _ in range(args.users)], args.items)
+        excl = rt.SparseMask.from_lists([rng.choice(args.items, args.excl, replace=False) for _ in range(args.users)], args.items)
+        kw = dict(kind=args.kind, user=U, item=V, bias=b, w=w, uid=uid)
+        rt.rank_metrics_csr(pos, excl, [50, 100], **kw)
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            r = rt.rank_metrics_csr(pos, excl, [50, 100], **kw)
+        ev = {"evaluate_ms": (time.perf_counter() - t0) / args.reps * 1e3, "positives_per_user": args.pos, "excluded_per_user": args.excl,
+              "auc_mean": float(np.nanmean(r["auc"])), "masks": "item lists -> device bitmaps (orx_rank_metrics_csr)"}
+        if args.users * args.items <= 200_000_000:          # the byte-mask entry point for comparison where the masks fit comfortably
+            pd, ed = np.asarray(pos), np.asarray(excl)
+            rt.rank_metrics(pd, ed, [50, 100], **kw)
+            t0 = time.perf_counter()
+            r2 = rt.rank_metrics(pd, ed, [50, 100], **kw)
+            ev["evaluate_ms_byte_masks"] = (time.perf_counter() - t0) * 1e3
+            ev["same_auc"] = bool(np.array_equal(r["auc"], r2["auc"], equal_nan=True))
+    print(json.dumps({"evaluate": ev, "metric": "all-item scoring, user-item pairs/s", "value": pairs / (us * 1e-6), "kernel_us": us,
                       "config": {"workload": f"{args.kind} {args.users} users x {args.items} items x dim {args.dim}",
                                  "kernel": "score_all_kernel (VALU)" if args.simple else "score_mfma_kernel"},
                       "roofline": {"bound": "hbm", "achieved": alg / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",

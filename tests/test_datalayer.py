@@ -1,6 +1,7 @@
 """Index work, bit-exact against the reference's own data layer (run under a stub
 `tensorflow` by tests/golden/make_golden_datalayer.py; fixture committed)."""
 import numpy as np
+import pytest
 
 from conftest import load_golden
 
@@ -66,3 +67,29 @@ def test_take_and_parallel_producers():
     for b in batches:                                  # negatives are never positives of that user
         for u, n in zip(b["user_id"], b["n_item_id"]):
             assert not ds.datastore.is_positive(u, n)
+
+
+def test_evaluation_masks_are_item_lists():
+    """The masks of an evaluation batch are SparseMask objects: dense on demand, and the lists are what goes to the device."""
+    from openrec_amd.tf2.data import Dataset
+    from openrec_amd.runtime import SparseMask
+    g = load_golden("datalayer.npz")
+    NU, NI = int(g["NU"]), int(g["NI"])
+    train = Dataset(_raw(g, "raw2_user", "raw2_item"), NU, NI, seed=1)
+    val = Dataset(_raw(g), NU, NI, seed=1)
+    b = next(val.evaluation(batch_size=16, excl_datasets=[train]))
+    for k in ("pos_mask", "excl_mask"):
+        m = b[k]
+        assert isinstance(m, SparseMask) and m.shape == (16, NI) and m.dtype == bool
+        d = np.asarray(m)
+        assert d.dtype == bool and d.shape == (16, NI) and int(d.sum()) == m.items.size == int(m.sum())
+        for q in range(16):
+            r = m.row(q)
+            assert np.array_equal(r, np.nonzero(d[q])[0]) and np.all(np.diff(r) > 0)      # sorted, distinct
+        back = SparseMask.from_dense(d)
+        assert np.array_equal(back.ptr, m.ptr) and np.array_equal(back.items, m.items)
+    assert np.array_equal(b["pos_mask"][3], np.asarray(b["pos_mask"])[3]) and (~b["pos_mask"]).shape == (16, NI)
+    with pytest.raises(IndexError):
+        SparseMask.from_lists([[1, NI]], NI)
+    rep = SparseMask.from_lists([[4, 2, 4, 2], []], 7)                                       # repeats collapse: a mask is a set
+    assert np.array_equal(rep.items, [2, 4]) and np.array_equal(rep.ptr, [0, 2, 2])
