@@ -264,6 +264,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hogwild", action="store_true", help="racy non-reference mode (never the headline)")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded engine even on one GPU (debug)")
+    ap.add_argument("--shard-dedup", choices=["auto", "on", "off"], default="auto",
+                    help="per-destination dedup of the sharded engine's item requests (auto: by list length vs items)")
     ap.add_argument("--zipf", type=float, default=0.0, help="item ids ~ Zipf(alpha) instead of uniform (secondary workload)")
     ap.add_argument("--host-ids", action="store_true",
                     help="hand the ids over as host buffers (the C ABI stages them over PCIe inside the timed call); "
@@ -352,7 +354,8 @@ def main():
     else:
         from openrec_amd import sharded
         eng = sharded.ShardedPairwise(args.model, args.opt, args.users, args.items, args.dim, lr=lr,
-                                      rank=rank, world=world, device=device, seed=0)
+                                      rank=rank, world=world, device=device, seed=0,
+                                      dedup={"auto": None, "on": True, "off": False}[args.shard_dedup])
         eng.force_collectives = dist is not None
         uid, pid, nid = make_ids(torch, args.users, args.items, K + W, args.batch, 1234 + rank, device)
         if W:

@@ -372,16 +372,67 @@ int orx_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int32_t worl
  * counters[world] scratch, overflow[1] sticky flag (a bucket was full: that id is dropped) */
 int orx_shard_bucket(orx_ctx* ctx, const int32_t* ids, int64_t n, int32_t world, int32_t cap,
                      int32_t* send_ids, int32_t* slot, int32_t* counters, int32_t* overflow);
+/* orx_shard_request_steps with PER-DESTINATION DEDUP: an item that several references of a list ask for claims one slot of its
+ * owner's bucket (its row travels once, the sum of the references' gradients travels back).  The distinct items of an owner fill
+ * its bucket in ascending row order (a stable sort of the references by (owner, row): deterministic).  Outputs besides
+ * send_ids / slot / u_loc: dupref[K][2T] = 1 on the references that share their slot; sorted_out [K][2T] x 8 bytes (the sorted
+ * (key, reference) list), seglist [K][T] x 8 bytes and segcount [K] (the shared slots): opaque, handed back to orx_shard_grads.
+ * items_global: rows of the global item table. */
+int orx_shard_request_dedup_steps(orx_ctx* ctx, const int32_t* trip, int64_t K, int64_t T, int32_t world, int32_t cap,
+                                  int64_t items_global, int32_t* send_ids, int32_t* slot, int32_t* u_loc, uint8_t* dupref,
+                                  void* sorted_out, void* seglist, int32_t* segcount, int32_t* overflow);
+/* dupref == NULL: every reference has a slot of its own.  Otherwise the list's outputs of orx_shard_request_dedup_steps and a side
+ * buffer gdup [2T][row_stride]: references that share a slot leave their gradients there and a second launch writes the slot's
+ * SUM, taken in reference order (no atomics: the result does not depend on timing). */
 int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const float* rows_in, const int32_t* u_loc,
-                    const int32_t* slot, int64_t T, int64_t row_stride, int64_t B_global, float margin, int flags,
+                    const int32_t* slot, const uint8_t* dupref, const void* sorted, const void* seglist, const int32_t* segcount,
+                    float* gdup, int64_t T, int64_t row_stride, int64_t B_global, float margin, int flags,
                     float* gu, float* send_g, double* loss_l2_accum);
 /* orx_shard_grads with SGD's apply of the local user rows folded in (row-sharded BPR / UCML step, phases 4 + 5 of
  * openrec_amd/sharded.py; the reference's single-process apply is tf2_examples/bpr_citeulike.py:38): a user row referenced
  * once in the step is updated in place; the references of a duplicated row leave gu[t] and u_apply[t] = local row for
  * orx_apply_rows_flagged (u_apply[t] = -1 elsewhere).  dup_u[T]: orx_rows_dupflags of u_loc. */
 int orx_shard_grads_sgd(orx_ctx* ctx, int model, orx_opt* opt, orx_table* user, const float* rows_in, const int32_t* u_loc,
-                        const int32_t* slot, const uint8_t* dup_u, int64_t T, int64_t row_stride, int64_t B_global,
+                        const int32_t* slot, const uint8_t* dupref, const void* sorted, const void* seglist, const int32_t* segcount,
+                        float* gdup, const uint8_t* dup_u, int64_t T, int64_t row_stride, int64_t B_global,
                         float margin, int flags, float* gu, int32_t* u_apply, float* send_g, double* loss_l2_accum);
+
+/* ---- the row-sharded pairwise step as one host call (the single-process step it shards is
+ * tf2_examples/bpr_citeulike.py:27-39).  Row r of every table lives on rank r % world at local index r / world; the ranks'
+ * batches together are ONE global batch (loss mean over world * B).  An orx_comm wraps an RCCL communicator (librccl.so is
+ * loaded at run time by orx_comm_create; the exchanges are ncclSend / ncclRecv groups on the context's stream) and owns the
+ * exchange buffers of the engine.
+ *   orx_comm_unique_id : rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means
+ *   orx_comm_create    : collective over the ranks (ncclCommInitRank).  unique_id == NULL with world 1: a one-rank
+ *                        communicator without RCCL (every exchange is the identity)
+ *   orx_sharded_pairwise_steps : K steps of this rank's uid / pid / nid [K][id_stride] (DEVICE int32, B ids per step) on its
+ *                        shards U / V / b.  The exchange plan (triplets -> owner of the user row, item ids -> owners) is made
+ *                        for plan_chunk steps at a time with one exchange per phase; a step is then gather -> exchange (rows)
+ *                        -> gradients -> apply users -> exchange (gradients) -> apply items.  Buckets have a fixed capacity
+ *                        (mean * slack + 6 sigma + 16, orx_sharded_caps): `overflow` (device int, sticky) reports a full one.
+ *                        loss_l2_accum: device double[2], this rank's (sum of loss, sum of l2_loss) contributions are added.
+ *                        flags: ORX_NO_L2; ORX_SHARD_OVERLAP (needs id_stride == B, B even, a communicator with RCCL): every
+ *                        step is cut into two half-batches whose exchanges run on a second stream beside the other half's
+ *                        kernels.  Same results as the per-phase entry points driven by openrec_amd/sharded.py. */
+#define ORX_COMM_ID_BYTES 128
+#define ORX_SHARD_OVERLAP 0x100
+#define ORX_SHARD_NO_DEDUP 0x200   /* every item reference claims a slot of its own (orx_shard_request_steps) */
+#define ORX_SHARD_DEDUP 0x400      /* per-destination dedup of the item requests (orx_shard_request_dedup_steps); neither flag: on
+                                    * when a list's item references number at least half the items (most slots are then shared) */
+typedef struct orx_comm orx_comm;
+int orx_comm_unique_id(void* id_out);
+int orx_comm_create(orx_ctx* ctx, const void* unique_id, int32_t rank, int32_t world, orx_comm** out);
+int orx_comm_destroy(orx_comm* comm);
+int orx_comm_rank(orx_comm* comm);
+int orx_comm_world(orx_comm* comm);
+int orx_sharded_caps(int64_t B, int32_t world, float slack, int64_t* cap1, int64_t* cap2);
+/* the regrouping the engine applies around the plan's exchanges: src [K][world][words] -> dst [world][K][words] 4-byte words
+ * (back != 0: the inverse); device pointers */
+int orx_shard_regroup(orx_ctx* ctx, const void* src, void* dst, int64_t K, int32_t world, int64_t words, int back);
+int orx_sharded_pairwise_steps(orx_comm* comm, orx_opt* opt, int model, orx_table* user, orx_table* item, orx_table* bias,
+                               const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t K, int64_t B, int64_t id_stride,
+                               int64_t users_global, int64_t items_global, float margin, float slack, int32_t plan_chunk,
+                               int flags, double* loss_l2_accum, int32_t* overflow);
 
 /* ---- device-time sampling of the kernels (HIP events on the ctx stream) --- */
 int orx_prof_enable(orx_ctx* ctx, int on);

@@ -15,6 +15,7 @@ ORX_SGD, ORX_ADAGRAD, ORX_ADAM = 0, 1, 2
 ORX_BPR, ORX_UCML = 0, 1
 ORX_GMF, ORX_WRMF = 0, 1
 ORX_IDS_DEVICE, ORX_HOGWILD, ORX_NO_L2, ORX_CENSOR = 1, 2, 4, 8
+ORX_SHARD_OVERLAP, ORX_SHARD_NO_DEDUP, ORX_SHARD_DEDUP, ORX_COMM_ID_BYTES = 0x100, 0x200, 0x400, 128
 ORX_DLRM_INTERACT_ITSELF, ORX_DLRM_SIGMOID_BOT, ORX_DLRM_SIGMOID_TOP, ORX_DLRM_LOSS_BCE, ORX_DLRM_REFERENCE_COMPAT = 1, 2, 4, 8, 16
 ORX_DLRM_FP16_MLP = 32
 ORX_DLRM_NO_EMB = 64
@@ -90,11 +91,21 @@ SIGNATURES = {
     "orx_shard_route": (c_int, [_p, _ip, _ip, _ip, c_int64, c_int64, c_int64, c_int32, c_int32, _ip, _ip, _ip]),
     "orx_shard_request": (c_int, [_p, _ip, c_int64, c_int32, c_int32, _ip, _ip, _ip, _ip, _ip]),
     "orx_shard_localize": (c_int, [_p, _ip, c_int64, c_int32, _ip]),
+    "orx_comm_unique_id": (c_int, [_p]),
+    "orx_comm_create": (c_int, [_p, _p, c_int32, c_int32, _pp]),
+    "orx_comm_destroy": (c_int, [_p]),
+    "orx_comm_rank": (c_int, [_p]),
+    "orx_comm_world": (c_int, [_p]),
+    "orx_sharded_caps": (c_int, [c_int64, c_int32, c_float, _p, _p]),
+    "orx_shard_regroup": (c_int, [_p, _p, _p, c_int64, c_int32, c_int64, c_int]),
+    "orx_sharded_pairwise_steps": (c_int, [_p, _p, c_int, _p, _p, _p, _ip, _ip, _ip, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                           c_float, c_float, c_int32, c_int, _p, _ip]),
     "orx_shard_route_steps": (c_int, [_p, _ip, _ip, _ip, c_int64, c_int64, c_int64, c_int64, c_int64, c_int32, c_int32, _ip, _ip, _ip]),
     "orx_shard_request_steps": (c_int, [_p, _ip, c_int64, c_int64, c_int32, c_int32, _ip, _ip, _ip, _ip, _ip]),
     "orx_shard_bucket": (c_int, [_p, _ip, c_int64, c_int32, c_int32, _ip, _ip, _ip, _ip]),
-    "orx_shard_grads": (c_int, [_p, c_int, _p, _fp, _ip, _ip, c_int64, c_int64, c_int64, c_float, c_int, _fp, _fp, _p]),
-    "orx_shard_grads_sgd": (c_int, [_p, c_int, _p, _p, _fp, _ip, _ip, _p, c_int64, c_int64, c_int64, c_float, c_int, _fp, _ip, _fp, _p]),
+    "orx_shard_grads": (c_int, [_p, c_int, _p, _fp, _ip, _ip, _p, _p, _p, _ip, _fp, c_int64, c_int64, c_int64, c_float, c_int, _fp, _fp, _p]),
+    "orx_shard_grads_sgd": (c_int, [_p, c_int, _p, _p, _fp, _ip, _ip, _p, _p, _p, _ip, _fp, _p, c_int64, c_int64, c_int64, c_float, c_int, _fp, _ip, _fp, _p]),
+    "orx_shard_request_dedup_steps": (c_int, [_p, _ip, c_int64, c_int64, c_int32, c_int32, c_int64, _ip, _ip, _ip, _p, _p, _p, _ip, _ip]),
     "orx_prof_enable": (c_int, [_p, c_int]),
     "orx_prof_reset": (c_int, [_p]),
     "orx_prof_get": (c_int, [_p, c_int, POINTER(c_double), POINTER(c_int64)]),

@@ -640,6 +640,35 @@ extern "C" int orx_shard_request_steps(orx_ctx* ctx, const int32_t* trip, int64_
     return orx_launch_shard_request(ctx, a, K);
 }
 
+// orx_shard_request_steps with per-destination dedup: an item several references of a list ask for claims ONE slot.
+// slot[r] of those references is the same, dupref[r] = 1 marks them (their gradients are added into the slot: orx_shard_grads);
+// the distinct items of an owner fill its bucket in ascending row order.
+extern "C" int orx_shard_request_dedup_steps(orx_ctx* ctx, const int32_t* trip, int64_t K, int64_t T, int32_t world, int32_t cap,
+                                             int64_t items_global, int32_t* send_ids, int32_t* slot, int32_t* u_loc,
+                                             uint8_t* dupref, void* sorted_out, void* seglist, int32_t* segcount, int32_t* overflow) {
+    ORX_ARG(ctx && trip && send_ids && slot && u_loc && dupref && sorted_out && seglist && segcount && overflow, "orx_shard_request_dedup_steps: NULL argument");
+    ORX_ARG(world >= 1 && world <= 64 && cap >= 1 && K >= 0 && K < 65536 && items_global > 0, "orx_shard_request_dedup_steps: world in [1, 64], cap positive, K < 65536");
+    if (K == 0 || T == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(ctx->device));
+    ORX_HIP(hipMemsetAsync(send_ids, 0xFF, (size_t)K * world * cap * sizeof(int32_t), ctx->stream));
+    DedupReqArgs a;
+    memset(&a, 0, sizeof(a));
+    a.trip = trip; a.T = T; a.world = world; a.cap = cap; a.Lr = (items_global + world - 1) / world;
+    a.nchunk = (int)((2 * T + 1023) / 1024);
+    // scratch: keys [K][2T] | uq [K][2T] | chunkcnt [K][nchunk] | ostart [K][64]
+    ENSURE(ctx->d_tmp, ctx->d_tmp_cap, ((size_t)K * 2 * T * 2 + (size_t)K * (a.nchunk + 64)) * sizeof(int32_t));
+    a.keys = (int32_t*)ctx->d_tmp; a.uq = a.keys + (size_t)K * 2 * T; a.chunkcnt = a.uq + (size_t)K * 2 * T; a.ostart = a.chunkcnt + (size_t)K * a.nchunk;
+    a.send_ids = send_ids; a.slot = slot; a.u_loc = u_loc; a.dupref = dupref; a.overflow = overflow;
+    a.seglist = (int2*)seglist; a.segcount = segcount;
+    CHECK(orx_launch_shard_keys(ctx, a, K));
+    const uint2* sorted = nullptr;
+    CHECK(orx_rows_sort(ctx, a.keys, K, 2 * T, 2 * T, (int64_t)world * a.Lr, &sorted));
+    // (the context's sort buffers are reused by the next sort -- the applies of the steps sort too: the plan keeps a copy)
+    ORX_HIP(hipMemcpyAsync(sorted_out, sorted, (size_t)K * 2 * T * sizeof(uint2), hipMemcpyDeviceToDevice, ctx->stream));
+    a.sorted = (const uint2*)sorted_out;
+    return orx_launch_shard_dedup_slots(ctx, a, K);
+}
+
 extern "C" int orx_shard_request(orx_ctx* ctx, const int32_t* trip, int64_t T, int32_t world, int32_t cap,
                                  int32_t* send_ids, int32_t* slot, int32_t* u_loc, int32_t* counters, int32_t* overflow) {
     ORX_ARG(ctx && trip && send_ids && slot && u_loc && counters && overflow, "orx_shard_request: NULL argument");
@@ -671,7 +700,8 @@ extern "C" int orx_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, i
 }
 
 extern "C" int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const float* rows_in, const int32_t* u_loc,
-                               const int32_t* slot, int64_t T, int64_t row_stride, int64_t B_global, float margin, int flags,
+                               const int32_t* slot, const uint8_t* dupref, const void* sorted, const void* seglist, const int32_t* segcount,
+                               float* gdup, int64_t T, int64_t row_stride, int64_t B_global, float margin, int flags,
                                float* gu, float* send_g, double* loss_l2_accum) {
     if (user && u_loc) CHECK(orx_table_touch(user, u_loc, T));        // a lazy table: the user rows read here are brought up to date
     ORX_ARG(ctx && user && rows_in && u_loc && slot && gu && send_g, "orx_shard_grads: NULL argument");
@@ -681,13 +711,15 @@ extern "C" int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const f
     ORX_HIP(hipSetDevice(ctx->device));
     ShardGradArgs a;
     memset(&a, 0, sizeof(a));
-    a.U = user->w; a.rows_in = rows_in; a.u_loc = u_loc; a.slot = slot; a.gu = gu; a.send_g = send_g;
+    a.U = user->w; a.rows_in = rows_in; a.u_loc = u_loc; a.slot = slot; a.gu = gu; a.send_g = send_g; a.dupref = dupref; a.gdup = gdup;
     a.T = T; a.D = user->dim; a.DS = (int)row_stride;
     a.invB = 1.0f / (float)B_global; a.margin = margin; a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f;
     ENSURE(ctx->d_partial, ctx->d_partial_cap, (size_t)(T + 4) * 2 * sizeof(float));
     a.partial = ctx->d_partial;
     int nw = 0;
+    ORX_ARG(!dupref || (sorted && seglist && segcount && gdup), "orx_shard_grads: dedup needs the plan's sorted list, segment list and a side buffer");
     CHECK(orx_launch_shard_grads(ctx, model, a, &nw));
+    if (dupref) CHECK(orx_launch_shard_segsum(ctx, (const int2*)seglist, segcount, (const uint2*)sorted, 2 * T, gdup, send_g, (int)row_stride));
     if (loss_l2_accum) CHECK(orx_launch_loss_accumulate(ctx, ctx->d_partial, nw, loss_l2_accum));
     return ORX_OK;
 }
@@ -696,7 +728,8 @@ extern "C" int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const f
 // place by the gradient kernel, the references of duplicated rows leave (u_apply[t] = local row, gu[t] = gradient) for
 // orx_apply_rows_flagged; u_apply[t] = -1 everywhere else.  dup_u: the flags orx_rows_dupflags made for u_loc.
 extern "C" int orx_shard_grads_sgd(orx_ctx* ctx, int model, orx_opt* opt, orx_table* user, const float* rows_in, const int32_t* u_loc,
-                                   const int32_t* slot, const uint8_t* dup_u, int64_t T, int64_t row_stride, int64_t B_global,
+                                   const int32_t* slot, const uint8_t* dupref, const void* sorted, const void* seglist, const int32_t* segcount,
+                                   float* gdup, const uint8_t* dup_u, int64_t T, int64_t row_stride, int64_t B_global,
                                    float margin, int flags, float* gu, int32_t* u_apply, float* send_g, double* loss_l2_accum) {
     ORX_ARG(ctx && opt && user && rows_in && u_loc && slot && dup_u && gu && u_apply && send_g, "orx_shard_grads_sgd: NULL argument");
     ORX_ARG(opt->kind == ORX_SGD, "orx_shard_grads_sgd: the folded apply is SGD's (Adagrad / Adam sum duplicates first: orx_shard_grads + orx_apply_rows)");
@@ -707,14 +740,16 @@ extern "C" int orx_shard_grads_sgd(orx_ctx* ctx, int model, orx_opt* opt, orx_ta
     ORX_HIP(hipSetDevice(ctx->device));
     ShardGradArgs a;
     memset(&a, 0, sizeof(a));
-    a.U = user->w; a.rows_in = rows_in; a.u_loc = u_loc; a.slot = slot; a.gu = gu; a.send_g = send_g;
+    a.U = user->w; a.rows_in = rows_in; a.u_loc = u_loc; a.slot = slot; a.gu = gu; a.send_g = send_g; a.dupref = dupref; a.gdup = gdup;
     a.T = T; a.D = user->dim; a.DS = (int)row_stride;
     a.invB = 1.0f / (float)B_global; a.margin = margin; a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f;
     a.fu = dup_u; a.Uw = user->w; a.lr = opt->lr; a.u_apply = u_apply;
     ENSURE(ctx->d_partial, ctx->d_partial_cap, (size_t)(T + 4) * 2 * sizeof(float));
     a.partial = ctx->d_partial;
     int nw = 0;
+    ORX_ARG(!dupref || (sorted && seglist && segcount && gdup), "orx_shard_grads: dedup needs the plan's sorted list, segment list and a side buffer");
     CHECK(orx_launch_shard_grads(ctx, model, a, &nw));
+    if (dupref) CHECK(orx_launch_shard_segsum(ctx, (const int2*)seglist, segcount, (const uint2*)sorted, 2 * T, gdup, send_g, (int)row_stride));
     if (loss_l2_accum) CHECK(orx_launch_loss_accumulate(ctx, ctx->d_partial, nw, loss_l2_accum));
     return ORX_OK;
 }

@@ -488,6 +488,168 @@ __global__ __launch_bounds__(1024) void shard_request_kernel(RequestArgs a) {
     a.u_loc[t] = (live && gp >= 0 && gn >= 0) ? u / a.world : -1;
 }
 
+// 2'. the same request plan with PER-DESTINATION DEDUP: an item asked for by several references of this rank's step travels
+// once (its row comes back once, the references' gradients are added into one slot before they leave).  Deterministic: the
+// references are sorted by (owner, local row) -- orx_rows_sort, stable in the reference index -- and the distinct keys of an owner
+// fill its bucket in ascending order.
+__global__ __launch_bounds__(256) void shard_keys_kernel(DedupReqArgs a) {
+    const int64_t k = blockIdx.y, r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * a.T) return;
+    const int64_t t = r < a.T ? r : r - a.T;
+    const int32_t* tr = a.trip + (k * a.T + t) * 3;
+    const int u = tr[0], id = tr[r < a.T ? 1 : 2];
+    a.keys[k * 2 * a.T + r] = u >= 0 ? (int32_t)((int64_t)(id % a.world) * a.Lr + id / a.world) : -1;
+}
+
+// Distinct keys of a sorted list, in parallel over chunks of 1024 entries (grid (chunks, lists)):
+//   heads    : number of segment heads per chunk                       -> chunkcnt[k][c]
+//   scan     : exclusive prefix of the chunk counts, one wave per list (in place)
+//   uniq     : uq[i] = index of entry i's key among the list's distinct keys; ostart[k][o] = that index at owner o's first key
+//   slots    : slot / dupref / send_ids of every reference; the segments of shared slots (slot, first entry) -> seglist
+//   live     : a triplet lives if both of its requests found a slot
+__device__ __forceinline__ bool dd_head(const uint2* sorted, int64_t i, int64_t n, uint32_t sentinel, uint32_t* key_out, uint32_t* prev_out) {
+    const uint32_t key = i < n ? sorted[i].x : 0xffffffffu;
+    const uint32_t prev = (i > 0 && i < n) ? sorted[i - 1].x : 0xffffffffu;
+    *key_out = key; *prev_out = prev;
+    return i < n && key < sentinel && (i == 0 || key != prev);
+}
+
+__global__ __launch_bounds__(1024) void shard_dd_heads_kernel(DedupReqArgs a) {
+    __shared__ int wsum[16];
+    const int64_t k = blockIdx.y, n = 2 * a.T, i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    uint32_t key, prev;
+    const bool head = dd_head(a.sorted + k * n, i, n, (uint32_t)((int64_t)a.world * a.Lr), &key, &prev);
+    const int c = __popcll(__ballot(head));
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; a.chunkcnt[k * a.nchunk + blockIdx.x] = t; }
+}
+
+__global__ __launch_bounds__(64) void shard_dd_scan_kernel(DedupReqArgs a) {
+    int* p = a.chunkcnt + (int64_t)blockIdx.x * a.nchunk;
+    const int lane = threadIdx.x;
+    int carry = 0;
+    for (int b0 = 0; b0 < a.nchunk; b0 += 64) {
+        const int c = b0 + lane < a.nchunk ? p[b0 + lane] : 0;
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        if (b0 + lane < a.nchunk) p[b0 + lane] = carry + incl - c;
+        carry += __shfl(incl, 63);
+    }
+    if (lane == 0) a.segcount[blockIdx.x] = 0;
+}
+
+__global__ __launch_bounds__(1024) void shard_dd_uniq_kernel(DedupReqArgs a) {
+    __shared__ int wsum[16];
+    const int64_t k = blockIdx.y, n = 2 * a.T, i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t sentinel = (uint32_t)((int64_t)a.world * a.Lr);
+    uint32_t key, prev;
+    const bool head = dd_head(a.sorted + k * n, i, n, sentinel, &key, &prev);
+    const unsigned long long m = __ballot(head);
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int before = a.chunkcnt[k * a.nchunk + blockIdx.x];
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    const int u = before + __popcll(m & ((2ull << lane) - 1ull)) - 1;       // heads up to and including this entry, minus one
+    if (i < n && key < sentinel) a.uq[k * n + i] = u;
+    if (head && (i == 0 || prev / (uint32_t)a.Lr != key / (uint32_t)a.Lr)) a.ostart[k * 64 + key / (uint32_t)a.Lr] = u;
+}
+
+__global__ __launch_bounds__(256) void shard_dd_slots_kernel(DedupReqArgs a) {
+    const int64_t k = blockIdx.y, n = 2 * a.T, i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint2* sorted = a.sorted + k * n;
+    int32_t* slot = a.slot + k * n; unsigned char* dupref = a.dupref + k * n;
+    const uint32_t sentinel = (uint32_t)((int64_t)a.world * a.Lr);
+    const uint2 e = i < n ? sorted[i] : make_uint2(0xffffffffu, 0u);
+    const bool live = i < n && e.x < sentinel;
+    if (i < n && !live) slot[e.y] = -1;
+    const uint32_t prev = (live && i > 0) ? sorted[i - 1].x : 0xffffffffu, next = (live && i + 1 < n) ? sorted[i + 1].x : 0xffffffffu;
+    const int o = live ? (int)(e.x / (uint32_t)a.Lr) : 0;
+    const int j = live ? a.uq[k * n + i] - a.ostart[k * 64 + o] : 0;
+    const bool shared = live && (e.x == prev || e.x == next);
+    const int s_ = (live && j < a.cap) ? o * a.cap + j : -1;
+    if (live) {
+        // ONE scattered store per reference (the un-sorting is what this kernel costs): the shared flag rides in bit 30 of the
+        // slot until shard_dd_live_kernel, reading by reference index, splits it off into dupref
+        slot[e.y] = s_ < 0 ? (shared ? -2 : -1) : (s_ | (shared ? 0x40000000 : 0));
+        if (s_ < 0) *a.overflow = 1;
+        else if (e.x != prev) a.send_ids[k * (int64_t)a.world * a.cap + s_] = (int32_t)((e.x % (uint32_t)a.Lr) * (uint32_t)a.world + (uint32_t)o);
+    }
+    // the shared slots: (slot, first sorted entry) for the segment sums.  One atomic per wavefront (same-address atomics serialize);
+    // the ORDER of this list does not reach any sum.
+    const bool lead = s_ >= 0 && e.x != prev && shared && a.seglist != nullptr;
+    const unsigned long long m = __ballot(lead);
+    if (m) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&a.segcount[k], __popcll(m));
+        base = __shfl(base, leader);
+        if (lead) a.seglist[k * a.T + base + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(s_, (int)i);
+    }
+}
+
+__global__ __launch_bounds__(256) void shard_dd_live_kernel(DedupReqArgs a) {
+    const int64_t k = blockIdx.y, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.T) return;
+    const int u = a.trip[(k * a.T + t) * 3];
+    int32_t* slot = a.slot + k * 2 * a.T; unsigned char* dupref = a.dupref + k * 2 * a.T;
+    const int rp = slot[t], rn = slot[a.T + t];
+    const int sp = rp < 0 ? -1 : (rp & 0x3fffffff), sn = rn < 0 ? -1 : (rn & 0x3fffffff);
+    slot[t] = sp; slot[a.T + t] = sn;
+    dupref[t] = (rp == -2 || (rp >= 0 && (rp & 0x40000000))) ? 1 : 0;
+    dupref[a.T + t] = (rn == -2 || (rn >= 0 && (rn & 0x40000000))) ? 1 : 0;
+    a.u_loc[k * a.T + t] = (u >= 0 && sp >= 0 && sn >= 0) ? u / a.world : -1;
+}
+
+// The gradients of the references that share a slot, summed in the order of the reference index (the sorted list is stable): one
+// wavefront per shared slot, rows of DS floats read from the side buffer the gradient kernel left them in (row = reference index).
+__global__ __launch_bounds__(256) void shard_segsum_kernel(const int2* seglist, const int* segcount, const uint2* sorted, int64_t n,
+                                                           const float* gdup, float* send_g, int DS, int G) {
+    // a group of G lanes per shared slot (G = the power of two >= DS / 4, at most 64), float4 columns
+    const int lane = threadIdx.x & 63, sub = lane % G, grp = lane / G, per_wave = 64 / G;
+    const int nseg = *segcount, C4 = DS / 4;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t sgi = wave * per_wave + grp; sgi < nseg; sgi += nwaves * per_wave) {
+        const int2 sg = seglist[sgi];
+        const uint32_t key = sorted[sg.y].x;
+        for (int c = sub; c < C4; c += G) {
+            f4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
+            for (int64_t i = sg.y; i < n && sorted[i].x == key; ++i)
+                acc = acc + *reinterpret_cast<const f4*>(gdup + (int64_t)sorted[i].y * DS + 4 * c);
+            *reinterpret_cast<f4*>(send_g + (int64_t)sg.x * DS + 4 * c) = acc;
+        }
+    }
+}
+
+int orx_launch_shard_segsum(orx_ctx* ctx, const int2* seglist, const int* segcount, const uint2* sorted, int64_t n, const float* gdup, float* send_g, int DS) {
+    int G = 1;
+    while (G < DS / 4 && G < 64) G *= 2;
+    ORX_LAUNCH(ctx, shard_segsum_kernel, dim3(1024), dim3(256), 0, seglist, segcount, sorted, n, gdup, send_g, DS, G);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_launch_shard_keys(orx_ctx* ctx, const DedupReqArgs& a, int64_t K) {
+    if (a.T == 0 || K == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, shard_keys_kernel, dim3((unsigned)((2 * a.T + 255) / 256), (unsigned)K), dim3(256), 0, a);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_launch_shard_dedup_slots(orx_ctx* ctx, const DedupReqArgs& a, int64_t K) {
+    if (a.T == 0 || K == 0) return ORX_OK;
+    const int64_t n = 2 * a.T;
+    ORX_LAUNCH(ctx, shard_dd_heads_kernel, dim3((unsigned)a.nchunk, (unsigned)K), dim3(1024), 0, a);
+    ORX_LAUNCH(ctx, shard_dd_scan_kernel, dim3((unsigned)K), dim3(64), 0, a);
+    ORX_LAUNCH(ctx, shard_dd_uniq_kernel, dim3((unsigned)a.nchunk, (unsigned)K), dim3(1024), 0, a);
+    ORX_LAUNCH(ctx, shard_dd_slots_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)K), dim3(256), 0, a);
+    ORX_LAUNCH(ctx, shard_dd_live_kernel, dim3((unsigned)((a.T + 255) / 256), (unsigned)K), dim3(256), 0, a);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
 // local row ids of a received id list: id / world (or -1)
 __global__ void shard_localize_kernel(const int32_t* ids, int64_t n, int world, int32_t* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -511,9 +673,9 @@ __global__ __launch_bounds__(256) void shard_grads_kernel(ShardGradArgs a) {
         const int sp = a.slot[t], sn = a.slot[a.T + t];
         const int ul = a.u_loc[t];
         if (ul < 0) {                    // empty slot, or a triplet dropped by a bucket overflow:
-            f4 z; z.x = z.y = z.z = z.w = 0.0f;                     // its surviving request gets a zero gradient
-            if (sp >= 0) { *reinterpret_cast<f4*>(a.send_g + (int64_t)sp * a.DS + 4 * sub) = z; if (sub == 0) a.send_g[(int64_t)sp * a.DS + D] = 0.f; }
-            if (sn >= 0) { *reinterpret_cast<f4*>(a.send_g + (int64_t)sn * a.DS + 4 * sub) = z; if (sub == 0) a.send_g[(int64_t)sn * a.DS + D] = 0.f; }
+            f4 z; z.x = z.y = z.z = z.w = 0.0f;                     // its surviving request gets a zero gradient (in the side buffer if the slot is shared)
+            if (sp >= 0) { float* o = (a.dupref && a.dupref[t]) ? a.gdup + t * a.DS : a.send_g + (int64_t)sp * a.DS; *reinterpret_cast<f4*>(o + 4 * sub) = z; if (sub == 0) o[D] = 0.f; }
+            if (sn >= 0) { float* o = (a.dupref && a.dupref[a.T + t]) ? a.gdup + (a.T + t) * a.DS : a.send_g + (int64_t)sn * a.DS; *reinterpret_cast<f4*>(o + 4 * sub) = z; if (sub == 0) o[D] = 0.f; }
             if (APPLY && sub == 0) a.u_apply[t] = -1;
             continue;
         }
@@ -538,9 +700,14 @@ __global__ __launch_bounds__(256) void shard_grads_kernel(ShardGradArgs a) {
         } else {
             *reinterpret_cast<f4*>(a.gu + t * D + 4 * sub) = gu;
         }
-        *reinterpret_cast<f4*>(a.send_g + (int64_t)sp * a.DS + 4 * sub) = gp;
-        *reinterpret_cast<f4*>(a.send_g + (int64_t)sn * a.DS + 4 * sub) = gn;
-        if (sub == 0) { a.send_g[(int64_t)sp * a.DS + D] = gbp; a.send_g[(int64_t)sn * a.DS + D] = gbn; }
+        // a reference that shares its slot leaves its gradient in the side buffer (row = reference index): shard_segsum_kernel adds
+        // the rows of a slot in reference order
+        const bool dp = a.dupref && a.dupref[t], dn = a.dupref && a.dupref[a.T + t];
+        float* op = dp ? a.gdup + t * a.DS : a.send_g + (int64_t)sp * a.DS;
+        float* on = dn ? a.gdup + (a.T + t) * a.DS : a.send_g + (int64_t)sn * a.DS;
+        *reinterpret_cast<f4*>(op + 4 * sub) = gp;
+        *reinterpret_cast<f4*>(on + 4 * sub) = gn;
+        if (sub == 0) { op[D] = gbp; on[D] = gbn; }
     }
     const float ls = wave_sum(loss_acc);
     const float sq = wave_sum(sq_acc);

@@ -515,8 +515,26 @@ struct ShardGradArgs {
     // SGD with the user apply folded in (orx_shard_grads_sgd): duplicate flags of the u_loc list, writable table, rate,
     // and the id list left for the flagged apply of the duplicated rows (-1: already applied)
     const unsigned char* fu; float* Uw; float lr; int32_t* u_apply;
+    // per-destination dedup of the requests (orx_shard_request_dedup_steps): references that share a slot add their gradients
+    // into it (send_g zeroed by the caller); NULL: every reference has a slot of its own
+    const unsigned char* dupref;   // [2T]
+    float* gdup;                   // [2T][DS] side buffer: gradients of the references that share a slot (row = reference index)
 };
 
+struct DedupReqArgs {
+    const int32_t* trip;     // [K][T][3]
+    int64_t T; int world; int cap; int64_t Lr;     // Lr = rows of the item table per rank (ceil(items_global / world))
+    int32_t* keys;           // [K][2T] scratch: owner * Lr + local row of every item reference (p refs, then n refs), -1 dead
+    const uint2* sorted;     // [K][2T] (key, reference) ascending
+    int32_t* uq;             // [K][2T] scratch
+    int* chunkcnt; int nchunk;  // [K][nchunk] heads per chunk of 1024 sorted entries, then their exclusive prefix
+    int* ostart;             // [K][64] index (among the list's distinct keys) of every owner's first key
+    int2* seglist; int* segcount;   // [K][T] (slot, first sorted entry) of the shared slots, [K] their number (NULL: not wanted)
+    int32_t* send_ids; int32_t* slot; int32_t* u_loc; unsigned char* dupref; int* overflow;
+};
+int orx_launch_shard_keys(orx_ctx* ctx, const DedupReqArgs& a, int64_t K);
+int orx_launch_shard_dedup_slots(orx_ctx* ctx, const DedupReqArgs& a, int64_t K);
+int orx_launch_shard_segsum(orx_ctx* ctx, const int2* seglist, const int* segcount, const uint2* sorted, int64_t n, const float* gdup, float* send_g, int DS);
 int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a, int64_t K = 1);
 int orx_launch_shard_request(orx_ctx* ctx, const RequestArgs& a, int64_t K = 1);
 int orx_launch_shard_bucket(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int cap, int32_t* send_ids, int32_t* slot,

@@ -1,0 +1,329 @@
+// The row-sharded pairwise step as ONE host call per K steps: exchange plan, gathers, gradients,
+// applies and the exchanges themselves (RCCL point-to-point groups on the context's stream) run from here, no interpreter between
+// the phases.  The per-phase entry points (orx_shard_*, orx_gather_rows, orx_apply_rows*) stay exported: openrec_amd/sharded.py
+// drives the same sequence over torch.distributed for the gloo tests and the in-process virtual clusters.
+//
+// RCCL is loaded at run time (dlopen of librccl.so in orx_comm_create): the library itself does not link against it, a
+// one-rank communicator made without an id never touches it.
+#include "orx_internal.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+
+#define CHECK(call) do { const int rc_ = (call); if (rc_ != ORX_OK) return rc_; } while (0)
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.handle ? &api : nullptr;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return nullptr;
+#define ORX_SYM(field, name) do { *(void**)(&api.field) = dlsym(h, name); if (!api.field) { dlclose(h); return nullptr; } } while (0)
+    ORX_SYM(GetUniqueId, "ncclGetUniqueId"); ORX_SYM(CommInitRank, "ncclCommInitRank"); ORX_SYM(CommDestroy, "ncclCommDestroy");
+    ORX_SYM(GroupStart, "ncclGroupStart"); ORX_SYM(GroupEnd, "ncclGroupEnd"); ORX_SYM(Send, "ncclSend"); ORX_SYM(Recv, "ncclRecv");
+    ORX_SYM(GetErrorString, "ncclGetErrorString");
+#undef ORX_SYM
+    api.handle = h;
+    return &api;
+}
+
+#define ORX_NCCL(api, expr) do { const ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { \
+        orx_set_error("RCCL: %s failed: %s", #expr, (api)->GetErrorString(r_)); return ORX_ERR_HIP; } } while (0)
+
+// [Kc][N][cw] words <-> [N][Kc][cw] words: the K-step plan's buckets regrouped so that every peer's share is one block
+__global__ __launch_bounds__(256) void shard_regroup_kernel(const uint32_t* src, uint32_t* dst, int Kc, int N, int64_t cw, int back) {
+    const int64_t total = (int64_t)Kc * N * cw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t w = i % cw, blk = i / cw;
+        // forward: dst index i = (p, k, w) reads src (k, p, w); back: dst index i = (k, p, w) reads src (p, k, w)
+        const int64_t a = blk / (back ? N : Kc), b2 = blk % (back ? N : Kc);
+        const int64_t s = back ? ((int64_t)b2 * Kc + a) : ((int64_t)b2 * N + a);
+        dst[i] = src[s * cw + w];
+    }
+}
+
+template <typename W>
+__global__ __launch_bounds__(256) void shard_copy_kernel(const W* src, W* dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+struct Buf { void* p = nullptr; size_t cap = 0; };
+
+}  // namespace
+
+struct orx_comm {
+    orx_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;                           // NULL: a one-rank communicator without RCCL (every exchange is the identity)
+    int rank = 0, world = 1;
+    hipStream_t xstream = nullptr;                       // the exchanges of the overlapped path run here, beside the kernels
+    hipEvent_t ev[8] = {};
+    // the engine's exchange buffers (grown on demand, kept between calls)
+    Buf send1, mine, tmp, cnt, send2, req, req_loc, slot, u_loc, fu, fv, rows_out, rows_in, gu, u_apply, send_g, g_in, dupref, dsorted, seglist, segcount, gdup;
+};
+
+static int ensure(orx_comm* c, Buf& b, size_t bytes) {
+    if (bytes <= b.cap) return ORX_OK;
+    if (b.p) { hipStreamSynchronize(c->ctx->stream); hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    const size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&b.p, want) != hipSuccess) { orx_set_error("sharded engine: out of device memory (%zu bytes)", want); return ORX_ERR_OOM; }
+    b.cap = want;
+    return ORX_OK;
+}
+
+extern "C" int orx_comm_unique_id(void* id_out) {
+    ORX_ARG(id_out, "orx_comm_unique_id: NULL argument");
+    RcclApi* api = rccl_api();
+    ORX_ARG(api, "orx_comm_unique_id: librccl.so could not be loaded");
+    static_assert(sizeof(ncclUniqueId) == ORX_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    ORX_NCCL(api, api->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return ORX_OK;
+}
+
+extern "C" int orx_comm_create(orx_ctx* ctx, const void* unique_id, int32_t rank, int32_t world, orx_comm** out) {
+    ORX_ARG(ctx && out, "orx_comm_create: NULL argument");
+    ORX_ARG(world >= 1 && world <= 64 && rank >= 0 && rank < world, "orx_comm_create: rank %d of world %d (at most 64 ranks)", rank, world);
+    ORX_ARG(unique_id || world == 1, "orx_comm_create: %d ranks need the id that rank 0 made with orx_comm_unique_id", world);
+    ORX_HIP(hipSetDevice(ctx->device));
+    orx_comm* c = new orx_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    if (unique_id) {
+        RcclApi* api = rccl_api();
+        if (!api) { delete c; orx_set_error("orx_comm_create: librccl.so could not be loaded"); return ORX_ERR_ARG; }
+        ncclUniqueId id;
+        memcpy(&id, unique_id, sizeof(id));
+        const ncclResult_t r = api->CommInitRank(&c->comm, world, id, rank);
+        if (r != ncclSuccess) { delete c; orx_set_error("RCCL: ncclCommInitRank failed: %s", api->GetErrorString(r)); return ORX_ERR_HIP; }
+    }
+    *out = c;
+    return ORX_OK;
+}
+
+extern "C" int orx_comm_destroy(orx_comm* c) {
+    if (!c) return ORX_OK;
+    hipSetDevice(c->ctx->device);
+    hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) rccl_api()->CommDestroy(c->comm);
+    if (c->xstream) hipStreamDestroy(c->xstream);
+    for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
+    for (Buf* b : {&c->send1, &c->mine, &c->tmp, &c->cnt, &c->send2, &c->req, &c->req_loc, &c->slot, &c->u_loc, &c->fu, &c->fv,
+                   &c->rows_out, &c->rows_in, &c->gu, &c->u_apply, &c->send_g, &c->g_in, &c->dupref, &c->dsorted, &c->seglist, &c->segcount, &c->gdup})
+        if (b->p) hipFree(b->p);
+    delete c;
+    return ORX_OK;
+}
+
+extern "C" int orx_comm_rank(orx_comm* c) { return c ? c->rank : -1; }
+extern "C" int orx_comm_world(orx_comm* c) { return c ? c->world : -1; }
+
+// all-to-all of equal blocks: peer p gets send[p * bytes .. ), its block lands in recv[p * bytes .. ).  Returns where the result
+// is: `recv`, or `send` itself for a one-rank communicator without RCCL.
+static int exchange(orx_comm* c, const void* send, void* recv, size_t bytes, const void** result, hipStream_t stream = nullptr) {
+    if (!stream) stream = c->ctx->stream;
+    *result = recv;
+    if (!c->comm) { *result = send; return ORX_OK; }
+    // this rank's own block is a copy kernel (RCCL's send-to-self kernel moved 18 MB in 25 us);
+    // ORX_SHARD_RCCL_SELF=1 sends it through RCCL like any other (what the one-rank test uses to exercise ncclSend / ncclRecv)
+    static const bool rccl_self = getenv("ORX_SHARD_RCCL_SELF") && atoi(getenv("ORX_SHARD_RCCL_SELF")) != 0;
+    if (!rccl_self) {
+        const size_t off = (size_t)c->rank * bytes;                // (a kernel, not hipMemcpyAsync: 37 MB in 15 us instead of ~100 us of runtime bookkeeping)
+        ORX_ARG(bytes % 4 == 0, "sharded engine: exchange blocks are 4-byte words");
+        const bool wide = bytes % 16 == 0 && off % 16 == 0;
+        const size_t nw = wide ? bytes / 16 : bytes / 4;
+        const dim3 grid((unsigned)std::min<size_t>((nw + 255) / 256, 2048));
+        if (nw && wide) hipLaunchKernelGGL(shard_copy_kernel<uint4>, grid, dim3(256), 0, stream, (const uint4*)((const char*)send + off), (uint4*)((char*)recv + off), (int64_t)nw);
+        else if (nw) hipLaunchKernelGGL(shard_copy_kernel<uint32_t>, grid, dim3(256), 0, stream, (const uint32_t*)((const char*)send + off), (uint32_t*)((char*)recv + off), (int64_t)nw);
+    }
+    if (c->world == 1 && !rccl_self) return ORX_OK;
+    RcclApi* api = rccl_api();
+    ORX_NCCL(api, api->GroupStart());
+    for (int p = 0; p < c->world; ++p) {
+        if (p == c->rank && !rccl_self) continue;
+        ORX_NCCL(api, api->Send((const char*)send + (size_t)p * bytes, bytes, ncclInt8, p, c->comm, stream));
+        ORX_NCCL(api, api->Recv((char*)recv + (size_t)p * bytes, bytes, ncclInt8, p, c->comm, stream));
+    }
+    ORX_NCCL(api, api->GroupEnd());
+    return ORX_OK;
+}
+
+// the plan's per-step buckets x [Kc][N * cw words] through ONE all-to-all: regroup by peer, exchange, regroup by step
+static int exchange_steps(orx_comm* c, const void* x, void* out, Buf& tmp, int Kc, int64_t cw, const void** result) {
+    if (!c->comm) { *result = x; return ORX_OK; }
+    const int N = c->world;
+    const size_t bytes = (size_t)Kc * N * cw * 4;
+    CHECK(ensure(c, tmp, 2 * bytes));
+    uint32_t* a = (uint32_t*)tmp.p; uint32_t* b = a + (size_t)Kc * N * cw;
+    const unsigned grid = (unsigned)std::min<int64_t>(((int64_t)Kc * N * cw + 255) / 256, 4096);
+    ORX_LAUNCH(c->ctx, shard_regroup_kernel, dim3(grid), dim3(256), 0, (const uint32_t*)x, a, Kc, N, cw, 0);
+    const void* r = nullptr;
+    CHECK(exchange(c, a, b, (size_t)Kc * cw * 4, &r));
+    ORX_LAUNCH(c->ctx, shard_regroup_kernel, dim3(grid), dim3(256), 0, (const uint32_t*)r, (uint32_t*)out, Kc, N, cw, 1);
+    ORX_HIP(hipGetLastError());
+    *result = out;
+    return ORX_OK;
+}
+
+// (exported for the tests: the regrouping of a K-step plan's buckets, [K][world][words] <-> [world][K][words] 4-byte words)
+extern "C" int orx_shard_regroup(orx_ctx* ctx, const void* src, void* dst, int64_t K, int32_t world, int64_t words, int back) {
+    ORX_ARG(ctx && src && dst && K >= 0 && world >= 1 && words >= 0, "orx_shard_regroup: bad argument");
+    if (K * world * words == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(ctx->device));
+    const unsigned grid = (unsigned)std::min<int64_t>((K * world * words + 255) / 256, 4096);
+    ORX_LAUNCH(ctx, shard_regroup_kernel, dim3(grid), dim3(256), 0, (const uint32_t*)src, (uint32_t*)dst, (int)K, (int)world, words, back);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// capacity of one (source, destination) bucket for n elements spread over `world` ranks (openrec_amd/sharded.py::_cap)
+static int64_t bucket_cap(int64_t n, int world, double slack) {
+    const double mean = (double)n / world;
+    return (int64_t)std::ceil(mean * slack + 6.0 * std::sqrt(mean) + 16.0);
+}
+
+extern "C" int orx_sharded_caps(int64_t B, int32_t world, float slack, int64_t* cap1, int64_t* cap2) {
+    ORX_ARG(B > 0 && world >= 1 && cap1 && cap2, "orx_sharded_caps: bad argument");
+    *cap1 = bucket_cap(B, world, slack);
+    *cap2 = bucket_cap(2 * (int64_t)world * *cap1, world, slack);
+    return ORX_OK;
+}
+
+extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, orx_table* U, orx_table* V, orx_table* b,
+                                          const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t K, int64_t B,
+                                          int64_t id_stride, int64_t users_global, int64_t items_global, float margin, float slack,
+                                          int32_t plan_chunk, int flags, double* loss_l2_accum, int32_t* overflow) {
+    ORX_ARG(c && opt && U && V && b && uid && pid && nid && loss_l2_accum && overflow, "orx_sharded_pairwise_steps: NULL argument");
+    ORX_ARG(model == ORX_BPR || model == ORX_UCML, "orx_sharded_pairwise_steps: unknown model %d", model);
+    ORX_ARG(K >= 0 && B > 0 && id_stride >= B && plan_chunk >= 1 && slack >= 1.0f, "orx_sharded_pairwise_steps: bad sizes");
+    ORX_ARG(U->dim == V->dim && b->dim == 1 && b->rows == V->rows, "orx_sharded_pairwise_steps: table shapes do not match");
+    const int D = U->dim;
+    ORX_ARG(D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "orx_sharded_pairwise_steps: dim must be 16/32/64/128/256 (got %d)", D);
+    orx_ctx* ctx = c->ctx;
+    ORX_ARG(U->ctx == ctx && V->ctx == ctx && b->ctx == ctx, "orx_sharded_pairwise_steps: the tables belong to another context");
+    const int N = c->world;
+    ORX_ARG(U->rows >= (users_global - c->rank + N - 1) / N && V->rows >= (items_global - c->rank + N - 1) / N,
+            "orx_sharded_pairwise_steps: the local shards are smaller than rows r = rank (mod world) of the global tables");
+    if (K == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(ctx->device));
+    // Overlap: a step is cut into two half-batches, planned as separate lists, whose exchanges run on a second stream beside the
+    // other half's kernels:   gather A | rows A || gather B | rows B || grads A | g A || grads B | g B || apply U | apply V(A) | apply V(B)
+    // All gathers and gradient kernels of a step still precede its applies (TF's snapshot semantics); the duplicate flags of the apply
+    // lists are taken over both halves together; Adagrad / Adam apply each table once per step from the halves' buffers side by side.
+    const int H = ((flags & ORX_SHARD_OVERLAP) && c->comm && c->world > 1 && B % 2 == 0 && id_stride == B) ? 2 : 1;
+    // Per-destination dedup (an item several references of a list ask for travels once) costs a sort and an un-sort of the
+    // references at plan time (~25 us per step at 131 k references): on by default where the item references a rank handles per list (2 B) are at least
+    // half as many as the items (then most slots are shared), off for sparse lists (1 M items: 6 % of the references repeat)
+    const int Hq = ((flags & ORX_SHARD_OVERLAP) && c->comm && c->world > 1 && B % 2 == 0 && id_stride == B) ? 2 : 1;
+    const bool dedup = (flags & ORX_SHARD_DEDUP) ? true : (flags & ORX_SHARD_NO_DEDUP) ? false : (4 * (B / Hq) >= items_global);
+    const int64_t Bh = B / H;
+    const int64_t cap1 = bucket_cap(Bh, N, slack), T = N * cap1, cap2 = bucket_cap(2 * T, N, slack), M = N * cap2;
+    const int DS = D + 4;                                 // row + bias column, rows stay 16-byte aligned
+    const int64_t B_global = B * N;
+    const bool sgd = opt->kind == ORX_SGD;
+    const int gflags = flags & ORX_NO_L2;
+    orx_table* tabs[3] = {U, V, b};
+    if (H == 2 && !c->xstream) {
+        ORX_HIP(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+        for (hipEvent_t& e : c->ev) ORX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    hipStream_t S = ctx->stream, X = H == 2 ? c->xstream : ctx->stream;
+    for (int64_t k0 = 0; k0 < K; k0 += plan_chunk) {
+        const int Kc = (int)std::min<int64_t>(plan_chunk, K - k0);
+        const int L = Kc * H;                             // lists of this chunk: half h of step k is list H k + h
+        CHECK(ensure(c, c->send1, (size_t)L * T * 3 * 4)); CHECK(ensure(c, c->mine, (size_t)L * T * 3 * 4));
+        CHECK(ensure(c, c->cnt, (size_t)L * N * 4));
+        CHECK(ensure(c, c->send2, (size_t)L * M * 4)); CHECK(ensure(c, c->req, (size_t)L * M * 4)); CHECK(ensure(c, c->req_loc, (size_t)L * M * 4));
+        CHECK(ensure(c, c->slot, (size_t)L * 2 * T * 4)); CHECK(ensure(c, c->u_loc, (size_t)L * T * 4));
+        CHECK(ensure(c, c->rows_out, (size_t)H * M * DS * 4)); CHECK(ensure(c, c->rows_in, (size_t)H * M * DS * 4));
+        CHECK(ensure(c, c->send_g, (size_t)H * M * DS * 4)); CHECK(ensure(c, c->g_in, (size_t)H * M * DS * 4));
+        CHECK(ensure(c, c->gu, (size_t)H * T * D * 4)); CHECK(ensure(c, c->u_apply, (size_t)H * T * 4));
+        if (sgd) { CHECK(ensure(c, c->fu, (size_t)L * T)); CHECK(ensure(c, c->fv, (size_t)L * M)); }
+        if (dedup) {
+            CHECK(ensure(c, c->dupref, (size_t)L * 2 * T)); CHECK(ensure(c, c->dsorted, (size_t)L * 2 * T * 8)); CHECK(ensure(c, c->seglist, (size_t)L * T * 8));
+            CHECK(ensure(c, c->segcount, (size_t)L * 4)); CHECK(ensure(c, c->gdup, (size_t)H * 2 * T * DS * 4));
+        }
+        int32_t* send1 = (int32_t*)c->send1.p; int32_t* cnt = (int32_t*)c->cnt.p; int32_t* send2 = (int32_t*)c->send2.p;
+        int32_t* slot = (int32_t*)c->slot.p; int32_t* u_loc = (int32_t*)c->u_loc.p; int32_t* req_loc = (int32_t*)c->req_loc.p;
+        unsigned char* fu = (unsigned char*)c->fu.p; unsigned char* fv = (unsigned char*)c->fv.p;
+        // ---- the plan of the chunk's lists: routes 1 and 2 depend on the ids alone
+        CHECK(orx_shard_route_steps(ctx, uid + k0 * id_stride, pid + k0 * id_stride, nid + k0 * id_stride, L, Bh, H == 2 ? Bh : id_stride,
+                                    users_global, items_global, N, (int32_t)cap1, send1, cnt, overflow));
+        const void* mine = nullptr;
+        CHECK(exchange_steps(c, send1, c->mine.p, c->tmp, L, cap1 * 3, &mine));                   // 1. triplets -> user owner
+        unsigned char* dupref = dedup ? (unsigned char*)c->dupref.p : nullptr;
+        if (dedup) CHECK(orx_shard_request_dedup_steps(ctx, (const int32_t*)mine, L, T, N, (int32_t)cap2, items_global, send2, slot, u_loc, dupref,
+                                                       c->dsorted.p, c->seglist.p, (int32_t*)c->segcount.p, overflow));
+        else CHECK(orx_shard_request_steps(ctx, (const int32_t*)mine, L, T, N, (int32_t)cap2, send2, slot, u_loc, cnt, overflow));
+        const void* req = nullptr;
+        CHECK(exchange_steps(c, send2, c->req.p, c->tmp, L, cap2, &req));                          // 2. item ids -> item owner
+        CHECK(orx_shard_localize(ctx, (const int32_t*)req, (int64_t)L * M, N, req_loc));
+        if (sgd) {                                         // duplicate flags of every step's two apply lists, one launch each
+            CHECK(orx_rows_dupflags(ctx, U->rows, u_loc, Kc, H * T, H * T, fu));
+            CHECK(orx_rows_dupflags(ctx, V->rows, req_loc, Kc, H * M, H * M, fv));
+        }
+        for (int k = 0; k < Kc; ++k) {
+            const void* rows_in[2] = {nullptr, nullptr};
+            const void* g_in[2] = {nullptr, nullptr};
+            for (int h = 0; h < H; ++h) {                  // 3. owners gather row + bias, the rows travel back
+                const int l = k * H + h;
+                float* ro = (float*)c->rows_out.p + (size_t)h * M * DS;
+                CHECK(orx_gather_rows(ctx, V, b, req_loc + (size_t)l * M, M, ro, DS));
+                if (H == 2) { ORX_HIP(hipEventRecord(c->ev[h], S)); ORX_HIP(hipStreamWaitEvent(X, c->ev[h], 0)); }
+                CHECK(exchange(c, ro, (float*)c->rows_in.p + (size_t)h * M * DS, (size_t)cap2 * DS * 4, &rows_in[h], X));
+                if (H == 2) ORX_HIP(hipEventRecord(c->ev[2 + h], X));
+            }
+            for (int h = 0; h < H; ++h) {                  // 4. gradients (+ SGD's apply of the user rows referenced once); 6. item gradients leave
+                const int l = k * H + h;
+                const int32_t* ul = u_loc + (size_t)l * T; const int32_t* sl = slot + (size_t)l * 2 * T;
+                float* gu = (float*)c->gu.p + (size_t)h * T * D; float* sg = (float*)c->send_g.p + (size_t)h * M * DS;
+                const unsigned char* dr = dedup ? dupref + (size_t)l * 2 * T : nullptr;
+                const void* so = dedup ? (const char*)c->dsorted.p + (size_t)l * 2 * T * 8 : nullptr;
+                const void* sgl = dedup ? (const char*)c->seglist.p + (size_t)l * T * 8 : nullptr;
+                const int32_t* sgc = dedup ? (const int32_t*)c->segcount.p + l : nullptr;
+                float* gd = dedup ? (float*)c->gdup.p + (size_t)h * 2 * T * DS : nullptr;
+                if (H == 2) ORX_HIP(hipStreamWaitEvent(S, c->ev[2 + h], 0));
+                if (sgd) CHECK(orx_shard_grads_sgd(ctx, model, opt, U, (const float*)rows_in[h], ul, sl, dr, so, sgl, sgc, gd, fu + (size_t)l * T, T, DS, B_global, margin, gflags,
+                                                   gu, (int32_t*)c->u_apply.p + (size_t)h * T, sg, loss_l2_accum));
+                else CHECK(orx_shard_grads(ctx, model, U, (const float*)rows_in[h], ul, sl, dr, so, sgl, sgc, gd, T, DS, B_global, margin, gflags, gu, sg, loss_l2_accum));
+                if (H == 2) { ORX_HIP(hipEventRecord(c->ev[4 + h], S)); ORX_HIP(hipStreamWaitEvent(X, c->ev[4 + h], 0)); }
+                CHECK(exchange(c, sg, (float*)c->g_in.p + (size_t)h * M * DS, (size_t)cap2 * DS * 4, &g_in[h], X));
+                if (H == 2) ORX_HIP(hipEventRecord(c->ev[6 + h], X));
+            }
+            if (opt->kind == ORX_ADAM) CHECK(orx_opt_advance(opt, tabs, 3));   // Keras `iterations` += 1: after the step's gathers, before its applies
+            if (sgd) {                                     // 5. user rows are local: the duplicated ones, half by half
+                for (int h = 0; h < H; ++h)
+                    CHECK(orx_apply_rows_flagged(ctx, opt, U, nullptr, (int32_t*)c->u_apply.p + (size_t)h * T, T, (float*)c->gu.p + (size_t)h * T * D, D,
+                                                 fu + (size_t)(k * H + h) * T));
+                for (int h = 0; h < H; ++h) {              // item-row gradients at their owners
+                    if (H == 2) ORX_HIP(hipStreamWaitEvent(S, c->ev[6 + h], 0));
+                    CHECK(orx_apply_rows_flagged(ctx, opt, V, b, req_loc + (size_t)(k * H + h) * M, M, (const float*)g_in[h], DS, fv + (size_t)(k * H + h) * M));
+                }
+            } else {                                       // Adagrad / Adam sum a row's duplicates FIRST: one list per table and step
+                CHECK(orx_apply_rows(ctx, opt, U, nullptr, u_loc + (size_t)k * H * T, H * T, (float*)c->gu.p, D));
+                for (int h = 0; h < H; ++h) if (H == 2) ORX_HIP(hipStreamWaitEvent(S, c->ev[6 + h], 0));
+                const float* g = H == 2 ? (const float*)c->g_in.p : (const float*)g_in[0];
+                CHECK(orx_apply_rows(ctx, opt, V, b, req_loc + (size_t)k * H * M, H * M, g, DS));
+            }
+        }
+    }
+    return ORX_OK;
+}

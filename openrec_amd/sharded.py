@@ -146,21 +146,84 @@ class HipBackend:
         self._ffi.check(self.lib.orx_shard_request_steps(self.ctx._h, trip.data_ptr(), K, T, world, cap, send_ids.data_ptr(),
                                                          slot.data_ptr(), u_loc.data_ptr(), counters.data_ptr(), overflow.data_ptr()))
 
+    def shard_request_dedup_steps(self, trip, world, cap, n_items, send_ids, slot, u_loc, dupref, overflow):
+        """the request plan with per-destination dedup: references of a list that ask for the same item share ONE slot
+        (dupref = 1 on them); the distinct items of an owner fill its bucket in ascending row order.  -> what the gradient
+        kernel needs to sum the shared slots (opaque: the sorted reference list and the list of shared slots)"""
+        K, T = trip.shape[0], trip.shape[1]
+        dev = trip.device
+        plan = dict(sorted=torch.empty((K, 2 * T, 2), dtype=torch.int32, device=dev), seglist=torch.empty((K, T, 2), dtype=torch.int32, device=dev),
+                    segcount=torch.empty(K, dtype=torch.int32, device=dev))
+        self._ffi.check(self.lib.orx_shard_request_dedup_steps(self.ctx._h, trip.data_ptr(), K, T, world, cap, n_items, send_ids.data_ptr(),
+                                                               slot.data_ptr(), u_loc.data_ptr(), dupref.data_ptr(), plan["sorted"].data_ptr(),
+                                                               plan["seglist"].data_ptr(), plan["segcount"].data_ptr(), overflow.data_ptr()))
+        return plan
+
+    def _dedup_args(self, dupref, rows_in):
+        """(dupref, sorted, seglist, segcount, gdup) pointers of one list, or five NULLs"""
+        if dupref is None:
+            return (None,) * 5
+        flags, plan, l = dupref
+        n2 = flags.shape[1]
+        key = (n2, rows_in.shape[1])
+        if getattr(self, "_gdup_key", None) != key:
+            self._gdup = [torch.empty((n2, rows_in.shape[1]), dtype=torch.float32, device=rows_in.device) for _ in range(2)]
+            self._gdup_key = key
+        g = self._gdup[l % 2]                                # (the two halves of an overlapped step use one each)
+        return (flags[l].data_ptr(), plan["sorted"][l].data_ptr(), plan["seglist"][l].data_ptr(), plan["segcount"][l:].data_ptr(), g.data_ptr())
+
     def shard_localize(self, ids, world, out):
         self._ffi.check(self.lib.orx_shard_localize(self.ctx._h, ids.data_ptr(), ids.numel(), world, out.data_ptr()))
 
-    def shard_grads(self, model, user, rows_in, u_loc, slot, b_global, margin, gu, send_g, accum):
+    def shard_grads(self, model, user, rows_in, u_loc, slot, b_global, margin, gu, send_g, accum, dupref=None):
+        """`dupref` = (flags [L, 2T], plan of shard_request_dedup_steps, list index): shared slots receive the sum of their references"""
         mid = {"bpr": self._ffi.ORX_BPR, "ucml": self._ffi.ORX_UCML}[model]
         self._ffi.check(self.lib.orx_shard_grads(self.ctx._h, mid, user._h, rows_in.data_ptr(), u_loc.data_ptr(),
-                                                 slot.data_ptr(), u_loc.numel(), rows_in.shape[1], b_global, margin, 0,
+                                                 slot.data_ptr(), *self._dedup_args(dupref, rows_in),
+                                                 u_loc.numel(), rows_in.shape[1], b_global, margin, 0,
                                                  gu.data_ptr(), send_g.data_ptr(), accum.data_ptr()))
 
-    def shard_grads_sgd(self, model, user, rows_in, u_loc, slot, dup_u, b_global, margin, gu, u_apply, send_g, accum):
+    def shard_grads_sgd(self, model, user, rows_in, u_loc, slot, dup_u, b_global, margin, gu, u_apply, send_g, accum, dupref=None):
         """gradients + SGD apply of the user rows referenced once (the duplicated ones are left in gu / u_apply)"""
         mid = {"bpr": self._ffi.ORX_BPR, "ucml": self._ffi.ORX_UCML}[model]
         self._ffi.check(self.lib.orx_shard_grads_sgd(self.ctx._h, mid, self.opt._h, user._h, rows_in.data_ptr(), u_loc.data_ptr(),
-                                                     slot.data_ptr(), dup_u.data_ptr(), u_loc.numel(), rows_in.shape[1], b_global, margin, 0,
+                                                     slot.data_ptr(), *self._dedup_args(dupref, rows_in),
+                                                     dup_u.data_ptr(), u_loc.numel(), rows_in.shape[1], b_global, margin, 0,
                                                      gu.data_ptr(), u_apply.data_ptr(), send_g.data_ptr(), accum.data_ptr()))
+
+    # ---- the whole K-step loop in the library (orx_sharded_pairwise_steps) --------
+    def make_comm(self, rank, world, group=None, rccl=None):
+        """-> an orx_comm handle on this backend's context.  `rccl`: exchange through RCCL (default: world > 1); the 128-byte
+        id made by rank 0 reaches the other ranks through `group` (any torch.distributed backend)."""
+        import ctypes
+        rccl = world > 1 if rccl is None else rccl
+        idp = None
+        if rccl:
+            buf = torch.zeros(self._ffi.ORX_COMM_ID_BYTES, dtype=torch.uint8)
+            if rank == 0:
+                raw = (ctypes.c_char * self._ffi.ORX_COMM_ID_BYTES)()
+                self._ffi.check(self.lib.orx_comm_unique_id(ctypes.cast(raw, ctypes.c_void_p)))
+                buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+            if world > 1:
+                dev_buf = buf.to(self.device) if dist.get_backend(group) == "nccl" else buf
+                dist.broadcast(dev_buf, src=0, group=group)
+                buf = dev_buf.cpu()
+            self._id_keep = buf.contiguous()
+            idp = ctypes.c_void_p(self._id_keep.data_ptr())
+        h = ctypes.c_void_p()
+        self._ffi.check(self.lib.orx_comm_create(self.ctx._h, idp, rank, world, ctypes.byref(h)))
+        import weakref
+        weakref.finalize(self, self.lib.orx_comm_destroy, h)
+        return h
+
+    def sharded_steps(self, comm, model, U, V, b, uid, pid, nid, n_users, n_items, margin, slack, plan_chunk, overlap, accum, ovf, dedup=True):
+        mid = {"bpr": self._ffi.ORX_BPR, "ucml": self._ffi.ORX_UCML}[model]
+        K, B = uid.shape
+        assert uid.stride(1) == 1 and pid.stride() == uid.stride() and nid.stride() == uid.stride()
+        flags = (self._ffi.ORX_SHARD_OVERLAP if overlap else 0) | (self._ffi.ORX_SHARD_DEDUP if dedup else self._ffi.ORX_SHARD_NO_DEDUP)
+        self._ffi.check(self.lib.orx_sharded_pairwise_steps(comm, self.opt._h, mid, U._h, V._h, b._h, uid.data_ptr(), pid.data_ptr(),
+                                                            nid.data_ptr(), K, B, uid.stride(0), n_users, n_items, margin, slack,
+                                                            plan_chunk, flags, accum.data_ptr(), ovf.data_ptr()))
 
     def stream_ctx(self):
         return torch.cuda.stream(self.stream)
@@ -174,7 +237,7 @@ class HipBackend:
 
 class ShardedPairwise:
     def __init__(self, model, opt, n_users, n_items, dim, lr, rank, world, device, seed=0, margin=0.5,
-                 backend=None, slack=1.05, opt_kw=None, group=None, a2a_fn=None, fast=None):
+                 backend=None, slack=1.05, opt_kw=None, group=None, a2a_fn=None, fast=None, engine=None, dedup=None):
         assert model in ("bpr", "ucml")
         self.model, self.dim, self.margin = model, dim, margin
         self.rank, self.world, self.device, self.group = rank, world, device, group
@@ -196,6 +259,25 @@ class ShardedPairwise:
         self.fast = can_fast if fast is None else (fast and can_fast)
         self._ovf = torch.zeros(1, dtype=torch.int32, device=device) if self.fast else None
         self._bufs = {}
+        self.engine = engine                              # "python": K-step calls stay on the per-phase path
+        # per-destination dedup of the item requests of the K-step plans (an item several references of a list ask for travels
+        # once); None: decided per call from the list length (`_dedup_for`)
+        self.dedup = dedup
+        self._comm = None
+
+    def _library_engine(self):
+        """The C engine (orx_sharded_pairwise_steps) takes the K-step calls when the compute backend is the library and the
+        exchange is RCCL's (process group backend "nccl") or the identity (one rank).  gloo groups and injected exchanges
+        (tests) keep the per-phase path below, which drives the same kernels from here."""
+        if self.engine == "python" or self.a2a_fn is not None or not hasattr(self.be, "sharded_steps"):
+            return False
+        if self._comm is None:
+            rccl = self.world > 1 or self.force_collectives
+            if self.world > 1 and dist.get_backend(self.group) != "nccl":
+                self.engine = "python"
+                return False
+            self._comm = self.be.make_comm(self.rank, self.world, self.group, rccl=rccl)
+        return True
 
     # capacity of one (source, destination) bucket for n elements spread over `world` ranks
     def _cap(self, n):
@@ -274,6 +356,14 @@ class ShardedPairwise:
                 self.step(uid[k], pid[k], nid[k])
             return None
         B = uid.shape[1]
+        if self._library_engine():
+            # one host call: plan, gathers, gradients, applies and the RCCL exchanges all run inside the library
+            ov = (self.world > 1 or self.force_collectives) if overlap is None else bool(overlap)
+            with self.be.stream_ctx():
+                self.be.sharded_steps(self._comm, self.model, self.U, self.V, self.b, uid, pid, nid, self.n_users, self.n_items,
+                                      self.margin, self.slack, plan_chunk, ov, self.accum, self._ovf,
+                                      dedup=self._dedup_for(B // 2 if (ov and self.world > 1 and B % 2 == 0) else B))
+            return None
         if overlap is None:       # two half-batches per step pay once there is a link to hide behind
             overlap = (self.world > 1 or self.force_collectives) and self.a2a_fn is None
         overlap = bool(overlap) and B % 2 == 0 and B >= 2
@@ -311,7 +401,8 @@ class ShardedPairwise:
         be.shard_route_steps(uh, ph, nh, self.n_users, self.n_items, N, fA["cap1"], send1, cnt, self._ovf)
         mine = self._a2a_steps(send1, N).contiguous()
         send2 = torch.empty((2 * Kc, M), **i32); slot = torch.empty((2 * Kc, 2 * T), **i32); u_loc = torch.empty((2 * Kc, T), **i32)
-        be.shard_request_steps(mine, N, fA["cap2"], send2, slot, u_loc, cnt, self._ovf)
+        dupref = self._request_plan(mine, fA["cap2"], send2, slot, u_loc, cnt)
+        dr = (lambda l: {"dupref": (dupref[0], dupref[1], l)}) if dupref is not None else (lambda l: {})
         req = self._a2a_steps(send2, N)
         req_loc = torch.empty_like(req)
         be.shard_localize(req.reshape(-1), N, req_loc.reshape(-1))
@@ -333,9 +424,9 @@ class ShardedPairwise:
                 wait_rows()
                 if folded:
                     be.shard_grads_sgd(self.model, self.U, rows, u_loc[h], slot[h], fu[h], B * N, self.margin, f["gu"], f["u_apply"],
-                                       f["send_g"], self.accum)
+                                       f["send_g"], self.accum, **dr(h))
                 else:
-                    be.shard_grads(self.model, self.U, rows, u_loc[h], slot[h], B * N, self.margin, f["gu"], f["send_g"], self.accum)
+                    be.shard_grads(self.model, self.U, rows, u_loc[h], slot[h], B * N, self.margin, f["gu"], f["send_g"], self.accum, **dr(h))
                 waits.append(self._a2a_async(f["send_g"], f["g_in"]))
             be.begin_step()
             if flagged:                                                      # SGD: every occurrence accumulates, half by half
@@ -349,6 +440,26 @@ class ShardedPairwise:
                 for _, wait_g in waits:
                     wait_g()
                 be.apply_rows(self.V, self.b, req_loc.view(Kc, 2 * M)[k], g_in2)
+
+    def _dedup_for(self, b_list):
+        """Dedup costs a sort and an un-sort of the references at plan time: on where the item references a rank handles per list
+        (2 x b_list: b_list triplets reach it) are at least half as many as the items -- most slots are then shared --, off for
+        sparse lists (the library engine decides the same way)."""
+        if not (self.fast and hasattr(self.be, "shard_request_dedup_steps")):
+            return False
+        if self.dedup is not None:
+            return bool(self.dedup)
+        return 4 * b_list >= self.n_items
+
+    def _request_plan(self, mine, cap2, send2, slot, u_loc, cnt):
+        """route 2 of the lists in `mine` [L, T, 3]; -> the shared-slot flags [L, 2T] (dedup) or None"""
+        be, N = self.be, self.world
+        if not self._dedup_for(mine.shape[1]):
+            be.shard_request_steps(mine, N, cap2, send2, slot, u_loc, cnt, self._ovf)
+            return None
+        dupref = torch.empty(slot.shape, dtype=torch.uint8, device=self.device)
+        plan = be.shard_request_dedup_steps(mine, N, cap2, self.n_items, send2, slot, u_loc, dupref, self._ovf)
+        return dupref, plan
 
     def _a2a_steps(self, x, N):
         """x: [Kc, N * c, ...] per-step buckets -> the same layout after ONE all-to-all over all Kc steps"""
@@ -373,7 +484,8 @@ class ShardedPairwise:
         be.shard_route_steps(uid, pid, nid, self.n_users, self.n_items, N, f["cap1"], send1, cnt, self._ovf)
         mine = self._a2a_steps(send1, N).contiguous()                              # 1. triplets -> user owner, all steps
         send2 = torch.empty((Kc, M), **i32); slot = torch.empty((Kc, 2 * T), **i32); u_loc = torch.empty((Kc, T), **i32)
-        be.shard_request_steps(mine, N, f["cap2"], send2, slot, u_loc, cnt, self._ovf)
+        dupref = self._request_plan(mine, f["cap2"], send2, slot, u_loc, cnt)
+        dr = (lambda l: {"dupref": (dupref[0], dupref[1], l)}) if dupref is not None else (lambda l: {})
         req = self._a2a_steps(send2, N)                                            # 2. item ids -> item owner, all steps
         req_loc = torch.empty_like(req)
         be.shard_localize(req.reshape(-1), N, req_loc.reshape(-1))
@@ -390,11 +502,11 @@ class ShardedPairwise:
             if flagged and hasattr(be, "shard_grads_sgd"):
                 # 4 + 5: user rows referenced once are updated by the gradient kernel itself; the duplicated ones follow
                 be.shard_grads_sgd(self.model, self.U, rows_in, u_loc[k], slot[k], fu[k], B * N, self.margin, f["gu"], f["u_apply"],
-                                   f["send_g"], self.accum)
+                                   f["send_g"], self.accum, **dr(k))
                 be.begin_step()
                 be.apply_rows_flagged(self.U, None, f["u_apply"], f["gu"], fu[k])
             else:
-                be.shard_grads(self.model, self.U, rows_in, u_loc[k], slot[k], B * N, self.margin, f["gu"], f["send_g"], self.accum)
+                be.shard_grads(self.model, self.U, rows_in, u_loc[k], slot[k], B * N, self.margin, f["gu"], f["send_g"], self.accum, **dr(k))
                 be.begin_step()
                 if flagged:
                     be.apply_rows_flagged(self.U, None, u_loc[k], f["gu"], fu[k])      # 5. user rows are local

@@ -33,7 +33,12 @@ def main():
     assert dist.get_backend() == "nccl"
 
     # ---- row-sharded BPR / UCML: 6 steps through the planned K-step path, 2 through the per-step path
-    for model, optk, D in (("bpr", "sgd", 64), ("bpr", "adagrad", 64), ("ucml", "sgd", 128), ("bpr", "adam", 64)):
+    # engine None: orx_sharded_pairwise_steps (the whole K-step loop and the ncclSend / ncclRecv groups inside the library, on an
+    # orx_comm made from an id of its own), overlapped halves and sequential; "python": the per-phase path over torch.distributed
+    for model, optk, D, engine, overlap in (("bpr", "sgd", 64, None, None), ("bpr", "sgd", 64, None, False), ("bpr", "sgd", 64, "python", None),
+                                            ("bpr", "adagrad", 64, None, None), ("bpr", "adagrad", 64, "python", None),
+                                            ("ucml", "sgd", 128, None, None), ("bpr", "adam", 64, None, None), ("bpr", "adam", 64, None, False),
+                                            ("bpr", "adam", 64, "python", None)):
         rng = np.random.default_rng(5)
         NU, NI, B, K = 3000, 4000, 4096, 8
         U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
@@ -42,12 +47,14 @@ def main():
         nid = rng.integers(0, NI, (K, B)).astype(np.int32)
         uid[:, :9] = 3
         lr = 0.002 if optk == "adam" else 0.05
-        eng = sharded.ShardedPairwise(model, optk, NU, NI, D, lr=lr, rank=0, world=1, device=dev, slack=1.0)
+        eng = sharded.ShardedPairwise(model, optk, NU, NI, D, lr=lr, rank=0, world=1, device=dev, slack=1.0, engine=engine,
+                                      dedup=True if overlap is False else None)      # (the sequential library runs also force the dedup plan)
         eng.force_collectives = True
         eng.U.write(U); eng.V.write(V); eng.b.write(b)
         tu, tp, tn = (torch.from_numpy(x).to(dev) for x in (uid, pid, nid))
         torch.cuda.synchronize()
-        eng.steps(tu[:6], tp[:6], tn[:6], plan_chunk=4)
+        eng.steps(tu[:6], tp[:6], tn[:6], plan_chunk=4, overlap=overlap)
+        assert (eng._comm is not None) == (engine is None)
         for s in (6, 7):
             eng.step(tu[s], tp[s], tn[s])
         eng.check()
@@ -61,7 +68,7 @@ def main():
         assert abs(loss - tl) <= 1e-5 * abs(tl), (model, optk, loss, tl)
         for got, want, nm in ((eng.U.read(), U, "U"), (eng.V.read(), V, "V"), (eng.b.read(), b, "b")):
             assert rel_err(got, want) < tol, (model, optk, nm, rel_err(got, want))
-        print(f"rccl-rank1 pairwise {model} {optk} D={D}: ok", flush=True)
+        print(f"rccl-rank1 pairwise {model} {optk} D={D} engine={engine or 'library'} overlap={overlap}: ok", flush=True)
 
     # ---- hybrid-parallel DLRM: embedding rows through all-to-all, dense gradients through all-reduce
     CFG = dict(m_spa=16, ln_emb=[1000, 37, 5000, 3, 250], ln_bot=[64, 16], ln_top=[128, 64, 1], dense_dim=13)

@@ -73,7 +73,8 @@ class FastOracleBackend(OracleBackend):
     """The DEVICE-SIDE exchange plan of the engine's K-step paths (`ShardedPairwise._steps_planned` / `_steps_overlapped`,
     what `bench.py --gpus N` runs) restated on the CPU, contract by contract, from the kernels it stands in for
     (openrec_amd/csrc/kernels_sharded.hip: shard_route_kernel, shard_request_kernel, shard_localize_kernel,
-    shard_grads_kernel; padding = -1, slots inside a bucket in arrival order), so that those paths run under gloo with
+    shard_grads_kernel, and the dedup request plan shard_keys / shard_dedup_slots; padding = -1, slots inside a bucket in arrival
+    order, or in ascending row order with dedup), so that those paths run under gloo with
     world > 1 -- the real collectives, asynchronous ones included.  No `rows_dupflags`: the engine then applies every list
     through `apply_rows` (the optimizer's own duplicate rule), which is the path Adagrad / Adam take on the GPU too."""
     fast = True
@@ -120,18 +121,48 @@ class FastOracleBackend(OracleBackend):
             if ov:
                 overflow.fill_(1)
 
+    def shard_request_dedup_steps(self, trip, world, cap, n_items, send_ids, slot, u_loc, dupref, overflow):
+        """kernels_sharded.hip: shard_keys_kernel + orx_rows_sort + shard_dedup_slots_kernel.  The distinct items a list asks an
+        owner for fill that owner's bucket in ascending local-row order; every reference of an item gets that one slot;
+        dupref = 1 on references whose item is asked for more than once; a triplet lives if both its requests found a slot."""
+        K, T = trip.shape[0], trip.shape[1]
+        send_ids.fill_(-1)
+        for k in range(K):
+            u, p, n = (trip[k, :, c].numpy().astype(np.int64) for c in range(3))
+            live = u >= 0
+            ids = np.concatenate([p, n]); alive = np.concatenate([live, live])
+            s = np.full(2 * T, -1, np.int64); d = np.zeros(2 * T, np.uint8)
+            for o in range(world):
+                sel = alive & (ids % world == o)
+                uniq, inv, cnt = np.unique(ids[sel] // world, return_inverse=True, return_counts=True)      # ascending local row
+                if uniq.size > cap:
+                    overflow.fill_(1)
+                ok = inv < cap
+                refs = np.nonzero(sel)[0]
+                s[refs[ok]] = o * cap + inv[ok]
+                d[refs] = (cnt[inv] > 1).astype(np.uint8)
+                m = min(uniq.size, cap)
+                send_ids[k, o * cap:o * cap + m] = torch.from_numpy((uniq[:m] * world + o).astype(np.int32))
+            slot[k] = torch.from_numpy(s.astype(np.int32)); dupref[k] = torch.from_numpy(d)
+            keep = live & (s[:T] >= 0) & (s[T:] >= 0)
+            u_loc[k] = torch.from_numpy(np.where(keep, u // world, -1).astype(np.int32))
+        return None                                          # (the GPU plan's opaque outputs: the sums below do not need them)
+
     def shard_localize(self, ids, world, out):
         out.copy_(torch.where(ids >= 0, torch.div(ids, world, rounding_mode="floor"), torch.full_like(ids, -1)))
 
-    def shard_grads(self, model, user, rows_in, u_loc, slot, b_global, margin, gu, send_g, accum):
+    def shard_grads(self, model, user, rows_in, u_loc, slot, b_global, margin, gu, send_g, accum, dupref=None):
         T = u_loc.numel()
         D = user.w.shape[1]
         ul, sp, sn = u_loc.numpy(), slot.numpy()[:T], slot.numpy()[T:]
         live = ul >= 0
         g_out = send_g.numpy()
-        for s_ in (sp, sn):                                  # surviving requests of dead triplets get zero gradients
-            dead = (~live) & (s_ >= 0)
-            g_out[s_[dead]] = 0.0
+        if dupref is not None:                               # dedup: shared slots receive the SUM of their references
+            g_out[:] = 0.0                                   # (dupref = (flags, plan, list index): only "dedup is on" matters here)
+        else:
+            for s_ in (sp, sn):                              # surviving requests of dead triplets get zero gradients
+                dead = (~live) & (s_ >= 0)
+                g_out[s_[dead]] = 0.0
         if not live.any():
             return
         k = int(live.sum())
@@ -152,8 +183,14 @@ class FastOracleBackend(OracleBackend):
             loss, l2, _ = orc.ucml_forward(U, V, b, ar, ar, ar + k, margin)
             gr = orc.ucml_grads(U, V, b, ar, ar, ar + k, margin)
         gu.numpy()[live] = gr["gu"]
-        g_out[sp[live], :D] = gr["gp"]; g_out[sp[live], D] = gr["gbp"]
-        g_out[sn[live], :D] = gr["gn"]; g_out[sn[live], D] = gr["gbn"]
+        if dupref is not None:
+            full = np.zeros((k, g_out.shape[1]), np.float32)
+            for sl_, g_, gb_ in ((sp[live], gr["gp"], gr["gbp"]), (sn[live], gr["gn"], gr["gbn"])):
+                full[:, :D] = g_; full[:, D] = np.asarray(gb_).reshape(-1)
+                np.add.at(g_out, sl_, full)
+        else:
+            g_out[sp[live], :D] = gr["gp"]; g_out[sp[live], D] = gr["gbp"]
+            g_out[sn[live], :D] = gr["gn"]; g_out[sn[live], D] = gr["gbn"]
         accum += torch.tensor([float(loss), float(l2)], dtype=torch.float64)
 
 
@@ -174,9 +211,9 @@ class FlaggedOracleBackend(FastOracleBackend):
     def apply_rows_flagged(self, table, bias, ids, grads, dflag):
         self.apply_rows(table, bias, ids, grads)          # scatter_add is the same sum with or without the flags
 
-    def shard_grads_sgd(self, model, user, rows_in, u_loc, slot, dup_u, b_global, margin, gu, u_apply, send_g, accum):
+    def shard_grads_sgd(self, model, user, rows_in, u_loc, slot, dup_u, b_global, margin, gu, u_apply, send_g, accum, dupref=None):
         assert self.opt_kind == "sgd"
-        self.shard_grads(model, user, rows_in, u_loc, slot, b_global, margin, gu, send_g, accum)
+        self.shard_grads(model, user, rows_in, u_loc, slot, b_global, margin, gu, send_g, accum, dupref=dupref)
         ul, dup = u_loc.numpy(), dup_u.numpy() != 0
         once = (ul >= 0) & ~dup
         user.w[ul[once]] -= np.float32(self.lr) * gu.numpy()[once]
