@@ -423,6 +423,14 @@ typedef struct orx_comm orx_comm;
 int orx_comm_unique_id(void* id_out);
 int orx_comm_create(orx_ctx* ctx, const void* unique_id, int32_t rank, int32_t world, orx_comm** out);
 int orx_comm_destroy(orx_comm* comm);
+/* An in-process group of `world` ranks that share ONE device -- one host thread and one context per rank, exchanges meeting at
+ * a host barrier, blocks copied by kernels: the engine's complete exchange schedule with world > 1 where there is no second GPU
+ * (tests/test_gpu_shard_engine.py).  orx_vgroup_abort releases ranks waiting for one that failed. */
+typedef struct orx_vgroup orx_vgroup;
+int orx_vgroup_create(int32_t world, orx_vgroup** out);
+int orx_vgroup_abort(orx_vgroup* group);
+int orx_vgroup_destroy(orx_vgroup* group);
+int orx_comm_create_virtual(orx_ctx* ctx, orx_vgroup* group, int32_t rank, orx_comm** out);
 int orx_comm_rank(orx_comm* comm);
 int orx_comm_world(orx_comm* comm);
 int orx_sharded_caps(int64_t B, int32_t world, float slack, int64_t* cap1, int64_t* cap2);

@@ -94,6 +94,10 @@ SIGNATURES = {
     "orx_comm_unique_id": (c_int, [_p]),
     "orx_comm_create": (c_int, [_p, _p, c_int32, c_int32, _pp]),
     "orx_comm_destroy": (c_int, [_p]),
+    "orx_vgroup_create": (c_int, [c_int32, _pp]),
+    "orx_vgroup_abort": (c_int, [_p]),
+    "orx_vgroup_destroy": (c_int, [_p]),
+    "orx_comm_create_virtual": (c_int, [_p, _p, c_int32, _pp]),
     "orx_comm_rank": (c_int, [_p]),
     "orx_comm_world": (c_int, [_p]),
     "orx_sharded_caps": (c_int, [c_int64, c_int32, c_float, _p, _p]),

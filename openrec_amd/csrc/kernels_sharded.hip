@@ -560,7 +560,7 @@ __global__ __launch_bounds__(1024) void shard_dd_uniq_kernel(DedupReqArgs a) {
 __global__ __launch_bounds__(256) void shard_dd_slots_kernel(DedupReqArgs a) {
     const int64_t k = blockIdx.y, n = 2 * a.T, i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const uint2* sorted = a.sorted + k * n;
-    int32_t* slot = a.slot + k * n; unsigned char* dupref = a.dupref + k * n;
+    int32_t* slot = a.slot + k * n;
     const uint32_t sentinel = (uint32_t)((int64_t)a.world * a.Lr);
     const uint2 e = i < n ? sorted[i] : make_uint2(0xffffffffu, 0u);
     const bool live = i < n && e.x < sentinel;

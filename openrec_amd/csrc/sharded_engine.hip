@@ -11,6 +11,8 @@
 #include <cmath>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 
 #define CHECK(call) do { const int rc_ = (call); if (rc_ != ORX_OK) return rc_; } while (0)
 
@@ -70,8 +72,25 @@ struct Buf { void* p = nullptr; size_t cap = 0; };
 
 }  // namespace
 
+// An in-process group of ranks on ONE device (one thread and one context per rank): the engine's whole exchange schedule with
+// world > 1 and no second GPU.  Exchanges meet at a host barrier; blocks are copied by kernels between the ranks' buffers.
+struct orx_vgroup {
+    int world = 1;
+    std::mutex mu; std::condition_variable cv; int waiting = 0; long generation = 0; bool broken = false;
+    const void* send[64] = {};
+    bool wait() {                                           // false: the group was aborted (a rank failed)
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
+        const long gen = generation;
+        if (++waiting == world) { waiting = 0; ++generation; cv.notify_all(); return true; }
+        cv.wait(lk, [&] { return generation != gen || broken; });
+        return !broken;
+    }
+};
+
 struct orx_comm {
     orx_ctx* ctx = nullptr;
+    orx_vgroup* vg = nullptr;
     ncclComm_t comm = nullptr;                           // NULL: a one-rank communicator without RCCL (every exchange is the identity)
     int rank = 0, world = 1;
     hipStream_t xstream = nullptr;                       // the exchanges of the overlapped path run here, beside the kernels
@@ -119,6 +138,31 @@ extern "C" int orx_comm_create(orx_ctx* ctx, const void* unique_id, int32_t rank
     return ORX_OK;
 }
 
+extern "C" int orx_vgroup_create(int32_t world, orx_vgroup** out) {
+    ORX_ARG(out && world >= 1 && world <= 64, "orx_vgroup_create: world in [1, 64]");
+    orx_vgroup* g = new orx_vgroup();
+    g->world = world;
+    *out = g;
+    return ORX_OK;
+}
+
+extern "C" int orx_vgroup_abort(orx_vgroup* g) {
+    if (!g) return ORX_OK;
+    { std::lock_guard<std::mutex> lk(g->mu); g->broken = true; }
+    g->cv.notify_all();
+    return ORX_OK;
+}
+
+extern "C" int orx_vgroup_destroy(orx_vgroup* g) { delete g; return ORX_OK; }
+
+extern "C" int orx_comm_create_virtual(orx_ctx* ctx, orx_vgroup* group, int32_t rank, orx_comm** out) {
+    ORX_ARG(ctx && group && out && rank >= 0 && rank < group->world, "orx_comm_create_virtual: bad argument");
+    orx_comm* c = new orx_comm();
+    c->ctx = ctx; c->vg = group; c->rank = rank; c->world = group->world;
+    *out = c;
+    return ORX_OK;
+}
+
 extern "C" int orx_comm_destroy(orx_comm* c) {
     if (!c) return ORX_OK;
     hipSetDevice(c->ctx->device);
@@ -141,6 +185,19 @@ extern "C" int orx_comm_world(orx_comm* c) { return c ? c->world : -1; }
 static int exchange(orx_comm* c, const void* send, void* recv, size_t bytes, const void** result, hipStream_t stream = nullptr) {
     if (!stream) stream = c->ctx->stream;
     *result = recv;
+    if (c->vg) {
+        ORX_ARG(bytes % 4 == 0, "sharded engine: exchange blocks are 4-byte words");
+        ORX_HIP(hipStreamSynchronize(stream));                      // my blocks are written
+        c->vg->send[c->rank] = send;
+        ORX_ARG(c->vg->wait(), "virtual group: another rank failed");
+        const size_t nw = bytes / 4;
+        for (int p = 0; p < c->world && nw; ++p)
+            hipLaunchKernelGGL(shard_copy_kernel<uint32_t>, dim3((unsigned)std::min<size_t>((nw + 255) / 256, 2048)), dim3(256), 0, stream,
+                               (const uint32_t*)((const char*)c->vg->send[p] + (size_t)c->rank * bytes), (uint32_t*)((char*)recv + (size_t)p * bytes), (int64_t)nw);
+        ORX_HIP(hipStreamSynchronize(stream));                      // ... and read before their owners write them again
+        ORX_ARG(c->vg->wait(), "virtual group: another rank failed");
+        return ORX_OK;
+    }
     if (!c->comm) { *result = send; return ORX_OK; }
     // this rank's own block is a copy kernel (RCCL's send-to-self kernel moved 18 MB in 25 us);
     // ORX_SHARD_RCCL_SELF=1 sends it through RCCL like any other (what the one-rank test uses to exercise ncclSend / ncclRecv)
@@ -168,7 +225,7 @@ static int exchange(orx_comm* c, const void* send, void* recv, size_t bytes, con
 
 // the plan's per-step buckets x [Kc][N * cw words] through ONE all-to-all: regroup by peer, exchange, regroup by step
 static int exchange_steps(orx_comm* c, const void* x, void* out, Buf& tmp, int Kc, int64_t cw, const void** result) {
-    if (!c->comm) { *result = x; return ORX_OK; }
+    if (!c->comm && !c->vg) { *result = x; return ORX_OK; }
     const int N = c->world;
     const size_t bytes = (size_t)Kc * N * cw * 4;
     CHECK(ensure(c, tmp, 2 * bytes));
@@ -228,11 +285,11 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
     // other half's kernels:   gather A | rows A || gather B | rows B || grads A | g A || grads B | g B || apply U | apply V(A) | apply V(B)
     // All gathers and gradient kernels of a step still precede its applies (TF's snapshot semantics); the duplicate flags of the apply
     // lists are taken over both halves together; Adagrad / Adam apply each table once per step from the halves' buffers side by side.
-    const int H = ((flags & ORX_SHARD_OVERLAP) && c->comm && c->world > 1 && B % 2 == 0 && id_stride == B) ? 2 : 1;
+    const int H = ((flags & ORX_SHARD_OVERLAP) && (c->comm || c->vg) && c->world > 1 && B % 2 == 0 && id_stride == B) ? 2 : 1;
     // Per-destination dedup (an item several references of a list ask for travels once) costs a sort and an un-sort of the
     // references at plan time (~25 us per step at 131 k references): on by default where the item references a rank handles per list (2 B) are at least
     // half as many as the items (then most slots are shared), off for sparse lists (1 M items: 6 % of the references repeat)
-    const int Hq = ((flags & ORX_SHARD_OVERLAP) && c->comm && c->world > 1 && B % 2 == 0 && id_stride == B) ? 2 : 1;
+    const int Hq = ((flags & ORX_SHARD_OVERLAP) && (c->comm || c->vg) && c->world > 1 && B % 2 == 0 && id_stride == B) ? 2 : 1;
     const bool dedup = (flags & ORX_SHARD_DEDUP) ? true : (flags & ORX_SHARD_NO_DEDUP) ? false : (4 * (B / Hq) >= items_global);
     const int64_t Bh = B / H;
     const int64_t cap1 = bucket_cap(Bh, N, slack), T = N * cap1, cap2 = bucket_cap(2 * T, N, slack), M = N * cap2;

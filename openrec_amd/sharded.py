@@ -192,10 +192,17 @@ class HipBackend:
                                                      gu.data_ptr(), u_apply.data_ptr(), send_g.data_ptr(), accum.data_ptr()))
 
     # ---- the whole K-step loop in the library (orx_sharded_pairwise_steps) --------
-    def make_comm(self, rank, world, group=None, rccl=None):
+    def make_comm(self, rank, world, group=None, rccl=None, vgroup=None):
         """-> an orx_comm handle on this backend's context.  `rccl`: exchange through RCCL (default: world > 1); the 128-byte
-        id made by rank 0 reaches the other ranks through `group` (any torch.distributed backend)."""
+        id made by rank 0 reaches the other ranks through `group` (any torch.distributed backend).  `vgroup`: an orx_vgroup
+        handle -- ranks in threads of this process on one device (tests)."""
         import ctypes
+        import weakref
+        if vgroup is not None:
+            h = ctypes.c_void_p()
+            self._ffi.check(self.lib.orx_comm_create_virtual(self.ctx._h, vgroup, rank, ctypes.byref(h)))
+            weakref.finalize(self, self.lib.orx_comm_destroy, h)
+            return h
         rccl = world > 1 if rccl is None else rccl
         idp = None
         if rccl:
@@ -237,7 +244,7 @@ class HipBackend:
 
 class ShardedPairwise:
     def __init__(self, model, opt, n_users, n_items, dim, lr, rank, world, device, seed=0, margin=0.5,
-                 backend=None, slack=1.05, opt_kw=None, group=None, a2a_fn=None, fast=None, engine=None, dedup=None):
+                 backend=None, slack=1.05, opt_kw=None, group=None, a2a_fn=None, fast=None, engine=None, dedup=None, vgroup=None):
         assert model in ("bpr", "ucml")
         self.model, self.dim, self.margin = model, dim, margin
         self.rank, self.world, self.device, self.group = rank, world, device, group
@@ -264,6 +271,7 @@ class ShardedPairwise:
         # once); None: decided per call from the list length (`_dedup_for`)
         self.dedup = dedup
         self._comm = None
+        self.vgroup = vgroup                              # orx_vgroup handle: ranks in threads of one process (tests)
 
     def _library_engine(self):
         """The C engine (orx_sharded_pairwise_steps) takes the K-step calls when the compute backend is the library and the
@@ -271,6 +279,8 @@ class ShardedPairwise:
         (tests) keep the per-phase path below, which drives the same kernels from here."""
         if self.engine == "python" or self.a2a_fn is not None or not hasattr(self.be, "sharded_steps"):
             return False
+        if self._comm is None and self.vgroup is not None:
+            self._comm = self.be.make_comm(self.rank, self.world, vgroup=self.vgroup)
         if self._comm is None:
             rccl = self.world > 1 or self.force_collectives
             if self.world > 1 and dist.get_backend(self.group) != "nccl":

@@ -95,3 +95,64 @@ def test_library_engine_with_and_without_dedup(optk, dedup):
     tol = 2e-4 if optk == "adam" else 2e-5                               # (sums of ~70 gradient rows per item row in fp32)
     for got, want, nm in ((eng.U.read(), U, "U"), (eng.V.read(), V, "V"), (eng.b.read(), b, "b")):
         assert rel_err(got, want) < tol, (nm, rel_err(got, want))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("model,optk", [("bpr", "sgd"), ("bpr", "adagrad"), ("ucml", "sgd"), ("bpr", "adam")])
+@pytest.mark.parametrize("overlap,dedup", [(False, False), (True, True), (False, True), (True, False)])
+def test_library_engine_with_virtual_ranks(world, model, optk, overlap, dedup):
+    """orx_sharded_pairwise_steps with world > 1 on one GPU: `world` ranks in threads of this process, each with its own context,
+    exchanging through an orx_vgroup (host barrier + copy kernels in place of the ncclSend / ncclRecv groups).  The whole schedule
+    of the engine -- plan regrouped by peer, gathers, gradients, applies, the halves of the overlapped path -- against the
+    single-process oracle on the global batch."""
+    import threading
+    import torch
+    from openrec_amd import sharded, _ffi
+    from oracle import numpy_oracle as orc
+    torch.cuda.init()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(7)
+    NU, NI, D, Bg, K = 1001, 1503, 64, 4096, 5
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    uid = rng.integers(0, NU, (K, Bg)).astype(np.int32); pid = rng.integers(0, NI, (K, Bg)).astype(np.int32); nid = rng.integers(0, NI, (K, Bg)).astype(np.int32)
+    uid[:, :17] = 5; pid[:, :40] = 9                                    # hot rows: duplicates within and across the ranks' slices
+    lib = _ffi.load()
+    vg = ctypes.c_void_p()
+    _ffi.check(lib.orx_vgroup_create(world, ctypes.byref(vg)))
+    lr = 0.002 if optk == "adam" else 0.05
+    engs, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            e = sharded.ShardedPairwise(model, optk, NU, NI, D, lr=lr, rank=rank, world=world, device=dev, slack=1.5, vgroup=vg, dedup=dedup)
+            e.U.write(U[rank::world]); e.V.write(V[rank::world]); e.b.write(b[rank::world])
+            engs[rank] = e
+            per = Bg // world
+            sl = slice(rank * per, (rank + 1) * per)
+            tu, tp, tn = (torch.from_numpy(np.ascontiguousarray(x[:, sl])).to(dev) for x in (uid, pid, nid))
+            torch.cuda.synchronize()
+            e.steps(tu, tp, tn, plan_chunk=2, overlap=overlap)
+            assert e._comm is not None
+            e.be.stream.synchronize()
+        except Exception as ex:                                         # pragma: no cover
+            errs.append(ex)
+            lib.orx_vgroup_abort(vg)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    oo = {"sgd": lambda: orc.SGD(lr), "adagrad": lambda: orc.Adagrad(lr, 0.1, 1e-7), "adam": lambda: orc.AdamTFSparse(lr)}[optk]()
+    step = orc.bpr_step if model == "bpr" else (lambda *a: orc.ucml_step(*a, do_censor=False))
+    tl = sum(float(step(U, V, b, uid[s], pid[s], nid[s], oo)[0]) for s in range(K))
+    got = 0.0
+    tol = 5e-5 if optk == "adam" else 1e-5
+    for r, e in enumerate(engs):
+        assert int(e._ovf[0]) == 0
+        for have, want, nm in ((e.U.read(), U, "U"), (e.V.read(), V, "V"), (e.b.read(), b, "b")):
+            assert rel_err(have[:len(want[r::world])], want[r::world]) < tol, (r, nm)
+        got += float(e.accum[0])
+    assert abs(got - tl) <= 1e-5 * abs(tl)
+    engs.clear()
+    import gc; gc.collect()
+    lib.orx_vgroup_destroy(vg)
