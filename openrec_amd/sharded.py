@@ -207,14 +207,20 @@ class HipBackend:
         idp = None
         if rccl:
             buf = torch.zeros(self._ffi.ORX_COMM_ID_BYTES, dtype=torch.uint8)
+            err = None
             if rank == 0:
-                raw = (ctypes.c_char * self._ffi.ORX_COMM_ID_BYTES)()
-                self._ffi.check(self.lib.orx_comm_unique_id(ctypes.cast(raw, ctypes.c_void_p)))
-                buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+                try:
+                    raw = (ctypes.c_char * self._ffi.ORX_COMM_ID_BYTES)()
+                    self._ffi.check(self.lib.orx_comm_unique_id(ctypes.cast(raw, ctypes.c_void_p)))
+                    buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+                except Exception as e:                    # noqa: BLE001  (the others wait in the broadcast: they get zeros)
+                    err = e
             if world > 1:
                 dev_buf = buf.to(self.device) if dist.get_backend(group) == "nccl" else buf
                 dist.broadcast(dev_buf, src=0, group=group)
                 buf = dev_buf.cpu()
+            if not bool(buf.any()):
+                raise RuntimeError(f"rank 0 could not make an RCCL id: {err!r}")
             self._id_keep = buf.contiguous()
             idp = ctypes.c_void_p(self._id_keep.data_ptr())
         h = ctypes.c_void_p()
@@ -277,6 +283,9 @@ class ShardedPairwise:
         """The C engine (orx_sharded_pairwise_steps) takes the K-step calls when the compute backend is the library and the
         exchange is RCCL's (process group backend "nccl") or the identity (one rank).  gloo groups and injected exchanges
         (tests) keep the per-phase path below, which drives the same kernels from here."""
+        import os
+        if self.engine is None and os.environ.get("ORX_SHARD_ENGINE") == "python":
+            self.engine = "python"
         if self.engine == "python" or self.a2a_fn is not None or not hasattr(self.be, "sharded_steps"):
             return False
         if self._comm is None and self.vgroup is not None:
@@ -286,7 +295,22 @@ class ShardedPairwise:
             if self.world > 1 and dist.get_backend(self.group) != "nccl":
                 self.engine = "python"
                 return False
-            self._comm = self.be.make_comm(self.rank, self.world, self.group, rccl=rccl)
+            # every rank must end up on the same path: a rank that cannot make its communicator (librccl.so not loadable, ...)
+            # takes all of them to the per-phase path over torch.distributed
+            comm, err = None, None
+            try:
+                comm = self.be.make_comm(self.rank, self.world, self.group, rccl=rccl)
+            except Exception as e:                        # noqa: BLE001
+                err = e
+            ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=self.device)
+            if self.world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) == 0:
+                import warnings
+                warnings.warn(f"sharded engine: no library communicator on every rank ({err!r}); using the per-phase path", RuntimeWarning)
+                self.engine = "python"
+                return False
+            self._comm = comm
         return True
 
     # capacity of one (source, destination) bucket for n elements spread over `world` ranks
