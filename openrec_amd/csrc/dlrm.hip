@@ -701,7 +701,10 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
     ColWindows cw;
     if (getenv("ORX_DLRM_NO_COLWIN") == nullptr) { cw.F = F; cw.win = m->d_colwin; }
     if (planned || sorted_apply) {
-        const int64_t kp = std::min<int64_t>(K, PC);
+        // sized for a whole chunk whatever K is: a loop's calls vary in length (warm-up calls of 5 steps, then one of 20), and growing
+        // these inside the longer call put ~0.5 ms of hipFree / hipMalloc into it
+        const int64_t kp = sorted_apply ? PC : std::min<int64_t>(K, PC);
+        if (sorted_apply) CHECK(orx_rows_sort_reserve(c, PC, B * F, m->emb->rows));
         if (m->idx_all_cap < kp * B * F) {
             if (m->d_idx_all) ORX_HIP(hipFree(m->d_idx_all));
             ORX_HIP(hipMalloc((void**)&m->d_idx_all, sizeof(int32_t) * kp * B * F)); m->idx_all_cap = kp * B * F;

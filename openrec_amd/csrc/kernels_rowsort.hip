@@ -329,6 +329,20 @@ int launch_csr(orx_ctx* ctx, const CsrArgs& a) {
 
 static inline int bit_width_u64(uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
 
+// the sort's buffers for K lists of n ids, without sorting: a caller whose calls vary in length reserves for its longest chunk
+// once (growing them inside a longer call costs hipFree + hipMalloc: ~0.5 ms of the DLRM step's first long call)
+int orx_rows_sort_reserve(orx_ctx* ctx, int64_t K, int64_t n, int64_t rows) {
+    if (K <= 0 || n <= 0) return ORX_OK;
+    const int total_bits = bit_width_u64((uint64_t)rows);
+    const int passes = (total_bits + SORT_MAXBITS - 1) / SORT_MAXBITS;
+    const int bits = (total_bits + passes - 1) / passes;
+    const int nblk = (int)((n + SORT_TILE - 1) / SORT_TILE), nbins = 1 << bits;
+    if (orx_ensure((void**)&ctx->d_sort[0], &ctx->d_sort_cap[0], (size_t)K * n * sizeof(uint2)) != ORX_OK) return ORX_ERR_OOM;
+    if (orx_ensure((void**)&ctx->d_sort[1], &ctx->d_sort_cap[1], (size_t)K * n * sizeof(uint2)) != ORX_OK) return ORX_ERR_OOM;
+    if (orx_ensure((void**)&ctx->d_sort_hist, &ctx->d_sort_hist_cap, (size_t)K * nbins * (nblk + 1) * sizeof(int)) != ORX_OK) return ORX_ERR_OOM;
+    return ORX_OK;
+}
+
 // sorted (row, position) pairs of K id lists of n ids each; `out` points into the context's sort buffers (valid until the
 // next orx_rows_sort on this context)
 int orx_rows_sort(orx_ctx* ctx, const int32_t* ids, int64_t K, int64_t n, int64_t id_stride, int64_t rows, const uint2** out) {

@@ -473,6 +473,7 @@ int orx_launch_rows_accum(orx_ctx* ctx, float* G, const int32_t* ids, const floa
 
 // kernels_rowsort.hip: deterministic apply of per-occurrence gradient rows (stable sort by row + segmented sums in position order)
 int orx_rows_sort(orx_ctx* ctx, const int32_t* ids, int64_t K, int64_t n, int64_t id_stride, int64_t rows, const uint2** sorted);
+int orx_rows_sort_reserve(orx_ctx* ctx, int64_t K, int64_t n, int64_t rows);
 int orx_csr_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride);
 int orx_csr_accum(orx_ctx* ctx, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride);
 int orx_csr_adam(orx_ctx* ctx, bool step, const AdamRowsArgs& r, orx_table* t, const uint2* sorted, int64_t n);
