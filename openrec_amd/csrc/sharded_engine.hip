@@ -306,17 +306,28 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
     for (int64_t k0 = 0; k0 < K; k0 += plan_chunk) {
         const int Kc = (int)std::min<int64_t>(plan_chunk, K - k0);
         const int L = Kc * H;                             // lists of this chunk: half h of step k is list H k + h
-        CHECK(ensure(c, c->send1, (size_t)L * T * 3 * 4)); CHECK(ensure(c, c->mine, (size_t)L * T * 3 * 4));
-        CHECK(ensure(c, c->cnt, (size_t)L * N * 4));
-        CHECK(ensure(c, c->send2, (size_t)L * M * 4)); CHECK(ensure(c, c->req, (size_t)L * M * 4)); CHECK(ensure(c, c->req_loc, (size_t)L * M * 4));
-        CHECK(ensure(c, c->slot, (size_t)L * 2 * T * 4)); CHECK(ensure(c, c->u_loc, (size_t)L * T * 4));
+        // (the buffers are sized for a whole chunk whatever K is: a loop's calls vary in length, and growing them -- a stream
+        // synchronisation, hipFree and hipMalloc each -- inside a longer call is paid in that call)
+        const size_t Lr = (size_t)plan_chunk * H;
+        CHECK(ensure(c, c->send1, Lr * T * 3 * 4)); CHECK(ensure(c, c->mine, Lr * T * 3 * 4));
+        CHECK(ensure(c, c->cnt, Lr * N * 4));
+        CHECK(ensure(c, c->send2, Lr * M * 4)); CHECK(ensure(c, c->req, Lr * M * 4)); CHECK(ensure(c, c->req_loc, Lr * M * 4));
+        CHECK(ensure(c, c->slot, Lr * 2 * T * 4)); CHECK(ensure(c, c->u_loc, Lr * T * 4));
         CHECK(ensure(c, c->rows_out, (size_t)H * M * DS * 4)); CHECK(ensure(c, c->rows_in, (size_t)H * M * DS * 4));
         CHECK(ensure(c, c->send_g, (size_t)H * M * DS * 4)); CHECK(ensure(c, c->g_in, (size_t)H * M * DS * 4));
         CHECK(ensure(c, c->gu, (size_t)H * T * D * 4)); CHECK(ensure(c, c->u_apply, (size_t)H * T * 4));
-        if (sgd) { CHECK(ensure(c, c->fu, (size_t)L * T)); CHECK(ensure(c, c->fv, (size_t)L * M)); }
+        if (sgd) {
+            CHECK(ensure(c, c->fu, Lr * T)); CHECK(ensure(c, c->fv, Lr * M));
+            // (the context's own scratch of orx_rows_dupflags, for a whole chunk as well)
+            const size_t lists = (size_t)plan_chunk, n_ids = (size_t)H * std::max<int64_t>(T, M);
+            CHECK(orx_ensure((void**)&ctx->d_dlist, &ctx->d_dlist_cap, lists * (n_ids / 2 + 1) * sizeof(uint32_t)));
+            CHECK(orx_ensure((void**)&ctx->d_dcount, &ctx->d_dcount_cap, lists * sizeof(int)));
+        }
         if (dedup) {
-            CHECK(ensure(c, c->dupref, (size_t)L * 2 * T)); CHECK(ensure(c, c->dsorted, (size_t)L * 2 * T * 8)); CHECK(ensure(c, c->seglist, (size_t)L * T * 8));
-            CHECK(ensure(c, c->segcount, (size_t)L * 4)); CHECK(ensure(c, c->gdup, (size_t)H * 2 * T * DS * 4));
+            CHECK(ensure(c, c->dupref, Lr * 2 * T)); CHECK(ensure(c, c->dsorted, Lr * 2 * T * 8)); CHECK(ensure(c, c->seglist, Lr * T * 8));
+            CHECK(ensure(c, c->segcount, Lr * 4)); CHECK(ensure(c, c->gdup, (size_t)H * 2 * T * DS * 4));
+            CHECK(orx_rows_sort_reserve(ctx, (int64_t)Lr, 2 * T, (int64_t)N * ((items_global + N - 1) / N)));
+            CHECK(orx_ensure((void**)&ctx->d_tmp, &ctx->d_tmp_cap, (Lr * 2 * T * 2 + Lr * ((2 * T + 1023) / 1024 + 64)) * sizeof(int32_t)));
         }
         int32_t* send1 = (int32_t*)c->send1.p; int32_t* cnt = (int32_t*)c->cnt.p; int32_t* send2 = (int32_t*)c->send2.p;
         int32_t* slot = (int32_t*)c->slot.p; int32_t* u_loc = (int32_t*)c->u_loc.p; int32_t* req_loc = (int32_t*)c->req_loc.p;
