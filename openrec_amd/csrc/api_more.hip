@@ -573,13 +573,21 @@ extern "C" int orx_rows_dupflags(orx_ctx* ctx, int64_t rows, const int32_t* ids,
 }
 
 // orx_apply_rows for SGD with the duplicate flags of the id list already known (orx_rows_dupflags)
+int orx_apply_rows_flagged_impl(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
+                                const float* grads, int64_t g_stride, const float* gbias, const unsigned char* dflag);
 extern "C" int orx_apply_rows_flagged(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
                                       const float* grads, int64_t g_stride, const unsigned char* dflag) {
+    return orx_apply_rows_flagged_impl(ctx, opt, t, bias, ids, n, grads, g_stride, nullptr, dflag);
+}
+
+// gbias != NULL: the bias gradients come in an array of their own ([n]) instead of column dim of the gradient rows
+int orx_apply_rows_flagged_impl(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
+                                const float* grads, int64_t g_stride, const float* gbias, const unsigned char* dflag) {
     if (t) CHECK(orx_table_sync(t));
     if (bias) CHECK(orx_table_sync(bias));
     ORX_ARG(ctx && opt && t && (n == 0 || (ids && grads && dflag)), "orx_apply_rows_flagged: NULL argument");
     ORX_ARG(opt->kind == ORX_SGD, "orx_apply_rows_flagged: SGD only (Adagrad / Adam: orx_apply_rows)");
-    ORX_ARG(g_stride >= t->dim + (bias ? 1 : 0), "orx_apply_rows_flagged: g_stride too small");
+    ORX_ARG(g_stride >= t->dim + ((bias && !gbias) ? 1 : 0), "orx_apply_rows_flagged: g_stride too small");
     ORX_ARG(!bias || (bias->dim == 1 && bias->rows == t->rows), "orx_apply_rows_flagged: bias must be [%lld, 1]", (long long)t->rows);
     if (n == 0) return ORX_OK;
     ORX_HIP(hipSetDevice(ctx->device));
@@ -587,7 +595,7 @@ extern "C" int orx_apply_rows_flagged(orx_ctx* ctx, orx_opt* opt, orx_table* t, 
     memset(&a, 0, sizeof(a));
     a.W = t->w; a.bias = bias ? bias->w : nullptr;
     a.ids = ids; a.grads = grads; a.g_stride = g_stride; a.n = n; a.rows = t->rows; a.D = t->dim;
-    a.lr = opt->lr; a.err = ctx->d_err; a.dflag = dflag;
+    a.lr = opt->lr; a.err = ctx->d_err; a.dflag = dflag; a.gbias = gbias;
     return orx_launch_apply_rows(ctx, ORX_SGD, true, a);
 }
 
@@ -699,29 +707,46 @@ extern "C" int orx_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, i
     return orx_launch_shard_localize(ctx, ids, n, world, out);
 }
 
-extern "C" int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const float* rows_in, const int32_t* u_loc,
-                               const int32_t* slot, const uint8_t* dupref, const void* sorted, const void* seglist, const int32_t* segcount,
-                               float* gdup, int64_t T, int64_t row_stride, int64_t B_global, float margin, int flags,
-                               float* gu, float* send_g, double* loss_l2_accum) {
-    if (user && u_loc) CHECK(orx_table_touch(user, u_loc, T));        // a lazy table: the user rows read here are brought up to date
-    ORX_ARG(ctx && user && rows_in && u_loc && slot && gu && send_g, "orx_shard_grads: NULL argument");
+// Both gradient entry points and the library's own sharded engine.  opt / dup_u / u_apply != NULL: SGD's apply of the user rows
+// referenced once folded in.  bias_in / gb_out != NULL: the biases travel apart from the rows (row_stride = D; the side buffer of
+// shared slots keeps rows of D + 4 floats with the bias gradient at column D), else at column D of the rows (row_stride > D).
+int orx_shard_grads_impl(orx_ctx* ctx, int model, orx_opt* opt, orx_table* user, const float* rows_in, const float* bias_in,
+                         const int32_t* u_loc, const int32_t* slot, const uint8_t* dupref, const void* sorted, const void* seglist,
+                         const int32_t* segcount, float* gdup, const uint8_t* dup_u, int64_t T, int64_t row_stride, int64_t B_global,
+                         float margin, int flags, float* gu, int32_t* u_apply, float* send_g, float* gb_out, double* loss_l2_accum) {
+    const bool fold = dup_u != nullptr;
+    if (fold) CHECK(orx_table_sync(user));
+    else if (user && u_loc) CHECK(orx_table_touch(user, u_loc, T));   // a lazy table: the user rows read here are brought up to date
+    ORX_ARG(ctx && user && rows_in && u_loc && slot && gu && send_g && (!fold || (opt && u_apply)), "orx_shard_grads: NULL argument");
+    ORX_ARG(!fold || opt->kind == ORX_SGD, "orx_shard_grads_sgd: the folded apply is SGD's (Adagrad / Adam sum duplicates first: orx_shard_grads + orx_apply_rows)");
     ORX_ARG(model == ORX_BPR || model == ORX_UCML, "orx_shard_grads: unknown model %d", model);
-    ORX_ARG(row_stride > user->dim && B_global > 0, "orx_shard_grads: row_stride must leave room for the bias column");
+    ORX_ARG((bias_in != nullptr) == (gb_out != nullptr), "orx_shard_grads: biases in and bias gradients out travel apart together");
+    ORX_ARG((bias_in ? row_stride >= user->dim : row_stride > user->dim) && B_global > 0, "orx_shard_grads: row_stride must leave room for the bias column");
+    ORX_ARG(!dupref || (sorted && seglist && segcount && gdup), "orx_shard_grads: dedup needs the plan's sorted list, segment list and a side buffer");
     if (T == 0) return ORX_OK;
     ORX_HIP(hipSetDevice(ctx->device));
     ShardGradArgs a;
     memset(&a, 0, sizeof(a));
     a.U = user->w; a.rows_in = rows_in; a.u_loc = u_loc; a.slot = slot; a.gu = gu; a.send_g = send_g; a.dupref = dupref; a.gdup = gdup;
-    a.T = T; a.D = user->dim; a.DS = (int)row_stride;
+    a.bias_in = bias_in; a.gb_out = gb_out;
+    a.T = T; a.D = user->dim; a.DS = (int)row_stride; a.DSg = bias_in ? user->dim + 4 : (int)row_stride;
     a.invB = 1.0f / (float)B_global; a.margin = margin; a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f;
+    if (fold) { a.fu = dup_u; a.Uw = user->w; a.lr = opt->lr; a.u_apply = u_apply; }
     ENSURE(ctx->d_partial, ctx->d_partial_cap, (size_t)(T + 4) * 2 * sizeof(float));
     a.partial = ctx->d_partial;
     int nw = 0;
-    ORX_ARG(!dupref || (sorted && seglist && segcount && gdup), "orx_shard_grads: dedup needs the plan's sorted list, segment list and a side buffer");
     CHECK(orx_launch_shard_grads(ctx, model, a, &nw));
-    if (dupref) CHECK(orx_launch_shard_segsum(ctx, (const int2*)seglist, segcount, (const uint2*)sorted, 2 * T, gdup, send_g, (int)row_stride));
+    if (dupref) CHECK(orx_launch_shard_segsum(ctx, (const int2*)seglist, segcount, (const uint2*)sorted, 2 * T, gdup, a.DSg, send_g, a.DS, a.D, gb_out));
     if (loss_l2_accum) CHECK(orx_launch_loss_accumulate(ctx, ctx->d_partial, nw, loss_l2_accum));
     return ORX_OK;
+}
+
+extern "C" int orx_shard_grads(orx_ctx* ctx, int model, orx_table* user, const float* rows_in, const int32_t* u_loc,
+                               const int32_t* slot, const uint8_t* dupref, const void* sorted, const void* seglist, const int32_t* segcount,
+                               float* gdup, int64_t T, int64_t row_stride, int64_t B_global, float margin, int flags,
+                               float* gu, float* send_g, double* loss_l2_accum) {
+    return orx_shard_grads_impl(ctx, model, nullptr, user, rows_in, nullptr, u_loc, slot, dupref, sorted, seglist, segcount, gdup, nullptr, T, row_stride,
+                                B_global, margin, flags, gu, nullptr, send_g, nullptr, loss_l2_accum);
 }
 
 // orx_shard_grads with the SGD apply of the (local) user rows folded in: rows referenced once in the step are updated in
@@ -731,27 +756,9 @@ extern "C" int orx_shard_grads_sgd(orx_ctx* ctx, int model, orx_opt* opt, orx_ta
                                    const int32_t* slot, const uint8_t* dupref, const void* sorted, const void* seglist, const int32_t* segcount,
                                    float* gdup, const uint8_t* dup_u, int64_t T, int64_t row_stride, int64_t B_global,
                                    float margin, int flags, float* gu, int32_t* u_apply, float* send_g, double* loss_l2_accum) {
-    ORX_ARG(ctx && opt && user && rows_in && u_loc && slot && dup_u && gu && u_apply && send_g, "orx_shard_grads_sgd: NULL argument");
-    ORX_ARG(opt->kind == ORX_SGD, "orx_shard_grads_sgd: the folded apply is SGD's (Adagrad / Adam sum duplicates first: orx_shard_grads + orx_apply_rows)");
-    ORX_ARG(model == ORX_BPR || model == ORX_UCML, "orx_shard_grads_sgd: unknown model %d", model);
-    ORX_ARG(row_stride > user->dim && B_global > 0, "orx_shard_grads_sgd: row_stride must leave room for the bias column");
-    CHECK(orx_table_sync(user));
-    if (T == 0) return ORX_OK;
-    ORX_HIP(hipSetDevice(ctx->device));
-    ShardGradArgs a;
-    memset(&a, 0, sizeof(a));
-    a.U = user->w; a.rows_in = rows_in; a.u_loc = u_loc; a.slot = slot; a.gu = gu; a.send_g = send_g; a.dupref = dupref; a.gdup = gdup;
-    a.T = T; a.D = user->dim; a.DS = (int)row_stride;
-    a.invB = 1.0f / (float)B_global; a.margin = margin; a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f;
-    a.fu = dup_u; a.Uw = user->w; a.lr = opt->lr; a.u_apply = u_apply;
-    ENSURE(ctx->d_partial, ctx->d_partial_cap, (size_t)(T + 4) * 2 * sizeof(float));
-    a.partial = ctx->d_partial;
-    int nw = 0;
-    ORX_ARG(!dupref || (sorted && seglist && segcount && gdup), "orx_shard_grads: dedup needs the plan's sorted list, segment list and a side buffer");
-    CHECK(orx_launch_shard_grads(ctx, model, a, &nw));
-    if (dupref) CHECK(orx_launch_shard_segsum(ctx, (const int2*)seglist, segcount, (const uint2*)sorted, 2 * T, gdup, send_g, (int)row_stride));
-    if (loss_l2_accum) CHECK(orx_launch_loss_accumulate(ctx, ctx->d_partial, nw, loss_l2_accum));
-    return ORX_OK;
+    ORX_ARG(opt && dup_u && u_apply, "orx_shard_grads_sgd: NULL argument");
+    return orx_shard_grads_impl(ctx, model, opt, user, rows_in, nullptr, u_loc, slot, dupref, sorted, seglist, segcount, gdup, dup_u, T, row_stride,
+                                B_global, margin, flags, gu, u_apply, send_g, nullptr, loss_l2_accum);
 }
 
 // ------------------------------------------------------------- ranking metrics ---

@@ -53,7 +53,7 @@ template <bool VEC4>
 __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                                      int64_t rows, int dim, const int32_t* __restrict__ ids,
                                                      int64_t n, float* __restrict__ out, int64_t out_stride, int* err,
-                                                     int skip_negative) {
+                                                     int skip_negative, float* __restrict__ bias_out) {
     const int per_row = VEC4 ? dim / 4 : dim;
     const int64_t total = n * per_row;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -68,18 +68,18 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ w
         } else {
             out[k * out_stride + e] = w[(size_t)r * dim + e];
         }
-        if (bias != nullptr && e == 0) out[k * out_stride + dim] = bias[r];
+        if (bias != nullptr && e == 0) { if (bias_out) bias_out[k] = bias[r]; else out[k * out_stride + dim] = bias[r]; }
     }
 }
 
 int orx_launch_gather(orx_ctx* ctx, const float* w, const float* bias, int64_t rows, int dim,
-                      const int32_t* ids, int64_t n, float* out, int64_t out_stride, int* err, int skip_negative) {
+                      const int32_t* ids, int64_t n, float* out, int64_t out_stride, int* err, int skip_negative, float* bias_out) {
     if (n == 0) return ORX_OK;
     const bool vec = (dim % 4 == 0) && (out_stride % 4 == 0) && (((uintptr_t)out) % 16 == 0);
     if (vec) {
-        ORX_LAUNCH(ctx, (gather_kernel<true>), dim3(grid_for(n * (dim / 4), 256)), dim3(256), 0, w, bias, rows, dim, ids, n, out, out_stride, err, skip_negative);
+        ORX_LAUNCH(ctx, (gather_kernel<true>), dim3(grid_for(n * (dim / 4), 256)), dim3(256), 0, w, bias, rows, dim, ids, n, out, out_stride, err, skip_negative, bias_out);
     } else {
-        ORX_LAUNCH(ctx, (gather_kernel<false>), dim3(grid_for(n * dim, 256)), dim3(256), 0, w, bias, rows, dim, ids, n, out, out_stride, err, skip_negative);
+        ORX_LAUNCH(ctx, (gather_kernel<false>), dim3(grid_for(n * dim, 256)), dim3(256), 0, w, bias, rows, dim, ids, n, out, out_stride, err, skip_negative, bias_out);
     }
     ORX_HIP(hipGetLastError());
     return ORX_OK;

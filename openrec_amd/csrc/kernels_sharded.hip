@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void apply_rows_sgd_flagged_kernel(RowsArgs a)
             *reinterpret_cast<f4*>(w) = *reinterpret_cast<const f4*>(w) - a.lr * g;
         }
         if (a.bias != nullptr && sub == 0) {
-            const float gb = a.grads[k * a.g_stride + D];
+            const float gb = a.gbias ? a.gbias[k] : a.grads[k * a.g_stride + D];
             if (dup) unsafeAtomicAdd(a.bias + r, -a.lr * gb);
             else a.bias[r] = a.bias[r] - a.lr * gb;
         }
@@ -606,10 +606,11 @@ __global__ __launch_bounds__(256) void shard_dd_live_kernel(DedupReqArgs a) {
 // The gradients of the references that share a slot, summed in the order of the reference index (the sorted list is stable): one
 // wavefront per shared slot, rows of DS floats read from the side buffer the gradient kernel left them in (row = reference index).
 __global__ __launch_bounds__(256) void shard_segsum_kernel(const int2* seglist, const int* segcount, const uint2* sorted, int64_t n,
-                                                           const float* gdup, float* send_g, int DS, int G) {
-    // a group of G lanes per shared slot (G = the power of two >= DS / 4, at most 64), float4 columns
+                                                           const float* gdup, int DSg, float* send_g, int DS, int D, float* gb_out, int G) {
+    // a group of G lanes per shared slot (G = the power of two >= DSg / 4, at most 64), float4 columns of the side-buffer rows;
+    // the column that holds the bias gradient (D .. D + 3) goes to gb_out when the bias travels apart from the rows
     const int lane = threadIdx.x & 63, sub = lane % G, grp = lane / G, per_wave = 64 / G;
-    const int nseg = *segcount, C4 = DS / 4;
+    const int nseg = *segcount, C4 = DSg / 4;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t sgi = wave * per_wave + grp; sgi < nseg; sgi += nwaves * per_wave) {
         const int2 sg = seglist[sgi];
@@ -617,16 +618,19 @@ __global__ __launch_bounds__(256) void shard_segsum_kernel(const int2* seglist, 
         for (int c = sub; c < C4; c += G) {
             f4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
             for (int64_t i = sg.y; i < n && sorted[i].x == key; ++i)
-                acc = acc + *reinterpret_cast<const f4*>(gdup + (int64_t)sorted[i].y * DS + 4 * c);
-            *reinterpret_cast<f4*>(send_g + (int64_t)sg.x * DS + 4 * c) = acc;
+                acc = acc + *reinterpret_cast<const f4*>(gdup + (int64_t)sorted[i].y * DSg + 4 * c);
+            if (4 * c < D) *reinterpret_cast<f4*>(send_g + (int64_t)sg.x * DS + 4 * c) = acc;
+            else if (gb_out) gb_out[sg.x] = acc.x;
+            else *reinterpret_cast<f4*>(send_g + (int64_t)sg.x * DS + 4 * c) = acc;
         }
     }
 }
 
-int orx_launch_shard_segsum(orx_ctx* ctx, const int2* seglist, const int* segcount, const uint2* sorted, int64_t n, const float* gdup, float* send_g, int DS) {
+int orx_launch_shard_segsum(orx_ctx* ctx, const int2* seglist, const int* segcount, const uint2* sorted, int64_t n, const float* gdup, int DSg,
+                            float* send_g, int DS, int D, float* gb_out) {
     int G = 1;
-    while (G < DS / 4 && G < 64) G *= 2;
-    ORX_LAUNCH(ctx, shard_segsum_kernel, dim3(1024), dim3(256), 0, seglist, segcount, sorted, n, gdup, send_g, DS, G);
+    while (G < DSg / 4 && G < 64) G *= 2;
+    ORX_LAUNCH(ctx, shard_segsum_kernel, dim3(1024), dim3(256), 0, seglist, segcount, sorted, n, gdup, DSg, send_g, DS, D, gb_out, G);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -674,15 +678,26 @@ __global__ __launch_bounds__(256) void shard_grads_kernel(ShardGradArgs a) {
         const int ul = a.u_loc[t];
         if (ul < 0) {                    // empty slot, or a triplet dropped by a bucket overflow:
             f4 z; z.x = z.y = z.z = z.w = 0.0f;                     // its surviving request gets a zero gradient (in the side buffer if the slot is shared)
-            if (sp >= 0) { float* o = (a.dupref && a.dupref[t]) ? a.gdup + t * a.DS : a.send_g + (int64_t)sp * a.DS; *reinterpret_cast<f4*>(o + 4 * sub) = z; if (sub == 0) o[D] = 0.f; }
-            if (sn >= 0) { float* o = (a.dupref && a.dupref[a.T + t]) ? a.gdup + (a.T + t) * a.DS : a.send_g + (int64_t)sn * a.DS; *reinterpret_cast<f4*>(o + 4 * sub) = z; if (sub == 0) o[D] = 0.f; }
+            if (sp >= 0) {
+                const bool dp = a.dupref && a.dupref[t];
+                float* o = dp ? a.gdup + t * a.DSg : a.send_g + (int64_t)sp * a.DS;
+                *reinterpret_cast<f4*>(o + 4 * sub) = z;
+                if (sub == 0) { if (!dp && a.gb_out) a.gb_out[sp] = 0.f; else o[D] = 0.f; }
+            }
+            if (sn >= 0) {
+                const bool dn = a.dupref && a.dupref[a.T + t];
+                float* o = dn ? a.gdup + (a.T + t) * a.DSg : a.send_g + (int64_t)sn * a.DS;
+                *reinterpret_cast<f4*>(o + 4 * sub) = z;
+                if (sub == 0) { if (!dn && a.gb_out) a.gb_out[sn] = 0.f; else o[D] = 0.f; }
+            }
             if (APPLY && sub == 0) a.u_apply[t] = -1;
             continue;
         }
         const f4 ru = *reinterpret_cast<const f4*>(a.U + (size_t)ul * D + 4 * sub);
         const f4 rp = *reinterpret_cast<const f4*>(a.rows_in + (int64_t)sp * a.DS + 4 * sub);
         const f4 rn = *reinterpret_cast<const f4*>(a.rows_in + (int64_t)sn * a.DS + 4 * sub);
-        const float bp = a.rows_in[(int64_t)sp * a.DS + D], bn = a.rows_in[(int64_t)sn * a.DS + D];
+        const float bp = a.bias_in ? a.bias_in[sp] : a.rows_in[(int64_t)sp * a.DS + D];
+        const float bn = a.bias_in ? a.bias_in[sn] : a.rows_in[(int64_t)sn * a.DS + D];
         const float red = group_allreduce<LPR>(score_partial<MODEL>(ru, rp, rn));
         float term, g;
         score<MODEL>(red, bp, bn, a.invB, a.margin, term, g);
@@ -703,11 +718,14 @@ __global__ __launch_bounds__(256) void shard_grads_kernel(ShardGradArgs a) {
         // a reference that shares its slot leaves its gradient in the side buffer (row = reference index): shard_segsum_kernel adds
         // the rows of a slot in reference order
         const bool dp = a.dupref && a.dupref[t], dn = a.dupref && a.dupref[a.T + t];
-        float* op = dp ? a.gdup + t * a.DS : a.send_g + (int64_t)sp * a.DS;
-        float* on = dn ? a.gdup + (a.T + t) * a.DS : a.send_g + (int64_t)sn * a.DS;
+        float* op = dp ? a.gdup + t * a.DSg : a.send_g + (int64_t)sp * a.DS;
+        float* on = dn ? a.gdup + (a.T + t) * a.DSg : a.send_g + (int64_t)sn * a.DS;
         *reinterpret_cast<f4*>(op + 4 * sub) = gp;
         *reinterpret_cast<f4*>(on + 4 * sub) = gn;
-        if (sub == 0) { op[D] = gbp; on[D] = gbn; }
+        if (sub == 0) {
+            if (!dp && a.gb_out) a.gb_out[sp] = gbp; else op[D] = gbp;
+            if (!dn && a.gb_out) a.gb_out[sn] = gbn; else on[D] = gbn;
+        }
     }
     const float ls = wave_sum(loss_acc);
     const float sq = wave_sum(sq_acc);

@@ -260,7 +260,8 @@ struct RowsArgs {                              // sharded building blocks (kerne
     float* A; float* ab;                      // Adagrad accumulators
     const int32_t* ids;                       // local row ids, < 0 = skip
     const unsigned char* dflag;
-    const float* grads; int64_t g_stride;     // [n, g_stride]; bias gradient at column D
+    const float* grads; int64_t g_stride;     // [n, g_stride]; bias gradient at column D ...
+    const float* gbias;                       // ... or, if not NULL, in this array [n] (apply_rows_sgd_flagged_kernel)
     int64_t n; int64_t rows; int D;
     float lr; float eps;
     int* err;
@@ -395,7 +396,7 @@ int orx_launch_init_uniform(orx_ctx* ctx, float* w, int64_t n, float lo, float h
 int orx_launch_fill(orx_ctx* ctx, float* w, int64_t n, float v);
 int orx_launch_gather(orx_ctx* ctx, const float* w, const float* bias, int64_t rows, int dim,
                       const int32_t* ids, int64_t n, float* out, int64_t out_stride, int* err,
-                      int skip_negative = 0);
+                      int skip_negative = 0, float* bias_out = nullptr);   // bias_out: the biases go there ([n]) instead of column dim of out
 int orx_launch_censor(orx_ctx* ctx, float* w, const unsigned char* dflag, int64_t rows, int dim, const int32_t* ids,
                       int64_t n, float min_norm, int* err);
 int orx_launch_censor2(orx_ctx* ctx, float* wA, const unsigned char* fA, int64_t rowsA, const int32_t* idsA, int64_t nA,
@@ -519,7 +520,10 @@ struct ShardGradArgs {
     // per-destination dedup of the requests (orx_shard_request_dedup_steps): references that share a slot add their gradients
     // into it (send_g zeroed by the caller); NULL: every reference has a slot of its own
     const unsigned char* dupref;   // [2T]
-    float* gdup;                   // [2T][DS] side buffer: gradients of the references that share a slot (row = reference index)
+    float* gdup;                   // [2T][DSg] side buffer: gradients of the references that share a slot (row = reference index)
+    // the bias apart from the rows (the sharded engine's exchange carries it as a message of its own: D + 1 floats per row on the
+    // wire instead of D + 4): received biases [world*cap2], bias gradients out [world*cap2]; rows_in / send_g rows are then DS = D floats
+    const float* bias_in; float* gb_out; int DSg;   // DSg: row stride of gdup (D + 4; its column D is the bias gradient)
 };
 
 struct DedupReqArgs {
@@ -535,7 +539,14 @@ struct DedupReqArgs {
 };
 int orx_launch_shard_keys(orx_ctx* ctx, const DedupReqArgs& a, int64_t K);
 int orx_launch_shard_dedup_slots(orx_ctx* ctx, const DedupReqArgs& a, int64_t K);
-int orx_launch_shard_segsum(orx_ctx* ctx, const int2* seglist, const int* segcount, const uint2* sorted, int64_t n, const float* gdup, float* send_g, int DS);
+int orx_shard_grads_impl(orx_ctx* ctx, int model, orx_opt* opt, orx_table* user, const float* rows_in, const float* bias_in,
+                         const int32_t* u_loc, const int32_t* slot, const uint8_t* dupref, const void* sorted, const void* seglist,
+                         const int32_t* segcount, float* gdup, const uint8_t* dup_u, int64_t T, int64_t row_stride, int64_t B_global,
+                         float margin, int flags, float* gu, int32_t* u_apply, float* send_g, float* gb_out, double* loss_l2_accum);
+int orx_apply_rows_flagged_impl(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
+                                const float* grads, int64_t g_stride, const float* gbias, const unsigned char* dflag);
+int orx_launch_shard_segsum(orx_ctx* ctx, const int2* seglist, const int* segcount, const uint2* sorted, int64_t n, const float* gdup, int DSg,
+                            float* send_g, int DS, int D, float* gb_out);
 int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a, int64_t K = 1);
 int orx_launch_shard_request(orx_ctx* ctx, const RequestArgs& a, int64_t K = 1);
 int orx_launch_shard_bucket(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int cap, int32_t* send_ids, int32_t* slot,

@@ -77,7 +77,7 @@ struct Buf { void* p = nullptr; size_t cap = 0; };
 struct orx_vgroup {
     int world = 1;
     std::mutex mu; std::condition_variable cv; int waiting = 0; long generation = 0; bool broken = false;
-    const void* send[64] = {};
+    const void* send[64] = {}; const void* send2[64] = {};
     bool wait() {                                           // false: the group was aborted (a rank failed)
         std::unique_lock<std::mutex> lk(mu);
         if (broken) return false;
@@ -96,7 +96,7 @@ struct orx_comm {
     hipStream_t xstream = nullptr;                       // the exchanges of the overlapped path run here, beside the kernels
     hipEvent_t ev[8] = {};
     // the engine's exchange buffers (grown on demand, kept between calls)
-    Buf send1, mine, tmp, cnt, send2, req, req_loc, slot, u_loc, fu, fv, rows_out, rows_in, gu, u_apply, send_g, g_in, dupref, dsorted, seglist, segcount, gdup;
+    Buf send1, mine, tmp, cnt, send2, req, req_loc, slot, u_loc, fu, fv, rows_out, rows_in, gu, u_apply, send_g, g_in, dupref, dsorted, seglist, segcount, gdup, bias_x;
 };
 
 static int ensure(orx_comm* c, Buf& b, size_t bytes) {
@@ -171,7 +171,7 @@ extern "C" int orx_comm_destroy(orx_comm* c) {
     if (c->xstream) hipStreamDestroy(c->xstream);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     for (Buf* b : {&c->send1, &c->mine, &c->tmp, &c->cnt, &c->send2, &c->req, &c->req_loc, &c->slot, &c->u_loc, &c->fu, &c->fv,
-                   &c->rows_out, &c->rows_in, &c->gu, &c->u_apply, &c->send_g, &c->g_in, &c->dupref, &c->dsorted, &c->seglist, &c->segcount, &c->gdup})
+                   &c->rows_out, &c->rows_in, &c->gu, &c->u_apply, &c->send_g, &c->g_in, &c->dupref, &c->dsorted, &c->seglist, &c->segcount, &c->gdup, &c->bias_x})
         if (b->p) hipFree(b->p);
     delete c;
     return ORX_OK;
@@ -182,42 +182,56 @@ extern "C" int orx_comm_world(orx_comm* c) { return c ? c->world : -1; }
 
 // all-to-all of equal blocks: peer p gets send[p * bytes .. ), its block lands in recv[p * bytes .. ).  Returns where the result
 // is: `recv`, or `send` itself for a one-rank communicator without RCCL.
-static int exchange(orx_comm* c, const void* send, void* recv, size_t bytes, const void** result, hipStream_t stream = nullptr) {
+// device copy of one block (the rank's own share of an exchange; the virtual group's transfers)
+static int copy_block(const void* src, void* dst, size_t bytes, hipStream_t stream) {
+    ORX_ARG(bytes % 4 == 0, "sharded engine: exchange blocks are 4-byte words");
+    const bool wide = bytes % 16 == 0 && ((uintptr_t)src | (uintptr_t)dst) % 16 == 0;
+    const size_t nw = wide ? bytes / 16 : bytes / 4;
+    if (!nw) return ORX_OK;
+    const dim3 grid((unsigned)std::min<size_t>((nw + 255) / 256, 2048));
+    if (wide) hipLaunchKernelGGL(shard_copy_kernel<uint4>, grid, dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, (int64_t)nw);
+    else hipLaunchKernelGGL(shard_copy_kernel<uint32_t>, grid, dim3(256), 0, stream, (const uint32_t*)src, (uint32_t*)dst, (int64_t)nw);
+    return ORX_OK;
+}
+
+// all-to-all of equal blocks: peer p gets send[p * bytes .. ), its block lands in recv[p * bytes .. ); optionally a second,
+// smaller block per peer in the same group (the biases beside the rows).  `result` / `result2`: where the data is afterwards --
+// `recv`, or `send` itself for a one-rank communicator without RCCL.
+static int exchange(orx_comm* c, const void* send, void* recv, size_t bytes, const void** result, hipStream_t stream = nullptr,
+                    const void* send2 = nullptr, void* recv2 = nullptr, size_t bytes2 = 0, const void** result2 = nullptr) {
     if (!stream) stream = c->ctx->stream;
     *result = recv;
+    if (result2) *result2 = recv2;
+    const int nblk = send2 ? 2 : 1;
+    const void* sv[2] = {send, send2}; void* rv[2] = {recv, recv2}; const size_t bv[2] = {bytes, bytes2};
     if (c->vg) {
-        ORX_ARG(bytes % 4 == 0, "sharded engine: exchange blocks are 4-byte words");
         ORX_HIP(hipStreamSynchronize(stream));                      // my blocks are written
-        c->vg->send[c->rank] = send;
+        c->vg->send[c->rank] = send; c->vg->send2[c->rank] = send2;
         ORX_ARG(c->vg->wait(), "virtual group: another rank failed");
-        const size_t nw = bytes / 4;
-        for (int p = 0; p < c->world && nw; ++p)
-            hipLaunchKernelGGL(shard_copy_kernel<uint32_t>, dim3((unsigned)std::min<size_t>((nw + 255) / 256, 2048)), dim3(256), 0, stream,
-                               (const uint32_t*)((const char*)c->vg->send[p] + (size_t)c->rank * bytes), (uint32_t*)((char*)recv + (size_t)p * bytes), (int64_t)nw);
+        for (int p = 0; p < c->world; ++p) {
+            CHECK(copy_block((const char*)c->vg->send[p] + (size_t)c->rank * bytes, (char*)recv + (size_t)p * bytes, bytes, stream));
+            if (send2) CHECK(copy_block((const char*)c->vg->send2[p] + (size_t)c->rank * bytes2, (char*)recv2 + (size_t)p * bytes2, bytes2, stream));
+        }
         ORX_HIP(hipStreamSynchronize(stream));                      // ... and read before their owners write them again
         ORX_ARG(c->vg->wait(), "virtual group: another rank failed");
         return ORX_OK;
     }
-    if (!c->comm) { *result = send; return ORX_OK; }
-    // this rank's own block is a copy kernel (RCCL's send-to-self kernel moved 18 MB in 25 us);
-    // ORX_SHARD_RCCL_SELF=1 sends it through RCCL like any other (what the one-rank test uses to exercise ncclSend / ncclRecv)
+    if (!c->comm) { *result = send; if (result2) *result2 = send2; return ORX_OK; }
+    // this rank's own block is a copy kernel (RCCL's send-to-self kernel moved 18 MB in 25 us; hipMemcpyAsync cost ~100 us of runtime
+    // bookkeeping per call); ORX_SHARD_RCCL_SELF=1 sends it through RCCL like any other (what the one-rank test uses to exercise
+    // ncclSend / ncclRecv)
     static const bool rccl_self = getenv("ORX_SHARD_RCCL_SELF") && atoi(getenv("ORX_SHARD_RCCL_SELF")) != 0;
-    if (!rccl_self) {
-        const size_t off = (size_t)c->rank * bytes;                // (a kernel, not hipMemcpyAsync: 37 MB in 15 us instead of ~100 us of runtime bookkeeping)
-        ORX_ARG(bytes % 4 == 0, "sharded engine: exchange blocks are 4-byte words");
-        const bool wide = bytes % 16 == 0 && off % 16 == 0;
-        const size_t nw = wide ? bytes / 16 : bytes / 4;
-        const dim3 grid((unsigned)std::min<size_t>((nw + 255) / 256, 2048));
-        if (nw && wide) hipLaunchKernelGGL(shard_copy_kernel<uint4>, grid, dim3(256), 0, stream, (const uint4*)((const char*)send + off), (uint4*)((char*)recv + off), (int64_t)nw);
-        else if (nw) hipLaunchKernelGGL(shard_copy_kernel<uint32_t>, grid, dim3(256), 0, stream, (const uint32_t*)((const char*)send + off), (uint32_t*)((char*)recv + off), (int64_t)nw);
-    }
+    if (!rccl_self)
+        for (int q = 0; q < nblk; ++q) CHECK(copy_block((const char*)sv[q] + (size_t)c->rank * bv[q], (char*)rv[q] + (size_t)c->rank * bv[q], bv[q], stream));
     if (c->world == 1 && !rccl_self) return ORX_OK;
     RcclApi* api = rccl_api();
     ORX_NCCL(api, api->GroupStart());
     for (int p = 0; p < c->world; ++p) {
         if (p == c->rank && !rccl_self) continue;
-        ORX_NCCL(api, api->Send((const char*)send + (size_t)p * bytes, bytes, ncclInt8, p, c->comm, stream));
-        ORX_NCCL(api, api->Recv((char*)recv + (size_t)p * bytes, bytes, ncclInt8, p, c->comm, stream));
+        for (int q = 0; q < nblk; ++q) {
+            ORX_NCCL(api, api->Send((const char*)sv[q] + (size_t)p * bv[q], bv[q], ncclInt8, p, c->comm, stream));
+            ORX_NCCL(api, api->Recv((char*)rv[q] + (size_t)p * bv[q], bv[q], ncclInt8, p, c->comm, stream));
+        }
     }
     ORX_NCCL(api, api->GroupEnd());
     return ORX_OK;
@@ -293,7 +307,10 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
     const bool dedup = (flags & ORX_SHARD_DEDUP) ? true : (flags & ORX_SHARD_NO_DEDUP) ? false : (4 * (B / Hq) >= items_global);
     const int64_t Bh = B / H;
     const int64_t cap1 = bucket_cap(Bh, N, slack), T = N * cap1, cap2 = bucket_cap(2 * T, N, slack), M = N * cap2;
-    const int DS = D + 4;                                 // row + bias column, rows stay 16-byte aligned
+    // SGD: the biases travel apart from the rows (D + 1 floats per requested row on the wire; the rows stay 16-byte aligned);
+    // Adagrad / Adam (whose applies take row + bias gradient as one row): row + bias column, D + 4 floats
+    const bool split = opt->kind == ORX_SGD;
+    const int DS = split ? D : D + 4, DSg = D + 4;
     const int64_t B_global = B * N;
     const bool sgd = opt->kind == ORX_SGD;
     const int gflags = flags & ORX_NO_L2;
@@ -316,6 +333,7 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
         CHECK(ensure(c, c->rows_out, (size_t)H * M * DS * 4)); CHECK(ensure(c, c->rows_in, (size_t)H * M * DS * 4));
         CHECK(ensure(c, c->send_g, (size_t)H * M * DS * 4)); CHECK(ensure(c, c->g_in, (size_t)H * M * DS * 4));
         CHECK(ensure(c, c->gu, (size_t)H * T * D * 4)); CHECK(ensure(c, c->u_apply, (size_t)H * T * 4));
+        if (split) CHECK(ensure(c, c->bias_x, (size_t)4 * H * M * 4));          // biases out | in | bias gradients out | in, [H][M] each
         if (sgd) {
             CHECK(ensure(c, c->fu, Lr * T)); CHECK(ensure(c, c->fv, Lr * M));
             // (the context's own scratch of orx_rows_dupflags, for a whole chunk as well)
@@ -325,7 +343,7 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
         }
         if (dedup) {
             CHECK(ensure(c, c->dupref, Lr * 2 * T)); CHECK(ensure(c, c->dsorted, Lr * 2 * T * 8)); CHECK(ensure(c, c->seglist, Lr * T * 8));
-            CHECK(ensure(c, c->segcount, Lr * 4)); CHECK(ensure(c, c->gdup, (size_t)H * 2 * T * DS * 4));
+            CHECK(ensure(c, c->segcount, Lr * 4)); CHECK(ensure(c, c->gdup, (size_t)H * 2 * T * DSg * 4));
             CHECK(orx_rows_sort_reserve(ctx, (int64_t)Lr, 2 * T, (int64_t)N * ((items_global + N - 1) / N)));
             CHECK(orx_ensure((void**)&ctx->d_tmp, &ctx->d_tmp_cap, (Lr * 2 * T * 2 + Lr * ((2 * T + 1023) / 1024 + 64)) * sizeof(int32_t)));
         }
@@ -351,29 +369,41 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
         for (int k = 0; k < Kc; ++k) {
             const void* rows_in[2] = {nullptr, nullptr};
             const void* g_in[2] = {nullptr, nullptr};
+            const void* b_in[2] = {nullptr, nullptr};
+            const void* gb_in[2] = {nullptr, nullptr};
+            float* bx = (float*)c->bias_x.p;                 // [4][H][M]
             for (int h = 0; h < H; ++h) {                  // 3. owners gather row + bias, the rows travel back
                 const int l = k * H + h;
                 float* ro = (float*)c->rows_out.p + (size_t)h * M * DS;
-                CHECK(orx_gather_rows(ctx, V, b, req_loc + (size_t)l * M, M, ro, DS));
+                const int32_t* rl = req_loc + (size_t)l * M;
+                if (split) {
+                    CHECK(orx_table_touch(V, rl, M)); CHECK(orx_table_touch(b, rl, M));
+                    CHECK(orx_launch_gather(ctx, V->w, b->w, V->rows, D, rl, M, ro, DS, ctx->d_err, 1, bx + (size_t)h * M));
+                } else CHECK(orx_gather_rows(ctx, V, b, rl, M, ro, DS));
                 if (H == 2) { ORX_HIP(hipEventRecord(c->ev[h], S)); ORX_HIP(hipStreamWaitEvent(X, c->ev[h], 0)); }
-                CHECK(exchange(c, ro, (float*)c->rows_in.p + (size_t)h * M * DS, (size_t)cap2 * DS * 4, &rows_in[h], X));
+                if (split) CHECK(exchange(c, ro, (float*)c->rows_in.p + (size_t)h * M * DS, (size_t)cap2 * DS * 4, &rows_in[h], X,
+                                          bx + (size_t)h * M, bx + (size_t)(H + h) * M, (size_t)cap2 * 4, &b_in[h]));
+                else CHECK(exchange(c, ro, (float*)c->rows_in.p + (size_t)h * M * DS, (size_t)cap2 * DS * 4, &rows_in[h], X));
                 if (H == 2) ORX_HIP(hipEventRecord(c->ev[2 + h], X));
             }
             for (int h = 0; h < H; ++h) {                  // 4. gradients (+ SGD's apply of the user rows referenced once); 6. item gradients leave
                 const int l = k * H + h;
                 const int32_t* ul = u_loc + (size_t)l * T; const int32_t* sl = slot + (size_t)l * 2 * T;
                 float* gu = (float*)c->gu.p + (size_t)h * T * D; float* sg = (float*)c->send_g.p + (size_t)h * M * DS;
+                float* gbo = split ? bx + (size_t)(2 * H + h) * M : nullptr;
                 const unsigned char* dr = dedup ? dupref + (size_t)l * 2 * T : nullptr;
                 const void* so = dedup ? (const char*)c->dsorted.p + (size_t)l * 2 * T * 8 : nullptr;
                 const void* sgl = dedup ? (const char*)c->seglist.p + (size_t)l * T * 8 : nullptr;
                 const int32_t* sgc = dedup ? (const int32_t*)c->segcount.p + l : nullptr;
-                float* gd = dedup ? (float*)c->gdup.p + (size_t)h * 2 * T * DS : nullptr;
+                float* gd = dedup ? (float*)c->gdup.p + (size_t)h * 2 * T * DSg : nullptr;
                 if (H == 2) ORX_HIP(hipStreamWaitEvent(S, c->ev[2 + h], 0));
-                if (sgd) CHECK(orx_shard_grads_sgd(ctx, model, opt, U, (const float*)rows_in[h], ul, sl, dr, so, sgl, sgc, gd, fu + (size_t)l * T, T, DS, B_global, margin, gflags,
-                                                   gu, (int32_t*)c->u_apply.p + (size_t)h * T, sg, loss_l2_accum));
-                else CHECK(orx_shard_grads(ctx, model, U, (const float*)rows_in[h], ul, sl, dr, so, sgl, sgc, gd, T, DS, B_global, margin, gflags, gu, sg, loss_l2_accum));
+                CHECK(orx_shard_grads_impl(ctx, model, sgd ? opt : nullptr, U, (const float*)rows_in[h], (const float*)b_in[h], ul, sl, dr, so, sgl, sgc, gd,
+                                           sgd ? fu + (size_t)l * T : nullptr, T, DS, B_global, margin, gflags, gu,
+                                           sgd ? (int32_t*)c->u_apply.p + (size_t)h * T : nullptr, sg, gbo, loss_l2_accum));
                 if (H == 2) { ORX_HIP(hipEventRecord(c->ev[4 + h], S)); ORX_HIP(hipStreamWaitEvent(X, c->ev[4 + h], 0)); }
-                CHECK(exchange(c, sg, (float*)c->g_in.p + (size_t)h * M * DS, (size_t)cap2 * DS * 4, &g_in[h], X));
+                if (split) CHECK(exchange(c, sg, (float*)c->g_in.p + (size_t)h * M * DS, (size_t)cap2 * DS * 4, &g_in[h], X,
+                                          gbo, bx + (size_t)(3 * H + h) * M, (size_t)cap2 * 4, &gb_in[h]));
+                else CHECK(exchange(c, sg, (float*)c->g_in.p + (size_t)h * M * DS, (size_t)cap2 * DS * 4, &g_in[h], X));
                 if (H == 2) ORX_HIP(hipEventRecord(c->ev[6 + h], X));
             }
             if (opt->kind == ORX_ADAM) CHECK(orx_opt_advance(opt, tabs, 3));   // Keras `iterations` += 1: after the step's gathers, before its applies
@@ -383,7 +413,8 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
                                                  fu + (size_t)(k * H + h) * T));
                 for (int h = 0; h < H; ++h) {              // item-row gradients at their owners
                     if (H == 2) ORX_HIP(hipStreamWaitEvent(S, c->ev[6 + h], 0));
-                    CHECK(orx_apply_rows_flagged(ctx, opt, V, b, req_loc + (size_t)(k * H + h) * M, M, (const float*)g_in[h], DS, fv + (size_t)(k * H + h) * M));
+                    CHECK(orx_apply_rows_flagged_impl(ctx, opt, V, b, req_loc + (size_t)(k * H + h) * M, M, (const float*)g_in[h], DS, (const float*)gb_in[h],
+                                                      fv + (size_t)(k * H + h) * M));
                 }
             } else {                                       // Adagrad / Adam sum a row's duplicates FIRST: one list per table and step
                 CHECK(orx_apply_rows(ctx, opt, U, nullptr, u_loc + (size_t)k * H * T, H * T, (float*)c->gu.p, D));
