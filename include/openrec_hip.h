@@ -305,6 +305,13 @@ int orx_dlrm_inference(orx_dlrm* m, const float* dense, const int32_t* sparse, i
  *                          flat[count] (after the all-reduce); advances the step counter. */
 int orx_dlrm_grads(orx_dlrm* m, const float* dense, const float* emb_rows, const float* label, int64_t B,
                    int64_t global_B, float* emb_grads, double* loss_accum);
+/*   orx_dlrm_grads_indirect : the same with the embedding rows read IN PLACE from the buffer the exchange filled (rows
+ *                          [n_rows][m_spa], idx[b (n_emb + 1) + f] = row of lookup f of sample b, slot n_emb unused) and the
+ *                          gradient of each lookup written to row idx[...] of grads_dst, the buffer that travels back: no
+ *                          reordering passes.  orx_dlrm_direct_ok: 1 if this model's shapes allow it. */
+int orx_dlrm_direct_ok(orx_dlrm* m);
+int orx_dlrm_grads_indirect(orx_dlrm* m, const float* dense, const float* rows, int64_t n_rows, const int32_t* idx,
+                            const float* label, int64_t B, int64_t global_B, float* grads_dst, double* loss_accum);
 int orx_dlrm_dense_count(orx_dlrm* m, int64_t* count);
 int orx_dlrm_dense_pack(orx_dlrm* m, float* flat);
 int orx_dlrm_dense_apply(orx_dlrm* m, orx_opt* opt, const float* flat);

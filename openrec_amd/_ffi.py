@@ -79,6 +79,8 @@ SIGNATURES = {
     "orx_dlrm_step": (c_int, [_p, _p, _fp, _ip, _fp, c_int64, c_int64, c_int, _fp]),
     "orx_dlrm_inference": (c_int, [_p, _fp, _ip, c_int64, c_int, _fp]),
     "orx_dlrm_grads": (c_int, [_p, _p, _p, _p, c_int64, c_int64, _p, _p]),
+    "orx_dlrm_direct_ok": (c_int, [_p]),
+    "orx_dlrm_grads_indirect": (c_int, [_p, _fp, _fp, c_int64, _ip, _fp, c_int64, c_int64, _fp, _p]),
     "orx_dlrm_dense_count": (c_int, [_p, POINTER(c_int64)]),
     "orx_dlrm_dense_pack": (c_int, [_p, _p]),
     "orx_dlrm_dense_apply": (c_int, [_p, _p, _p]),

@@ -63,6 +63,9 @@ struct orx_dlrm {
     void* g16 = nullptr, *g16b = nullptr;   // dY after the activation backward, [cap][up8(maxw)], ping-pong
     ShadowParam* d_shadow = nullptr; int n_shadow = 0; int64_t shadow_max = 0;
     const int32_t* direct_idx = nullptr;    // set by forward(): the interaction reads embedding rows through these ids (no gathered copy in Z)
+    const float* direct_base = nullptr; int64_t direct_rows = 0;     // ... from this array (the combined table, or rows handed in)
+    // hybrid-parallel step with the exchanged rows read in place (orx_dlrm_grads_indirect): rows, their count, where the gradients go
+    const float* ext_rows = nullptr; int64_t ext_n = 0; float* ext_gdst = nullptr;
     bool gen2 = false;                  // ORX_DLRM_FP16_MLP with the kernels of kernels_gemm16.hip (ORX_DLRM_GEMM_V1 = the round-1 kernels)
     SlabReduce* d_slabjobs[2] = {nullptr, nullptr}; int n_slabjobs[2] = {0, 0}, slab_max_tiles[2] = {0, 0};   // [0] bottom, [1] top MLP
     void* dense16 = nullptr; int ld_dense16 = 0;   // fp16 copy of the dense features (operand of the first bottom layer)
@@ -357,8 +360,11 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
     orx_ctx* c = m->ctx;
     const int F = m->F, d = m->m_spa;
     const int compat = (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0, itself = (m->flags & ORX_DLRM_INTERACT_ITSELF) ? 1 : 0;
-    m->direct_idx = nullptr;
-    if (emb_rows != nullptr) {
+    m->direct_idx = nullptr; m->direct_base = nullptr; m->direct_rows = 0;
+    if (m->ext_rows != nullptr) {                     // rows of an exchange buffer, read in place through idx
+        ORX_ARG(idx != nullptr && orx_interact_direct_ok(F, d, compat), "dlrm: rows in place need the MFMA interaction kernels");
+        m->direct_idx = idx; m->direct_base = m->ext_rows; m->direct_rows = m->ext_n;
+    } else if (emb_rows != nullptr) {
         CHECK(orx_launch_copy2d(c, m->Z, (int64_t)F * d, emb_rows, (int64_t)m->n_emb * d, (int)B, m->n_emb * d));
     } else {
         ORX_ARG(m->emb, "dlrm: the model was created with ORX_DLRM_NO_EMB (use orx_dlrm_grads)");
@@ -371,6 +377,7 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
         // dlrm.py:83-85: the n_emb gathers = one gather on the combined table (dense slot skipped) -- or none at all: the
         // MFMA interaction kernels (forward and backward) read the rows from the table through idx
         m->direct_idx = orx_interact_direct_ok(F, d, compat) ? idx : nullptr;
+        if (m->direct_idx) { m->direct_base = m->emb->w; m->direct_rows = m->emb->rows; }
         if (!m->direct_idx) CHECK(orx_launch_gather(c, m->emb->w, nullptr, m->emb->rows, d, idx, B * F, m->Z, d, c->d_err, 1));
     }
     const bool f16 = (m->flags & ORX_DLRM_FP16_MLP) != 0;
@@ -411,7 +418,7 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
     // dlrm.py:89-92: R = concat(dense_emb, interaction)
     bool have16 = false;                                         // does the current activation have an fp16 copy?
     CHECK(orx_launch_interact(c, true, m->Z, nullptr, F, d, compat, itself, m->R, m->P, B, m->ldR, f16 ? m->R16 : nullptr, m->ldR16, &have16,
-                              m->direct_idx ? m->emb->w : nullptr, m->direct_idx, m->direct_idx ? m->emb->rows : 0));
+                              m->direct_idx ? m->direct_base : nullptr, m->direct_idx, m->direct_idx ? m->direct_rows : 0));
     if (m->gen2 && !have16) {            // (the LDS interaction kernels -- reference_compat, odd shapes -- write fp32 only)
         CHECK(orx_launch_cast16(c, m->R, m->ldR, m->R16, m->ldR16, (int)B, m->m_spa + m->P));
         have16 = true;
@@ -634,7 +641,8 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale, bool 
     // ---- interaction backward: dZ for every slot (slot F-1 = d dense_emb)
     // (dR carries the loss scale; dZ -- the embedding rows' gradients -- leaves unscaled)
     CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B, m->ldR, nullptr, 0, nullptr,
-                              m->direct_idx ? m->emb->w : nullptr, m->direct_idx, m->direct_idx ? m->emb->rows : 0, 1.0f / gscale));
+                              m->direct_idx ? m->direct_base : nullptr, m->direct_idx, m->direct_idx ? m->direct_rows : 0, 1.0f / gscale,
+                              m->ext_rows ? m->ext_gdst : nullptr));
     // ---- bottom MLP backward from dZ[:, F-1, :]
     float* dy = (dR == m->gA) ? m->gB : m->gA;
     float* other = (dy == m->gA) ? m->gB : m->gA;
@@ -838,6 +846,36 @@ extern "C" int orx_dlrm_grads(orx_dlrm* m, const float* dense, const float* emb_
     m->grads_pending = true;
     const int d = m->m_spa;
     return orx_launch_copy2d(c, emb_grads, (int64_t)m->n_emb * d, m->dZ, (int64_t)m->F * d, (int)B, m->n_emb * d);
+}
+
+// can the hybrid-parallel step read the exchanged rows in place (MFMA interaction kernels for this model's shapes)?
+extern "C" int orx_dlrm_direct_ok(orx_dlrm* m) {
+    return m && orx_interact_direct_ok(m->F, m->m_spa, (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0) ? 1 : 0;
+}
+
+// orx_dlrm_grads with the embedding rows read IN PLACE: rows [n_rows][m_spa] is the buffer the exchange filled, idx[b (n_emb + 1) + f]
+// the row of lookup f of sample b in it (slot n_emb of every sample is not read), and the gradient of that lookup is written to
+// row idx[...] of grads_dst -- the buffer that travels back.  Four passes over B n_emb m_spa floats fewer than the copying form.
+extern "C" int orx_dlrm_grads_indirect(orx_dlrm* m, const float* dense, const float* rows, int64_t n_rows, const int32_t* idx,
+                                       const float* label, int64_t B, int64_t global_B, float* grads_dst, double* loss_accum) {
+    ORX_ARG(m && dense && rows && idx && label && grads_dst && loss_accum && n_rows > 0, "orx_dlrm_grads_indirect: NULL argument");
+    ORX_ARG(B > 0 && global_B >= B, "orx_dlrm_grads_indirect: need 0 < B <= global_B");
+    ORX_ARG(!m->grads_pending, "orx_dlrm_grads_indirect: the dense gradients of the previous call were not applied (orx_dlrm_dense_apply)");
+    ORX_ARG(orx_dlrm_direct_ok(m), "orx_dlrm_grads_indirect: this model's shapes need the copying form (orx_dlrm_grads)");
+    orx_ctx* c = m->ctx;
+    ORX_HIP(hipSetDevice(c->device));
+    CHECK(ensure_buffers(m, B));
+    Batch bt; bt.dense = dense; bt.sparse = nullptr; bt.label = label;
+    m->ext_rows = rows; m->ext_n = n_rows; m->ext_gdst = grads_dst;
+    int rc = forward(m, bt, B, nullptr, idx);
+    if (rc == ORX_OK) {
+        const float gscale = loss_scale(m, global_B);
+        rc = orx_launch_dlrm_loss(c, m->top_y.back(), label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, loss_accum, global_B, 1, gscale);
+        if (rc == ORX_OK) rc = backward(m, bt, B, gscale);
+    }
+    m->ext_rows = nullptr; m->ext_n = 0; m->ext_gdst = nullptr;
+    if (rc == ORX_OK) m->grads_pending = true;
+    return rc;
 }
 
 extern "C" int orx_dlrm_dense_count(orx_dlrm* m, int64_t* count) {

@@ -739,6 +739,8 @@ __global__ __launch_bounds__(256) void interact_bwd_kernel(const float* Z, const
 // directly removes the gather pass: 109 MB written and read again per step at the C5 shapes.
 struct RowSrc {
     const float* Z; const float* emb; const int32_t* idx; int64_t rows; int* err;
+    float* gdst;       // backward: the gradient of embedding slot f of sample b goes to row idx[b F + f] of this array instead of dZ
+                       // (hybrid-parallel step: straight into the buffer that travels back to the rows' owners); NULL: dZ
     __device__ __forceinline__ const float* row(int64_t b, int f, int F, int d) const {
         if (emb == nullptr || f == F - 1) return Z + (b * F + f) * d;
         const int r = idx[b * F + f];
@@ -860,6 +862,11 @@ __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, cons
             const int g = 16 * ti + q * 4 + r;
             if (g >= F) continue;
             float* out = dZ + (b * F + g) * d + coff + CPL * i;
+            if (src.gdst != nullptr && g != F - 1) {
+                const int r = src.idx[b * F + g];
+                if ((uint32_t)r >= (uint64_t)src.rows) continue;         // (reported by the forward pass)
+                out = src.gdst + (size_t)r * d + coff + CPL * i;
+            }
             float o[CPL];
 #pragma unroll
             for (int t = 0; t < CPL; ++t) o[t] = (acc[ti][t][r] + (g == F - 1 ? rb[coff + CPL * i + t] : 0.0f)) * scale;
@@ -880,13 +887,14 @@ bool orx_interact_direct_ok(int F, int d, int compat) {
 
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
                         float* out, int P, int64_t B, int ldR, void* R16, int ldR16, bool* wrote16,
-                        const float* emb, const int32_t* idx, int64_t emb_rows, float scale) {
+                        const float* emb, const int32_t* idx, int64_t emb_rows, float scale, float* gdst) {
     if (wrote16) *wrote16 = false;
     if (B == 0) return ORX_OK;
     const bool mfma = !compat && F <= 32 && d % 32 == 0 && ((uintptr_t)Z & 15) == 0 && getenv("ORX_INTERACT_SIMPLE") == nullptr;
     const bool bwd_ok = d == 32 || d == 64 || d == 128 || d == 256;
     ORX_ARG(emb == nullptr || (mfma && bwd_ok), "interact: direct table rows need the MFMA kernels");
-    const RowSrc src{Z, emb, idx, emb_rows, ctx->d_err};
+    const RowSrc src{Z, emb, idx, emb_rows, ctx->d_err, fwd ? nullptr : gdst};
+    ORX_ARG(gdst == nullptr || (emb != nullptr && mfma && bwd_ok), "interact: a gradient destination needs the direct rows");
     if (mfma && (fwd || bwd_ok)) {
         const dim3 g((unsigned)((B + 3) / 4));
         if (fwd) {

@@ -461,7 +461,8 @@ int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int
 int orx_launch_copy2d(orx_ctx* ctx, float* dst, int64_t ldd, const float* src, int64_t lds_, int M, int N, float scale = 1.0f);
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
                         float* out, int P, int64_t B, int ldR, void* R16 = nullptr, int ldR16 = 0, bool* wrote16 = nullptr,
-                        const float* emb = nullptr, const int32_t* idx = nullptr, int64_t emb_rows = 0, float scale = 1.0f);
+                        const float* emb = nullptr, const int32_t* idx = nullptr, int64_t emb_rows = 0, float scale = 1.0f,
+                        float* gdst = nullptr);
 bool orx_interact_direct_ok(int F, int d, int compat);
 int orx_launch_dlrm_loss(orx_ctx* ctx, float* P, const float* y, int64_t B, int bce, float thr, float* dP, double* loss_out,
                          int64_t n_mean = 0, int accumulate = 0, float gscale = 1.0f);

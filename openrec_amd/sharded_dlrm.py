@@ -82,6 +82,16 @@ class HipDLRMBackend:
         self.model.grads(dense.data_ptr(), emb_rows.data_ptr(), label.data_ptr(), label.numel(), global_b,
                          emb_grads.data_ptr(), loss_accum.data_ptr())
 
+    def direct_ok(self):
+        """may the step read the exchanged rows in place (orx_dlrm_grads_indirect)?"""
+        return bool(self.lib.orx_dlrm_direct_ok(self.model._h))
+
+    def grads_indirect(self, dense, rows, idx, label, global_b, grads_dst, loss_accum):
+        """forward + backward with the embedding rows read in place from `rows` (the receive buffer) through idx [B, n_emb + 1];
+        the gradient of every lookup is written to row idx[b, f] of `grads_dst` (the buffer that travels back)"""
+        self._ffi.check(self.lib.orx_dlrm_grads_indirect(self.model._h, dense.data_ptr(), rows.data_ptr(), rows.shape[0], idx.data_ptr(),
+                                                         label.data_ptr(), label.numel(), global_b, grads_dst.data_ptr(), loss_accum.data_ptr()))
+
     def dense_count(self):
         return self.model.dense_count()
 
@@ -121,6 +131,7 @@ class ShardedDLRM:
         self.overflow = torch.zeros((), dtype=torch.bool, device=device)
         self.bad_id = torch.zeros((), dtype=torch.bool, device=device)
         self.force_collectives = False          # world size 1 still goes through RCCL (bench.py --sharded under torchrun)
+        self.copying = False                    # True: always the copying form of the local step (orx_dlrm_grads)
         self._cnt = torch.zeros(64, dtype=torch.int32, device=device)
         self._ovf = torch.zeros(1, dtype=torch.int32, device=device)
 
@@ -196,15 +207,26 @@ class ShardedDLRM:
         rows_out, rows_in, emb_grads, send_g = buf["rows_out"], buf["rows_in"], buf["emb_grads"], buf["send_g"]
         self.be.gather_rows(self.emb, req_loc, rows_out)
         self._a2a_into(rows_in[:trash], rows_out)
-        emb_rows = rows_in.index_select(0, slot_t)                           # [B*nf, d] in lookup order
-        # ---- 3. local forward + backward
-        self.be.grads(dense, emb_rows, label, B * N, emb_grads, self.loss_accum)
+        indirect = hasattr(self.be, "grads_indirect") and self.be.direct_ok() and not self.copying
+        if indirect:
+            # ---- 3. local forward + backward on the rows where they arrived: lookup (b, f) reads row slot[b, f] of rows_in and its
+            # gradient goes to row slot[b, f] of send_g (no reordering passes over the B x n_emb x d block)
+            idx = buf.get("idx")
+            if idx is None or idx.shape[0] != B:
+                idx = buf["idx"] = torch.full((B, nf + 1), -1, dtype=torch.int32, device=dev)
+            idx[:, :nf] = slot_t.view(B, nf)
+            self.be.grads_indirect(dense, rows_in, idx, label, B * N, send_g, self.loss_accum)
+        else:
+            emb_rows = rows_in.index_select(0, slot_t)                       # [B*nf, d] in lookup order
+            # ---- 3. local forward + backward
+            self.be.grads(dense, emb_rows, label, B * N, emb_grads, self.loss_accum)
         # ---- 4. dense gradients: one all-reduce, then the dense rule on every replica
         self.be.dense_pack(self.flat)
         self._allreduce(self.flat)
         self.be.dense_apply(self.flat)
         # ---- 5. embedding gradients back to the owners (padding slots carry garbage and are skipped: id -1)
-        send_g.index_copy_(0, slot_t, emb_grads)
+        if not indirect:
+            send_g.index_copy_(0, slot_t, emb_grads)
         g_in = self._a2a(send_g[:trash])
         self.be.apply_rows(self.emb, req_loc, g_in)
         return None

@@ -60,8 +60,12 @@ def _case(steps, B, seed=3):
 
 
 @pytest.mark.parametrize("world", [1, 2, 4])
-@pytest.mark.parametrize("optk,compat,loss", [("sgd", False, "bce"), ("adagrad", False, "mse"), ("sgd", True, "mse"), ("adam", False, "bce")])
-def test_virtual_cluster_dlrm_matches_oracle(world, optk, compat, loss):
+@pytest.mark.parametrize("optk,compat,loss,m_spa", [("sgd", False, "bce", 16), ("adagrad", False, "mse", 16), ("sgd", True, "mse", 16), ("adam", False, "bce", 16),
+                                                    ("sgd", False, "bce", 32), ("adagrad", False, "mse", 64), ("adam", False, "mse", 32), ("sgd", True, "mse", 32)])
+def test_virtual_cluster_dlrm_matches_oracle(world, optk, compat, loss, m_spa):
+    """m_spa 32 / 64 (without reference_compat): the local step reads the exchanged rows in place and writes the row gradients
+    straight into the buffer that travels back (orx_dlrm_grads_indirect); m_spa 16 and reference_compat: the copying form."""
+    CFG = dict(globals()["CFG"], m_spa=m_spa, ln_bot=[64, m_spa])          # (dlrm.py: the bottom MLP ends at the embedding width)
     import torch
     from openrec_amd.sharded_dlrm import ShardedDLRM
     from oracle.dlrm_oracle import DLRMOracle
@@ -86,6 +90,7 @@ def test_virtual_cluster_dlrm_matches_oracle(world, optk, compat, loss):
                 for l, (W, b) in enumerate(layers):
                     e.be.dense_param(name + "_w", l).write(W); e.be.dense_param(name + "_b", l).write(b.reshape(1, -1))
             engs[rank] = e
+            assert e.be.direct_ok() == (m_spa >= 32 and not compat)
             per = Bg // world
             sl = slice(rank * per, (rank + 1) * per)
             for dense, sparse, label in data:
