@@ -157,3 +157,21 @@ def test_sharded_kstep_paths_world4(tmp_path, model, optk, overlap):
     """four ranks: the [dest][step][slot] <-> [step][src][slot] transposes of the chunk-wide exchanges are their own inverse
     at world 2 -- here they are not"""
     test_sharded_kstep_paths_equal_single_process(tmp_path, 4, model, optk, overlap)
+
+
+def test_library_engine_bucket_capacities_equal_the_python_engine():
+    """orx_sharded_caps (host arithmetic of the library's engine, no device needed) against ShardedPairwise._cap: the two engines
+    must size their exchange buckets alike, or a job that mixes them (per-phase tests against the library's K-step call) disagrees
+    about what overflows."""
+    import ctypes
+    import math
+    from openrec_amd import _ffi
+    lib = _ffi.load()
+    for B in (1, 7, 4096, 65536, 32768):
+        for world in (1, 2, 8, 64):
+            for slack in (1.0, 1.05, 1.5):
+                c1, c2 = ctypes.c_int64(), ctypes.c_int64()
+                _ffi.check(lib.orx_sharded_caps(B, world, slack, ctypes.byref(c1), ctypes.byref(c2)))
+                cap = lambda n: int(math.ceil(n / world * slack + 6 * math.sqrt(n / world) + 16))
+                assert c1.value == cap(B), (B, world, slack)
+                assert c2.value == cap(2 * world * cap(B)), (B, world, slack)
