@@ -31,21 +31,22 @@ struct RcclApi {
 };
 
 RcclApi* rccl_api() {
-    static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.handle ? &api : nullptr;
-    tried = true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    void* h = nullptr;
-    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
-    if (!h) return nullptr;
+    // (a function-local static: initialised once, thread-safely, whichever thread asks first)
+    static RcclApi* loaded = []() -> RcclApi* {
+        static RcclApi api;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        void* h = nullptr;
+        for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) return nullptr;
 #define ORX_SYM(field, name) do { *(void**)(&api.field) = dlsym(h, name); if (!api.field) { dlclose(h); return nullptr; } } while (0)
-    ORX_SYM(GetUniqueId, "ncclGetUniqueId"); ORX_SYM(CommInitRank, "ncclCommInitRank"); ORX_SYM(CommDestroy, "ncclCommDestroy");
-    ORX_SYM(GroupStart, "ncclGroupStart"); ORX_SYM(GroupEnd, "ncclGroupEnd"); ORX_SYM(Send, "ncclSend"); ORX_SYM(Recv, "ncclRecv");
-    ORX_SYM(GetErrorString, "ncclGetErrorString");
+        ORX_SYM(GetUniqueId, "ncclGetUniqueId"); ORX_SYM(CommInitRank, "ncclCommInitRank"); ORX_SYM(CommDestroy, "ncclCommDestroy");
+        ORX_SYM(GroupStart, "ncclGroupStart"); ORX_SYM(GroupEnd, "ncclGroupEnd"); ORX_SYM(Send, "ncclSend"); ORX_SYM(Recv, "ncclRecv");
+        ORX_SYM(GetErrorString, "ncclGetErrorString");
 #undef ORX_SYM
-    api.handle = h;
-    return &api;
+        api.handle = h;
+        return &api;
+    }();
+    return loaded;
 }
 
 #define ORX_NCCL(api, expr) do { const ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { \
