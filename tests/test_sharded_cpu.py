@@ -99,7 +99,7 @@ def test_bucket_slots_is_a_stable_partition():
     assert bool(ov) and ((slot.numpy() >= 0).sum() == 40)
 
 
-def _run_rank_ksteps(rank, world, port, model, optk, overlap, out):
+def _run_rank_ksteps(rank, world, port, model, optk, overlap, out, dedup=None):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from sharded_ref_backend import FastOracleBackend, FlaggedOracleBackend
@@ -112,7 +112,7 @@ def _run_rank_ksteps(rank, world, port, model, optk, overlap, out):
     # case here does too
     be = (FlaggedOracleBackend if optk == "sgd" and (model == "bpr") == bool(overlap) else FastOracleBackend)(optk, 0.05)
     eng = sharded.ShardedPairwise(model, optk, U.shape[0], V.shape[0], U.shape[1], lr=0.05, rank=rank, world=world,
-                                  device=torch.device("cpu"), backend=be, slack=1.5)
+                                  device=torch.device("cpu"), backend=be, slack=1.5, dedup=dedup)
     assert eng.fast
     eng.U.w[:] = U[rank::world]; eng.V.w[:] = V[rank::world]; eng.b.w[:] = b[rank::world]
     B = steps[0][0].shape[0]; per = B // world
@@ -130,16 +130,16 @@ def _run_rank_ksteps(rank, world, port, model, optk, overlap, out):
 @pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("world", [1, 2])
 @pytest.mark.parametrize("model,optk", [("bpr", "sgd"), ("bpr", "adagrad"), ("ucml", "sgd"), ("bpr", "adam")])
-def test_sharded_kstep_paths_equal_single_process(tmp_path, world, model, optk, overlap):
+def test_sharded_kstep_paths_equal_single_process(tmp_path, world, model, optk, overlap, dedup=None):
     """What `bench.py --gpus N` runs -- `ShardedPairwise.steps`: the exchange plan of a chunk of steps in one all-to-all per
     phase, and the overlapped form with two half-batches per step and ASYNCHRONOUS all-to-alls -- over real collectives with
     two ranks (gloo).  The device kernels of the plan are restated in tests/sharded_ref_backend.py (FastOracleBackend); the
     GPU tests hold the kernels themselves against the same oracle on a virtual cluster."""
     out = str(tmp_path / "k%d.npz")
     if world == 1:
-        _run_rank_ksteps(0, 1, 0, model, optk, overlap, out)
+        _run_rank_ksteps(0, 1, 0, model, optk, overlap, out, dedup)
     else:
-        mp.spawn(_run_rank_ksteps, args=(world, _free_port(), model, optk, overlap, out), nprocs=world, join=True)
+        mp.spawn(_run_rank_ksteps, args=(world, _free_port(), model, optk, overlap, out, dedup), nprocs=world, join=True)
     U, V, b, steps = _global_case(model)
     o = {"sgd": lambda: orc.SGD(0.05), "adagrad": lambda: orc.Adagrad(0.05, 0.1, 1e-7), "adam": lambda: orc.AdamTFSparse(0.05)}[optk]()
     tl = tl2 = 0.0
@@ -157,6 +157,14 @@ def test_sharded_kstep_paths_world4(tmp_path, model, optk, overlap):
     """four ranks: the [dest][step][slot] <-> [step][src][slot] transposes of the chunk-wide exchanges are their own inverse
     at world 2 -- here they are not"""
     test_sharded_kstep_paths_equal_single_process(tmp_path, 4, model, optk, overlap)
+
+
+@pytest.mark.parametrize("dedup", [False, True])
+@pytest.mark.parametrize("model,optk,overlap", [("bpr", "sgd", False), ("bpr", "adagrad", True), ("ucml", "adam", False)])
+def test_sharded_kstep_paths_with_and_without_request_dedup(tmp_path, model, optk, overlap, dedup):
+    """The request plan both ways, whatever the size heuristic (ShardedPairwise._dedup_for) would pick for this case: one slot
+    per reference, and one slot per distinct item of a list with the owner's gradients summed per slot before they travel."""
+    test_sharded_kstep_paths_equal_single_process(tmp_path, 2, model, optk, overlap, dedup)
 
 
 def test_library_engine_bucket_capacities_equal_the_python_engine():
