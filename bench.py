@@ -70,9 +70,15 @@ def cpu_baseline(args, budget_s=15.0, max_steps=2000):
     V = rng.uniform(-0.05, 0.05, (args.items, args.dim)).astype(np.float32)
     b = rng.uniform(-0.05, 0.05, (args.items, 1)).astype(np.float32)
     cpu, cores, what = c_oracle.PairwiseCPU(args.model, args.opt, U, V, b, lr=0.05), c_oracle.num_threads(), "oracle/orx_oracle.c (OpenMP)"
-    ids = [(rng.integers(0, args.users, args.batch).astype(np.int32),
-            rng.integers(0, args.items, args.batch).astype(np.int32),
-            rng.integers(0, args.items, args.batch).astype(np.int32)) for _ in range(32)]
+    def draw():       # the same id law as make_ids: uniform users / items, negatives that collide with the positive are redrawn
+        u, p, n = (rng.integers(0, hi, args.batch).astype(np.int32) for hi in (args.users, args.items, args.items))
+        for _ in range(4):
+            clash = n == p
+            if not clash.any():
+                break
+            n = np.where(clash, rng.integers(0, args.items, args.batch).astype(np.int32), n)
+        return u, p, n
+    ids = [draw() for _ in range(32)]
     for s in range(2):
         cpu.step(*ids[s])
     t0 = time.perf_counter()

@@ -43,11 +43,16 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+HASH_FILE = LIB + ".hash"      # source_hash() of the sources the .so was built from (mtimes say nothing on a shipped snapshot)
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(HASH_FILE):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(f) > t for f in _deps())
+    try:
+        return open(HASH_FILE).read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 def _compile(src):
@@ -80,6 +85,8 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    with open(HASH_FILE, "w") as f:
+        f.write(source_hash() + "\n")
     if verbose:
         print("built", LIB)
     return LIB

@@ -267,9 +267,23 @@ class L2Sum:
         self._step = None
 
     def __add__(self, other):
+        mine = getattr(self, "scale", 1.0)
         if isinstance(other, L2Sum):
-            return L2Sum(self.rows + other.rows, self.extra + other.extra, self.params + other.params)
-        return L2Sum(self.rows, self.extra + float(other), self.params)
+            theirs = getattr(other, "scale", 1.0)
+            if mine == theirs:
+                # `k * l2(a) + k * l2(b)`: the rows merge and the common weight travels with them
+                out = L2Sum(self.rows + other.rows, self.extra + other.extra, self.params + other.params)
+            else:
+                # different weights: no fused step takes such a term -- the scaled VALUE goes into `extra` (a host number), and
+                # resolve() then never matches a recorded step (tape.gradient raises instead of training with another weight)
+                out = L2Sum(self.rows, self.extra + float(other.numpy()), self.params)
+            if mine != 1.0:
+                out.scale = mine
+            return out
+        out = L2Sum(self.rows, self.extra + float(other), self.params)
+        if mine != 1.0:
+            out.scale = mine
+        return out
 
     __radd__ = __add__
 

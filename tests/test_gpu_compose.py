@@ -274,3 +274,16 @@ def test_a_lookup_made_before_a_step_holds_the_pre_step_rows_and_a_scaled_l2_ter
     assert float(l2) == pytest.approx(want, rel=1e-5)
     with pytest.raises(NotImplementedError, match="scaled by 0.01"):
         tape.gradient((loss, l2), vars_)
+    # `k * l2(a) + k * l2(b) + k * l2(c)`: the sum keeps the common weight (value k * sum, and the tape still refuses it) ...
+    with tf.GradientTape() as tape:
+        uv, pv, nv = Uf(u), Vf(p), Vf(n)
+        loss = PairwiseLogLoss()(uv, pv, nv, bf(p), bf(n))
+        l2 = 0.01 * tf.nn.l2_loss(uv) + 0.01 * tf.nn.l2_loss(pv) + 0.01 * tf.nn.l2_loss(nv)
+    assert float(l2) == pytest.approx(want, rel=1e-5)
+    with pytest.raises(NotImplementedError, match="scaled by 0.01"):
+        tape.gradient((loss, l2), vars_)
+    # ... and terms with different weights evaluate to their weighted sum and never resolve to a fused step
+    mixed = 0.5 * tf.nn.l2_loss(uv) + 0.25 * tf.nn.l2_loss(pv)
+    want_mixed = 0.5 * 0.5 * float((U1[u].astype(np.float64) ** 2).sum()) + 0.25 * 0.5 * float((V1[p].astype(np.float64) ** 2).sum())
+    assert float(mixed) == pytest.approx(want_mixed, rel=1e-5)
+    assert mixed.resolve() is None
