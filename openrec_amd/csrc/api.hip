@@ -104,6 +104,7 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_evalbits); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_cflag); hipFree(c->d_dupbits); hipFree(c->d_dlist);
     hipFree(c->d_dcount); hipFree(c->d_refinfo); hipFree(c->d_tricnt); hipFree(c->d_segstart); hipFree(c->d_alloc); hipFree(c->d_dseg); hipFree(c->d_dcnt); hipFree(c->d_chunks); hipFree(c->d_part); hipFree(c->d_partb); hipFree(c->d_stage); hipFree(c->d_stageb); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
     hipFree(c->d_wpart); hipFree(c->d_pl_cnt); hipFree(c->d_pl_list);
+    hipFree(c->d_pinfo); hipFree(c->d_claim); hipFree(c->d_swaps);
     hipFree(c->d_sort[0]); hipFree(c->d_sort[1]); hipFree(c->d_sort_hist); hipFree(c->d_csr_part[0]); hipFree(c->d_csr_part[1]); hipFree(c->d_splitk);
     if (c->h_plan) hipHostFree(c->h_plan);
     if (c->plan_ev) hipEventDestroy(c->plan_ev);
@@ -620,7 +621,7 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
     plan->item_stride = item_stride; plan->tree_off[0] = 0; plan->tree_off[1] = (int)cap1; plan->tree_off[2] = (int)(cap1 + cap2);
 
     chunk = used_chunk;
-    plan->nw = nw; plan->chunk = chunk; plan->list_stride = list_stride; plan->Bp = Bp;
+    plan->nw = nw; plan->chunk = chunk; plan->list_stride = list_stride; plan->Bp = Bp; plan->cap = chunk_cap;
     plan->min_late = -1;
     return ORX_OK;
 }
@@ -640,6 +641,10 @@ static void plan_dedup_args(orx_ctx* c, orx_table* U, orx_table* V, const int32_
     d.nbu = orx_dedup_buckets(U->rows); d.nbi = orx_dedup_buckets(V->rows);
     d.min_late = plan.min_late;
     d.alloc = c->d_alloc ? c->d_alloc + 8 * i0 : nullptr;
+    if (plan.pair_tpw > 1) {        // pairing (kernels_plan.hip): per-step claims, pairing words, accepted pairs
+        d.pair_tpw = plan.pair_tpw; d.pair_stride = B; d.swap_stride = B / 2 + 1;
+        d.claim = c->d_claim + (size_t)i0 * B; d.pinfo = c->d_pinfo + (size_t)i0 * B; d.swaps = c->d_swaps + (size_t)i0 * d.swap_stride;
+    }
     if (staging) {
         d.refinfo = c->d_refinfo + (size_t)i0 * 3 * plan.Bp; d.tricnt = c->d_tricnt + (size_t)i0 * B; d.segstart = c->d_segstart + (size_t)i0 * B;
         d.dseg = c->d_dseg + (size_t)i0 * plan.list_stride; d.dcnt = c->d_dcnt + (size_t)i0 * plan.list_stride; d.items = c->d_chunks + (size_t)i0 * plan.item_stride;
@@ -688,6 +693,13 @@ int orx_exact_plan_issue(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
     CHECK(orx_launch_plan(c, d, kc, inline_apply, i0));
     ORX_HIP(hipMemcpyAsync(c->h_plan + 8 * i0, c->d_alloc + 8 * i0, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // ([5] = duplicated rows)
     ORX_HIP(hipEventRecord(counters, c->stream));
+    if (d.pair_tpw > 1) {
+        // pairing: the accepted pairs are moved together once every flag sits on the rewritten ids (urgent marks included)
+        if (inline_apply) CHECK(orx_launch_plan_urgent(c, d, kc, i0));
+        CHECK(orx_launch_plan_swap(c, d, kc));
+        if (after_readback && *after_readback) CHECK((*after_readback)());
+        return ORX_OK;
+    }
     // step 0 of a chunk carries no apply blocks and needs no urgent marks: it may go out before them
     if (after_readback && *after_readback) CHECK((*after_readback)());
     if (inline_apply) CHECK(orx_launch_plan_urgent(c, d, kc, i0));
@@ -702,6 +714,9 @@ int orx_exact_plan_finish(orx_ctx* c, int64_t kc, int64_t B, bool inline_apply, 
     const int* hp = c->h_plan + 8 * i0;
     for (int64_t i = 0; i < kc; ++i) { dcv[i] = hp[8 * i + 5]; big = std::max(big, hp[8 * i + 6]); }
     c->plan_big = big > 16384;          // ([6] = the step's largest bucket, if above 8 k references)
+    if (getenv("ORX_PLAN_DEBUG") != nullptr && kc > 0)
+        fprintf(stderr, "[orx plan] steps %lld..%lld: step %lld has %d duplicated rows left for the apply, %d accepted pairs, %d staged references\n",
+                (long long)i0, (long long)(i0 + kc - 1), (long long)i0, hp[5], hp[7], hp[1]);
     plan_decide(kc, B, inline_apply, staging, dcv.data(), hp, out);
     return ORX_OK;
 }
@@ -761,6 +776,20 @@ void orx_exact_step_views(orx_ctx* c, const PairPlan& plan, int64_t i, int64_t B
     } else {
         a->stage = nullptr; a->stageb = nullptr; a->dcnt = nullptr; a->dseg = nullptr; a->prev_dcnt = nullptr; a->prev_dseg = nullptr;
     }
+}
+
+// pairing (kernels_plan.hip): SGD / Adagrad on the float4 dims with >= 2 triplets per wavefront, bucketed plan
+// (ORX_FORCE_FALLBACK bit 4 / ORX_NO_PAIR=1: off)
+static bool pairing_wanted(int mode, bool role_bits, int optkind, int dim, int64_t B, int fb) {
+    return mode == MODE_EXACT && orx_plan_v2(role_bits) && optkind != ORX_ADAM && orx_fused_tpw(dim) > 1 && B >= 2 && !(fb & 16) &&
+           getenv("ORX_NO_PAIR") == nullptr;
+}
+static int pairing_buffers(orx_ctx* c, int64_t B, int dim, PairPlan* plan) {
+    ENSURE(c->d_pinfo, c->d_pinfo_cap, (size_t)plan->cap * B * sizeof(uint32_t));
+    ENSURE(c->d_claim, c->d_claim_cap, (size_t)plan->cap * B * sizeof(int));
+    ENSURE(c->d_swaps, c->d_swaps_cap, (size_t)plan->cap * (B / 2 + 1) * sizeof(int4));
+    plan->pair_tpw = orx_fused_tpw(dim);
+    return ORX_OK;
 }
 
 // TF-2.0 Adam applied lazily (see orx_pairwise_step): float4 dims, role bits available, not hogwild
@@ -833,6 +862,9 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     // Adam's normalised update amplifies summation-order noise where an element's summed gradient nearly cancels: its
     // rows referenced >= 3 times always take staging slots (fixed summation order), never fp32 atomics
     if (opt->kind == ORX_ADAM) plan.min_late = 1;
+    // pairing (kernels_plan.hip): the two triplets of a row referenced exactly twice share a wavefront and exchange gradients there
+    // (SGD / Adagrad on the float4 dims with >= 2 triplets per wavefront; fb bit 4 / ORX_NO_PAIR=1: off)
+    if (pairing_wanted(mode, role_bits, opt->kind, U->dim, B, fb)) CHECK(pairing_buffers(c, B, U->dim, &plan));
 
     PairArgs a;
     memset(&a, 0, sizeof(a));
@@ -880,6 +912,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
                 a.uid = du + s * ds; a.pid = dp + s * ds; a.nid = dn + s * ds;
             }
             orx_exact_step_views(c, plan, i, B, U->dim, stage_views, &a);
+            a.pinfo = plan.pair_tpw > 1 ? c->d_pinfo + (size_t)i * B : nullptr;
             a.partial = c->d_partial + (size_t)i * nw * 2;
             a.epoch = ++c->epoch;           // one epoch per step: ready flags and censor side marks are tagged with it
             if (lazy_adam) { opt->t += 1; a.step_t = (int)opt->t; }
@@ -1025,6 +1058,7 @@ extern "C" int orx_pairwise_reserve(orx_ctx* c, orx_opt* opt, orx_table* U, orx_
     CHECK(orx_opt_slots(opt, U, &s)); CHECK(orx_opt_slots(opt, V, &s)); CHECK(orx_opt_slots(opt, b, &s));
     PairPlan plan;
     CHECK(orx_exact_buffers(c, U, V, K, B, mode, role_bits, inline_apply, staging, nb_total, orx_fused_nwaves(U->dim, B), &plan));
+    if (pairing_wanted(mode, role_bits, opt->kind, U->dim, B, 0)) CHECK(pairing_buffers(c, B, U->dim, &plan));
     ORX_HIP(hipStreamSynchronize(c->stream));
     return ORX_OK;
 }

@@ -465,6 +465,10 @@ template <int LPR, int MODEL, int OPT, int MODE, bool CENSOR = false, bool STAGE
 __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
+    __shared__ f4 pair_xg[(MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) ? 256 : 1];            // pairing: gradient exchange, one slot per lane
+    __shared__ float pair_xb[(MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) ? 256 / LPR : 1];   // ... and per lane group (item bias)
+    __shared__ f4 pair_xw[(MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) ? 256 : 1];            // the writer's copy of the shared row as read
+    __shared__ float pair_xwb[(MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) ? 256 / LPR : 1];
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
@@ -478,25 +482,34 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     float loss_acc = 0.0f, sq_acc = 0.0f;
 
     for (int64_t t = wave_global * TPW + grp; t < a.B; t += stride) {
-        int u = a.uid[t], p = a.pid[t], n = a.nid[t];
-        int du = 0, dp = 0, dn = 0;
-        int ku = 2, kp = 2, kn = 2;     // duplicate role: 0 / 1 = plain store into scratch row 1 / 2, 2 = atomics
-        int urgent = 0;
-        if (MODE == MODE_EXACT) {       // ids rewritten by dedup_kernel: bit 31 = "row is referenced more than once"
-            du = (uint32_t)u >> 31; dp = (uint32_t)p >> 31; dn = (uint32_t)n >> 31;
-            if (a.role_bits) {          // bits 30:29 = role among the row's references, bit 28 = urgent
-                ku = ((uint32_t)u >> 29) & 3; kp = ((uint32_t)p >> 29) & 3; kn = ((uint32_t)n >> 29) & 3;
-                urgent = (((uint32_t)u >> 28) & 1) | (((uint32_t)p >> 27) & 2) | (((uint32_t)n >> 26) & 4);
-                u &= 0x0fffffff; p &= 0x0fffffff; n &= 0x0fffffff;
-            } else {
-                u &= 0x7fffffff; p &= 0x7fffffff; n &= 0x7fffffff;
-            }
-        }
-        if (MODE == MODE_ACCUM) { du = dp = dn = 1; }
+        // ids as rewritten by the plan: bit 31 = "row is referenced more than once", bits 30:29 = role of this reference among the row's
+        // references (0 / 1 = plain store into scratch row 1 / 2, 2 = atomics or staging slot, 3 = no store: pairing), bit 28 = urgent.
+        // The flags stay IN the id words and are tested where they are needed (six flag registers fewer per lane).
+        uint32_t uw = (uint32_t)a.uid[t], pw = (uint32_t)a.pid[t], nw = (uint32_t)a.nid[t];
+        // pairing word (kernels_plan.hip, "pairing"): this triplet shares a row with another lane group of this wavefront
+        uint32_t pi = 0u;
+        if (MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) { if (a.pinfo != nullptr) pi = a.pinfo[t]; }
+        const uint32_t idmask = MODE == MODE_EXACT ? (a.role_bits ? 0x0fffffffu : 0x7fffffffu) : 0xffffffffu;
+        const int u = (int)(uw & idmask), p = (int)(pw & idmask), n = (int)(nw & idmask);
+#define du FLAG_DUP(uw)
+#define dp FLAG_DUP(pw)
+#define dn FLAG_DUP(nw)
+#define ku FLAG_ROLE(uw)
+#define kp FLAG_ROLE(pw)
+#define kn FLAG_ROLE(nw)
+#define FLAG_DUP(w) (MODE == MODE_ACCUM ? 1 : (MODE == MODE_EXACT ? (int)((w) >> 31) : 0))
+#define FLAG_ROLE(w) ((MODE == MODE_EXACT && a.role_bits) ? (int)(((w) >> 29) & 3u) : 2)
         // bitwise &: all three id loads are issued together (a short-circuit && lets the compiler
         // sink the loads behind each other: three dependent round trips)
         if (!(id_ok(u, a.NU) & id_ok(p, a.NI) & id_ok(n, a.NI))) {
             if (sub == 0) *a.err = 1;       // the reference's CPU gather raises; the triplet is skipped
+            if (MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) {
+                if (pi & ORX_PAIR_VALID) {  // (its partner must not add what an earlier iteration left in LDS)
+                    f4 z; z.x = z.y = z.z = z.w = 0.0f;
+                    pair_xg[threadIdx.x] = z;
+                    if (sub == 0) pair_xb[threadIdx.x / LPR] = 0.0f;
+                }
+            }
             continue;
         }
         // staged references (role 2 with a staging plan): slot = segment start of the row + rank of the
@@ -507,12 +520,12 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             const int2 ri = a.refinfo[ref];
             return ri.x < 0 ? -1 : a.segstart[ri.x] + ri.y;      // (-1, 0): the row's range made no plan -> atomics
         };
-        if (MODE == MODE_EXACT && urgent && nab) {      // (the marks are made before the host knows whether the launch applies)
+        if (MODE == MODE_EXACT && nab && a.role_bits && (((uw | pw | nw) >> 28) & 1u)) {      // (the marks are made before the host knows whether the launch applies)
             // a row of this triplet is being updated by an apply block of this launch
             if (sub == 0) {
-                if (urgent & 1) wait_ready(a.readyU + u, a.epoch);
-                if (urgent & 2) wait_ready(a.readyV + p, a.epoch);
-                if (urgent & 4) wait_ready(a.readyV + n, a.epoch);
+                if ((uw >> 28) & 1u) wait_ready(a.readyU + u, a.epoch);
+                if ((pw >> 28) & 1u) wait_ready(a.readyV + p, a.epoch);
+                if ((nw >> 28) & 1u) wait_ready(a.readyV + n, a.epoch);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
@@ -557,6 +570,47 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
 
         f4 gu, gp, gn; float gbp, gbn;
         row_grads<MODEL>(ru, rp, rn, g, a.l2w, gu, gp, gn, gbp, gbn);
+
+        // pairing: the two lane groups that share a row leave their gradient of it in LDS (one slot per lane; a wavefront's LDS
+        // operations execute in order, so no barrier), the WRITER also the row and bias it read; for both the slot is then settled
+        // (role 3: no store below).  After the other stores (pair_tail) the writer sums the two gradients -- TF sums the gradients
+        // of duplicate indices before the sparse apply -- and updates the row as the unique row it has become.
+        if (MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) {
+            if (pi & ORX_PAIR_VALID) {
+                const int myslot = (pi >> 4) & 3;
+                pair_xg[threadIdx.x] = myslot == 0 ? gu : (myslot == 1 ? gp : gn);
+                if (pi & ORX_PAIR_WRITER) pair_xw[threadIdx.x] = myslot == 0 ? ru : (myslot == 1 ? rp : rn);
+                if (sub == 0) {
+                    pair_xb[threadIdx.x / LPR] = myslot == 1 ? gbp : gbn;
+                    if (pi & ORX_PAIR_WRITER) pair_xwb[threadIdx.x / LPR] = myslot == 1 ? bp : bn;
+                }
+                if (myslot == 0) uw |= 0xe0000000u;         // duplicate flag + role 3
+                else if (myslot == 1) pw |= 0xe0000000u;
+                else nw |= 0xe0000000u;
+            }
+        }
+        auto pair_tail = [&]() {
+            if (!(MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1)) return;
+            if (!(pi & ORX_PAIR_WRITER)) return;
+            const int myslot = (pi >> 4) & 3, oslot = (pi >> 6) & 3;
+            const int xsrc = (int)(threadIdx.x & ~63u) + (int)(pi & 15u) * LPR + sub;
+            const int id = (myslot == 0 ? a.uid[t] : (myslot == 1 ? a.pid[t] : a.nid[t])) & 0x0fffffff;
+            const size_t off = (size_t)id * D + 4 * sub;
+            float* W = myslot == 0 ? a.U : a.V;
+            float* A = myslot == 0 ? a.aU : a.aV;
+            const f4 gs = pair_xg[threadIdx.x] + pair_xg[xsrc];
+            const f4 w = pair_xw[threadIdx.x];
+            if (CENSOR) {
+                f4 wn = censor4<LPR>(opt_new4<OPT>(A + off, w, gs, a.lr, a.eps), a.min_norm);
+                // a positive of one triplet and a negative of the other: censored once per id list (ucml.py:46-48)
+                if (myslot != oslot) wn = censor4<LPR>(wn, a.min_norm);
+                *reinterpret_cast<f4*>(W + off) = wn;
+            } else {
+                opt_apply4<OPT>(W + off, A + off, w, gs, a.lr, a.eps);
+            }
+            if (myslot != 0 && sub == 0)
+                opt_apply1<OPT>(a.b + id, a.ab + id, pair_xwb[threadIdx.x / LPR], pair_xb[threadIdx.x / LPR] + pair_xb[xsrc / LPR], a.lr, a.eps);
+        };
 
         if (OPT == ORX_ADAM) {
             // a row referenced once takes its step here (replayed state + gradient), a duplicated one deposits the gradient
@@ -611,7 +665,7 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             } else {
                 const int sp = kp == 2 ? slot_of(Bp + t) : -1;
                 dup_store4s(a.gV, a.gV2, (size_t)p * D + 4 * sub, gp, kp, a.stage, sp, D, sub);
-                if (sub == 0) { dup_store1s(a.gb, a.gb2, p, gbp, kp, a.stageb, sp); a.sideV[2 * (size_t)p] = a.epoch; }
+                if (sub == 0) { dup_store1s(a.gb, a.gb2, p, gbp, kp, a.stageb, sp); if (kp != 3) a.sideV[2 * (size_t)p] = a.epoch; }
             }
             if (dn == 0) {
                 wn = opt_new4<OPT>(a.aV + (size_t)n * D + 4 * sub, rn, gn, a.lr, a.eps);
@@ -619,12 +673,13 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             } else {
                 const int sn = kn == 2 ? slot_of(2 * Bp + t) : -1;
                 dup_store4s(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn, a.stage, sn, D, sub);
-                if (sub == 0) { dup_store1s(a.gb, a.gb2, n, gbn, kn, a.stageb, sn); a.sideV[2 * (size_t)n + 1] = a.epoch; }
+                if (sub == 0) { dup_store1s(a.gb, a.gb2, n, gbn, kn, a.stageb, sn); if (kn != 3) a.sideV[2 * (size_t)n + 1] = a.epoch; }
             }
             wu = censor4<LPR>(wu, a.min_norm); wp = censor4<LPR>(wp, a.min_norm); wn = censor4<LPR>(wn, a.min_norm);
             if (du == 0) *reinterpret_cast<f4*>(Up) = wu;
             if (dp == 0) *reinterpret_cast<f4*>(Pp) = wp;
             if (dn == 0) *reinterpret_cast<f4*>(Np) = wn;
+            pair_tail();
             continue;
         }
         if (du == 0) opt_apply4<OPT>(Up, a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
@@ -645,7 +700,16 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             dup_store4s(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn, a.stage, sn, D, sub);
             if (sub == 0) dup_store1s(a.gb, a.gb2, n, gbn, kn, a.stageb, sn);
         }
+        pair_tail();
     }
+#undef du
+#undef dp
+#undef dn
+#undef ku
+#undef kp
+#undef kn
+#undef FLAG_DUP
+#undef FLAG_ROLE
     const float ls = wave_sum(loss_acc);
     const float sq = wave_sum(sq_acc);
     if (lane == 0) {
@@ -947,6 +1011,7 @@ static void launch_fused_lpr(int lpr, int mode, dim3 g, orx_ctx* s, const PairAr
 }
 
 int orx_fused_can_inline_apply(int D) { return lpr_for_dim(D) != 0; }
+int orx_fused_tpw(int D) { const int lpr = lpr_for_dim(D); return lpr ? 64 / lpr : 0; }
 
 // lazy Adam (exact mode, float4 dims): its own small set of instantiations
 template <int MODEL>

@@ -18,6 +18,17 @@
 //                        numbering of the rows with >= 3 references, their ranks and staging segments (per-row
 //                        counters in LDS), duplicate list with (segment, count), reduction-tree work items
 //   plan_urgent_kernel   bit 28 on the references of step s whose row was duplicated in step s-1 (in-launch apply)
+//   plan_swap_kernel     pairing (below): moves the two triplets of an accepted pair into one wavefront, writes their pairing words
+//
+// PAIRING (round 4).  A row referenced exactly twice in a step costs the exact step ten row moves (two reads, two gradient
+// deposits, and the apply's three reads + three writes) where a racy kernel pays four.  The order of the triplets inside a
+// batch is free (the loss is a sum over the batch), so plan_range_kernel proposes, for every such row, to bring its two
+// triplets into the SAME WAVEFRONT of the fused kernel: there the two lane groups exchange their gradients of the shared row by
+// a cross-lane permute, one of them adds both and updates the row in place, the other does not write it -- two row moves, no
+// deposit, no apply, no ready flag.  A proposal claims the two triplets and, when they do not already share a wavefront, one
+// more position next to one of them (atomic exchange on a per-step claim array); a triplet takes part in at most one pair and
+// a displaced neighbour in none.  Proposals that lose a claim, rows with three or more references and rows whose two references
+// sit in one triplet keep the deposit / apply path.  The fused kernel sees a paired reference as a reference to a unique row.
 // The reference's semantics being restated are TF's: every gradient of a step is taken on the pre-step tables and
 // duplicate indices are summed before the sparse apply (tf2_examples/bpr_citeulike.py:35-38).
 #include "orx_internal.h"
@@ -96,7 +107,13 @@ __global__ __launch_bounds__(PL_THREADS) void plan_part_kernel(PlanArgs a) {
             }
             // the rewritten ids start as a (coalesced) copy; plan_range_kernel then touches only the duplicated references --
             // a scattered 4-byte store costs a memory transaction of its own.  0x7fffffff: out-of-range id, never a valid row
-            if (SCATTER) a.d.ids_out[s * a.d.flag_stride + pos] = ok ? id : 0x7fffffff;
+            if (SCATTER) {
+                a.d.ids_out[s * a.d.flag_stride + pos] = ok ? id : 0x7fffffff;
+                if (a.d.pair_tpw > 1 && j < a.d.pair_stride) {          // pairing: the step's claims and pairing words start at zero
+                    a.d.claim[s * a.d.pair_stride + j] = 0;
+                    a.d.pinfo[s * a.d.pair_stride + j] = 0u;
+                }
+            }
         }
     }
 #pragma unroll
@@ -180,6 +197,46 @@ __device__ __forceinline__ int pl_rank(int* cnt, int dn) {
     return rank;
 }
 
+// pairing: claim the triplets ta and tb (positions of the step's batch) and, unless they already sit in one wavefront of
+// `tpw` triplets, a free position next to one of them.  On success: `mover` goes to position `q` (q == mover: nothing moves),
+// `stay` stays.  Claims are exclusive (atomic exchange on the step's claim array, zero = free); a loser releases what it took.
+constexpr int PL_PAIR_CAP = 1024;                 // rows referenced exactly twice that a range can pair (their positions live in LDS)
+// (every atomic below is issued before any of its results is looked at: the chain is two or three memory round trips, not six)
+__device__ __forceinline__ bool pair_claim(int* claim, int B, int tpw, int ta, int tb, int& stay, int& mover, int& q) {
+    if (ta == tb) return false;                       // both references in ONE triplet (p == n, ...): nothing to exchange across lane groups
+    const int ca = atomicExch(claim + ta, 1), cb = atomicExch(claim + tb, 1);
+    if (ca != 0 || cb != 0) {
+        if (ca == 0) atomicExch(claim + ta, 0);
+        if (cb == 0) atomicExch(claim + tb, 0);
+        return false;
+    }
+    const int qa = ta & ~(tpw - 1), qb = tb & ~(tpw - 1);
+    if (qa == qb) { stay = ta; mover = tb; q = tb; return true; }
+    // a free position beside ta, else beside tb: the (up to) three other positions of its aligned group of four at once -- inside
+    // the wavefront for every tpw -- and the first free one is kept
+    const int g = tpw < 4 ? tpw : 4;
+    for (int side = 0; side < 2; ++side) {
+        const int self = side ? tb : ta, q0 = self & ~(g - 1);
+        int r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = q0 + k;
+            r[k] = (k < g && c != self && c < B) ? atomicExch(claim + c, 1) : 1;
+        }
+        int keep = -1;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) if (r[k] == 0) keep = k;
+        if (keep >= 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (r[k] == 0 && k != keep) atomicExch(claim + q0 + k, 0);
+            stay = self; mover = side ? ta : tb; q = q0 + keep;
+            return true;
+        }
+    }
+    atomicExch(claim + ta, 0); atomicExch(claim + tb, 0);
+    return false;
+}
+
 // One workgroup per (range, step): the same plan dedup_kernel makes for its range, on the range's own references.
 template <int T>
 __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
@@ -191,6 +248,10 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
     unsigned int* tri = pl_lds + 2 * W;
     unsigned short* prefix16 = reinterpret_cast<unsigned short*>(pl_lds + 3 * W);     // dense number of a word's first tri row
     int* lcnt = reinterpret_cast<int*>(pl_lds + 3 * W + (W + 1) / 2);                  // references per dense tri row (LDS or global)
+    // pairing: dense number of a word's first twice-referenced row, then per such row (local row, position of reference 0, of reference 1)
+    unsigned short* dprefix16 = reinterpret_cast<unsigned short*>(lcnt + PL_LCNT);
+    int* pairrow = reinterpret_cast<int*>(lcnt + PL_LCNT + (W + 1) / 2);
+    int* pairpos = pairrow + PL_PAIR_CAP;
     __shared__ int wave_tot[T / 64];
     __shared__ int sh_late, sh_dense, sh_seg, list_cnt, list_base;
     const int nb = a.nru + a.nri;
@@ -260,15 +321,42 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
             __syncthreads();
         }
     }
+    // pairing: dense numbers of the rows referenced exactly twice (dup and not tri), in row order
+    int ndup2 = 0;
+    const bool pairing = d.pair_tpw > 1 && W <= 4096;      // (larger bitmaps leave no LDS for the pairing tables)
+    if (pairing) {
+        const int per = (W + T - 1) / T;
+        const int w0 = threadIdx.x * per;
+        int mine2 = 0;
+        for (int w = w0; w < w0 + per && w < W; ++w) mine2 += __popc(dup[w] & ~tri[w]);
+        int pre = plan_scan_excl<T>(mine2, wave_tot, ndup2);
+        if (ndup2 > 65535) ndup2 = 0;                   // (16-bit prefixes; such a range keeps the deposit path)
+        if (ndup2) {
+            for (int w = w0; w < w0 + per && w < W; ++w) { dprefix16[w] = (unsigned short)pre; pre += __popc(dup[w] & ~tri[w]); }
+            const int np = ndup2 < PL_PAIR_CAP ? ndup2 : PL_PAIR_CAP;
+            for (int i = threadIdx.x; i < 2 * np; i += T) pairpos[i] = -1;
+            __syncthreads();
+        }
+    }
     // pass 2: rewritten ids, (dense row, rank) of the references that stage
     pl_for_each<T>(ent, n, [&](int, int2 e) {
         const int l = e.x >> lg;
         const int pos = e.y & 0x3fffffff;
-        const unsigned int dd = (dup[l >> 5] >> (l & 31)) & 1u;
+        const unsigned int dw = dup[l >> 5];
+        const unsigned int dd = (dw >> (l & 31)) & 1u;
         if (dd) {                                       // (references of unique rows keep the plain id plan_part_kernel wrote)
             uint32_t v = (uint32_t)e.x | (1u << 31);
             const unsigned int tw = tri[l >> 5];
             const unsigned int t3 = (tw >> (l & 31)) & 1u;
+            if (ndup2 && !t3) {
+                // a row referenced exactly twice: the pairing phase below decides (and writes both rewritten ids)
+                const int dn2 = (int)dprefix16[l >> 5] + __popc(dw & ~tw & ((1u << (l & 31)) - 1u));
+                if (dn2 < PL_PAIR_CAP) {
+                    pairpos[2 * dn2 + (int)(((uint32_t)e.y >> 30) & 1u)] = pos;
+                    pairrow[dn2] = l;
+                    return;
+                }
+            }
             v |= (t3 ? 2u : ((uint32_t)e.y >> 30)) << 29;
             if (t3 && ntri) {
                 const int dn = (int)prefix16[l >> 5] + __popc(tw & ((1u << (l & 31)) - 1u));
@@ -279,6 +367,50 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
             ids_out[pos] = (int32_t)v;
         }
     });
+    if (ndup2) {
+        // pairing phase: one thread per row referenced exactly twice.  Accepted: both references become references to a
+        // unique row (plain id), the row leaves the duplicate bitmap (no list entry, no urgent marks in the next step) and
+        // the pair is recorded for plan_swap_kernel.  Refused: the roles the deposit path needs.
+        __syncthreads();
+        const int np = ndup2 < PL_PAIR_CAP ? ndup2 : PL_PAIR_CAP;
+        const int Bp = (int)d.role_stride;
+        int* claim = d.claim + s * d.pair_stride;
+        for (int k0 = 0; k0 < np; k0 += T) {               // (wave-uniform trip count: the ballot below)
+            const int k = k0 + threadIdx.x;
+            bool ok = false;
+            int posA = 0, posB = 0, l = 0, stay = 0, mover = 0, q = 0, sa = 0, sb = 0, ta = 0;
+            if (k < np) {
+                posA = pairpos[2 * k]; posB = pairpos[2 * k + 1];
+                l = pairrow[k];
+                if (posA >= 0 && posB >= 0) {               // (always: a row of this class has exactly one reference of each role)
+                    sa = posA / Bp; sb = posB / Bp;
+                    ta = posA - sa * Bp;
+                    ok = pair_claim(claim, (int)d.pair_stride, d.pair_tpw, ta, posB - sb * Bp, stay, mover, q);
+                    const uint32_t id = (uint32_t)((l << lg) | bl);
+                    if (ok) {
+                        ids_out[posA] = (int32_t)id; ids_out[posB] = (int32_t)id;
+                        atomicAnd(&dup[l >> 5], ~(1u << (l & 31)));
+                    } else {
+                        ids_out[posA] = (int32_t)(id | (1u << 31));                   // role 0
+                        ids_out[posB] = (int32_t)(id | (1u << 31) | (1u << 29));      // role 1
+                    }
+                }
+            }
+            // one allocation per wavefront for its accepted pairs (thousands of atomics on ONE counter serialize)
+            const unsigned long long okm = __ballot(ok);
+            if (okm) {
+                const int lane = threadIdx.x & 63, first = __ffsll((long long)okm) - 1;
+                int base = 0;
+                if (lane == first) base = atomicAdd(d.alloc + 8 * s + 7, __popcll(okm));
+                base = __shfl(base, first);
+                if (ok) {
+                    const int s_stay = stay == ta ? sa : sb, s_mov = stay == ta ? sb : sa;
+                    d.swaps[s * d.swap_stride + base + __popcll(okm & ((1ull << lane) - 1ull))] = make_int4(stay, mover, q, s_stay | (s_mov << 2));
+                }
+            }
+        }
+        __syncthreads();
+    }
     if (dupout) for (int w = threadIdx.x; w < W; w += T) dupout[w] = dup[w];
     // segment start of every tri row (its references' slots are contiguous: segstart + rank)
     if (ntri) {
@@ -370,6 +502,39 @@ __global__ __launch_bounds__(T) void plan_urgent_kernel(PlanArgs a) {
     });
 }
 
+// pairing: one thread per accepted pair of a step -- the triplet `mover` changes places with the one at `q` (three rewritten ids
+// each, and their staging records), then both partners get their pairing word.  Runs after plan_urgent_kernel: flags travel with the ids.
+__global__ __launch_bounds__(256) void plan_swap_kernel(DedupArgs d) {
+    const int64_t s = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= d.alloc[8 * s + 7]) return;
+    const int4 r = d.swaps[s * d.swap_stride + k];
+    const int stay = r.x, mover = r.y, q = r.z;
+    int32_t* ids = d.ids_out + s * d.flag_stride;
+    int2* refinfo = d.refinfo ? d.refinfo + s * d.flag_stride : nullptr;
+    const int64_t Bp = d.role_stride;
+    if (q != mover) {
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            const int32_t x = ids[sl * Bp + q], y = ids[sl * Bp + mover];
+            ids[sl * Bp + q] = y; ids[sl * Bp + mover] = x;
+            if (refinfo) { const int2 u = refinfo[sl * Bp + q], v = refinfo[sl * Bp + mover]; refinfo[sl * Bp + q] = v; refinfo[sl * Bp + mover] = u; }
+        }
+    }
+    const uint32_t s_stay = (uint32_t)r.w & 3u, s_mov = ((uint32_t)r.w >> 2) & 3u, m = (uint32_t)d.pair_tpw - 1u;
+    uint32_t* pinfo = d.pinfo + s * d.pair_stride;
+    pinfo[stay] = ORX_PAIR_VALID | ORX_PAIR_WRITER | ((uint32_t)q & m) | (s_stay << 4) | (s_mov << 6);
+    pinfo[q] = ORX_PAIR_VALID | ((uint32_t)stay & m) | (s_mov << 4) | (s_stay << 6);
+}
+
+int orx_launch_plan_swap(orx_ctx* ctx, const DedupArgs& d, int64_t kc) {
+    if (d.pair_tpw < 2 || kc <= 0) return ORX_OK;
+    ProfScope ps(ctx, ORX_K_DEDUP);
+    ORX_LAUNCH(ctx, plan_swap_kernel, dim3((unsigned)((d.swap_stride + 255) / 256), (unsigned)kc), dim3(256), 0, d);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
 // ------------------------------------------------------------------------------------------ host side ---
 // Geometry of the plan: buckets per table (a power of two; row r -> bucket r & (n - 1)) such that a workgroup gets ~2-4 k
 // references -- few references per bucket cost a workgroup's fixed work (10 M x 50 M tables in 16 384-row buckets were 3663
@@ -449,7 +614,8 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
     ORX_LAUNCH(ctx, (plan_part_kernel<false>), gp, dim3(PL_THREADS), hist_bytes, a);
     ORX_LAUNCH(ctx, (plan_part_kernel<true>), gp, dim3(PL_THREADS), hist_bytes, a);
     const int W = (1 << a.shift) >> 5;
-    const size_t lds = (size_t)(3 * W + (W + 1) / 2) * 4 + (size_t)PL_LCNT * 4;
+    const size_t lds = (size_t)(3 * W + (W + 1) / 2) * 4 + (size_t)PL_LCNT * 4 +
+                       (d.pair_tpw > 1 && W <= 4096 ? (size_t)((W + 1) / 2) * 4 + (size_t)3 * PL_PAIR_CAP * 4 : 0);      // (+ pairing: prefixes, rows, positions)
     // workgroups of 1024 threads where the previous plan met a bucket with more than 16 k references (skewed ids: the head of
     // a Zipf distribution puts 100 k of a step's 131 k item references into one range, 0.7 ms for 256 threads)
     if (ctx->plan_big) ORX_LAUNCH(ctx, plan_range_kernel<1024>, dim3((unsigned)nb, (unsigned)kc), dim3(1024), lds, a);

@@ -60,6 +60,10 @@ struct orx_ctx {
     int* d_pl_cnt = nullptr;   size_t d_pl_cnt_cap = 0;          // [K][3 ranges + 1]: counts, cursors, offsets
     int2* d_pl_list = nullptr; size_t d_pl_list_cap = 0;         // [K][references per step] (id, output position | role << 30)
     bool plan_big = false;                                       // the last plan met a bucket of > 16 k references: 1024-thread workgroups
+    // pairing (kernels_plan.hip, "pairing"): the two references of a row referenced exactly twice are brought into one wavefront
+    uint32_t* d_pinfo = nullptr; size_t d_pinfo_cap = 0;         // [K][B] per-triplet pairing word read by the fused kernel (0: not paired)
+    int* d_claim = nullptr;    size_t d_claim_cap = 0;           // [K][B] position claims of the pairing (zero = free)
+    int4* d_swaps = nullptr;   size_t d_swaps_cap = 0;           // [K][B/2] accepted pairs (stay, mover, destination, slots)
     int* h_plan = nullptr;                                       // pinned host mirror of the per-step plan counters
     size_t h_plan_cap = 0;
     hipEvent_t plan_ev = nullptr;                                // "plan counters have arrived on the host"
@@ -192,6 +196,7 @@ struct PairArgs {
     int newton;                 // lazy Adam: carry 1/(sqrt(v)+eps) by Newton steps (1 - sqrt(beta_2) <= 1e-3)
     int long_gap;               // lazy Adam: tables large relative to the batch (rows wait hundreds of steps): LONGGAP kernel
     const int32_t* uid; const int32_t* pid; const int32_t* nid;
+    const uint32_t* pinfo;                    // [B] pairing word per triplet (see ORX_PAIR_*), or NULL: no pairing in this launch
     int role_bits;                            // ids carry role (bits 30:29) and urgent (bit 28): tables < 2^28 rows
     // in-launch application of the PREVIOUS step's duplicated rows (n_apply_blocks == 0: off)
     int n_apply_blocks; int epoch;
@@ -244,7 +249,13 @@ struct DedupArgs {
     int64_t tri_stride; int64_t item_stride;
     int tree_off[3];
     int min_late;                             // bucketed plan: see PairPlan
+    // pairing (bucketed plan only; pair_tpw < 2: off): triplets per wavefront of the fused kernel that will run the steps,
+    // per-step arrays [K][pair_stride] claim / pinfo and [K][swap_stride] swaps; the number of accepted pairs of step s is alloc[8 s + 7]
+    int pair_tpw; int* claim; uint32_t* pinfo; int4* swaps; int64_t pair_stride; int64_t swap_stride;
 };
+// pairing word of a triplet (PairArgs::pinfo): the triplet shares one row with the triplet of lane group PARTNER of the same wavefront;
+// the WRITER adds the partner's gradient of that row to its own and updates the row in place, the other one does not write it
+constexpr uint32_t ORX_PAIR_VALID = 0x200u, ORX_PAIR_WRITER = 0x100u;      // bits 3:0 partner lane group, 5:4 my slot (0 user, 1 pos, 2 neg), 7:6 partner's slot
 constexpr int ORX_SEG_DIRECT = 16;            // the apply sums up to this many staged gradients / partial sums of a row itself
 constexpr int ORX_PIECE = 64;                 // longer segments: a tree of 64-to-1 partial sums (hot_reduce_kernel, one wavefront per piece)
 
@@ -350,7 +361,9 @@ int orx_launch_hot_reduce(orx_ctx* ctx, const PairArgs& a, int level);
 
 // host-side plan of the exact steps (api.hip), shared by the pairwise and the pointwise step
 struct PairPlan { int nw; int64_t chunk; int64_t list_stride; int64_t Bp; int64_t item_stride; int tree_off[3];
-                  int min_late = -1; };   // staging plan from this many third-or-later references per range on (< 0: max(64, n / 512))
+                  int min_late = -1;      // staging plan from this many third-or-later references per range on (< 0: max(64, n / 512))
+                  int pair_tpw = 0;       // pairing: triplets per wavefront of the fused kernel (0: off)
+                  int64_t cap = 0; };     // steps the per-step scratch is sized for (>= chunk)
 struct ExactChunk { bool hot = false, use_stage = false, dense_dups = false; int tree_levels = 0; };
 int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t B, int mode, bool role_bits,
                       bool inline_apply, bool staging, int nb_total, int nw, PairPlan* plan);
@@ -378,6 +391,8 @@ bool orx_plan_v2(bool role_bits);
 int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t B, int64_t NU, int64_t NI, bool want_dupbits);
 int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupbits, int64_t step0 = 0);
 int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc, int64_t step0 = 0);
+int orx_launch_plan_swap(orx_ctx* ctx, const DedupArgs& d, int64_t kc);      // pairing: move the accepted pairs together, write pinfo
+int orx_fused_tpw(int D);                        // triplets per wavefront of the float4 fused kernel (0: generic dim)
 int orx_fused_can_inline_apply(int D);
 int orx_dedup_words(void);
 int orx_launch_loss_reduce(orx_ctx* ctx, const ReduceArgs& a, int64_t K);

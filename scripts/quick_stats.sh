@@ -8,7 +8,7 @@ cd $REPO
 python - <<PY
 import csv, glob
 f = glob.glob("gpurun_out/q_$TAG/**/*kernel_stats.csv", recursive=True)[0]
-for r in list(csv.reader(open(f)))[:9]:
+for r in list(csv.reader(open(f)))[:14]:
     print(r[0][:60], r[1:5])
 PY
 tail -1 $OUT/q_$TAG.log | cut -c1-400
