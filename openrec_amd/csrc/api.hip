@@ -104,7 +104,7 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_evalbits); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_cflag); hipFree(c->d_dupbits); hipFree(c->d_dlist);
     hipFree(c->d_dcount); hipFree(c->d_refinfo); hipFree(c->d_tricnt); hipFree(c->d_segstart); hipFree(c->d_alloc); hipFree(c->d_dseg); hipFree(c->d_dcnt); hipFree(c->d_chunks); hipFree(c->d_part); hipFree(c->d_partb); hipFree(c->d_stage); hipFree(c->d_stageb); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
     hipFree(c->d_wpart); hipFree(c->d_pl_cnt); hipFree(c->d_pl_list);
-    hipFree(c->d_pinfo); hipFree(c->d_claim); hipFree(c->d_swaps);
+    hipFree(c->d_pinfo); hipFree(c->d_partner); hipFree(c->d_pslot); hipFree(c->d_perm); hipFree(c->d_ids4);
     hipFree(c->d_sort[0]); hipFree(c->d_sort[1]); hipFree(c->d_sort_hist); hipFree(c->d_csr_part[0]); hipFree(c->d_csr_part[1]); hipFree(c->d_splitk);
     if (c->h_plan) hipHostFree(c->h_plan);
     if (c->plan_ev) hipEventDestroy(c->plan_ev);
@@ -642,8 +642,8 @@ static void plan_dedup_args(orx_ctx* c, orx_table* U, orx_table* V, const int32_
     d.min_late = plan.min_late;
     d.alloc = c->d_alloc ? c->d_alloc + 8 * i0 : nullptr;
     if (plan.pair_tpw > 1) {        // pairing (kernels_plan.hip): per-step claims, pairing words, accepted pairs
-        d.pair_tpw = plan.pair_tpw; d.pair_stride = B; d.swap_stride = B / 2 + 1;
-        d.claim = c->d_claim + (size_t)i0 * B; d.pinfo = c->d_pinfo + (size_t)i0 * B; d.swaps = c->d_swaps + (size_t)i0 * d.swap_stride;
+        d.pair_tpw = plan.pair_tpw; d.pair_stride = B;
+        d.partner = c->d_partner + (size_t)i0 * 3 * plan.Bp; d.pslot = c->d_pslot + (size_t)i0 * plan.list_stride; d.pinfo = c->d_pinfo + (size_t)i0 * B; d.perm = c->d_perm + (size_t)i0 * B; d.ids4 = c->d_ids4 + (size_t)i0 * B;
     }
     if (staging) {
         d.refinfo = c->d_refinfo + (size_t)i0 * 3 * plan.Bp; d.tricnt = c->d_tricnt + (size_t)i0 * B; d.segstart = c->d_segstart + (size_t)i0 * B;
@@ -694,9 +694,9 @@ int orx_exact_plan_issue(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
     ORX_HIP(hipMemcpyAsync(c->h_plan + 8 * i0, c->d_alloc + 8 * i0, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // ([5] = duplicated rows)
     ORX_HIP(hipEventRecord(counters, c->stream));
     if (d.pair_tpw > 1) {
-        // pairing: the accepted pairs are moved together once every flag sits on the rewritten ids (urgent marks included)
+        // pairing: the fused kernel's input is packed once every flag sits on the rewritten ids (urgent marks included)
         if (inline_apply) CHECK(orx_launch_plan_urgent(c, d, kc, i0));
-        CHECK(orx_launch_plan_swap(c, d, kc));
+        CHECK(orx_launch_plan_pack(c, d, kc));
         if (after_readback && *after_readback) CHECK((*after_readback)());
         return ORX_OK;
     }
@@ -712,11 +712,11 @@ int orx_exact_plan_finish(orx_ctx* c, int64_t kc, int64_t B, bool inline_apply, 
     std::vector<int> dcv((size_t)kc);
     int big = 0;
     const int* hp = c->h_plan + 8 * i0;
-    for (int64_t i = 0; i < kc; ++i) { dcv[i] = hp[8 * i + 5]; big = std::max(big, hp[8 * i + 6]); }
+    for (int64_t i = 0; i < kc; ++i) { dcv[i] = hp[8 * i + 5] - hp[8 * i + 7]; big = std::max(big, hp[8 * i + 6]); }      // ([5] list entries, [7] of them paired after all)
     c->plan_big = big > 16384;          // ([6] = the step's largest bucket, if above 8 k references)
     if (getenv("ORX_PLAN_DEBUG") != nullptr && kc > 0)
         fprintf(stderr, "[orx plan] steps %lld..%lld: step %lld has %d duplicated rows left for the apply, %d accepted pairs, %d staged references\n",
-                (long long)i0, (long long)(i0 + kc - 1), (long long)i0, hp[5], hp[7], hp[1]);
+                (long long)i0, (long long)(i0 + kc - 1), (long long)i0, hp[5] - hp[7], hp[7], hp[1]);
     plan_decide(kc, B, inline_apply, staging, dcv.data(), hp, out);
     return ORX_OK;
 }
@@ -781,13 +781,15 @@ void orx_exact_step_views(orx_ctx* c, const PairPlan& plan, int64_t i, int64_t B
 // pairing (kernels_plan.hip): SGD / Adagrad on the float4 dims with >= 2 triplets per wavefront, bucketed plan
 // (ORX_FORCE_FALLBACK bit 4 / ORX_NO_PAIR=1: off)
 static bool pairing_wanted(int mode, bool role_bits, int optkind, int dim, int64_t B, int fb) {
-    return mode == MODE_EXACT && orx_plan_v2(role_bits) && optkind != ORX_ADAM && orx_fused_tpw(dim) > 1 && B >= 2 && !(fb & 16) &&
+    return mode == MODE_EXACT && orx_plan_v2(role_bits) && optkind != ORX_ADAM && orx_fused_tpw(dim) > 1 && B >= 2 && B <= (1 << 22) && !(fb & 16) &&
            getenv("ORX_NO_PAIR") == nullptr;
 }
 static int pairing_buffers(orx_ctx* c, int64_t B, int dim, PairPlan* plan) {
     ENSURE(c->d_pinfo, c->d_pinfo_cap, (size_t)plan->cap * B * sizeof(uint32_t));
-    ENSURE(c->d_claim, c->d_claim_cap, (size_t)plan->cap * B * sizeof(int));
-    ENSURE(c->d_swaps, c->d_swaps_cap, (size_t)plan->cap * (B / 2 + 1) * sizeof(int4));
+    ENSURE(c->d_partner, c->d_partner_cap, (size_t)plan->cap * 3 * plan->Bp * sizeof(int));
+    ENSURE(c->d_pslot, c->d_pslot_cap, (size_t)plan->cap * plan->list_stride * sizeof(int));
+    ENSURE(c->d_perm, c->d_perm_cap, (size_t)plan->cap * B * sizeof(int));
+    ENSURE(c->d_ids4, c->d_ids4_cap, (size_t)plan->cap * B * sizeof(int4));
     plan->pair_tpw = orx_fused_tpw(dim);
     return ORX_OK;
 }
@@ -912,7 +914,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
                 a.uid = du + s * ds; a.pid = dp + s * ds; a.nid = dn + s * ds;
             }
             orx_exact_step_views(c, plan, i, B, U->dim, stage_views, &a);
-            a.pinfo = plan.pair_tpw > 1 ? c->d_pinfo + (size_t)i * B : nullptr;
+            a.ids4 = plan.pair_tpw > 1 ? c->d_ids4 + (size_t)i * B : nullptr;
             a.partial = c->d_partial + (size_t)i * nw * 2;
             a.epoch = ++c->epoch;           // one epoch per step: ready flags and censor side marks are tagged with it
             if (lazy_adam) { opt->t += 1; a.step_t = (int)opt->t; }

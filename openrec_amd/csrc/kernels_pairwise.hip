@@ -481,14 +481,26 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     const int64_t stride = (int64_t)(gridDim.x - nab) * 4 * TPW;
     float loss_acc = 0.0f, sq_acc = 0.0f;
 
+    constexpr bool PAIRS = MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1;
     for (int64_t t = wave_global * TPW + grp; t < a.B; t += stride) {
         // ids as rewritten by the plan: bit 31 = "row is referenced more than once", bits 30:29 = role of this reference among the row's
         // references (0 / 1 = plain store into scratch row 1 / 2, 2 = atomics or staging slot, 3 = no store: pairing), bit 28 = urgent.
         // The flags stay IN the id words and are tested where they are needed (six flag registers fewer per lane).
-        uint32_t uw = (uint32_t)a.uid[t], pw = (uint32_t)a.pid[t], nw = (uint32_t)a.nid[t];
-        // pairing word (kernels_plan.hip, "pairing"): this triplet shares a row with another lane group of this wavefront
+        uint32_t uw, pw, nw;
+        // pairing (kernels_plan.hip): position t processes the triplet the plan put there -- one 16-byte record: its three ids, the
+        // pairing word (this triplet shares a row with another lane group of this wavefront) and where the triplet stood (t0: its
+        // staging records are indexed by that)
         uint32_t pi = 0u;
-        if (MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) { if (a.pinfo != nullptr) pi = a.pinfo[t]; }
+        int64_t t0 = t;
+        bool packed = false;
+        if (PAIRS) { packed = a.ids4 != nullptr; }
+        if (packed) {
+            const int4 v = a.ids4[t];
+            uw = (uint32_t)v.x; pw = (uint32_t)v.y; nw = (uint32_t)v.z;
+            pi = (uint32_t)v.w & 0x3ffu; t0 = (int64_t)((uint32_t)v.w >> 10);
+        } else {
+            uw = (uint32_t)a.uid[t]; pw = (uint32_t)a.pid[t]; nw = (uint32_t)a.nid[t];
+        }
         const uint32_t idmask = MODE == MODE_EXACT ? (a.role_bits ? 0x0fffffffu : 0x7fffffffu) : 0xffffffffu;
         const int u = (int)(uw & idmask), p = (int)(pw & idmask), n = (int)(nw & idmask);
 #define du FLAG_DUP(uw)
@@ -503,7 +515,7 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
         // sink the loads behind each other: three dependent round trips)
         if (!(id_ok(u, a.NU) & id_ok(p, a.NI) & id_ok(n, a.NI))) {
             if (sub == 0) *a.err = 1;       // the reference's CPU gather raises; the triplet is skipped
-            if (MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) {
+            if (PAIRS) {
                 if (pi & ORX_PAIR_VALID) {  // (its partner must not add what an earlier iteration left in LDS)
                     f4 z; z.x = z.y = z.z = z.w = 0.0f;
                     pair_xg[threadIdx.x] = z;
@@ -575,7 +587,7 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
         // operations execute in order, so no barrier), the WRITER also the row and bias it read; for both the slot is then settled
         // (role 3: no store below).  After the other stores (pair_tail) the writer sums the two gradients -- TF sums the gradients
         // of duplicate indices before the sparse apply -- and updates the row as the unique row it has become.
-        if (MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) {
+        if (PAIRS) {
             if (pi & ORX_PAIR_VALID) {
                 const int myslot = (pi >> 4) & 3;
                 pair_xg[threadIdx.x] = myslot == 0 ? gu : (myslot == 1 ? gp : gn);
@@ -590,11 +602,11 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             }
         }
         auto pair_tail = [&]() {
-            if (!(MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1)) return;
+            if (!PAIRS) return;
             if (!(pi & ORX_PAIR_WRITER)) return;
             const int myslot = (pi >> 4) & 3, oslot = (pi >> 6) & 3;
             const int xsrc = (int)(threadIdx.x & ~63u) + (int)(pi & 15u) * LPR + sub;
-            const int id = (myslot == 0 ? a.uid[t] : (myslot == 1 ? a.pid[t] : a.nid[t])) & 0x0fffffff;
+            const int id = reinterpret_cast<const int*>(a.ids4 + t)[myslot] & 0x0fffffff;      // (the tail keeps nothing of the triplet alive but t and its pairing word)
             const size_t off = (size_t)id * D + 4 * sub;
             float* W = myslot == 0 ? a.U : a.V;
             float* A = myslot == 0 ? a.aU : a.aV;
@@ -621,7 +633,7 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
                 *reinterpret_cast<f4*>(Up) = ru; *reinterpret_cast<f4*>(a.aU + (size_t)u * D + 4 * sub) = mu;
                 *reinterpret_cast<f4*>(a.a2U + (size_t)u * D + 4 * sub) = vu;
                 if (sub == 0) a.lastU[u] = a.step_t;
-            } else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t) : -1, D, sub);
+            } else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t0) : -1, D, sub);
             if (dp == 0) {
                 adam_elem4(rp, mp, vp, gp, lrT, a.b1, a.b2, a.eps);
                 if (CENSOR) rp = censor4<LPR>(rp, a.min_norm);
@@ -632,7 +644,7 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
                     a.b[p] = bp; a.ab[p] = mbp; a.a2b[p] = vbp; a.lastV[p] = a.step_t; a.lastb[p] = a.step_t;
                 }
             } else {
-                const int sp = kp == 2 ? slot_of(Bp + t) : -1;
+                const int sp = kp == 2 ? slot_of(Bp + t0) : -1;
                 dup_store4s(a.gV, a.gV2, (size_t)p * D + 4 * sub, gp, kp, a.stage, sp, D, sub);
                 if (sub == 0) { dup_store1s(a.gb, a.gb2, p, gbp, kp, a.stageb, sp); if (CENSOR) a.sideV[2 * (size_t)p] = a.epoch; }
             }
@@ -646,7 +658,7 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
                     a.b[n] = bn; a.ab[n] = mbn; a.a2b[n] = vbn; a.lastV[n] = a.step_t; a.lastb[n] = a.step_t;
                 }
             } else {
-                const int sn = kn == 2 ? slot_of(2 * Bp + t) : -1;
+                const int sn = kn == 2 ? slot_of(2 * Bp + t0) : -1;
                 dup_store4s(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn, a.stage, sn, D, sub);
                 if (sub == 0) { dup_store1s(a.gb, a.gb2, n, gbn, kn, a.stageb, sn); if (CENSOR) a.sideV[2 * (size_t)n + 1] = a.epoch; }
             }
@@ -658,12 +670,12 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             // duplicated rows are censored by the kernel that applies their summed gradient
             f4 wu = ru, wp = rp, wn = rn;
             if (du == 0) wu = opt_new4<OPT>(a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
-            else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t) : -1, D, sub);
+            else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t0) : -1, D, sub);
             if (dp == 0) {
                 wp = opt_new4<OPT>(a.aV + (size_t)p * D + 4 * sub, rp, gp, a.lr, a.eps);
                 if (sub == 0) opt_apply1<OPT>(a.b + p, a.ab + p, bp, gbp, a.lr, a.eps);
             } else {
-                const int sp = kp == 2 ? slot_of(Bp + t) : -1;
+                const int sp = kp == 2 ? slot_of(Bp + t0) : -1;
                 dup_store4s(a.gV, a.gV2, (size_t)p * D + 4 * sub, gp, kp, a.stage, sp, D, sub);
                 if (sub == 0) { dup_store1s(a.gb, a.gb2, p, gbp, kp, a.stageb, sp); if (kp != 3) a.sideV[2 * (size_t)p] = a.epoch; }
             }
@@ -671,7 +683,7 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
                 wn = opt_new4<OPT>(a.aV + (size_t)n * D + 4 * sub, rn, gn, a.lr, a.eps);
                 if (sub == 0) opt_apply1<OPT>(a.b + n, a.ab + n, bn, gbn, a.lr, a.eps);
             } else {
-                const int sn = kn == 2 ? slot_of(2 * Bp + t) : -1;
+                const int sn = kn == 2 ? slot_of(2 * Bp + t0) : -1;
                 dup_store4s(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn, a.stage, sn, D, sub);
                 if (sub == 0) { dup_store1s(a.gb, a.gb2, n, gbn, kn, a.stageb, sn); if (kn != 3) a.sideV[2 * (size_t)n + 1] = a.epoch; }
             }
@@ -683,12 +695,12 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             continue;
         }
         if (du == 0) opt_apply4<OPT>(Up, a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
-        else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t) : -1, D, sub);
+        else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t0) : -1, D, sub);
         if (dp == 0) {
             opt_apply4<OPT>(Pp, a.aV + (size_t)p * D + 4 * sub, rp, gp, a.lr, a.eps);
             if (sub == 0) opt_apply1<OPT>(a.b + p, a.ab + p, bp, gbp, a.lr, a.eps);
         } else {
-            const int sp = kp == 2 ? slot_of(Bp + t) : -1;
+            const int sp = kp == 2 ? slot_of(Bp + t0) : -1;
             dup_store4s(a.gV, a.gV2, (size_t)p * D + 4 * sub, gp, kp, a.stage, sp, D, sub);
             if (sub == 0) dup_store1s(a.gb, a.gb2, p, gbp, kp, a.stageb, sp);
         }
@@ -696,7 +708,7 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             opt_apply4<OPT>(Np, a.aV + (size_t)n * D + 4 * sub, rn, gn, a.lr, a.eps);
             if (sub == 0) opt_apply1<OPT>(a.b + n, a.ab + n, bn, gbn, a.lr, a.eps);
         } else {
-            const int sn = kn == 2 ? slot_of(2 * Bp + t) : -1;
+            const int sn = kn == 2 ? slot_of(2 * Bp + t0) : -1;
             dup_store4s(a.gV, a.gV2, (size_t)n * D + 4 * sub, gn, kn, a.stage, sn, D, sub);
             if (sub == 0) dup_store1s(a.gb, a.gb2, n, gbn, kn, a.stageb, sn);
         }
@@ -730,6 +742,7 @@ __global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
     const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
     for (int64_t e = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + grp; e < n; e += stride) {
         const uint32_t ent = a.dlist[e];
+        if (ent == ORX_DLIST_DEAD) continue;            // (the row was paired after all: updated in place by the step's launch)
         const bool item = (ent >> 31) != 0;
         const size_t row = ent & 0x7fffffffu;
         float* W = item ? a.V : a.U;

@@ -18,17 +18,19 @@
 //                        numbering of the rows with >= 3 references, their ranks and staging segments (per-row
 //                        counters in LDS), duplicate list with (segment, count), reduction-tree work items
 //   plan_urgent_kernel   bit 28 on the references of step s whose row was duplicated in step s-1 (in-launch apply)
-//   plan_swap_kernel     pairing (below): moves the two triplets of an accepted pair into one wavefront, writes their pairing words
+//   plan_pair_kernel     pairing (below): accepts / refuses the rows referenced exactly twice
+//   plan_pack_kernel     pairing: the fused kernel's input, (user, pos, neg, pairing word) per position in the paired order
 //
 // PAIRING (round 4).  A row referenced exactly twice in a step costs the exact step ten row moves (two reads, two gradient
 // deposits, and the apply's three reads + three writes) where a racy kernel pays four.  The order of the triplets inside a
-// batch is free (the loss is a sum over the batch), so plan_range_kernel proposes, for every such row, to bring its two
-// triplets into the SAME WAVEFRONT of the fused kernel: there the two lane groups exchange their gradients of the shared row by
-// a cross-lane permute, one of them adds both and updates the row in place, the other does not write it -- two row moves, no
-// deposit, no apply, no ready flag.  A proposal claims the two triplets and, when they do not already share a wavefront, one
-// more position next to one of them (atomic exchange on a per-step claim array); a triplet takes part in at most one pair and
-// a displaced neighbour in none.  Proposals that lose a claim, rows with three or more references and rows whose two references
-// sit in one triplet keep the deposit / apply path.  The fused kernel sees a paired reference as a reference to a unique row.
+// batch is free (the loss is a sum over the batch), so the plan brings the two triplets of such a row into the SAME WAVEFRONT of
+// the fused kernel: there the two lane groups exchange their gradients of the shared row, one of them adds both and updates the
+// row in place, the other does not write it -- two row moves, no deposit, no apply, no ready flag.  plan_range_kernel tells
+// each of the two references where the other sits; plan_pair_kernel (one thread per entry of the step's list of duplicated rows)
+// accepts a row when it is the first such row of both its triplets and a neighbouring position can be displaced -- a rule on data nothing writes meanwhile: no claims,
+// deterministic -- and sends the refused rows down the deposit / apply path; plan_pack_kernel writes the fused kernel's input in the
+// new order.  Rows with three or more references and rows whose two references sit in one triplet always keep the deposit path.
+// The fused kernel sees a paired reference as a reference to a unique row.
 // The reference's semantics being restated are TF's: every gradient of a step is taken on the pre-step tables and
 // duplicate indices are summed before the sparse apply (tf2_examples/bpr_citeulike.py:35-38).
 #include "orx_internal.h"
@@ -36,6 +38,8 @@
 #include "orx_device.h"
 
 #include <cstring>
+#include <vector>
+#include <algorithm>
 
 constexpr int PL_THREADS = 256;
 constexpr int PL_REFS = 8;                        // references per thread in the count / scatter kernels
@@ -54,7 +58,9 @@ struct PlanArgs {
     unsigned int* dupbits;     // [K][nb][words] "seen twice" bitmaps for plan_urgent_kernel, or NULL
     int min_late;              // staging plan in ranges with at least this many third-or-later references (< 0: max(64, n / 512))
     int s_first;               // plan_urgent_kernel: first step to mark (1, or 0 when the plan's step 0 has a predecessor in the same arrays)
+    unsigned long long* tstamp; // ORX_PLAN_TIMING: [workgroups][8] wall-clock stamps of plan_range_kernel's phases (NULL: off)
 };
+#define PL_STAMP(i) do { if (a.tstamp != nullptr && threadIdx.x == 0) a.tstamp[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
 
 // reference j of the step (users, then pos items, then neg items): id, table, position in ids_out / refinfo
 __device__ __forceinline__ bool plan_ref(const PlanArgs& a, int64_t s, int64_t j, int& id, bool& is_user, int& pos) {
@@ -109,9 +115,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_part_kernel(PlanArgs a) {
             // a scattered 4-byte store costs a memory transaction of its own.  0x7fffffff: out-of-range id, never a valid row
             if (SCATTER) {
                 a.d.ids_out[s * a.d.flag_stride + pos] = ok ? id : 0x7fffffff;
-                if (a.d.pair_tpw > 1 && j < a.d.pair_stride) {          // pairing: the step's claims and pairing words start at zero
-                    a.d.claim[s * a.d.pair_stride + j] = 0;
-                    a.d.pinfo[s * a.d.pair_stride + j] = 0u;
+                if (a.d.pair_tpw > 1) {          // pairing: no reference has a partner yet, no triplet a pairing word, every triplet is where it stands
+                    a.d.partner[s * a.d.flag_stride + pos] = -1;
+                    if (j < a.d.pair_stride) { a.d.pinfo[s * a.d.pair_stride + j] = 0u; a.d.perm[s * a.d.pair_stride + j] = (int)j; }
                 }
             }
         }
@@ -197,45 +203,7 @@ __device__ __forceinline__ int pl_rank(int* cnt, int dn) {
     return rank;
 }
 
-// pairing: claim the triplets ta and tb (positions of the step's batch) and, unless they already sit in one wavefront of
-// `tpw` triplets, a free position next to one of them.  On success: `mover` goes to position `q` (q == mover: nothing moves),
-// `stay` stays.  Claims are exclusive (atomic exchange on the step's claim array, zero = free); a loser releases what it took.
-constexpr int PL_PAIR_CAP = 1024;                 // rows referenced exactly twice that a range can pair (their positions live in LDS)
-// (every atomic below is issued before any of its results is looked at: the chain is two or three memory round trips, not six)
-__device__ __forceinline__ bool pair_claim(int* claim, int B, int tpw, int ta, int tb, int& stay, int& mover, int& q) {
-    if (ta == tb) return false;                       // both references in ONE triplet (p == n, ...): nothing to exchange across lane groups
-    const int ca = atomicExch(claim + ta, 1), cb = atomicExch(claim + tb, 1);
-    if (ca != 0 || cb != 0) {
-        if (ca == 0) atomicExch(claim + ta, 0);
-        if (cb == 0) atomicExch(claim + tb, 0);
-        return false;
-    }
-    const int qa = ta & ~(tpw - 1), qb = tb & ~(tpw - 1);
-    if (qa == qb) { stay = ta; mover = tb; q = tb; return true; }
-    // a free position beside ta, else beside tb: the (up to) three other positions of its aligned group of four at once -- inside
-    // the wavefront for every tpw -- and the first free one is kept
-    const int g = tpw < 4 ? tpw : 4;
-    for (int side = 0; side < 2; ++side) {
-        const int self = side ? tb : ta, q0 = self & ~(g - 1);
-        int r[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = q0 + k;
-            r[k] = (k < g && c != self && c < B) ? atomicExch(claim + c, 1) : 1;
-        }
-        int keep = -1;
-#pragma unroll
-        for (int k = 3; k >= 0; --k) if (r[k] == 0) keep = k;
-        if (keep >= 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (r[k] == 0 && k != keep) atomicExch(claim + q0 + k, 0);
-            stay = self; mover = side ? ta : tb; q = q0 + keep;
-            return true;
-        }
-    }
-    atomicExch(claim + ta, 0); atomicExch(claim + tb, 0);
-    return false;
-}
+constexpr int PL_PAIR_CAP = 1024;                 // rows referenced exactly twice per range whose references learn of each other (positions in LDS)
 
 // One workgroup per (range, step): the same plan dedup_kernel makes for its range, on the range's own references.
 template <int T>
@@ -249,9 +217,8 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
     unsigned short* prefix16 = reinterpret_cast<unsigned short*>(pl_lds + 3 * W);     // dense number of a word's first tri row
     int* lcnt = reinterpret_cast<int*>(pl_lds + 3 * W + (W + 1) / 2);                  // references per dense tri row (LDS or global)
     // pairing: dense number of a word's first twice-referenced row, then per such row (local row, position of reference 0, of reference 1)
-    unsigned short* dprefix16 = reinterpret_cast<unsigned short*>(lcnt + PL_LCNT);
-    int* pairrow = reinterpret_cast<int*>(lcnt + PL_LCNT + (W + 1) / 2);
-    int* pairpos = pairrow + PL_PAIR_CAP;
+    unsigned short* dprefix16 = reinterpret_cast<unsigned short*>(seen);                // ("seen" is dead after pass 1)
+    int* pairpos = reinterpret_cast<int*>(lcnt + PL_LCNT);
     __shared__ int wave_tot[T / 64];
     __shared__ int sh_late, sh_dense, sh_seg, list_cnt, list_base;
     const int nb = a.nru + a.nri;
@@ -261,6 +228,7 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
     const int lg = is_user ? a.lgu : a.lgi;             // local row of id: id >> lg; id of local row l: (l << lg) | bl
     const int bl = is_user ? b : b - a.nru;
     const int* cnt = a.bcnt + s * (3 * nb + 1) + 2 * nb;
+    PL_STAMP(0);
     const int lo = cnt[b], n = cnt[b + 1] - lo;
     int2* ent = a.list + s * a.nref + lo;
     unsigned int* dupout = a.dupbits ? a.dupbits + ((size_t)s * nb + b) * W : nullptr;
@@ -274,6 +242,7 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
     for (int i = threadIdx.x; i < 3 * W; i += T) pl_lds[i] = 0u;
     if (threadIdx.x == 0) { sh_late = 0; list_cnt = 0; }
     __syncthreads();
+    PL_STAMP(1);
     // pass 1: bitmaps; the role of a reference among its row's references (first / second / later, by arrival)
     int late = 0;
     pl_for_each<T>(ent, n, [&](int i, int2 e) {
@@ -297,6 +266,7 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
     });
     if (refinfo != nullptr && late) atomicAdd(&sh_late, late);
     __syncthreads();
+    PL_STAMP(2);
     // staging plan where atomics would pile up: ranges with at least max(64, n / 512) third-or-later references
     const bool plan = refinfo != nullptr && sh_late >= (a.min_late < 0 ? (n / 512 > 64 ? n / 512 : 64) : a.min_late);
     int ntri = 0, dense0 = 0;
@@ -330,14 +300,14 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
         int mine2 = 0;
         for (int w = w0; w < w0 + per && w < W; ++w) mine2 += __popc(dup[w] & ~tri[w]);
         int pre = plan_scan_excl<T>(mine2, wave_tot, ndup2);
-        if (ndup2 > 65535) ndup2 = 0;                   // (16-bit prefixes; such a range keeps the deposit path)
+        if (ndup2 > PL_PAIR_CAP) ndup2 = 0;             // (more such rows than the LDS tables hold: this range keeps the deposit path)
         if (ndup2) {
             for (int w = w0; w < w0 + per && w < W; ++w) { dprefix16[w] = (unsigned short)pre; pre += __popc(dup[w] & ~tri[w]); }
-            const int np = ndup2 < PL_PAIR_CAP ? ndup2 : PL_PAIR_CAP;
-            for (int i = threadIdx.x; i < 2 * np; i += T) pairpos[i] = -1;
+            for (int i = threadIdx.x; i < 2 * ndup2; i += T) pairpos[i] = -1;
             __syncthreads();
         }
     }
+    PL_STAMP(3);
     // pass 2: rewritten ids, (dense row, rank) of the references that stage
     pl_for_each<T>(ent, n, [&](int, int2 e) {
         const int l = e.x >> lg;
@@ -351,11 +321,8 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
             if (ndup2 && !t3) {
                 // a row referenced exactly twice: the pairing phase below decides (and writes both rewritten ids)
                 const int dn2 = (int)dprefix16[l >> 5] + __popc(dw & ~tw & ((1u << (l & 31)) - 1u));
-                if (dn2 < PL_PAIR_CAP) {
-                    pairpos[2 * dn2 + (int)(((uint32_t)e.y >> 30) & 1u)] = pos;
-                    pairrow[dn2] = l;
-                    return;
-                }
+                pairpos[2 * dn2 + (int)(((uint32_t)e.y >> 30) & 1u)] = pos;
+                return;
             }
             v |= (t3 ? 2u : ((uint32_t)e.y >> 30)) << 29;
             if (t3 && ntri) {
@@ -367,51 +334,21 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
             ids_out[pos] = (int32_t)v;
         }
     });
+    PL_STAMP(4);
     if (ndup2) {
-        // pairing phase: one thread per row referenced exactly twice.  Accepted: both references become references to a
-        // unique row (plain id), the row leaves the duplicate bitmap (no list entry, no urgent marks in the next step) and
-        // the pair is recorded for plan_swap_kernel.  Refused: the roles the deposit path needs.
+        // pairing: the two references of a row referenced exactly twice learn where the other one sits (partner[], read by
+        // plan_pair_kernel, which decides about the row: the rewritten ids of both, its list entry and its bit in the duplicate
+        // bitmap are that kernel's) -- here the row leaves this range's bitmap
         __syncthreads();
-        const int np = ndup2 < PL_PAIR_CAP ? ndup2 : PL_PAIR_CAP;
-        const int Bp = (int)d.role_stride;
-        int* claim = d.claim + s * d.pair_stride;
-        for (int k0 = 0; k0 < np; k0 += T) {               // (wave-uniform trip count: the ballot below)
-            const int k = k0 + threadIdx.x;
-            bool ok = false;
-            int posA = 0, posB = 0, l = 0, stay = 0, mover = 0, q = 0, sa = 0, sb = 0, ta = 0;
-            if (k < np) {
-                posA = pairpos[2 * k]; posB = pairpos[2 * k + 1];
-                l = pairrow[k];
-                if (posA >= 0 && posB >= 0) {               // (always: a row of this class has exactly one reference of each role)
-                    sa = posA / Bp; sb = posB / Bp;
-                    ta = posA - sa * Bp;
-                    ok = pair_claim(claim, (int)d.pair_stride, d.pair_tpw, ta, posB - sb * Bp, stay, mover, q);
-                    const uint32_t id = (uint32_t)((l << lg) | bl);
-                    if (ok) {
-                        ids_out[posA] = (int32_t)id; ids_out[posB] = (int32_t)id;
-                        atomicAnd(&dup[l >> 5], ~(1u << (l & 31)));
-                    } else {
-                        ids_out[posA] = (int32_t)(id | (1u << 31));                   // role 0
-                        ids_out[posB] = (int32_t)(id | (1u << 31) | (1u << 29));      // role 1
-                    }
-                }
-            }
-            // one allocation per wavefront for its accepted pairs (thousands of atomics on ONE counter serialize)
-            const unsigned long long okm = __ballot(ok);
-            if (okm) {
-                const int lane = threadIdx.x & 63, first = __ffsll((long long)okm) - 1;
-                int base = 0;
-                if (lane == first) base = atomicAdd(d.alloc + 8 * s + 7, __popcll(okm));
-                base = __shfl(base, first);
-                if (ok) {
-                    const int s_stay = stay == ta ? sa : sb, s_mov = stay == ta ? sb : sa;
-                    d.swaps[s * d.swap_stride + base + __popcll(okm & ((1ull << lane) - 1ull))] = make_int4(stay, mover, q, s_stay | (s_mov << 2));
-                }
-            }
+        int* partner = d.partner + s * d.flag_stride;
+        for (int k = threadIdx.x; k < ndup2; k += T) {
+            const int posA = pairpos[2 * k], posB = pairpos[2 * k + 1];
+            partner[posA] = posB;                           // (bit 30 clear: the row's first reference, which owns the decision)
+            partner[posB] = posA | (1 << 30);
         }
-        __syncthreads();
     }
-    if (dupout) for (int w = threadIdx.x; w < W; w += T) dupout[w] = dup[w];
+    PL_STAMP(5);
+    if (dupout) for (int w = threadIdx.x; w < W; w += T) dupout[w] = ndup2 ? tri[w] : dup[w];      // (pairing: plan_pair_kernel adds the refused rows)
     // segment start of every tri row (its references' slots are contiguous: segstart + rank)
     if (ntri) {
         __syncthreads();                               // the counts are final
@@ -433,20 +370,33 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
     int off = 0;
     if (mine) off = atomicAdd(&list_cnt, mine);
     __syncthreads();
+    PL_STAMP(6);
     if (threadIdx.x == 0) {
         list_base = list_cnt ? atomicAdd(d.dcount + s, list_cnt) : 0;
         if (list_cnt) atomicAdd(d.alloc + 8 * s + 5, list_cnt);      // (the host reads the allocators only: one copy)
     }
     __syncthreads();
+    PL_STAMP(7);
     if (mine) {
         int64_t e = s * d.list_stride + list_base + off;
         const uint32_t tag = is_user ? 0u : 0x80000000u;
         for (int w = threadIdx.x; w < W; w += T) {
             unsigned int m = dup[w];
+            const unsigned int m0 = m;
             const unsigned int tw = tri[w];
             while (m) {
                 const int bpos = __ffs(m) - 1;
                 m &= m - 1;
+                if (ndup2 && !((tw >> bpos) & 1u)) {
+                    // a row referenced exactly twice: the entry is reserved; plan_pair_kernel, which gets the position of the row's
+                    // first reference here, fills it (the row, or ORX_DLIST_DEAD) and the pair record behind it
+                    const int dn2 = (int)dprefix16[w] + __popc(m0 & ~tw & ((1u << bpos) - 1u));
+                    d.pslot[e] = pairpos[2 * dn2];
+                    if (d.dcnt != nullptr) { d.dseg[e] = 0; d.dcnt[e] = 0; }
+                    ++e;
+                    continue;
+                }
+                if (d.pair_tpw > 1) d.pslot[e] = -1;       // (not a row plan_pair_kernel decides about)
                 d.dlist[e] = (uint32_t)((((int64_t)w * 32 + bpos) << lg) | bl) | tag;
                 if (d.dcnt != nullptr) {
                     int c = 0, sg = 0;
@@ -502,35 +452,104 @@ __global__ __launch_bounds__(T) void plan_urgent_kernel(PlanArgs a) {
     });
 }
 
-// pairing: one thread per accepted pair of a step -- the triplet `mover` changes places with the one at `q` (three rewritten ids
-// each, and their staging records), then both partners get their pairing word.  Runs after plan_urgent_kernel: flags travel with the ids.
-__global__ __launch_bounds__(256) void plan_swap_kernel(DedupArgs d) {
+// pairing: one thread per entry of a step's list of duplicated rows decides about the row behind it, if that row is referenced
+// exactly twice (plan_range_kernel left the position of its first reference in pslot), from partner[] alone -- which nothing
+// writes here: no claims, no atomics on the way to a decision, the same outcome in every run.
+//   A triplet's CHOICE is its first slot (user, pos item, neg item) that references such a row.  The row is ACCEPTED when it is the
+//   choice of both its triplets (a triplet is then in at most one accepted pair) and the two can be brought together: they already
+//   share a wavefront, or the position next to the lower one (its buddy, index ^ 1) may be displaced -- it is not itself in a mutual
+//   pair -- or else the buddy of the upper one.  A position can only ever be displaced for its own buddy: accepted pairs never collide.
+//   Accepted: the list entry is marked dead; perm[] sends the mover to the free position (and the displaced triplet to the mover's),
+//   the two positions get their pairing words.  Both references stay what plan_part_kernel wrote: references to a unique row.
+//   Refused: the two rewritten ids get the duplicate flag and roles 0 / 1, the entry its row, and the row its bit in the bitmap
+//   plan_urgent_kernel reads.
+__global__ __launch_bounds__(256) void plan_pair_kernel(PlanArgs a) {
+    const DedupArgs& d = a.d;
     const int64_t s = blockIdx.y;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= d.alloc[8 * s + 7]) return;
-    const int4 r = d.swaps[s * d.swap_stride + k];
-    const int stay = r.x, mover = r.y, q = r.z;
+    const int B = (int)d.pair_stride, Bp = (int)d.role_stride, tpw = d.pair_tpw;
+    const int* part = d.partner + s * d.flag_stride;
     int32_t* ids = d.ids_out + s * d.flag_stride;
-    int2* refinfo = d.refinfo ? d.refinfo + s * d.flag_stride : nullptr;
-    const int64_t Bp = d.role_stride;
-    if (q != mover) {
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl) {
-            const int32_t x = ids[sl * Bp + q], y = ids[sl * Bp + mover];
-            ids[sl * Bp + q] = y; ids[sl * Bp + mover] = x;
-            if (refinfo) { const int2 u = refinfo[sl * Bp + q], v = refinfo[sl * Bp + mover]; refinfo[sl * Bp + q] = v; refinfo[sl * Bp + mover] = u; }
+    int* perm = d.perm + s * d.pair_stride;
+    uint32_t* pinfo = d.pinfo + s * d.pair_stride;
+    const int nb = a.nru + a.nri, W = (1 << a.shift) >> 5;
+    const int n = d.dcount[s];
+    auto slot_of = [&](int pos) { return (pos >= Bp ? 1 : 0) + (pos >= 2 * Bp ? 1 : 0); };
+    // is slot sy the choice of triplet y?  (no earlier slot of y references a row of this kind)
+    auto chooses = [&](int y, int sy) { bool ok = true; for (int k = 0; k < sy; ++k) ok = ok && part[k * Bp + y] < 0; return ok; };
+    // is position x part of a mutual pair (its choice's partner chooses it back)?  positions outside the batch count as taken
+    auto in_pair = [&](int x) {
+        if (x >= B) return true;
+        const int p0 = part[x], p1 = part[Bp + x], p2 = part[2 * Bp + x];
+        const int sx = p0 >= 0 ? 0 : (p1 >= 0 ? 1 : (p2 >= 0 ? 2 : -1));
+        if (sx < 0) return false;
+        const int pp = (sx == 0 ? p0 : (sx == 1 ? p1 : p2)) & 0x3fffffff;
+        const int sy = slot_of(pp), y = pp - sy * Bp;
+        return y != x && chooses(y, sy);
+    };
+    int npair = 0;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const int64_t eg = s * d.list_stride + e;
+        const int posA = d.pslot[eg];
+        if (posA < 0) continue;                             // (a row with three or more references: plan_range_kernel's)
+        const int posB = part[posA] & 0x3fffffff;
+        const int sa = slot_of(posA), sb = slot_of(posB);
+        const int ta = posA - sa * Bp, tb = posB - sb * Bp;
+        bool acc = false;
+        int stay = 0, mover = 0, q = 0;
+        if (ta != tb && chooses(ta, sa) && chooses(tb, sb)) {
+            const int lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+            if ((lo & ~(tpw - 1)) == (hi & ~(tpw - 1))) { acc = true; stay = lo; mover = hi; q = hi; }
+            else if (!in_pair(lo ^ 1)) { acc = true; stay = lo; mover = hi; q = lo ^ 1; }
+            else if (!in_pair(hi ^ 1)) { acc = true; stay = hi; mover = lo; q = hi ^ 1; }
+        }
+        if (acc) {
+            d.dlist[eg] = ORX_DLIST_DEAD;
+            if (q != mover) { perm[q] = mover; perm[mover] = q; }
+            const uint32_t s_stay = (uint32_t)(stay == ta ? sa : sb), s_mov = (uint32_t)(stay == ta ? sb : sa), m = (uint32_t)tpw - 1u;
+            pinfo[stay] = ORX_PAIR_VALID | ORX_PAIR_WRITER | ((uint32_t)q & m) | (s_stay << 4) | (s_mov << 6);
+            pinfo[q] = ORX_PAIR_VALID | ((uint32_t)stay & m) | (s_mov << 4) | (s_stay << 6);
+            npair += 1;
+        } else {
+            const uint32_t id = (uint32_t)ids[posA];
+            ids[posA] = (int32_t)(id | (1u << 31));                         // role 0
+            ids[posB] = (int32_t)(id | (1u << 31) | (1u << 29));            // role 1
+            d.dlist[eg] = id | (sa ? 0x80000000u : 0u);
+            if (a.dupbits != nullptr) {
+                const int bk = sa ? a.nru + (int)(id & (uint32_t)(a.nri - 1)) : (int)(id & (uint32_t)(a.nru - 1));
+                const int l = (int)(id >> (sa ? a.lgi : a.lgu));
+                atomicOr(a.dupbits + ((size_t)s * nb + bk) * W + (l >> 5), 1u << (l & 31));
+            }
         }
     }
-    const uint32_t s_stay = (uint32_t)r.w & 3u, s_mov = ((uint32_t)r.w >> 2) & 3u, m = (uint32_t)d.pair_tpw - 1u;
-    uint32_t* pinfo = d.pinfo + s * d.pair_stride;
-    pinfo[stay] = ORX_PAIR_VALID | ORX_PAIR_WRITER | ((uint32_t)q & m) | (s_stay << 4) | (s_mov << 6);
-    pinfo[q] = ORX_PAIR_VALID | ((uint32_t)stay & m) | (s_mov << 4) | (s_stay << 6);
+    // accepted pairs of the step (host: list entries - pairs = rows the apply really has): one atomic per workgroup
+    __shared__ int sh_np;
+    if (threadIdx.x == 0) sh_np = 0;
+    __syncthreads();
+    if (npair) atomicAdd(&sh_np, npair);
+    __syncthreads();
+    if (threadIdx.x == 0 && sh_np) atomicAdd(d.alloc + 8 * s + 7, sh_np);
 }
 
-int orx_launch_plan_swap(orx_ctx* ctx, const DedupArgs& d, int64_t kc) {
+// pairing: the fused kernel's input, one 16-byte record per position j of the batch -- the three rewritten ids of the triplet that is
+// processed there (perm: itself, unless a pair moved it) with every flag the plan put on them, the position's pairing word and the
+// triplet's original position (its staging records stay where they were).  Runs after plan_urgent_kernel.
+__global__ __launch_bounds__(256) void plan_pack_kernel(DedupArgs d) {
+    const int64_t s = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= d.pair_stride) return;
+    const int src = d.perm[s * d.pair_stride + j];
+    const int32_t* ids = d.ids_out + s * d.flag_stride;
+    const int64_t Bp = d.role_stride;
+    int4 v;
+    v.x = ids[src]; v.y = ids[Bp + src]; v.z = ids[2 * Bp + src];
+    v.w = (int)(d.pinfo[s * d.pair_stride + j] | ((uint32_t)src << 10));
+    d.ids4[s * d.pair_stride + j] = v;
+}
+
+int orx_launch_plan_pack(orx_ctx* ctx, const DedupArgs& d, int64_t kc) {
     if (d.pair_tpw < 2 || kc <= 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_DEDUP);
-    ORX_LAUNCH(ctx, plan_swap_kernel, dim3((unsigned)((d.swap_stride + 255) / 256), (unsigned)kc), dim3(256), 0, d);
+    ORX_LAUNCH(ctx, plan_pack_kernel, dim3((unsigned)((d.pair_stride + 255) / 256), (unsigned)kc), dim3(256), 0, d);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -602,6 +621,12 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
     a.bcnt = ctx->d_pl_cnt + step0 * (3 * nb + 1); a.list = ctx->d_pl_list + step0 * a.nref;
     a.dupbits = keep_dupbits ? ctx->d_dupbits + step0 * words : nullptr;
     a.s_first = 1;
+    a.tstamp = nullptr;
+    static const bool timing = getenv("ORX_PLAN_TIMING") != nullptr;     // experiments: per-phase wall-clock stamps of plan_range_kernel
+    if (timing) {
+        ORX_HIP(hipMalloc((void**)&a.tstamp, (size_t)nb * kc * 8 * sizeof(unsigned long long)));
+        ORX_HIP(hipMemsetAsync(a.tstamp, 0, (size_t)nb * kc * 8 * sizeof(unsigned long long), ctx->stream));
+    }
     const char* ml = getenv("ORX_PLAN_MIN_LATE");      // experiments
     a.min_late = ml ? atoi(ml) : d.min_late;
     ORX_HIP(hipMemsetAsync(a.bcnt, 0, (size_t)kc * (3 * nb + 1) * sizeof(int), ctx->stream));
@@ -615,12 +640,31 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
     ORX_LAUNCH(ctx, (plan_part_kernel<true>), gp, dim3(PL_THREADS), hist_bytes, a);
     const int W = (1 << a.shift) >> 5;
     const size_t lds = (size_t)(3 * W + (W + 1) / 2) * 4 + (size_t)PL_LCNT * 4 +
-                       (d.pair_tpw > 1 && W <= 4096 ? (size_t)((W + 1) / 2) * 4 + (size_t)3 * PL_PAIR_CAP * 4 : 0);      // (+ pairing: prefixes, rows, positions)
+                       (d.pair_tpw > 1 && W <= 4096 ? (size_t)2 * PL_PAIR_CAP * 4 : 0);      // (+ pairing: positions)
     // workgroups of 1024 threads where the previous plan met a bucket with more than 16 k references (skewed ids: the head of
     // a Zipf distribution puts 100 k of a step's 131 k item references into one range, 0.7 ms for 256 threads)
     if (ctx->plan_big) ORX_LAUNCH(ctx, plan_range_kernel<1024>, dim3((unsigned)nb, (unsigned)kc), dim3(1024), lds, a);
     else ORX_LAUNCH(ctx, plan_range_kernel<256>, dim3((unsigned)nb, (unsigned)kc), dim3(256), lds, a);
+    // (a grid-stride loop over the step's list: ~0.16 B entries with uniform ids)
+    if (d.pair_tpw > 1) ORX_LAUNCH(ctx, plan_pair_kernel, dim3((unsigned)std::max<int64_t>(4, (d.pair_stride / 4 + 255) / 256), (unsigned)kc), dim3(256), 0, a);
     ORX_HIP(hipGetLastError());
+    if (a.tstamp != nullptr) {
+        // stamps are in ticks of the 100 MHz constant clock
+        ORX_HIP(hipStreamSynchronize(ctx->stream));
+        std::vector<unsigned long long> h((size_t)nb * kc * 8);
+        ORX_HIP(hipMemcpy(h.data(), a.tstamp, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        ORX_HIP(hipFree(a.tstamp));
+        double sum[8] = {0}; unsigned long long t_min = ~0ull, t_max = 0; size_t live = 0;
+        for (size_t w = 0; w < (size_t)nb * kc; ++w) {
+            const unsigned long long* t = &h[w * 8];
+            if (t[7] == 0) continue;                    // (an empty range returned early)
+            ++live; t_min = std::min(t_min, t[0]); t_max = std::max(t_max, t[7]);
+            for (int i = 1; i < 8; ++i) sum[i] += (double)(t[i] - t[i - 1]);
+        }
+        fprintf(stderr, "[orx plan timing] K=%lld, %zu workgroups, span %.1f us; mean us per phase: zero+cnt %.2f | pass1 %.2f | staging+prefix %.2f | pass2 %.2f | "
+                "pairing %.2f | dupbits %.2f | list alloc %.2f\n", (long long)kc, live, (double)(t_max - t_min) * 0.01,
+                sum[1] / live * 0.01, sum[2] / live * 0.01, sum[3] / live * 0.01, sum[4] / live * 0.01, sum[5] / live * 0.01, sum[6] / live * 0.01, sum[7] / live * 0.01);
+    }
     return ORX_OK;
 }
 

@@ -82,6 +82,7 @@ __device__ __forceinline__ void inline_apply(const PairArgs& a) {
     const int64_t stride = (int64_t)a.n_apply_blocks * 4 * TPW;
     for (int64_t e = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + grp; e < n; e += stride) {
         const uint32_t ent = a.prev_dlist[e];
+        if (ent == ORX_DLIST_DEAD) continue;            // (the row was paired after all: updated in place by step s-1's launch)
         const bool item = (ent >> 31) != 0;
         const size_t row = ent & 0x7fffffffu;
         float* W = item ? a.V : a.U;

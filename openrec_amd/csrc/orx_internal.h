@@ -62,8 +62,10 @@ struct orx_ctx {
     bool plan_big = false;                                       // the last plan met a bucket of > 16 k references: 1024-thread workgroups
     // pairing (kernels_plan.hip, "pairing"): the two references of a row referenced exactly twice are brought into one wavefront
     uint32_t* d_pinfo = nullptr; size_t d_pinfo_cap = 0;         // [K][B] per-triplet pairing word read by the fused kernel (0: not paired)
-    int* d_claim = nullptr;    size_t d_claim_cap = 0;           // [K][B] position claims of the pairing (zero = free)
-    int4* d_swaps = nullptr;   size_t d_swaps_cap = 0;           // [K][B/2] accepted pairs (stay, mover, destination, slots)
+    int* d_partner = nullptr;  size_t d_partner_cap = 0;         // [K][3 Bp] per reference of a row referenced exactly twice: where the other one sits (-1: none)
+    int* d_pslot = nullptr;    size_t d_pslot_cap = 0;           // [K][2B] parallel to dlist: position of the FIRST reference of a row referenced exactly twice (-1: another kind of row)
+    int* d_perm = nullptr;     size_t d_perm_cap = 0;            // [K][B] pairing: which triplet of the batch is processed at position j
+    int4* d_ids4 = nullptr;    size_t d_ids4_cap = 0;            // [K][B] the fused kernel's input with pairing: (user, pos, neg) rewritten ids of position j, pinfo | origin << 10
     int* h_plan = nullptr;                                       // pinned host mirror of the per-step plan counters
     size_t h_plan_cap = 0;
     hipEvent_t plan_ev = nullptr;                                // "plan counters have arrived on the host"
@@ -196,7 +198,8 @@ struct PairArgs {
     int newton;                 // lazy Adam: carry 1/(sqrt(v)+eps) by Newton steps (1 - sqrt(beta_2) <= 1e-3)
     int long_gap;               // lazy Adam: tables large relative to the batch (rows wait hundreds of steps): LONGGAP kernel
     const int32_t* uid; const int32_t* pid; const int32_t* nid;
-    const uint32_t* pinfo;                    // [B] pairing word per triplet (see ORX_PAIR_*), or NULL: no pairing in this launch
+    const int4* ids4;                         // pairing: [B] (user, pos item, neg item) rewritten ids of the triplet processed at position j and, in w, its pairing
+                                              // word (ORX_PAIR_*, bits 9:0) and the triplet's original position (bits 31:10); NULL: uid / pid / nid as usual
     int role_bits;                            // ids carry role (bits 30:29) and urgent (bit 28): tables < 2^28 rows
     // in-launch application of the PREVIOUS step's duplicated rows (n_apply_blocks == 0: off)
     int n_apply_blocks; int epoch;
@@ -250,11 +253,13 @@ struct DedupArgs {
     int tree_off[3];
     int min_late;                             // bucketed plan: see PairPlan
     // pairing (bucketed plan only; pair_tpw < 2: off): triplets per wavefront of the fused kernel that will run the steps,
-    // per-step arrays [K][pair_stride] claim / pinfo and [K][swap_stride] swaps; the number of accepted pairs of step s is alloc[8 s + 7]
-    int pair_tpw; int* claim; uint32_t* pinfo; int4* swaps; int64_t pair_stride; int64_t swap_stride;
+    // per-step arrays [K][flag_stride] partner, [K][pair_stride] pinfo and [K][swap_stride] swaps; the number of accepted pairs of step s
+    // is alloc[8 s + 7]
+    int pair_tpw; int* partner; int* pslot; uint32_t* pinfo; int* perm; int4* ids4; int64_t pair_stride;
 };
 // pairing word of a triplet (PairArgs::pinfo): the triplet shares one row with the triplet of lane group PARTNER of the same wavefront;
 // the WRITER adds the partner's gradient of that row to its own and updates the row in place, the other one does not write it
+constexpr uint32_t ORX_DLIST_DEAD = 0xffffffffu;     // entry of a step's list of duplicated rows whose row was paired after all: nothing to apply
 constexpr uint32_t ORX_PAIR_VALID = 0x200u, ORX_PAIR_WRITER = 0x100u;      // bits 3:0 partner lane group, 5:4 my slot (0 user, 1 pos, 2 neg), 7:6 partner's slot
 constexpr int ORX_SEG_DIRECT = 16;            // the apply sums up to this many staged gradients / partial sums of a row itself
 constexpr int ORX_PIECE = 64;                 // longer segments: a tree of 64-to-1 partial sums (hot_reduce_kernel, one wavefront per piece)
@@ -391,7 +396,7 @@ bool orx_plan_v2(bool role_bits);
 int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t B, int64_t NU, int64_t NI, bool want_dupbits);
 int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupbits, int64_t step0 = 0);
 int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc, int64_t step0 = 0);
-int orx_launch_plan_swap(orx_ctx* ctx, const DedupArgs& d, int64_t kc);      // pairing: move the accepted pairs together, write pinfo
+int orx_launch_plan_pack(orx_ctx* ctx, const DedupArgs& d, int64_t kc);      // pairing: permuted (u, p, n, pairing word) records for the fused kernel
 int orx_fused_tpw(int D);                        // triplets per wavefront of the float4 fused kernel (0: generic dim)
 int orx_fused_can_inline_apply(int D);
 int orx_dedup_words(void);
