@@ -104,7 +104,7 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipFree(c->d_err); hipFree(c->d_ids); hipFree(c->d_lab); hipFree(c->d_dflag); hipFree(c->d_evalbits); hipFree(c->d_ids2); hipFree(c->d_roles); hipFree(c->d_cflag); hipFree(c->d_dupbits); hipFree(c->d_dlist);
     hipFree(c->d_dcount); hipFree(c->d_refinfo); hipFree(c->d_tricnt); hipFree(c->d_segstart); hipFree(c->d_alloc); hipFree(c->d_dseg); hipFree(c->d_dcnt); hipFree(c->d_chunks); hipFree(c->d_part); hipFree(c->d_partb); hipFree(c->d_stage); hipFree(c->d_stageb); hipFree(c->d_partial); hipFree(c->d_loss); hipFree(c->d_tmp);
     hipFree(c->d_wpart); hipFree(c->d_pl_cnt); hipFree(c->d_pl_list);
-    hipFree(c->d_pinfo); hipFree(c->d_partner); hipFree(c->d_pslot); hipFree(c->d_perm); hipFree(c->d_ids4);
+    hipFree(c->d_partner); hipFree(c->d_pslot); hipFree(c->d_ids4);
     hipFree(c->d_sort[0]); hipFree(c->d_sort[1]); hipFree(c->d_sort_hist); hipFree(c->d_csr_part[0]); hipFree(c->d_csr_part[1]); hipFree(c->d_splitk);
     if (c->h_plan) hipHostFree(c->h_plan);
     if (c->plan_ev) hipEventDestroy(c->plan_ev);
@@ -643,7 +643,7 @@ static void plan_dedup_args(orx_ctx* c, orx_table* U, orx_table* V, const int32_
     d.alloc = c->d_alloc ? c->d_alloc + 8 * i0 : nullptr;
     if (plan.pair_tpw > 1) {        // pairing (kernels_plan.hip): per-step claims, pairing words, accepted pairs
         d.pair_tpw = plan.pair_tpw; d.pair_stride = B;
-        d.partner = c->d_partner + (size_t)i0 * 3 * plan.Bp; d.pslot = c->d_pslot + (size_t)i0 * plan.list_stride; d.pinfo = c->d_pinfo + (size_t)i0 * B; d.perm = c->d_perm + (size_t)i0 * B; d.ids4 = c->d_ids4 + (size_t)i0 * B;
+        d.partner = c->d_partner + (size_t)i0 * B; d.pslot = c->d_pslot + (size_t)i0 * 2 * plan.list_stride; d.ids4 = c->d_ids4 + (size_t)i0 * B;
     }
     if (staging) {
         d.refinfo = c->d_refinfo + (size_t)i0 * 3 * plan.Bp; d.tricnt = c->d_tricnt + (size_t)i0 * B; d.segstart = c->d_segstart + (size_t)i0 * B;
@@ -706,7 +706,7 @@ int orx_exact_plan_issue(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
     return ORX_OK;
 }
 
-int orx_exact_plan_finish(orx_ctx* c, int64_t kc, int64_t B, bool inline_apply, bool staging, int64_t i0, hipEvent_t counters, ExactChunk* out) {
+int orx_exact_plan_finish(orx_ctx* c, int64_t kc, int64_t B, bool inline_apply, bool staging, int64_t i0, hipEvent_t counters, ExactChunk* out, bool pairing_on) {
     *out = ExactChunk();
     ORX_HIP(hipEventSynchronize(counters));
     std::vector<int> dcv((size_t)kc);
@@ -714,6 +714,11 @@ int orx_exact_plan_finish(orx_ctx* c, int64_t kc, int64_t B, bool inline_apply, 
     const int* hp = c->h_plan + 8 * i0;
     for (int64_t i = 0; i < kc; ++i) { dcv[i] = hp[8 * i + 5] - hp[8 * i + 7]; big = std::max(big, hp[8 * i + 6]); }      // ([5] list entries, [7] of them paired after all)
     c->plan_big = big > 16384;          // ([6] = the step's largest bucket, if above 8 k references)
+    if (pairing_on && kc > 0 && getenv("ORX_PAIR_ALWAYS") == nullptr) {
+        int64_t pairs = 0;
+        for (int64_t i = 0; i < kc; ++i) pairs += hp[8 * i + 7];
+        if (pairs * 16 < kc * B) c->pair_pause = 32;        // fewer than B / 16 accepted pairs per step: not worth its plan
+    }
     if (getenv("ORX_PLAN_DEBUG") != nullptr && kc > 0)
         fprintf(stderr, "[orx plan] steps %lld..%lld: step %lld has %d duplicated rows left for the apply, %d accepted pairs, %d staged references\n",
                 (long long)i0, (long long)(i0 + kc - 1), (long long)i0, hp[5] - hp[7], hp[7], hp[1]);
@@ -731,7 +736,7 @@ int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
         // work that does not depend on the counters goes to the device before the host blocks on them (the first fused launch
         // of the chunk: the device would otherwise idle through the host's wake-up and the first launch's latency)
         CHECK(orx_exact_plan_issue(c, U, V, uid, pid, nid, ds, nU, nP, nN, kc, B, inline_apply, staging, plan, 0, c->plan_ev, while_waiting));
-        return orx_exact_plan_finish(c, kc, B, inline_apply, staging, 0, c->plan_ev, out);
+        return orx_exact_plan_finish(c, kc, B, inline_apply, staging, 0, c->plan_ev, out, plan.pair_tpw > 1);
     }
     // duplicate detection for every step of the chunk, on the id arrays alone
     DedupArgs d;
@@ -778,17 +783,15 @@ void orx_exact_step_views(orx_ctx* c, const PairPlan& plan, int64_t i, int64_t B
     }
 }
 
-// pairing (kernels_plan.hip): SGD / Adagrad on the float4 dims with >= 2 triplets per wavefront, bucketed plan
+// pairing (kernels_plan.hip): SGD on the float4 dims with >= 2 triplets per wavefront, bucketed plan
 // (ORX_FORCE_FALLBACK bit 4 / ORX_NO_PAIR=1: off)
 static bool pairing_wanted(int mode, bool role_bits, int optkind, int dim, int64_t B, int fb) {
-    return mode == MODE_EXACT && orx_plan_v2(role_bits) && optkind != ORX_ADAM && orx_fused_tpw(dim) > 1 && B >= 2 && B <= (1 << 22) && !(fb & 16) &&
+    return mode == MODE_EXACT && orx_plan_v2(role_bits) && optkind == ORX_SGD && orx_fused_tpw(dim) > 1 && B >= 2 && B <= (1 << 22) && !(fb & 16) &&
            getenv("ORX_NO_PAIR") == nullptr;
 }
 static int pairing_buffers(orx_ctx* c, int64_t B, int dim, PairPlan* plan) {
-    ENSURE(c->d_pinfo, c->d_pinfo_cap, (size_t)plan->cap * B * sizeof(uint32_t));
-    ENSURE(c->d_partner, c->d_partner_cap, (size_t)plan->cap * 3 * plan->Bp * sizeof(int));
-    ENSURE(c->d_pslot, c->d_pslot_cap, (size_t)plan->cap * plan->list_stride * sizeof(int));
-    ENSURE(c->d_perm, c->d_perm_cap, (size_t)plan->cap * B * sizeof(int));
+    ENSURE(c->d_partner, c->d_partner_cap, (size_t)plan->cap * B * sizeof(int4));
+    ENSURE(c->d_pslot, c->d_pslot_cap, (size_t)plan->cap * 2 * plan->list_stride * sizeof(int));
     ENSURE(c->d_ids4, c->d_ids4_cap, (size_t)plan->cap * B * sizeof(int4));
     plan->pair_tpw = orx_fused_tpw(dim);
     return ORX_OK;
@@ -866,7 +869,13 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     if (opt->kind == ORX_ADAM) plan.min_late = 1;
     // pairing (kernels_plan.hip): the two triplets of a row referenced exactly twice share a wavefront and exchange gradients there
     // (SGD / Adagrad on the float4 dims with >= 2 triplets per wavefront; fb bit 4 / ORX_NO_PAIR=1: off)
-    if (pairing_wanted(mode, role_bits, opt->kind, U->dim, B, fb)) CHECK(pairing_buffers(c, B, U->dim, &plan));
+    // The pairing plan costs ~1.5 us per step (records, decisions, the packed input); it pays where a good share of the batch pairs
+    // (uniform ids over tables ~ 10 x the batch: 11 %).  Tables so small that most duplicated rows have three or more references, or
+    // ids so skewed that the hot rows take them, pair little: the plan of a call tells (accepted pairs per step), and pairing then
+    // pauses for 32 calls before it is tried again.  ORX_PAIR_ALWAYS=1: no pause.
+    const bool pair_ok = pairing_wanted(mode, role_bits, opt->kind, U->dim, B, fb);
+    if (pair_ok && c->pair_pause > 0) c->pair_pause -= 1;
+    else if (pair_ok) CHECK(pairing_buffers(c, B, U->dim, &plan));
 
     PairArgs a;
     memset(&a, 0, sizeof(a));
@@ -929,6 +938,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             return orx_launch_fused(c, model, opt->kind, mode, a);
         };
         bool first_launched = false;
+        bool tail_done = false;             // the chunk's loss sums left with the last step's duplicate apply
         // ---- the plan of the chunk, optionally in PIECES (bucketed plan, in-launch apply): piece 0 (6 steps) is planned on the step
         // stream, every later piece (4x the previous one) on a second stream while the steps of the piece before it run -- the fused
         // launches of a K-step call then start ~45 us after the call instead of after the plan of all K steps (110 us at K = 20,
@@ -960,7 +970,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             if (pipe) {
                 CHECK(orx_exact_plan_issue(c, U, V, du + s0 * ds, dp + s0 * ds, dn + s0 * ds, ds, B, B, B, pc_hi[0], B, inline_apply, staging, plan, 0,
                                            c->plan_ev, can_early ? &early : nullptr));
-                CHECK(orx_exact_plan_finish(c, pc_hi[0], B, inline_apply, staging, 0, c->plan_ev, &pck[0]));
+                CHECK(orx_exact_plan_finish(c, pc_hi[0], B, inline_apply, staging, 0, c->plan_ev, &pck[0], plan.pair_tpw > 1));
             } else {
                 CHECK(orx_exact_plan_chunk(c, U, V, du + s0 * ds, dp + s0 * ds, dn + s0 * ds, ds, B, B, B, kc, B, role_bits, inline_apply, staging,
                                            plan, &pck[0], can_early ? &early : nullptr));
@@ -1007,7 +1017,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
                 bool inl_next = inl_j;                         // is step i + 1 launched with apply blocks for step i's rows?
                 if (i == hi - 1 && j + 1 < npc) {
                     // the last step of a piece: the next piece's counters decide (its plan has had the whole piece to finish)
-                    CHECK(orx_exact_plan_finish(c, pc_hi[j + 1] - pc_lo[j + 1], B, inline_apply, staging, pc_lo[j + 1], c->pipe_cnt[(j + 1) & 1], &pck[j + 1]));
+                    CHECK(orx_exact_plan_finish(c, pc_hi[j + 1] - pc_lo[j + 1], B, inline_apply, staging, pc_lo[j + 1], c->pipe_cnt[(j + 1) & 1], &pck[j + 1], plan.pair_tpw > 1));
                     inl_next = inl_j && piece_inl(j + 1);
                 }
                 const bool defer = mode == MODE_EXACT && inl_next && i < kc - 1;      // step i's duplicated rows wait for launch i + 1
@@ -1018,7 +1028,16 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
                     CHECK(launch_step(i, sv, prev_deferred));
                 }
                 for (int l = 0; l < tree_levels; ++l) CHECK(orx_launch_hot_reduce(c, a, l));
-                if (mode == MODE_EXACT && !defer) CHECK(orx_launch_dup_apply(c, opt->kind, a));
+                if (mode == MODE_EXACT && !defer) {
+                    // the chunk's last step: its duplicated rows and the chunk's loss sums leave in ONE launch where that is possible
+                    if (i == kc - 1 && !censor && !lazy_adam) {
+                        ReduceArgs r;
+                        r.partial = c->d_partial; r.out = c->d_loss + 2 * s0; r.nwaves = nw;
+                        int rc = ORX_OK;
+                        if (orx_launch_tail(c, opt->kind, a, r, kc, &rc)) { CHECK(rc); tail_done = true; }
+                    }
+                    if (!tail_done) CHECK(orx_launch_dup_apply(c, opt->kind, a));
+                }
                 if (mode == MODE_ACCUM) {   // Adam: dense-decay sweep of TF 2.0 over the whole tables
                     opt->t += 1;
                     const double b1 = opt->p0, b2 = opt->p1;
@@ -1036,9 +1055,11 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
                 }
             }
         }
-        ReduceArgs r;
-        r.partial = c->d_partial; r.out = c->d_loss + 2 * s0; r.nwaves = nw;
-        CHECK(orx_launch_loss_reduce(c, r, kc));
+        if (!tail_done) {
+            ReduceArgs r;
+            r.partial = c->d_partial; r.out = c->d_loss + 2 * s0; r.nwaves = nw;
+            CHECK(orx_launch_loss_reduce(c, r, kc));
+        }
     }
     CHECK(fetch_losses(c, K, loss_out, l2_out));
     if (!(flags & ORX_IDS_DEVICE)) return orx_check_index_error(c);

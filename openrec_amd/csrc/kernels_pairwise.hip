@@ -420,9 +420,9 @@ int orx_launch_urgent(orx_ctx* ctx, const DedupArgs& a, int64_t K) {
 
 // -------------------------------------------------- loss partial reduction ---
 // One block per step: sum nwaves x {loss, l2} fp32 partials in fp64.
-__global__ __launch_bounds__(1024) void loss_reduce_kernel(ReduceArgs a) {
+__device__ __forceinline__ void loss_reduce_body(const ReduceArgs& a, int step) {
     __shared__ double sh[2][16];
-    const float* part = a.partial + (size_t)blockIdx.x * a.nwaves * 2;
+    const float* part = a.partial + (size_t)step * a.nwaves * 2;
     double s0 = 0.0, s1 = 0.0;
     constexpr int UN = 8;                                    // 8 independent loads in flight per thread (the pass is latency-bound)
     for (int i0 = threadIdx.x; i0 < a.nwaves; i0 += UN * blockDim.x) {
@@ -445,10 +445,12 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(ReduceArgs a) {
     if (threadIdx.x == 0) {
         double t0 = 0.0, t1 = 0.0;
         for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { t0 += sh[0][k]; t1 += sh[1][k]; }
-        a.out[2 * blockIdx.x] = t0;
-        a.out[2 * blockIdx.x + 1] = t1;
+        a.out[2 * step] = t0;
+        a.out[2 * step + 1] = t1;
     }
 }
+
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(ReduceArgs a) { loss_reduce_body(a, (int)blockIdx.x); }
 
 int orx_launch_loss_reduce(orx_ctx* ctx, const ReduceArgs& a, int64_t K) {
     ProfScope ps(ctx, ORX_K_REDUCE);
@@ -465,10 +467,10 @@ template <int LPR, int MODEL, int OPT, int MODE, bool CENSOR = false, bool STAGE
 __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
-    __shared__ f4 pair_xg[(MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) ? 256 : 1];            // pairing: gradient exchange, one slot per lane
-    __shared__ float pair_xb[(MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) ? 256 / LPR : 1];   // ... and per lane group (item bias)
-    __shared__ f4 pair_xw[(MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) ? 256 : 1];            // the writer's copy of the shared row as read
-    __shared__ float pair_xwb[(MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1) ? 256 / LPR : 1];
+    __shared__ f4 pair_xg[(MODE == MODE_EXACT && OPT == ORX_SGD && TPW > 1) ? 256 : 1];            // pairing: gradient exchange, one slot per lane
+    __shared__ float pair_xb[(MODE == MODE_EXACT && OPT == ORX_SGD && TPW > 1) ? 256 / LPR : 1];   // ... and per lane group (item bias)
+    __shared__ f4 pair_xw[(MODE == MODE_EXACT && OPT == ORX_SGD && TPW > 1) ? 256 : 1];            // the writer's copy of the shared row as read
+    __shared__ float pair_xwb[(MODE == MODE_EXACT && OPT == ORX_SGD && TPW > 1) ? 256 / LPR : 1];
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
@@ -481,7 +483,9 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     const int64_t stride = (int64_t)(gridDim.x - nab) * 4 * TPW;
     float loss_acc = 0.0f, sq_acc = 0.0f;
 
-    constexpr bool PAIRS = MODE == MODE_EXACT && OPT != ORX_ADAM && TPW > 1;
+    // (SGD only: the Adagrad instantiation is register-bound -- 111 VGPRs with the pairing tail against 90 without, a wavefront of
+    // occupancy -- and measured no faster with pairs than without)
+    constexpr bool PAIRS = MODE == MODE_EXACT && OPT == ORX_SGD && TPW > 1;
     for (int64_t t = wave_global * TPW + grp; t < a.B; t += stride) {
         // ids as rewritten by the plan: bit 31 = "row is referenced more than once", bits 30:29 = role of this reference among the row's
         // references (0 / 1 = plain store into scratch row 1 / 2, 2 = atomics or staging slot, 3 = no store: pairing), bit 28 = urgent.
@@ -732,15 +736,16 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
 
 // dup_apply: one group of LPR lanes per duplicated row of the step.
 template <int LPR, int OPT>
-__global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
+__device__ __forceinline__ void dup_apply_body(const PairArgs& a, int block, int nblocks) {
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
     const int n = *a.dcount;
-    const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
-    for (int64_t e = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + grp; e < n; e += stride) {
+    const int wpb = (int)(blockDim.x >> 6);             // wavefronts per block (256 or 1024 threads)
+    const int64_t stride = (int64_t)nblocks * wpb * TPW;
+    for (int64_t e = ((int64_t)block * wpb + (threadIdx.x >> 6)) * TPW + grp; e < n; e += stride) {
         const uint32_t ent = a.dlist[e];
         if (ent == ORX_DLIST_DEAD) continue;            // (the row was paired after all: updated in place by the step's launch)
         const bool item = (ent >> 31) != 0;
@@ -810,6 +815,18 @@ __global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) {
             }
         }
     }
+}
+
+template <int LPR, int OPT>
+__global__ __launch_bounds__(256) void dup_apply_kernel(PairArgs a) { dup_apply_body<LPR, OPT>(a, (int)blockIdx.x, (int)gridDim.x); }
+
+// The tail of a K-step call in ONE launch: the duplicated rows of the last step (what dup_apply_kernel does) and, in the first
+// `nred` blocks, the per-step sums of the loss partials (what loss_reduce_kernel does) -- two launches and the gap between them
+// fewer at the end of every call.
+template <int LPR, int OPT>
+__global__ __launch_bounds__(1024) void tail_kernel(PairArgs a, ReduceArgs r, int nred) {
+    if ((int)blockIdx.x < nred) { loss_reduce_body(r, (int)blockIdx.x); return; }
+    dup_apply_body<LPR, OPT>(a, (int)blockIdx.x - nred, (int)gridDim.x - nred);
 }
 
 // hot_reduce: one level of the reduction tree over long staging segments.  One wavefront per work
@@ -1105,6 +1122,30 @@ int orx_launch_hot_reduce(orx_ctx* ctx, const PairArgs& a, int level) {
     }
     ORX_HIP(hipGetLastError());
     return ORX_OK;
+}
+
+// dup_apply of the call's last step + loss_reduce of its K steps in one launch (float4 dims; SGD / Adagrad); false: not applicable
+bool orx_launch_tail(orx_ctx* ctx, int optkind, const PairArgs& a, const ReduceArgs& r, int64_t K, int* rc) {
+    const int lpr = lpr_for_dim(a.D);
+    if (lpr == 0 || optkind == ORX_ADAM || K > 4096) return false;
+    ProfScope ps(ctx, ORX_K_DUPAPPLY);
+    int64_t want = (a.B * 3 / 16) / (16 * (64 / lpr)) + 1;      // (1024-thread blocks: the loss sums want them)
+    if (want > 512) want = 512;
+    if (want < 16) want = 16;
+    const dim3 g((unsigned)(want + K));
+#define ORX_TL(L) do { if (optkind == ORX_ADAGRAD) ORX_LAUNCH(ctx, (tail_kernel<L, ORX_ADAGRAD>), g, dim3(1024), 0, a, r, (int)K); \
+                       else ORX_LAUNCH(ctx, (tail_kernel<L, ORX_SGD>), g, dim3(1024), 0, a, r, (int)K); } while (0)
+    switch (lpr) {
+        case 4: ORX_TL(4); break;
+        case 8: ORX_TL(8); break;
+        case 16: ORX_TL(16); break;
+        case 32: ORX_TL(32); break;
+        default: ORX_TL(64); break;
+    }
+#undef ORX_TL
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { orx_set_error("tail_kernel launch failed: %s", hipGetErrorString(e)); *rc = ORX_ERR_HIP; } else *rc = ORX_OK;
+    return true;
 }
 
 // The number of duplicated rows lives in device memory: fixed grid, grid-stride loop.

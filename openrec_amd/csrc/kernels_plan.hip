@@ -71,6 +71,11 @@ __device__ __forceinline__ bool plan_ref(const PlanArgs& a, int64_t s, int64_t j
     return id_ok(id, is_user ? d.NU : d.NI);
 }
 
+// Workgroup barrier that orders LDS traffic only: global loads and returning atomics already in flight stay in flight across it (the
+// compiler waits for their registers where they are used).  __syncthreads() drains vmcnt too -- in kernels that are chains of
+// dependent global round trips that serializes what could overlap.  NOT for handing GLOBAL data from one wavefront to another.
+__device__ __forceinline__ void pl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // exclusive prefix sum of one int per thread over the PL_THREADS-thread workgroup; `total` = sum
 template <int T = PL_THREADS>
 __device__ __forceinline__ int plan_scan_excl(int v, int* wave_tot, int& total) {
@@ -79,11 +84,11 @@ __device__ __forceinline__ int plan_scan_excl(int v, int* wave_tot, int& total) 
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
     if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
+    pl_lds_barrier();
     int before = 0, all = 0;
 #pragma unroll
     for (int k = 0; k < T / 64; ++k) { const int t = wave_tot[k]; if (k < wave) before += t; all += t; }
-    __syncthreads();
+    pl_lds_barrier();
     total = all;
     return before + incl - v;
 }
@@ -115,10 +120,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_part_kernel(PlanArgs a) {
             // a scattered 4-byte store costs a memory transaction of its own.  0x7fffffff: out-of-range id, never a valid row
             if (SCATTER) {
                 a.d.ids_out[s * a.d.flag_stride + pos] = ok ? id : 0x7fffffff;
-                if (a.d.pair_tpw > 1) {          // pairing: no reference has a partner yet, no triplet a pairing word, every triplet is where it stands
-                    a.d.partner[s * a.d.flag_stride + pos] = -1;
-                    if (j < a.d.pair_stride) { a.d.pinfo[s * a.d.pair_stride + j] = 0u; a.d.perm[s * a.d.pair_stride + j] = (int)j; }
-                }
+                // pairing: one 16-byte record per triplet -- no reference has a partner yet (x, y, z = -1), no pairing word and the
+                // triplet is processed where it stands (w = position << 10)
+                if (a.d.pair_tpw > 1 && j < a.d.pair_stride) a.d.partner[s * a.d.pair_stride + j] = make_int4(-1, -1, -1, (int)((uint32_t)j << 10));
             }
         }
     }
@@ -229,6 +233,8 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
     const int bl = is_user ? b : b - a.nru;
     const int* cnt = a.bcnt + s * (3 * nb + 1) + 2 * nb;
     PL_STAMP(0);
+    // (the step's counts and cursors have served plan_part_kernel: they go back to zero for the next plan, see orx_launch_plan)
+    if (b == 0) for (int i = threadIdx.x; i < 2 * nb; i += T) a.bcnt[s * (3 * nb + 1) + i] = 0;
     const int lo = cnt[b], n = cnt[b + 1] - lo;
     int2* ent = a.list + s * a.nref + lo;
     unsigned int* dupout = a.dupbits ? a.dupbits + ((size_t)s * nb + b) * W : nullptr;
@@ -239,13 +245,21 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
     }
     int32_t* ids_out = d.ids_out + s * d.flag_stride;
     int2* refinfo = d.refinfo ? d.refinfo + s * d.flag_stride : nullptr;
+    // The usual range (<= PL_UN entries per thread) keeps its entries in registers: they are requested before the LDS is zeroed and
+    // serve both passes (one global round trip instead of three: load, role write-back, reload).
+    const bool small = n <= PL_UN * T;
+    int2 er[PL_UN];
+    if (small) {
+#pragma unroll
+        for (int k = 0; k < PL_UN; ++k) { const int i = threadIdx.x + k * T; if (i < n) er[k] = ent[i]; }
+    }
     for (int i = threadIdx.x; i < 3 * W; i += T) pl_lds[i] = 0u;
     if (threadIdx.x == 0) { sh_late = 0; list_cnt = 0; }
-    __syncthreads();
+    pl_lds_barrier();
     PL_STAMP(1);
     // pass 1: bitmaps; the role of a reference among its row's references (first / second / later, by arrival)
     int late = 0;
-    pl_for_each<T>(ent, n, [&](int i, int2 e) {
+    auto pass1 = [&](int2 e) -> int {
         const int l = e.x >> lg;
         const unsigned int bit = 1u << (l & 31);
         // the bitmaps only gain bits: a plain read that already shows the bit decides like the atomic would (a hot row
@@ -262,11 +276,35 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
                 role = 2; ++late;
             }
         }
-        if (role) ent[i].y = (int)((uint32_t)e.y | ((uint32_t)role << 30));       // (read back by the same thread in pass 2)
-    });
+        return role;
+    };
+    if (small) {
+#pragma unroll
+        for (int k = 0; k < PL_UN; ++k) {
+            const int i = threadIdx.x + k * T;
+            if (i < n) er[k].y = (int)((uint32_t)er[k].y | ((uint32_t)pass1(er[k]) << 30));
+        }
+    } else {
+        pl_for_each<T>(ent, n, [&](int i, int2 e) {
+            const int role = pass1(e);
+            if (role) ent[i].y = (int)((uint32_t)e.y | ((uint32_t)role << 30));       // (read back by the same thread in pass 2)
+        });
+    }
     if (refinfo != nullptr && late) atomicAdd(&sh_late, late);
-    __syncthreads();
+    pl_lds_barrier();
     PL_STAMP(2);
+    // The bitmaps are final: the range's share of the step's list of duplicated rows is allocated NOW -- the returning atomic is in
+    // flight through pass 2 and is only looked at where the list is written.
+    int mine = 0;
+    for (int w = threadIdx.x; w < W; w += T) mine += __popc(dup[w]);
+    int off = 0;
+    if (mine) off = atomicAdd(&list_cnt, mine);
+    pl_lds_barrier();
+    int list_base_r = 0;
+    if (threadIdx.x == 0 && list_cnt) {
+        list_base_r = atomicAdd(d.dcount + s, list_cnt);
+        atomicAdd(d.alloc + 8 * s + 5, list_cnt);      // (the host reads the allocators only: one copy)
+    }
     // staging plan where atomics would pile up: ranges with at least max(64, n / 512) third-or-later references
     const bool plan = refinfo != nullptr && sh_late >= (a.min_late < 0 ? (n / 512 > 64 ? n / 512 : 64) : a.min_late);
     int ntri = 0, dense0 = 0;
@@ -304,12 +342,12 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
         if (ndup2) {
             for (int w = w0; w < w0 + per && w < W; ++w) { dprefix16[w] = (unsigned short)pre; pre += __popc(dup[w] & ~tri[w]); }
             for (int i = threadIdx.x; i < 2 * ndup2; i += T) pairpos[i] = -1;
-            __syncthreads();
+            pl_lds_barrier();
         }
     }
     PL_STAMP(3);
     // pass 2: rewritten ids, (dense row, rank) of the references that stage
-    pl_for_each<T>(ent, n, [&](int, int2 e) {
+    auto pass2 = [&](int2 e) {
         const int l = e.x >> lg;
         const int pos = e.y & 0x3fffffff;
         const unsigned int dw = dup[l >> 5];
@@ -333,18 +371,26 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
             }
             ids_out[pos] = (int32_t)v;
         }
-    });
+    };
+    if (small) {
+#pragma unroll
+        for (int k = 0; k < PL_UN; ++k) { const int i = threadIdx.x + k * T; if (i < n) pass2(er[k]); }
+    } else {
+        pl_for_each<T>(ent, n, [&](int, int2 e) { pass2(e); });
+    }
     PL_STAMP(4);
     if (ndup2) {
         // pairing: the two references of a row referenced exactly twice learn where the other one sits (partner[], read by
         // plan_pair_kernel, which decides about the row: the rewritten ids of both, its list entry and its bit in the duplicate
-        // bitmap are that kernel's) -- here the row leaves this range's bitmap
-        __syncthreads();
-        int* partner = d.partner + s * d.flag_stride;
+        // bitmap are that kernel's)
+        pl_lds_barrier();
+        int* partner = reinterpret_cast<int*>(d.partner + s * d.pair_stride);      // record of triplet t, slot k: word 4 t + k
+        const int Bp = (int)d.role_stride;
         for (int k = threadIdx.x; k < ndup2; k += T) {
             const int posA = pairpos[2 * k], posB = pairpos[2 * k + 1];
-            partner[posA] = posB;                           // (bit 30 clear: the row's first reference, which owns the decision)
-            partner[posB] = posA | (1 << 30);
+            const int sa = (posA >= Bp ? 1 : 0) + (posA >= 2 * Bp ? 1 : 0), sb = (posB >= Bp ? 1 : 0) + (posB >= 2 * Bp ? 1 : 0);
+            partner[4 * (posA - sa * Bp) + sa] = posB;                           // (bit 30 clear: the row's first reference, which owns the decision)
+            partner[4 * (posB - sb * Bp) + sb] = posA | (1 << 30);
         }
     }
     PL_STAMP(5);
@@ -364,18 +410,10 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
         for (int k = d0; k < d0 + per && k < ntri; ++k) { segstart[dense0 + k] = run; run += pl_cnt(lcnt + k); }
         __syncthreads();                               // list emission below reads segstart of other threads' rows (agent-scope loads)
     }
-    // append the duplicated rows of this range to the step's list
-    int mine = 0;
-    for (int w = threadIdx.x; w < W; w += T) mine += __popc(dup[w]);
-    int off = 0;
-    if (mine) off = atomicAdd(&list_cnt, mine);
-    __syncthreads();
+    // append the duplicated rows of this range to the step's list (allocated after pass 1)
     PL_STAMP(6);
-    if (threadIdx.x == 0) {
-        list_base = list_cnt ? atomicAdd(d.dcount + s, list_cnt) : 0;
-        if (list_cnt) atomicAdd(d.alloc + 8 * s + 5, list_cnt);      // (the host reads the allocators only: one copy)
-    }
-    __syncthreads();
+    if (threadIdx.x == 0) list_base = list_base_r;
+    pl_lds_barrier();
     PL_STAMP(7);
     if (mine) {
         int64_t e = s * d.list_stride + list_base + off;
@@ -391,12 +429,12 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
                     // a row referenced exactly twice: the entry is reserved; plan_pair_kernel, which gets the position of the row's
                     // first reference here, fills it (the row, or ORX_DLIST_DEAD) and the pair record behind it
                     const int dn2 = (int)dprefix16[w] + __popc(m0 & ~tw & ((1u << bpos) - 1u));
-                    d.pslot[e] = pairpos[2 * dn2];
+                    reinterpret_cast<int2*>(d.pslot)[e] = make_int2(pairpos[2 * dn2], pairpos[2 * dn2 + 1]);
                     if (d.dcnt != nullptr) { d.dseg[e] = 0; d.dcnt[e] = 0; }
                     ++e;
                     continue;
                 }
-                if (d.pair_tpw > 1) d.pslot[e] = -1;       // (not a row plan_pair_kernel decides about)
+                if (d.pair_tpw > 1) reinterpret_cast<int2*>(d.pslot)[e] = make_int2(-1, -1);       // (not a row plan_pair_kernel decides about)
                 d.dlist[e] = (uint32_t)((((int64_t)w * 32 + bpos) << lg) | bl) | tag;
                 if (d.dcnt != nullptr) {
                     int c = 0, sg = 0;
@@ -467,47 +505,56 @@ __global__ __launch_bounds__(256) void plan_pair_kernel(PlanArgs a) {
     const DedupArgs& d = a.d;
     const int64_t s = blockIdx.y;
     const int B = (int)d.pair_stride, Bp = (int)d.role_stride, tpw = d.pair_tpw;
-    const int* part = d.partner + s * d.flag_stride;
+    const int4* part = d.partner + s * d.pair_stride;      // per triplet: where the partner of slot 0 / 1 / 2 sits (-1: none), w: its pairing word
+    int* pword = reinterpret_cast<int*>(d.partner + s * d.pair_stride) + 3;       // ... which is this kernel's to write (word 4 t + 3)
     int32_t* ids = d.ids_out + s * d.flag_stride;
-    int* perm = d.perm + s * d.pair_stride;
-    uint32_t* pinfo = d.pinfo + s * d.pair_stride;
     const int nb = a.nru + a.nri, W = (1 << a.shift) >> 5;
     const int n = d.dcount[s];
     auto slot_of = [&](int pos) { return (pos >= Bp ? 1 : 0) + (pos >= 2 * Bp ? 1 : 0); };
-    // is slot sy the choice of triplet y?  (no earlier slot of y references a row of this kind)
-    auto chooses = [&](int y, int sy) { bool ok = true; for (int k = 0; k < sy; ++k) ok = ok && part[k * Bp + y] < 0; return ok; };
-    // is position x part of a mutual pair (its choice's partner chooses it back)?  positions outside the batch count as taken
-    auto in_pair = [&](int x) {
-        if (x >= B) return true;
-        const int p0 = part[x], p1 = part[Bp + x], p2 = part[2 * Bp + x];
-        const int sx = p0 >= 0 ? 0 : (p1 >= 0 ? 1 : (p2 >= 0 ? 2 : -1));
-        if (sx < 0) return false;
-        const int pp = (sx == 0 ? p0 : (sx == 1 ? p1 : p2)) & 0x3fffffff;
-        const int sy = slot_of(pp), y = pp - sy * Bp;
-        return y != x && chooses(y, sy);
-    };
+    // the choice of a triplet from its record: its first slot with a partner (-1: none)
+    auto choice = [](int4 r) { return r.x >= 0 ? 0 : (r.y >= 0 ? 1 : (r.z >= 0 ? 2 : -1)); };
+    auto word = [](int4 r, int k) { return k == 0 ? r.x : (k == 1 ? r.y : r.z); };
+    const int4 none = make_int4(-1, -1, -1, 0);
     int npair = 0;
+    // Two dependent levels of 16-byte record loads after the entry's two positions: the records of both triplets and of both buddies
+    // (a buddy's record shares its triplet's 32 bytes); then the records of the buddies' partners.
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         const int64_t eg = s * d.list_stride + e;
-        const int posA = d.pslot[eg];
+        const int2 ab = reinterpret_cast<const int2*>(d.pslot)[eg];
+        const int posA = ab.x, posB = ab.y;
         if (posA < 0) continue;                             // (a row with three or more references: plan_range_kernel's)
-        const int posB = part[posA] & 0x3fffffff;
         const int sa = slot_of(posA), sb = slot_of(posB);
         const int ta = posA - sa * Bp, tb = posB - sb * Bp;
+        const int lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+        const int bl = lo ^ 1, bh = hi ^ 1;                 // the buddies
+        const bool same = (lo & ~(tpw - 1)) == (hi & ~(tpw - 1));
+        const bool needq = ta != tb && !same;
+        const int4 ra = part[ta], rb = part[tb];
+        const int4 rl = (needq && bl < B) ? part[bl] : none, rh = (needq && bh < B) ? part[bh] : none;
+        // the row is the choice of both its triplets
+        const bool mutual = (ta != tb) & (choice(ra) == sa) & (choice(rb) == sb);
+        // is a buddy in a mutual pair of its own?  its choice's partner y must choose it back
+        const int cl = choice(rl), ch = choice(rh);
+        const int ppl = word(rl, cl) & 0x3fffffff, pph = word(rh, ch) & 0x3fffffff;
+        const int syl = slot_of(ppl), syh = slot_of(pph);
+        const int yl = ppl - syl * Bp, yh = pph - syh * Bp;
+        const int4 ryl = (cl >= 0 && yl != bl) ? part[yl] : none, ryh = (ch >= 0 && yh != bh) ? part[yh] : none;
+        const bool lo_taken = bl >= B || (cl >= 0 && yl != bl && choice(ryl) == syl);
+        const bool hi_taken = bh >= B || (ch >= 0 && yh != bh && choice(ryh) == syh);
         bool acc = false;
         int stay = 0, mover = 0, q = 0;
-        if (ta != tb && chooses(ta, sa) && chooses(tb, sb)) {
-            const int lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
-            if ((lo & ~(tpw - 1)) == (hi & ~(tpw - 1))) { acc = true; stay = lo; mover = hi; q = hi; }
-            else if (!in_pair(lo ^ 1)) { acc = true; stay = lo; mover = hi; q = lo ^ 1; }
-            else if (!in_pair(hi ^ 1)) { acc = true; stay = hi; mover = lo; q = hi ^ 1; }
+        if (mutual) {
+            if (same) { acc = true; stay = lo; mover = hi; q = hi; }
+            else if (!lo_taken) { acc = true; stay = lo; mover = hi; q = bl; }
+            else if (!hi_taken) { acc = true; stay = hi; mover = lo; q = bh; }
         }
         if (acc) {
             d.dlist[eg] = ORX_DLIST_DEAD;
-            if (q != mover) { perm[q] = mover; perm[mover] = q; }
+            // position q processes the mover (and the mover's position the triplet that stood at q); the pairing words of the two positions
             const uint32_t s_stay = (uint32_t)(stay == ta ? sa : sb), s_mov = (uint32_t)(stay == ta ? sb : sa), m = (uint32_t)tpw - 1u;
-            pinfo[stay] = ORX_PAIR_VALID | ORX_PAIR_WRITER | ((uint32_t)q & m) | (s_stay << 4) | (s_mov << 6);
-            pinfo[q] = ORX_PAIR_VALID | ((uint32_t)stay & m) | (s_mov << 4) | (s_stay << 6);
+            pword[4 * stay] = (int)(ORX_PAIR_VALID | ORX_PAIR_WRITER | ((uint32_t)q & m) | (s_stay << 4) | (s_mov << 6) | ((uint32_t)stay << 10));
+            pword[4 * q] = (int)(ORX_PAIR_VALID | ((uint32_t)stay & m) | (s_mov << 4) | (s_stay << 6) | ((uint32_t)mover << 10));
+            if (q != mover) pword[4 * mover] = (int)((uint32_t)q << 10);
             npair += 1;
         } else {
             const uint32_t id = (uint32_t)ids[posA];
@@ -535,21 +582,30 @@ __global__ __launch_bounds__(256) void plan_pair_kernel(PlanArgs a) {
 // triplet's original position (its staging records stay where they were).  Runs after plan_urgent_kernel.
 __global__ __launch_bounds__(256) void plan_pack_kernel(DedupArgs d) {
     const int64_t s = blockIdx.y;
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= d.pair_stride) return;
-    const int src = d.perm[s * d.pair_stride + j];
     const int32_t* ids = d.ids_out + s * d.flag_stride;
     const int64_t Bp = d.role_stride;
-    int4 v;
-    v.x = ids[src]; v.y = ids[Bp + src]; v.z = ids[2 * Bp + src];
-    v.w = (int)(d.pinfo[s * d.pair_stride + j] | ((uint32_t)src << 10));
-    d.ids4[s * d.pair_stride + j] = v;
+    constexpr int R = 4;                                 // positions per thread: four independent chains perm -> ids in flight
+    int src[R]; uint32_t pw[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int64_t j = ((int64_t)blockIdx.x * R + k) * 256 + threadIdx.x;
+        pw[k] = j < d.pair_stride ? (uint32_t)reinterpret_cast<const int*>(d.partner + s * d.pair_stride)[4 * j + 3] : 0u;
+        src[k] = (int)(pw[k] >> 10);
+    }
+    int4 v[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { v[k].x = ids[src[k]]; v[k].y = ids[Bp + src[k]]; v[k].z = ids[2 * Bp + src[k]]; v[k].w = (int)pw[k]; }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int64_t j = ((int64_t)blockIdx.x * R + k) * 256 + threadIdx.x;
+        if (j < d.pair_stride) d.ids4[s * d.pair_stride + j] = v[k];
+    }
 }
 
 int orx_launch_plan_pack(orx_ctx* ctx, const DedupArgs& d, int64_t kc) {
     if (d.pair_tpw < 2 || kc <= 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_DEDUP);
-    ORX_LAUNCH(ctx, plan_pack_kernel, dim3((unsigned)((d.pair_stride + 255) / 256), (unsigned)kc), dim3(256), 0, d);
+    ORX_LAUNCH(ctx, plan_pack_kernel, dim3((unsigned)((d.pair_stride + 1023) / 1024), (unsigned)kc), dim3(256), 0, d);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -629,7 +685,12 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
     }
     const char* ml = getenv("ORX_PLAN_MIN_LATE");      // experiments
     a.min_late = ml ? atoi(ml) : d.min_late;
-    ORX_HIP(hipMemsetAsync(a.bcnt, 0, (size_t)kc * (3 * nb + 1) * sizeof(int), ctx->stream));
+    // The counts and cursors of a step are zeroed again by plan_range_kernel once the scatter has used them: no memset (a launch and
+    // a gap at the head of every call) unless the buffer is new or was last used with another number of ranges per step.
+    if (ctx->pl_cnt_clean != ctx->d_pl_cnt || ctx->pl_cnt_clean_cap != ctx->d_pl_cnt_cap || ctx->pl_cnt_nb != nb) {
+        ORX_HIP(hipMemsetAsync(ctx->d_pl_cnt, 0, ctx->d_pl_cnt_cap, ctx->stream));
+        ctx->pl_cnt_clean = ctx->d_pl_cnt; ctx->pl_cnt_clean_cap = ctx->d_pl_cnt_cap; ctx->pl_cnt_nb = nb;
+    }
     const dim3 gp((unsigned)((a.nref + PL_CHUNK - 1) / PL_CHUNK), (unsigned)kc);
     const size_t hist_bytes = (size_t)(3 * nb + 1) * sizeof(int);
     ORX_ONCE_PER_DEVICE(ctx, ORX_HIP(hipFuncSetAttribute((const void*)plan_part_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)));

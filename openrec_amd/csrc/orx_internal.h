@@ -58,13 +58,13 @@ struct orx_ctx {
     unsigned int* d_dupbits = nullptr; size_t d_dupbits_cap = 0; // [K][buckets][words] duplicate bitmaps
     // bucketed plan (kernels_plan.hip): references per (step, row range), scatter cursors, bucket lists
     int* d_pl_cnt = nullptr;   size_t d_pl_cnt_cap = 0;          // [K][3 ranges + 1]: counts, cursors, offsets
+    const void* pl_cnt_clean = nullptr; size_t pl_cnt_clean_cap = 0; int pl_cnt_nb = -1;      // the buffer (and ranges per step) whose counts and cursors are all zero between plans
     int2* d_pl_list = nullptr; size_t d_pl_list_cap = 0;         // [K][references per step] (id, output position | role << 30)
     bool plan_big = false;                                       // the last plan met a bucket of > 16 k references: 1024-thread workgroups
+    int pair_pause = 0;                                          // pairing: calls left before it is tried again (the last plan that paired accepted too few rows to pay for itself)
     // pairing (kernels_plan.hip, "pairing"): the two references of a row referenced exactly twice are brought into one wavefront
-    uint32_t* d_pinfo = nullptr; size_t d_pinfo_cap = 0;         // [K][B] per-triplet pairing word read by the fused kernel (0: not paired)
-    int* d_partner = nullptr;  size_t d_partner_cap = 0;         // [K][3 Bp] per reference of a row referenced exactly twice: where the other one sits (-1: none)
+    int4* d_partner = nullptr; size_t d_partner_cap = 0;         // [K][B] per triplet: where the partner of its slot 0 / 1 / 2 sits if that row is referenced exactly twice (-1: no), pairing word
     int* d_pslot = nullptr;    size_t d_pslot_cap = 0;           // [K][2B] parallel to dlist: position of the FIRST reference of a row referenced exactly twice (-1: another kind of row)
-    int* d_perm = nullptr;     size_t d_perm_cap = 0;            // [K][B] pairing: which triplet of the batch is processed at position j
     int4* d_ids4 = nullptr;    size_t d_ids4_cap = 0;            // [K][B] the fused kernel's input with pairing: (user, pos, neg) rewritten ids of position j, pinfo | origin << 10
     int* h_plan = nullptr;                                       // pinned host mirror of the per-step plan counters
     size_t h_plan_cap = 0;
@@ -253,9 +253,9 @@ struct DedupArgs {
     int tree_off[3];
     int min_late;                             // bucketed plan: see PairPlan
     // pairing (bucketed plan only; pair_tpw < 2: off): triplets per wavefront of the fused kernel that will run the steps,
-    // per-step arrays [K][flag_stride] partner, [K][pair_stride] pinfo and [K][swap_stride] swaps; the number of accepted pairs of step s
-    // is alloc[8 s + 7]
-    int pair_tpw; int* partner; int* pslot; uint32_t* pinfo; int* perm; int4* ids4; int64_t pair_stride;
+    // per-step arrays [K][pair_stride] partner (16-byte record per triplet) and ids4, [K][2 list_stride] pslot; the number of accepted pairs
+    // of step s is alloc[8 s + 7]
+    int pair_tpw; int4* partner; int* pslot; int4* ids4; int64_t pair_stride;
 };
 // pairing word of a triplet (PairArgs::pinfo): the triplet shares one row with the triplet of lane group PARTNER of the same wavefront;
 // the WRITER adds the partner's gradient of that row to its own and updates the row in place, the other one does not write it
@@ -380,7 +380,7 @@ int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
 int orx_exact_plan_issue(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,
                          int64_t nU, int64_t nP, int64_t nN, int64_t kc, int64_t B, bool inline_apply, bool staging,
                          const PairPlan& plan, int64_t i0, hipEvent_t counters, const std::function<int()>* after_readback = nullptr);
-int orx_exact_plan_finish(orx_ctx* c, int64_t kc, int64_t B, bool inline_apply, bool staging, int64_t i0, hipEvent_t counters, ExactChunk* out);
+int orx_exact_plan_finish(orx_ctx* c, int64_t kc, int64_t B, bool inline_apply, bool staging, int64_t i0, hipEvent_t counters, ExactChunk* out, bool pairing_on = false);
 void orx_exact_step_views(orx_ctx* c, const PairPlan& plan, int64_t i, int64_t B, int D, bool use_stage, PairArgs* a);
 int orx_launch_rows_planned(orx_ctx* ctx, int optkind, const RowsArgs& a);
 // K id lists of n local rows each (ids [K][n], < 0 = padding) against ONE table: plan once (duplicate roles, staging
@@ -390,6 +390,7 @@ int orx_apply_rows_plan(orx_ctx* ctx, orx_table* t, const int32_t* ids, int64_t 
 int orx_apply_rows_planned_step(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const RowsPlan& rp, int64_t i,
                                 const int32_t* ids, const float* grads, int64_t g_stride);
 int orx_launch_dup_apply(orx_ctx* ctx, int optkind, const PairArgs& a);
+bool orx_launch_tail(orx_ctx* ctx, int optkind, const PairArgs& a, const ReduceArgs& r, int64_t K, int* rc);     // dup_apply of the last step + loss_reduce in one launch
 int orx_launch_urgent(orx_ctx* ctx, const DedupArgs& a, int64_t K);
 // bucketed plan (kernels_plan.hip): same outputs as orx_launch_dedup (+ orx_launch_urgent) with `d` filled the same way
 bool orx_plan_v2(bool role_bits);

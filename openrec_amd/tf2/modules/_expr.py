@@ -65,12 +65,29 @@ class Expr:
     # ---- anything that looks at the values gets the host array
     def numpy(self):
         if self._host is None:
+            # dlrm.py:76-100 (inference): the whole tree is one device call
+            from ._compose import try_dlrm_inference
+            v = try_dlrm_inference(self)
+            if v is not None:
+                self._host = np.asarray(v, np.float32)
+                return self._host
             from .._lazy import active_tape
             if active_tape() is not None:
-                from ._compose import host_fallback
-                host_fallback("arithmetic on looked-up rows")
-            a = [host(x) for x in self.args]
+                # under a tape the caller expects to TRAIN through this value: a host forward has no gradients
+                raise NotImplementedError(f"this expression (ending in `{self.op}`) is not one of the compositions this package runs as a fused "
+                                          "device step (bpr.py / ucml.py / gmf.py / wrmf.py / dlrm.py of the reference): it would be computed on "
+                                          "the host WITHOUT gradients -- evaluate it outside the GradientTape if only its values are wanted")
             op, kw = self.op, self.kw
+            if op == "mlp":
+                self._host = np.asarray(self.args[0].host_forward(host(self.args[1])), np.float32)
+                return self._host
+            if op == "interact":
+                self._host = np.asarray(self.args[0].host_forward([host(x) for x in self.args[1:]]), np.float32)
+                return self._host
+            if op == "concat":
+                self._host = np.concatenate([np.asarray(host(x), np.float32) for x in self.args], axis=kw["axis"])
+                return self._host
+            a = [host(x) for x in self.args]
             if op == "add": v = a[0] + a[1]
             elif op == "sub": v = a[0] - a[1]
             elif op == "mul": v = a[0] * a[1]
@@ -82,6 +99,7 @@ class Expr:
             elif op == "squeeze": v = np.squeeze(a[0], axis=kw.get("axis"))
             elif op == "reshape": v = np.reshape(a[0], kw["shape"])
             elif op == "dense1": v = a[1] @ self.args[0].layers[0].kernel.read()
+            elif op == "clip": v = np.clip(a[0], kw["lo"], kw["hi"])
             else: raise NotImplementedError(op)
             self._host = np.asarray(v, np.float32)
         return self._host
@@ -125,6 +143,20 @@ def maximum(a, b):
     return Expr("maximum", a, b) if (is_lazy(a) or is_lazy(b)) else np.maximum(np.asarray(a), np.asarray(b))
 
 
+def concat(values, axis):
+    values = list(values)
+    return Expr("concat", *values, axis=axis) if any(is_lazy(v) for v in values) else np.concatenate([np.asarray(v) for v in values], axis=axis)
+
+
+def clip_by_value(x, lo, hi):
+    return Expr("clip", x, lo=float(lo), hi=float(hi)) if is_lazy(x) else np.clip(np.asarray(x), lo, hi)
+
+
+def unstack(x, axis=0):
+    a = np.asarray(x.numpy() if hasattr(x, "numpy") and not isinstance(x, np.ndarray) else x)
+    return [np.take(a, k, axis=axis) for k in range(a.shape[axis])]
+
+
 def expand_dims(x, axis):
     return Expr("expand_dims", x, axis=axis) if is_lazy(x) else np.expand_dims(np.asarray(x), axis)
 
@@ -145,9 +177,27 @@ class BinaryCrossentropy:
             r = try_gmf_loss(y_true, y_pred)
             if r is not None:
                 return r
+        if isinstance(y_pred, Expr) and not self.from_logits and sample_weight is None:
+            from ._compose import try_dlrm_loss          # dlrm.py:54-55, :72-73
+            r = try_dlrm_loss("bce", y_true, y_pred)
+            if r is not None:
+                return r
         y, x = np.asarray(y_true, np.float32).reshape(-1), host(y_pred).reshape(-1).astype(np.float32)
         if self.from_logits:
             return np.float32(np.mean(np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))))
         eps = 1e-7
         p = np.clip(x, eps, 1 - eps)
         return np.float32(np.mean(-(y * np.log(p + eps) + (1 - y) * np.log(1 - p + eps))))
+
+
+class MeanSquaredError:
+    """tf.keras.losses.MeanSquaredError as dlrm.py:52-53 makes it (mean over the batch)"""
+
+    def __call__(self, y_true, y_pred, sample_weight=None):
+        if isinstance(y_pred, Expr) and sample_weight is None:
+            from ._compose import try_dlrm_loss          # dlrm.py:72-73
+            r = try_dlrm_loss("mse", y_true, y_pred)
+            if r is not None:
+                return r
+        y, x = np.asarray(y_true, np.float32).reshape(-1), host(y_pred).reshape(-1).astype(np.float32)
+        return np.float32(np.mean((y - x) ** 2))

@@ -1,7 +1,9 @@
 """MLP factory (openrec/tf2/modules/multi_layer_perceptron.py:5-18): a stack of
-Dense layers.  Only what the hot path needs is device-backed: GMF uses
+Dense layers whose kernels / biases are HBM tables.  GMF uses
 `MLP(units_list=[1], use_bias=False)`, a single [D, 1] kernel that the fused
-pointwise kernel reads and updates in HBM."""
+pointwise kernel reads and updates in HBM; DLRM's bottom and top MLPs
+(recommenders/dlrm.py:34-37) become the parameters of `orx_dlrm_step` when the
+composition dlrm.py:76-100 is recognised (modules/_compose.py)."""
 from __future__ import annotations
 
 import numpy as np
@@ -47,24 +49,8 @@ class MLP:
                     out.append(Variable(layer.bias, f"dense_{k}/bias"))
         return out
 
-    def __call__(self, x):
-        """Forward on the host (weights read back from HBM), WITHOUT gradients: the device paths are the packaged recommenders
-        (GMF's fused pointwise step reads and updates `layers[0].kernel` in HBM; DLRM runs its MLPs inside `orx_dlrm_step`).
-        Under a GradientTape -- where the caller expects to train through it -- this says so once."""
-        from ._expr import Expr
-        if isinstance(x, Expr) and x.op == "mul" and len(self.layers) == 1 and self.layers[0].units == 1 and not self.layers[0].use_bias \
-                and self.layers[0].activation is None:
-            # gmf.py:28 / :39: Dense(1, no bias) of (user rows * item rows): the fused GMF step / scorer reads this kernel in HBM
-            from .latent_factor import GatheredRows
-            rows = [a for a in x.args if isinstance(a, GatheredRows)] + [a.args[0] for a in x.args if isinstance(a, Expr) and a.op == "expand_dims"
-                                                                          and isinstance(a.args[0], GatheredRows)]
-            if rows:
-                self.build(rows[0].factor.dim, rows[0].factor.table.ctx)
-                return Expr("dense1", self, x)
-        from .._lazy import active_tape
-        if active_tape() is not None:
-            from ._compose import host_fallback
-            host_fallback("MLP")
+    def host_forward(self, x):
+        """the stack applied to a host array (weights read back from HBM): values only, no gradients"""
         x = np.asarray(x, np.float32)
         self.build(x.shape[-1])
         for layer in self.layers:
@@ -76,3 +62,20 @@ class MLP:
             elif layer.activation == 'sigmoid':
                 x = 1.0 / (1.0 + np.exp(-x))
         return x
+
+    def __call__(self, x):
+        """A node of a lazy expression (modules/_expr.py): the compositions of the reference that contain an MLP run as fused
+        device steps -- gmf.py:28 (`Dense(1, no bias)` of user rows * item rows: the fused GMF step / scorer reads the kernel in
+        HBM) and dlrm.py:87-93 (bottom MLP -> feature interaction -> top MLP: `orx_dlrm_step`, whose parameters this object's
+        layers then ARE).  A tree that matches neither evaluates on the host when somebody looks at its values -- outside a
+        tape: under a GradientTape, where the caller expects to train through it, that raises."""
+        from ._expr import Expr
+        if isinstance(x, Expr) and x.op == "mul" and len(self.layers) == 1 and self.layers[0].units == 1 and not self.layers[0].use_bias \
+                and self.layers[0].activation is None:
+            from .latent_factor import GatheredRows
+            rows = [a for a in x.args if isinstance(a, GatheredRows)] + [a.args[0] for a in x.args if isinstance(a, Expr) and a.op == "expand_dims"
+                                                                          and isinstance(a.args[0], GatheredRows)]
+            if rows:
+                self.build(rows[0].factor.dim, rows[0].factor.table.ctx)
+                return Expr("dense1", self, x)
+        return Expr("mlp", self, x)
