@@ -66,9 +66,12 @@ enum orx_flags {
                              (NOT reference semantics; speed comparisons only)  */
     ORX_NO_L2 = 4,        /* objective = loss only (tape over `loss` alone)
                              instead of the example's (loss, l2_loss) tuple     */
-    ORX_CENSOR = 8        /* orx_pairwise_step: after every step, UCML.censor_vec
+    ORX_CENSOR = 8,       /* orx_pairwise_step: after every step, UCML.censor_vec
                              (ucml.py:44-48) on that step's ids: users, then pos
                              items, then neg items, min_norm 0.1                */
+    ORX_POINT_SIGMOID = 16 /* orx_pointwise_step / _loss with ORX_WRMF: PointwiseMSELoss(sigmoid=True),
+                             the prediction goes through a sigmoid before the weighted squared
+                             error (modules/pointwise_mse_loss.py:24-25)        */
 };
 
 /* kernels whose device time can be sampled with orx_prof_* */

@@ -14,7 +14,7 @@ ORX_OK, ORX_ERR_ARG, ORX_ERR_HIP, ORX_ERR_OOM, ORX_ERR_INDEX, ORX_ERR_STATE = 0,
 ORX_SGD, ORX_ADAGRAD, ORX_ADAM = 0, 1, 2
 ORX_BPR, ORX_UCML = 0, 1
 ORX_GMF, ORX_WRMF = 0, 1
-ORX_IDS_DEVICE, ORX_HOGWILD, ORX_NO_L2, ORX_CENSOR = 1, 2, 4, 8
+ORX_IDS_DEVICE, ORX_HOGWILD, ORX_NO_L2, ORX_CENSOR, ORX_POINT_SIGMOID = 1, 2, 4, 8, 16
 ORX_SHARD_OVERLAP, ORX_SHARD_NO_DEDUP, ORX_SHARD_DEDUP, ORX_COMM_ID_BYTES = 0x100, 0x200, 0x400, 128
 ORX_DLRM_INTERACT_ITSELF, ORX_DLRM_SIGMOID_BOT, ORX_DLRM_SIGMOID_TOP, ORX_DLRM_LOSS_BCE, ORX_DLRM_REFERENCE_COMPAT = 1, 2, 4, 8, 16
 ORX_DLRM_FP16_MLP = 32

@@ -122,6 +122,7 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     a.B = B; a.NU = U->rows; a.NI = V->rows; a.D = D;
     a.lr = opt->lr; a.eps = opt->kind == ORX_ADAGRAD ? opt->p1 : 0.f;
     a.invB = 1.0f / (float)B; a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f; a.a_w = a_w; a.b_w = b_w;
+    a.sigmoid = (model == ORX_WRMF && (flags & ORX_POINT_SIGMOID)) ? 1 : 0;
     a.wpartial = c->d_wpart; a.err = c->d_err;
     if (role_bits) { a.role_bits = 1; a.gU2 = U->gsum2; a.gV2 = V->gsum2; a.gb2 = b->gsum2; a.readyU = U->ready; a.readyV = V->ready; }
     PairArgs pa;                                 // view of the same tables for dup_apply_kernel / hot_reduce_kernel / the in-launch apply
@@ -233,6 +234,7 @@ extern "C" int orx_pointwise_loss(orx_ctx* c, int model, orx_table* U, orx_table
     a.U = U->w; a.V = V->w; a.b = b->w; a.w = w ? w->w : nullptr;
     a.B = B; a.NU = U->rows; a.NI = V->rows; a.D = D;
     a.invB = 1.0f / (float)B; a.l2w = 1.f; a.a_w = a_w; a.b_w = b_w;
+    a.sigmoid = (model == ORX_WRMF && (flags & ORX_POINT_SIGMOID)) ? 1 : 0;
     a.partial = c->d_partial; a.err = c->d_err;
     a.uid = du; a.iid = di; a.label = dl;
     CHECK(orx_launch_point_fused(c, model, ORX_SGD, MODE_LOSS, a));

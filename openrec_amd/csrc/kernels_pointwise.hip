@@ -15,7 +15,7 @@
 
 // per-sample loss term and d(loss)/d(score)
 template <int MODEL>
-__device__ __forceinline__ void point_score(float s, float y, float invB, float a_w, float b_w, float& term, float& gs) {
+__device__ __forceinline__ void point_score(float s, float y, float invB, float a_w, float b_w, float& term, float& gs, int sigmoid = 0) {
     if (MODEL == ORX_GMF) {
         const float e = __expf(-fabsf(s));
         term = (fmaxf(s, 0.0f) - s * y + log1pf(e)) * invB;            // BCE with logits, mean
@@ -23,9 +23,15 @@ __device__ __forceinline__ void point_score(float s, float y, float invB, float 
         gs = (sig - y) * invB;
     } else {
         const float c = (a_w - b_w) * y + b_w;                         // pointwise_mse_loss.py:30
-        const float r = y - s;
+        float pred = s, dpred = 1.0f;
+        if (sigmoid) {                                                 // :24-25  pred = sigmoid(dot + bias)
+            const float e = __expf(-fabsf(s));
+            pred = (s >= 0.0f) ? 1.0f / (1.0f + e) : e / (1.0f + e);
+            dpred = pred * (1.0f - pred);
+        }
+        const float r = y - pred;
         term = c * r * r;                                              // :31 (sum)
-        gs = -2.0f * c * r;
+        gs = -2.0f * c * r * dpred;
     }
 }
 
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
         const f4 ui = ru * ri;
         const float s = group_allreduce<LPR>(dot4(ui, wv)) + bi;
         float term, gs;
-        point_score<MODEL>(s, y, a.invB, a.a_w, a.b_w, term, gs);
+        point_score<MODEL>(s, y, a.invB, a.a_w, a.b_w, term, gs, a.sigmoid);
         sq_acc += dot4(ru, ru) + dot4(ri, ri);
         if (sub == 0) loss_acc += term;
         if (MODE == MODE_LOSS) continue;
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256) void point_generic_kernel(PointArgs a) {
         }
         const float s = wave_sum(part) + bi;
         float term, gs;
-        point_score<MODEL>(s, y, a.invB, a.a_w, a.b_w, term, gs);
+        point_score<MODEL>(s, y, a.invB, a.a_w, a.b_w, term, gs, a.sigmoid);
         if (lane == 0) loss_acc += term;
         if (MODE == MODE_LOSS) continue;
         for (int e = lane; e < D; e += 64) {

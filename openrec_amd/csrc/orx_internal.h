@@ -336,6 +336,7 @@ struct PointArgs {
     int64_t B; int64_t NU; int64_t NI;
     int D;
     float lr; float eps; float invB; float l2w; float a_w; float b_w;
+    int sigmoid;                              // WRMF: PointwiseMSELoss(sigmoid=True), pointwise_mse_loss.py:24-25
     float* partial;                           // [nwaves][2]
     float* wpartial;                          // [nwaves][D] (GMF)
     int* err;

@@ -286,8 +286,9 @@ _POINT = {"gmf": _ffi.ORX_GMF, "wrmf": _ffi.ORX_WRMF}
 
 
 def pointwise_step(model, opt, user, item, bias, w, uid, iid, label, K=1, B=None, id_stride=None,
-                   a=1.0, b_w=1.0, hogwild=False, no_l2=False, want_loss=True):
-    """K fused GMF / WRMF train steps (gmf.py:22-34, wrmf.py:21-34)."""
+                   a=1.0, b_w=1.0, hogwild=False, no_l2=False, want_loss=True, sigmoid=False):
+    """K fused GMF / WRMF train steps (gmf.py:22-34, wrmf.py:21-34); sigmoid: PointwiseMSELoss(sigmoid=True)
+    (pointwise_mse_loss.py:24-25; WRMF only)."""
     lib = user.ctx._lib
     pu, nu, du, k0 = _ids_arg(uid)
     pi, ni, di, k1 = _ids_arg(iid)
@@ -298,7 +299,8 @@ def pointwise_step(model, opt, user, item, bias, w, uid, iid, label, K=1, B=None
         B = nu // K
     if id_stride is None:
         id_stride = B
-    flags = (_ffi.ORX_IDS_DEVICE if du else 0) | (_ffi.ORX_HOGWILD if hogwild else 0) | (_ffi.ORX_NO_L2 if no_l2 else 0)
+    flags = (_ffi.ORX_IDS_DEVICE if du else 0) | (_ffi.ORX_HOGWILD if hogwild else 0) | (_ffi.ORX_NO_L2 if no_l2 else 0) \
+        | (_ffi.ORX_POINT_SIGMOID if sigmoid else 0)
     loss = np.empty(K, np.float32) if want_loss else None
     l2 = np.empty(K, np.float32) if want_loss else None
     check(lib.orx_pointwise_step(user.ctx._h, _POINT[model], opt._h, user._h, item._h, bias._h,
@@ -309,7 +311,7 @@ def pointwise_step(model, opt, user, item, bias, w, uid, iid, label, K=1, B=None
     return (loss, l2) if want_loss else None
 
 
-def pointwise_loss(model, user, item, bias, w, uid, iid, label, a=1.0, b_w=1.0):
+def pointwise_loss(model, user, item, bias, w, uid, iid, label, a=1.0, b_w=1.0, sigmoid=False):
     lib = user.ctx._lib
     pu, nu, du, k0 = _ids_arg(uid)
     pi, _, di, k1 = _ids_arg(iid)
@@ -318,7 +320,7 @@ def pointwise_loss(model, user, item, bias, w, uid, iid, label, a=1.0, b_w=1.0):
     l2 = np.empty(1, np.float32)
     check(lib.orx_pointwise_loss(user.ctx._h, _POINT[model], user._h, item._h, bias._h,
                                  w._h if w is not None else None, pu, pi, pl, nu, float(a), float(b_w),
-                                 _ffi.ORX_IDS_DEVICE if du else 0, loss.ctypes.data, l2.ctypes.data))
+                                 (_ffi.ORX_IDS_DEVICE if du else 0) | (_ffi.ORX_POINT_SIGMOID if sigmoid else 0), loss.ctypes.data, l2.ctypes.data))
     return float(loss[0]), float(l2[0])
 
 

@@ -278,10 +278,12 @@ class Model:
     def trainable_variables(self):
         out, seen = [], set()
         for v in vars(self).values():
-            for var in (getattr(v, "trainable_variables", None) or getattr(v, "variables", None) or []):
-                if id(var) not in seen:
-                    seen.add(id(var))
-                    out.append(var)
+            # (Keras tracks lists of layers too: dlrm.py:30-31 keeps its latent factors in one)
+            for mod in (v if isinstance(v, (list, tuple)) else [v]):
+                for var in (getattr(mod, "trainable_variables", None) or getattr(mod, "variables", None) or []):
+                    if id(var) not in seen:
+                        seen.add(id(var))
+                        out.append(var)
         return out
 
     variables = trainable_variables
@@ -366,9 +368,19 @@ def _expand_dims(x, axis): return _expr_ops().expand_dims(x, axis)
 def _squeeze(x, axis=None): return _expr_ops().squeeze(x, axis=axis)
 
 
+def _concat(values, axis): return _expr_ops().concat(values, axis)
+def _clip_by_value(x, clip_value_min, clip_value_max): return _expr_ops().clip_by_value(x, clip_value_min, clip_value_max)
+def _unstack(value, num=None, axis=0): return _expr_ops().unstack(value, axis=axis)
+
+
 class _BCE:
     def __new__(cls, *a, **k):
         return _expr_ops().BinaryCrossentropy(*a, **k)
+
+
+class _MSE:
+    def __new__(cls, *a, **k):
+        return _expr_ops().MeanSquaredError()
 
 
 def _l2_loss(x):
@@ -377,7 +389,7 @@ def _l2_loss(x):
 
 
 optimizers = types.SimpleNamespace(SGD=SGD, Adagrad=Adagrad, Adam=Adam)
-losses = types.SimpleNamespace(BinaryCrossentropy=_BCE)
+losses = types.SimpleNamespace(BinaryCrossentropy=_BCE, MeanSquaredError=_MSE)
 keras = types.SimpleNamespace(optimizers=optimizers, metrics=types.SimpleNamespace(Mean=Mean, AUC=AUC), Model=Model, losses=losses)
 math = types.SimpleNamespace(square=_square, reduce_sum=_reduce_sum, maximum=_maximum)
 data = types.SimpleNamespace(Dataset=TensorSliceDataset)
@@ -385,7 +397,8 @@ nn = types.SimpleNamespace(l2_loss=_l2_loss)
 linalg = types.SimpleNamespace(matmul=matmul)
 tf = types.SimpleNamespace(function=function, GradientTape=GradientTape, constant=constant, keras=keras, data=data, nn=nn,
                            linalg=linalg, matmul=matmul, reshape=reshape, int32=int32, float32=float32, bool=bool_,
-                           math=math, reduce_sum=_reduce_sum, maximum=_maximum, square=_square, expand_dims=_expand_dims, squeeze=_squeeze)
+                           math=math, reduce_sum=_reduce_sum, maximum=_maximum, square=_square, expand_dims=_expand_dims, squeeze=_squeeze,
+                           concat=_concat, clip_by_value=_clip_by_value, unstack=_unstack)
 
 
 def install():

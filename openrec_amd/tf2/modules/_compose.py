@@ -20,6 +20,12 @@ _warned = set()
 
 
 def host_fallback(what):
+    from .._lazy import active_tape
+    if active_tape() is not None:
+        # under a tape the caller expects to TRAIN through this value: a host forward has no gradients
+        raise NotImplementedError(f"{what}: this call is not one of the compositions this package runs as a fused device step (bpr.py / ucml.py "
+                                  "/ gmf.py / wrmf.py / dlrm.py of the reference) -- it would be computed on the host WITHOUT gradients; evaluate "
+                                  "it outside the GradientTape if only its value is wanted")
     if what not in _warned:
         _warned.add(what)
         warnings.warn(f"{what}: this call is not one of the compositions this package runs as a fused device step -- computed "
@@ -72,7 +78,7 @@ def composed_model(kind, user_lf, item_lf, bias_lf, **kw):
         else:
             class _Composed(PointwiseRecommender):
                 def _point_args(self):
-                    return "wrmf", None, dict(a=kw["a"], b_w=kw["b"])
+                    return "wrmf", None, dict(a=kw["a"], b_w=kw["b"], sigmoid=kw.get("sigmoid", False))
         m = _Composed.__new__(_Composed)
         m.user_latent_factor, m.item_latent_factor, m.item_bias = user_lf, item_lf, bias_lf
         m._queue = _StepQueue()
@@ -245,7 +251,7 @@ def pairwise_step_of(user_vec, p_item_vec, n_item_vec, p_item_bias, n_item_bias)
     return out
 
 
-def pointwise_step_of(user_vec, item_vec, item_bias, label, a, b):
+def pointwise_step_of(user_vec, item_vec, item_bias, label, a, b, sigmoid=False):
     rows = (user_vec, item_vec, item_bias)
     if not all(isinstance(r, GatheredRows) for r in rows):
         return None
@@ -253,7 +259,7 @@ def pointwise_step_of(user_vec, item_vec, item_bias, label, a, b):
     if bb.dim != 1 or U.dim != V.dim or bb.num_instances != V.num_instances or not _same_ids(item_vec.ids, item_bias.ids):
         return None
     _consume(*rows)
-    out = composed_model("wrmf", U, V, bb, a=float(a), b=float(b))(user_vec.ids, item_vec.ids, label)
+    out = composed_model("wrmf", U, V, bb, a=float(a), b=float(b), sigmoid=bool(sigmoid))(user_vec.ids, item_vec.ids, label)
     _tag(out[0]._step, (user_vec, item_vec))
     return out
 
@@ -332,3 +338,161 @@ def l2_loss(x):
     if isinstance(x, Variable):
         return L2Sum([], params=[x.table])
     return np.float32(0.5 * float((np.asarray(x, np.float64) ** 2).sum()))
+
+
+# ---- DLRM: recommenders/dlrm.py:76-100 written against the modules --------------------------------------------------------
+class _RowRangeTable:
+    """Rows [row0, row0 + rows) of another table, as the `table` of a LatentFactor / Variable: the 26 embedding tables of the
+    composition dlrm.py:30-31 are slices of the ONE combined table `orx_dlrm_step` trains (every access goes through that table:
+    queued steps run first, a lazily-applied Adam is brought up to date)."""
+
+    def __init__(self, base, row0, rows):
+        self.base, self.row0, self.rows, self.dim, self.ctx = base, int(row0), int(rows), base.dim, base.ctx
+
+    @property
+    def shape(self):
+        return (self.rows, self.dim)
+
+    def read(self, row0=0, nrows=None):
+        nrows = self.rows - row0 if nrows is None else nrows
+        if row0 < 0 or row0 + nrows > self.rows:
+            raise IndexError("row range outside the table")
+        return self.base.read(self.row0 + row0, nrows)
+
+    numpy = read
+
+    def write(self, values, row0=0):
+        a = np.ascontiguousarray(values, np.float32).reshape(-1, self.dim)
+        if row0 < 0 or row0 + a.shape[0] > self.rows:
+            raise IndexError("row range outside the table")
+        self.base.write(a, self.row0 + row0)
+        return self
+
+    def gather(self, ids):
+        i = np.asarray(ids).reshape(-1)
+        if i.size and (i.min() < 0 or i.max() >= self.rows):
+            raise IndexError("embedding id out of range")
+        return self.base.gather((i.astype(np.int64) + self.row0).astype(np.int32))
+
+    def censor(self, ids, min_norm=0.1):
+        i = np.asarray(ids).reshape(-1)
+        self.base.censor((i.astype(np.int64) + self.row0).astype(np.int32), min_norm)
+
+    def fill(self, v):
+        self.base.write(np.full((self.rows, self.dim), v, np.float32), self.row0)
+        return self
+
+
+def _match_dlrm(pred):
+    """reshape([clip_by_value](mlp_top(concat([mlp_bot(dense), interaction(embeddings + [mlp_bot(dense)])], axis=1))), [-1])
+    (dlrm.py:84-100) -> dict of its parts, or None"""
+    from ._expr import Expr
+    e = pred
+    if not (_node(e, "reshape", 1) and list(np.atleast_1d(e.kw.get("shape"))) == [-1]):
+        return None
+    e = e.args[0]
+    thr = 0.0
+    if _node(e, "clip", 1):
+        lo, hi = e.kw["lo"], e.kw["hi"]
+        if not (0.0 < lo < 1.0 and abs((1.0 - lo) - hi) < 1e-6):
+            return None
+        thr, e = lo, e.args[0]
+    if not _node(e, "mlp", 2):
+        return None
+    top, cat = e.args
+    if not (_node(cat, "concat") and cat.kw.get("axis") == 1 and len(cat.args) == 2):
+        return None
+    bot_e, inter = cat.args
+    if not (_node(bot_e, "mlp", 2) and _node(inter, "interact") and len(inter.args) >= 3):
+        return None
+    bot, dense = bot_e.args
+    if isinstance(dense, (Expr, GatheredRows)) or inter.args[-1] is not bot_e:
+        return None
+    rows = list(inter.args[1:-1])
+    if not all(isinstance(r, GatheredRows) and len(r.shape) == 2 for r in rows):
+        return None
+    lfs = [r.factor for r in rows]
+    if len({id(f) for f in lfs}) != len(lfs) or len({f.dim for f in lfs}) != 1:
+        return None
+    if bot.layers[-1].units != lfs[0].dim or top.layers[-1].units != 1 or top is bot:
+        return None
+    acts = lambda m: ({l.activation for l in m.layers[:-1]} <= {"relu"}) and all(l.use_bias for l in m.layers) and m.layers[-1].activation in ("relu", "sigmoid")
+    if not (acts(bot) and acts(top)):
+        return None
+    return dict(top=top, bot=bot, interaction=inter.args[0], dense=dense, rows=rows, lfs=lfs, threshold=thr)
+
+
+def _dlrm_for(parts, loss_func):
+    """the packaged DLRM recommender (recommenders/dlrm.py of this package: step queue, `orx_dlrm_step`) over THESE modules: made once
+    per (latent factors, MLPs, interaction, loss), it takes the current values of the latent factors into its combined embedding
+    table and from then on its parameters ARE the modules' (LatentFactor.table -> a row range of the combined table, Dense.kernel /
+    .bias -> the model's parameter tables)"""
+    from ..recommenders.dlrm import DLRM
+    from .latent_factor import Variable
+    top, bot, inter, lfs = parts["top"], parts["bot"], parts["interaction"], parts["lfs"]
+    dense = np.asarray(parts["dense"])
+    key = ("dlrm", tuple(id(f) for f in lfs), id(top), id(bot), id(inter), loss_func, float(parts["threshold"]))
+    owned = lfs[0].__dict__.setdefault("_composed", {})
+    m = owned.get(key)
+    if m is not None:
+        return m
+    if any(isinstance(f.table, _RowRangeTable) for f in lfs) or any(getattr(l, "_adopted", False) for l in bot.layers + top.layers):
+        # these modules already belong to another composition (another loss, another threshold ...): their parameters cannot be two models'
+        raise NotImplementedError("DLRM composition: these modules are already the parameters of another fused DLRM step")
+    ctx = lfs[0].table.ctx
+    m = DLRM(lfs[0].dim, [f.num_instances for f in lfs], [l.units for l in bot.layers], [l.units for l in top.layers],
+             arch_interaction_itself=inter._self_interaction, sigmoid_bot=bot.layers[-1].activation == "sigmoid",
+             sigmoid_top=top.layers[-1].activation == "sigmoid", loss_func=loss_func, loss_threshold=parts["threshold"],
+             reference_compat=inter._reference_compat, dense_dim=dense.shape[-1], ctx=ctx)
+    emb = m._param("emb")
+    row0 = 0
+    for f in lfs:
+        emb.write(f.table.read(), row0)                     # (the composition's embeddings keep their initial values)
+        f.table = _RowRangeTable(emb, row0, f.num_instances)
+        f._var = Variable(f.table, f._var.name)
+        row0 += f.num_instances
+    for name, mlp in (("bot", bot), ("top", top)):
+        for l, layer in enumerate(mlp.layers):
+            w, b = m._param(name + "_w", l), m._param(name + "_b", l)
+            if layer.kernel is not None:                    # (built by an earlier host evaluation, e.g. inference before any loss call: keep those values)
+                w.write(layer.kernel.read()); b.write(layer.bias.read())
+            layer.kernel, layer.bias, layer._adopted = w, b, True
+    owned[key] = m
+    _models[key] = m
+    return m
+
+
+def _dlrm_sparse(parts):
+    cols = []
+    for r in parts["rows"]:
+        i = r.flat_ids()
+        if getattr(i, "is_cuda", False):
+            i = i.cpu().numpy()
+        cols.append(np.asarray(i).reshape(-1).astype(np.int32))
+    return np.stack(cols, axis=1)
+
+
+def try_dlrm_loss(loss_func, label, pred):
+    """MeanSquaredError / BinaryCrossentropy()(y_true=label, y_pred=<the tree of dlrm.py:84-100>) (dlrm.py:72-73) -> the loss of the
+    fused DLRM step, or None"""
+    parts = _match_dlrm(pred)
+    if parts is None:
+        return None
+    m = _dlrm_for(parts, loss_func)
+    _consume(*parts["rows"])
+    return m(np.asarray(parts["dense"], np.float32), _dlrm_sparse(parts), np.asarray(label, np.float32).reshape(-1))
+
+
+def try_dlrm_inference(pred):
+    """np.asarray(<the tree of dlrm.py:84-100>) (DLRM.inference, dlrm_criteo.py:52) -> predictions from `orx_dlrm_inference`, or None.
+    Only for modules that already are a fused model's parameters (a loss call made them so)."""
+    parts = _match_dlrm(pred)
+    if parts is None:
+        return None
+    owned = parts["lfs"][0].__dict__.get("_composed", {})
+    for key, m in owned.items():
+        if key[0] == "dlrm" and key[1:5] == (tuple(id(f) for f in parts["lfs"]), id(parts["top"]), id(parts["bot"]), id(parts["interaction"])) \
+                and key[6] == float(parts["threshold"]):
+            _consume(*parts["rows"])
+            return m.inference(np.asarray(parts["dense"], np.float32), _dlrm_sparse(parts))
+    return None

@@ -1,6 +1,6 @@
 """PointwiseMSELoss on already gathered vectors
 (openrec/tf2/modules/pointwise_mse_loss.py:4-31).  Given the three lookups of wrmf.py:23-25 it records the fused
-WRMF step (`WRMF.__call__` of this package); with `sigmoid=True` or plain arrays it computes on the host."""
+WRMF step (`WRMF.__call__` of this package; `sigmoid=True` is a flag of the same fused kernel); plain arrays compute on the host."""
 import numpy as np
 
 from . import _compose
@@ -12,10 +12,9 @@ class PointwiseMSELoss:
         self._a, self._b, self._sigmoid = a, b, sigmoid
 
     def __call__(self, user_vec, item_vec, item_bias, label):
-        if not self._sigmoid:
-            fused = _compose.pointwise_step_of(user_vec, item_vec, item_bias, label, self._a, self._b)
-            if fused is not None:
-                return fused[0]
+        fused = _compose.pointwise_step_of(user_vec, item_vec, item_bias, label, self._a, self._b, sigmoid=bool(self._sigmoid))
+        if fused is not None:
+            return fused[0]
         if any(isinstance(x, _compose.GatheredRows) for x in (user_vec, item_vec)):
             _compose.host_fallback("PointwiseMSELoss")
         u, i = np.asarray(user_vec, np.float32), np.asarray(item_vec, np.float32)

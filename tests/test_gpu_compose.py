@@ -227,8 +227,9 @@ def test_loss_only_objective_and_host_uses_of_a_lookup():
     assert rel_err(Uf.variables[0].numpy(), U) < TOL and rel_err(Vf.variables[0].numpy(), V) < TOL and rel_err(bf.variables[0].numpy(), b) < TOL
 
 
-def test_unrecognised_composition_warns_instead_of_silently_leaving_the_device():
-    from openrec_amd.tf2.modules import LatentFactor, PairwiseLogLoss, PointwiseMSELoss
+def test_unrecognised_composition_warns_outside_a_tape_and_raises_under_one():
+    from openrec_amd.tf2.compat import tf
+    from openrec_amd.tf2.modules import LatentFactor, PairwiseLogLoss
     Uf, Vf, bf = LatentFactor(50, 8), LatentFactor(60, 8), LatentFactor(60, 1)
     ids = np.arange(10, dtype=np.int32)
     import openrec_amd.tf2.modules._compose as C
@@ -238,8 +239,43 @@ def test_unrecognised_composition_warns_instead_of_silently_leaving_the_device()
     U, V = Uf.variables[0].numpy(), Vf.variables[0].numpy()
     x = ((U[ids] * V[ids]).sum(1) - (U[ids] * V[ids + 1]).sum(1)).astype(np.float64)
     assert float(v) == pytest.approx(float(np.mean(np.log1p(np.exp(-x)))), rel=1e-5)
-    with pytest.warns(RuntimeWarning, match="WITHOUT gradients"):
-        PointwiseMSELoss(sigmoid=True)(Uf(ids), Vf(ids), bf(ids), np.ones(10, np.float32))
+    with tf.GradientTape():                                                    # a tape expects to train through it: refused
+        with pytest.raises(NotImplementedError, match="WITHOUT gradients"):
+            PairwiseLogLoss()(Uf(ids), Vf(ids), Vf(ids + 1))
+
+
+@pytest.mark.parametrize("optk", ["sgd", "adagrad"])
+def test_pointwise_mse_loss_with_sigmoid_trains_on_the_fused_path(optk):
+    """PointwiseMSELoss(sigmoid=True) (modules/pointwise_mse_loss.py:24-25) over the three lookups of wrmf.py:23-25: the same fused
+    kernel as WRMF with the prediction through a sigmoid (ORX_POINT_SIGMOID), against the oracle"""
+    from openrec_amd.tf2.compat import tf, optimizers
+    from openrec_amd.tf2.modules import LatentFactor, PointwiseMSELoss
+    from oracle import numpy_oracle as orc
+    NU, NI, D, B = 300, 400, 32, 512
+    Uf, Vf, bf = LatentFactor(NU, D, name="u"), LatentFactor(NI, D, name="v"), LatentFactor(NI, 1, name="b")
+    U, V, b = (f.variables[0].numpy() for f in (Uf, Vf, bf))
+    opt, oo = {"sgd": (optimizers.SGD(0.05), orc.SGD(0.05)), "adagrad": (optimizers.Adagrad(0.05), orc.Adagrad(0.05))}[optk]
+    vars_ = Uf.variables + Vf.variables + bf.variables
+    rng = np.random.default_rng(2)
+    loss_mod = PointwiseMSELoss(a=2.0, b=0.5, sigmoid=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for it in range(4):
+            u, i = rng.integers(0, NU, B).astype(np.int32), rng.integers(0, NI, B).astype(np.int32)
+            u[:7] = 3; i[5:11] = 9                                             # duplicates
+            y = (rng.random(B) < 0.4).astype(np.float32)
+            with tf.GradientTape() as tape:
+                uv, iv = Uf(u), Vf(i)
+                loss = loss_mod(uv, iv, bf(i), y)
+                l2 = tf.nn.l2_loss(uv) + tf.nn.l2_loss(iv)
+            opt.apply_gradients(zip(tape.gradient((loss, l2), vars_), vars_))
+            want, _, _ = orc.wrmf_forward(U, V, b, u, i, y, 2.0, 0.5, sigmoid=True)
+            gr = orc.wrmf_grads(U, V, b, u, i, y, 2.0, 0.5, sigmoid=True)
+            if hasattr(oo, "begin_step"):
+                oo.begin_step()
+            oo.apply(U, u, gr["gu"], key="U"); oo.apply(V, i, gr["gi"], key="V"); oo.apply(b, i, gr["gb"][:, None], key="b")
+            assert abs(float(loss) - float(want)) <= TOL * abs(float(want)), it
+    assert rel_err(Uf.variables[0].numpy(), U) < TOL and rel_err(Vf.variables[0].numpy(), V) < TOL and rel_err(bf.variables[0].numpy(), b) < TOL
 
 
 def test_a_lookup_made_before_a_step_holds_the_pre_step_rows_and_a_scaled_l2_term_is_refused():
@@ -287,3 +323,77 @@ def test_a_lookup_made_before_a_step_holds_the_pre_step_rows_and_a_scaled_l2_ter
     want_mixed = 0.5 * 0.5 * float((U1[u].astype(np.float64) ** 2).sum()) + 0.25 * 0.5 * float((V1[p].astype(np.float64) ** 2).sum())
     assert float(mixed) == pytest.approx(want_mixed, rel=1e-5)
     assert mixed.resolve() is None
+
+
+@pytest.mark.parametrize("optk,loss_func,compat", [("sgd", "mse", True), ("sgd", "bce", False), ("adagrad", "mse", False), ("adam", "bce", False)])
+def test_reference_dlrm_class_text_trains_on_the_fused_path(optk, loss_func, compat):
+    """recommenders/dlrm.py of the reference, executed as it stands: its `call` composes LatentFactor lookups, the bottom MLP,
+    SecondOrderFeatureInteraction, tf.concat, the top MLP, [tf.clip_by_value,] tf.reshape and a keras loss object
+    (dlrm.py:76-100, :63-74).  The loss object recognises the tree and the model trains through `orx_dlrm_step` -- the modules'
+    tables become that step's parameters -- and gives the oracle's parameters, not a host forward without gradients."""
+    from openrec_amd.tf2.compat import optimizers
+    from openrec_amd.tf2.modules import SecondOrderFeatureInteraction
+    from openrec_amd.tf2.modules._compose import _models, _RowRangeTable
+    from oracle import numpy_oracle as orc
+    from oracle.dlrm_oracle import DLRMOracle
+    from dlrm_util import draw_batch, round_to_fp32
+    DLRM = _ref_class("dlrm.py", "DLRM")
+    cfg = dict(m_spa=16, ln_emb=[50, 7, 300, 3], ln_bot=[32, 16], ln_top=[64, 32, 1])
+    model = DLRM(loss_func=loss_func, loss_threshold=0.0 if loss_func == "mse" else 0.01, **cfg)
+    if not compat:      # (the module's own switch: the evidently intended interaction instead of the reference's all-zero one, SURVEY.md E.1)
+        model._dot_interaction = SecondOrderFeatureInteraction(self_interaction=False, reference_compat=False)
+    rng = np.random.default_rng(11)
+    B = 256
+    d0 = np.log1p(rng.integers(0, 100, (B, 13))).astype(np.float32)
+    s0 = np.stack([rng.integers(0, n, B) for n in cfg["ln_emb"]], 1).astype(np.int32)
+    y0 = (rng.random(B) < 0.3).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        first = float(model(d0, s0, y0))                                  # forward only: the composition is recognised and bound
+        assert len(model._latent_factors[0]._composed) == 1
+        assert all(isinstance(f.table, _RowRangeTable) for f in model._latent_factors)
+        names = [v.name for v in model.trainable_variables]
+        assert len(names) == 4 + 2 * (2 + 3)                              # four embedding tables, kernel + bias of five Dense layers
+        # the oracle starts from the model's own parameters
+        o = DLRMOracle(dtype=np.float64, seed=1, reference_compat=compat, loss_func=loss_func,
+                       loss_threshold=0.0 if loss_func == "mse" else 0.01, dense_dim=13, **cfg)
+        for f, lf in enumerate(model._latent_factors):
+            o.emb[f] = lf.variables[0].numpy().astype(np.float64)
+        for layers, mlp in ((o.bot, model._mlp_bot), (o.top, model._mlp_top)):
+            for l, layer in enumerate(mlp.layers):
+                layers[l][0] = layer.kernel.read().astype(np.float64); layers[l][1] = layer.bias.read().reshape(-1).astype(np.float64)
+        assert first == pytest.approx(float(o.loss_and_grads(d0, s0, y0)[0]), rel=1e-5)
+        opt, oo = {"sgd": (optimizers.SGD(0.05), orc.SGD(0.05)), "adagrad": (optimizers.Adagrad(0.05), orc.Adagrad(0.05)),
+                   "adam": (optimizers.Adam(0.002), orc.AdamTFSparse(0.002))}[optk]
+        step = _train_step(model, opt)
+        got, want = [], []
+        for it in range(4):
+            de, sp, la = draw_batch(o, rng, B, cfg["ln_emb"])              # (away from the network's relu ties: tests/dlrm_util.py)
+            got.append(step(de, sp, la))
+            want.append(float(o.step(de, sp, la, oo)))
+        pred = model.inference(d0, s0)                                    # dlrm.py:76-100 again, outside a tape: orx_dlrm_inference
+        assert np.asarray(pred).shape == (B,)
+    assert len(model._latent_factors[0]._composed) == 1                   # one fused model for all of it
+    tol = TOL_ADAM if optk == "adam" else 2e-5
+    assert np.allclose([float(g) for g in got], want, rtol=2e-5)
+    for f, lf in enumerate(model._latent_factors):
+        assert rel_err(lf.variables[0].numpy(), o.emb[f]) < tol, f
+    for layers, mlp in ((o.bot, model._mlp_bot), (o.top, model._mlp_top)):
+        for l, layer in enumerate(mlp.layers):
+            assert rel_err(layer.kernel.read(), layers[l][0]) < tol and rel_err(layer.bias.read().reshape(-1), layers[l][1]) < tol, l
+    assert np.allclose(np.asarray(pred), np.asarray(o.forward(d0, s0)["pred"]).reshape(-1), rtol=1e-4, atol=1e-6)
+
+
+def test_an_unrecognised_composition_under_a_tape_raises_instead_of_training_nothing():
+    """A tree of modules that is none of the reference's compositions has no device path; under a GradientTape its host
+    evaluation raises (it has no gradients) -- outside a tape it is just the values."""
+    from openrec_amd.tf2.compat import tf
+    from openrec_amd.tf2.modules import LatentFactor, MLP
+    lf = LatentFactor(40, 8, name="x")
+    mlp = MLP([4, 1])
+    ids = np.arange(10, dtype=np.int32)
+    out = mlp(lf(ids) * lf(ids))                                          # (not gmf.py:28: two layers, bias)
+    assert np.asarray(out).shape == (10, 1)                               # values, on the host
+    with tf.GradientTape():
+        with pytest.raises(NotImplementedError, match="not one of the compositions"):
+            float(tf.reduce_sum(mlp(lf(ids) * lf(ids))))
