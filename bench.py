@@ -385,7 +385,46 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         eng.check()
-        prof = eng.prof()
+        # ---- diagnosis of the sharded step (after the timed region): the same K steps again with dispatch-attached events on the
+        # kernels and HIP events around every exchange, and what a link delivers to the engine's own ncclSend / ncclRecv groups
+        sharded_extra = {}
+        try:
+            ping = eng.comm_ping(32 << 20, 5)              # (first: connections are up before anything is timed)
+            eng.be.ctx.prof_reset(); eng.be.ctx.prof_enable(True)
+            eng.comm_stats_start()
+            tq0 = time.perf_counter()
+            eng.steps(uid[W:W + K], pid[W:W + K], nid[W:W + K])
+            torch.cuda.synchronize()
+            tq = time.perf_counter() - tq0
+            st = eng.comm_stats_stop()
+            eng.be.ctx.prof_enable(False)
+            prof = eng.prof()
+            ovf = int(eng._ovf.item()) if eng._ovf is not None else 0
+            ker = {k: v for k, v in prof.items() if v.get("launches")}
+            ker_ms = sum(v["total_ms"] for v in ker.values())
+            bpt_alg = alg_bytes_per_triplet(args.dim, args.opt, args.model)
+            sharded_extra["phases_us"] = {
+                **{"kernels:" + k: v["total_ms"] / K * 1e3 for k, v in ker.items()},
+                "exchanges": (st["exchange_ms"] / K * 1e3) if st else None,
+                "step_profiled": tq / K * 1e6}
+            if ker_ms > 0:
+                # per rank: the rows of its B triplets are read and written once somewhere in the job -- the single-GPU step's algorithmic
+                # bytes -- against the time of this rank's kernels (gathers, gradient kernels, applies; the exchanges are not HBM work)
+                ach = args.batch * bpt_alg * K / (ker_ms * 1e-3) / 1e9
+                sharded_extra["roofline"] = {"bound": "hbm", "kernel": "this rank's gather / gradient / apply kernels of the sharded step",
+                                             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                             "bytes_per_triplet": bpt_alg, "kernel_us_per_step": ker_ms / K * 1e3}
+            if st:
+                sharded_extra["link_GBps"] = {
+                    "ping_out_all_links": ping["GBps_out"] if ping else None, "ping_per_link": ping["GBps_per_link"] if ping else None,
+                    "ping_us_per_all_to_all_of_32MiB": ping["us_per_all_to_all"] if ping else None,
+                    "in_step_out_all_links": (st["wire_bytes"] / (st["exchange_ms"] * 1e-3) / 1e9) if st["exchange_ms"] > 0 else None,
+                    "wire_bytes_per_step": st["wire_bytes"] / K, "self_bytes_per_step": st["self_bytes"] / K,
+                    "exchanges_per_step": st["exchanges"] / K}
+            sharded_extra["overflow"] = ovf
+        except Exception as e:                              # the diagnosis must never hide the number
+            sharded_extra["diagnosis_error"] = repr(e)
+            prof = eng.prof()
         losses = None
         parallelism = f"row-sharded x{world}, all-to-all"
 
@@ -437,6 +476,8 @@ def main():
                                "bytes_per_triplet": bpt, "kernel_us": dur * 1e6,
                                "other_kernels_us": {k: v["total_ms"] / v["launches"] * 1e3
                                                     for k, v in prof.items() if v.get("launches") and k not in ("fused", "pointwise")}}
+        if world > 1 or args.sharded:
+            out.update(sharded_extra)
         if losses is not None:
             out["loss_first_last"] = [float(losses[0][0]), float(losses[0][-1])]
         headline = (args.model, args.dim, args.users, args.items, args.batch, args.opt, args.zipf, args.hogwild, args.host_ids, args.censor) == \

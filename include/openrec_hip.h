@@ -443,6 +443,17 @@ int orx_vgroup_destroy(orx_vgroup* group);
 int orx_comm_create_virtual(orx_ctx* ctx, orx_vgroup* group, int32_t rank, orx_comm** out);
 int orx_comm_rank(orx_comm* comm);
 int orx_comm_world(orx_comm* comm);
+/* Measurement of the exchanges (bench.py --gpus N: phases_us / link_GBps).
+ *   orx_comm_stats(comm, 1, NULL): start counting, counters at zero (HIP events around every exchange from now on);
+ *   orx_comm_stats(comm, 0, out) : stop; out[0] = exchanges, out[1] = bytes this rank SENT to other ranks, out[2] = their device
+ *                                  time in ms (sum over the exchanges, each timed on the stream it ran on), out[3] = bytes of the
+ *                                  rank's own blocks (device copies, not on the wire).
+ *   orx_comm_ping(comm, bytes, reps, out): `reps` all-to-alls of `bytes` per peer (ncclSend / ncclRecv to every other rank at once,
+ *                                  as the engine's exchanges do) on fresh buffers; out[0] = GB/s this rank sent (all links together),
+ *                                  out[1] = GB/s per link, out[2] = microseconds per all-to-all.  Collective: every rank calls it.
+ *                                  A one-rank communicator measures the device copy of its own block. */
+int orx_comm_stats(orx_comm* comm, int start, double* out4);
+int orx_comm_ping(orx_comm* comm, int64_t bytes, int32_t reps, double* out3);
 int orx_sharded_caps(int64_t B, int32_t world, float slack, int64_t* cap1, int64_t* cap2);
 /* the regrouping the engine applies around the plan's exchanges: src [K][world][words] -> dst [world][K][words] 4-byte words
  * (back != 0: the inverse); device pointers */

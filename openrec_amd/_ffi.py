@@ -102,6 +102,8 @@ SIGNATURES = {
     "orx_comm_create_virtual": (c_int, [_p, _p, c_int32, _pp]),
     "orx_comm_rank": (c_int, [_p]),
     "orx_comm_world": (c_int, [_p]),
+    "orx_comm_stats": (c_int, [_p, c_int, _p]),
+    "orx_comm_ping": (c_int, [_p, c_int64, c_int32, _p]),
     "orx_sharded_caps": (c_int, [c_int64, c_int32, c_float, _p, _p]),
     "orx_shard_regroup": (c_int, [_p, _p, _p, c_int64, c_int32, c_int64, c_int]),
     "orx_sharded_pairwise_steps": (c_int, [_p, _p, c_int, _p, _p, _p, _ip, _ip, _ip, c_int64, c_int64, c_int64, c_int64, c_int64,

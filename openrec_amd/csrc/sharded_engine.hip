@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <condition_variable>
 #include <mutex>
+#include <vector>
+#include <utility>
 
 #define CHECK(call) do { const int rc_ = (call); if (rc_ != ORX_OK) return rc_; } while (0)
 
@@ -96,6 +98,9 @@ struct orx_comm {
     int rank = 0, world = 1;
     hipStream_t xstream = nullptr;                       // the exchanges of the overlapped path run here, beside the kernels
     hipEvent_t ev[8] = {};
+    // orx_comm_stats: counters of the exchanges, (start, stop) event pairs awaiting collection
+    bool stats_on = false; double st_exchanges = 0, st_wire = 0, st_self = 0, st_ms = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> st_ev;
     // the engine's exchange buffers (grown on demand, kept between calls)
     Buf send1, mine, tmp, cnt, send2, req, req_loc, slot, u_loc, fu, fv, rows_out, rows_in, gu, u_apply, send_g, g_in, dupref, dsorted, seglist, segcount, gdup, bias_x;
 };
@@ -107,6 +112,64 @@ static int ensure(orx_comm* c, Buf& b, size_t bytes) {
     if (hipMalloc(&b.p, want) != hipSuccess) { orx_set_error("sharded engine: out of device memory (%zu bytes)", want); return ORX_ERR_OOM; }
     b.cap = want;
     return ORX_OK;
+}
+
+static int exchange(orx_comm* c, const void* send, void* recv, size_t bytes, const void** result, hipStream_t stream = nullptr,
+                    const void* send2 = nullptr, void* recv2 = nullptr, size_t bytes2 = 0, const void** result2 = nullptr);
+
+extern "C" int orx_comm_stats(orx_comm* c, int start, double* out4) {
+    ORX_ARG(c, "orx_comm_stats: NULL communicator");
+    ORX_HIP(hipSetDevice(c->ctx->device));
+    if (start) {
+        for (auto& p : c->st_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+        c->st_ev.clear();
+        c->st_exchanges = c->st_wire = c->st_self = c->st_ms = 0;
+        c->stats_on = true;
+        return ORX_OK;
+    }
+    c->stats_on = false;
+    ORX_HIP(hipStreamSynchronize(c->ctx->stream));
+    if (c->xstream) ORX_HIP(hipStreamSynchronize(c->xstream));
+    for (auto& p : c->st_ev) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) c->st_ms += ms;
+        hipEventDestroy(p.first); hipEventDestroy(p.second);
+    }
+    c->st_ev.clear();
+    if (out4) { out4[0] = c->st_exchanges; out4[1] = c->st_wire; out4[2] = c->st_ms; out4[3] = c->st_self; }
+    return ORX_OK;
+}
+
+extern "C" int orx_comm_ping(orx_comm* c, int64_t bytes, int32_t reps, double* out3) {
+    ORX_ARG(c && out3 && bytes > 0 && reps > 0, "orx_comm_ping: bad arguments");
+    ORX_ARG(!c->vg, "orx_comm_ping: a virtual group has no wire");
+    ORX_HIP(hipSetDevice(c->ctx->device));
+    const int N = c->world;
+    void *sbuf = nullptr, *rbuf = nullptr;
+    ORX_HIP(hipMalloc(&sbuf, (size_t)bytes * N)); 
+    if (hipMalloc(&rbuf, (size_t)bytes * N) != hipSuccess) { hipFree(sbuf); orx_set_error("orx_comm_ping: out of device memory"); return ORX_ERR_OOM; }
+    hipMemsetAsync(sbuf, 1, (size_t)bytes * N, c->ctx->stream);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const void* res = nullptr;
+    const bool was_on = c->stats_on; c->stats_on = false;
+    int rc = exchange(c, sbuf, rbuf, (size_t)bytes, &res, nullptr, nullptr, nullptr, 0, nullptr);              // warm-up (connections are set up on first use)
+    if (rc == ORX_OK) {
+        hipEventRecord(e0, c->ctx->stream);
+        for (int r = 0; r < reps && rc == ORX_OK; ++r) rc = exchange(c, sbuf, rbuf, (size_t)bytes, &res, nullptr, nullptr, nullptr, 0, nullptr);
+        hipEventRecord(e1, c->ctx->stream);
+        hipStreamSynchronize(c->ctx->stream);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double sec = (double)ms * 1e-3, links = N > 1 ? N - 1 : 1;
+        out3[0] = sec > 0 ? (double)bytes * links * reps / sec / 1e9 : 0.0;
+        out3[1] = out3[0] / links;
+        out3[2] = (double)ms * 1e3 / reps;
+    }
+    c->stats_on = was_on;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(sbuf); hipFree(rbuf);
+    return rc;
 }
 
 extern "C" int orx_comm_unique_id(void* id_out) {
@@ -198,8 +261,8 @@ static int copy_block(const void* src, void* dst, size_t bytes, hipStream_t stre
 // all-to-all of equal blocks: peer p gets send[p * bytes .. ), its block lands in recv[p * bytes .. ); optionally a second,
 // smaller block per peer in the same group (the biases beside the rows).  `result` / `result2`: where the data is afterwards --
 // `recv`, or `send` itself for a one-rank communicator without RCCL.
-static int exchange(orx_comm* c, const void* send, void* recv, size_t bytes, const void** result, hipStream_t stream = nullptr,
-                    const void* send2 = nullptr, void* recv2 = nullptr, size_t bytes2 = 0, const void** result2 = nullptr) {
+static int exchange(orx_comm* c, const void* send, void* recv, size_t bytes, const void** result, hipStream_t stream,
+                    const void* send2, void* recv2, size_t bytes2, const void** result2) {
     if (!stream) stream = c->ctx->stream;
     *result = recv;
     if (result2) *result2 = recv2;
@@ -218,6 +281,21 @@ static int exchange(orx_comm* c, const void* send, void* recv, size_t bytes, con
         return ORX_OK;
     }
     if (!c->comm) { *result = send; if (result2) *result2 = send2; return ORX_OK; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->stats_on) {
+        ORX_HIP(hipEventCreate(&e0)); ORX_HIP(hipEventCreate(&e1));
+        ORX_HIP(hipEventRecord(e0, stream));
+        c->st_exchanges += 1;
+        static const bool self_on_wire = getenv("ORX_SHARD_RCCL_SELF") && atoi(getenv("ORX_SHARD_RCCL_SELF")) != 0;
+        for (int q = 0; q < nblk; ++q) {                // (the rank's own block is a device copy unless ORX_SHARD_RCCL_SELF sends it through RCCL too)
+            c->st_wire += (double)bv[q] * (c->world - 1 + (self_on_wire ? 1 : 0));
+            c->st_self += self_on_wire ? 0.0 : (double)bv[q];
+        }
+    }
+    struct Stop {                       // the stop event goes behind whatever this call put on the stream, on every way out
+        orx_comm* c; hipEvent_t e0, e1; hipStream_t s;
+        ~Stop() { if (e0) { hipEventRecord(e1, s); c->st_ev.emplace_back(e0, e1); } }
+    } stop{c, e0, e1, stream};
     // this rank's own block is a copy kernel (RCCL's send-to-self kernel moved 18 MB in 25 us; hipMemcpyAsync cost ~100 us of runtime
     // bookkeeping per call); ORX_SHARD_RCCL_SELF=1 sends it through RCCL like any other (what the one-rank test uses to exercise
     // ncclSend / ncclRecv)

@@ -7,6 +7,8 @@ import ctypes
 import weakref
 from ctypes import byref, c_double, c_int64, c_void_p
 
+import os
+
 import numpy as np
 
 from . import _ffi
@@ -220,6 +222,16 @@ class Optimizer:
     def set_slot(self, table, values, slot=0):
         a = np.ascontiguousarray(values, np.float32).reshape(table.rows, table.dim)
         check(self._lib.orx_opt_slot_write(self._h, table._h, slot, 0, table.rows, a.ctypes.data))
+
+    def slot_rows(self, table, slot, row0, nrows):
+        """rows [row0, row0 + nrows) of an optimizer slot of `table` (checkpoints stream slots in row ranges)"""
+        out = np.empty((nrows, table.dim), np.float32)
+        check(self._lib.orx_opt_slot_read(self._h, table._h, int(slot), int(row0), int(nrows), out.ctypes.data))
+        return out
+
+    def set_slot_rows(self, table, values, slot, row0):
+        a = np.ascontiguousarray(values, np.float32).reshape(-1, table.dim)
+        check(self._lib.orx_opt_slot_write(self._h, table._h, int(slot), int(row0), a.shape[0], a.ctypes.data))
 
 
 def pairwise_step(model, opt, user, item, bias, uid, pid, nid, K=1, B=None, id_stride=None,
@@ -574,33 +586,106 @@ def rank_metrics_csr(pos, excl, at, pred=None, kind=None, user=None, item=None, 
     return dict(auc=auc, ndcg=ndcg, recall=rec)
 
 
-def save_checkpoint(path, tables, opt=None):
-    """Tables (and the optimizer's slots for them) -> one .npz.  The tf2 reference has no
-    checkpointing (`save_interval` is unused, tf2_examples/bpr_citeulike.py:16); tf1 used
-    tf.train.Saver (tf1/recommenders/recommender.py:430-473).  `tables`: {name: Table}."""
-    out = {}
+CKPT_PIECE_BYTES = 256 << 20          # tables and slots move through the host in pieces of at most this many bytes
+
+
+def _stream_rows(read, rows, dim, dst):
+    """rows [0, rows) through `read(row0, n) -> [n, dim]` into the (memory-mapped) array `dst`, CKPT_PIECE_BYTES at a time"""
+    step = max(1, CKPT_PIECE_BYTES // max(1, 4 * dim))
+    for r0 in range(0, rows, step):
+        n = min(step, rows - r0)
+        dst[r0:r0 + n] = read(r0, n)
+
+
+def save_checkpoint(path, tables, opt=None, shard=None):
+    """Tables (and the optimizer's slots for them) -> a checkpoint.  The tf2 reference has no checkpointing (`save_interval` is
+    unused, tf2_examples/bpr_citeulike.py:16); tf1 used tf.train.Saver (tf1/recommenders/recommender.py:430-473).
+    `tables`: {name: Table}.
+
+    `path` ending in ".npz": ONE file, every tensor whole in host memory on the way (small models, the round-1 format).
+    Otherwise `path` is a DIRECTORY: one .npy per tensor -- `table.<name>.npy`, `slot0.<name>.npy`, `slot1.<name>.npy` -- written
+    through a memory map in row ranges of at most CKPT_PIECE_BYTES (a 10 M x 128 table never sits in host memory whole), and
+    `manifest.json` (shapes, optimizer kind and step counter).  `shard=(rank, world)`: this rank's files get the suffix
+    `.rank<r>of<w>` and the manifest records the sharding (row r of the global table = local row r // world of rank r % world,
+    SURVEY.md 8(e)): every rank of a row-sharded job saves its own shard into the same directory."""
+    import json
+    if str(path).endswith(".npz"):
+        out = {}
+        for name, t in tables.items():
+            out["table/" + name] = t.read()
+            if opt is not None and opt.kind in ("adagrad", "adam"):
+                out["slot0/" + name] = opt.slot(t, 0)
+                if opt.kind == "adam":
+                    out["slot1/" + name] = opt.slot(t, 1)
+        if opt is not None:
+            out["opt/kind"] = np.array(opt.kind)
+            out["opt/step"] = np.array(opt.step, np.int64)          # Adam's bias correction resumes where it stopped
+        np.savez(path, **out)
+        return
+    os.makedirs(path, exist_ok=True)
+    suffix = "" if shard is None else ".rank%dof%d" % (int(shard[0]), int(shard[1]))
+    man = dict(format="openrec_amd-ckpt-1", tensors={}, shard=None if shard is None else dict(rank=int(shard[0]), world=int(shard[1])))
+    nslots = 0 if opt is None else {"sgd": 0, "adagrad": 1, "adam": 2}[opt.kind]
     for name, t in tables.items():
-        out["table/" + name] = t.read()
-        if opt is not None and opt.kind in ("adagrad", "adam"):
-            out["slot0/" + name] = opt.slot(t, 0)
-            if opt.kind == "adam":
-                out["slot1/" + name] = opt.slot(t, 1)
+        if hasattr(t, "_sync_pending"):
+            t._sync_pending()
+        man["tensors"][name] = dict(rows=t.rows, dim=t.dim, slots=nslots)
+        mm = np.lib.format.open_memmap(os.path.join(path, f"table.{name}{suffix}.npy"), mode="w+", dtype=np.float32, shape=(t.rows, t.dim))
+        _stream_rows(t.read, t.rows, t.dim, mm)
+        mm.flush(); del mm
+        for k in range(nslots):
+            mm = np.lib.format.open_memmap(os.path.join(path, f"slot{k}.{name}{suffix}.npy"), mode="w+", dtype=np.float32, shape=(t.rows, t.dim))
+            _stream_rows(lambda r0, n, k=k: opt.slot_rows(t, k, r0, n), t.rows, t.dim, mm)
+            mm.flush(); del mm
     if opt is not None:
-        out["opt/kind"] = np.array(opt.kind)
-        out["opt/step"] = np.array(opt.step, np.int64)          # Adam's bias correction resumes where it stopped
-    np.savez(path, **out)
+        man["opt"] = dict(kind=opt.kind, step=int(opt.step))
+    with open(os.path.join(path, f"manifest{suffix}.json"), "w") as f:
+        json.dump(man, f, indent=1)
 
 
-def load_checkpoint(path, tables, opt=None):
-    z = np.load(path)
+def load_checkpoint(path, tables, opt=None, shard=None):
+    """the inverse of save_checkpoint (same `path` / `shard` conventions); shapes and the optimizer kind are checked"""
+    import json
+    if str(path).endswith(".npz"):
+        z = np.load(path)
+        for name, t in tables.items():
+            t.write(z["table/" + name])
+            if opt is not None and ("slot0/" + name) in z:
+                opt.set_slot(t, z["slot0/" + name], 0)
+                if ("slot1/" + name) in z:
+                    opt.set_slot(t, z["slot1/" + name], 1)
+        if opt is not None and "opt/step" in z:
+            opt.step = int(z["opt/step"])
+        return
+    suffix = "" if shard is None else ".rank%dof%d" % (int(shard[0]), int(shard[1]))
+    with open(os.path.join(path, f"manifest{suffix}.json")) as f:
+        man = json.load(f)
+    if man.get("format") != "openrec_amd-ckpt-1":
+        raise ValueError(f"{path}: not an openrec_amd checkpoint directory")
+    want_shard = None if shard is None else dict(rank=int(shard[0]), world=int(shard[1]))
+    if man.get("shard") != want_shard:
+        raise ValueError(f"{path}: saved with shard={man.get('shard')}, asked for {want_shard}")
+    if opt is not None and "opt" in man and man["opt"]["kind"] != opt.kind:
+        raise ValueError(f"{path}: saved with a {man['opt']['kind']} optimizer, loading into {opt.kind}")
     for name, t in tables.items():
-        t.write(z["table/" + name])
-        if opt is not None and ("slot0/" + name) in z:
-            opt.set_slot(t, z["slot0/" + name], 0)
-            if ("slot1/" + name) in z:
-                opt.set_slot(t, z["slot1/" + name], 1)
-    if opt is not None and "opt/step" in z:
-        opt.step = int(z["opt/step"])
+        info = man["tensors"].get(name)
+        if info is None:
+            raise KeyError(f"{path}: no tensor named {name!r}")
+        if (info["rows"], info["dim"]) != (t.rows, t.dim):
+            raise ValueError(f"{path}: {name} is [{info['rows']}, {info['dim']}], the table [{t.rows}, {t.dim}]")
+        step = max(1, CKPT_PIECE_BYTES // max(1, 4 * t.dim))
+        mm = np.load(os.path.join(path, f"table.{name}{suffix}.npy"), mmap_mode="r")
+        for r0 in range(0, t.rows, step):
+            t.write(np.ascontiguousarray(mm[r0:r0 + step]), r0)
+        del mm
+        if opt is not None:
+            for k in range(min(info["slots"], {"sgd": 0, "adagrad": 1, "adam": 2}[opt.kind])):
+                mm = np.load(os.path.join(path, f"slot{k}.{name}{suffix}.npy"), mmap_mode="r")
+                for r0 in range(0, t.rows, step):
+                    opt.set_slot_rows(t, np.ascontiguousarray(mm[r0:r0 + step]), k, r0)
+                del mm
+    if opt is not None and "opt" in man:
+        opt.step = int(man["opt"]["step"])
 
 
 class DeviceSampler:

@@ -93,6 +93,15 @@ class HipBackend:
         if self.opt_kind == "adam":
             self.opt.advance()           # (the engine's optimizer holds only the engine's tables)
 
+    # checkpoints of this rank's shards: runtime.save_checkpoint's directory format, one set of files per rank
+    def save_tables(self, path, tables, shard):
+        self.stream.synchronize()
+        self.rt.save_checkpoint(path, tables, self.opt, shard=shard)
+
+    def load_tables(self, path, tables, shard):
+        self.stream.synchronize()
+        self.rt.load_checkpoint(path, tables, self.opt, shard=shard)
+
     def make_table(self, rows, dim, seed):
         return self.rt.Table(max(rows, 1), dim, self.ctx).init_uniform(seed=seed)
 
@@ -377,6 +386,48 @@ class ShardedPairwise:
         g_in = self._a2a(f["send_g"], f["g_in"])                                   # 6. item-row gradients -> owners
         be.apply_rows(self.V, self.b, f["req_loc"], g_in)
         return None
+
+    # ---- checkpoints: every rank writes / reads its own shard (row r of a table = local row r // world of rank r % world) ----
+    def save(self, path):
+        """this rank's shards of the three tables (and their optimizer slots, the Adam step counter) into directory `path`
+        (runtime.save_checkpoint: one .npy per tensor, streamed in row ranges; files carry `.rank<r>of<w>`).  Collective when
+        world > 1: returns once every rank has written."""
+        self.check()
+        self.be.save_tables(path, dict(U=self.U, V=self.V, b=self.b), (self.rank, self.world))
+        if self.world > 1 and dist.is_initialized():
+            dist.barrier(group=self.group)
+
+    def load(self, path):
+        """the inverse of save(): same world size and rank layout"""
+        self.be.load_tables(path, dict(U=self.U, V=self.V, b=self.b), (self.rank, self.world))
+        if self.world > 1 and dist.is_initialized():
+            dist.barrier(group=self.group)
+
+    # ---- measurement of the library engine's exchanges (bench.py --gpus N) ----
+    def comm_stats_start(self):
+        """count the exchanges from here on (bytes on the wire, device time)"""
+        if self._library_engine():
+            self.be._ffi.check(self.be.lib.orx_comm_stats(self._comm, 1, None))
+
+    def comm_stats_stop(self):
+        """-> dict(exchanges, wire_bytes, exchange_ms, self_bytes) since comm_stats_start, or None without the library engine"""
+        import ctypes
+        if not self._library_engine():
+            return None
+        out = (ctypes.c_double * 4)()
+        self.be._ffi.check(self.be.lib.orx_comm_stats(self._comm, 0, ctypes.cast(out, ctypes.c_void_p)))
+        return dict(exchanges=int(out[0]), wire_bytes=float(out[1]), exchange_ms=float(out[2]), self_bytes=float(out[3]))
+
+    def comm_ping(self, nbytes=32 << 20, reps=5):
+        """all-to-all of `nbytes` per peer through the engine's own exchange (ncclSend / ncclRecv groups): what a link delivers
+        -> dict(GBps_out, GBps_per_link, us_per_all_to_all); collective (every rank calls it)"""
+        import ctypes
+        if not self._library_engine():
+            return None
+        out = (ctypes.c_double * 3)()
+        with self.be.stream_ctx():
+            self.be._ffi.check(self.be.lib.orx_comm_ping(self._comm, int(nbytes), int(reps), ctypes.cast(out, ctypes.c_void_p)))
+        return dict(GBps_out=float(out[0]), GBps_per_link=float(out[1]), us_per_all_to_all=float(out[2]))
 
     def steps(self, uid, pid, nid, plan_chunk=64, overlap=None):
         """K steps: uid/pid/nid int32 [K, B] on self.device.  The exchange PLAN of a step (which triplet goes

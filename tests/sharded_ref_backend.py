@@ -25,6 +25,30 @@ class OracleBackend:
     def make_table(self, rows, dim, seed):
         return Tab(max(rows, 1), dim)
 
+    # checkpoint hooks of ShardedPairwise.save / load: this rank's tables and the oracle optimizer's state for them
+    def save_tables(self, path, tables, shard):
+        import os, pickle
+        os.makedirs(path, exist_ok=True)
+        state = {k: {n: (v.get(id(t)) if isinstance(v, dict) else None) for n, t in tables.items()}
+                 for k, v in vars(self.opt).items() if isinstance(v, dict)}
+        scal = {k: v for k, v in vars(self.opt).items() if not isinstance(v, dict)}
+        with open(os.path.join(path, "ref.rank%dof%d.pkl" % shard), "wb") as f:
+            pickle.dump(dict(tables={n: t.w for n, t in tables.items()}, state=state, scal=scal), f)
+
+    def load_tables(self, path, tables, shard):
+        import os, pickle
+        with open(os.path.join(path, "ref.rank%dof%d.pkl" % shard), "rb") as f:
+            z = pickle.load(f)
+        for n, t in tables.items():
+            t.w[:] = z["tables"][n]
+        for k, per in z["state"].items():
+            d = getattr(self.opt, k)
+            for n, t in tables.items():
+                if per[n] is not None:
+                    d[id(t)] = per[n]
+        for k, v in z["scal"].items():
+            setattr(self.opt, k, v)
+
     def gather_rows(self, table, bias, ids, out):
         i = ids.numpy()
         o = out.numpy()

@@ -1,6 +1,8 @@
 """The reference's Python surface on the GPU: a train step written exactly like
 tf2_examples/bpr_citeulike.py:33-39 (tape + apply_gradients) must give the
 oracle's result, executed as one fused device call."""
+import os
+
 import numpy as np
 import pytest
 
@@ -114,18 +116,27 @@ def test_example_script_trains_end_to_end():
     assert len(hist) == 3 and abs(hist[0] - 0.5) < 0.05 and hist[-1] > hist[0] + 0.05, hist
 
 
-def test_checkpoint_roundtrip_resumes(tmp_path):
+@pytest.mark.parametrize("fmt", ["ck.npz", "ckdir"])
+def test_checkpoint_roundtrip_resumes(tmp_path, fmt, monkeypatch):
     from openrec_amd import runtime as rt
+    monkeypatch.setattr(rt, "CKPT_PIECE_BYTES", 37 * 64 * 4)          # the directory format streams in row ranges: many ragged pieces
     rng = np.random.default_rng(0)
     mk = lambda: (rt.Table(300, 64).init_uniform(seed=1), rt.Table(400, 64).init_uniform(seed=2), rt.Table(400, 1).init_uniform(seed=3))
     ids = [rng.integers(0, n, (4, 512)).astype(np.int32) for n in (300, 400, 400)]
     U, V, b = mk(); opt = rt.Optimizer.adagrad(0.05)
     rt.pairwise_step("bpr", opt, U, V, b, ids[0][:2], ids[1][:2], ids[2][:2], K=2, B=512)
-    rt.save_checkpoint(str(tmp_path / "ck.npz"), dict(U=U, V=V, b=b), opt)
+    rt.save_checkpoint(str(tmp_path / fmt), dict(U=U, V=V, b=b), opt)
+    if fmt == "ckdir":
+        assert sorted(os.listdir(tmp_path / fmt)) == ["manifest.json", "slot0.U.npy", "slot0.V.npy", "slot0.b.npy", "table.U.npy", "table.V.npy", "table.b.npy"]
     rt.pairwise_step("bpr", opt, U, V, b, ids[0][2:], ids[1][2:], ids[2][2:], K=2, B=512)
     U2, V2, b2 = mk(); opt2 = rt.Optimizer.adagrad(0.05)
     rt.pairwise_step("bpr", opt2, U2, V2, b2, ids[0][:1], ids[1][:1], ids[2][:1], K=1, B=512)   # allocate slots
-    rt.load_checkpoint(str(tmp_path / "ck.npz"), dict(U=U2, V=V2, b=b2), opt2)
+    rt.load_checkpoint(str(tmp_path / fmt), dict(U=U2, V=V2, b=b2), opt2)
+    if fmt == "ckdir":
+        with pytest.raises(ValueError, match="saved with a adagrad optimizer"):
+            rt.load_checkpoint(str(tmp_path / fmt), dict(U=U2, V=V2, b=b2), rt.Optimizer.adam(0.001))
+        with pytest.raises(ValueError, match=r"U is \[300, 64\]"):
+            rt.load_checkpoint(str(tmp_path / fmt), dict(U=V2), None)
     rt.pairwise_step("bpr", opt2, U2, V2, b2, ids[0][2:], ids[1][2:], ids[2][2:], K=2, B=512)
     # rows referenced >= 3 times in a batch are summed with atomics (order varies run to run): compare to 1e-6
     for x, y in ((U, U2), (V, V2), (b, b2)):
@@ -133,7 +144,8 @@ def test_checkpoint_roundtrip_resumes(tmp_path):
     assert np.abs(opt.slot(V) - opt2.slot(V2)).max() <= 1e-6 * np.abs(opt.slot(V)).max()
 
 
-def test_adam_checkpoint_resumes_with_its_step_counter(tmp_path):
+@pytest.mark.parametrize("fmt", ["ck.npz", "ckdir"])
+def test_adam_checkpoint_resumes_with_its_step_counter(tmp_path, fmt):
     """Adam's bias correction depends on the step counter and (TF 2.0) every row moves every step: a resume from a
     checkpoint taken mid-run (tables, m, v, counter) must continue exactly like the uninterrupted run."""
     from openrec_amd import runtime as rt
@@ -142,11 +154,11 @@ def test_adam_checkpoint_resumes_with_its_step_counter(tmp_path):
     ids = [rng.integers(0, n, (12, 256)).astype(np.int32) for n in (3000, 4000, 4000)]
     U, V, b = mk(); opt = rt.Optimizer.adam(0.002)
     rt.pairwise_step("bpr", opt, U, V, b, ids[0][:6], ids[1][:6], ids[2][:6], K=6, B=256)
-    rt.save_checkpoint(str(tmp_path / "ck.npz"), dict(U=U, V=V, b=b), opt)
+    rt.save_checkpoint(str(tmp_path / fmt), dict(U=U, V=V, b=b), opt)
     assert opt.step == 6
     rt.pairwise_step("bpr", opt, U, V, b, ids[0][6:], ids[1][6:], ids[2][6:], K=6, B=256)
     U2, V2, b2 = mk(); opt2 = rt.Optimizer.adam(0.002)
-    rt.load_checkpoint(str(tmp_path / "ck.npz"), dict(U=U2, V=V2, b=b2), opt2)
+    rt.load_checkpoint(str(tmp_path / fmt), dict(U=U2, V=V2, b=b2), opt2)
     assert opt2.step == 6
     rt.pairwise_step("bpr", opt2, U2, V2, b2, ids[0][6:], ids[1][6:], ids[2][6:], K=6, B=256)
     for x, y in ((U, U2), (V, V2), (b, b2)):

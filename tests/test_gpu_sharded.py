@@ -1,5 +1,7 @@
 """GPU parity of the sharded building blocks (orx_gather_rows / orx_pair_grads /
 orx_apply_rows) and of the whole sharded step at world size 1 against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -184,3 +186,33 @@ def test_gather_apply_rows_adam_is_the_dense_decay_rule(rows, D, n, K):
         oo.begin_step(); oo.apply(W, ids_all[s][live], g_all[s][live].astype(np.float64), key="W")
     assert rel_err(t.read(), W) < 2e-5
     assert rel_err(opt.slot(t, 0), oo.m["W"]) < 5e-5 and rel_err(opt.slot(t, 1), oo.v["W"]) < 5e-4
+
+
+@pytest.mark.parametrize("optk", ["sgd", "adagrad", "adam"])
+def test_sharded_engine_checkpoint_resumes(tmp_path, optk):
+    """ShardedPairwise.save / load on the device backend (one rank): tables, optimizer slots and Adam's step counter of the shard
+    go to `table.<name>.rank0of1.npy` ... and a fresh engine that loads them continues like the uninterrupted run."""
+    import torch
+    from openrec_amd import sharded
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(4)
+    NU, NI, D, B, K = 900, 1100, 64, 1024, 6
+    ids = [torch.from_numpy(rng.integers(0, n, (K, B)).astype(np.int32)).to(dev) for n in (NU, NI, NI)]
+    lr = 0.002 if optk == "adam" else 0.05
+
+    def engine():
+        return sharded.ShardedPairwise("bpr", optk, NU, NI, D, lr=lr, rank=0, world=1, device=dev, seed=3)
+    a = engine()
+    a.steps(ids[0][:3], ids[1][:3], ids[2][:3])
+    a.save(str(tmp_path / "ck"))
+    assert "table.U.rank0of1.npy" in os.listdir(tmp_path / "ck") and "manifest.rank0of1.json" in os.listdir(tmp_path / "ck")
+    a.steps(ids[0][3:], ids[1][3:], ids[2][3:])
+    a.check()
+    r = engine()
+    if optk != "sgd":
+        r.steps(ids[0][:1], ids[1][:1], ids[2][:1])          # (slots exist once a step has used them)
+    r.load(str(tmp_path / "ck"))
+    r.steps(ids[0][3:], ids[1][3:], ids[2][3:])
+    r.check()
+    for x, y in ((a.U, r.U), (a.V, r.V), (a.b, r.b)):
+        assert np.abs(x.read() - y.read()).max() <= 1e-6 * np.abs(x.read()).max()

@@ -183,3 +183,46 @@ def test_library_engine_bucket_capacities_equal_the_python_engine():
                 cap = lambda n: int(math.ceil(n / world * slack + 6 * math.sqrt(n / world) + 16))
                 assert c1.value == cap(B), (B, world, slack)
                 assert c2.value == cap(2 * world * cap(B)), (B, world, slack)
+
+
+def _run_rank_ckpt(rank, world, port, optk, out, ckdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sharded_ref_backend import OracleBackend
+    from openrec_amd import sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    U, V, b, steps = _global_case("bpr")
+    per = steps[0][0].shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)
+
+    def engine():
+        e = sharded.ShardedPairwise("bpr", optk, U.shape[0], V.shape[0], U.shape[1], lr=0.05, rank=rank, world=world,
+                                    device=torch.device("cpu"), backend=OracleBackend(optk, 0.05), slack=1.5)
+        e.U.w[:] = U[rank::world]; e.V.w[:] = V[rank::world]; e.b.w[:] = b[rank::world]
+        return e
+    a = engine()
+    for (u, p, n) in steps[:2]:
+        a.step(torch.from_numpy(u[sl].copy()), torch.from_numpy(p[sl].copy()), torch.from_numpy(n[sl].copy()))
+    a.save(ckdir)                                    # every rank writes its own shard into the same directory
+    u, p, n = steps[2]
+    a.step(torch.from_numpy(u[sl].copy()), torch.from_numpy(p[sl].copy()), torch.from_numpy(n[sl].copy()))
+    r = engine()                                     # a fresh engine resumes from the directory
+    r.U.w[:] = 0; r.V.w[:] = 0; r.b.w[:] = 0
+    r.load(ckdir)
+    r.step(torch.from_numpy(u[sl].copy()), torch.from_numpy(p[sl].copy()), torch.from_numpy(n[sl].copy()))
+    np.savez(out % rank, U=a.U.w, V=a.V.w, b=a.b.w, U2=r.U.w, V2=r.V.w, b2=r.b.w)
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("optk", ["sgd", "adagrad", "adam"])
+def test_sharded_checkpoint_resumes_at_world_2(tmp_path, optk):
+    """ShardedPairwise.save / load: every rank writes its shard (tables, optimizer state) into one directory; a fresh engine of the
+    same layout that loads it continues exactly like the uninterrupted run (gloo, two ranks, oracle compute)."""
+    out = str(tmp_path / "c%d.npz")
+    mp.spawn(_run_rank_ckpt, args=(2, _free_port(), optk, out, str(tmp_path / "ck")), nprocs=2, join=True)
+    for r in range(2):
+        g = np.load(out % r)
+        for k in ("U", "V", "b"):
+            assert np.array_equal(g[k], g[k + "2"]), (r, k)
+    assert sorted(f for f in os.listdir(tmp_path / "ck")) == ["ref.rank0of2.pkl", "ref.rank1of2.pkl"]
