@@ -463,6 +463,18 @@ int orx_sharded_pairwise_steps(orx_comm* comm, orx_opt* opt, int model, orx_tabl
                                int64_t users_global, int64_t items_global, float margin, float slack, int32_t plan_chunk,
                                int flags, double* loss_l2_accum, int32_t* overflow);
 
+/* The hybrid-parallel DLRM step as one host call (BASELINE.json configs[4]; the single-process step: recommenders/dlrm.py:63-100 under
+ * tf2_examples/dlrm_criteo.py:42-48).  `emb` is this rank's shard of the COMBINED embedding table (row r of the concatenated tables
+ * on rank r % world at local index r / world), `m` a model made with ORX_DLRM_NO_EMB (its MLPs are replicas), dense / sparse / label
+ * this rank's K x B slice of the global batches (DEVICE pointers; sparse ids are ids within their own table).  Per step: lookups ->
+ * owners (ncclSend / ncclRecv groups), rows back, forward + backward on the rows where they arrived, row gradients to the owners,
+ * ONE ncclAllReduce of the packed dense gradients, applies.  loss_accum: device double[1], this rank's share of the global-batch
+ * loss is added per step; overflow: device int, sticky (a request bucket -- mean * slack + 8 -- was full).  Same results as the
+ * per-phase entry points (orx_shard_bucket, orx_gather_rows, orx_dlrm_grads_indirect, orx_dlrm_dense_pack / _apply, orx_apply_rows)
+ * driven by openrec_amd/sharded_dlrm.py. */
+int orx_sharded_dlrm_steps(orx_comm* comm, orx_dlrm* m, orx_opt* opt, orx_table* emb, const float* dense, const int32_t* sparse,
+                           const float* label, int64_t K, int64_t B, float slack, double* loss_accum, int32_t* overflow);
+
 /* ---- device-time sampling of the kernels (HIP events on the ctx stream) --- */
 int orx_prof_enable(orx_ctx* ctx, int on);
 int orx_prof_reset(orx_ctx* ctx);

@@ -78,6 +78,7 @@ struct orx_dlrm {
     DenseFused* d_fused = nullptr;      // ... and for the fused launch of the fp16 mode (slab reduce + rule + fp16 copies)
     orx_opt* fused_opt = nullptr; int fused_tiles = 0; DenseFusedTiles fused_tt;
     bool grads_pending = false;         // orx_dlrm_grads ran, orx_dlrm_dense_apply not yet
+    void* d_flatseg = nullptr; const void* flatseg_key = nullptr; int flatseg_n = 0;     // descriptors of dlrm_flat_kernel
     double* d_loss = nullptr;           // [Kcap]
     int64_t loss_cap = 0;
     int maxw = 0;
@@ -227,7 +228,7 @@ extern "C" int orx_dlrm_destroy(orx_dlrm* m) {
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     free_buffers(m);
-    hipFree(m->d_offset); hipFree(m->d_colwin); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params); hipFree(m->d_fused); hipFree(m->d_idx_all); hipFree(m->d_sparse_all); hipFree(m->d_tiny_f); hipFree(m->d_is_tiny);
+    hipFree(m->d_offset); hipFree(m->d_colwin); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params); hipFree(m->d_fused); hipFree(m->d_idx_all); hipFree(m->d_sparse_all); hipFree(m->d_tiny_f); hipFree(m->d_is_tiny); hipFree(m->d_flatseg);
     orx_table_destroy(m->emb);
     for (auto& d : m->bot) { orx_table_destroy(d.W); orx_table_destroy(d.b); hipFree(d.w16); hipFree(d.w16t); }
     for (auto& d : m->top) { orx_table_destroy(d.W); orx_table_destroy(d.b); hipFree(d.w16); hipFree(d.w16t); }
@@ -887,18 +888,55 @@ extern "C" int orx_dlrm_dense_count(orx_dlrm* m, int64_t* count) {
     return ORX_OK;
 }
 
+// every dense parameter's gradient (gsum) <-> one flat vector (the all-reduce buffer of the hybrid-parallel step), ONE launch:
+// a hipMemcpyAsync per tensor is ~16 runtime calls of 5-10 us each, twice per step
+struct FlatSeg { float* p; int64_t off; int64_t n; };
+__global__ __launch_bounds__(256) void dlrm_flat_kernel(const FlatSeg* seg, float* flat, int to_flat) {
+    const FlatSeg sg = seg[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < sg.n; i += (int64_t)gridDim.x * 256) {
+        if (to_flat) flat[sg.off + i] = sg.p[i];
+        else sg.p[i] = flat[sg.off + i];
+    }
+}
+
+static int dlrm_flat(orx_dlrm* m, float* flat, int to_flat) {
+    orx_ctx* c = m->ctx;
+    std::vector<orx_table*> ps; dense_params(m, ps);
+    std::vector<FlatSeg> h;
+    int64_t off = 0, max_n = 0;
+    for (orx_table* t : ps) {
+        CHECK(orx_table_scratch(t));
+        const int64_t n = t->rows * t->dim;
+        h.push_back(FlatSeg{t->gsum, off, n});
+        off += n; max_n = std::max(max_n, n);
+    }
+    if (!m->d_flatseg || m->flatseg_key != (const void*)ps[0]->gsum || m->flatseg_n != (int)h.size()) {
+        if (!m->d_flatseg) ORX_HIP(hipMalloc((void**)&m->d_flatseg, 64 * sizeof(FlatSeg)));
+        ORX_ARG(h.size() <= 64, "dlrm: too many dense parameters (%zu)", h.size());
+        ORX_HIP(hipMemcpyAsync(m->d_flatseg, h.data(), h.size() * sizeof(FlatSeg), hipMemcpyHostToDevice, c->stream));
+        ORX_HIP(hipStreamSynchronize(c->stream));          // (h is a local: the copy must have read it)
+        m->flatseg_key = (const void*)ps[0]->gsum; m->flatseg_n = (int)h.size();
+    }
+    const int gx = (int)std::min<int64_t>(256, (max_n + 1023) / 1024 + 1);
+    ORX_LAUNCH(c, dlrm_flat_kernel, dim3((unsigned)gx, (unsigned)h.size()), dim3(256), 0, (const FlatSeg*)m->d_flatseg, flat, to_flat);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
 extern "C" int orx_dlrm_dense_pack(orx_dlrm* m, float* flat) {
     ORX_ARG(m && flat, "orx_dlrm_dense_pack: NULL argument");
     ORX_HIP(hipSetDevice(m->ctx->device));
     std::vector<orx_table*> ps; dense_params(m, ps);
-    for (orx_table* t : ps) {
-        ORX_ARG(t->gsum, "orx_dlrm_dense_pack: no gradients yet (call orx_dlrm_grads first)");
-        const size_t n = (size_t)t->rows * t->dim;
-        ORX_HIP(hipMemcpyAsync(flat, t->gsum, n * sizeof(float), hipMemcpyDeviceToDevice, m->ctx->stream));
-        flat += n;
-    }
+    for (orx_table* t : ps) ORX_ARG(t->gsum, "orx_dlrm_dense_pack: no gradients yet (call orx_dlrm_grads first)");
+    return dlrm_flat(m, flat, 1);
+}
+
+// shapes of the model for the library's hybrid-parallel engine (sharded_engine.hip)
+int orx_dlrm_geometry(orx_dlrm* m, int* m_spa, int* n_emb, int* dense_dim, const int64_t** d_offset, const int64_t** d_rows) {
+    *m_spa = m->m_spa; *n_emb = m->n_emb; *dense_dim = m->dense_dim; *d_offset = m->d_offset; *d_rows = m->d_rows;
     return ORX_OK;
 }
+orx_ctx* orx_dlrm_ctx(orx_dlrm* m) { return m->ctx; }
 
 extern "C" int orx_dlrm_dense_apply(orx_dlrm* m, orx_opt* opt, const float* flat) {
     ORX_ARG(m && opt && flat, "orx_dlrm_dense_apply: NULL argument");
@@ -911,12 +949,7 @@ extern "C" int orx_dlrm_dense_apply(orx_dlrm* m, orx_opt* opt, const float* flat
         const double b1 = opt->p0, b2 = opt->p1;
         lr_t = (float)(opt->lr * std::sqrt(1.0 - std::pow(b2, (double)opt->t)) / (1.0 - std::pow(b1, (double)opt->t)));
     }
-    for (orx_table* t : ps) {
-        CHECK(orx_table_scratch(t));
-        const size_t n = (size_t)t->rows * t->dim;
-        ORX_HIP(hipMemcpyAsync(t->gsum, flat, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-        flat += n;
-    }
+    CHECK(dlrm_flat(m, const_cast<float*>(flat), 0));
     CHECK(dense_apply_all(m, opt, lr_t));
     m->grads_pending = false;
     return ORX_OK;

@@ -44,7 +44,7 @@
 constexpr int PL_THREADS = 256;
 constexpr int PL_REFS = 8;                        // references per thread in the count / scatter kernels
 constexpr int PL_CHUNK = PL_THREADS * PL_REFS;
-constexpr int PL_LCNT = 2048;                     // per-row reference counters of the staging plan kept in LDS (more tri rows in a range: global counters)
+constexpr int PL_LCNT = 1024;                     // per-row reference counters of the staging plan kept in LDS (more tri rows in a range: global counters)
 
 struct PlanArgs {
     DedupArgs d;
@@ -207,7 +207,7 @@ __device__ __forceinline__ int pl_rank(int* cnt, int dn) {
     return rank;
 }
 
-constexpr int PL_PAIR_CAP = 1024;                 // rows referenced exactly twice per range whose references learn of each other (positions in LDS)
+constexpr int PL_PAIR_CAP = 512;                  // rows referenced exactly twice per range whose references learn of each other (positions in LDS)
 
 // One workgroup per (range, step): the same plan dedup_kernel makes for its range, on the range's own references.
 template <int T>

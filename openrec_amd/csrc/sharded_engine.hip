@@ -29,6 +29,7 @@ struct RcclApi {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -43,7 +44,7 @@ RcclApi* rccl_api() {
 #define ORX_SYM(field, name) do { *(void**)(&api.field) = dlsym(h, name); if (!api.field) { dlclose(h); return nullptr; } } while (0)
         ORX_SYM(GetUniqueId, "ncclGetUniqueId"); ORX_SYM(CommInitRank, "ncclCommInitRank"); ORX_SYM(CommDestroy, "ncclCommDestroy");
         ORX_SYM(GroupStart, "ncclGroupStart"); ORX_SYM(GroupEnd, "ncclGroupEnd"); ORX_SYM(Send, "ncclSend"); ORX_SYM(Recv, "ncclRecv");
-        ORX_SYM(GetErrorString, "ncclGetErrorString");
+        ORX_SYM(GetErrorString, "ncclGetErrorString"); ORX_SYM(AllReduce, "ncclAllReduce");
 #undef ORX_SYM
         api.handle = h;
         return &api;
@@ -81,6 +82,7 @@ struct orx_vgroup {
     int world = 1;
     std::mutex mu; std::condition_variable cv; int waiting = 0; long generation = 0; bool broken = false;
     const void* send[64] = {}; const void* send2[64] = {};
+    const void* red[64] = {};                              // all-reduce of the virtual group: every rank's vector
     bool wait() {                                           // false: the group was aborted (a rank failed)
         std::unique_lock<std::mutex> lk(mu);
         if (broken) return false;
@@ -102,6 +104,7 @@ struct orx_comm {
     bool stats_on = false; double st_exchanges = 0, st_wire = 0, st_self = 0, st_ms = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> st_ev;
     // the engine's exchange buffers (grown on demand, kept between calls)
+    Buf dl_send, dl_slot, dl_req, dl_reqloc, dl_rows_out, dl_rows_in, dl_send_g, dl_g_in, dl_idx, dl_ids, dl_flat, dl_sum, dl_cnt, dl_ptrs;     // hybrid-parallel DLRM engine
     Buf send1, mine, tmp, cnt, send2, req, req_loc, slot, u_loc, fu, fv, rows_out, rows_in, gu, u_apply, send_g, g_in, dupref, dsorted, seglist, segcount, gdup, bias_x;
 };
 
@@ -502,6 +505,126 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
                 CHECK(orx_apply_rows(ctx, opt, V, b, req_loc + (size_t)k * H * M, H * M, g, DS));
             }
         }
+    }
+    return ORX_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The hybrid-parallel DLRM step inside the library (the single-process step it shards: recommenders/dlrm.py:63-100
+// under tf2_examples/dlrm_criteo.py:42-48).  Embedding rows are sharded by combined row id (row r on rank r % world), the MLPs are
+// replicated; per step, all on the context's stream:
+//   combined ids of this rank's B x n_emb lookups -> buckets by owner -> exchange (ids) -> owners gather -> exchange (rows) ->
+//   forward + backward with the rows read where they arrived (orx_dlrm_grads_indirect) -> exchange (row gradients) ->
+//   ncclAllReduce of the packed dense gradients (one buffer) -> owners apply the row gradients -> every replica applies the dense rule.
+// Same arithmetic as the per-phase entry points driven by openrec_amd/sharded_dlrm.py (which the gloo tests keep driving).
+int orx_dlrm_geometry(orx_dlrm* m, int* m_spa, int* n_emb, int* dense_dim, const int64_t** d_offset, const int64_t** d_rows);
+orx_ctx* orx_dlrm_ctx(orx_dlrm* m);
+int orx_launch_dlrm_ids(orx_ctx* ctx, const int32_t* sparse, const int64_t* offset, const int64_t* rows, int nf, int64_t B, int32_t* idx);
+
+namespace {
+// lookup (b, f) reads row slot[b, f] of the receive buffer; a lookup dropped by a full bucket (or an invalid id) reads the zero row
+// `trash`; the pad column of the interaction's id matrix stays -1
+__global__ __launch_bounds__(256) void dlrm_slot_idx_kernel(const int32_t* slot, int64_t n, int F, int32_t trash, int32_t* idx) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int f = (int)(i % F);
+        const int32_t s = slot[i];
+        idx[i] = f == F - 1 ? -1 : (s >= 0 ? s : trash);
+    }
+}
+__global__ __launch_bounds__(256) void vec_sum_kernel(const float* const* src, int N, float* dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float a = src[0][i];
+        for (int p = 1; p < N; ++p) a += src[p][i];          // rank order: the same sum on every rank
+        dst[i] = a;
+    }
+}
+}  // namespace
+
+// in-place sum of `x` over the ranks
+static int all_reduce(orx_comm* c, float* x, int64_t n, Buf& tmp, Buf& ptrs) {
+    hipStream_t S = c->ctx->stream;
+    if (c->vg) {
+        CHECK(ensure(c, tmp, (size_t)n * 4)); CHECK(ensure(c, ptrs, 64 * sizeof(void*)));
+        ORX_HIP(hipStreamSynchronize(S));
+        c->vg->red[c->rank] = x;
+        ORX_ARG(c->vg->wait(), "virtual group: another rank failed");
+        const void* h[64];
+        for (int p = 0; p < c->world; ++p) h[p] = c->vg->red[p];
+        ORX_HIP(hipMemcpyAsync(ptrs.p, h, c->world * sizeof(void*), hipMemcpyHostToDevice, S));
+        ORX_LAUNCH(c->ctx, vec_sum_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0,
+                   (const float* const*)ptrs.p, c->world, (float*)tmp.p, n);
+        ORX_HIP(hipStreamSynchronize(S));                   // everybody has read everybody's vector ...
+        ORX_ARG(c->vg->wait(), "virtual group: another rank failed");
+        ORX_HIP(hipMemcpyAsync(x, tmp.p, (size_t)n * 4, hipMemcpyDeviceToDevice, S));      // ... before any of them is overwritten
+        return ORX_OK;
+    }
+    if (!c->comm) return ORX_OK;                            // one rank without RCCL: the sum of one
+    RcclApi* api = rccl_api();
+    ORX_NCCL(api, api->AllReduce(x, x, (size_t)n, ncclFloat, ncclSum, c->comm, S));
+    return ORX_OK;
+}
+
+extern "C" int orx_sharded_dlrm_steps(orx_comm* c, orx_dlrm* m, orx_opt* opt, orx_table* emb, const float* dense, const int32_t* sparse,
+                                      const float* label, int64_t K, int64_t B, float slack, double* loss_accum, int32_t* overflow) {
+    ORX_ARG(c && m && opt && emb && dense && sparse && label && loss_accum && overflow, "orx_sharded_dlrm_steps: NULL argument");
+    ORX_ARG(K >= 0 && B > 0 && slack >= 1.0f, "orx_sharded_dlrm_steps: bad sizes");
+    orx_ctx* ctx = c->ctx;
+    ORX_ARG(orx_dlrm_ctx(m) == ctx && emb->ctx == ctx && opt->ctx == ctx, "orx_sharded_dlrm_steps: model, table and optimizer must live on the communicator's context");
+    ORX_ARG(orx_dlrm_direct_ok(m), "orx_sharded_dlrm_steps: this model's shapes need the copying form of the local step (drive the per-phase entry points)");
+    if (K == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(ctx->device));
+    int d = 0, nf = 0, dd = 0; const int64_t *d_off = nullptr, *d_rows = nullptr;
+    CHECK(orx_dlrm_geometry(m, &d, &nf, &dd, &d_off, &d_rows));
+    ORX_ARG(emb->dim == d, "orx_sharded_dlrm_steps: the embedding shard has dim %d, the model %d", emb->dim, d);
+    const int N = c->world, F = nf + 1;
+    const int64_t n = B * nf, nF = B * F;
+    const int64_t cap = (int64_t)std::ceil((double)n / N * slack) + 8, trash = (int64_t)N * cap;
+    ORX_ARG(trash + 1 < (1LL << 31), "orx_sharded_dlrm_steps: batch too large");
+    int64_t n_dense = 0;
+    CHECK(orx_dlrm_dense_count(m, &n_dense));
+    CHECK(ensure(c, c->dl_ids, (size_t)nF * 4)); CHECK(ensure(c, c->dl_send, (size_t)trash * 4)); CHECK(ensure(c, c->dl_slot, (size_t)nF * 4));
+    CHECK(ensure(c, c->dl_req, (size_t)trash * 4)); CHECK(ensure(c, c->dl_reqloc, (size_t)trash * 4)); CHECK(ensure(c, c->dl_idx, (size_t)nF * 4));
+    const size_t rows_out_before = c->dl_rows_out.cap;
+    CHECK(ensure(c, c->dl_rows_out, (size_t)(trash + 1) * d * 4)); CHECK(ensure(c, c->dl_g_in, (size_t)trash * d * 4));
+    const size_t rows_in_before = c->dl_rows_in.cap;
+    CHECK(ensure(c, c->dl_rows_in, (size_t)(trash + 1) * d * 4)); CHECK(ensure(c, c->dl_send_g, (size_t)(trash + 1) * d * 4));
+    CHECK(ensure(c, c->dl_flat, (size_t)n_dense * 4)); CHECK(ensure(c, c->dl_cnt, 64 * 4));
+    hipStream_t S = ctx->stream;
+    // (row `trash` of the receive buffer stands in for dropped lookups: it must read as zeros; the exchanges never write it)
+    if (c->dl_rows_in.cap != rows_in_before) ORX_HIP(hipMemsetAsync(c->dl_rows_in.p, 0, c->dl_rows_in.cap, S));
+    else ORX_HIP(hipMemsetAsync((float*)c->dl_rows_in.p + (size_t)trash * d, 0, (size_t)d * 4, S));
+    // (a one-rank communicator without RCCL hands the send buffer back as "received": the zero row then lives behind the gathered rows)
+    if (c->dl_rows_out.cap != rows_out_before) ORX_HIP(hipMemsetAsync(c->dl_rows_out.p, 0, c->dl_rows_out.cap, S));
+    else ORX_HIP(hipMemsetAsync((float*)c->dl_rows_out.p + (size_t)trash * d, 0, (size_t)d * 4, S));
+    int32_t* ids = (int32_t*)c->dl_ids.p; int32_t* send = (int32_t*)c->dl_send.p; int32_t* slot = (int32_t*)c->dl_slot.p;
+    int32_t* req_loc = (int32_t*)c->dl_reqloc.p; int32_t* idx = (int32_t*)c->dl_idx.p;
+    float* rows_out = (float*)c->dl_rows_out.p; float* rows_in = (float*)c->dl_rows_in.p; float* send_g = (float*)c->dl_send_g.p;
+    float* flat = (float*)c->dl_flat.p;
+    for (int64_t k = 0; k < K; ++k) {
+        const float* de = dense + k * B * dd; const int32_t* sp = sparse + k * B * nf; const float* la = label + k * B;
+        // 1. requests to the owners
+        CHECK(orx_launch_dlrm_ids(ctx, sp, d_off, d_rows, nf, B, ids));                    // combined row ids [B][n_emb + 1] (pad column -1)
+        CHECK(orx_shard_bucket(ctx, ids, nF, N, (int32_t)cap, send, slot, (int32_t*)c->dl_cnt.p, overflow));
+        ORX_LAUNCH(ctx, dlrm_slot_idx_kernel, dim3((unsigned)std::min<int64_t>(1024, (nF + 255) / 256)), dim3(256), 0, (const int32_t*)slot, nF, F, (int32_t)trash, idx);
+        const void* req = nullptr;
+        CHECK(exchange(c, send, c->dl_req.p, (size_t)cap * 4, &req));
+        CHECK(orx_shard_localize(ctx, (const int32_t*)req, trash, N, req_loc));
+        // 2. owners gather, the rows travel back
+        CHECK(orx_gather_rows(ctx, emb, nullptr, req_loc, trash, rows_out, d));
+        const void* rin = nullptr;
+        CHECK(exchange(c, rows_out, rows_in, (size_t)cap * d * 4, &rin));
+        // 3. local forward + backward on the rows where they arrived; the gradient of lookup (b, f) goes to row idx[b, f] of send_g
+        CHECK(orx_dlrm_grads_indirect(m, de, (const float*)rin, trash + 1, idx, la, B, B * N, send_g, loss_accum));
+        // 4. row gradients back to the owners; dense gradients: one all-reduce
+        const void* gin = nullptr;
+        CHECK(exchange(c, send_g, c->dl_g_in.p, (size_t)cap * d * 4, &gin));
+        CHECK(orx_dlrm_dense_pack(m, flat));
+        CHECK(all_reduce(c, flat, n_dense, c->dl_sum, c->dl_ptrs));
+        // 5. replicas apply the dense rule (Keras `iterations` += 1 happens there: before the row applies, as in the per-phase path),
+        // owners apply the row gradients (padding slots carry garbage and are skipped: id -1)
+        CHECK(orx_dlrm_dense_apply(m, opt, flat));
+        CHECK(orx_apply_rows(ctx, opt, emb, nullptr, req_loc, trash, (const float*)gin, d));
     }
     return ORX_OK;
 }

@@ -60,6 +60,43 @@ def bucket_slots(dest, world, cap):
     return slot, overflow
 
 
+def make_comm(be, rank, world, group=None, rccl=None, vgroup=None):
+    """-> an orx_comm handle on the context of backend `be` (anything with .ctx, .lib, ._ffi, .device).  `rccl`: exchange through
+    RCCL (default: world > 1); the 128-byte id made by rank 0 reaches the other ranks through `group` (any torch.distributed
+    backend).  `vgroup`: an orx_vgroup handle -- ranks in threads of this process on one device (tests)."""
+    import ctypes
+    import weakref
+    if vgroup is not None:
+        h = ctypes.c_void_p()
+        be._ffi.check(be.lib.orx_comm_create_virtual(be.ctx._h, vgroup, rank, ctypes.byref(h)))
+        weakref.finalize(be, be.lib.orx_comm_destroy, h)
+        return h
+    rccl = world > 1 if rccl is None else rccl
+    idp = None
+    if rccl:
+        buf = torch.zeros(be._ffi.ORX_COMM_ID_BYTES, dtype=torch.uint8)
+        err = None
+        if rank == 0:
+            try:
+                raw = (ctypes.c_char * be._ffi.ORX_COMM_ID_BYTES)()
+                be._ffi.check(be.lib.orx_comm_unique_id(ctypes.cast(raw, ctypes.c_void_p)))
+                buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+            except Exception as e:                    # noqa: BLE001  (the others wait in the broadcast: they get zeros)
+                err = e
+        if world > 1:
+            dev_buf = buf.to(be.device) if dist.get_backend(group) == "nccl" else buf
+            dist.broadcast(dev_buf, src=0, group=group)
+            buf = dev_buf.cpu()
+        if not bool(buf.any()):
+            raise RuntimeError(f"rank 0 could not make an RCCL id: {err!r}")
+        be._id_keep = buf.contiguous()
+        idp = ctypes.c_void_p(be._id_keep.data_ptr())
+    h = ctypes.c_void_p()
+    be._ffi.check(be.lib.orx_comm_create(be.ctx._h, idp, rank, world, ctypes.byref(h)))
+    weakref.finalize(be, be.lib.orx_comm_destroy, h)
+    return h
+
+
 class HipBackend:
     """Compute backend = the C ABI.  Buffers are torch tensors on the rank's GPU,
     kernels run on torch's current stream so that they order with the collectives."""
@@ -202,41 +239,7 @@ class HipBackend:
 
     # ---- the whole K-step loop in the library (orx_sharded_pairwise_steps) --------
     def make_comm(self, rank, world, group=None, rccl=None, vgroup=None):
-        """-> an orx_comm handle on this backend's context.  `rccl`: exchange through RCCL (default: world > 1); the 128-byte
-        id made by rank 0 reaches the other ranks through `group` (any torch.distributed backend).  `vgroup`: an orx_vgroup
-        handle -- ranks in threads of this process on one device (tests)."""
-        import ctypes
-        import weakref
-        if vgroup is not None:
-            h = ctypes.c_void_p()
-            self._ffi.check(self.lib.orx_comm_create_virtual(self.ctx._h, vgroup, rank, ctypes.byref(h)))
-            weakref.finalize(self, self.lib.orx_comm_destroy, h)
-            return h
-        rccl = world > 1 if rccl is None else rccl
-        idp = None
-        if rccl:
-            buf = torch.zeros(self._ffi.ORX_COMM_ID_BYTES, dtype=torch.uint8)
-            err = None
-            if rank == 0:
-                try:
-                    raw = (ctypes.c_char * self._ffi.ORX_COMM_ID_BYTES)()
-                    self._ffi.check(self.lib.orx_comm_unique_id(ctypes.cast(raw, ctypes.c_void_p)))
-                    buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
-                except Exception as e:                    # noqa: BLE001  (the others wait in the broadcast: they get zeros)
-                    err = e
-            if world > 1:
-                dev_buf = buf.to(self.device) if dist.get_backend(group) == "nccl" else buf
-                dist.broadcast(dev_buf, src=0, group=group)
-                buf = dev_buf.cpu()
-            if not bool(buf.any()):
-                raise RuntimeError(f"rank 0 could not make an RCCL id: {err!r}")
-            self._id_keep = buf.contiguous()
-            idp = ctypes.c_void_p(self._id_keep.data_ptr())
-        h = ctypes.c_void_p()
-        self._ffi.check(self.lib.orx_comm_create(self.ctx._h, idp, rank, world, ctypes.byref(h)))
-        import weakref
-        weakref.finalize(self, self.lib.orx_comm_destroy, h)
-        return h
+        return make_comm(self, rank, world, group, rccl, vgroup)
 
     def sharded_steps(self, comm, model, U, V, b, uid, pid, nid, n_users, n_items, margin, slack, plan_chunk, overlap, accum, ovf, dedup=True):
         mid = {"bpr": self._ffi.ORX_BPR, "ucml": self._ffi.ORX_UCML}[model]

@@ -29,7 +29,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .sharded import bucket_slots, rows_on_rank
+from .sharded import bucket_slots, make_comm, rows_on_rank
 
 
 class HipDLRMBackend:
@@ -110,10 +110,19 @@ class HipDLRMBackend:
     def check(self):
         self.ctx.check_index_error()
 
+    # the whole K-step loop in the library (orx_sharded_dlrm_steps)
+    def make_comm(self, rank, world, group=None, rccl=None, vgroup=None):
+        return make_comm(self, rank, world, group, rccl, vgroup)
+
+    def sharded_steps(self, comm, emb, dense, sparse, label, slack, loss_accum, ovf):
+        K, B = label.shape
+        self._ffi.check(self.lib.orx_sharded_dlrm_steps(comm, self.model._h, self.opt._h, emb._h, dense.data_ptr(), sparse.data_ptr(), label.data_ptr(),
+                                                        K, B, slack, loss_accum.data_ptr(), ovf.data_ptr()))
+
 
 class ShardedDLRM:
     def __init__(self, m_spa, ln_emb, ln_bot, ln_top, dense_dim, rank, world, device, opt="sgd", lr=0.01, opt_kw=None,
-                 seed=0, slack=1.25, backend=None, group=None, a2a_fn=None, allreduce_fn=None, fp16_mlp=False,
+                 seed=0, slack=1.25, backend=None, group=None, a2a_fn=None, allreduce_fn=None, fp16_mlp=False, engine=None, vgroup=None,
                  **model_kw):
         self.m_spa, self.ln_emb, self.n_emb = int(m_spa), [int(x) for x in ln_emb], len(ln_emb)
         self.dense_dim, self.rank, self.world, self.device = int(dense_dim), rank, world, device
@@ -134,6 +143,9 @@ class ShardedDLRM:
         self.copying = False                    # True: always the copying form of the local step (orx_dlrm_grads)
         self._cnt = torch.zeros(64, dtype=torch.int32, device=device)
         self._ovf = torch.zeros(1, dtype=torch.int32, device=device)
+        self.engine = engine                    # None: the library's K-step engine where it applies; "python": the per-phase path
+        self.vgroup = vgroup                    # orx_vgroup handle: ranks in threads of one process (tests)
+        self._comm = None
 
     # ---- table access by GLOBAL combined row (tests, checkpoints) ----------
     def load_embeddings(self, combined):
@@ -161,6 +173,54 @@ class ShardedDLRM:
         elif self.world > 1 or self.force_collectives:
             dist.all_reduce(x, group=self.group)
         return x
+
+    def _library_engine(self):
+        """orx_sharded_dlrm_steps takes the K-step calls when the compute backend is the library, the model's shapes allow reading
+        the exchanged rows in place, and the exchange is RCCL's (process group backend "nccl"), a virtual group, or the identity
+        (one rank).  gloo groups and injected exchanges (tests) keep the per-phase path, which drives the same kernels from here."""
+        import os
+        if self.engine is None and os.environ.get("ORX_SHARD_ENGINE") == "python":
+            self.engine = "python"
+        if self.engine == "python" or self.a2a_fn is not None or self.allreduce_fn is not None or not hasattr(self.be, "sharded_steps") \
+                or self.copying or not self.be.direct_ok():
+            return False
+        if self._comm is None and self.vgroup is not None:
+            self._comm = self.be.make_comm(self.rank, self.world, vgroup=self.vgroup)
+        if self._comm is None:
+            rccl = self.world > 1 or self.force_collectives
+            if self.world > 1 and dist.get_backend(self.group) != "nccl":
+                self.engine = "python"
+                return False
+            comm, err = None, None
+            try:
+                comm = self.be.make_comm(self.rank, self.world, self.group, rccl=rccl)
+            except Exception as e:                        # noqa: BLE001
+                err = e
+            ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=self.device)
+            if self.world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) == 0:
+                import warnings
+                warnings.warn(f"sharded DLRM: no library communicator on every rank ({err!r}); using the per-phase path", RuntimeWarning)
+                self.engine = "python"
+                return False
+            self._comm = comm
+        return True
+
+    def steps(self, dense, sparse, label):
+        """K steps: dense [K, B, dense_dim] fp32, sparse [K, B, n_emb] int32, label [K, B] fp32 -- this rank's slices of K global
+        batches, on self.device.  One host call into the library's engine where it applies (see _library_engine), K calls of
+        step() otherwise."""
+        K = label.shape[0]
+        if self._library_engine():
+            self.be.stream.wait_stream(torch.cuda.current_stream(self.device))      # the inputs were made on the caller's stream
+            with self.be.stream_ctx():
+                de = dense.to(torch.float32).contiguous(); sp = sparse.to(torch.int32).contiguous(); la = label.to(torch.float32).contiguous()
+                self.be.sharded_steps(self._comm, self.emb, de, sp, la, float(self.slack), self.loss_accum, self._ovf)
+            return None
+        for k in range(K):
+            self.step(dense[k], sparse[k], label[k])
+        return None
 
     def step(self, dense, sparse, label):
         """dense [B, dense_dim] fp32, sparse [B, n_emb] int (id within its own table), label [B] fp32 -

@@ -24,7 +24,7 @@ PAIRWISE_CASES = (  # model, optimizer, dim, engine (None = library), overlap, d
     ("bpr", "sgd", 64, "python", None, None), ("bpr", "adagrad", 64, None, None, None), ("bpr", "adagrad", 64, "python", None, None),
     ("ucml", "sgd", 128, None, None, None), ("ucml", "sgd", 128, None, False, False),
     ("bpr", "adam", 64, None, None, None), ("bpr", "adam", 64, None, False, True), ("bpr", "adam", 64, "python", None, None))
-DLRM_CASES = (("sgd", "bce"), ("adagrad", "bce"), ("adam", "mse"))
+DLRM_CASES = (("sgd", "bce", None), ("adagrad", "bce", "python"), ("adam", "mse", None), ("sgd", "mse", "python"))      # optimizer, loss, engine (None = library)
 
 
 def main():
@@ -83,10 +83,11 @@ def main():
 
     # ---- hybrid-parallel DLRM: embedding rows through all-to-all, dense gradients through all-reduce
     CFG = dict(m_spa=16, ln_emb=[1000, 37, 5000, 3, 250], ln_bot=[64, 16], ln_top=[128, 64, 1], dense_dim=13)
-    for optk, loss_func in DLRM_CASES:
+    CFG = dict(m_spa=32, ln_emb=[1000, 37, 5000, 3, 250], ln_bot=[64, 32], ln_top=[128, 64, 1], dense_dim=13)     # (m_spa 32: the rows are read where they arrive)
+    for optk, loss_func, engine in DLRM_CASES:
         kw = dict(reference_compat=False, loss_func=loss_func)
         ref = DLRMOracle(seed=5, **dict(CFG, **kw))
-        e = ShardedDLRM(rank=rank, world=world, device=dev, opt=optk, lr=0.05, slack=2.0, seed=5, **CFG, **kw)
+        e = ShardedDLRM(rank=rank, world=world, device=dev, opt=optk, lr=0.05, slack=2.0, seed=5, engine=engine, **CFG, **kw)
         e.force_collectives = True
         e.load_embeddings(np.concatenate(ref.emb))
         for name, layers in (("bot", ref.bot), ("top", ref.top)):
@@ -101,7 +102,9 @@ def main():
             sparse = np.stack([rng.integers(0, n, Bl * world) for n in CFG["ln_emb"]], 1).astype(np.int32)
             label = (rng.random(Bl * world) < 0.3).astype(np.float32)
             sl = slice(rank * Bl, (rank + 1) * Bl)
-            e.step(torch.from_numpy(dense[sl].copy()).to(dev), torch.from_numpy(sparse[sl].copy()).to(dev), torch.from_numpy(label[sl].copy()).to(dev))
+            torch.cuda.synchronize()
+            e.steps(torch.from_numpy(dense[sl].copy()).to(dev)[None], torch.from_numpy(sparse[sl].copy()).to(dev)[None], torch.from_numpy(label[sl].copy()).to(dev)[None])
+            assert (e._comm is not None) == (engine is None)
             total += float(ref.step(dense, sparse, label, oo))
         e.check()
         tol = 5e-5 if optk == "adam" else 2e-5           # (tests/test_sharded_dlrm_cpu.py)
@@ -111,7 +114,7 @@ def main():
                 assert rel_err(e.be.dense_param(name + "_w", l).read(), W) < tol, (rank, optk, name, l)
         assert abs(e.loss_sum() - total) < 1e-5 * abs(total), (rank, optk)
         dist.barrier()
-        say(f"rccl-world{world} dlrm {optk} {loss_func}: ok")
+        say(f"rccl-world{world} dlrm {optk} {loss_func} engine={engine or 'library'}: ok")
 
     dist.barrier()
     dist.destroy_process_group()

@@ -72,10 +72,12 @@ def main():
 
     # ---- hybrid-parallel DLRM: embedding rows through all-to-all, dense gradients through all-reduce
     CFG = dict(m_spa=16, ln_emb=[1000, 37, 5000, 3, 250], ln_bot=[64, 16], ln_top=[128, 64, 1], dense_dim=13)
-    for optk, loss_func in (("sgd", "bce"), ("adam", "mse")):
+    for optk, loss_func, engine in (("sgd", "bce", "python"), ("adam", "mse", "python"), ("sgd", "bce", None), ("adam", "mse", None)):
+        if engine is None:      # the library's engine (orx_sharded_dlrm_steps) reads the rows where they arrive: m_spa >= 32
+            CFG = dict(CFG, m_spa=32, ln_bot=[64, 32])
         kw = dict(reference_compat=False, loss_func=loss_func)
         ref = DLRMOracle(seed=5, **dict(CFG, **kw))
-        e = ShardedDLRM(rank=0, world=1, device=dev, opt=optk, lr=0.05, slack=2.0, seed=5, **CFG, **kw)
+        e = ShardedDLRM(rank=0, world=1, device=dev, opt=optk, lr=0.05, slack=2.0, seed=5, engine=engine, **CFG, **kw)
         e.force_collectives = True
         e.load_embeddings(np.concatenate(ref.emb))
         for name, layers in (("bot", ref.bot), ("top", ref.top)):
@@ -88,7 +90,9 @@ def main():
             dense = rng.normal(size=(512, 13)).astype(np.float32)
             sparse = np.stack([rng.integers(0, n, 512) for n in CFG["ln_emb"]], 1).astype(np.int32)
             label = (rng.random(512) < 0.3).astype(np.float32)
-            e.step(torch.from_numpy(dense).to(dev), torch.from_numpy(sparse).to(dev), torch.from_numpy(label).to(dev))
+            torch.cuda.synchronize()
+            e.steps(torch.from_numpy(dense).to(dev)[None], torch.from_numpy(sparse).to(dev)[None], torch.from_numpy(label).to(dev)[None])
+            assert (e._comm is not None) == (engine is None)
             total += float(ref.step(dense, sparse, label, oo))
         e.check()
         tol = 5e-5 if optk == "adam" else 1e-5
@@ -97,7 +101,7 @@ def main():
             for l, (W, bb) in enumerate(layers):
                 assert rel_err(e.be.dense_param(name + "_w", l).read(), W) < tol, (optk, name, l)
         assert abs(float(e.loss_accum.item()) - total) < 1e-5 * abs(total)
-        print(f"rccl-rank1 dlrm {optk} {loss_func}: ok", flush=True)
+        print(f"rccl-rank1 dlrm {optk} {loss_func} engine={engine or 'library'}: ok", flush=True)
 
     dist.barrier()
     dist.destroy_process_group()
