@@ -24,6 +24,8 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
+
 import torch
 import torch.distributed as dist
 
@@ -262,7 +264,8 @@ class HipBackend:
 
 class ShardedPairwise:
     def __init__(self, model, opt, n_users, n_items, dim, lr, rank, world, device, seed=0, margin=0.5,
-                 backend=None, slack=1.05, opt_kw=None, group=None, a2a_fn=None, fast=None, engine=None, dedup=None, vgroup=None):
+                 backend=None, slack=1.05, opt_kw=None, group=None, a2a_fn=None, fast=None, engine=None, dedup=None, vgroup=None,
+                 hot_items=0, allreduce_fn=None):
         assert model in ("bpr", "ucml")
         self.model, self.dim, self.margin = model, dim, margin
         self.rank, self.world, self.device, self.group = rank, world, device, group
@@ -290,6 +293,75 @@ class ShardedPairwise:
         self.dedup = dedup
         self._comm = None
         self.vgroup = vgroup                              # orx_vgroup handle: ranks in threads of one process (tests)
+        # ---- skewed item popularity: the `hot_items` most popular items -- ids 0 .. hot_items-1, a vocabulary
+        # sorted by frequency -- are REPLICATED on every rank (rows + biases, [H, D] + [H, 1]).  Their references read the local
+        # replica and send nothing; their gradients are summed locally, then over the ranks by ONE all-reduce of the [H, D + 4]
+        # block per step, and every rank applies the same sums to its replica (the replicas stay bit-identical: same addends,
+        # same order).  With Zipf(1.05) ids over 1 M items the first 16 k items take 78 % of the item references of a step: that
+        # share of the row and gradient exchanges leaves the wire, for 2 * (N - 1) / N * H * (D + 4) * 4 bytes of all-reduce.
+        # The replica is the authority for those rows while training; sync_hot() writes them back into the owners' shards.
+        # Per-phase path only (the K-step engines fall back to it); exact: TF sums the gradients of duplicate ids before the
+        # sparse apply and a sum over ranks of per-rank sums is such a sum.
+        self.hot = int(min(max(hot_items, 0), n_items))
+        self.allreduce_fn = allreduce_fn
+        if self.hot:
+            self.fast = False                             # (the device-side plans do not know about replicas)
+            self._ovf = None
+            self.Vh = self.be.make_table(self.hot, dim, seed * 3 + 7)
+            self.bh = self.be.make_table(self.hot, 1, seed * 3 + 8)
+            self._hot_loaded = False
+
+    # ---- hot rows ------------------------------------------------------------------------------------------------------
+    def _allreduce(self, x):
+        if self.allreduce_fn is not None:                 # tests: in-place sum over an in-process fake cluster
+            self.allreduce_fn(x)
+        elif self.world > 1 or self.force_collectives:
+            dist.all_reduce(x, group=self.group)
+        return x
+
+    def load_hot(self):
+        """replicas <- the owners' shards (collective): row i < hot_items lives at local row i // world of rank i % world.
+        Called once before the first step (and after anything wrote the shards: load(), a test's U.write ...)."""
+        H, N, D, dev = self.hot, self.world, self.dim, self.device
+        if not H:
+            return
+        blk = torch.zeros((H, D + 1), dtype=torch.float32, device=dev)
+        mine = torch.arange(self.rank, H, N, device=dev)                  # the hot rows this rank owns
+        if mine.numel():
+            rows = torch.zeros((mine.numel(), self.DS), dtype=torch.float32, device=dev)
+            self.be.gather_rows(self.V, self.b, local_index(mine, N).to(torch.int32).contiguous(), rows)
+            if hasattr(self.be, "stream"):
+                self.be.stream.synchronize()
+            blk[mine] = rows[:, :D + 1]
+        self._allreduce(blk)                                              # (every row has exactly one owner: the sum is a gather)
+        self._write_table(self.Vh, blk[:, :D]); self._write_table(self.bh, blk[:, D:D + 1])
+        self._hot_loaded = True
+
+    def sync_hot(self):
+        """the owners' shards <- replicas (local: every rank's replica is the same): after this, V / b hold the trained hot rows"""
+        H, N, D = self.hot, self.world, self.dim
+        if not H or not self._hot_loaded:
+            return
+        if hasattr(self.be, "stream"):
+            self.be.stream.synchronize()
+        vh, bh = self._read_table(self.Vh), self._read_table(self.bh)
+        own = np.arange(self.rank, H, N)
+        if own.size:
+            v, b = self._read_table(self.V), self._read_table(self.b)
+            v[own // N] = vh[own]; b[own // N] = bh[own]
+            self._write_table(self.V, v); self._write_table(self.b, b)
+
+    @staticmethod
+    def _read_table(t):
+        return t.read() if hasattr(t, "read") else t.w.copy()
+
+    @staticmethod
+    def _write_table(t, values):
+        a = values.detach().cpu().numpy() if hasattr(values, "detach") else np.asarray(values)
+        if hasattr(t, "write"):
+            t.write(np.ascontiguousarray(a, np.float32))
+        else:
+            t.w[:] = a
 
     def _library_engine(self):
         """The C engine (orx_sharded_pairwise_steps) takes the K-step calls when the compute backend is the library and the
@@ -298,7 +370,7 @@ class ShardedPairwise:
         import os
         if self.engine is None and os.environ.get("ORX_SHARD_ENGINE") == "python":
             self.engine = "python"
-        if self.engine == "python" or self.a2a_fn is not None or not hasattr(self.be, "sharded_steps"):
+        if self.engine == "python" or self.a2a_fn is not None or not hasattr(self.be, "sharded_steps") or self.hot:
             return False
         if self._comm is None and self.vgroup is not None:
             self._comm = self.be.make_comm(self.rank, self.world, vgroup=self.vgroup)
@@ -396,6 +468,7 @@ class ShardedPairwise:
         (runtime.save_checkpoint: one .npy per tensor, streamed in row ranges; files carry `.rank<r>of<w>`).  Collective when
         world > 1: returns once every rank has written."""
         self.check()
+        self.sync_hot()
         self.be.save_tables(path, dict(U=self.U, V=self.V, b=self.b), (self.rank, self.world))
         if self.world > 1 and dist.is_initialized():
             dist.barrier(group=self.group)
@@ -405,6 +478,8 @@ class ShardedPairwise:
         self.be.load_tables(path, dict(U=self.U, V=self.V, b=self.b), (self.rank, self.world))
         if self.world > 1 and dist.is_initialized():
             dist.barrier(group=self.group)
+        if self.hot:
+            self.load_hot()
 
     # ---- measurement of the library engine's exchanges (bench.py --gpus N) ----
     def comm_stats_start(self):
@@ -630,15 +705,19 @@ class ShardedPairwise:
         u_g, p_g, n_g = mine[:, 0].long(), mine[:, 1].long(), mine[:, 2].long()
         live = u_g >= 0
         u_loc = torch.where(live, local_index(u_g, N), torch.full_like(u_g, -1)).to(torch.int32).contiguous()
-        # ---- 2. request item rows from their owners
+        # ---- 2. request item rows from their owners (references to replicated hot items ask nobody)
         item_g = torch.cat([p_g, n_g])                                    # [2T]
         live2 = torch.cat([live, live])
+        H = self.hot
+        is_hot = live2 & (item_g < H) if H else torch.zeros_like(live2)
+        if H and not self._hot_loaded:
+            self.load_hot()
         cap2 = self._cap(2 * T)
-        slot2, ov2 = bucket_slots(torch.where(live2, owner_of(item_g, N), torch.full_like(item_g, -1)), N, cap2)
+        slot2, ov2 = bucket_slots(torch.where(live2 & ~is_hot, owner_of(item_g, N), torch.full_like(item_g, -1)), N, cap2)
         trash2 = N * cap2
         slot2s = torch.where(slot2 >= 0, slot2, torch.full_like(slot2, trash2))
         send2 = torch.full((trash2 + 1,), -1, dtype=torch.int32, device=dev)
-        send2.index_copy_(0, slot2s, item_g.to(torch.int32))
+        send2.index_copy_(0, slot2s, torch.where(is_hot, torch.full_like(item_g, -1), item_g).to(torch.int32))
         req = self._a2a(send2[:trash2].contiguous()).long()               # ids requested from me
         req_loc = torch.where(req >= 0, local_index(req, N), torch.full_like(req, -1)).to(torch.int32).contiguous()
         # ---- 3. owners gather rows (+ bias at column D) and send them back
@@ -647,9 +726,15 @@ class ShardedPairwise:
         rows_in = torch.zeros((trash2 + 1, DS), dtype=torch.float32, device=dev)
         rows_in[:trash2] = self._a2a(rows_out)
         item_rows = rows_in.index_select(0, slot2s)                       # [2T, DS] in my reference order
+        if H:                                                             # hot references: the local replica
+            hot_ids = torch.where(is_hot, item_g, torch.full_like(item_g, -1)).to(torch.int32).contiguous()
+            hot_rows = torch.zeros((2 * T, DS), dtype=torch.float32, device=dev)
+            self.be.gather_rows(self.Vh, self.bh, hot_ids, hot_rows)
+            item_rows = torch.where(is_hot[:, None], hot_rows, item_rows)
         p_rows, n_rows = item_rows[:T].contiguous(), item_rows[T:].contiguous()
         # a triplet whose item request overflowed a bucket is dropped (and reported by check())
-        ok = live & (slot2[:T] >= 0) & (slot2[T:] >= 0)
+        got = (slot2 >= 0) | is_hot
+        ok = live & got[:T] & got[T:]
         valid = torch.where(ok, u_loc, torch.full_like(u_loc, -1)).contiguous()
         # ---- 4. local rows, score, gradients
         u_rows = torch.zeros((T, DS), dtype=torch.float32, device=dev)
@@ -662,13 +747,22 @@ class ShardedPairwise:
         self.be.begin_step()
         self.be.apply_rows(self.U, None, valid, gu)
         # ---- 6. item-row gradients go back along route 2 and are applied by the owners
+        g_all = torch.cat([gp, gn])
         send_g = torch.zeros((trash2 + 1, DS), dtype=torch.float32, device=dev)
-        dead = ~torch.cat([ok, ok])
-        send_g.index_copy_(0, torch.where(dead, torch.full_like(slot2s, trash2), slot2s), torch.cat([gp, gn]))
+        dead = ~torch.cat([ok, ok]) | is_hot
+        send_g.index_copy_(0, torch.where(dead, torch.full_like(slot2s, trash2), slot2s), g_all)
         g_in = self._a2a(send_g[:trash2].contiguous())
         # a request whose triplet was dropped carries a zero gradient: harmless for SGD, and for
         # Adagrad acc += 0, var -= 0
         self.be.apply_rows(self.V, self.b, req_loc, g_in)
+        if H:
+            # ---- 7. hot rows: this rank's gradients summed per row, ONE all-reduce of the [H, DS] block, the same apply on every replica
+            # (every row of the block: a row nobody referenced carries a zero gradient, see above)
+            hg = torch.zeros((H, DS), dtype=torch.float32, device=dev)
+            use = is_hot & torch.cat([ok, ok])
+            hg.index_add_(0, torch.where(use, item_g, torch.zeros_like(item_g)), torch.where(use[:, None], g_all, torch.zeros_like(g_all)))
+            self._allreduce(hg)
+            self.be.apply_rows(self.Vh, self.bh, torch.arange(H, dtype=torch.int32, device=dev), hg)
         self.overflow |= ov1 | ov2
         return None
 

@@ -216,3 +216,74 @@ def test_sharded_engine_checkpoint_resumes(tmp_path, optk):
     r.check()
     for x, y in ((a.U, r.U), (a.V, r.V), (a.b, r.b)):
         assert np.abs(x.read() - y.read()).max() <= 1e-6 * np.abs(x.read()).max()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+@pytest.mark.parametrize("model,optk", [("bpr", "sgd"), ("bpr", "adagrad"), ("ucml", "sgd"), ("bpr", "adam")])
+def test_hot_item_replication_on_the_device_backend(world, model, optk):
+    """ShardedPairwise(hot_items=H) with the HIP building blocks (orx_gather_rows / orx_pair_grads / orx_apply_rows on shards AND
+    replicas): Zipf(1.05) item ids, the 256 most popular of 3000 items replicated, `world` engines in threads of this process
+    (in-process all-to-all / all-reduce), against the single-process oracle on the global batch."""
+    import threading
+    import torch
+    from openrec_amd import sharded
+    from oracle import numpy_oracle as orc
+    torch.cuda.init()
+    dev = torch.device("cuda", 0)
+    NU, NI, D, Bg, H, steps = 1001, 3000, 64, 2048, 256, 3
+    rng = np.random.default_rng(9)
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    w = 1.0 / np.arange(1, NI + 1) ** 1.05
+    cdf = np.cumsum(w / w.sum())
+    draw = lambda: np.minimum(np.searchsorted(cdf, rng.random(Bg)), NI - 1).astype(np.int32)
+    data = [(rng.integers(0, NU, Bg).astype(np.int32), draw(), draw()) for _ in range(steps)]
+    assert np.mean(np.concatenate([d[1] for d in data]) < H) > 0.5          # most references are to replicated rows
+    cl = _FakeCluster(world)
+    red = [None] * world
+
+    def allreduce(rank):
+        def fn(x):
+            torch.cuda.synchronize()
+            red[rank] = x.clone()
+            cl.bar.wait()
+            x.zero_()
+            for src in range(world):
+                x += red[src]
+            torch.cuda.synchronize()
+            cl.bar.wait()
+        return fn
+    lr = LR_ADAM if optk == "adam" else 0.05
+    engs, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            e = sharded.ShardedPairwise(model, optk, NU, NI, D, lr=lr, rank=rank, world=world, device=dev, slack=3.0, hot_items=H,
+                                        a2a_fn=cl.a2a(rank) if world > 1 else None, allreduce_fn=allreduce(rank) if world > 1 else None)
+            e.U.write(U[rank::world]); e.V.write(V[rank::world]); e.b.write(b[rank::world])
+            engs[rank] = e
+            per = Bg // world
+            sl = slice(rank * per, (rank + 1) * per)
+            for (u, p, n) in data:
+                e.step(torch.from_numpy(u[sl].copy()).to(dev), torch.from_numpy(p[sl].copy()).to(dev), torch.from_numpy(n[sl].copy()).to(dev))
+            e.check()
+            e.sync_hot()
+        except Exception as ex:                             # pragma: no cover
+            errs.append(ex)
+            cl.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    o = {"sgd": lambda: orc.SGD(0.05), "adagrad": lambda: orc.Adagrad(0.05, 0.1, 1e-7), "adam": lambda: orc.AdamTFSparse(LR_ADAM)}[optk]()
+    tl = 0.0
+    for (u, p, n) in data:
+        l, _ = orc.bpr_step(U, V, b, u, p, n, o) if model == "bpr" else orc.ucml_step(U, V, b, u, p, n, o, do_censor=False)
+        tl += float(l)
+    tol = TOL_ADAM if optk == "adam" else 2e-5
+    got = 0.0
+    for r, e in enumerate(engs):
+        for have, want, nm in ((e.U.read(), U, "U"), (e.V.read(), V, "V"), (e.b.read(), b, "b")):
+            assert rel_err(have[:len(want[r::world])], want[r::world]) < tol, (r, nm)
+        got += float(e.accum[0])
+    assert abs(got - tl) <= 2e-5 * abs(tl)

@@ -226,3 +226,78 @@ def test_sharded_checkpoint_resumes_at_world_2(tmp_path, optk):
         for k in ("U", "V", "b"):
             assert np.array_equal(g[k], g[k + "2"]), (r, k)
     assert sorted(f for f in os.listdir(tmp_path / "ck")) == ["ref.rank0of2.pkl", "ref.rank1of2.pkl"]
+
+
+def _zipf_case(model, seed=1, NU=101, NI=400, B=96, D=16, steps=3):
+    """item ids ~ Zipf(1.05) over a vocabulary sorted by popularity: the head of the distribution takes most references"""
+    rng = np.random.default_rng(seed)
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32)
+    V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    w = 1.0 / np.arange(1, NI + 1) ** 1.05
+    cdf = np.cumsum(w / w.sum())
+    draw = lambda: np.minimum(np.searchsorted(cdf, rng.random(B)), NI - 1).astype(np.int32)
+    out = []
+    for s in range(steps):
+        out.append((rng.integers(0, NU, B).astype(np.int32), draw(), draw()))
+    return U, V, b, out
+
+
+def _run_rank_hot(rank, world, port, model, optk, hot, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sharded_ref_backend import OracleBackend
+    from openrec_amd import sharded
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    U, V, b, steps = _zipf_case(model)
+    eng = sharded.ShardedPairwise(model, optk, U.shape[0], V.shape[0], U.shape[1], lr=0.05, rank=rank, world=world,
+                                  device=torch.device("cpu"), backend=OracleBackend(optk, 0.05), slack=3.0, hot_items=hot)
+    eng.U.w[:] = U[rank::world]; eng.V.w[:] = V[rank::world]; eng.b.w[:] = b[rank::world]
+    per = steps[0][0].shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)
+    wire = 0
+    real_a2a = eng._a2a
+
+    def counting(send, recv=None):                        # floats this rank puts on the wire in the row / gradient exchanges
+        nonlocal wire
+        if send.dtype == torch.float32:
+            wire += int((send.abs().sum(-1) > 0).sum())
+        return real_a2a(send, recv)
+    eng._a2a = counting
+    for (u, p, n) in steps:
+        eng.step(torch.from_numpy(u[sl].copy()), torch.from_numpy(p[sl].copy()), torch.from_numpy(n[sl].copy()))
+    eng.check()
+    eng.sync_hot()                                        # the trained hot rows go back into the owners' shards
+    loss, l2 = eng.loss_sums()
+    np.savez(out % rank, U=eng.U.w, V=eng.V.w, b=eng.b.w, loss=loss, l2=l2, wire=wire)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model,optk", [("bpr", "sgd"), ("bpr", "adagrad"), ("ucml", "sgd"), ("bpr", "adam")])
+def test_hot_item_replication_equals_single_process_on_zipf_ids(tmp_path, model, optk):
+    """with Zipf(1.05) item ids the 64 most popular of 400 items are replicated on both ranks (references read the
+    replica, gradients are summed over the ranks by one all-reduce per step).  Same tables and losses as the single-process oracle on
+    the global batch -- and far fewer item rows on the wire than without replication."""
+    U, V, b, steps = _zipf_case(model)
+    res = {}
+    for hot in (0, 64):
+        out = str(tmp_path / ("h%d_" % hot)) + "r%d.npz"
+        mp.spawn(_run_rank_hot, args=(2, _free_port(), model, optk, hot, out), nprocs=2, join=True)
+        res[hot] = [np.load(out % r) for r in range(2)]
+    o = {"sgd": lambda: orc.SGD(0.05), "adagrad": lambda: orc.Adagrad(0.05, 0.1, 1e-7), "adam": lambda: orc.AdamTFSparse(0.05)}[optk]()
+    Uo, Vo, bo = U.copy(), V.copy(), b.copy()
+    tl = 0.0
+    for (u, p, n) in steps:
+        l, _ = orc.bpr_step(Uo, Vo, bo, u, p, n, o) if model == "bpr" else orc.ucml_step(Uo, Vo, bo, u, p, n, o, do_censor=False)
+        tl += float(l)
+    tol = 5e-5 if optk == "adam" else 1e-5
+    for hot in (0, 64):
+        for r in range(2):
+            g = res[hot][r]
+            assert rel_err(g["U"], Uo[r::2]) < tol and rel_err(g["V"], Vo[r::2]) < tol and rel_err(g["b"], bo[r::2]) < tol, (hot, r)
+            assert abs(float(g["loss"]) - tl) < 1e-5 * abs(tl)
+    wire0, wire1 = (sum(int(g["wire"]) for g in res[h]) for h in (0, 64))
+    assert wire1 < 0.55 * wire0, (wire0, wire1)           # most item references were to hot rows
