@@ -772,7 +772,7 @@ class ShardedPairwise:
         if hasattr(self.be, "stream"):
             self.be.stream.synchronize()
         t = self.accum.clone()
-        if self.world > 1:
+        if self.world > 1 and self.a2a_fn is None:          # (an injected exchange -- tests -- has no process group: per-rank sums)
             dist.all_reduce(t, group=self.group)
         return float(t[0]), float(t[1])
 
@@ -785,7 +785,7 @@ class ShardedPairwise:
         ov = self.overflow.clone().to(torch.int32)
         if self._ovf is not None:
             ov = ov + self._ovf[0]
-        if self.world > 1:
+        if self.world > 1 and self.a2a_fn is None:
             dist.all_reduce(ov, group=self.group)
         if int(ov) != 0:
             raise RuntimeError("sharded exchange: bucket capacity exceeded (raise `slack`)")
