@@ -694,7 +694,30 @@ int orx_exact_plan_issue(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
     ORX_HIP(hipMemcpyAsync(c->h_plan + 8 * i0, c->d_alloc + 8 * i0, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // ([5] = duplicated rows)
     ORX_HIP(hipEventRecord(counters, c->stream));
     if (d.pair_tpw > 1) {
-        // pairing: the fused kernel's input is packed once every flag sits on the rewritten ids (urgent marks included)
+        // pairing: the fused kernel's input is packed once every flag sits on the rewritten ids (urgent marks included).
+        // MEASURED AND LEFT OFF (profiles/r4_plan_side_stream.txt; ORX_PLAN_SIDE=1 turns it on): step 0 of a chunk needs no urgent
+        // marks, so its record can be packed alone and its launch go out at once while the marks and the records of the other steps
+        // (~25 us of light kernels at K = 20) are made on the plan stream BESIDE step 0 -- 37.8 us/step against 37.1 without: what
+        // runs beside a fused launch takes from it what it gets (the verdict of rounds 2 and 3 on every such overlap).
+        static const bool side = getenv("ORX_PLAN_SIDE") != nullptr && getenv("ORX_PLAN_PIPE") == nullptr;
+        if (side && after_readback && *after_readback && kc > 1 && c->plan_stream && c->stream != c->plan_stream && i0 == 0) {
+            hipStream_t main_stream = c->stream;
+            ORX_HIP(hipEventRecord(c->pipe_cnt[1], main_stream));               // the plan (ranges, pairs) is complete here
+            ORX_HIP(hipStreamWaitEvent(c->plan_stream, c->pipe_cnt[1], 0));
+            c->stream = c->plan_stream;
+            int rc = inline_apply ? orx_launch_plan_urgent(c, d, kc, i0) : ORX_OK;
+            DedupArgs rest = d;                                                 // steps 1 .. kc - 1 (the arrays the pack kernel reads / writes)
+            rest.ids_out += d.flag_stride; rest.partner += d.pair_stride; rest.ids4 += d.pair_stride;
+            if (rc == ORX_OK) rc = orx_launch_plan_pack(c, rest, kc - 1);
+            const hipError_t e = hipEventRecord(c->pipe_done[1], c->plan_stream);
+            c->stream = main_stream;
+            CHECK(rc);
+            ORX_HIP(e);
+            CHECK(orx_launch_plan_pack(c, d, 1));
+            CHECK((*after_readback)());
+            ORX_HIP(hipStreamWaitEvent(main_stream, c->pipe_done[1], 0));
+            return ORX_OK;
+        }
         if (inline_apply) CHECK(orx_launch_plan_urgent(c, d, kc, i0));
         CHECK(orx_launch_plan_pack(c, d, kc));
         if (after_readback && *after_readback) CHECK((*after_readback)());
