@@ -884,18 +884,33 @@ extern "C" int orx_rank_metrics_csr(orx_ctx* c, int kind, orx_table* U, orx_tabl
     a.excl_ptr = d_ep; a.excl_items = d_ei; a.NI = items; a.W = W; a.at = d_at; a.nat = nat;
     a.auc = d_auc; a.ndcg = d_ndcg; a.recall = d_rec; a.err = c->d_err; a.part = d_part; a.neval = d_neval; a.S = S;
     a.flag_out = d_flag; a.q0 = 0;
-    CHECK(orx_launch_mask_bits(c, a, n, 0));
-    if (dev_pred || pred) {
-        if (!dev_pred) ORX_HIP(hipMemcpyAsync(d_pred, pred, cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        CHECK(orx_launch_rank_sweeps(c, a, 0, n, max_pos));
-    } else {
+    // Everything that can fail without touching the bitmaps comes FIRST: the bitmaps are all zero between calls, the first
+    // orx_launch_mask_bits sets bits and only the last one clears them again -- an early return in between would leave every later
+    // evaluation on this context with stale masks.
+    const bool scorer = !(dev_pred || pred);
+    if (scorer) {
         ORX_ARG(kind >= 0 && kind <= 2 && U->dim == V->dim && U->dim <= 1024, "orx_rank_metrics_csr: bad scorer arguments");
         ENSURE(c->d_ids, c->d_ids_cap, (size_t)n * sizeof(int32_t));
         CHECK(stage_ids(c, uid, n, 0));
-        // (scoring and sweeping slices of the batch on two streams -- a write stream beside a read stream -- was measured and is
-        // slower at every slice count: profiles/r3_eval_notes.txt)
-        CHECK(orx_launch_score_all(c, U->w, V->w, b->w, w ? w->w : nullptr, c->d_ids, n, U->rows, V->rows, U->dim, kind, d_pred));
-        CHECK(orx_launch_rank_sweeps(c, a, 0, n, max_pos));
+    }
+    CHECK(orx_launch_mask_bits(c, a, n, 0));
+    // ... and whatever fails from here on clears them before it leaves
+    auto body = [&]() -> int {
+        if (!scorer) {
+            if (!dev_pred) ORX_HIP(hipMemcpyAsync(d_pred, pred, cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            CHECK(orx_launch_rank_sweeps(c, a, 0, n, max_pos));
+        } else {
+            // (scoring and sweeping slices of the batch on two streams -- a write stream beside a read stream -- was measured and is
+            // slower at every slice count: profiles/r3_eval_notes.txt)
+            CHECK(orx_launch_score_all(c, U->w, V->w, b->w, w ? w->w : nullptr, c->d_ids, n, U->rows, V->rows, U->dim, kind, d_pred));
+            CHECK(orx_launch_rank_sweeps(c, a, 0, n, max_pos));
+        }
+        return ORX_OK;
+    };
+    const int body_rc = body();
+    if (body_rc != ORX_OK) {
+        hipMemsetAsync(c->d_evalbits, 0, bit_bytes, c->stream);
+        return body_rc;
     }
     CHECK(orx_launch_mask_bits(c, a, n, 1));
     ORX_HIP(hipMemcpyAsync(pack.data(), d_auc, nout * 4, hipMemcpyDeviceToHost, c->stream));

@@ -130,7 +130,8 @@ __device__ __forceinline__ void rank_thresholds(RankLds<STEPS>& L, const EvalCsr
     constexpr int NT = RankLds<STEPS>::NT;
     const int tid = threadIdx.x;
     if (tid < NT) {
-        const int i = tid < pc ? a.pos_items[p0 + c0 + tid] : -1;
+        int i = tid < pc ? a.pos_items[p0 + c0 + tid] : -1;
+        if ((int64_t)i >= a.NI) i = -1;                   // (an item id outside the table: mask_bits has flagged it, nothing is read for it)
         L.raw_s[tid] = i >= 0 ? s[i] : INFINITY;
         L.raw_ex[tid] = i >= 0 && ((eb[i >> 5] >> (i & 31)) & 1u);
     }
