@@ -385,8 +385,7 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
     // Per-destination dedup (an item several references of a list ask for travels once) costs a sort and an un-sort of the
     // references at plan time (~25 us per step at 131 k references): on by default where the item references a rank handles per list (2 B) are at least
     // half as many as the items (then most slots are shared), off for sparse lists (1 M items: 6 % of the references repeat)
-    const int Hq = ((flags & ORX_SHARD_OVERLAP) && (c->comm || c->vg) && c->world > 1 && B % 2 == 0 && id_stride == B) ? 2 : 1;
-    const bool dedup = (flags & ORX_SHARD_DEDUP) ? true : (flags & ORX_SHARD_NO_DEDUP) ? false : (4 * (B / Hq) >= items_global);
+    const bool dedup = (flags & ORX_SHARD_DEDUP) ? true : (flags & ORX_SHARD_NO_DEDUP) ? false : (4 * (B / H) >= items_global);
     const int64_t Bh = B / H;
     const int64_t cap1 = bucket_cap(Bh, N, slack), T = N * cap1, cap2 = bucket_cap(2 * T, N, slack), M = N * cap2;
     // SGD: the biases travel apart from the rows (D + 1 floats per requested row on the wire; the rows stay 16-byte aligned);

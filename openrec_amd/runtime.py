@@ -425,8 +425,13 @@ def score_all_items(kind, user, item, bias, uid, w=None, device=False):
         raise ValueError("score_all_items takes host ids")
     k = {"dot": 0, "l2": 1, "gmf": 2}[kind]
     if device:
-        import torch
+        try:
+            import torch
+        except ImportError:                  # torch is optional on the single-GPU path: the scores then come back as a host array
+            torch = None
+    if device and torch is not None:
         out = torch.empty((n, item.rows), dtype=torch.float32, device=torch.device("cuda", user.ctx.device))
+        user.ctx.after_torch(out)            # (a cached block may still have work of torch's stream pending: the library's stream waits for it)
         check(lib.orx_score_all_items_device(user.ctx._h, k, user._h, item._h, bias._h, w._h if w is not None else None,
                                              ptr, n, out.data_ptr()))
         return DeviceScores(user.ctx, out)

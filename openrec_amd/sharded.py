@@ -247,7 +247,8 @@ class HipBackend:
         mid = {"bpr": self._ffi.ORX_BPR, "ucml": self._ffi.ORX_UCML}[model]
         K, B = uid.shape
         assert uid.stride(1) == 1 and pid.stride() == uid.stride() and nid.stride() == uid.stride()
-        flags = (self._ffi.ORX_SHARD_OVERLAP if overlap else 0) | (self._ffi.ORX_SHARD_DEDUP if dedup else self._ffi.ORX_SHARD_NO_DEDUP)
+        flags = (self._ffi.ORX_SHARD_OVERLAP if overlap else 0) | \
+            (0 if dedup is None else (self._ffi.ORX_SHARD_DEDUP if dedup else self._ffi.ORX_SHARD_NO_DEDUP))
         self._ffi.check(self.lib.orx_sharded_pairwise_steps(comm, self.opt._h, mid, U._h, V._h, b._h, uid.data_ptr(), pid.data_ptr(),
                                                             nid.data_ptr(), K, B, uid.stride(0), n_users, n_items, margin, slack,
                                                             plan_chunk, flags, accum.data_ptr(), ovf.data_ptr()))
@@ -525,7 +526,7 @@ class ShardedPairwise:
             with self.be.stream_ctx():
                 self.be.sharded_steps(self._comm, self.model, self.U, self.V, self.b, uid, pid, nid, self.n_users, self.n_items,
                                       self.margin, self.slack, plan_chunk, ov, self.accum, self._ovf,
-                                      dedup=self._dedup_for(B // 2 if (ov and self.world > 1 and B % 2 == 0) else B))
+                                      dedup=self.dedup)      # (None: the engine decides per list, by the same rule as _dedup_for)
             return None
         if overlap is None:       # two half-batches per step pay once there is a link to hide behind
             overlap = (self.world > 1 or self.force_collectives) and self.a2a_fn is None

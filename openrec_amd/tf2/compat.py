@@ -301,6 +301,7 @@ class _AllItemScores:
         bias = getattr(other, "flat_of", None)
         if isinstance(bias, Variable) and bias.table.dim == 1 and bias.table.rows == self.item_var.table.rows:
             ids = self.rows.flat_ids()
+            self.rows.consumed()         # (scored in HBM: the lookup is never gathered to the host)
             return rt.score_all_items("dot", self.rows.factor.table, self.item_var.table, bias.table, ids, device=True)
         return HostTensor(np.asarray(self) + np.asarray(other))
 

@@ -230,6 +230,7 @@ def try_all_item_scores(e):
     rows, item_var = ui
     if item_var.table.rows != bias.table.rows or rows.factor.dim != item_var.table.dim:
         return None
+    rows.consumed()          # (the scorer reads the user rows in HBM: nobody will look at this lookup on the host)
     return rt.score_all_items(kind, rows.factor.table, item_var.table, bias.table, rows.flat_ids(), w=w, device=True)
 
 
