@@ -762,6 +762,8 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         CHECK(orx_launch_dlrm_loss(c, pred, bt.label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, m->d_loss + s, 0, 0, gscale));
         const bool fuse_dense = m->gen2 && getenv("ORX_DLRM_NO_FUSED_DENSE") == nullptr;
         CHECK(backward(m, bt, B, gscale, fuse_dense));
+        // (tried, round 4: the sorted sparse apply on a second stream beside the bottom MLP's backward and the dense apply -- 0.578 against
+        // 0.580 ms per step: the launches fill the chip one after the other either way.)
         // ---- optimizer: one step counter for all variables (Keras `iterations`)
         opt->t += 1;
         float lr_t = 0.f;

@@ -18,6 +18,7 @@
 //                      gradient: fp32 atomics run at ~85 G/s here (+95 us for a 1024x1024 layer), an in-kernel last-arriver
 //                      reduction pays an L2 write-back + invalidate per workgroup (+50 us), slabs + one reduce launch +14 us.
 #include "orx_device.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -37,6 +38,117 @@ struct Nt16Args {
 // XCD-aware tile order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so id b -> slot
 // (b % 8) * (n / 8) + b / 8 hands every XCD a contiguous run of the row-major tile list
 __device__ __forceinline__ int xcd_slot(int b, int n) { return (n & 7) ? b : (b & 7) * (n >> 3) + (b >> 3); }
+
+// the products' common epilogue: + bias, activation, stores, or the fused activation backward with its column sums (see the head
+// of the file); `red` = LDS that is free once the main loop is over, [WM][BN] floats
+template <int WM, int WN, int TM, int TN, bool NTS = false>
+__device__ __forceinline__ void nt_epilogue(const Nt16Args& g, f32x4 (&acc)[TM][TN], int bm, int bn, int wm, int wn, float* red) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = 64 * WM * WN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    // ---- epilogue: the lane holds C[row = .. + r16][col = 32 * np + 8q .. + 7] for every tile pair np
+    static_assert(TN % 2 == 0, "tile pairs");
+    const bool vec = (g.N & 7) == 0;
+    float cs[TN / 2][8];
+#pragma unroll
+    for (int np = 0; np < TN / 2; ++np)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[np][e] = 0.0f;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int row = bm + wm + mi * 16 + r16;
+#pragma unroll
+        for (int np = 0; np < TN / 2; ++np) {
+            const int col = bn + wn + np * 32 + q * 8;
+            if (row >= g.M || col >= g.N) continue;
+            float v[8] = {acc[mi][2 * np].x, acc[mi][2 * np].y, acc[mi][2 * np].z, acc[mi][2 * np].w,
+                          acc[mi][2 * np + 1].x, acc[mi][2 * np + 1].y, acc[mi][2 * np + 1].z, acc[mi][2 * np + 1].w};
+            const bool full = vec && col + 7 < g.N;
+            if (g.bias) {
+                if (full) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + col), b1 = *reinterpret_cast<const f32x4*>(g.bias + col + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (col + e < g.N) v[e] += g.bias[col + e];
+                }
+            }
+            if (g.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+            } else if (g.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
+            }
+            if (g.actY || g.actY16) {
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = 0.0f;
+                if (g.actY16) {
+                    if (full && (g.ldy & 7) == 0) {
+                        const h8 t8 = *reinterpret_cast<const h8*>(g.actY16 + (int64_t)row * g.ldy + col);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) y[e] = (float)t8[e];
+                    } else {
+                        for (int e = 0; e < 8; ++e) if (col + e < g.N) y[e] = (float)g.actY16[(int64_t)row * g.ldy + col + e];
+                    }
+                } else {
+                    if (full && (g.ldy & 3) == 0) {
+                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(g.actY + (int64_t)row * g.ldy + col), t1 = *reinterpret_cast<const f32x4*>(g.actY + (int64_t)row * g.ldy + col + 4);
+                        y[0] = t0.x; y[1] = t0.y; y[2] = t0.z; y[3] = t0.w; y[4] = t1.x; y[5] = t1.y; y[6] = t1.z; y[7] = t1.w;
+                    } else {
+                        for (int e = 0; e < 8; ++e) if (col + e < g.N) y[e] = g.actY[(int64_t)row * g.ldy + col + e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = g.act_y == 1 ? (y[e] > 0.0f ? v[e] : 0.0f) : (g.act_y == 2 ? v[e] * y[e] * (1.0f - y[e]) : v[e]);
+                    if (col + e < g.N) cs[np][e] += v[e];
+                }
+            }
+            if (g.C) {
+                float* p = g.C + (int64_t)row * g.ldc + col;
+                if (full && (g.ldc & 3) == 0) {
+                    f32x4 o0, o1; o0.x = v[0]; o0.y = v[1]; o0.z = v[2]; o0.w = v[3]; o1.x = v[4]; o1.y = v[5]; o1.z = v[6]; o1.w = v[7];
+                    if (NTS) { __builtin_nontemporal_store(o0, reinterpret_cast<f32x4*>(p)); __builtin_nontemporal_store(o1, reinterpret_cast<f32x4*>(p + 4)); }
+                    else { *reinterpret_cast<f32x4*>(p) = o0; *reinterpret_cast<f32x4*>(p + 4) = o1; }
+                } else {
+                    for (int e = 0; e < 8; ++e) if (col + e < g.N) p[e] = v[e];
+                }
+            }
+            if (g.C16) {
+                _Float16* p = g.C16 + (int64_t)row * g.ldc16 + col;
+                if (full && (g.ldc16 & 7) == 0) {
+                    h8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+                    if (NTS) __builtin_nontemporal_store(o, reinterpret_cast<h8*>(p)); else *reinterpret_cast<h8*>(p) = o;
+                } else {
+                    for (int e = 0; e < 8; ++e) if (col + e < g.N) p[e] = (_Float16)v[e];
+                }
+            }
+        }
+    }
+    if (g.gb) {
+        // column sums: over the 16 rows of a lane group (DPP), over the block's WM wavefronts through LDS (the stages are
+        // free now), then ONE plain store per (workgroup, column) into the row block's partial row: colparts_reduce_kernel adds
+        // the row blocks in order (atomics would make the sum depend on arrival order)
+#pragma unroll
+        for (int np = 0; np < TN / 2; ++np)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float s = group_allreduce<16>(cs[np][e]);
+                if (r16 == 0) red[(wave / WN) * BN + wn + np * 32 + q * 8 + e] = s;
+            }
+        __syncthreads();
+        for (int cidx = threadIdx.x; cidx < BN; cidx += NT) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) s += red[w * BN + cidx];
+            if (bn + cidx < g.N) g.gb[(int64_t)(bm / BM) * g.N + bn + cidx] = s;
+        }
+    }
+}
 
 // PAD: halves of padding per LDS tile row.  8 (144-byte rows) leaves 36 % of the LDS-active cycles in bank conflicts
 // (profiles/r2_dlrm_fp16_pmc_mfma_lds.csv); 16 (160-byte rows) removes them: main loop 21.1 -> 20.0 us on 8192 x 1024 x 1024
@@ -116,108 +228,204 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_kernel(Nt16Args 
         compute(cur);
         __syncthreads();
     }
-    // ---- epilogue: the lane holds C[row = .. + r16][col = 32 * np + 8q .. + 7] for every tile pair np
-    static_assert(TN % 2 == 0, "tile pairs");
-    const bool vec = (g.N & 7) == 0;
-    float cs[TN / 2][8];
+    nt_epilogue<WM, WN, TM, TN>(g, acc, bm, bn, wm, wn, reinterpret_cast<float*>(lds16));
+}
+
+// ---- the same product with the tiles brought into LDS by the LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+// ds_write pass -- the 16-byte LDS stores of the kernel above move 48 KB per K step at ~79 B/clk, more LDS time than the
+// fragment reads of the step).  The DMA writes lane-linear (wave-uniform base + 16 * lane), so a tile row is 128 bytes without
+// padding and the bank spread comes from the SOURCE side: LDS row r holds the eight 16-byte chunks of its K slice at slot
+// (chunk ^ (r & 7)); a ds_read_b128 lane group (16 rows, two of the four k-chunks) then covers all 64 banks once.
+// NS LDS stages: tile s + NS is requested while the second half of tile s is multiplied; one raw s_barrier per K step, the waits
+// on the DMA are counted (vmcnt) so that NS - 2 tiles stay in flight across the barrier.
+// Chunks beyond a row's leading dimension (K tails) and rows beyond M / N come from a 16-byte block of zeros.
+__device__ __attribute__((aligned(16))) const _Float16 g_zero_chunk[8] = {};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// TAIL: a leading dimension is not a multiple of 64 halves (the last tile's chunks beyond it come from the zeros, through per-lane
+// 64-bit addresses).  All other requests are `global_load_lds_dwordx4 v_offset, s[base]`: a scalar base that advances with the tile
+// and 32-bit per-lane offsets made once -- no vector arithmetic per request.
+// DBG (scratch/exp_dma.hip only): 1 = no epilogue, 2 = no DMA inside the loop, 4 = no fragment reads / MFMA, 16 = nontemporal stores,
+// 8 = with 1: the main loop's duration in shader cycles and in 100 MHz ticks goes to g.C as [workgroup][2] 64-bit counts
+template <int WM, int WN, int TM, int TN, int MINB, int NS, bool TAIL, int DBG = 0>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_dma_kernel(Nt16Args g) {
+    constexpr int BK = 64, BM = WM * TM * 16, BN = WN * TN * 16, NT = 64 * WM * WN;
+    constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT, NL = NA + NB;            // DMA instructions per wavefront and tile
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile / thread mismatch");
+    static_assert(NS == 2 || NS == 3, "two or three stages");
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds16[];
+    constexpr int STAGE = (BM + BN) * BK;                                      // halves
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = xcd_slot(blockIdx.x, gridDim.x);
+    const int ntn = (g.N + BN - 1) / BN;
+    const int bm = (t / ntn) * BM, bn = (t % ntn) * BN;
+    const int wm = (wave / WN) * TM * 16, wn = (wave % WN) * TN * 16;
+    const int r16 = lane & 15, q = lane >> 4;
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int np = 0; np < TN / 2; ++np)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) cs[np][e] = 0.0f;
+        for (int j = 0; j < TN; ++j) { acc[i][j].x = acc[i][j].y = acc[i][j].z = acc[i][j].w = 0.0f; }
+    // the lane's source chunk of DMA instruction i: LDS chunk c = 64 * wave + lane + NT * i -> LDS row c / 8, slot c % 8.  Rows
+    // beyond M / N are clamped to the last one (their products are never stored).
+    // B rows are permuted on their way into LDS exactly as in the kernel above (column n = 32a + 8b + 4c + d sits in LDS row
+    // 32a + 16c + 4b + d): LDS row r = 32a + 16c + 4b + d is column 32a + 8b + 4c + d
+    unsigned off[NL];                                                          // byte offset of the chunk from A / B at k0 = 0
+    int kc[NL];                                                                // TAIL: the chunk's k offset inside a tile (halves)
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        const int row = bm + wm + mi * 16 + r16;
-#pragma unroll
-        for (int np = 0; np < TN / 2; ++np) {
-            const int col = bn + wn + np * 32 + q * 8;
-            if (row >= g.M || col >= g.N) continue;
-            float v[8] = {acc[mi][2 * np].x, acc[mi][2 * np].y, acc[mi][2 * np].z, acc[mi][2 * np].w,
-                          acc[mi][2 * np + 1].x, acc[mi][2 * np + 1].y, acc[mi][2 * np + 1].z, acc[mi][2 * np + 1].w};
-            const bool full = vec && col + 7 < g.N;
-            if (g.bias) {
-                if (full) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + col), b1 = *reinterpret_cast<const f32x4*>(g.bias + col + 4);
-                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) if (col + e < g.N) v[e] += g.bias[col + e];
-                }
-            }
-            if (g.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
-            } else if (g.act == 2) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
-            }
-            if (g.actY || g.actY16) {
-                float y[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = 0.0f;
-                if (g.actY16) {
-                    if (full && (g.ldy & 7) == 0) {
-                        const h8 t8 = *reinterpret_cast<const h8*>(g.actY16 + (int64_t)row * g.ldy + col);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) y[e] = (float)t8[e];
-                    } else {
-                        for (int e = 0; e < 8; ++e) if (col + e < g.N) y[e] = (float)g.actY16[(int64_t)row * g.ldy + col + e];
-                    }
-                } else {
-                    if (full && (g.ldy & 3) == 0) {
-                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(g.actY + (int64_t)row * g.ldy + col), t1 = *reinterpret_cast<const f32x4*>(g.actY + (int64_t)row * g.ldy + col + 4);
-                        y[0] = t0.x; y[1] = t0.y; y[2] = t0.z; y[3] = t0.w; y[4] = t1.x; y[5] = t1.y; y[6] = t1.z; y[7] = t1.w;
-                    } else {
-                        for (int e = 0; e < 8; ++e) if (col + e < g.N) y[e] = g.actY[(int64_t)row * g.ldy + col + e];
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    v[e] = g.act_y == 1 ? (y[e] > 0.0f ? v[e] : 0.0f) : (g.act_y == 2 ? v[e] * y[e] * (1.0f - y[e]) : v[e]);
-                    if (col + e < g.N) cs[np][e] += v[e];
-                }
-            }
-            if (g.C) {
-                float* p = g.C + (int64_t)row * g.ldc + col;
-                if (full && (g.ldc & 3) == 0) {
-                    f32x4 o0, o1; o0.x = v[0]; o0.y = v[1]; o0.z = v[2]; o0.w = v[3]; o1.x = v[4]; o1.y = v[5]; o1.z = v[6]; o1.w = v[7];
-                    *reinterpret_cast<f32x4*>(p) = o0; *reinterpret_cast<f32x4*>(p + 4) = o1;
-                } else {
-                    for (int e = 0; e < 8; ++e) if (col + e < g.N) p[e] = v[e];
-                }
-            }
-            if (g.C16) {
-                _Float16* p = g.C16 + (int64_t)row * g.ldc16 + col;
-                if (full && (g.ldc16 & 7) == 0) {
-                    h8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
-                    *reinterpret_cast<h8*>(p) = o;
-                } else {
-                    for (int e = 0; e < 8; ++e) if (col + e < g.N) p[e] = (_Float16)v[e];
-                }
-            }
+    for (int i = 0; i < NL; ++i) {
+        const int c = wave * 64 + lane + NT * (i < NA ? i : i - NA), r = c >> 3;
+        kc[i] = ((c & 7) ^ (r & 7)) * 8;
+        if (i < NA) {
+            off[i] = (unsigned)(((int64_t)min(bm + r, g.M - 1) * g.lda + kc[i]) * 2);
+        } else {
+            const int n = (r & ~31) | ((r & 12) << 1) | ((r & 16) >> 2) | (r & 3);
+            off[i] = (unsigned)(((int64_t)min(bn + n, g.N - 1) * g.ldb + kc[i]) * 2);
         }
     }
-    if (g.gb) {
-        // column sums: over the 16 rows of a lane group (DPP), over the block's WM wavefronts through LDS (the stages are
-        // free now), then ONE plain store per (workgroup, column) into the row block's partial row: colparts_reduce_kernel adds
-        // the row blocks in order (atomics would make the sum depend on arrival order)
-        float* red = reinterpret_cast<float*>(lds16);           // [WM][BN]
-#pragma unroll
-        for (int np = 0; np < TN / 2; ++np)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float s = group_allreduce<16>(cs[np][e]);
-                if (r16 == 0) red[(wave / WN) * BN + wn + np * 32 + q * 8 + e] = s;
-            }
-        __syncthreads();
-        for (int cidx = threadIdx.x; cidx < BN; cidx += NT) {
-            float s = 0.0f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) s += red[w * BN + cidx];
-            if (bn + cidx < g.N) g.gb[(int64_t)(bm / BM) * g.N + bn + cidx] = s;
+    const char* const baseA = reinterpret_cast<const char*>(g.A);
+    const char* const baseB = reinterpret_cast<const char*>(g.B);
+    const int lda = (int)g.lda, ldb = (int)g.ldb;
+    auto issue_one = [&](int k0, _Float16* S, int i) {                       // request i of the NL of a tile (i: a constant after unrolling)
+        const int j = i < NA ? i : i - NA;
+        _Float16* dst = S + (i < NA ? 0 : BM * BK) + (NT * j + wave * 64) * 8;
+        if (TAIL && k0 + BK > (i < NA ? lda : ldb)) {                          // (uniform: the last tile of a row that ends inside it)
+            const char* p = (i < NA ? baseA : baseB) + (size_t)k0 * 2 + off[i];
+            if (k0 + kc[i] >= (i < NA ? lda : ldb)) p = reinterpret_cast<const char*>(g_zero_chunk);
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)dst, 16, 0, 0);
+        } else {
+            // (written out: the compiler folds the tile's advance into per-lane 64-bit addresses, two vector adds per request)
+            const char* sb = (i < NA ? baseA : baseB) + (size_t)k0 * 2;
+            const unsigned m0v = (unsigned)(uintptr_t)(lptr_t)dst;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off[i]), "s"(sb), "s"(m0v) : "memory");
         }
+    };
+    auto issue = [&](int k0, _Float16* S) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) issue_one(k0, S, i);
+    };
+    // fragment addresses: row * 64 halves + ((4 kk + q) ^ (row & 7)) * 8, and (row & 7) == (r16 & 7) for every fragment row
+    const int fa0 = (wm + r16) * BK + ((q ^ (r16 & 7)) * 8), fb0 = (BM + wn + r16) * BK + ((q ^ (r16 & 7)) * 8);
+    h8 a0[TM], b0[TN], a1[TM], b1[TN];                                         // fragments of the two 32-deep halves of a tile
+    auto fetch = [&](const _Float16* S, int kk, h8 (&a)[TM], h8 (&b)[TN]) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) a[mi] = *reinterpret_cast<const h8*>(S + ((fa0 + mi * 16 * BK) ^ (kk * 32)));
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const h8*>(S + ((fb0 + ni * 16 * BK) ^ (kk * 32)));
+    };
+    auto arrived = [&](h8 (&a)[TM], h8 (&b)[TN]) {                             // (see the end of `step`)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) asm volatile("" : "+v"(a[mi]));
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) asm volatile("" : "+v"(b[ni]));
+    };
+    // The loop is software-pipelined around ONE barrier per tile: the fragments of half 1 are read while half 0 is multiplied;
+    // then the barrier (every wavefront has read all of tile s: its stage is free; tile s + 1 has landed for everyone); then
+    // the fragments of tile s + 1's half 0 are read and the NL DMA requests of tile s + NS go out BETWEEN the products of half 1
+    // (a wavefront that issues its requests back to back stands still for ~150 cycles each).
+    const int nk = (g.K + BK - 1) / BK;
+    int cur = 0;                                                               // stage of tile s
+    // DMA: tile s + NS exists and is requested; MORE: tile s + 1 exists; INFLIGHT: tile s + 2 has been requested (NS = 3)
+    auto step = [&](auto dma_c, auto more_c, auto inflight_c, int s) {
+        constexpr bool DMA = decltype(dma_c)::value && !(DBG & 2), MORE = decltype(more_c)::value, INFLIGHT = decltype(inflight_c)::value;
+        _Float16* S = lds16 + cur * STAGE;
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        if (!(DBG & 4)) {
+            fetch(S, 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);                                 // (the reads go out first ...)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
+        }
+        // my reads of tile s are complete (their data is in a1 / b1); tile s + 1 has landed for me
+        __builtin_amdgcn_sched_barrier(0);                                     // (... and the products above stay above: they cover the reads)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (MORE) { if (NS == 3 && INFLIGHT) wait_vm<NL>(); else wait_vm<0>(); }
+        __builtin_amdgcn_s_barrier();
+        if (!(DBG & 4) && MORE) fetch(lds16 + cur * STAGE, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k0 = (s + NS) * BK;
+        if (DBG & 4) {
+            if (DMA) issue(k0, S);
+            return;
+        }
+        constexpr int EVERY = TM * TN / NL > 0 ? TM * TN / NL : 1;             // one request after every EVERY-th product
+        static_assert(TM * TN / EVERY >= NL, "not every request of a tile finds a place");
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+                const int done = mi * TN + ni + 1;
+                if (DMA && done % EVERY == 0 && done / EVERY <= NL) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_one(k0, S, done / EVERY - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        // the fragments read behind the barrier have arrived long before these products end; saying so HERE leaves no LDS read
+        // pending across the back edge (the compiler's wait counts then let the next half's reads fly under the products above)
+        if (MORE) arrived(a0, b0);
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) if (s < nk) issue(s * BK, lds16 + s * STAGE);
+    if (nk > 2 && NS == 3) wait_vm<2 * NL>(); else if (nk > 1) wait_vm<NL>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (!(DBG & 4)) { fetch(lds16, 0, a0, b0); arrived(a0, b0); }
+    unsigned long long dbg_c0 = 0, dbg_w0 = 0;
+    if (DBG & 8) { dbg_c0 = __builtin_amdgcn_s_memtime(); dbg_w0 = wall_clock64(); }
+    using T = std::true_type; using F = std::false_type;
+    int s = 0;
+    for (; s + NS < nk; ++s) step(T(), T(), T(), s);
+    if (NS == 3 && s + 2 < nk) { step(F(), T(), T(), s); ++s; }                // (tile s + 2 is the last one: in flight, nothing more to request)
+    if (s + 1 < nk) { step(F(), T(), F(), s); ++s; }
+    if (s < nk) step(F(), F(), F(), s);
+    if (DBG & 8) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();
+        if (threadIdx.x == 0) { unsigned long long* o = reinterpret_cast<unsigned long long*>(g.C) + 2 * blockIdx.x; o[0] = c1 - dbg_c0; o[1] = w1 - dbg_w0; }
     }
+    if (DBG & 1) {
+        float x = 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) x += acc[i][j].x + acc[i][j].y + acc[i][j].z + acc[i][j].w;
+        if (x == 12345.678f) g.C16[0] = (_Float16)x;
+        return;
+    }
+    if (g.gb) __syncthreads();                                                 // (the column sums go through the stages' LDS)
+    nt_epilogue<WM, WN, TM, TN, (DBG & 16) != 0>(g, acc, bm, bn, wm, wn, reinterpret_cast<float*>(lds16));
+}
+
+template <int WM, int WN, int TM, int TN, int MINB, int NS>
+static int launch_nt_dma(orx_ctx* ctx, const Nt16Args& g) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr size_t shm = (size_t)NS * (BM + BN) * 64 * 2;
+    const bool tail = (g.lda & 63) != 0 || (g.ldb & 63) != 0;
+    // ORX_GEMM16_NTS=1: the outputs leave through nontemporal stores.  Alone, 8192 x 1024 x 1024 goes from 24.4 to 21.0 us
+    // (scratch/exp_dma.hip); in the DLRM step the NEXT product then reads its operand from HBM instead of the caches and the
+    // step is slower (0.585 against 0.573 ms): off.
+    static const bool nts = getenv("ORX_GEMM16_NTS") != nullptr && atoi(getenv("ORX_GEMM16_NTS")) != 0;
+    auto kern = nts ? (tail ? gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, true, 16> : gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, false, 16>)
+                    : (tail ? gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, true, 0> : gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, false, 0>);
+    ORX_ONCE_PER_DEVICE(ctx, {
+        ORX_HIP(hipFuncSetAttribute((const void*)gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        ORX_HIP(hipFuncSetAttribute((const void*)gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        ORX_HIP(hipFuncSetAttribute((const void*)gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        ORX_HIP(hipFuncSetAttribute((const void*)gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    });
+    const unsigned nb = (unsigned)(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN));
+    ORX_LAUNCH(ctx, kern, dim3(nb), dim3(64 * WM * WN), shm, g);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
 }
 
 template <int WM, int WN, int TM, int TN, int MINB, int PAD>
@@ -249,9 +457,19 @@ int orx_launch_gemm16_nt(orx_ctx* ctx, const void* A16, int64_t lda, const void*
     const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
     // (the 4-wavefront configurations want two workgroups per CU: with one, every load and barrier latency of the short K
     // loops of the narrow layers is exposed -- a fused 8192 x 512 x 256 product took 18 us on 256 tiles of 128 x 128)
-    if (force == 1 || (force == 0 && blocks(256, 128) >= cus)) { if (gbp) gbp->P = (M + 255) / 256; return launch_nt<4, 2, 4, 4, 1, 16>(ctx, g); }
+    // ORX_GEMM16_DMA: 0 = the register-staged kernels, 2 / 3 = LDS-DMA staging with that many stages (default 3 for the 256 x 128 tile)
+    static const int dma_env = getenv("ORX_GEMM16_DMA") ? atoi(getenv("ORX_GEMM16_DMA")) : 3;
+    const int dma = ((int64_t)M * lda < (1LL << 30) && (int64_t)N * ldb < (1LL << 30)) ? dma_env : 0;      // (32-bit byte offsets from A and B)
+    if (force == 1 || (force == 0 && blocks(256, 128) >= cus)) {
+        if (gbp) gbp->P = (M + 255) / 256;
+        if (dma == 3) return launch_nt_dma<4, 2, 4, 4, 1, 3>(ctx, g);
+        if (dma == 2) return launch_nt_dma<4, 2, 4, 4, 1, 2>(ctx, g);
+        return launch_nt<4, 2, 4, 4, 1, 16>(ctx, g);
+    }
     if (gbp) gbp->P = (M + 127) / 128;
-    if (force == 2 || (force == 0 && blocks(128, 128) >= 2 * cus)) return launch_nt<2, 2, 4, 4, 2, 8>(ctx, g);
+    if (force == 2 || (force == 0 && blocks(128, 128) >= 2 * cus)) return dma ? launch_nt_dma<2, 2, 4, 4, 2, 2>(ctx, g) : launch_nt<2, 2, 4, 4, 2, 8>(ctx, g);
+    if (dma == 3) return launch_nt_dma<2, 2, 4, 2, 2, 3>(ctx, g);
+    if (dma == 2) return launch_nt_dma<2, 2, 4, 2, 2, 2>(ctx, g);
     return launch_nt<2, 2, 4, 2, 2, 16>(ctx, g);
 }
 
