@@ -34,6 +34,9 @@ struct DenseLayer {
 };
 
 static inline int up8(int x) { return (x + 7) & ~7; }
+// leading dimension of an fp16 operand whose rows are read in 64-deep K tiles (kernels_gemm16.hip: the LDS-DMA kernels take whole
+// tiles; a row that ends inside one costs the slower zero-chunk form) -- rows of 64 halves and more are padded to whole tiles
+static inline int up_k(int x) { return x >= 64 ? (x + 63) & ~63 : up8(x); }
 
 struct orx_dlrm {
     orx_ctx* ctx = nullptr;
@@ -158,7 +161,7 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
     if (flags & ORX_DLRM_FP16_MLP) {
         std::vector<ShadowParam> sp;
         auto add = [&](DenseLayer& D) -> int {
-            D.ld16 = up8(D.out); D.ld16t = up8(D.in);
+            D.ld16 = up8(D.out); D.ld16t = up_k(D.in);
             ORX_HIP(hipMalloc(&D.w16, (size_t)D.in * D.ld16 * 2)); ORX_HIP(hipMemset(D.w16, 0, (size_t)D.in * D.ld16 * 2));
             ORX_HIP(hipMalloc(&D.w16t, (size_t)D.out * D.ld16t * 2)); ORX_HIP(hipMemset(D.w16t, 0, (size_t)D.out * D.ld16t * 2));
             ShadowParam p; p.w = D.W->w; p.w16 = D.w16; p.w16t = D.w16t; p.in = D.in; p.out = D.out; p.ld16 = D.ld16; p.ld16t = D.ld16t;
@@ -286,7 +289,7 @@ static int ensure_buffers(orx_dlrm* m, int64_t B) {
             }
     }
     if (m->flags & ORX_DLRM_FP16_MLP) {
-        m->ldR16 = up8(m->m_spa + m->P);
+        m->ldR16 = (up_k(m->m_spa + m->P) + 127) / 128 * 128 <= up_k(m->m_spa + m->P) + 64 ? (up_k(m->m_spa + m->P) + 127) / 128 * 128 : up_k(m->m_spa + m->P);   // (whole 128-column tiles of the weight gradient where that costs <= 64 columns)
         ORX_HIP(hipMalloc(&m->R16, (size_t)B * m->ldR16 * 2)); ORX_HIP(hipMemsetAsync(m->R16, 0, (size_t)B * m->ldR16 * 2, m->ctx->stream));
         ORX_HIP(hipMalloc(&m->g16, (size_t)B * up8(m->maxw) * 2));
         ORX_HIP(hipMalloc(&m->g16b, (size_t)B * up8(m->maxw) * 2));

@@ -348,6 +348,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_dma_kernel(Nt16A
         // my reads of tile s are complete (their data is in a1 / b1); tile s + 1 has landed for me
         __builtin_amdgcn_sched_barrier(0);                                     // (... and the products above stay above: they cover the reads)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(DBG & 4)) arrived(a1, b1);                                       // (the compiler's own count: nothing pending behind the barrier)
         if (MORE) { if (NS == 3 && INFLIGHT) wait_vm<NL>(); else wait_vm<0>(); }
         __builtin_amdgcn_s_barrier();
         if (!(DBG & 4) && MORE) fetch(lds16 + cur * STAGE, 0, a0, b0);
@@ -601,6 +602,156 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_tn_kernel(Tn16Args 
     }
 }
 
+// ---- the weight gradient with LDS-DMA staging (see gemm16_nt_dma_kernel): a stage holds 64 k-rows x 128 columns of each operand,
+// 256-byte rows without padding.  The transposing reads take 32 contiguous bytes of 8 different rows per LDS cycle: row r keeps
+// the 16-byte chunk c of its 256 bytes at slot c ^ (2 * (r & 7)) -- chunk PAIRS stay adjacent and the eight rows of a cycle sit on
+// eight different quarters of the banks (what the 288-byte pitch does for the register-staged kernel).
+// TAIL: a tile reaches beyond a leading dimension or the slice ends inside a stage (zero chunk through per-lane addresses).
+template <int MINB, int NS, bool TAIL>
+__global__ __launch_bounds__(256, MINB) void gemm16_tn_dma_kernel(Tn16Args g) {
+    constexpr int BK = 64, BM = 128, BN = 128, NT = 256, TM = 4, TN = 4, WN = 2;
+    constexpr int NA = BK * (BM / 8) / NT, NB = BK * (BN / 8) / NT, NL = NA + NB;      // 4 + 4 requests per wavefront and stage
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds16[];
+    constexpr int STAGE = BK * (BM + BN);                                      // halves
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM, nt = ntn * ntm;
+    const int t = xcd_slot(blockIdx.x, gridDim.x);
+    const int bz = t / nt, tile = t - bz * nt;
+    const int bm = (tile / ntn) * BM, bn = (tile % ntn) * BN;
+    const int wm = (wave / WN) * TM * 16, wn = (wave % WN) * TN * 16;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int kbeg = bz * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { acc[i][j].x = acc[i][j].y = acc[i][j].z = acc[i][j].w = 0.0f; }
+    // request i of a wavefront covers LDS chunks c = 64 * wave + lane + 256 * i: row c / 16, slot c % 16
+    unsigned off[NL]; int kr[NL], col[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int c = wave * 64 + lane + NT * (i < NA ? i : i - NA), r = c >> 4, ch = (c & 15) ^ (2 * (r & 7));
+        kr[i] = r; col[i] = (i < NA ? bm : bn) + ch * 8;
+        off[i] = (unsigned)(((int64_t)r * (i < NA ? g.lda : g.ldb) + col[i]) * 2);
+    }
+    const int lda = (int)g.lda, ldb = (int)g.ldb;
+    auto issue_one = [&](int k0, _Float16* S, int i) {                       // the k-rows k0 .. k0 + 63 of the slice
+        const int j = i < NA ? i : i - NA;
+        _Float16* dst = S + (i < NA ? 0 : BK * BM) + (NT * j + wave * 64) * 8;
+        const char* sb = reinterpret_cast<const char*>(i < NA ? g.A : g.B) + (size_t)k0 * (i < NA ? lda : ldb) * 2;
+        if (TAIL) {
+            const char* p = (k0 + kr[i] < kend && col[i] < (i < NA ? lda : ldb)) ? sb + off[i] : reinterpret_cast<const char*>(g_zero_chunk);
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)dst, 16, 0, 0);
+        } else {
+            const unsigned m0v = (unsigned)(uintptr_t)(lptr_t)dst;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off[i]), "s"(sb), "s"(m0v) : "memory");
+        }
+    };
+    auto issue = [&](int k0, _Float16* S) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) issue_one(k0, S, i);
+    };
+    // transposing reads: lane i of a 16-lane group supplies &blk[i / 4][4 * (i % 4)] of a [4 rows][16 columns] block; lane group q
+    // takes rows 4q .. 4q + 3 and 16 + 4q .. (the k order inside a 32-deep product, the same for both operands)
+    const int rr = q * 4 + i16 / 4, x = rr & 7;
+    int fa[TM], fb[TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) fa[mi] = rr * BM + ((((wm >> 4) + mi) ^ x) * 16) + (i16 % 4) * 4;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) fb[ni] = BK * BM + rr * BN + ((((wn >> 4) + ni) ^ x) * 16) + (i16 % 4) * 4;
+    h8 a0[TM], b0[TN], a1[TM], b1[TN];
+    auto fetch = [&](const _Float16* S, int kk, h8 (&a)[TM], h8 (&b)[TN]) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const h4 lo = lds_tr_read(S + fa[mi] + (kk * 32) * BM), hi = lds_tr_read(S + fa[mi] + (kk * 32 + 16) * BM);
+            a[mi] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const h4 lo = lds_tr_read(S + fb[ni] + (kk * 32) * BN), hi = lds_tr_read(S + fb[ni] + (kk * 32 + 16) * BN);
+            b[ni] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    auto arrived = [&](h8 (&a)[TM], h8 (&b)[TN]) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) asm volatile("" : "+v"(a[mi]));
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) asm volatile("" : "+v"(b[ni]));
+    };
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    int cur = 0;
+    auto step = [&](auto dma_c, auto more_c, auto inflight_c, int s) {          // (the schedule of gemm16_nt_dma_kernel)
+        constexpr bool DMA = decltype(dma_c)::value, MORE = decltype(more_c)::value, INFLIGHT = decltype(inflight_c)::value;
+        _Float16* S = lds16 + cur * STAGE;
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        fetch(S, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        arrived(a1, b1);
+        if (MORE) { if (NS == 3 && INFLIGHT) wait_vm<NL>(); else wait_vm<0>(); }
+        __builtin_amdgcn_s_barrier();
+        if (MORE) fetch(lds16 + cur * STAGE, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k0 = kbeg + (s + NS) * BK;
+        constexpr int EVERY = TM * TN / NL;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+                const int done = mi * TN + ni + 1;
+                if (DMA && done % EVERY == 0 && done / EVERY <= NL) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_one(k0, S, done / EVERY - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        if (MORE) arrived(a0, b0);
+    };
+    if (nk > 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (s < nk) issue(kbeg + s * BK, lds16 + s * STAGE);
+        if (nk > 2 && NS == 3) wait_vm<2 * NL>(); else if (nk > 1) wait_vm<NL>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        fetch(lds16, 0, a0, b0); arrived(a0, b0);
+        using T = std::true_type; using F = std::false_type;
+        int s = 0;
+        for (; s + NS < nk; ++s) step(T(), T(), T(), s);
+        if (NS == 3 && s + 2 < nk) { step(F(), T(), T(), s); ++s; }
+        if (s + 1 < nk) { step(F(), T(), F(), s); ++s; }
+        if (s < nk) step(F(), F(), F(), s);
+    }
+    const int S = gridDim.x / nt;
+    if (S > 1) {
+        float* mine = g.slab + ((size_t)tile * S + bz) * SLAB_STRIDE;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                *reinterpret_cast<f32x4*>(mine + (wm + mi * 16 + i16) * BN + wn + ni * 16 + q * 4) = acc[mi][ni];
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int row = bm + wm + mi * 16 + i16;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int c0 = bn + wn + ni * 16 + q * 4;
+            if (row >= g.M) continue;
+            const float v[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c0 + e < g.N) g.C[(int64_t)row * g.ldc + c0 + e] += v[e] * g.out_scale;
+        }
+    }
+}
+
 // C += sum over the S slices of every tile; one launch serves all layers of an MLP backward.  grid = (max tiles, 8 parts, layers)
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduce* jobs, float out_scale) {
@@ -655,6 +806,24 @@ int orx_launch_gemm16_tn(orx_ctx* ctx, const void* A16, int64_t lda, const void*
     orx_gemm16_tn_plan(ctx, M, N, K, &S, &tiles, &kchunk);
     ORX_ARG(S == 1 || slab != nullptr, "gemm16_tn: split-K needs a slab workspace");
     Tn16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, slab, M, N, K, kchunk, out_scale};
+    // ORX_GEMM16_TN_DMA: 0 = the register-staged kernel, 2 = LDS-DMA staging with two stages and two workgroups per CU (default),
+    // 3 = three stages, one workgroup per CU
+    static const int dma = getenv("ORX_GEMM16_TN_DMA") ? atoi(getenv("ORX_GEMM16_TN_DMA")) : 2;
+    if (dma == 2 || dma == 3) {
+        const bool tail = (K & 63) != 0 || kchunk % 64 != 0 || (int64_t)((M + 127) / 128) * 128 > lda || (int64_t)((N + 127) / 128) * 128 > ldb;
+        const size_t shm = (size_t)dma * 64 * 256 * 2;
+        auto kern = dma == 2 ? (tail ? gemm16_tn_dma_kernel<2, 2, true> : gemm16_tn_dma_kernel<2, 2, false>)
+                             : (tail ? gemm16_tn_dma_kernel<1, 3, true> : gemm16_tn_dma_kernel<1, 3, false>);
+        ORX_ONCE_PER_DEVICE(ctx, {
+            ORX_HIP(hipFuncSetAttribute((const void*)gemm16_tn_dma_kernel<2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 256 * 2));
+            ORX_HIP(hipFuncSetAttribute((const void*)gemm16_tn_dma_kernel<2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 256 * 2));
+            ORX_HIP(hipFuncSetAttribute((const void*)gemm16_tn_dma_kernel<1, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 256 * 2));
+            ORX_HIP(hipFuncSetAttribute((const void*)gemm16_tn_dma_kernel<1, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 256 * 2));
+        });
+        ORX_LAUNCH(ctx, kern, dim3((unsigned)(tiles * S)), dim3(256), shm, g);
+        ORX_HIP(hipGetLastError());
+        return ORX_OK;
+    }
     constexpr size_t shm = (size_t)2 * 64 * (128 + 16 + 128 + 16) * 2;
     auto kern = gemm16_tn_kernel<2, 2, 4, 4, 2>;
     ORX_ONCE_PER_DEVICE(ctx, ORX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)));

@@ -19,6 +19,25 @@ template <typename F> static float time_us(F f, int reps = 30) {
     return ms * 1000.0f / reps;
 }
 
+__global__ void flush_kernel(float4* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = float4{1.f, 2.f, 3.f, 4.f};
+}
+static float4* g_flush = nullptr;
+// one launch at a time, each behind a 512 MB write (caches cold) and, optionally, behind the launch that PRODUCES its operand
+template <typename F, typename P> static float time_cold_us(F f, P producer, int reps = 8) {
+    if (!g_flush) CK(hipMalloc(&g_flush, (size_t)512 << 20));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float tot = 0;
+    for (int i = 0; i < reps + 2; ++i) {
+        hipLaunchKernelGGL(flush_kernel, dim3(2048), dim3(256), 0, 0, g_flush, ((size_t)512 << 20) / 16);
+        producer();
+        CK(hipEventRecord(e0, 0)); f(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (i >= 2) tot += ms;
+    }
+    return tot * 1000.0f / reps;
+}
+
 template <int WM, int WN, int TM, int TN, int MINB, int NS, int DBG>
 static void launch_dbg(const Nt16Args& g) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -64,8 +83,53 @@ int main() {
                    n, c, w / 100.0, c / (w * 10.0), c / (n * 16.0 * 2.0));
         }
     }
+    {   // ---- weight gradient: C[M][N] (slabs) = A16[K][M]^T * B16[K][N], K = 8192 samples
+        const int K = 8192;
+        orx_ctx ctx; ctx.num_cu = 256;
+        const int shapes[][2] = {{1024, 1024}, {512, 1024}, {1024, 512}, {256, 512}};
+        for (auto& sh : shapes) {
+            const int M = sh[0], N = sh[1];
+            std::vector<_Float16> hA((size_t)K * M), hB((size_t)K * N);
+            unsigned s = 4242;
+            auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 9) & 0xffff) / 65536.0f - 0.5f; };
+            for (auto& v : hA) v = (_Float16)rnd();
+            for (auto& v : hB) v = (_Float16)(rnd() * 0.1f);
+            _Float16 *A, *B; float* slab; float* C;
+            int S, tiles, kchunk;
+            orx_gemm16_tn_plan(&ctx, M, N, K, &S, &tiles, &kchunk);
+            CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&B, hB.size() * 2)); CK(hipMalloc(&slab, (size_t)tiles * S * SLAB_STRIDE * 4)); CK(hipMalloc(&C, (size_t)M * N * 4));
+            CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+            Tn16Args g{A, M, B, N, C, N, slab, M, N, K, kchunk, 1.0f};
+            const double gf = 2.0 * M * N * K * 1e-9;
+            printf("== weight gradient M %d N %d K %d (%.1f GFLOP), %d tiles x %d slices\n", M, N, K, gf, tiles, S);
+            auto rep = [&](const char* name, float us) { printf("  %-44s %7.2f us  %6.0f TFLOP/s\n", name, us, gf / us * 1e3); };
+            auto run_reg = [&] { hipFuncSetAttribute((const void*)gemm16_tn_kernel<2, 2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 288 * 2);
+                                 hipLaunchKernelGGL((gemm16_tn_kernel<2, 2, 4, 4, 2>), dim3(tiles * S), dim3(256), 2 * 64 * 288 * 2, 0, g); };
+            auto run_d2 = [&] { hipFuncSetAttribute((const void*)gemm16_tn_dma_kernel<2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 256 * 2);
+                                hipLaunchKernelGGL((gemm16_tn_dma_kernel<2, 2, false>), dim3(tiles * S), dim3(256), 2 * 64 * 256 * 2, 0, g); };
+            auto run_d3 = [&] { hipFuncSetAttribute((const void*)gemm16_tn_dma_kernel<1, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 256 * 2);
+                                hipLaunchKernelGGL((gemm16_tn_dma_kernel<1, 3, false>), dim3(tiles * S), dim3(256), 3 * 64 * 256 * 2, 0, g); };
+            auto run_d2t = [&] { hipFuncSetAttribute((const void*)gemm16_tn_dma_kernel<2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 256 * 2);
+                                 hipLaunchKernelGGL((gemm16_tn_dma_kernel<2, 2, true>), dim3(tiles * S), dim3(256), 2 * 64 * 256 * 2, 0, g); };
+            const size_t nsl = (size_t)tiles * S * SLAB_STRIDE;
+            std::vector<float> ref(nsl), got(nsl);
+            CK(hipMemset(slab, 0, nsl * 4)); run_reg(); CK(hipDeviceSynchronize()); CK(hipMemcpy(ref.data(), slab, nsl * 4, hipMemcpyDeviceToHost));
+            auto check = [&](const char* name) {
+                CK(hipDeviceSynchronize()); CK(hipMemcpy(got.data(), slab, nsl * 4, hipMemcpyDeviceToHost));
+                double worst = 0; for (size_t i = 0; i < nsl; ++i) worst = std::max(worst, (double)fabsf(got[i] - ref[i]));
+                printf("  %-44s max |diff| vs register-staged %.3g\n", name, worst);
+            };
+            CK(hipMemset(slab, 0, nsl * 4)); run_d2(); check("dma 2 stages");
+            CK(hipMemset(slab, 0, nsl * 4)); run_d3(); check("dma 3 stages");
+            CK(hipMemset(slab, 0, nsl * 4)); run_d2t(); check("dma 2 stages, tail form");
+            rep("reg", time_us(run_reg)); rep("dma 2 stages, 2 / CU", time_us(run_d2)); rep("dma 3 stages, 1 / CU", time_us(run_d3)); rep("dma 2 stages, tail form", time_us(run_d2t));
+            auto none = [] {};
+            rep("cold: reg", time_cold_us(run_reg, none)); rep("cold: dma 2 stages", time_cold_us(run_d2, none)); rep("cold: dma 3 stages", time_cold_us(run_d3, none));
+            CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(slab)); CK(hipFree(C));
+        }
+    }
     const int M = 8192;
-    const int shapes[][2] = {{1024, 1024}, {1024, 512}, {512, 1024}, {256, 512}, {1024, 480}};
+    const int shapes[][2] = {{1024, 1024}, {512, 1024}};
     orx_ctx ctx; ctx.num_cu = 256;
     for (auto& sh : shapes) {
         const int N = sh[0], K = sh[1];
@@ -81,7 +145,7 @@ int main() {
         Nt16Args g{A, K, B, K, nullptr, N, C16, N, bias, M, N, K, 1, nullptr, nullptr, 0, 0, nullptr};
         const double gf = 2.0 * M * N * K * 1e-9;
         printf("== M %d N %d K %d  (%.1f GFLOP), fp16-only epilogue (bias + relu)\n", M, N, K, gf);
-        auto rep = [&](const char* name, float us) { printf("  %-44s %7.2f us  %6.0f TFLOP/s\n", name, us, gf / us * 1e-3 * 1e3); };
+        auto rep = [&](const char* name, float us) { printf("  %-44s %7.2f us  %6.0f TFLOP/s\n", name, us, gf / us * 1e3); };
         // correctness of the DMA kernels against the register-staged kernel (same operands, same k order per MFMA chain)
         launch_nt<4, 2, 4, 4, 1, 16>(&ctx, g); CK(hipDeviceSynchronize());
         std::vector<_Float16> ref((size_t)M * N), got((size_t)M * N);
@@ -100,6 +164,24 @@ int main() {
         rep("dma 256x128 2 stages", time_us([&] { launch_nt_dma<4, 2, 4, 4, 1, 2>(&ctx, g); }));
         rep("dma 128x128 2 stages, 2 / CU", time_us([&] { launch_nt_dma<2, 2, 4, 4, 2, 2>(&ctx, g); }));
         rep("dma 128x64 3 stages", time_us([&] { launch_nt_dma<2, 2, 4, 2, 2, 3>(&ctx, g); }));
+        if (K == N) {
+            // the operand of the timed launch is the output of the launch before it (as in the MLP), caches flushed before the pair
+            _Float16* Y; CK(hipMalloc(&Y, (size_t)M * N * 2));
+            Nt16Args g1 = g; g1.C16 = Y;
+            Nt16Args g2 = g; g2.A = Y; g2.lda = N;
+            auto none = [] {};
+            rep("cold: reg 256x128", time_cold_us([&] { launch_nt<4, 2, 4, 4, 1, 16>(&ctx, g); }, none));
+            rep("cold: dma 256x128 3 stages", time_cold_us([&] { launch_nt_dma<4, 2, 4, 4, 1, 3>(&ctx, g); }, none));
+            rep("cold: dma 256x128 2 stages", time_cold_us([&] { launch_nt_dma<4, 2, 4, 4, 1, 2>(&ctx, g); }, none));
+            rep("cold: dma 128x128 2 stages", time_cold_us([&] { launch_nt_dma<2, 2, 4, 4, 2, 2>(&ctx, g); }, none));
+            rep("behind its producer: reg 256x128", time_cold_us([&] { launch_nt<4, 2, 4, 4, 1, 16>(&ctx, g2); }, [&] { launch_nt<4, 2, 4, 4, 1, 16>(&ctx, g1); }));
+            rep("behind its producer: dma 256x128 3 stages", time_cold_us([&] { launch_nt_dma<4, 2, 4, 4, 1, 3>(&ctx, g2); }, [&] { launch_nt_dma<4, 2, 4, 4, 1, 3>(&ctx, g1); }));
+            rep("behind its producer: dma 128x128 2 stages", time_cold_us([&] { launch_nt_dma<2, 2, 4, 4, 2, 2>(&ctx, g2); }, [&] { launch_nt_dma<2, 2, 4, 4, 2, 2>(&ctx, g1); }));
+            rep("behind its producer: dma 3st, no epilogue", time_cold_us([&] { launch_dbg<4, 2, 4, 4, 1, 3, 1>(g2); }, [&] { launch_nt_dma<4, 2, 4, 4, 1, 3>(&ctx, g1); }));
+            rep("behind its producer: dma 3st, no epi, no MFMA", time_cold_us([&] { launch_dbg<4, 2, 4, 4, 1, 3, 5>(g2); }, [&] { launch_nt_dma<4, 2, 4, 4, 1, 3>(&ctx, g1); }));
+            rep("behind its producer: dma 3st, no epi, no DMA", time_cold_us([&] { launch_dbg<4, 2, 4, 4, 1, 3, 3>(g2); }, [&] { launch_nt_dma<4, 2, 4, 4, 1, 3>(&ctx, g1); }));
+            CK(hipFree(Y));
+        }
         rep("dma 256x128 3st, nontemporal stores", time_us([&] { launch_dbg<4, 2, 4, 4, 1, 3, 16>(g); }));
         rep("dma 128x64 3st, nontemporal stores", time_us([&] { launch_dbg<2, 2, 4, 2, 2, 3, 16>(g); }));
         rep("dma 256x128 3st, no epilogue", time_us([&] { launch_dbg<4, 2, 4, 4, 1, 3, 1>(g); }));

@@ -1,14 +1,16 @@
 #!/bin/bash
 rm -rf gpurun_out/r4r; mkdir -p gpurun_out/r4r
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_dlrm.py tests/test_gpu_reference_examples.py -q -x > gpurun_out/r4r/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r4r/pytest.log
+timeout 900 python -m pytest tests/test_gpu_dlrm.py tests/test_gpu_reference_examples.py tests/test_gpu_sharded_dlrm.py -q -x > gpurun_out/r4r/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r4r/pytest.log
 tail -4 gpurun_out/r4r/pytest.log
 one() { timeout 200 python bench.py --no-cpu-baseline --model dlrm "$@" --steps 40 --warmup 10 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms/step', round(d['ms_per_step'],4), 'gemm ms', round(d['roofline'].get('gemm_ms_per_step',0),4), 'frac', round(d['roofline']['frac'],4))"; }
 for i in 1 2; do
-  echo "side apply on:"; one --fp16-mlp
-  echo "side apply off:"; ORX_DLRM_NO_SIDE_APPLY=1 one --fp16-mlp
+  echo "tn dma 2:"; one --fp16-mlp
+  echo "tn reg:"; ORX_GEMM16_TN_DMA=0 one --fp16-mlp
+  echo "tn dma 3:"; ORX_GEMM16_TN_DMA=3 one --fp16-mlp
 done
-echo "fp32 side on:"; one
-echo "fp32 side off:"; ORX_DLRM_NO_SIDE_APPLY=1 one
-echo "adagrad fp16 side on:"; one --fp16-mlp --opt adagrad
-echo "adagrad fp16 side off:"; ORX_DLRM_NO_SIDE_APPLY=1 one --fp16-mlp --opt adagrad
+echo "all reg:"; ORX_GEMM16_TN_DMA=0 ORX_GEMM16_DMA=0 one --fp16-mlp
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r4r/prof -o p -- python bench.py --no-cpu-baseline --model dlrm --fp16-mlp --steps 20 --warmup 5 > gpurun_out/r4r/prof.log 2>&1
+f=$(find gpurun_out/r4r/prof -name '*kernel_trace.csv' | head -1)
+python scripts/trace_last_step.py "$f" dlrm_loss_kernel > gpurun_out/r4r/step.txt; grep "gemm16\|head" gpurun_out/r4r/step.txt
+rm -rf gpurun_out/r4r/prof
