@@ -805,6 +805,9 @@ __global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(RowSrc src, int 
 // SPLIT wavefronts may share a sample, each taking d / SPLIT of the columns.  Measured at d = 128, B = 8192: two wavefronts of 64
 // columns (16 384 wavefronts of ~90 VGPRs) are SLOWER than one of 128 (8192 of ~170): step 0.6285 against 0.6125 ms -- every
 // wavefront re-reads the sample's dR and the 256-byte half rows lose the 512-byte bursts.  No launch uses SPLIT > 1.
+// (round 4: NSAMP samples per wavefront in turn, the next sample's rows requested before the current sample's products -- 2 samples:
+// no change, 0.5547 against 0.5546 ms per step; 4 / 8 samples: +2 % / +9 %, too few wavefronts.  The launch is not the sum of one
+// wavefront's phases; the random 512-byte rows set its pace.)
 template <int CPL, int SPLIT>
 __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, const float* dR, int F, int itself, float* dZ,
                                                                 int64_t B, int ldR, float scale) {

@@ -41,7 +41,12 @@ __device__ __forceinline__ int xcd_slot(int b, int n) { return (n & 7) ? b : (b 
 
 // the products' common epilogue: + bias, activation, stores, or the fused activation backward with its column sums (see the head
 // of the file); `red` = LDS that is free once the main loop is over, [WM][BN] floats
-template <int WM, int WN, int TM, int TN, bool NTS = false>
+// NTS: how the outputs are stored: 0 = ordinary stores, 1 = nontemporal, 2 = write-through (sc1: past the XCD's L2 as they are issued,
+// nothing left dirty for the end of the kernel)
+template <typename V> __device__ __forceinline__ void store_sc1(V* p, V v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+template <int WM, int WN, int TM, int TN, int NTS = 0>
 __device__ __forceinline__ void nt_epilogue(const Nt16Args& g, f32x4 (&acc)[TM][TN], int bm, int bn, int wm, int wn, float* red) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = 64 * WM * WN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -110,7 +115,8 @@ __device__ __forceinline__ void nt_epilogue(const Nt16Args& g, f32x4 (&acc)[TM][
                 float* p = g.C + (int64_t)row * g.ldc + col;
                 if (full && (g.ldc & 3) == 0) {
                     f32x4 o0, o1; o0.x = v[0]; o0.y = v[1]; o0.z = v[2]; o0.w = v[3]; o1.x = v[4]; o1.y = v[5]; o1.z = v[6]; o1.w = v[7];
-                    if (NTS) { __builtin_nontemporal_store(o0, reinterpret_cast<f32x4*>(p)); __builtin_nontemporal_store(o1, reinterpret_cast<f32x4*>(p + 4)); }
+                    if (NTS == 2) { store_sc1(reinterpret_cast<f32x4*>(p), o0); store_sc1(reinterpret_cast<f32x4*>(p + 4), o1); }
+                    else if (NTS == 1) { __builtin_nontemporal_store(o0, reinterpret_cast<f32x4*>(p)); __builtin_nontemporal_store(o1, reinterpret_cast<f32x4*>(p + 4)); }
                     else { *reinterpret_cast<f32x4*>(p) = o0; *reinterpret_cast<f32x4*>(p + 4) = o1; }
                 } else {
                     for (int e = 0; e < 8; ++e) if (col + e < g.N) p[e] = v[e];
@@ -122,7 +128,7 @@ __device__ __forceinline__ void nt_epilogue(const Nt16Args& g, f32x4 (&acc)[TM][
                     h8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
-                    if (NTS) __builtin_nontemporal_store(o, reinterpret_cast<h8*>(p)); else *reinterpret_cast<h8*>(p) = o;
+                    if (NTS == 2) store_sc1(reinterpret_cast<h8*>(p), o); else if (NTS == 1) __builtin_nontemporal_store(o, reinterpret_cast<h8*>(p)); else *reinterpret_cast<h8*>(p) = o;
                 } else {
                     for (int e = 0; e < 8; ++e) if (col + e < g.N) p[e] = (_Float16)v[e];
                 }
@@ -249,7 +255,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // TAIL: a leading dimension is not a multiple of 64 halves (the last tile's chunks beyond it come from the zeros, through per-lane
 // 64-bit addresses).  All other requests are `global_load_lds_dwordx4 v_offset, s[base]`: a scalar base that advances with the tile
 // and 32-bit per-lane offsets made once -- no vector arithmetic per request.
-// DBG (scratch/exp_dma.hip only): 1 = no epilogue, 2 = no DMA inside the loop, 4 = no fragment reads / MFMA, 16 = nontemporal stores,
+// DBG (scratch/exp_dma.hip only): 1 = no epilogue, 2 = no DMA inside the loop, 4 = no fragment reads / MFMA, 16 = nontemporal stores, 32 = write-through stores,
 // 8 = with 1: the main loop's duration in shader cycles and in 100 MHz ticks goes to g.C as [workgroup][2] 64-bit counts
 template <int WM, int WN, int TM, int TN, int MINB, int NS, bool TAIL, int DBG = 0>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_dma_kernel(Nt16Args g) {
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_dma_kernel(Nt16A
         return;
     }
     if (g.gb) __syncthreads();                                                 // (the column sums go through the stages' LDS)
-    nt_epilogue<WM, WN, TM, TN, (DBG & 16) != 0>(g, acc, bm, bn, wm, wn, reinterpret_cast<float*>(lds16));
+    nt_epilogue<WM, WN, TM, TN, (DBG & 32) ? 2 : (DBG & 16) ? 1 : 0>(g, acc, bm, bn, wm, wn, reinterpret_cast<float*>(lds16));
 }
 
 template <int WM, int WN, int TM, int TN, int MINB, int NS>
@@ -411,18 +417,20 @@ static int launch_nt_dma(orx_ctx* ctx, const Nt16Args& g) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr size_t shm = (size_t)NS * (BM + BN) * 64 * 2;
     const bool tail = (g.lda & 63) != 0 || (g.ldb & 63) != 0;
-    // ORX_GEMM16_NTS=1: the outputs leave through nontemporal stores.  Alone, 8192 x 1024 x 1024 goes from 24.4 to 21.0 us
-    // (scratch/exp_dma.hip); in the DLRM step the NEXT product then reads its operand from HBM instead of the caches and the
-    // step is slower (0.585 against 0.573 ms): off.
-    static const bool nts = getenv("ORX_GEMM16_NTS") != nullptr && atoi(getenv("ORX_GEMM16_NTS")) != 0;
-    auto kern = nts ? (tail ? gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, true, 16> : gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, false, 16>)
-                    : (tail ? gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, true, 0> : gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, false, 0>);
+    // How the outputs leave (ORX_GEMM16_NTS): 2 (default) = write-through stores, nothing left dirty in the XCD's L2 for the end of the
+    // kernel: alone, 8192 x 1024 x 1024 goes from 24.3 to 21.0 us (scratch/exp_dma.hip), in the DLRM step the products gain 1 %;
+    // 1 = nontemporal stores: 19.9 us alone, but the NEXT product then reads its operand from HBM and the step is 2 % slower;
+    // 0 = ordinary stores.
+    static const int nts = getenv("ORX_GEMM16_NTS") != nullptr ? atoi(getenv("ORX_GEMM16_NTS")) : 2;
+    using K = void (*)(Nt16Args);
+    const K kerns[3][2] = {{gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, false, 0>, gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, true, 0>},
+                           {gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, false, 16>, gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, true, 16>},
+                           {gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, false, 32>, gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, true, 32>}};
     ORX_ONCE_PER_DEVICE(ctx, {
-        ORX_HIP(hipFuncSetAttribute((const void*)gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        ORX_HIP(hipFuncSetAttribute((const void*)gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        ORX_HIP(hipFuncSetAttribute((const void*)gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        ORX_HIP(hipFuncSetAttribute((const void*)gemm16_nt_dma_kernel<WM, WN, TM, TN, MINB, NS, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 2; ++b)
+            ORX_HIP(hipFuncSetAttribute((const void*)kerns[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     });
+    const K kern = kerns[nts >= 0 && nts <= 2 ? nts : 0][tail ? 1 : 0];
     const unsigned nb = (unsigned)(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN));
     ORX_LAUNCH(ctx, kern, dim3(nb), dim3(64 * WM * WN), shm, g);
     ORX_HIP(hipGetLastError());
