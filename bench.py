@@ -138,7 +138,7 @@ def bench_dlrm(args, torch, rt, world, rank, local_rank, device, dist):
         if gp.get("launches"):
             tf = flops * K / (gp["total_ms"] * 1e-3) / 1e12
             peak = 2500.0 if args.fp16_mlp else 157.3         # MI355X_MICROARCH.md: dense fp16 MFMA / fp32 (xf32-less) matrix peak, TFLOP/s
-            extra = {"roofline": {"bound": "mfma", "kernel": ("gemm16_nt_kernel + gemm16_tn_kernel + slab_reduce_kernel + head kernels (all MLP products of the step)"
+            extra = {"roofline": {"bound": "mfma", "kernel": ("gemm16_nt_dma_kernel + gemm16_tn_dma_kernel + slab_reduce_kernel + head kernels (all MLP products of the step)"
                                                               if args.fp16_mlp else "gemm_f32v_kernel"), "achieved": tf,
                                   "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
                                   "gemm_ms_per_step": gp["total_ms"] / K, "flops_per_step": flops}}
@@ -251,7 +251,7 @@ def secondary_dlrm(torch, rt, ctx, device, fp16, K, W, B=8192):
     if gp.get("launches"):
         tf = flops * K / (gp["total_ms"] * 1e-3) / 1e12
         peak = 2500.0 if fp16 else 157.3
-        out["roofline"] = {"bound": "mfma", "kernel": "all MLP products of the step (gemm16_nt / gemm16_tn / slab_reduce / head kernels)" if fp16 else "gemm_f32v_kernel",
+        out["roofline"] = {"bound": "mfma", "kernel": "all MLP products of the step (gemm16_nt_dma / gemm16_tn_dma / slab_reduce / head kernels)" if fp16 else "gemm_f32v_kernel",
                            "kernel_us": gp["total_ms"] / K * 1e3, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "flops_per_step": flops}
     return out
 

@@ -995,7 +995,7 @@ int orx_launch_head_bwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* 
     if (B == 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_GEMM);
     const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
-    int rows = std::max(64, (int)((B + cus - 1) / cus));           // <= one workgroup per CU, >= 64 rows each (partial rows = blocks)
+    int rows = std::max(32, (int)((B + cus - 1) / cus));           // <= one workgroup per CU, >= 32 rows each (partial rows = blocks)
     rows = (rows + 7) / 8 * 8;
     gW->P = gb->P = gb_below->P = (B + rows - 1) / rows;
     HeadBwdArgs a{(const _Float16*)X16, ldx, (const _Float16*)w16, dy, pred, act, act_below, gW->parts, gb->parts, (_Float16*)dZ16, ld16, dZ32, ld32, gb_below->parts, B, K, rows};
