@@ -798,7 +798,11 @@ void orx_gemm16_tn_plan(orx_ctx* ctx, int M, int N, int K, int* S_out, int* tile
     // S depends on the SHAPE of the gradient only, never on the number of samples: the workspace and the reduce descriptors
     // are made once per model, and a later call with fewer samples (the last batch of an epoch) must write -- and the
     // reduce must add -- the same S slices; slices beyond the samples write zeros
-    const int S = std::max(1, std::min(32, (2 * cus) / tiles));     // two 4-wavefront workgroups per CU
+    // ONE workgroup per CU (three LDS stages): half the slices of two per CU -- the slabs are written here and read again by the
+    // optimizer launch, 146 -> 73 MB each way at the C5 shapes; the products take the same time (0.290 ms), the step 0.558 -> 0.543 ms.
+    // ORX_GEMM16_TN_PER_CU=2 with ORX_GEMM16_TN_DMA=2: the two-per-CU form
+    static const int per_cu = getenv("ORX_GEMM16_TN_PER_CU") ? atoi(getenv("ORX_GEMM16_TN_PER_CU")) : 1;
+    const int S = std::max(1, std::min(32, (per_cu * cus) / tiles));
     const int kchunk = std::max(64, (((K + S - 1) / S + 63) / 64) * 64);
     *S_out = S; *tiles_out = tiles; *kchunk_out = kchunk;
 }
@@ -814,9 +818,9 @@ int orx_launch_gemm16_tn(orx_ctx* ctx, const void* A16, int64_t lda, const void*
     orx_gemm16_tn_plan(ctx, M, N, K, &S, &tiles, &kchunk);
     ORX_ARG(S == 1 || slab != nullptr, "gemm16_tn: split-K needs a slab workspace");
     Tn16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, slab, M, N, K, kchunk, out_scale};
-    // ORX_GEMM16_TN_DMA: 0 = the register-staged kernel, 2 = LDS-DMA staging with two stages and two workgroups per CU (default),
-    // 3 = three stages, one workgroup per CU
-    static const int dma = getenv("ORX_GEMM16_TN_DMA") ? atoi(getenv("ORX_GEMM16_TN_DMA")) : 2;
+    // ORX_GEMM16_TN_DMA: 0 = the register-staged kernel, 2 = LDS-DMA staging with two stages and two workgroups per CU,
+    // 3 (default) = three stages, one workgroup per CU
+    static const int dma = getenv("ORX_GEMM16_TN_DMA") ? atoi(getenv("ORX_GEMM16_TN_DMA")) : 3;
     if (dma == 2 || dma == 3) {
         const bool tail = (K & 63) != 0 || kchunk % 64 != 0 || (int64_t)((M + 127) / 128) * 128 > lda || (int64_t)((N + 127) / 128) * 128 > ldb;
         const size_t shm = (size_t)dma * 64 * 256 * 2;
