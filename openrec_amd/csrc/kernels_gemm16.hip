@@ -43,9 +43,6 @@ __device__ __forceinline__ int xcd_slot(int b, int n) { return (n & 7) ? b : (b 
 // of the file); `red` = LDS that is free once the main loop is over, [WM][BN] floats
 // NTS: how the outputs are stored: 0 = ordinary stores, 1 = nontemporal, 2 = write-through (sc1: past the XCD's L2 as they are issued,
 // nothing left dirty for the end of the kernel)
-template <typename V> __device__ __forceinline__ void store_sc1(V* p, V v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
-}
 template <int WM, int WN, int TM, int TN, int NTS = 0>
 __device__ __forceinline__ void nt_epilogue(const Nt16Args& g, f32x4 (&acc)[TM][TN], int bm, int bn, int wm, int wn, float* red) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = 64 * WM * WN;
@@ -135,6 +132,7 @@ __device__ __forceinline__ void nt_epilogue(const Nt16Args& g, f32x4 (&acc)[TM][
             }
         }
     }
+    if (NTS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the write-through stores are acknowledged before the wavefront ends)
     if (g.gb) {
         // column sums: over the 16 rows of a lane group (DPP), over the block's WM wavefronts through LDS (the stages are
         // free now), then ONE plain store per (workgroup, column) into the row block's partial row: colparts_reduce_kernel adds
@@ -593,7 +591,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_tn_kernel(Tn16Args 
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                *reinterpret_cast<f32x4*>(mine + (wm + mi * 16 + i16) * BN + wn + ni * 16 + q * 4) = acc[mi][ni];
+                store_sc1(reinterpret_cast<f32x4*>(mine + (wm + mi * 16 + i16) * BN + wn + ni * 16 + q * 4), acc[mi][ni]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // (the write-through stores are acknowledged before the wavefront ends)
         return;
     }
 #pragma unroll
@@ -743,7 +742,8 @@ __global__ __launch_bounds__(256, MINB) void gemm16_tn_dma_kernel(Tn16Args g) {
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                *reinterpret_cast<f32x4*>(mine + (wm + mi * 16 + i16) * BN + wn + ni * 16 + q * 4) = acc[mi][ni];
+                store_sc1(reinterpret_cast<f32x4*>(mine + (wm + mi * 16 + i16) * BN + wn + ni * 16 + q * 4), acc[mi][ni]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // (the write-through stores are acknowledged before the wavefront ends)
         return;
     }
 #pragma unroll

@@ -4,6 +4,15 @@
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// 16-byte write-through store (sc1: past the XCD's L2 as it is issued).  For outputs the kernel never reads again: nothing of them is
+// left dirty for the write-back at the end of the kernel (kernels_gemm16.hip has the measurement)
+template <typename V> __device__ __forceinline__ void store_sc1(V* p, V v) {
+    static_assert(sizeof(V) == 16, "16-byte stores");
+    // (s_nop 1: the two wait states a store of more than 64 bits needs before a VALU instruction may overwrite its data registers --
+    // the compiler's hazard recognizer does not see through inline asm, and `v_accvgpr_read v0, ..` right behind the store corrupted it)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+
 // ------------------------------------------------------------ lane helpers ---
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float x) {
