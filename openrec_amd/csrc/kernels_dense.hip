@@ -777,25 +777,38 @@ __global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(RowSrc src, int 
                 a11 = __builtin_amdgcn_mfma_f32_16x16x4f32(t1[h][st], t1[h][st], a11, 0, 0, 0);
             }
     }
-    float* rb = R + b * ldR;
-    _Float16* rh = R16 ? R16 + b * ldR16 : nullptr;
-    for (int k = lane; k < d; k += 64) {
-        const float v = zlast[k];
-        rb[k] = v;
-        if (rh) rh[k] = (_Float16)v;
-    }
+    // the sample's output row is put together in LDS and leaves in whole 16-byte pieces (the pair products land at triangular
+    // offsets: written straight to memory they are 24 wavefront stores of 4 scattered bytes per lane, twice with the fp16 copy)
+    extern __shared__ __attribute__((aligned(16))) float r_lds[];
+    const int rowlen = ldR > ldR16 ? ldR : ldR16;        // (R16 == NULL: ldR16 = 0)
+    float* rs = r_lds + (threadIdx.x >> 6) * rowlen;
+    const int P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    for (int k = lane; k < d; k += 64) rs[k] = zlast[k];
+    for (int k = d + P + lane; k < rowlen; k += 64) rs[k] = 0.0f;      // padding columns
     auto emit = [&](const f32x4& acc, int r0, int c0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gi = r0 + q * 4 + r, gj = c0 + i;
-            if (gi < F && (itself ? gj <= gi : gj < gi)) {
-                const int o = d + (itself ? gi * (gi + 1) / 2 + gj : gi * (gi - 1) / 2 + gj);
-                rb[o] = acc[r];
-                if (rh) rh[o] = (_Float16)acc[r];
-            }
+            if (gi < F && (itself ? gj <= gi : gj < gi)) rs[d + (itself ? gi * (gi + 1) / 2 + gj : gi * (gi - 1) / 2 + gj)] = acc[r];
         }
     };
     emit(a00, 0, 0); emit(a10, 16, 0); emit(a11, 16, 16);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* rb = R + b * ldR;
+    for (int k = lane * 4; k < ldR; k += 256) *reinterpret_cast<f32x4*>(rb + k) = *reinterpret_cast<const f32x4*>(rs + k);
+    if (R16) {
+        _Float16* rh = R16 + b * ldR16;
+        for (int k = lane * 8; k < ldR16; k += 512) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(rs + k), v1 = *reinterpret_cast<const f32x4*>(rs + k + 4);
+            typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+            h8v o;
+            o[0] = (_Float16)v0.x; o[1] = (_Float16)v0.y; o[2] = (_Float16)v0.z; o[3] = (_Float16)v0.w;
+            o[4] = (_Float16)v1.x; o[5] = (_Float16)v1.y; o[6] = (_Float16)v1.z; o[7] = (_Float16)v1.w;
+            *reinterpret_cast<h8v*>(rh + k) = o;
+        }
+    }
 }
 
 // backward: dZ = (Gs + Gs^T) Z (+ dR[0:d] on the dense slot), Gs = the pair gradients scattered back to [F][F].
@@ -818,7 +831,17 @@ __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, cons
     const int coff = (int)(wv % SPLIT) * 16 * CPL;          // first column of this wavefront's share
     if (b >= B) return;
     const int i = lane & 15, q = lane >> 4;
-    const float* rb = dR + b * ldR;
+    // the sample's dR row goes through LDS: two coalesced 16-byte loads per lane instead of the sixteen 4-byte gathers that build
+    // the A operand (each a wavefront instruction with 64 different addresses)
+    extern __shared__ __attribute__((aligned(16))) float dr_lds[];
+    float* rb = dr_lds + (threadIdx.x >> 6) * ldR;
+    {
+        const float* rg = dR + b * ldR;                  // (ldR is a multiple of 4 floats, the rows are 16-byte aligned)
+        for (int k = lane * 4; k < ldR; k += 256) *reinterpret_cast<f32x4*>(rb + k) = *reinterpret_cast<const f32x4*>(rg + k);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     auto sval = [&](int r, int c) -> float {             // (Gs + Gs^T)[r][c]
         if (r >= F || c >= F) return 0.0f;
         if (r == c) return itself ? 2.0f * rb[d + r * (r + 1) / 2 + r] : 0.0f;
@@ -830,6 +853,8 @@ __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, cons
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int s = 0; s < 8; ++s) sa[ti][s] = sval(16 * ti + i, 4 * s + q);
+    // (tried: lane i taking columns (t / 4) * 64 + 4 i + t % 4, so that a 16-byte access of sixteen lanes covers 256 contiguous bytes instead
+    // of every other 16 bytes of 512 -- 72.1 against 68.8 us, no gain)
     float zr[8][CPL];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -901,13 +926,14 @@ int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR,
     if (mfma && (fwd || bwd_ok)) {
         const dim3 g((unsigned)((B + 3) / 4));
         if (fwd) {
-            ORX_LAUNCH(ctx, interact_fwd_mfma_kernel, g, dim3(256), 0, src, F, d, itself, out, B, ldR, (_Float16*)R16, ldR16);
+            ORX_ARG(ldR % 4 == 0 && (R16 == nullptr || ldR16 % 8 == 0), "interact: rows of R need 16-byte strides");
+            ORX_LAUNCH(ctx, interact_fwd_mfma_kernel, g, dim3(256), (size_t)4 * std::max(ldR, R16 ? ldR16 : 0) * sizeof(float), src, F, d, itself, out, B, ldR, (_Float16*)R16, R16 ? ldR16 : 0);
             if (wrote16 && R16) *wrote16 = true;
         }
-        else if (d == 32) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<2, 1>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
-        else if (d == 64) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4, 1>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
-        else if (d == 128) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8, 1>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
-        else ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<16, 1>), g, dim3(256), 0, src, dR, F, itself, out, B, ldR, scale);
+        else if (d == 32) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<2, 1>), g, dim3(256), (size_t)4 * ldR * sizeof(float), src, dR, F, itself, out, B, ldR, scale);
+        else if (d == 64) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4, 1>), g, dim3(256), (size_t)4 * ldR * sizeof(float), src, dR, F, itself, out, B, ldR, scale);
+        else if (d == 128) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8, 1>), g, dim3(256), (size_t)4 * ldR * sizeof(float), src, dR, F, itself, out, B, ldR, scale);
+        else ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<16, 1>), g, dim3(256), (size_t)4 * ldR * sizeof(float), src, dR, F, itself, out, B, ldR, scale);
         ORX_HIP(hipGetLastError());
         return ORX_OK;
     }
