@@ -6,6 +6,8 @@ fp32 atomics and no arrival-order decisions: split-K partial products, bias-grad
 gradient sums are all added in a fixed order).  Batches are drawn away from the network's relu ties (tests/dlrm_util.py), and
 what remains is held to 1e-5 on every parameter UPDATE in exact mode; the fp16-MLP mode is held to 1e-4 against the oracle
 with fp16-rounded operands (oracle/dlrm_oracle.py: operand_dtype)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -385,3 +387,24 @@ def test_dlrm_lazy_adam_long_gaps_take_the_bounded_replay():
     # of one sample to fall on the other side; (a row's gradient scale itself carries ~3e-4 of fp32 noise)
     assert np.median(rv) < 2e-4 and (rv > 2e-3).mean() <= 0.01, (float(np.median(rv)), float((rv > 2e-3).mean()))
     assert np.median(rm) < 2e-4 and (rm > 1e-2).mean() <= 0.01, (float(np.median(rm)), float((rm > 1e-2).mean()))
+
+
+def test_dlrm_fp16_staging_forms_are_bit_identical():
+    """The fp16 products exist in several forms behind environment switches: tiles staged through registers or by the
+    LDS-DMA with two or three stages (forward / input gradient: ORX_GEMM16_DMA, weight gradient: ORX_GEMM16_TN_DMA), ordinary,
+    nontemporal or write-through output stores (ORX_GEMM16_NTS).  None of them changes which products are summed in which order: two
+    steps at shapes that take every tile configuration end in the same bits under each of them."""
+    import subprocess
+    import sys as _sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dlrm_variant_worker.py")
+    variants = [{}, {"ORX_GEMM16_DMA": "0"}, {"ORX_GEMM16_DMA": "2"}, {"ORX_GEMM16_TN_DMA": "0"}, {"ORX_GEMM16_TN_DMA": "2"},
+                {"ORX_GEMM16_NTS": "0"}, {"ORX_GEMM16_NTS": "1"}]
+    digests = []
+    for v in variants:
+        env = dict(os.environ); env.update(v)
+        r = subprocess.run([_sys.executable, worker], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, f"{v}: {r.stderr[-2000:]}"
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")]
+        assert line, f"{v}: no digest in {r.stdout[-500:]}"
+        digests.append(line[-1])
+    assert all(d == digests[0] for d in digests), list(zip([str(v) for v in variants], digests))
