@@ -715,7 +715,8 @@ extern "C" int orx_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, i
 int orx_shard_grads_impl(orx_ctx* ctx, int model, orx_opt* opt, orx_table* user, const float* rows_in, const float* bias_in,
                          const int32_t* u_loc, const int32_t* slot, const uint8_t* dupref, const void* sorted, const void* seglist,
                          const int32_t* segcount, float* gdup, const uint8_t* dup_u, int64_t T, int64_t row_stride, int64_t B_global,
-                         float margin, int flags, float* gu, int32_t* u_apply, float* send_g, float* gb_out, double* loss_l2_accum) {
+                         float margin, int flags, float* gu, int32_t* u_apply, float* send_g, float* gb_out, double* loss_l2_accum,
+                         float* partial_ext, int* nwaves_out) {
     const bool fold = dup_u != nullptr;
     if (fold) CHECK(orx_table_sync(user));
     else if (user && u_loc) CHECK(orx_table_touch(user, u_loc, T));   // a lazy table: the user rows read here are brought up to date
@@ -734,12 +735,15 @@ int orx_shard_grads_impl(orx_ctx* ctx, int model, orx_opt* opt, orx_table* user,
     a.T = T; a.D = user->dim; a.DS = (int)row_stride; a.DSg = bias_in ? user->dim + 4 : (int)row_stride;
     a.invB = 1.0f / (float)B_global; a.margin = margin; a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f;
     if (fold) { a.fu = dup_u; a.Uw = user->w; a.lr = opt->lr; a.u_apply = u_apply; }
-    ENSURE(ctx->d_partial, ctx->d_partial_cap, (size_t)(T + 4) * 2 * sizeof(float));
-    a.partial = ctx->d_partial;
+    // partial_ext (the library's engine): the launch's loss partials stay in the caller's buffer, which adds a whole chunk of steps
+    // to the sums with ONE launch (a launch per step and half cost 4 us + a kernel boundary of every 84 us step)
+    if (partial_ext == nullptr) ENSURE(ctx->d_partial, ctx->d_partial_cap, (size_t)(T + 4) * 2 * sizeof(float));
+    a.partial = partial_ext ? partial_ext : ctx->d_partial;
     int nw = 0;
     CHECK(orx_launch_shard_grads(ctx, model, a, &nw));
+    if (nwaves_out) *nwaves_out = nw;
     if (dupref) CHECK(orx_launch_shard_segsum(ctx, (const int2*)seglist, segcount, (const uint2*)sorted, 2 * T, gdup, a.DSg, send_g, a.DS, a.D, gb_out));
-    if (loss_l2_accum) CHECK(orx_launch_loss_accumulate(ctx, ctx->d_partial, nw, loss_l2_accum));
+    if (loss_l2_accum && partial_ext == nullptr) CHECK(orx_launch_loss_accumulate(ctx, ctx->d_partial, nw, loss_l2_accum));
     return ORX_OK;
 }
 

@@ -386,10 +386,10 @@ int orx_launch_apply_rows(orx_ctx* ctx, int optkind, bool use_dflag, const RowsA
 }
 
 // ---------------------------------------------------------- loss accumulate ---
-__global__ __launch_bounds__(256) void loss_accumulate_kernel(const float* partial, int nwaves, double* accum) {
+__global__ __launch_bounds__(256) void loss_accumulate_kernel(const float* partial, int64_t nwaves, double* accum) {
     __shared__ double sh[2][4];
     double s0 = 0.0, s1 = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nwaves; i += gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwaves; i += (int64_t)gridDim.x * blockDim.x) {
         const float2 v = *reinterpret_cast<const float2*>(partial + 2 * i);
         s0 += (double)v.x; s1 += (double)v.y;
     }
@@ -403,9 +403,10 @@ __global__ __launch_bounds__(256) void loss_accumulate_kernel(const float* parti
     }
 }
 
-int orx_launch_loss_accumulate(orx_ctx* ctx, const float* partial, int nwaves, double* accum) {
+int orx_launch_loss_accumulate(orx_ctx* ctx, const float* partial, int64_t nwaves, double* accum) {
     ProfScope ps(ctx, ORX_K_REDUCE);
-    ORX_LAUNCH(ctx, loss_accumulate_kernel, dim3(nwaves > 2048 ? 16 : 1), dim3(256), 0, partial, nwaves, accum);
+    const unsigned blocks = nwaves > (1 << 18) ? 128 : (nwaves > 2048 ? 16 : 1);       // (a chunk of steps at once: the library's sharded engine)
+    ORX_LAUNCH(ctx, loss_accumulate_kernel, dim3(blocks), dim3(256), 0, partial, nwaves, accum);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -779,6 +780,13 @@ int orx_launch_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int w
     ORX_LAUNCH(ctx, shard_localize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ids, n, world, out);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
+}
+
+// the loss partials (one pair per wavefront) a gradient launch over T triplets of dimension D writes; 0: no fast path for D
+int orx_shard_grads_nwaves(int D, int64_t T) {
+    int lpr = 0;
+    switch (D) { case 16: lpr = 4; break; case 32: lpr = 8; break; case 64: lpr = 16; break; case 128: lpr = 32; break; case 256: lpr = 64; break; }
+    return lpr == 0 ? 0 : (int)grid_for_rows(lpr, T) * 4;
 }
 
 int orx_launch_shard_grads(orx_ctx* ctx, int model, const ShardGradArgs& a, int* nwaves) {

@@ -320,7 +320,8 @@ struct GradArgs {
 
 int orx_launch_pair_grads(orx_ctx* ctx, int model, const GradArgs& a, int* nwaves);
 int orx_launch_apply_rows(orx_ctx* ctx, int optkind, bool use_dflag, const RowsArgs& a);
-int orx_launch_loss_accumulate(orx_ctx* ctx, const float* partial, int nwaves, double* accum);
+int orx_launch_loss_accumulate(orx_ctx* ctx, const float* partial, int64_t nwaves, double* accum);
+int orx_shard_grads_nwaves(int D, int64_t T);
 
 // pointwise (GMF / WRMF) step, kernels_pointwise.hip
 struct PointArgs {
@@ -565,7 +566,8 @@ int orx_launch_shard_dedup_slots(orx_ctx* ctx, const DedupReqArgs& a, int64_t K)
 int orx_shard_grads_impl(orx_ctx* ctx, int model, orx_opt* opt, orx_table* user, const float* rows_in, const float* bias_in,
                          const int32_t* u_loc, const int32_t* slot, const uint8_t* dupref, const void* sorted, const void* seglist,
                          const int32_t* segcount, float* gdup, const uint8_t* dup_u, int64_t T, int64_t row_stride, int64_t B_global,
-                         float margin, int flags, float* gu, int32_t* u_apply, float* send_g, float* gb_out, double* loss_l2_accum);
+                         float margin, int flags, float* gu, int32_t* u_apply, float* send_g, float* gb_out, double* loss_l2_accum,
+                         float* partial_ext = nullptr, int* nwaves_out = nullptr);
 int orx_apply_rows_flagged_impl(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
                                 const float* grads, int64_t g_stride, const float* gbias, const unsigned char* dflag);
 int orx_launch_shard_segsum(orx_ctx* ctx, const int2* seglist, const int* segcount, const uint2* sorted, int64_t n, const float* gdup, int DSg,

@@ -105,7 +105,7 @@ struct orx_comm {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> st_ev;
     // the engine's exchange buffers (grown on demand, kept between calls)
     Buf dl_send, dl_slot, dl_req, dl_reqloc, dl_rows_out, dl_rows_in, dl_send_g, dl_g_in, dl_idx, dl_ids, dl_flat, dl_sum, dl_cnt, dl_ptrs;     // hybrid-parallel DLRM engine
-    Buf send1, mine, tmp, cnt, send2, req, req_loc, slot, u_loc, fu, fv, rows_out, rows_in, gu, u_apply, send_g, g_in, dupref, dsorted, seglist, segcount, gdup, bias_x;
+    Buf send1, mine, tmp, cnt, send2, req, req_loc, slot, u_loc, fu, fv, rows_out, rows_in, gu, u_apply, send_g, g_in, dupref, dsorted, seglist, segcount, gdup, bias_x, partials;
 };
 
 static int ensure(orx_comm* c, Buf& b, size_t bytes) {
@@ -414,6 +414,10 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
         CHECK(ensure(c, c->rows_out, (size_t)H * M * DS * 4)); CHECK(ensure(c, c->rows_in, (size_t)H * M * DS * 4));
         CHECK(ensure(c, c->send_g, (size_t)H * M * DS * 4)); CHECK(ensure(c, c->g_in, (size_t)H * M * DS * 4));
         CHECK(ensure(c, c->gu, (size_t)H * T * D * 4)); CHECK(ensure(c, c->u_apply, (size_t)H * T * 4));
+        const int nw_list = orx_shard_grads_nwaves(D, T);             // the loss partials of every list of a chunk: ONE accumulate launch per chunk
+        ORX_ARG(nw_list > 0, "sharded engine: dim must be 16/32/64/128/256 (got %d)", D);
+        CHECK(ensure(c, c->partials, Lr * (size_t)nw_list * 2 * 4));
+        int nw_now = 0;
         if (split) CHECK(ensure(c, c->bias_x, (size_t)4 * H * M * 4));          // biases out | in | bias gradients out | in, [H][M] each
         if (sgd) {
             CHECK(ensure(c, c->fu, Lr * T)); CHECK(ensure(c, c->fv, Lr * M));
@@ -480,7 +484,9 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
                 if (H == 2) ORX_HIP(hipStreamWaitEvent(S, c->ev[2 + h], 0));
                 CHECK(orx_shard_grads_impl(ctx, model, sgd ? opt : nullptr, U, (const float*)rows_in[h], (const float*)b_in[h], ul, sl, dr, so, sgl, sgc, gd,
                                            sgd ? fu + (size_t)l * T : nullptr, T, DS, B_global, margin, gflags, gu,
-                                           sgd ? (int32_t*)c->u_apply.p + (size_t)h * T : nullptr, sg, gbo, loss_l2_accum));
+                                           sgd ? (int32_t*)c->u_apply.p + (size_t)h * T : nullptr, sg, gbo, loss_l2_accum,
+                                           (float*)c->partials.p + (size_t)l * 2 * (size_t)nw_list, &nw_now));
+                ORX_ARG(nw_now == nw_list, "sharded engine: the gradient launch wrote %d loss partials, %d were expected", nw_now, nw_list);
                 if (H == 2) { ORX_HIP(hipEventRecord(c->ev[4 + h], S)); ORX_HIP(hipStreamWaitEvent(X, c->ev[4 + h], 0)); }
                 if (split) CHECK(exchange(c, sg, (float*)c->g_in.p + (size_t)h * M * DS, (size_t)cap2 * DS * 4, &g_in[h], X,
                                           gbo, bx + (size_t)(3 * H + h) * M, (size_t)cap2 * 4, &gb_in[h]));
@@ -504,6 +510,7 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
                 CHECK(orx_apply_rows(ctx, opt, V, b, req_loc + (size_t)k * H * M, H * M, g, DS));
             }
         }
+        CHECK(orx_launch_loss_accumulate(ctx, (const float*)c->partials.p, (int64_t)L * nw_list, loss_l2_accum));
     }
     return ORX_OK;
 }
