@@ -518,7 +518,8 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
                         const std::vector<const float*>& outs, const std::vector<int64_t>& ld_out,
                         float* dy, float* other, int64_t B, bool need_dx0, float** dx_out, float gscale, bool defer_slabs,
                         const std::vector<const void*>* ins16 = nullptr, const std::vector<int64_t>* ld_in16 = nullptr,
-                        const std::vector<const void*>* outs16 = nullptr) {
+                        const std::vector<const void*>* outs16 = nullptr, std::vector<ColJob>* jobs_out = nullptr,
+                        const float* dy_src = nullptr, int64_t dy_src_ld = 0, float dy_src_scale = 1.0f) {
     orx_ctx* c = m->ctx;
     const int which = &L == &m->top ? 1 : 0;
     bool act_done = false;              // the activation backward of layer l was fused into the product above it
@@ -554,7 +555,9 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
             ORX_ARG(dy32, "dlrm backward: fp32 gradient missing for layer %d", l);
             dy16 = (s16 || (D.dw16 && m->g16 != nullptr)) ? m->g16 : nullptr;
             ColPart pb = colpart_of(D.gbpart);
-            CHECK(orx_launch_act_bwd_colsum(c, dy, outs[l], ld_out[l], (int)B, D.out, D.act, &pb, dy16, D.out));
+            // (dy_src: the MLP's incoming gradient is still a strided, unscaled slice of another array -- read in place, once)
+            CHECK(orx_launch_act_bwd_colsum(c, dy, outs[l], ld_out[l], (int)B, D.out, D.act, &pb, dy16, D.out, dy_src, dy_src_ld, dy_src_scale));
+            dy_src = nullptr;
             add_job(pb, D.b->gsum, D.out);
         }
         act_done = false;
@@ -611,7 +614,9 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
             float* t = dy; dy = other; other = t;
         }
     }
-    CHECK(orx_launch_colparts_reduce(c, coljobs.data(), (int)coljobs.size()));
+    // (jobs_out: the caller reduces the partial rows of both MLPs with one launch)
+    if (jobs_out) jobs_out->insert(jobs_out->end(), coljobs.begin(), coljobs.end());
+    else CHECK(orx_launch_colparts_reduce(c, coljobs.data(), (int)coljobs.size()));
     if (slabs > 0) {
         ORX_ARG(slabs == m->n_slabjobs[which], "dlrm backward: %d of %d split-K weight gradients were produced", slabs, m->n_slabjobs[which]);
         // (deferred: the fused optimizer launch adds the slices itself -- orx_dlrm_step in fp16 mode)
@@ -641,7 +646,8 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale, bool 
             ins16.push_back(l == 0 ? m->R16 : m->top_y16[l - 1]); ldi16.push_back(l == 0 ? m->ldR16 : up8(m->top[l - 1].out));
             outs16.push_back(l + 1 < m->top.size() ? m->top_y16[l] : nullptr);
         }
-    CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR, gscale, defer_slabs, m->gen2 ? &ins16 : nullptr, &ldi16, &outs16));
+    std::vector<ColJob> coljobs;                         // bias gradients (and the head's weight gradient) of both MLPs: one reduce launch at the end
+    CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR, gscale, defer_slabs, m->gen2 ? &ins16 : nullptr, &ldi16, &outs16, &coljobs));
     // ---- interaction backward: dZ for every slot (slot F-1 = d dense_emb)
     // (dR carries the loss scale; dZ -- the embedding rows' gradients -- leaves unscaled)
     CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B, m->ldR, nullptr, 0, nullptr,
@@ -650,7 +656,6 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale, bool 
     // ---- bottom MLP backward from dZ[:, F-1, :]
     float* dy = (dR == m->gA) ? m->gB : m->gA;
     float* other = (dy == m->gA) ? m->gB : m->gA;
-    CHECK(orx_launch_copy2d(c, dy, d, m->dZ + (size_t)(F - 1) * d, (int64_t)F * d, (int)B, d, gscale));
     ins.clear(); outs.clear(); ldi.clear(); ldo.clear();
     for (size_t l = 0; l < m->bot.size(); ++l) {
         const bool last = l + 1 == m->bot.size();
@@ -665,7 +670,10 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale, bool 
             ins16.push_back(l == 0 ? m->dense16 : m->bot_y16[l - 1]); ldi16.push_back(l == 0 ? m->ld_dense16 : up8(m->bot[l - 1].out));
             outs16.push_back(l + 1 < m->bot.size() ? m->bot_y16[l] : nullptr);
         }
-    CHECK(mlp_backward(m, m->bot, ins, ldi, outs, ldo, dy, other, B, false, &dx0, gscale, defer_slabs, bot16 ? &ins16 : nullptr, &ldi16, &outs16));
+    // (the bottom MLP's dY = gscale * dZ[:, F-1, :]: its first activation backward reads the slice in place)
+    CHECK(mlp_backward(m, m->bot, ins, ldi, outs, ldo, dy, other, B, false, &dx0, gscale, defer_slabs, bot16 ? &ins16 : nullptr, &ldi16, &outs16, &coljobs,
+                       m->dZ + (size_t)(F - 1) * d, (int64_t)F * d, gscale));
+    CHECK(orx_launch_colparts_reduce(c, coljobs.data(), (int)coljobs.size()));
     }
     return ORX_OK;
 }

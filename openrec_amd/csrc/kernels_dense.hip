@@ -571,8 +571,10 @@ int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int
 
 // dZ = dY * act'(Y) in place AND the column sums of dZ (the bias gradient) of every row slab in the same pass:
 // parts[slab][c], plain stores; colparts_reduce_kernel adds the slabs in order.  grid = (columns / 64, row slabs).
+// src != NULL: the incoming gradient is src[r * ld_src + c] * src_scale instead of dY (the bottom MLP's dY is a strided slice of dZ:
+// no copy launch of its own)
 __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* dY, const float* Y, int64_t ldy, int M, int N, int act, float* gb,
-                                                             _Float16* d16, int64_t ld16, int slab) {
+                                                             _Float16* d16, int64_t ld16, int slab, const float* src, int64_t ld_src, float src_scale) {
     __shared__ float sh[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* dY, const fl
     if (c < N) {
         for (int r = r0 + part; r < r1; r += 4) {
             const float y = Y[(int64_t)r * ldy + c];
-            float d = dY[(int64_t)r * N + c];
+            float d = src ? src[(int64_t)r * ld_src + c] * src_scale : dY[(int64_t)r * N + c];
             if (act == 1) d = y > 0.0f ? d : 0.0f;
             else if (act == 2) d = d * y * (1.0f - y);
             dY[(int64_t)r * N + c] = d;
@@ -594,13 +596,14 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(float* dY, const fl
     if (part == 0 && c < N) gb[(int64_t)blockIdx.y * N + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
-int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, ColPart* gbp, void* d16, int64_t ld16) {
+int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, ColPart* gbp, void* d16, int64_t ld16,
+                              const float* src, int64_t ld_src, float src_scale) {
     if (M == 0 || N == 0) return ORX_OK;
     const int slab = (int64_t)M * N >= (4 << 20) ? 256 : 32;          // small layers: more, shorter slabs (the pass is latency-bound)
     float* gb = gbp->parts;
     gbp->P = (M + slab - 1) / slab;
     ORX_LAUNCH(ctx, act_bwd_colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + slab - 1) / slab)), dim3(256), 0, dY, Y, ldy, M, N, act, gb,
-               (_Float16*)d16, ld16, slab);
+               (_Float16*)d16, ld16, slab, src, ld_src, src_scale);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -1095,8 +1098,10 @@ __global__ __launch_bounds__(256) void dense_apply_fused_kernel(const DenseFused
     const int64_t i = (int64_t)row * p.cols + col;
     if (live) {
         if (vec) {
-            const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.g + i), w4 = *reinterpret_cast<const f32x4*>(p.w + i);
-            gi[0] = g4.x; gi[1] = g4.y; gi[2] = g4.z; gi[3] = g4.w; wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.w + i);
+            // (a gradient that arrives in split-K slices never touches g: it is zero and stays zero -- not read, not re-zeroed)
+            if (p.slab == nullptr) { const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.g + i); gi[0] = g4.x; gi[1] = g4.y; gi[2] = g4.z; gi[3] = g4.w; }
+            wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
             if (optkind != ORX_SGD) { const f32x4 q = *reinterpret_cast<const f32x4*>(p.acc + i); a1[0] = q.x; a1[1] = q.y; a1[2] = q.z; a1[3] = q.w; }
             if (optkind == ORX_ADAM) { const f32x4 q = *reinterpret_cast<const f32x4*>(p.acc2 + i); a2[0] = q.x; a2[1] = q.y; a2[2] = q.z; a2[3] = q.w; }
         } else {
@@ -1132,7 +1137,7 @@ __global__ __launch_bounds__(256) void dense_apply_fused_kernel(const DenseFused
             f32x4 o; o.x = wv[0]; o.y = wv[1]; o.z = wv[2]; o.w = wv[3];
             *reinterpret_cast<f32x4*>(p.w + i) = o;
             f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(p.g + i) = z4;
+            if (p.slab == nullptr) *reinterpret_cast<f32x4*>(p.g + i) = z4;
             if (optkind != ORX_SGD) { f32x4 q; q.x = a1[0]; q.y = a1[1]; q.z = a1[2]; q.w = a1[3]; *reinterpret_cast<f32x4*>(p.acc + i) = q; }
             if (optkind == ORX_ADAM) { f32x4 q; q.x = a2[0]; q.y = a2[1]; q.z = a2[2]; q.w = a2[3]; *reinterpret_cast<f32x4*>(p.acc2 + i) = q; }
         } else {

@@ -456,7 +456,7 @@ constexpr int ORX_COLJOBS_MAX = 24;
 struct ColJobs { ColJob j[ORX_COLJOBS_MAX]; };
 int orx_launch_colparts_reduce(orx_ctx* ctx, const ColJob* jobs, int n);
 int orx_launch_act_bwd_colsum(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act, ColPart* gb,
-                              void* d16 = nullptr, int64_t ld16 = 0);
+                              void* d16 = nullptr, int64_t ld16 = 0, const float* src = nullptr, int64_t ld_src = 0, float src_scale = 1.0f);
 int orx_launch_gemm_f16s(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                          void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act,
                          const float* actY = nullptr, int64_t ldy = 0, int act_y = 0, ColPart* gb = nullptr);

@@ -1,10 +1,7 @@
 #!/bin/bash
 rm -rf gpurun_out/r4s; mkdir -p gpurun_out/r4s
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_dlrm.py tests/test_gpu_sharded_dlrm.py tests/test_gpu_c5_shapes.py -q -x 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_dlrm.py tests/test_gpu_sharded_dlrm.py tests/test_gpu_c5_shapes.py tests/test_gpu_reference_examples.py tests/test_gpu_compose.py -q -x 2>&1 | tail -2
 one() { timeout 200 python bench.py --no-cpu-baseline --model dlrm "$@" --steps 40 --warmup 10 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms/step', round(d['ms_per_step'],4), 'gemm ms', round(d['roofline'].get('gemm_ms_per_step',0),4), 'frac', round(d['roofline']['frac'],4))"; }
 for i in 1 2 3; do one --fp16-mlp; done
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r4s/prof -o p -- python bench.py --no-cpu-baseline --model dlrm --fp16-mlp --steps 20 --warmup 5 > gpurun_out/r4s/prof.log 2>&1
-f=$(find gpurun_out/r4s/prof -name '*kernel_trace.csv' | head -1)
-python scripts/trace_last_step.py "$f" dlrm_loss_kernel > gpurun_out/r4s/step.txt; grep "interact" gpurun_out/r4s/step.txt
-rm -rf gpurun_out/r4s/prof
+one
