@@ -43,3 +43,19 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_the_library_in_the_tree_is_built_from_the_sources_in_the_tree():
+    """__graft_entry__.build() rebuilds by content, not by mtime (a shipped snapshot has arbitrary mtimes): after a build the hash
+    file beside the .so names the sources it was built from, and a changed source asks for a rebuild."""
+    from openrec_amd import build
+    build.build()
+    assert os.path.exists(build.LIB) and not build.needs_build()
+    assert open(build.HASH_FILE).read().strip() == build.source_hash()
+    saved = open(build.HASH_FILE).read()
+    try:
+        open(build.HASH_FILE, "w").write("0" * 16)          # as if a source had changed since the build
+        assert build.needs_build()
+    finally:
+        open(build.HASH_FILE, "w").write(saved)
+    assert not build.needs_build()
