@@ -2,7 +2,6 @@
 the C ABI (gather_rows / apply_rows / dlrm grads / dense pack + apply) restated with the NumPy oracle, so
 that the exchange plan can be exercised with gloo on CPU."""
 import numpy as np
-import torch
 
 from oracle import numpy_oracle as orc
 from oracle.dlrm_oracle import DLRMOracle

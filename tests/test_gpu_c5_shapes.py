@@ -8,7 +8,6 @@ ids renumbered densely per table, oracle/dlrm_oracle.py stepped on the small tab
 its exact bits.  Batches are drawn away from the network's relu ties (tests/dlrm_util.py; the dropped share is recorded), the
 steps run twice and must agree bit for bit, and every parameter update is held to 1e-5 in exact fp32 mode and to 1e-4 against
 the fp16-operand oracle in fp16-MLP mode."""
-import copy
 
 import numpy as np
 import pytest

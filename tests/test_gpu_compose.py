@@ -336,7 +336,7 @@ def test_reference_dlrm_class_text_trains_on_the_fused_path(optk, loss_func, com
     from openrec_amd.tf2.modules._compose import _models, _RowRangeTable
     from oracle import numpy_oracle as orc
     from oracle.dlrm_oracle import DLRMOracle
-    from dlrm_util import draw_batch, round_to_fp32
+    from dlrm_util import draw_batch
     DLRM = _ref_class("dlrm.py", "DLRM")
     cfg = dict(m_spa=16, ln_emb=[50, 7, 300, 3], ln_bot=[32, 16], ln_top=[64, 32, 1])
     model = DLRM(loss_func=loss_func, loss_threshold=0.0 if loss_func == "mse" else 0.01, **cfg)

@@ -5,7 +5,6 @@ reference repository).  Nothing in the scripts is patched: bpr_citeulike.py loop
 `total_iter` is never read), so the run is ended from outside, by the `print` handed to the script's globals, after the
 second evaluation line.  The script text comes from /root/reference when it exists (this container) and from the
 git-ignored blob __graft_entry__.build() leaves for the GPU box otherwise."""
-import io
 import json
 import os
 import re

@@ -10,7 +10,6 @@ import pytest
 
 def test_second_order_interaction_values_and_tape_refusal():
     from openrec_amd.tf2.modules import SecondOrderFeatureInteraction
-    from openrec_amd.tf2.modules import _compose
     from openrec_amd.tf2._lazy import GradientTape
     rng = np.random.default_rng(0)
     xs = [rng.normal(size=(5, 4)).astype(np.float32) for _ in range(3)]
