@@ -13,6 +13,22 @@
 // ----------------------------------------------------------------- errors ---
 static thread_local char g_err[1024] = "";
 
+// ORX_HOST_TIMING=1 (experiments): wall-clock stamps of the host's way through a train-step call
+#include <chrono>
+static bool host_timing() { static const bool on = getenv("ORX_HOST_TIMING") != nullptr; return on; }
+static thread_local double g_ht[16]; static thread_local const char* g_htn[16]; static thread_local int g_htc = 0;
+static void ht_mark(const char* what) {
+    if (!host_timing() || g_htc >= 16) return;
+    g_ht[g_htc] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); g_htn[g_htc++] = what;
+}
+static void ht_dump() {
+    if (!host_timing() || g_htc == 0) return;
+    fprintf(stderr, "[orx host]");
+    for (int i = 1; i < g_htc; ++i) fprintf(stderr, " %s +%.1f", g_htn[i], g_ht[i] - g_ht[i - 1]);
+    fprintf(stderr, " | total %.1f us\n", g_ht[g_htc - 1] - g_ht[0]);
+    g_htc = 0;
+}
+
 void orx_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -51,6 +67,7 @@ void orx_prof_begin(orx_ctx* ctx, int kid) {
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
     ctx->prof_slot[kid].ev.push_back(e0);
     ctx->prof_slot[kid].ev.push_back(e1);
+    ctx->prof_order.push_back(kid);
     ctx->cur_e0 = e0; ctx->cur_e1 = e1;
 }
 
@@ -60,6 +77,26 @@ void orx_prof_end(orx_ctx* ctx, int kid) {
 }
 
 static int prof_collect(orx_ctx* ctx) {
+    // ORX_PROF_TIMELINE=1 (experiments): begin / duration of every profiled launch since the last collection, in launch order, relative
+    // to the first one's begin -- the gaps between launches without a tracing tool in the way
+    static const bool timeline = getenv("ORX_PROF_TIMELINE") != nullptr;
+    if (timeline && !ctx->prof_order.empty()) {
+        size_t cur[ORX_K_NUM] = {0};
+        hipEvent_t first = nullptr;
+        float prev_end = 0.f;
+        for (int kid : ctx->prof_order) {
+            auto& s = ctx->prof_slot[kid];
+            const size_t i = cur[kid]; cur[kid] += 2;
+            if (i + 1 >= s.ev.size()) break;
+            if (hipEventSynchronize(s.ev[i + 1]) != hipSuccess) break;
+            if (!first) first = s.ev[i];
+            float t0 = 0.f, dur = 0.f;
+            if (hipEventElapsedTime(&t0, first, s.ev[i]) != hipSuccess || hipEventElapsedTime(&dur, s.ev[i], s.ev[i + 1]) != hipSuccess) { (void)hipGetLastError(); continue; }
+            fprintf(stderr, "[orx timeline] %9.1f us  +%6.1f gap  %7.1f us  class %d\n", t0 * 1e3, (t0 - prev_end) * 1e3, dur * 1e3, kid);
+            prev_end = t0 + dur;
+        }
+    }
+    ctx->prof_order.clear();
     for (int k = 0; k < ORX_K_NUM; ++k) {
         auto& s = ctx->prof_slot[k];
         for (size_t i = 0; i + 1 < s.ev.size(); i += 2) {
@@ -108,6 +145,7 @@ extern "C" int orx_ctx_destroy(orx_ctx* c) {
     hipFree(c->d_sort[0]); hipFree(c->d_sort[1]); hipFree(c->d_sort_hist); hipFree(c->d_csr_part[0]); hipFree(c->d_csr_part[1]); hipFree(c->d_splitk);
     if (c->h_plan) hipHostFree(c->h_plan);
     if (c->plan_ev) hipEventDestroy(c->plan_ev);
+    if (c->stats_ev) hipEventDestroy(c->stats_ev);
     for (int k = 0; k < 2; ++k) { if (c->pipe_cnt[k]) hipEventDestroy(c->pipe_cnt[k]); if (c->pipe_done[k]) hipEventDestroy(c->pipe_done[k]); }
     if (c->plan_stream) hipStreamDestroy(c->plan_stream);
     if (c->wait_ev) hipEventDestroy(c->wait_ev);
@@ -579,7 +617,7 @@ int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t
             CHECK(orx_plan_buffers(c, chunk, B, U->rows, V->rows, inline_apply));
             if (c->h_plan_cap < (size_t)chunk * 9 * sizeof(int)) {
                 if (c->h_plan) ORX_HIP(hipHostFree(c->h_plan));
-                c->h_plan = nullptr; c->h_plan_cap = 0;
+                c->h_plan = nullptr; c->h_plan_cap = 0; c->stats_pending = false;      // (counters a call left there are gone)
                 ORX_HIP(hipHostMalloc((void**)&c->h_plan, (size_t)chunk * 9 * sizeof(int), hipHostMallocDefault));
                 c->h_plan_cap = (size_t)chunk * 9 * sizeof(int);
             }
@@ -691,8 +729,10 @@ int orx_exact_plan_issue(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
     // the host waits for it (the fused kernel ignores them in a launch without apply blocks)
     d.roles = nullptr; d.dupbits = nullptr;
     CHECK(orx_launch_plan(c, d, kc, inline_apply, i0));
-    ORX_HIP(hipMemcpyAsync(c->h_plan + 8 * i0, c->d_alloc + 8 * i0, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // ([5] = duplicated rows)
-    ORX_HIP(hipEventRecord(counters, c->stream));
+    if (counters != nullptr) {      // (NULL: nobody waits for this plan's counters, see orx_plan_stats_*)
+        ORX_HIP(hipMemcpyAsync(c->h_plan + 8 * i0, c->d_alloc + 8 * i0, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // ([5] = duplicated rows)
+        ORX_HIP(hipEventRecord(counters, c->stream));
+    }
     if (d.pair_tpw > 1) {
         // pairing: the fused kernel's input is packed once every flag sits on the rewritten ids (urgent marks included).
         // MEASURED AND LEFT OFF (profiles/r4_plan_side_stream.txt; ORX_PLAN_SIDE=1 turns it on): step 0 of a chunk needs no urgent
@@ -729,23 +769,70 @@ int orx_exact_plan_issue(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
     return ORX_OK;
 }
 
-int orx_exact_plan_finish(orx_ctx* c, int64_t kc, int64_t B, bool inline_apply, bool staging, int64_t i0, hipEvent_t counters, ExactChunk* out, bool pairing_on) {
-    *out = ExactChunk();
-    ORX_HIP(hipEventSynchronize(counters));
-    std::vector<int> dcv((size_t)kc);
-    int big = 0;
-    const int* hp = c->h_plan + 8 * i0;
-    for (int64_t i = 0; i < kc; ++i) { dcv[i] = hp[8 * i + 5] - hp[8 * i + 7]; big = std::max(big, hp[8 * i + 6]); }      // ([5] list entries, [7] of them paired after all)
+// What the host takes from the per-step counters of a plan (hp: [kc][8]) whether it waited for them or finds them later: the
+// geometry of the next plan's workgroups, the pairing pause, and whether the plan was QUIET -- no range wanted a staging plan, the
+// duplicated rows stay well below the in-launch apply's break-even, no oversized bucket.
+static bool plan_counters_seen(orx_ctx* c, int64_t kc, int64_t B, int64_t i0, const int* hp, bool pairing_on, std::vector<int>* dcv) {
+    int big = 0, max_dup = 0;
+    bool quiet = true;
+    if (dcv) dcv->resize((size_t)kc);
+    for (int64_t i = 0; i < kc; ++i) {
+        const int dc = hp[8 * i + 5] - hp[8 * i + 7];       // ([5] list entries, [7] of them paired after all)
+        if (dcv) (*dcv)[i] = dc;
+        max_dup = std::max(max_dup, dc); big = std::max(big, hp[8 * i + 6]);
+        if (hp[8 * i + 1] > 0 || hp[8 * i + 2] > 0 || hp[8 * i + 3] > 0 || hp[8 * i + 4] > 0) quiet = false;      // staged references / tree items
+    }
     c->plan_big = big > 16384;          // ([6] = the step's largest bucket, if above 8 k references)
+    if ((int64_t)max_dup * 6 > B || c->plan_big) quiet = false;      // (the in-launch apply stops paying at B / 5 duplicated rows: plan_decide)
     if (pairing_on && kc > 0 && getenv("ORX_PAIR_ALWAYS") == nullptr) {
         int64_t pairs = 0;
         for (int64_t i = 0; i < kc; ++i) pairs += hp[8 * i + 7];
         if (pairs * 16 < kc * B) c->pair_pause = 32;        // fewer than B / 16 accepted pairs per step: not worth its plan
     }
     if (getenv("ORX_PLAN_DEBUG") != nullptr && kc > 0)
-        fprintf(stderr, "[orx plan] steps %lld..%lld: step %lld has %d duplicated rows left for the apply, %d accepted pairs, %d staged references\n",
-                (long long)i0, (long long)(i0 + kc - 1), (long long)i0, hp[5] - hp[7], hp[7], hp[1]);
+        fprintf(stderr, "[orx plan] steps %lld..%lld: step %lld has %d duplicated rows left for the apply, %d accepted pairs, %d staged references; %s\n",
+                (long long)i0, (long long)(i0 + kc - 1), (long long)i0, hp[5] - hp[7], hp[7], hp[1], quiet ? "quiet" : "not quiet");
+    return quiet;
+}
+
+int orx_exact_plan_finish(orx_ctx* c, int64_t kc, int64_t B, bool inline_apply, bool staging, int64_t i0, hipEvent_t counters, ExactChunk* out, bool pairing_on) {
+    *out = ExactChunk();
+    ORX_HIP(hipEventSynchronize(counters));
+    std::vector<int> dcv;
+    const int* hp = c->h_plan + 8 * i0;
+    const bool quiet = plan_counters_seen(c, kc, B, i0, hp, pairing_on, &dcv);
     plan_decide(kc, B, inline_apply, staging, dcv.data(), hp, out);
+    out->quiet = quiet;
+    return ORX_OK;
+}
+
+// ---- no read-back (orx_pairwise_step).  A K-step call used to stop in its middle: the plan's counters were copied to the host, which
+// waited for them before it enqueued steps 1 .. K-1 (is the in-launch apply worth it, did any range stage, are there tree levels).
+// Those answers rarely change from one call of a training loop to the next, and none of them is needed for CORRECTNESS once the
+// plan is made with staging off (rows referenced >= 3 times then use fp32 atomics; the in-launch apply is exact at any density):
+// a call whose predecessor's counters were quiet takes that form, enqueues everything without a host wait, and leaves the copy of its
+// own counters behind its last launch for the next call to look at (not quiet any more: that call plans with the read-back again).
+static int plan_stats_poll(orx_ctx* c) {
+    if (!c->stats_pending) return ORX_OK;
+    hipError_t e = hipEventQuery(c->stats_ev);
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        if (++c->stats_age < 8) return ORX_OK;              // (a host far ahead of the device: keep the old answer a little longer)
+        e = hipEventSynchronize(c->stats_ev);
+    }
+    ORX_HIP(e);
+    c->stats_pending = false; c->stats_age = 0;
+    const bool quiet = plan_counters_seen(c, c->stats_kc, c->stats_B, 0, c->h_plan, c->stats_pairing, nullptr);
+    c->plan_stats.valid = true; c->plan_stats.quiet = quiet;
+    for (int k = 0; k < 5; ++k) c->plan_stats.key[k] = c->stats_key[k];
+    return ORX_OK;
+}
+static int plan_stats_leave(orx_ctx* c, int64_t kc, int64_t B, bool pairing_on, const int64_t key[5]) {
+    if (!c->stats_ev) ORX_HIP(hipEventCreateWithFlags(&c->stats_ev, hipEventDisableTiming));
+    ORX_HIP(hipMemcpyAsync(c->h_plan, c->d_alloc, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    ORX_HIP(hipEventRecord(c->stats_ev, c->stream));
+    c->stats_pending = true; c->stats_kc = kc; c->stats_B = B; c->stats_pairing = pairing_on; c->stats_age = 0;
+    for (int k = 0; k < 5; ++k) c->stats_key[k] = key[k];
     return ORX_OK;
 }
 
@@ -759,7 +846,10 @@ int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
         // work that does not depend on the counters goes to the device before the host blocks on them (the first fused launch
         // of the chunk: the device would otherwise idle through the host's wake-up and the first launch's latency)
         CHECK(orx_exact_plan_issue(c, U, V, uid, pid, nid, ds, nU, nP, nN, kc, B, inline_apply, staging, plan, 0, c->plan_ev, while_waiting));
-        return orx_exact_plan_finish(c, kc, B, inline_apply, staging, 0, c->plan_ev, out, plan.pair_tpw > 1);
+        ht_mark("plan_issued");
+        const int rc_fin = orx_exact_plan_finish(c, kc, B, inline_apply, staging, 0, c->plan_ev, out, plan.pair_tpw > 1);
+        ht_mark("counters");
+        return rc_fin;
     }
     // duplicate detection for every step of the chunk, on the id arrays alone
     DedupArgs d;
@@ -839,6 +929,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     ORX_ARG(K >= 0 && B >= 0, "orx_pairwise_step: negative K or B");
     ORX_ARG(K == 0 || B == 0 || (uid && pid && nid), "orx_pairwise_step: NULL id pointer");
     if (K == 0) return ORX_OK;
+    g_htc = 0; ht_mark("enter");
     ORX_HIP(hipSetDevice(c->device));
     if (B == 0) {           // empty batch: reduce_mean of nothing is NaN in TF; tables untouched
         for (int64_t s = 0; s < K; ++s) { if (loss_out) loss_out[s] = model == ORX_BPR ? NAN : 0.f; if (l2_out) l2_out[s] = 0.f; }
@@ -875,7 +966,15 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     // (no dup_apply launch, no kernel boundary) -- not with a separate censor pass between the steps
     const bool inline_apply = role_bits && !censor && K > 1 && orx_fused_can_inline_apply(U->dim) && !(fb & 2);
     // rows referenced >= 3 times in a step: private staging slots instead of atomics (fb bit 3: atomics)
-    const bool staging = role_bits && orx_fused_can_inline_apply(U->dim) && !(fb & 8);
+    bool staging = role_bits && orx_fused_can_inline_apply(U->dim) && !(fb & 8);
+    // no read-back (see plan_stats_poll): the previous call of this shape was quiet
+    const int64_t stats_key[5] = {B, U->rows, V->rows, (int64_t)model * 16 + opt->kind, (int64_t)U->dim * 4 + (want_censor ? 1 : 0) + (inline_apply ? 2 : 0)};
+    CHECK(plan_stats_poll(c));
+    static const bool plan_wait = getenv("ORX_PLAN_WAIT") != nullptr || getenv("ORX_PLAN_PIPE") != nullptr || getenv("ORX_PLAN_SIDE") != nullptr;      // (experiments: always read back)
+    bool nowait = mode == MODE_EXACT && orx_plan_v2(role_bits) && staging && !censor && opt->kind != ORX_ADAM && !plan_wait &&
+                  c->plan_stats.valid && c->plan_stats.quiet;
+    for (int k = 0; k < 5 && nowait; ++k) nowait = c->plan_stats.key[k] == stats_key[k];
+    if (nowait) staging = false;
     const int nb_total = orx_dedup_buckets(U->rows) + orx_dedup_buckets(V->rows);
     if (mode != MODE_HOGWILD) {
         CHECK(orx_table_scratch(U, role_bits)); CHECK(orx_table_scratch(V, role_bits)); CHECK(orx_table_scratch(b, role_bits));
@@ -935,6 +1034,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     }
     if (fused_censor) { CHECK(orx_table_side(V)); a.censor = 1; a.min_norm = 0.1f; a.sideV = V->side; }
 
+    ht_mark("setup");
     for (int64_t s0 = 0; s0 < K; s0 += chunk) {
         const int64_t kc = (K - s0 < chunk) ? (K - s0) : chunk;
         // arguments of step i of the chunk, and its fused launch
@@ -990,7 +1090,11 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             // any range made a staging plan (references without one carry (-1, 0) and use atomics).
             const std::function<int()> early = [&]() -> int { first_launched = true; return launch_step(0, staging, false); };
             const bool can_early = v2 && !censor && getenv("ORX_PLAN_NO_EARLY") == nullptr;
-            if (pipe) {
+            if (nowait) {
+                CHECK(orx_exact_plan_issue(c, U, V, du + s0 * ds, dp + s0 * ds, dn + s0 * ds, ds, B, B, B, kc, B, inline_apply, staging, plan, 0, nullptr, nullptr));
+                pck[0] = ExactChunk();                       // (in-launch apply where the call allows it, no staging, no tree)
+                ht_mark("plan_issued");
+            } else if (pipe) {
                 CHECK(orx_exact_plan_issue(c, U, V, du + s0 * ds, dp + s0 * ds, dn + s0 * ds, ds, B, B, B, pc_hi[0], B, inline_apply, staging, plan, 0,
                                            c->plan_ev, can_early ? &early : nullptr));
                 CHECK(orx_exact_plan_finish(c, pc_hi[0], B, inline_apply, staging, 0, c->plan_ev, &pck[0], plan.pair_tpw > 1));
@@ -1083,8 +1187,20 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             r.partial = c->d_partial; r.out = c->d_loss + 2 * s0; r.nwaves = nw;
             CHECK(orx_launch_loss_reduce(c, r, kc));
         }
+        if (mode == MODE_EXACT && orx_plan_v2(role_bits)) {
+            // what this chunk's plan counted: left behind the last launch for the next call (no read-back), or seen already
+            if (nowait) CHECK(plan_stats_leave(c, kc, B, plan.pair_tpw > 1, stats_key));
+            else {
+                bool quiet = true;
+                for (const ExactChunk& ck : pck) quiet = quiet && ck.quiet;
+                c->plan_stats.valid = true; c->plan_stats.quiet = quiet; c->stats_pending = false;
+                for (int k = 0; k < 5; ++k) c->plan_stats.key[k] = stats_key[k];
+            }
+        }
     }
+    ht_mark("launched");
     CHECK(fetch_losses(c, K, loss_out, l2_out));
+    ht_mark("losses"); ht_dump();
     if (!(flags & ORX_IDS_DEVICE)) return orx_check_index_error(c);
     return ORX_OK;
 }

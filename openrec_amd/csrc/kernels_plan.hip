@@ -290,7 +290,7 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
             if (role) ent[i].y = (int)((uint32_t)e.y | ((uint32_t)role << 30));       // (read back by the same thread in pass 2)
         });
     }
-    if (refinfo != nullptr && late) atomicAdd(&sh_late, late);
+    if (late) atomicAdd(&sh_late, late);
     pl_lds_barrier();
     PL_STAMP(2);
     // The bitmaps are final: the range's share of the step's list of duplicated rows is allocated NOW -- the returning atomic is in
@@ -306,7 +306,11 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
         atomicAdd(d.alloc + 8 * s + 5, list_cnt);      // (the host reads the allocators only: one copy)
     }
     // staging plan where atomics would pile up: ranges with at least max(64, n / 512) third-or-later references
-    const bool plan = refinfo != nullptr && sh_late >= (a.min_late < 0 ? (n / 512 > 64 ? n / 512 : 64) : a.min_late);
+    const bool want_plan = sh_late >= (a.min_late < 0 ? (n / 512 > 64 ? n / 512 : 64) : a.min_late);
+    const bool plan = refinfo != nullptr && want_plan;
+    // (a plan made with staging off: the allocator nobody uses then tells the host that a range would have staged -- the next
+    // call's plan is made with staging on again, see orx_pairwise_step)
+    if (want_plan && refinfo == nullptr && threadIdx.x == 0) atomicAdd(d.alloc + 8 * s + 1, sh_late);
     int ntri = 0, dense0 = 0;
     int* segstart = nullptr;
     if (plan) {

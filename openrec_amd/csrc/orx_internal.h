@@ -69,6 +69,12 @@ struct orx_ctx {
     int* h_plan = nullptr;                                       // pinned host mirror of the per-step plan counters
     size_t h_plan_cap = 0;
     hipEvent_t plan_ev = nullptr;                                // "plan counters have arrived on the host"
+    // What the counters of the LAST plan that was looked at said (api.hip, "no read-back"): a pairwise call whose predecessor was quiet
+    // -- no range wanted a staging plan, few duplicated rows, no oversized bucket -- makes its plan with staging off, launches every step
+    // without waiting for its own counters and leaves them for the next call to look at (stats_ev: their copy has arrived).
+    struct { bool valid = false, quiet = false; int64_t key[5] = {0, 0, 0, 0, 0}; } plan_stats;
+    hipEvent_t stats_ev = nullptr;
+    bool stats_pending = false; int64_t stats_kc = 0, stats_B = 0; bool stats_pairing = false; int stats_age = 0; int64_t stats_key[5] = {0, 0, 0, 0, 0};
     // plan pipeline (api.hip): the pieces of a chunk after the first are planned on a second stream while the previous piece's
     // steps run; per piece parity: counters on the host / plan complete on the device
     hipStream_t plan_stream = nullptr;
@@ -102,6 +108,7 @@ struct orx_ctx {
     float* d_splitk = nullptr; size_t d_splitk_cap = 0;     // [splits][M][N] partial products of a split-K fp32 product
     bool prof = false;
     ProfSlot prof_slot[ORX_K_NUM];
+    std::vector<int> prof_order;                     // kernel class of every profiled launch, in launch order (ORX_PROF_TIMELINE)
     hipEvent_t cur_e0 = nullptr, cur_e1 = nullptr;   // events of the launch being profiled (or null)
     int num_cu = 256;
 };
@@ -371,7 +378,8 @@ struct PairPlan { int nw; int64_t chunk; int64_t list_stride; int64_t Bp; int64_
                   int min_late = -1;      // staging plan from this many third-or-later references per range on (< 0: max(64, n / 512))
                   int pair_tpw = 0;       // pairing: triplets per wavefront of the fused kernel (0: off)
                   int64_t cap = 0; };     // steps the per-step scratch is sized for (>= chunk)
-struct ExactChunk { bool hot = false, use_stage = false, dense_dups = false; int tree_levels = 0; };
+struct ExactChunk { bool hot = false, use_stage = false, dense_dups = false; int tree_levels = 0;
+                    bool quiet = false; };      // the plan's counters were quiet (api.hip, "no read-back")
 int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t B, int mode, bool role_bits,
                       bool inline_apply, bool staging, int nb_total, int nw, PairPlan* plan);
 int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,

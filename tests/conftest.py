@@ -19,8 +19,18 @@ def golden_files(prefix=""):
     return sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith(prefix))
 
 
+GOLDEN_TF = os.path.join(GOLDEN, "tf")          # written by tests/golden/make_golden_tf.py --backend tf (real TensorFlow 2.0.1)
+
+
+def golden_source(name):
+    """"tf": the fixture was minted by the reference itself under real TensorFlow (tests/golden/tf/, preferred when present);
+    "torch": by the torch-autograd restatement (tests/golden/make_golden*.py)"""
+    return "tf" if os.path.exists(os.path.join(GOLDEN_TF, name)) else "torch"
+
+
 def load_golden(name):
-    return dict(np.load(os.path.join(GOLDEN, name)))
+    src = os.path.join(GOLDEN_TF, name) if golden_source(name) == "tf" else os.path.join(GOLDEN, name)
+    return dict(np.load(src))
 
 
 def rel_err(a, b):
