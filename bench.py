@@ -390,7 +390,24 @@ def main():
         # ---- diagnosis of the sharded step (after the timed region): the same K steps again with dispatch-attached events on the
         # kernels and HIP events around every exchange, and what a link delivers to the engine's own ncclSend / ncclRecv groups
         sharded_extra = {}
+
+        def all_ranks_ok(ok):
+            # the diagnosis below makes COLLECTIVE calls: a rank that failed must take the others out with it, not leave them
+            # waiting inside an exchange
+            if dist is None:
+                return ok
+            t = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
         try:
+            ready = True
+            try:
+                eng.check()
+            except Exception as e:                          # noqa: BLE001
+                ready = False
+                sharded_extra["diagnosis_error"] = repr(e)
+            if not all_ranks_ok(ready):
+                raise RuntimeError(sharded_extra.get("diagnosis_error", "another rank is not ready for the diagnosis pass"))
             ping = eng.comm_ping(32 << 20, 5)              # (first: connections are up before anything is timed)
             eng.be.ctx.prof_reset(); eng.be.ctx.prof_enable(True)
             eng.comm_stats_start()

@@ -313,6 +313,18 @@ int orx_dlrm_grads(orx_dlrm* m, const float* dense, const float* emb_rows, const
  *                          gradient of each lookup written to row idx[...] of grads_dst, the buffer that travels back: no
  *                          reordering passes.  orx_dlrm_direct_ok: 1 if this model's shapes allow it. */
 int orx_dlrm_direct_ok(orx_dlrm* m);
+/* The DLRM modules called on PLAIN ARRAYS (outside the composition dlrm.py:76-100, which is orx_dlrm_step / orx_dlrm_inference):
+ *   orx_mlp_forward      openrec/tf2/modules/multi_layer_perceptron.py:5-18: y = act_L(... act_1(x W_1 + b_1) ...); kernels[l] is a
+ *                        table [in_l, out_l] (Keras Dense layout), biases[l] a table [1, out_l] or NULL (biases may be NULL altogether),
+ *                        acts[l] 0 none / 1 relu / 2 sigmoid; x [B, in_dim] -> y_out [B, out_L]; exact fp32 products.
+ *   orx_interact_forward openrec/tf2/modules/second_order_feature_interaction.py:12-34: z [B, F, d] = the F inputs stacked on axis 1,
+ *                        out [B, P], P = F (F - 1) / 2 (self_interaction: F (F + 1) / 2), the selected elements of Z Z^T in
+ *                        boolean_mask order; reference_compat != 0 reproduces the reference's text (zeros: SURVEY.md E.1).
+ * flags & ORX_IDS_DEVICE: x / z and the output are device pointers (asynchronous on the context's stream); otherwise host pointers. */
+int orx_mlp_forward(orx_ctx* ctx, int32_t n_layers, orx_table* const* kernels, orx_table* const* biases, const int32_t* acts,
+                    const float* x, int64_t B, int32_t in_dim, int flags, float* y_out);
+int orx_interact_forward(orx_ctx* ctx, const float* z, int64_t B, int32_t F, int32_t d, int self_interaction, int reference_compat,
+                         int flags, float* out);
 int orx_dlrm_grads_indirect(orx_dlrm* m, const float* dense, const float* rows, int64_t n_rows, const int32_t* idx,
                             const float* label, int64_t B, int64_t global_B, float* grads_dst, double* loss_accum);
 int orx_dlrm_dense_count(orx_dlrm* m, int64_t* count);
@@ -451,7 +463,8 @@ int orx_comm_world(orx_comm* comm);
  *   orx_comm_ping(comm, bytes, reps, out): `reps` all-to-alls of `bytes` per peer (ncclSend / ncclRecv to every other rank at once,
  *                                  as the engine's exchanges do) on fresh buffers; out[0] = GB/s this rank sent (all links together),
  *                                  out[1] = GB/s per link, out[2] = microseconds per all-to-all.  Collective: every rank calls it.
- *                                  A one-rank communicator measures the device copy of its own block. */
+ *                                  A one-rank RCCL communicator measures the device copy of its own block; one made WITHOUT RCCL
+ *                                  (every exchange is the identity) has nothing to time: out = {0, 0, 0}. */
 int orx_comm_stats(orx_comm* comm, int start, double* out4);
 int orx_comm_ping(orx_comm* comm, int64_t bytes, int32_t reps, double* out3);
 int orx_sharded_caps(int64_t B, int32_t world, float slack, int64_t* cap1, int64_t* cap2);
@@ -480,6 +493,13 @@ int orx_prof_enable(orx_ctx* ctx, int on);
 int orx_prof_reset(orx_ctx* ctx);
 /* total device milliseconds and launch count recorded for kernel `kid` */
 int orx_prof_get(orx_ctx* ctx, int kid, double* total_ms, int64_t* launches);
+/* What the plan of the most recent exact pairwise call counted (tests, diagnosis; waits for that call's counters if nobody has
+ * looked at them yet -- see DESIGN.md 4.0 "no read-back"):
+ *   what = 0  rows referenced exactly twice that were PAIRED (accepted pairs, summed over the call's steps)
+ *        = 1  largest number of duplicated rows one step left for the apply
+ *        = 2  pairwise calls so far that enqueued every launch without waiting for their plan's counters
+ *        = 3  1 if those counters were "quiet" (no range wanted a staging plan, few duplicated rows), else 0 */
+int orx_ctx_stat(orx_ctx* ctx, int what, int64_t* out);
 
 #ifdef __cplusplus
 }

@@ -783,6 +783,8 @@ static bool plan_counters_seen(orx_ctx* c, int64_t kc, int64_t B, int64_t i0, co
         if (hp[8 * i + 1] > 0 || hp[8 * i + 2] > 0 || hp[8 * i + 3] > 0 || hp[8 * i + 4] > 0) quiet = false;      // staged references / tree items
     }
     c->plan_big = big > 16384;          // ([6] = the step's largest bucket, if above 8 k references)
+    c->stat_max_dup = max_dup; c->stat_pairs = 0;
+    for (int64_t i = 0; i < kc; ++i) c->stat_pairs += hp[8 * i + 7];
     if ((int64_t)max_dup * 6 > B || c->plan_big) quiet = false;      // (the in-launch apply stops paying at B / 5 duplicated rows: plan_decide)
     if (pairing_on && kc > 0 && getenv("ORX_PAIR_ALWAYS") == nullptr) {
         int64_t pairs = 0;
@@ -827,7 +829,15 @@ static int plan_stats_poll(orx_ctx* c) {
     for (int k = 0; k < 5; ++k) c->plan_stats.key[k] = c->stats_key[k];
     return ORX_OK;
 }
+extern "C" int orx_ctx_stat(orx_ctx* c, int what, int64_t* out) {
+    ORX_ARG(c && out && what >= 0 && what <= 3, "orx_ctx_stat: bad argument");
+    ORX_HIP(hipSetDevice(c->device));
+    if (c->stats_pending) { c->stats_age = 1 << 20; CHECK(plan_stats_poll(c)); }      // (wait for the counters the last call left behind)
+    *out = what == 0 ? c->stat_pairs : what == 1 ? c->stat_max_dup : what == 2 ? c->stat_nowait_calls : (int64_t)(c->plan_stats.valid && c->plan_stats.quiet);
+    return ORX_OK;
+}
 static int plan_stats_leave(orx_ctx* c, int64_t kc, int64_t B, bool pairing_on, const int64_t key[5]) {
+    c->stat_nowait_calls += 1;
     if (!c->stats_ev) ORX_HIP(hipEventCreateWithFlags(&c->stats_ev, hipEventDisableTiming));
     ORX_HIP(hipMemcpyAsync(c->h_plan, c->d_alloc, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     ORX_HIP(hipEventRecord(c->stats_ev, c->stream));
@@ -970,7 +980,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     // no read-back (see plan_stats_poll): the previous call of this shape was quiet
     const int64_t stats_key[5] = {B, U->rows, V->rows, (int64_t)model * 16 + opt->kind, (int64_t)U->dim * 4 + (want_censor ? 1 : 0) + (inline_apply ? 2 : 0)};
     CHECK(plan_stats_poll(c));
-    static const bool plan_wait = getenv("ORX_PLAN_WAIT") != nullptr || getenv("ORX_PLAN_PIPE") != nullptr || getenv("ORX_PLAN_SIDE") != nullptr;      // (experiments: always read back)
+    const bool plan_wait = getenv("ORX_PLAN_WAIT") != nullptr || getenv("ORX_PLAN_PIPE") != nullptr || getenv("ORX_PLAN_SIDE") != nullptr;      // (experiments / tests: always read back)
     bool nowait = mode == MODE_EXACT && orx_plan_v2(role_bits) && staging && !censor && opt->kind != ORX_ADAM && !plan_wait &&
                   c->plan_stats.valid && c->plan_stats.quiet;
     for (int k = 0; k < 5 && nowait; ++k) nowait = c->plan_stats.key[k] == stats_key[k];

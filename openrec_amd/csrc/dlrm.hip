@@ -967,3 +967,74 @@ extern "C" int orx_dlrm_dense_apply(orx_dlrm* m, orx_opt* opt, const float* flat
     m->grads_pending = false;
     return ORX_OK;
 }
+
+// ------------------------------------------------ the DLRM modules on plain arrays ---
+// multi_layer_perceptron.py:5-18 called on an array (not inside the composition dlrm.py:76-100, which is orx_dlrm_step /
+// orx_dlrm_inference): y = act_L(... act_1(x W_1 + b_1) ...) through the same exact-fp32 MFMA product kernel the DLRM step uses.
+// kernels[l]: table [in_l, out_l] (the Keras Dense layout); biases[l]: table [1, out_l] or NULL; acts[l]: 0 none, 1 relu, 2 sigmoid.
+extern "C" int orx_mlp_forward(orx_ctx* c, int32_t n_layers, orx_table* const* kernels, orx_table* const* biases, const int32_t* acts,
+                               const float* x, int64_t B, int32_t in_dim, int flags, float* y_out) {
+    ORX_ARG(c && kernels && acts && x && y_out && n_layers > 0 && B > 0 && in_dim > 0, "orx_mlp_forward: bad argument");
+    ORX_ARG(B < (1LL << 31), "orx_mlp_forward: batch too large");
+    ORX_HIP(hipSetDevice(c->device));
+    int64_t widest = in_dim, d = in_dim;
+    for (int l = 0; l < n_layers; ++l) {
+        ORX_ARG(kernels[l] && kernels[l]->ctx == c && kernels[l]->rows == d, "orx_mlp_forward: layer %d expects a [%lld, out] kernel", l, (long long)d);
+        ORX_ARG(!biases || !biases[l] || (biases[l]->rows == 1 && biases[l]->dim == kernels[l]->dim), "orx_mlp_forward: layer %d: bias must be [1, %d]", l, kernels[l]->dim);
+        ORX_ARG(acts[l] >= 0 && acts[l] <= 2, "orx_mlp_forward: unknown activation %d", acts[l]);
+        CHECK(orx_table_sync(kernels[l]));
+        d = kernels[l]->dim;
+        widest = std::max<int64_t>(widest, d);
+    }
+    // two ping-pong activations + (host input) the staged x
+    const size_t act_elems = (size_t)B * widest;
+    const bool dev = (flags & ORX_IDS_DEVICE) != 0;
+    if (orx_ensure((void**)&c->d_tmp, &c->d_tmp_cap, (2 * act_elems + (dev ? 0 : (size_t)B * in_dim)) * sizeof(float)) != ORX_OK) return ORX_ERR_OOM;
+    float* buf[2] = {c->d_tmp, c->d_tmp + act_elems};
+    const float* cur = x; int64_t ld = in_dim;
+    if (!dev) {
+        float* xs = c->d_tmp + 2 * act_elems;
+        ORX_HIP(hipMemcpyAsync(xs, x, (size_t)B * in_dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        cur = xs;
+    }
+    d = in_dim;
+    for (int l = 0; l < n_layers; ++l) {
+        const int out = kernels[l]->dim;
+        const bool last = l + 1 == n_layers;
+        float* y = (last && dev) ? y_out : buf[l & 1];
+        CHECK(orx_launch_gemm(c, cur, ld, 1, kernels[l]->w, out, 1, y, out, (biases && biases[l]) ? biases[l]->w : nullptr, (int)B, out, (int)d, acts[l]));
+        cur = y; ld = out; d = out;
+    }
+    if (!dev) {
+        ORX_HIP(hipMemcpyAsync(y_out, cur, (size_t)B * d * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        ORX_HIP(hipStreamSynchronize(c->stream));
+    }
+    return ORX_OK;
+}
+
+// second_order_feature_interaction.py:12-34 on plain arrays: z [B, F, d] (the F inputs stacked, :19), out [B, P] with
+// P = F (F - 1) / 2, or F (F + 1) / 2 with self_interaction -- the selected elements of Z Z^T in boolean_mask (row-major) order.
+// reference_compat != 0: the reference's text as written (lower triangle kept, strictly upper triangle selected: zeros).
+extern "C" int orx_interact_forward(orx_ctx* c, const float* z, int64_t B, int32_t F, int32_t d, int self_interaction, int reference_compat,
+                                    int flags, float* out) {
+    ORX_ARG(c && z && out && B > 0 && F > 0 && d > 0, "orx_interact_forward: bad argument");
+    ORX_HIP(hipSetDevice(c->device));
+    const int P = self_interaction ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    const int ldR = ((d + P + 3) / 4) * 4;
+    const bool dev = (flags & ORX_IDS_DEVICE) != 0;
+    const size_t zel = (size_t)B * F * d, rel = (size_t)B * ldR;
+    if (orx_ensure((void**)&c->d_tmp, &c->d_tmp_cap, (rel + (dev ? 0 : zel)) * sizeof(float)) != ORX_OK) return ORX_ERR_OOM;
+    float* R = c->d_tmp;
+    const float* Z = z;
+    if (!dev) {
+        float* zs = c->d_tmp + rel;
+        ORX_HIP(hipMemcpyAsync(zs, z, zel * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        Z = zs;
+    }
+    CHECK(orx_launch_interact(c, true, Z, nullptr, F, d, reference_compat ? 1 : 0, self_interaction ? 1 : 0, R, P, B, ldR));
+    if (P > 0)
+        ORX_HIP(hipMemcpy2DAsync(out, (size_t)P * sizeof(float), R + d, (size_t)ldR * sizeof(float), (size_t)P * sizeof(float), (size_t)B,
+                                 dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    if (!dev) ORX_HIP(hipStreamSynchronize(c->stream));
+    return ORX_OK;
+}

@@ -122,7 +122,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_part_kernel(PlanArgs a) {
                 a.d.ids_out[s * a.d.flag_stride + pos] = ok ? id : 0x7fffffff;
                 // pairing: one 16-byte record per triplet -- no reference has a partner yet (x, y, z = -1), no pairing word and the
                 // triplet is processed where it stands (w = position << 10)
-                if (a.d.pair_tpw > 1 && j < a.d.pair_stride) a.d.partner[s * a.d.pair_stride + j] = make_int4(-1, -1, -1, (int)((uint32_t)j << 10));
+                // (bit 0 of w: one of the triplet's ids is out of range -- the fused kernel skips such a triplet altogether, so it must
+                // never be the partner a valid triplet relies on: plan_pair_kernel refuses its rows)
+                if (a.d.pair_tpw > 1 && j < a.d.pair_stride) {
+                    const bool tri_ok = ok & id_ok(a.d.pid[s * a.d.id_stride + j], a.d.NI) & id_ok(a.d.nid[s * a.d.id_stride + j], a.d.NI);
+                    a.d.partner[s * a.d.pair_stride + j] = make_int4(-1, -1, -1, (int)(((uint32_t)j << 10) | (tri_ok ? 0u : 1u)));
+                }
             }
         }
     }
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(256) void plan_pair_kernel(PlanArgs a) {
         const int4 ra = part[ta], rb = part[tb];
         const int4 rl = (needq && bl < B) ? part[bl] : none, rh = (needq && bh < B) ? part[bh] : none;
         // the row is the choice of both its triplets
-        const bool mutual = (ta != tb) & (choice(ra) == sa) & (choice(rb) == sb);
+        const bool mutual = (ta != tb) & (choice(ra) == sa) & (choice(rb) == sb) & !((ra.w | rb.w) & 1);       // (bit 0: a triplet with an invalid id)
         // is a buddy in a mutual pair of its own?  its choice's partner y must choose it back
         const int cl = choice(rl), ch = choice(rh);
         const int ppl = word(rl, cl) & 0x3fffffff, pph = word(rh, ch) & 0x3fffffff;
@@ -691,10 +696,13 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
     a.min_late = ml ? atoi(ml) : d.min_late;
     // The counts and cursors of a step are zeroed again by plan_range_kernel once the scatter has used them: no memset (a launch and
     // a gap at the head of every call) unless the buffer is new or was last used with another number of ranges per step.
-    if (ctx->pl_cnt_clean != ctx->d_pl_cnt || ctx->pl_cnt_clean_cap != ctx->d_pl_cnt_cap || ctx->pl_cnt_nb != nb) {
+    if (ctx->pl_cnt_clean != ctx->d_pl_cnt || ctx->pl_cnt_clean_cap != ctx->d_pl_cnt_cap || ctx->pl_cnt_nb != nb)
         ORX_HIP(hipMemsetAsync(ctx->d_pl_cnt, 0, ctx->d_pl_cnt_cap, ctx->stream));
-        ctx->pl_cnt_clean = ctx->d_pl_cnt; ctx->pl_cnt_clean_cap = ctx->d_pl_cnt_cap; ctx->pl_cnt_nb = nb;
-    }
+    // The buffer counts as clean again only once plan_range_kernel (which re-zeroes what the scatter used) has been enqueued: any
+    // error return between here and there leaves it marked dirty, and the next plan starts with the memset (self-healing).
+    ctx->pl_cnt_clean = nullptr;
+    struct CleanMark { orx_ctx* c; int nb; bool ok = false;
+                       ~CleanMark() { if (ok) { c->pl_cnt_clean = c->d_pl_cnt; c->pl_cnt_clean_cap = c->d_pl_cnt_cap; c->pl_cnt_nb = nb; } } } clean_mark{ctx, nb};
     const dim3 gp((unsigned)((a.nref + PL_CHUNK - 1) / PL_CHUNK), (unsigned)kc);
     const size_t hist_bytes = (size_t)(3 * nb + 1) * sizeof(int);
     ORX_ONCE_PER_DEVICE(ctx, ORX_HIP(hipFuncSetAttribute((const void*)plan_part_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)));
@@ -713,6 +721,7 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
     // (a grid-stride loop over the step's list: ~0.16 B entries with uniform ids)
     if (d.pair_tpw > 1) ORX_LAUNCH(ctx, plan_pair_kernel, dim3((unsigned)std::max<int64_t>(4, (d.pair_stride / 4 + 255) / 256), (unsigned)kc), dim3(256), 0, a);
     ORX_HIP(hipGetLastError());
+    clean_mark.ok = true;
     if (a.tstamp != nullptr) {
         // stamps are in ticks of the 100 MHz constant clock
         ORX_HIP(hipStreamSynchronize(ctx->stream));

@@ -73,6 +73,7 @@ struct orx_ctx {
     // -- no range wanted a staging plan, few duplicated rows, no oversized bucket -- makes its plan with staging off, launches every step
     // without waiting for its own counters and leaves them for the next call to look at (stats_ev: their copy has arrived).
     struct { bool valid = false, quiet = false; int64_t key[5] = {0, 0, 0, 0, 0}; } plan_stats;
+    int64_t stat_pairs = 0, stat_max_dup = 0, stat_nowait_calls = 0;      // orx_ctx_stat
     hipEvent_t stats_ev = nullptr;
     bool stats_pending = false; int64_t stats_kc = 0, stats_B = 0; bool stats_pairing = false; int stats_age = 0; int64_t stats_key[5] = {0, 0, 0, 0, 0};
     // plan pipeline (api.hip): the pieces of a chunk after the first are planned on a second stream while the previous piece's

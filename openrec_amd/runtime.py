@@ -76,6 +76,12 @@ class Context:
     def prof_reset(self):
         check(self._lib.orx_prof_reset(self._h))
 
+    def stat(self, what):
+        """orx_ctx_stat: 'pairs' | 'max_dup' | 'nowait_calls' | 'quiet' of the most recent exact pairwise call's plan"""
+        v = c_int64()
+        check(self._lib.orx_ctx_stat(self._h, {"pairs": 0, "max_dup": 1, "nowait_calls": 2, "quiet": 3}[what], byref(v)))
+        return int(v.value)
+
     def prof_get(self):
         out = {}
         for kid, name in _ffi.KERNEL_NAMES.items():

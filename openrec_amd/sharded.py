@@ -471,15 +471,41 @@ class ShardedPairwise:
         self.check()
         self.sync_hot()
         self.be.save_tables(path, dict(U=self.U, V=self.V, b=self.b), (self.rank, self.world))
+        # The replicated hot rows are trained on the replica: their OPTIMIZER STATE (Adagrad accumulators, Adam m / v) lives in the
+        # replica's slots, not in the owners' shards (sync_hot moves weights only).  Every rank writes its replica -- tables and slots,
+        # identical on all ranks -- next to its shard, and a meta file says how the shard files are to be read.
+        import json
+        import os
+        trained = bool(self.hot) and self._hot_loaded
+        if trained:
+            self.be.save_tables(os.path.join(path, "hot"), dict(Vh=self.Vh, bh=self.bh), (self.rank, self.world))
+        with open(os.path.join(path, "sharded_meta.rank%dof%d.json" % (self.rank, self.world)), "w") as f:
+            json.dump(dict(hot_items=self.hot, hot_saved=trained, opt=str(self.opt_kind), world=self.world), f)
         if self.world > 1 and dist.is_initialized():
             dist.barrier(group=self.group)
 
     def load(self, path):
-        """the inverse of save(): same world size and rank layout"""
+        """the inverse of save(): same world size and rank layout -- and, unless the optimizer is stateless, the same `hot_items`
+        (the slots of the replicated rows come back with the replica, see save(); they cannot be re-sharded from here)"""
+        import json
+        import os
+        meta_fn = os.path.join(path, "sharded_meta.rank%dof%d.json" % (self.rank, self.world))
+        meta = dict(hot_items=0, hot_saved=False)               # (a checkpoint written before the meta file existed: no replicas)
+        if os.path.exists(meta_fn):
+            with open(meta_fn) as f:
+                meta.update(json.load(f))
+        saved_hot, hot_saved = int(meta["hot_items"]), bool(meta["hot_saved"])
+        if not (saved_hot == self.hot or self.opt_kind == "sgd" or (self.hot == 0 and not hot_saved)):
+            raise ValueError(f"checkpoint {path!r} was written with hot_items={saved_hot}, this engine has hot_items={self.hot}: the "
+                             f"optimizer state of replicated rows ({self.opt_kind}) is stored with the replica and is not re-sharded")
         self.be.load_tables(path, dict(U=self.U, V=self.V, b=self.b), (self.rank, self.world))
+        from_replica = bool(self.hot) and hot_saved and saved_hot == self.hot
+        if from_replica:
+            self.be.load_tables(os.path.join(path, "hot"), dict(Vh=self.Vh, bh=self.bh), (self.rank, self.world))
+            self._hot_loaded = True
         if self.world > 1 and dist.is_initialized():
             dist.barrier(group=self.group)
-        if self.hot:
+        if self.hot and not from_replica:
             self.load_hot()
 
     # ---- measurement of the library engine's exchanges (bench.py --gpus N) ----

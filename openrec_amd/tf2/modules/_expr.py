@@ -79,10 +79,10 @@ class Expr:
                                           "the host WITHOUT gradients -- evaluate it outside the GradientTape if only its values are wanted")
             op, kw = self.op, self.kw
             if op == "mlp":
-                self._host = np.asarray(self.args[0].host_forward(host(self.args[1])), np.float32)
+                self._host = np.asarray(self.args[0].device_forward(host(self.args[1])), np.float32)          # orx_mlp_forward
                 return self._host
             if op == "interact":
-                self._host = np.asarray(self.args[0].host_forward([host(x) for x in self.args[1:]]), np.float32)
+                self._host = np.asarray(self.args[0].device_forward([host(x) for x in self.args[1:]]), np.float32)      # orx_interact_forward
                 return self._host
             if op == "concat":
                 self._host = np.concatenate([np.asarray(host(x), np.float32) for x in self.args], axis=kw["axis"])

@@ -49,19 +49,25 @@ class MLP:
                     out.append(Variable(layer.bias, f"dense_{k}/bias"))
         return out
 
-    def host_forward(self, x):
-        """the stack applied to a host array (weights read back from HBM): values only, no gradients"""
-        x = np.asarray(x, np.float32)
-        self.build(x.shape[-1])
-        for layer in self.layers:
-            x = x @ layer.kernel.read()
-            if layer.bias is not None:
-                x = x + layer.bias.read()
-            if layer.activation == 'relu':
-                x = np.maximum(x, 0)
-            elif layer.activation == 'sigmoid':
-                x = 1.0 / (1.0 + np.exp(-x))
-        return x
+    def device_forward(self, x):
+        """the stack applied to a plain array ON THE DEVICE (multi_layer_perceptron.py:5-18 outside a fused composition):
+        `orx_mlp_forward` -- the exact-fp32 MFMA products of the DLRM step, bias and activation in their epilogues; the weights
+        never leave HBM.  Values only (no gradients: under a tape the caller gets the fused compositions or an error)."""
+        import ctypes
+        from ... import _ffi
+        x = np.ascontiguousarray(np.asarray(x, np.float32))
+        lead, in_dim = x.shape[:-1], x.shape[-1]
+        self.build(in_dim)
+        x2 = x.reshape(-1, in_dim)
+        n = len(self.layers)
+        ctx = self.layers[0].kernel.ctx
+        kernels = (ctypes.c_void_p * n)(*[l.kernel._h for l in self.layers])
+        biases = (ctypes.c_void_p * n)(*[(l.bias._h if l.bias is not None else None) for l in self.layers])
+        acts = (ctypes.c_int32 * n)(*[{None: 0, "linear": 0, "relu": 1, "sigmoid": 2}[l.activation] for l in self.layers])
+        out = np.empty((x2.shape[0], self.layers[-1].units), np.float32)
+        if x2.shape[0]:
+            _ffi.check(ctx._lib.orx_mlp_forward(ctx._h, n, kernels, biases, acts, x2.ctypes.data, x2.shape[0], in_dim, 0, out.ctypes.data))
+        return out.reshape(lead + (self.layers[-1].units,))
 
     def __call__(self, x):
         """A node of a lazy expression (modules/_expr.py): the compositions of the reference that contain an MLP run as fused

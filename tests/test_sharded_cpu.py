@@ -225,7 +225,58 @@ def test_sharded_checkpoint_resumes_at_world_2(tmp_path, optk):
         g = np.load(out % r)
         for k in ("U", "V", "b"):
             assert np.array_equal(g[k], g[k + "2"]), (r, k)
-    assert sorted(f for f in os.listdir(tmp_path / "ck")) == ["ref.rank0of2.pkl", "ref.rank1of2.pkl"]
+    assert sorted(f for f in os.listdir(tmp_path / "ck")) == ["ref.rank0of2.pkl", "ref.rank1of2.pkl", "sharded_meta.rank0of2.json",
+                                                                "sharded_meta.rank1of2.json"]
+
+
+def _run_rank_hot_ckpt(rank, world, port, optk, out, ckdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sharded_ref_backend import OracleBackend
+    from openrec_amd import sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    U, V, b, steps = _zipf_case("bpr", steps=4)
+    per = steps[0][0].shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)
+
+    def engine(hot=64):
+        e = sharded.ShardedPairwise("bpr", optk, U.shape[0], V.shape[0], U.shape[1], lr=0.05, rank=rank, world=world,
+                                    device=torch.device("cpu"), backend=OracleBackend(optk, 0.05), slack=3.0, hot_items=hot)
+        e.U.w[:] = U[rank::world]; e.V.w[:] = V[rank::world]; e.b.w[:] = b[rank::world]
+        return e
+    step = lambda e, k: e.step(*(torch.from_numpy(x[sl].copy()) for x in steps[k]))
+    a = engine()
+    step(a, 0); step(a, 1)
+    a.save(ckdir)
+    step(a, 2); step(a, 3)
+    a.sync_hot()
+    r = engine()                                     # a fresh engine resumes from the directory: tables AND the replicas' optimizer state
+    r.U.w[:] = 0; r.V.w[:] = 0; r.b.w[:] = 0
+    r.load(ckdir)
+    step(r, 2); step(r, 3)
+    r.sync_hot()
+    refused = False
+    try:                                             # another replica layout cannot take over the replicas' optimizer state
+        engine(hot=32).load(ckdir)
+    except ValueError:
+        refused = True
+    np.savez(out % rank, U=a.U.w, V=a.V.w, b=a.b.w, U2=r.U.w, V2=r.V.w, b2=r.b.w, refused=refused)
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("optk", ["sgd", "adagrad", "adam"])
+def test_sharded_checkpoint_with_hot_items_resumes_at_world_2(tmp_path, optk):
+    """the replicated hot rows are trained on the replica, so their Adagrad accumulators / Adam moments live in the
+    replica's slots; save() writes the replica (tables + slots) beside the shards and load() brings it back -- a resumed run
+    continues bit for bit like the uninterrupted one.  A checkpoint of another `hot_items` is refused unless the optimizer is SGD."""
+    out = str(tmp_path / "c%d.npz")
+    mp.spawn(_run_rank_hot_ckpt, args=(2, _free_port(), optk, out, str(tmp_path / "ck")), nprocs=2, join=True)
+    for r in range(2):
+        g = np.load(out % r)
+        for k in ("U", "V", "b"):
+            assert np.array_equal(g[k], g[k + "2"]), (r, k)
+        assert bool(g["refused"]) == (optk != "sgd")
 
 
 def _zipf_case(model, seed=1, NU=101, NI=400, B=96, D=16, steps=3):
