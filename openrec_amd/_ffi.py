@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_lib", "libopenrec_hip.so")
+LIB_PATH = os.environ.get("ORX_LIB_PATH") or os.path.join(HERE, "_lib", "libopenrec_hip.so")      # (ORX_LIB_PATH: A/B runs of two builds on one box)
 
 ORX_OK, ORX_ERR_ARG, ORX_ERR_HIP, ORX_ERR_OOM, ORX_ERR_INDEX, ORX_ERR_STATE = 0, -1, -2, -3, -4, -5
 ORX_SGD, ORX_ADAGRAD, ORX_ADAM = 0, 1, 2

@@ -164,6 +164,12 @@ extern "C" int orx_ctx_wait_stream(orx_ctx* c, void* producer_stream) {
     ORX_ARG(c, "orx_ctx_wait_stream: NULL context");
     if ((hipStream_t)producer_stream == c->stream) return ORX_OK;
     ORX_HIP(hipSetDevice(c->device));
+    // nothing pending on the producer's stream: whatever it produced is there already, and the context's stream need not carry a
+    // cross-stream wait (a barrier packet and its latency at the head of the next call: a few us of a K = 20 call)
+    const hipError_t q = hipStreamQuery((hipStream_t)producer_stream);
+    if (q == hipSuccess) return ORX_OK;
+    if (q != hipErrorNotReady) ORX_HIP(q);
+    (void)hipGetLastError();
     if (!c->wait_ev) ORX_HIP(hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming));
     ORX_HIP(hipEventRecord(c->wait_ev, (hipStream_t)producer_stream));
     ORX_HIP(hipStreamWaitEvent(c->stream, c->wait_ev, 0));

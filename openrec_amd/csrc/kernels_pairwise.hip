@@ -467,10 +467,14 @@ template <int LPR, int MODEL, int OPT, int MODE, bool CENSOR = false, bool STAGE
 __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
-    __shared__ f4 pair_xg[(MODE == MODE_EXACT && OPT == ORX_SGD && TPW > 1) ? 256 : 1];            // pairing: gradient exchange, one slot per lane
-    __shared__ float pair_xb[(MODE == MODE_EXACT && OPT == ORX_SGD && TPW > 1) ? 256 / LPR : 1];   // ... and per lane group (item bias)
-    __shared__ f4 pair_xw[(MODE == MODE_EXACT && OPT == ORX_SGD && TPW > 1) ? 256 : 1];            // the writer's copy of the shared row as read
-    __shared__ float pair_xwb[(MODE == MODE_EXACT && OPT == ORX_SGD && TPW > 1) ? 256 / LPR : 1];
+    // (SGD only.  Adagrad: 111 VGPRs with the pairing tail against 84 without -- a wavefront of occupancy; bounded to 96 registers
+    // (`__launch_bounds__(256, 5)`: no spills) the kernel with pairs still takes 51.5 us against 49.6 without and the step 62.1
+    // against 57.7, K = 20, one box: profiles/r5_adagrad_pairing_ab.txt -- the pair tail reads and writes the accumulator row too)
+    constexpr bool PAIRS = MODE == MODE_EXACT && OPT == ORX_SGD && TPW > 1;
+    __shared__ f4 pair_xg[PAIRS ? 256 : 1];            // pairing: gradient exchange, one slot per lane
+    __shared__ float pair_xb[PAIRS ? 256 / LPR : 1];   // ... and per lane group (item bias)
+    __shared__ f4 pair_xw[PAIRS ? 256 : 1];            // the writer's copy of the shared row as read
+    __shared__ float pair_xwb[PAIRS ? 256 / LPR : 1];
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
@@ -483,9 +487,6 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     const int64_t stride = (int64_t)(gridDim.x - nab) * 4 * TPW;
     float loss_acc = 0.0f, sq_acc = 0.0f;
 
-    // (SGD only: the Adagrad instantiation is register-bound -- 111 VGPRs with the pairing tail against 90 without, a wavefront of
-    // occupancy -- and measured no faster with pairs than without)
-    constexpr bool PAIRS = MODE == MODE_EXACT && OPT == ORX_SGD && TPW > 1;
     for (int64_t t = wave_global * TPW + grp; t < a.B; t += stride) {
         // ids as rewritten by the plan: bit 31 = "row is referenced more than once", bits 30:29 = role of this reference among the row's
         // references (0 / 1 = plain store into scratch row 1 / 2, 2 = atomics or staging slot, 3 = no store: pairing), bit 28 = urgent.
