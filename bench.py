@@ -275,6 +275,8 @@ def main():
     ap.add_argument("--shard-dedup", choices=["auto", "on", "off"], default="auto",
                     help="per-destination dedup of the sharded engine's item requests (auto: by list length vs items)")
     ap.add_argument("--zipf", type=float, default=0.0, help="item ids ~ Zipf(alpha) instead of uniform (secondary workload)")
+    ap.add_argument("--hot-items", type=int, default=0,
+                    help="sharded engine: replicate the H most popular items on every rank (SURVEY.md D.3; use with --zipf)")
     ap.add_argument("--host-ids", action="store_true",
                     help="hand the ids over as host buffers (the C ABI stages them over PCIe inside the timed call); "
                          "reported for DESIGN.md, never the headline")
@@ -366,11 +368,21 @@ def main():
         parallelism = "single-gpu"
     else:
         from openrec_amd import sharded
+        uid, pid, nid = make_ids(torch, args.users, args.items, K + W, args.batch, 1234 + rank, device, args.zipf)
+        cold = 1.0
+        if args.hot_items:
+            # the exchanged buckets are sized for the share of item references that are NOT replicated (measured on this rank's ids,
+            # the largest share of any step, plus a margin; the ranks agree on the largest)
+            per_step = ((pid >= args.hot_items).float().mean(1) + (nid >= args.hot_items).float().mean(1)) / 2
+            ct = (per_step.max() * 1.05 + 0.002).clamp(max=1.0)
+            if dist is not None:
+                dist.all_reduce(ct, op=dist.ReduceOp.MAX)
+            cold = float(ct.item())
         eng = sharded.ShardedPairwise(args.model, args.opt, args.users, args.items, args.dim, lr=lr,
                                       rank=rank, world=world, device=device, seed=0,
-                                      dedup={"auto": None, "on": True, "off": False}[args.shard_dedup])
+                                      dedup={"auto": None, "on": True, "off": False}[args.shard_dedup],
+                                      hot_items=args.hot_items, hot_cold_fraction=cold)
         eng.force_collectives = dist is not None
-        uid, pid, nid = make_ids(torch, args.users, args.items, K + W, args.batch, 1234 + rank, device)
         if W:
             w1 = W - W // 2
             eng.steps(uid[:w1], pid[:w1], nid[:w1])
@@ -446,6 +458,9 @@ def main():
                     "wire_bytes_per_step": st["wire_bytes"] / K, "self_bytes_per_step": st["self_bytes"] / K,
                     "exchanges_per_step": st["exchanges"] / K}
             sharded_extra["overflow"] = ovf
+            if args.hot_items:
+                sharded_extra["hot_items"] = {"H": args.hot_items, "cold_fraction_of_item_references": cold,
+                                              "allreduce_bytes_per_step": 2.0 * (world - 1) / world * args.hot_items * (args.dim + 4) * 4}
         except Exception as e:                              # the diagnosis must never hide the number
             sharded_extra["diagnosis_error"] = repr(e)
             prof = eng.prof()

@@ -475,6 +475,21 @@ int orx_sharded_pairwise_steps(orx_comm* comm, orx_opt* opt, int model, orx_tabl
                                const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t K, int64_t B, int64_t id_stride,
                                int64_t users_global, int64_t items_global, float margin, float slack, int32_t plan_chunk,
                                int flags, double* loss_l2_accum, int32_t* overflow);
+/* The same with HOT-ITEM REPLICATION (skewed item popularity): items 0 .. hot_items-1 of a vocabulary sorted by
+ * popularity live in the replica tables item_hot [hot_items, D] / bias_hot [hot_items, 1], identical on every rank (the caller fills
+ * them from the owners' shards before the first call and writes them back when it wants the shards current: openrec_amd/sharded.py
+ * load_hot / sync_hot).  References to those items read the local replica and put nothing on the wire; their gradients are summed
+ * per item on the rank, then over the ranks by ONE all-reduce of the [hot_items, D + 4] block per step, and every rank applies the
+ * same sums to its replica (the replicas stay identical).  Exact: TF sums the gradients of duplicate ids before the sparse apply.
+ * cold_fraction in (0, 1]: the share of a list's item references expected NOT to be hot -- the exchanged buckets (which travel
+ * whole: fixed capacities, no size exchange) are sized for that share, which is what takes the hot rows off the wire; a list with
+ * more cold references than its buckets hold sets *overflow like any other overflow.  1.0: buckets as without replication.
+ * hot_items = 0: orx_sharded_pairwise_steps.  At most 63 ranks. */
+int orx_sharded_pairwise_steps_hot(orx_comm* comm, orx_opt* opt, int model, orx_table* user, orx_table* item, orx_table* bias,
+                                   orx_table* item_hot, orx_table* bias_hot, int64_t hot_items, float cold_fraction,
+                                   const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t K, int64_t B, int64_t id_stride,
+                                   int64_t users_global, int64_t items_global, float margin, float slack, int32_t plan_chunk, int flags,
+                                   double* loss_l2_accum, int32_t* overflow);
 
 /* The hybrid-parallel DLRM step as one host call (BASELINE.json configs[4]; the single-process step: recommenders/dlrm.py:63-100 under
  * tf2_examples/dlrm_criteo.py:42-48).  `emb` is this rank's shard of the COMBINED embedding table (row r of the concatenated tables

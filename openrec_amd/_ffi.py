@@ -108,6 +108,8 @@ SIGNATURES = {
     "orx_shard_regroup": (c_int, [_p, _p, _p, c_int64, c_int32, c_int64, c_int]),
     "orx_sharded_pairwise_steps": (c_int, [_p, _p, c_int, _p, _p, _p, _ip, _ip, _ip, c_int64, c_int64, c_int64, c_int64, c_int64,
                                            c_float, c_float, c_int32, c_int, _p, _ip]),
+    "orx_sharded_pairwise_steps_hot": (c_int, [_p, _p, c_int, _p, _p, _p, _p, _p, c_int64, c_float, _ip, _ip, _ip, c_int64, c_int64, c_int64, c_int64,
+                                               c_int64, c_float, c_float, c_int32, c_int, _p, _ip]),
     "orx_sharded_dlrm_steps": (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int64, c_int64, c_float, _p, _p]),
     "orx_shard_route_steps": (c_int, [_p, _ip, _ip, _ip, c_int64, c_int64, c_int64, c_int64, c_int64, c_int32, c_int32, _ip, _ip, _ip]),
     "orx_shard_request_steps": (c_int, [_p, _ip, c_int64, c_int64, c_int32, c_int32, _ip, _ip, _ip, _ip, _ip]),

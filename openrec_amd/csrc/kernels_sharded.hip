@@ -470,20 +470,25 @@ __global__ __launch_bounds__(1024) void shard_route_kernel(RouteArgs a) {
 // 2. request the two item rows of every live triplet from their owners (rank = id % world)
 __global__ __launch_bounds__(1024) void shard_request_kernel(RequestArgs a) {
     const int64_t step = blockIdx.y;                    // K-step launch: one grid row per step
+    const int nd = a.world + (a.hot ? 1 : 0);           // destinations: the ranks, and the local replica of the hot items
     a.trip += step * a.T * 3; a.send_ids += step * (int64_t)a.world * a.cap; a.slot += step * 2 * a.T;
-    a.u_loc += step * a.T; a.counters += step * a.world;
+    a.u_loc += step * a.T; a.counters += step * nd;
+    if (a.hot) a.hot_ids += step * (int64_t)a.cap_hot;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool inb = t < a.T;
     int u = -1, p = 0, n = 0;
     if (inb) { u = a.trip[3 * t]; p = a.trip[3 * t + 1]; n = a.trip[3 * t + 2]; }
     const bool live = inb && u >= 0;
-    const int sp = claim_slot(live ? p % a.world : 0, live, a.world, a.counters);
-    const int sn = claim_slot(live ? n % a.world : 0, live, a.world, a.counters);
+    const bool hp = live && p < a.hot, hn = live && n < a.hot;
+    const int sp = claim_slot(live ? (hp ? a.world : p % a.world) : 0, live, nd, a.counters);
+    const int sn = claim_slot(live ? (hn ? a.world : n % a.world) : 0, live, nd, a.counters);
     if (!inb) return;
     int gp = -1, gn = -1;
     if (live) {
-        if (sp < a.cap) { gp = (p % a.world) * a.cap + sp; a.send_ids[gp] = p; } else *a.overflow = 1;
-        if (sn < a.cap) { gn = (n % a.world) * a.cap + sn; a.send_ids[gn] = n; } else *a.overflow = 1;
+        if (hp) { if (sp < a.cap_hot) { gp = a.world * a.cap + sp; a.hot_ids[sp] = p; } else *a.overflow = 1; }
+        else if (sp < a.cap) { gp = (p % a.world) * a.cap + sp; a.send_ids[gp] = p; } else *a.overflow = 1;
+        if (hn) { if (sn < a.cap_hot) { gn = a.world * a.cap + sn; a.hot_ids[sn] = n; } else *a.overflow = 1; }
+        else if (sn < a.cap) { gn = (n % a.world) * a.cap + sn; a.send_ids[gn] = n; } else *a.overflow = 1;
     }
     a.slot[t] = gp; a.slot[a.T + t] = gn;
     a.u_loc[t] = (live && gp >= 0 && gn >= 0) ? u / a.world : -1;
@@ -734,6 +739,27 @@ __global__ __launch_bounds__(256) void shard_grads_kernel(ShardGradArgs a) {
         float2 v; v.x = ls; v.y = 0.5f * sq;
         *reinterpret_cast<float2*>(a.partial + 2 * wave_global) = v;
     }
+}
+
+// hot-item replication: the per-item sums of this rank's gradients of the replicated rows were accumulated into the replicas' scratch
+// tables (orx_csr_accum on the plan-time sorted slot list: segmented sums in a fixed order, whatever the skew -- the head of a Zipf
+// distribution sends thousands of references to ONE row); this packs them as the [H][D + 4] block that is summed over the ranks and
+// applied (row, then the bias gradient at column D), and leaves the scratch tables all-zero again
+__global__ __launch_bounds__(256) void shard_hot_pack_kernel(float* gV, float* gb, float* hg, int64_t H, int D, int DSh) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < H * DSh; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / DSh; const int c = (int)(i % DSh);
+        float v = 0.0f;
+        if (c < D) { v = gV[r * D + c]; gV[r * D + c] = 0.0f; }
+        else if (c == D) { v = gb[r]; gb[r] = 0.0f; }
+        hg[i] = v;
+    }
+}
+
+int orx_launch_shard_hot_pack(orx_ctx* ctx, float* gV, float* gb, float* hg, int64_t H, int D, int DSh) {
+    if (H == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, shard_hot_pack_kernel, dim3((unsigned)std::min<int64_t>((H * DSh + 255) / 256, 4096)), dim3(256), 0, gV, gb, hg, H, D, DSh);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
 }
 
 int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a, int64_t K) {

@@ -535,6 +535,10 @@ struct RequestArgs {
     int* counters;           // [world], zeroed
     int* overflow;
     // K-step launch (grid.y = step): every array of step k at + k * (its per-step size)
+    // hot-item replication (0: off): items 0 .. hot-1 live in a replica on every rank -- their references ask nobody.
+    // They take slots world * cap .. world * cap + cap_hot - 1 (the region BEHIND the exchanged buckets in the row / gradient buffers)
+    // and leave their ids in hot_ids [cap_hot] (pre-filled with -1); counters then has world + 1 entries per step
+    int hot; int cap_hot; int32_t* hot_ids;
 };
 
 struct ShardGradArgs {
@@ -583,6 +587,7 @@ int orx_launch_shard_segsum(orx_ctx* ctx, const int2* seglist, const int* segcou
                             float* send_g, int DS, int D, float* gb_out);
 int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a, int64_t K = 1);
 int orx_launch_shard_request(orx_ctx* ctx, const RequestArgs& a, int64_t K = 1);
+int orx_launch_shard_hot_pack(orx_ctx* ctx, float* gV, float* gb, float* hg, int64_t H, int D, int DSh);      // hot-item replication: scratch sums -> [H][D + 4] block
 int orx_launch_shard_bucket(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int cap, int32_t* send_ids, int32_t* slot,
                             int* counters, int* overflow);
 int orx_launch_shard_localize(orx_ctx* ctx, const int32_t* ids, int64_t n, int world, int32_t* out);

@@ -106,6 +106,7 @@ struct orx_comm {
     // the engine's exchange buffers (grown on demand, kept between calls)
     Buf dl_send, dl_slot, dl_req, dl_reqloc, dl_rows_out, dl_rows_in, dl_send_g, dl_g_in, dl_idx, dl_ids, dl_flat, dl_sum, dl_cnt, dl_ptrs;     // hybrid-parallel DLRM engine
     Buf send1, mine, tmp, cnt, send2, req, req_loc, slot, u_loc, fu, fv, rows_out, rows_in, gu, u_apply, send_g, g_in, dupref, dsorted, seglist, segcount, gdup, bias_x, partials;
+    Buf hot_ids, hot_g, hot_arange, hot_sorted; int64_t hot_arange_n = -1;        // hot-item replication: slot ids [L][2T], the [hot, D + 4] gradient block, 0 .. hot-1
 };
 
 static int ensure(orx_comm* c, Buf& b, size_t bytes) {
@@ -242,7 +243,9 @@ extern "C" int orx_comm_destroy(orx_comm* c) {
     if (c->xstream) hipStreamDestroy(c->xstream);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     for (Buf* b : {&c->send1, &c->mine, &c->tmp, &c->cnt, &c->send2, &c->req, &c->req_loc, &c->slot, &c->u_loc, &c->fu, &c->fv,
-                   &c->rows_out, &c->rows_in, &c->gu, &c->u_apply, &c->send_g, &c->g_in, &c->dupref, &c->dsorted, &c->seglist, &c->segcount, &c->gdup, &c->bias_x})
+                   &c->rows_out, &c->rows_in, &c->gu, &c->u_apply, &c->send_g, &c->g_in, &c->dupref, &c->dsorted, &c->seglist, &c->segcount, &c->gdup, &c->bias_x,
+                   &c->partials, &c->hot_ids, &c->hot_g, &c->hot_arange, &c->hot_sorted, &c->dl_send, &c->dl_slot, &c->dl_req, &c->dl_reqloc, &c->dl_rows_out, &c->dl_rows_in,
+                   &c->dl_send_g, &c->dl_g_in, &c->dl_idx, &c->dl_ids, &c->dl_flat, &c->dl_sum, &c->dl_cnt, &c->dl_ptrs})
         if (b->p) hipFree(b->p);
     delete c;
     return ORX_OK;
@@ -364,11 +367,24 @@ extern "C" int orx_sharded_caps(int64_t B, int32_t world, float slack, int64_t* 
     return ORX_OK;
 }
 
-extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, orx_table* U, orx_table* V, orx_table* b,
-                                          const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t K, int64_t B,
-                                          int64_t id_stride, int64_t users_global, int64_t items_global, float margin, float slack,
-                                          int32_t plan_chunk, int flags, double* loss_l2_accum, int32_t* overflow) {
+static int all_reduce(orx_comm* c, float* x, int64_t n, Buf& tmp, Buf& ptrs);
+
+// hot > 0: HOT-ITEM REPLICATION.  Items 0 .. hot-1 (a vocabulary sorted by popularity) live in the replica tables
+// Vh [hot, D] / bh [hot, 1], identical on every rank.  Their references ask nobody: the request plan gives them slots in a region
+// BEHIND the exchanged buckets of the row / gradient buffers, the rows come from the local replica, the gradient kernel reads and
+// writes that region like any other slot; the step's gradients of the replicated rows are summed per item (segmented sums over the plan-time sorted slots: orx_csr_accum),
+// then over the ranks by ONE all-reduce of the [hot, D + 4] block, and every rank applies the same sums to its replica.  Exact in
+// TF's sense: duplicate ids are summed before the sparse apply, and a sum over ranks of per-rank sums is such a sum.
+static int sharded_pairwise_impl(orx_comm* c, orx_opt* opt, int model, orx_table* U, orx_table* V, orx_table* b, orx_table* Vh, orx_table* bh,
+                                 int64_t hot, float cold_fraction, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t K, int64_t B,
+                                 int64_t id_stride, int64_t users_global, int64_t items_global, float margin, float slack,
+                                 int32_t plan_chunk, int flags, double* loss_l2_accum, int32_t* overflow) {
     ORX_ARG(c && opt && U && V && b && uid && pid && nid && loss_l2_accum && overflow, "orx_sharded_pairwise_steps: NULL argument");
+    ORX_ARG(hot >= 0 && hot <= items_global && hot < (1LL << 30), "orx_sharded_pairwise_steps: hot_items out of range");
+    ORX_ARG(hot == 0 || (Vh && bh && Vh->ctx == c->ctx && bh->ctx == c->ctx && Vh->rows >= hot && bh->rows >= hot && Vh->dim == V->dim && bh->dim == 1),
+            "orx_sharded_pairwise_steps: the replicas must be tables [hot_items, D] and [hot_items, 1] on the communicator's context");
+    ORX_ARG(hot == 0 || c->world < 64, "orx_sharded_pairwise_steps: hot-item replication takes at most 63 ranks");
+    ORX_ARG(hot == 0 || (cold_fraction > 0.f && cold_fraction <= 1.f), "orx_sharded_pairwise_steps: cold_fraction must be in (0, 1]");
     ORX_ARG(model == ORX_BPR || model == ORX_UCML, "orx_sharded_pairwise_steps: unknown model %d", model);
     ORX_ARG(K >= 0 && B > 0 && id_stride >= B && plan_chunk >= 1 && slack >= 1.0f, "orx_sharded_pairwise_steps: bad sizes");
     ORX_ARG(U->dim == V->dim && b->dim == 1 && b->rows == V->rows, "orx_sharded_pairwise_steps: table shapes do not match");
@@ -389,9 +405,17 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
     // Per-destination dedup (an item several references of a list ask for travels once) costs a sort and an un-sort of the
     // references at plan time (~25 us per step at 131 k references): on by default where the item references a rank handles per list (2 B) are at least
     // half as many as the items (then most slots are shared), off for sparse lists (1 M items: 6 % of the references repeat)
-    const bool dedup = (flags & ORX_SHARD_DEDUP) ? true : (flags & ORX_SHARD_NO_DEDUP) ? false : (4 * (B / H) >= items_global);
+    // (replication: the request plan with the replica as an extra destination is the one without dedup -- what is left for the wire
+    // after the head of the distribution stayed at home repeats little)
+    const bool dedup = hot ? false : (flags & ORX_SHARD_DEDUP) ? true : (flags & ORX_SHARD_NO_DEDUP) ? false : (4 * (B / H) >= items_global);
     const int64_t Bh = B / H;
-    const int64_t cap1 = bucket_cap(Bh, N, slack), T = N * cap1, cap2 = bucket_cap(2 * T, N, slack), M = N * cap2;
+    // (replication: the exchanged buckets are sized for the COLD share of a list's item references -- that is what takes the hot rows
+    // off the wire, the buckets travel whole; a list with more cold references than that overflows and is reported as usual)
+    const int64_t cap1 = bucket_cap(Bh, N, slack), T = N * cap1;
+    const int64_t cap2 = bucket_cap(hot ? (int64_t)std::ceil(2.0 * (double)T * cold_fraction) : 2 * T, N, slack), M = N * cap2;
+    const int64_t capH = hot ? 2 * T : 0;                 // every item reference of a list may be a hot one
+    const int64_t Mx = M + capH;                          // rows of a list's row / gradient buffers: the buckets, then the replica's region
+    const int DSh = U->dim + 4;
     // SGD: the biases travel apart from the rows (D + 1 floats per requested row on the wire; the rows stay 16-byte aligned);
     // Adagrad / Adam (whose applies take row + bias gradient as one row): row + bias column, D + 4 floats
     const bool split = opt->kind == ORX_SGD;
@@ -399,7 +423,8 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
     const int64_t B_global = B * N;
     const bool sgd = opt->kind == ORX_SGD;
     const int gflags = flags & ORX_NO_L2;
-    orx_table* tabs[3] = {U, V, b};
+    orx_table* tabs[5] = {U, V, b, Vh, bh};
+    const int ntabs = hot ? 5 : 3;
     if (H == 2 && !c->xstream) {
         ORX_HIP(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
         for (hipEvent_t& e : c->ev) ORX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -412,17 +437,31 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
         // synchronisation, hipFree and hipMalloc each -- inside a longer call is paid in that call)
         const size_t Lr = (size_t)plan_chunk * H;
         CHECK(ensure(c, c->send1, Lr * T * 3 * 4)); CHECK(ensure(c, c->mine, Lr * T * 3 * 4));
-        CHECK(ensure(c, c->cnt, Lr * N * 4));
+        CHECK(ensure(c, c->cnt, Lr * (N + 1) * 4));
         CHECK(ensure(c, c->send2, Lr * M * 4)); CHECK(ensure(c, c->req, Lr * M * 4)); CHECK(ensure(c, c->req_loc, Lr * M * 4));
         CHECK(ensure(c, c->slot, Lr * 2 * T * 4)); CHECK(ensure(c, c->u_loc, Lr * T * 4));
-        CHECK(ensure(c, c->rows_out, (size_t)H * M * DS * 4)); CHECK(ensure(c, c->rows_in, (size_t)H * M * DS * 4));
-        CHECK(ensure(c, c->send_g, (size_t)H * M * DS * 4)); CHECK(ensure(c, c->g_in, (size_t)H * M * DS * 4));
+        CHECK(ensure(c, c->rows_out, (size_t)H * Mx * DS * 4)); CHECK(ensure(c, c->rows_in, (size_t)H * Mx * DS * 4));
+        CHECK(ensure(c, c->send_g, (size_t)H * Mx * DS * 4)); CHECK(ensure(c, c->g_in, (size_t)H * M * DS * 4));
+        if (hot) {
+            CHECK(ensure(c, c->hot_ids, Lr * (size_t)capH * 4)); CHECK(ensure(c, c->hot_g, (size_t)hot * DSh * 4));
+            CHECK(ensure(c, c->hot_sorted, Lr * (size_t)capH * 8));
+            CHECK(orx_rows_sort_reserve(ctx, (int64_t)Lr, capH, hot));
+            CHECK(orx_table_scratch(Vh)); CHECK(orx_table_scratch(bh));
+            if (c->hot_arange_n != hot) {                 // 0 .. hot-1: the id list of the replica's apply
+                CHECK(ensure(c, c->hot_arange, (size_t)hot * 4));
+                std::vector<int32_t> ar((size_t)hot);
+                for (int64_t i = 0; i < hot; ++i) ar[(size_t)i] = (int32_t)i;
+                ORX_HIP(hipMemcpyAsync(c->hot_arange.p, ar.data(), (size_t)hot * 4, hipMemcpyHostToDevice, ctx->stream));
+                ORX_HIP(hipStreamSynchronize(ctx->stream));
+                c->hot_arange_n = hot;
+            }
+        }
         CHECK(ensure(c, c->gu, (size_t)H * T * D * 4)); CHECK(ensure(c, c->u_apply, (size_t)H * T * 4));
         const int nw_list = orx_shard_grads_nwaves(D, T);             // the loss partials of every list of a chunk: ONE accumulate launch per chunk
         ORX_ARG(nw_list > 0, "sharded engine: dim must be 16/32/64/128/256 (got %d)", D);
         CHECK(ensure(c, c->partials, Lr * (size_t)nw_list * 2 * 4));
         int nw_now = 0;
-        if (split) CHECK(ensure(c, c->bias_x, (size_t)4 * H * M * 4));          // biases out | in | bias gradients out | in, [H][M] each
+        if (split) CHECK(ensure(c, c->bias_x, (size_t)4 * H * Mx * 4));         // biases out | in | bias gradients out | in, [H][Mx] each
         if (sgd) {
             CHECK(ensure(c, c->fu, Lr * T)); CHECK(ensure(c, c->fv, Lr * M));
             // (the context's own scratch of orx_rows_dupflags, for a whole chunk as well)
@@ -447,6 +486,22 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
         unsigned char* dupref = dedup ? (unsigned char*)c->dupref.p : nullptr;
         if (dedup) CHECK(orx_shard_request_dedup_steps(ctx, (const int32_t*)mine, L, T, N, (int32_t)cap2, items_global, send2, slot, u_loc, dupref,
                                                        c->dsorted.p, c->seglist.p, (int32_t*)c->segcount.p, overflow));
+        else if (hot) {
+            int32_t* hot_ids = (int32_t*)c->hot_ids.p;
+            ORX_HIP(hipMemsetAsync(send2, 0xFF, (size_t)L * M * 4, S));
+            ORX_HIP(hipMemsetAsync(hot_ids, 0xFF, (size_t)L * capH * 4, S));
+            ORX_HIP(hipMemsetAsync(cnt, 0, (size_t)L * (N + 1) * 4, S));
+            RequestArgs ra;
+            memset(&ra, 0, sizeof(ra));
+            ra.trip = (const int32_t*)mine; ra.T = T; ra.world = N; ra.cap = (int)cap2; ra.send_ids = send2; ra.slot = slot; ra.u_loc = u_loc;
+            ra.counters = cnt; ra.overflow = overflow; ra.hot = (int)hot; ra.cap_hot = (int)capH; ra.hot_ids = hot_ids;
+            CHECK(orx_launch_shard_request(ctx, ra, L));
+            // the slots of every list sorted by item (stable in the slot index), once per plan: the per-item gradient sums of the steps
+            // are then segmented sums over this order -- no atomics, the same sums in every run
+            const uint2* hs = nullptr;
+            CHECK(orx_rows_sort(ctx, hot_ids, L, capH, capH, hot, &hs));
+            ORX_HIP(hipMemcpyAsync(c->hot_sorted.p, hs, (size_t)L * capH * sizeof(uint2), hipMemcpyDeviceToDevice, S));
+        }
         else CHECK(orx_shard_request_steps(ctx, (const int32_t*)mine, L, T, N, (int32_t)cap2, send2, slot, u_loc, cnt, overflow));
         const void* req = nullptr;
         CHECK(exchange_steps(c, send2, c->req.p, c->tmp, L, cap2, &req));                          // 2. item ids -> item owner
@@ -463,23 +518,33 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
             float* bx = (float*)c->bias_x.p;                 // [4][H][M]
             for (int h = 0; h < H; ++h) {                  // 3. owners gather row + bias, the rows travel back
                 const int l = k * H + h;
-                float* ro = (float*)c->rows_out.p + (size_t)h * M * DS;
+                float* ro = (float*)c->rows_out.p + (size_t)h * Mx * DS;
                 const int32_t* rl = req_loc + (size_t)l * M;
                 if (split) {
                     CHECK(orx_table_touch(V, rl, M)); CHECK(orx_table_touch(b, rl, M));
-                    CHECK(orx_launch_gather(ctx, V->w, b->w, V->rows, D, rl, M, ro, DS, ctx->d_err, 1, bx + (size_t)h * M));
+                    CHECK(orx_launch_gather(ctx, V->w, b->w, V->rows, D, rl, M, ro, DS, ctx->d_err, 1, bx + (size_t)h * Mx));
                 } else CHECK(orx_gather_rows(ctx, V, b, rl, M, ro, DS));
                 if (H == 2) { ORX_HIP(hipEventRecord(c->ev[h], S)); ORX_HIP(hipStreamWaitEvent(X, c->ev[h], 0)); }
-                if (split) CHECK(exchange(c, ro, (float*)c->rows_in.p + (size_t)h * M * DS, (size_t)cap2 * DS * 4, &rows_in[h], X,
-                                          bx + (size_t)h * M, bx + (size_t)(H + h) * M, (size_t)cap2 * 4, &b_in[h]));
-                else CHECK(exchange(c, ro, (float*)c->rows_in.p + (size_t)h * M * DS, (size_t)cap2 * DS * 4, &rows_in[h], X));
+                if (split) CHECK(exchange(c, ro, (float*)c->rows_in.p + (size_t)h * Mx * DS, (size_t)cap2 * DS * 4, &rows_in[h], X,
+                                          bx + (size_t)h * Mx, bx + (size_t)(H + h) * Mx, (size_t)cap2 * 4, &b_in[h]));
+                else CHECK(exchange(c, ro, (float*)c->rows_in.p + (size_t)h * Mx * DS, (size_t)cap2 * DS * 4, &rows_in[h], X));
                 if (H == 2) ORX_HIP(hipEventRecord(c->ev[2 + h], X));
+                if (hot) {
+                    // the references to replicated items read the local replica: its rows (and biases) go into the region behind the
+                    // buckets of the buffer the gradient kernel will read (the exchange's receive buffer, or -- one rank without RCCL:
+                    // the exchange is the identity -- the gather's own output); on the step stream, beside the exchange
+                    const int32_t* hi = (const int32_t*)c->hot_ids.p + (size_t)l * capH;
+                    float* dst = const_cast<float*>((const float*)rows_in[h]) + (size_t)M * DS;
+                    CHECK(orx_table_touch(Vh, hi, capH)); CHECK(orx_table_touch(bh, hi, capH));
+                    if (split) CHECK(orx_launch_gather(ctx, Vh->w, bh->w, Vh->rows, D, hi, capH, dst, DS, ctx->d_err, 1, const_cast<float*>((const float*)b_in[h]) + M));
+                    else CHECK(orx_gather_rows(ctx, Vh, bh, hi, capH, dst, DS));
+                }
             }
             for (int h = 0; h < H; ++h) {                  // 4. gradients (+ SGD's apply of the user rows referenced once); 6. item gradients leave
                 const int l = k * H + h;
                 const int32_t* ul = u_loc + (size_t)l * T; const int32_t* sl = slot + (size_t)l * 2 * T;
-                float* gu = (float*)c->gu.p + (size_t)h * T * D; float* sg = (float*)c->send_g.p + (size_t)h * M * DS;
-                float* gbo = split ? bx + (size_t)(2 * H + h) * M : nullptr;
+                float* gu = (float*)c->gu.p + (size_t)h * T * D; float* sg = (float*)c->send_g.p + (size_t)h * Mx * DS;
+                float* gbo = split ? bx + (size_t)(2 * H + h) * Mx : nullptr;
                 const unsigned char* dr = dedup ? dupref + (size_t)l * 2 * T : nullptr;
                 const void* so = dedup ? (const char*)c->dsorted.p + (size_t)l * 2 * T * 8 : nullptr;
                 const void* sgl = dedup ? (const char*)c->seglist.p + (size_t)l * T * 8 : nullptr;
@@ -493,11 +558,11 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
                 ORX_ARG(nw_now == nw_list, "sharded engine: the gradient launch wrote %d loss partials, %d were expected", nw_now, nw_list);
                 if (H == 2) { ORX_HIP(hipEventRecord(c->ev[4 + h], S)); ORX_HIP(hipStreamWaitEvent(X, c->ev[4 + h], 0)); }
                 if (split) CHECK(exchange(c, sg, (float*)c->g_in.p + (size_t)h * M * DS, (size_t)cap2 * DS * 4, &g_in[h], X,
-                                          gbo, bx + (size_t)(3 * H + h) * M, (size_t)cap2 * 4, &gb_in[h]));
+                                          gbo, bx + (size_t)(3 * H + h) * Mx, (size_t)cap2 * 4, &gb_in[h]));
                 else CHECK(exchange(c, sg, (float*)c->g_in.p + (size_t)h * M * DS, (size_t)cap2 * DS * 4, &g_in[h], X));
                 if (H == 2) ORX_HIP(hipEventRecord(c->ev[6 + h], X));
             }
-            if (opt->kind == ORX_ADAM) CHECK(orx_opt_advance(opt, tabs, 3));   // Keras `iterations` += 1: after the step's gathers, before its applies
+            if (opt->kind == ORX_ADAM) CHECK(orx_opt_advance(opt, tabs, ntabs));   // Keras `iterations` += 1: after the step's gathers, before its applies
             if (sgd) {                                     // 5. user rows are local: the duplicated ones, half by half
                 for (int h = 0; h < H; ++h)
                     CHECK(orx_apply_rows_flagged(ctx, opt, U, nullptr, (int32_t*)c->u_apply.p + (size_t)h * T, T, (float*)c->gu.p + (size_t)h * T * D, D,
@@ -513,12 +578,44 @@ extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, 
                 const float* g = H == 2 ? (const float*)c->g_in.p : (const float*)g_in[0];
                 CHECK(orx_apply_rows(ctx, opt, V, b, req_loc + (size_t)k * H * M, H * M, g, DS));
             }
+            if (hot) {
+                // the replicated rows: this rank's gradients summed per item (both halves), ONE all-reduce of the block, the same apply on
+                // every replica (a row nobody referenced carries a zero gradient: SGD / Adagrad leave it alone, TF-2.0 Adam decays it
+                // like every other row)
+                for (int h = 0; h < H; ++h) {
+                    const uint2* hs = (const uint2*)c->hot_sorted.p + (size_t)(k * H + h) * capH;
+                    const float* gr = (const float*)c->send_g.p + ((size_t)h * Mx + M) * DS;
+                    CHECK(orx_csr_accum(ctx, Vh, hs, capH, gr, DS));
+                    if (split) CHECK(orx_csr_accum(ctx, bh, hs, capH, bx + (size_t)(2 * H + h) * Mx + M, 1));
+                    else CHECK(orx_csr_accum(ctx, bh, hs, capH, gr + D, DS));
+                }
+                CHECK(orx_launch_shard_hot_pack(ctx, Vh->gsum, bh->gsum, (float*)c->hot_g.p, hot, D, DSh));
+                CHECK(all_reduce(c, (float*)c->hot_g.p, hot * DSh, c->dl_sum, c->dl_ptrs));
+                CHECK(orx_apply_rows(ctx, opt, Vh, bh, (const int32_t*)c->hot_arange.p, hot, (const float*)c->hot_g.p, DSh));
+            }
         }
         CHECK(orx_launch_loss_accumulate(ctx, (const float*)c->partials.p, (int64_t)L * nw_list, loss_l2_accum));
     }
     return ORX_OK;
 }
 
+
+extern "C" int orx_sharded_pairwise_steps(orx_comm* c, orx_opt* opt, int model, orx_table* U, orx_table* V, orx_table* b,
+                                          const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t K, int64_t B,
+                                          int64_t id_stride, int64_t users_global, int64_t items_global, float margin, float slack,
+                                          int32_t plan_chunk, int flags, double* loss_l2_accum, int32_t* overflow) {
+    return sharded_pairwise_impl(c, opt, model, U, V, b, nullptr, nullptr, 0, 1.0f, uid, pid, nid, K, B, id_stride, users_global, items_global, margin, slack,
+                                 plan_chunk, flags, loss_l2_accum, overflow);
+}
+
+extern "C" int orx_sharded_pairwise_steps_hot(orx_comm* c, orx_opt* opt, int model, orx_table* U, orx_table* V, orx_table* b,
+                                              orx_table* Vh, orx_table* bh, int64_t hot_items, float cold_fraction,
+                                              const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t K, int64_t B,
+                                              int64_t id_stride, int64_t users_global, int64_t items_global, float margin, float slack,
+                                              int32_t plan_chunk, int flags, double* loss_l2_accum, int32_t* overflow) {
+    return sharded_pairwise_impl(c, opt, model, U, V, b, Vh, bh, hot_items, cold_fraction, uid, pid, nid, K, B, id_stride, users_global, items_global, margin, slack,
+                                 plan_chunk, flags, loss_l2_accum, overflow);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // The hybrid-parallel DLRM step inside the library (the single-process step it shards: recommenders/dlrm.py:63-100

@@ -243,12 +243,21 @@ class HipBackend:
     def make_comm(self, rank, world, group=None, rccl=None, vgroup=None):
         return make_comm(self, rank, world, group, rccl, vgroup)
 
-    def sharded_steps(self, comm, model, U, V, b, uid, pid, nid, n_users, n_items, margin, slack, plan_chunk, overlap, accum, ovf, dedup=True):
+    def sharded_steps(self, comm, model, U, V, b, uid, pid, nid, n_users, n_items, margin, slack, plan_chunk, overlap, accum, ovf, dedup=True,
+                      hot=None):
+        """hot = (hot_items, Vh, bh): the K steps with the replicated hot items (orx_sharded_pairwise_steps_hot)"""
         mid = {"bpr": self._ffi.ORX_BPR, "ucml": self._ffi.ORX_UCML}[model]
         K, B = uid.shape
         assert uid.stride(1) == 1 and pid.stride() == uid.stride() and nid.stride() == uid.stride()
         flags = (self._ffi.ORX_SHARD_OVERLAP if overlap else 0) | \
             (0 if dedup is None else (self._ffi.ORX_SHARD_DEDUP if dedup else self._ffi.ORX_SHARD_NO_DEDUP))
+        if hot is not None and hot[0] > 0:
+            H, Vh, bh, cold = hot
+            self._ffi.check(self.lib.orx_sharded_pairwise_steps_hot(comm, self.opt._h, mid, U._h, V._h, b._h, Vh._h, bh._h, int(H), float(cold),
+                                                                    uid.data_ptr(), pid.data_ptr(), nid.data_ptr(), K, B, uid.stride(0),
+                                                                    n_users, n_items, margin, slack, plan_chunk, flags, accum.data_ptr(),
+                                                                    ovf.data_ptr()))
+            return
         self._ffi.check(self.lib.orx_sharded_pairwise_steps(comm, self.opt._h, mid, U._h, V._h, b._h, uid.data_ptr(), pid.data_ptr(),
                                                             nid.data_ptr(), K, B, uid.stride(0), n_users, n_items, margin, slack,
                                                             plan_chunk, flags, accum.data_ptr(), ovf.data_ptr()))
@@ -266,7 +275,7 @@ class HipBackend:
 class ShardedPairwise:
     def __init__(self, model, opt, n_users, n_items, dim, lr, rank, world, device, seed=0, margin=0.5,
                  backend=None, slack=1.05, opt_kw=None, group=None, a2a_fn=None, fast=None, engine=None, dedup=None, vgroup=None,
-                 hot_items=0, allreduce_fn=None):
+                 hot_items=0, allreduce_fn=None, hot_cold_fraction=1.0):
         assert model in ("bpr", "ucml")
         self.model, self.dim, self.margin = model, dim, margin
         self.rank, self.world, self.device, self.group = rank, world, device, group
@@ -304,10 +313,16 @@ class ShardedPairwise:
         # Per-phase path only (the K-step engines fall back to it); exact: TF sums the gradients of duplicate ids before the
         # sparse apply and a sum over ranks of per-rank sums is such a sum.
         self.hot = int(min(max(hot_items, 0), n_items))
+        # the library's engine sizes the exchanged buckets for this share of a list's item references (those that are NOT hot): the
+        # buckets travel whole, so this is what takes the hot rows off the wire; more cold references than that -> check() raises
+        self.hot_cold_fraction = float(hot_cold_fraction)
         self.allreduce_fn = allreduce_fn
         if self.hot:
-            self.fast = False                             # (the device-side plans do not know about replicas)
-            self._ovf = None
+            # (the per-phase device plans do not know about replicas; the library's K-step engine does: orx_sharded_pairwise_steps_hot)
+            self._fast_hot = bool(self.fast) and hasattr(self.be, "sharded_steps") and world < 64
+            self.fast = False
+            if not self._fast_hot:
+                self._ovf = None
             self.Vh = self.be.make_table(self.hot, dim, seed * 3 + 7)
             self.bh = self.be.make_table(self.hot, 1, seed * 3 + 8)
             self._hot_loaded = False
@@ -371,7 +386,7 @@ class ShardedPairwise:
         import os
         if self.engine is None and os.environ.get("ORX_SHARD_ENGINE") == "python":
             self.engine = "python"
-        if self.engine == "python" or self.a2a_fn is not None or not hasattr(self.be, "sharded_steps") or self.hot:
+        if self.engine == "python" or self.a2a_fn is not None or not hasattr(self.be, "sharded_steps") or (self.hot and not getattr(self, "_fast_hot", False)):
             return False
         if self._comm is None and self.vgroup is not None:
             self._comm = self.be.make_comm(self.rank, self.world, vgroup=self.vgroup)
@@ -541,6 +556,16 @@ class ShardedPairwise:
         the per-step dependency chain is then gather -> all-to-all (rows) -> gradients -> all-to-all (gradients)
         -> apply: two collectives per step instead of four."""
         K = uid.shape[0]
+        if self.hot and getattr(self, "_fast_hot", False) and self._library_engine():
+            # replicated hot items inside the library's K-step engine: the replicas are filled once, the engine keeps them identical
+            if not self._hot_loaded:
+                self.load_hot()
+            ov = (self.world > 1 or self.force_collectives) if overlap is None else bool(overlap)
+            with self.be.stream_ctx():
+                self.be.sharded_steps(self._comm, self.model, self.U, self.V, self.b, uid, pid, nid, self.n_users, self.n_items,
+                                      self.margin, self.slack, plan_chunk, ov, self.accum, self._ovf, dedup=False,
+                                      hot=(self.hot, self.Vh, self.bh, self.hot_cold_fraction))
+            return None
         if not self.fast:
             for k in range(K):
                 self.step(uid[k], pid[k], nid[k])

@@ -156,3 +156,125 @@ def test_library_engine_with_virtual_ranks(world, model, optk, overlap, dedup):
     engs.clear()
     import gc; gc.collect()
     lib.orx_vgroup_destroy(vg)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("model,optk", [("bpr", "sgd"), ("bpr", "adagrad"), ("ucml", "sgd"), ("bpr", "adam")])
+@pytest.mark.parametrize("overlap", [False, True])
+def test_library_engine_replicates_hot_items(world, model, optk, overlap):
+    """orx_sharded_pairwise_steps_hot: with Zipf(1.05) item ids the H most popular items are
+    replicated on every rank -- their references read the local replica, ask nobody and send nothing; their gradients are summed
+    per item, then over the ranks by ONE all-reduce per step, and applied to every replica alike.  Virtual ranks in threads of this
+    process (world > 1) or a one-rank communicator, against the single-process oracle on the global batch; the replicas of all
+    ranks must be bit-identical, and the item rows that still travel must be far fewer than without replication."""
+    import threading
+    import torch
+    from openrec_amd import sharded, _ffi
+    from oracle import numpy_oracle as orc
+    torch.cuda.init()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    NU, NI, D, Bg, K, H = 1001, 1503, 64, 4096, 5, 128
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    w = 1.0 / np.arange(1, NI + 1) ** 1.05
+    cdf = np.cumsum(w / w.sum())
+    draw = lambda: np.minimum(np.searchsorted(cdf, rng.random((K, Bg))), NI - 1).astype(np.int32)
+    uid = rng.integers(0, NU, (K, Bg)).astype(np.int32); pid, nid = draw(), draw()
+    share = float(((pid < H).sum() + (nid < H).sum()) / (2 * K * Bg))
+    assert share > 0.5                                                  # most item references are hot
+    lib = _ffi.load()
+    vg = ctypes.c_void_p()
+    if world > 1:
+        _ffi.check(lib.orx_vgroup_create(world, ctypes.byref(vg)))
+    # (lr * references of the hottest row < 1: SGD's l2 term moves a row referenced c times by lr * c * row per step)
+    lr = 0.002 if optk == "adam" else 0.0005
+    engs, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            e = sharded.ShardedPairwise(model, optk, NU, NI, D, lr=lr, rank=rank, world=world, device=dev, slack=3.0, hot_items=H,
+                                        vgroup=vg if world > 1 else None)
+            e.U.write(U[rank::world]); e.V.write(V[rank::world]); e.b.write(b[rank::world])
+            e.Vh.write(V[:H]); e.bh.write(b[:H]); e._hot_loaded = True     # (load_hot() is a torch.distributed collective: not among threads)
+            engs[rank] = e
+            per = Bg // world
+            sl = slice(rank * per, (rank + 1) * per)
+            tu, tp, tn = (torch.from_numpy(np.ascontiguousarray(x[:, sl])).to(dev) for x in (uid, pid, nid))
+            torch.cuda.synchronize()
+            if world > 1:
+                e.steps(tu, tp, tn, plan_chunk=2, overlap=overlap)
+            else:
+                e.steps(tu, tp, tn, plan_chunk=2)
+            assert e._comm is not None and e._fast_hot                  # the K-step call ran inside the library, replicas and all
+            e.be.stream.synchronize()
+        except Exception as ex:                                         # pragma: no cover
+            errs.append(ex)
+            if world > 1:
+                lib.orx_vgroup_abort(vg)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    oo = {"sgd": lambda: orc.SGD(lr), "adagrad": lambda: orc.Adagrad(lr, 0.1, 1e-7), "adam": lambda: orc.AdamTFSparse(lr)}[optk]()
+    step = orc.bpr_step if model == "bpr" else (lambda *a: orc.ucml_step(*a, do_censor=False))
+    Uo, Vo, bo = U.astype(np.float64), V.astype(np.float64), b.astype(np.float64)      # (the hottest rows sum ~1000 gradients per step)
+    tl = sum(float(step(Uo, Vo, bo, uid[s], pid[s], nid[s], oo)[0]) for s in range(K))
+    got = 0.0
+    tol = 5e-5 if optk == "adam" else 1e-5
+    vh0, bh0 = engs[0].Vh.read(), engs[0].bh.read()
+    for r, e in enumerate(engs):
+        assert int(e._ovf[0]) == 0
+        assert np.array_equal(e.Vh.read(), vh0) and np.array_equal(e.bh.read(), bh0), "replicas diverged"
+        e.sync_hot()                                                    # the trained hot rows go back into the owners' shards
+        for have, want, nm in ((e.U.read(), Uo, "U"), (e.V.read(), Vo, "V"), (e.b.read(), bo, "b")):
+            assert rel_err(have[:len(want[r::world])], want[r::world]) < tol, (r, nm, rel_err(have[:len(want[r::world])], want[r::world]))
+        got += float(e.accum[0])
+    assert abs(got - tl) <= 1e-5 * abs(tl)
+    assert rel_err(vh0[:H], Vo[:H]) < tol
+    engs.clear()
+    import gc; gc.collect()
+    if world > 1:
+        lib.orx_vgroup_destroy(vg)
+
+
+def test_hot_items_shrink_the_exchanged_buckets():
+    """the exchanged buckets travel whole (fixed capacities): with `hot_cold_fraction` they are sized for the references that are
+    not replicated -- same results; a share set too small is an overflow that check() reports (which also shows that the buckets
+    are sized by it: the wire bytes of an exchange are world - 1 buckets of that capacity, whatever they hold)"""
+    import torch
+    from openrec_amd import sharded
+    from oracle import numpy_oracle as orc
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(12)
+    NU, NI, D, B, K, H = 2000, 3000, 64, 4096, 4, 256
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    w = 1.0 / np.arange(1, NI + 1) ** 1.05
+    cdf = np.cumsum(w / w.sum())
+    draw = lambda: np.minimum(np.searchsorted(cdf, rng.random((K, B))), NI - 1).astype(np.int32)
+    uid = rng.integers(0, NU, (K, B)).astype(np.int32); pid, nid = draw(), draw()
+    cold = float(max(((pid[k] >= H).mean() + (nid[k] >= H).mean()) / 2 for k in range(K)))
+    assert cold < 0.5
+    lr = 0.0005
+    res = {}
+    for frac in (1.0, cold * 1.05 + 0.01, cold * 0.5):
+        e = sharded.ShardedPairwise("bpr", "sgd", NU, NI, D, lr=lr, rank=0, world=1, device=dev, slack=1.05, hot_items=H, hot_cold_fraction=frac)
+        e.U.write(U); e.V.write(V); e.b.write(b)
+        tu, tp, tn = (torch.from_numpy(x).to(dev) for x in (uid, pid, nid))
+        torch.cuda.synchronize()
+        e.steps(tu, tp, tn, plan_chunk=2)
+        if frac < cold:
+            with pytest.raises(RuntimeError):
+                e.check()
+            continue
+        e.check()
+        e.sync_hot()
+        res[frac] = (e.U.read(), e.V.read(), e.b.read())
+    Uo, Vo, bo = U.astype(np.float64), V.astype(np.float64), b.astype(np.float64)
+    oo = orc.SGD(lr)
+    for s in range(K):
+        orc.bpr_step(Uo, Vo, bo, uid[s], pid[s], nid[s], oo)
+    assert len(res) == 2                                             # (the third share overflowed, above: the buckets ARE sized by it)
+    for got in res.values():
+        assert rel_err(got[0], Uo) < 1e-5 and rel_err(got[1], Vo) < 1e-5 and rel_err(got[2], bo) < 1e-5
