@@ -24,6 +24,7 @@ PAIRWISE_CASES = (  # model, optimizer, dim, engine (None = library), overlap, d
     ("bpr", "sgd", 64, "python", None, None), ("bpr", "adagrad", 64, None, None, None), ("bpr", "adagrad", 64, "python", None, None),
     ("ucml", "sgd", 128, None, None, None), ("ucml", "sgd", 128, None, False, False),
     ("bpr", "adam", 64, None, None, None), ("bpr", "adam", 64, None, False, True), ("bpr", "adam", 64, "python", None, None))
+HOT_CASES = (("bpr", "sgd", None), ("bpr", "adagrad", False), ("bpr", "adam", None))      # model, optimizer, overlap: hot-item replication in the library's engine
 DLRM_CASES = (("sgd", "bce", None), ("adagrad", "bce", "python"), ("adam", "mse", None), ("sgd", "mse", "python"))      # optimizer, loss, engine (None = library)
 
 
@@ -80,6 +81,47 @@ def main():
             assert rel_err(got, want) < tol, (rank, model, optk, nm, rel_err(got, want))
         dist.barrier()
         say(f"rccl-world{world} pairwise {model} {optk} D={D} engine={engine or 'library'} overlap={overlap} dedup={dedup}: ok")
+
+    # ---- hot-item replication inside the library's engine (orx_sharded_pairwise_steps_hot): Zipf(1.05) item ids, the H most popular
+    # items replicated on every rank (load_hot: an all-reduce of the owners' rows), ONE ncclAllReduce of the hot block per step, the
+    # exchanged buckets sized for the cold share; replicas must stay identical on all ranks
+    for model, optk, overlap in HOT_CASES:
+        rng = np.random.default_rng(6)
+        NU, NI, Bl, K, D, H = 3001, 4003, 2048, 6, 64, 256
+        B = Bl * world
+        U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+        b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+        w = 1.0 / np.arange(1, NI + 1) ** 1.05
+        cdf = np.cumsum(w / w.sum())
+        draw = lambda: np.minimum(np.searchsorted(cdf, rng.random((K, B))), NI - 1).astype(np.int32)
+        uid = rng.integers(0, NU, (K, B)).astype(np.int32); pid, nid = draw(), draw()
+        cold = float(max(((pid[k] >= H).mean() + (nid[k] >= H).mean()) / 2 for k in range(K)))
+        lr = 0.002 if optk == "adam" else 0.0005
+        eng = sharded.ShardedPairwise(model, optk, NU, NI, D, lr=lr, rank=rank, world=world, device=dev, slack=2.0, hot_items=H,
+                                      hot_cold_fraction=min(1.0, cold * 1.5 + 0.05))
+        eng.force_collectives = True
+        eng.U.write(U[rank::world]); eng.V.write(V[rank::world]); eng.b.write(b[rank::world])
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        tu, tp, tn = (torch.from_numpy(np.ascontiguousarray(x[:, sl])).to(dev) for x in (uid, pid, nid))
+        torch.cuda.synchronize(); dist.barrier()
+        eng.steps(tu, tp, tn, plan_chunk=4, overlap=overlap)
+        assert eng._comm is not None and eng._fast_hot
+        eng.check()
+        vh = torch.from_numpy(eng.Vh.read()).to(dev)
+        lo, hi = vh.clone(), vh.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "replicas diverged across the ranks"
+        eng.sync_hot()
+        oo = {"sgd": lambda: orc.SGD(lr), "adagrad": lambda: orc.Adagrad(lr, 0.1, 1e-7), "adam": lambda: orc.AdamTFSparse(lr)}[optk]()
+        Uo, Vo, bo = U.astype(np.float64), V.astype(np.float64), b.astype(np.float64)
+        tl = sum(float(orc.bpr_step(Uo, Vo, bo, uid[s], pid[s], nid[s], oo)[0]) for s in range(K))
+        loss, _ = eng.loss_sums()
+        tol = 5e-5 if optk == "adam" else 1e-5
+        assert abs(loss - tl) <= 1e-5 * abs(tl), (rank, "hot", optk, loss, tl)
+        for got, want, nm in ((eng.U.read(), Uo[rank::world], "U"), (eng.V.read(), Vo[rank::world], "V"), (eng.b.read(), bo[rank::world], "b")):
+            assert rel_err(got[:len(want)], want) < tol, (rank, "hot", optk, nm, rel_err(got[:len(want)], want))
+        dist.barrier()
+        say(f"rccl-world{world} pairwise hot-items {model} {optk} overlap={overlap}: ok")
 
     # ---- hybrid-parallel DLRM: embedding rows through all-to-all, dense gradients through all-reduce
     CFG = dict(m_spa=16, ln_emb=[1000, 37, 5000, 3, 250], ln_bot=[64, 16], ln_top=[128, 64, 1], dense_dim=13)

@@ -70,6 +70,37 @@ def main():
             assert rel_err(got, want) < tol, (model, optk, nm, rel_err(got, want))
         print(f"rccl-rank1 pairwise {model} {optk} D={D} engine={engine or 'library'} overlap={overlap}: ok", flush=True)
 
+    # ---- hot-item replication inside the library's engine (orx_sharded_pairwise_steps_hot): Zipf item ids, the replica filled by
+    # load_hot() (an all-reduce over the process group), the per-step all-reduce of the hot block through ncclAllReduce
+    for model, optk, overlap in (("bpr", "sgd", None), ("bpr", "adagrad", False), ("bpr", "adam", None)):
+        rng = np.random.default_rng(6)
+        NU, NI, B, K, D, H = 3000, 4000, 4096, 6, 64, 256
+        U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+        b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+        w = 1.0 / np.arange(1, NI + 1) ** 1.05
+        cdf = np.cumsum(w / w.sum())
+        draw = lambda: np.minimum(np.searchsorted(cdf, rng.random((K, B))), NI - 1).astype(np.int32)
+        uid = rng.integers(0, NU, (K, B)).astype(np.int32); pid, nid = draw(), draw()
+        lr = 0.002 if optk == "adam" else 0.0005
+        eng = sharded.ShardedPairwise(model, optk, NU, NI, D, lr=lr, rank=0, world=1, device=dev, slack=3.0, hot_items=H)
+        eng.force_collectives = True
+        eng.U.write(U); eng.V.write(V); eng.b.write(b)
+        tu, tp, tn = (torch.from_numpy(x).to(dev) for x in (uid, pid, nid))
+        torch.cuda.synchronize()
+        eng.steps(tu, tp, tn, plan_chunk=4, overlap=overlap)
+        assert eng._comm is not None and eng._fast_hot
+        eng.check()
+        eng.sync_hot()
+        oo = {"sgd": lambda: orc.SGD(lr), "adagrad": lambda: orc.Adagrad(lr, 0.1, 1e-7), "adam": lambda: orc.AdamTFSparse(lr)}[optk]()
+        Uo, Vo, bo = U.astype(np.float64), V.astype(np.float64), b.astype(np.float64)
+        tl = sum(float(orc.bpr_step(Uo, Vo, bo, uid[s], pid[s], nid[s], oo)[0]) for s in range(K))
+        loss, _ = eng.loss_sums()
+        tol = 5e-5 if optk == "adam" else 1e-5
+        assert abs(loss - tl) <= 1e-5 * abs(tl), (model, optk, loss, tl)
+        for got, want, nm in ((eng.U.read(), Uo, "U"), (eng.V.read(), Vo, "V"), (eng.b.read(), bo, "b")):
+            assert rel_err(got, want) < tol, ("hot", model, optk, nm, rel_err(got, want))
+        print(f"rccl-rank1 pairwise hot-items {model} {optk} overlap={overlap}: ok", flush=True)
+
     # ---- hybrid-parallel DLRM: embedding rows through all-to-all, dense gradients through all-reduce
     CFG = dict(m_spa=16, ln_emb=[1000, 37, 5000, 3, 250], ln_bot=[64, 16], ln_top=[128, 64, 1], dense_dim=13)
     for optk, loss_func, engine in (("sgd", "bce", "python"), ("adam", "mse", "python"), ("sgd", "bce", None), ("adam", "mse", None)):

@@ -32,10 +32,10 @@ def test_sharded_engines_on_rccl_with_w_ranks(world):
     if _gpus() < world:
         pytest.skip(f"needs {world} GPUs on one node, this box has {_gpus()}")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from rccl_multirank_worker import PAIRWISE_CASES, DLRM_CASES
+    from rccl_multirank_worker import PAIRWISE_CASES, HOT_CASES, DLRM_CASES
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "rccl_multirank_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and "RCCL_MULTIRANK_OK" in r.stdout, r.stdout[-3000:] + "\n---- stderr ----\n" + r.stderr[-3000:]
-    assert r.stdout.count(": ok") == len(PAIRWISE_CASES) + len(DLRM_CASES), r.stdout
+    assert r.stdout.count(": ok") == len(PAIRWISE_CASES) + len(HOT_CASES) + len(DLRM_CASES), r.stdout

@@ -28,4 +28,4 @@ def test_sharded_engines_on_rccl_with_one_rank(rccl_self):
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "rccl_rank1_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_RANK1_OK" in r.stdout, r.stdout[-3000:] + "\n---- stderr ----\n" + r.stderr[-3000:]
-    assert r.stdout.count(": ok") == 13, r.stdout
+    assert r.stdout.count(": ok") == 16, r.stdout
