@@ -5,7 +5,8 @@ a loss module on the looked-up vectors, `tf.nn.l2_loss` of the same vectors, the
 `optimizer.apply_gradients` (tf2_examples/bpr_citeulike.py:33-39).  A user who writes such a model by hand gets the same
 fused kernel as `openrec_amd.tf2.recommenders.BPR / WRMF`: the loss modules recognise lookups of three (two) tables and
 record a pending step on a model object made of those very `LatentFactor`s; the l2 terms resolve to the step's second
-output.  What is NOT a recognised composition computes on the host, without gradients -- and says so once."""
+output.  What is NOT a recognised composition has no gradients (it raises under a tape); looked at outside a tape, its MLP and
+interaction nodes run on the device (orx_mlp_forward / orx_interact_forward) and only element-wise glue on fetched values is NumPy."""
 from __future__ import annotations
 
 import warnings

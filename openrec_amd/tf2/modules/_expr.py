@@ -10,7 +10,8 @@ stay on the device path:
 
 An `Expr` is a small tree over `GatheredRows` / variables / constants.  The ops that END one of these compositions
 (`tf.reduce_sum`, the BCE loss object, `+ tf.reshape(bias, [-1])`) match the tree against the reference's text and record
-the fused step (modules/_compose.py); a tree that matches nothing evaluates on the host as a plain array -- without
+the fused step (modules/_compose.py); a tree that matches nothing is evaluated node by node when its values are looked at (MLP /
+interaction nodes on the device, element-wise glue on the fetched arrays) -- without
 gradients, and says so once under a tape."""
 from __future__ import annotations
 

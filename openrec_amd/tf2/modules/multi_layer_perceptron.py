@@ -73,7 +73,7 @@ class MLP:
         """A node of a lazy expression (modules/_expr.py): the compositions of the reference that contain an MLP run as fused
         device steps -- gmf.py:28 (`Dense(1, no bias)` of user rows * item rows: the fused GMF step / scorer reads the kernel in
         HBM) and dlrm.py:87-93 (bottom MLP -> feature interaction -> top MLP: `orx_dlrm_step`, whose parameters this object's
-        layers then ARE).  A tree that matches neither evaluates on the host when somebody looks at its values -- outside a
+        layers then ARE).  A tree that matches neither runs through `orx_mlp_forward` (device) when somebody looks at its values -- outside a
         tape: under a GradientTape, where the caller expects to train through it, that raises."""
         from ._expr import Expr
         if isinstance(x, Expr) and x.op == "mul" and len(self.layers) == 1 and self.layers[0].units == 1 and not self.layers[0].use_bias \

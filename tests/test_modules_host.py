@@ -1,33 +1,35 @@
-"""SecondOrderFeatureInteraction (openrec/tf2/modules/second_order_feature_interaction.py:4-34) on PLAIN arrays computes on the
-host, values as in the reference (with anything lazy among its inputs -- looked-up rows, an MLP output -- it is a node of the DLRM
-composition, covered on the GPU: tests/test_gpu_compose.py); a lazy tree that is none of the reference's compositions raises under a
-GradientTape, where a caller would expect to train through it."""
-import warnings
-
+"""SecondOrderFeatureInteraction / MLP (openrec/tf2/modules/second_order_feature_interaction.py:4-34, multi_layer_perceptron.py:5-18)
+on the host side: with anything lazy among its inputs the interaction is a node of the DLRM composition (device: tests/test_gpu_compose.py);
+a lazy tree that is none of the reference's compositions raises under a GradientTape, where a caller would expect to train through
+it; and on PLAIN arrays both modules run on the device (tests/test_gpu_modules.py) -- without a usable device they fail loudly:
+there is no host fallback that computes model values."""
 import numpy as np
 import pytest
 
 
-def test_second_order_interaction_values_and_tape_refusal():
+def test_lazy_interaction_is_a_tree_node_and_refuses_a_tape():
     from openrec_amd.tf2.modules import SecondOrderFeatureInteraction
     from openrec_amd.tf2._lazy import GradientTape
+    from openrec_amd.tf2.modules._expr import Expr
     rng = np.random.default_rng(0)
     xs = [rng.normal(size=(5, 4)).astype(np.float32) for _ in range(3)]
-    z = np.stack(xs, 1)
-    want = np.stack([(z[:, 1] * z[:, 0]).sum(1), (z[:, 2] * z[:, 0]).sum(1), (z[:, 2] * z[:, 1]).sum(1)], 1)
-    got = SecondOrderFeatureInteraction(reference_compat=False)(xs)
-    assert np.allclose(got, want, rtol=1e-6)
-    # the reference's own output: lower triangle kept, strictly-upper selected -> zeros
-    assert not SecondOrderFeatureInteraction()(xs).any()
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")
-        SecondOrderFeatureInteraction()(xs)                          # no tape: silent
     with GradientTape():
-        assert np.allclose(SecondOrderFeatureInteraction(reference_compat=False)(xs), want, rtol=1e-6)     # plain arrays: plain values
-        from openrec_amd.tf2.modules._expr import Expr
         lazy = SecondOrderFeatureInteraction()([Expr("neg", xs[0]), xs[1], xs[2]])                         # a lazy input: a tree node ...
         assert isinstance(lazy, Expr) and lazy.op == "interact"
         with pytest.raises(NotImplementedError, match="not one of the compositions"):                     # ... with no device path
             np.asarray(lazy)
-    assert np.allclose(np.asarray(SecondOrderFeatureInteraction(reference_compat=False)([Expr("neg", xs[0]), xs[1], xs[2]])),
-                       SecondOrderFeatureInteraction(reference_compat=False)([-xs[0], xs[1], xs[2]]), rtol=1e-6)      # outside a tape: its values
+
+
+def test_plain_array_modules_have_no_host_fallback():
+    """no GPU in the CPU test tier: the modules must fail loudly, not compute on the host"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: tests/test_gpu_modules.py covers the values")
+    from openrec_amd.tf2.modules import MLP, SecondOrderFeatureInteraction
+    from openrec_amd import _ffi
+    xs = [np.ones((5, 4), np.float32) for _ in range(3)]
+    assert not hasattr(SecondOrderFeatureInteraction, "host_forward") and not hasattr(MLP, "host_forward")
+    with pytest.raises((_ffi.OrxError, RuntimeError, OSError)):
+        SecondOrderFeatureInteraction(reference_compat=False)(xs)
+    with pytest.raises((_ffi.OrxError, RuntimeError, OSError)):
+        np.asarray(MLP([4, 1])(np.ones((3, 8), np.float32)))
