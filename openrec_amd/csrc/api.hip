@@ -686,7 +686,7 @@ static void plan_dedup_args(orx_ctx* c, orx_table* U, orx_table* V, const int32_
     d.min_late = plan.min_late;
     d.alloc = c->d_alloc ? c->d_alloc + 8 * i0 : nullptr;
     if (plan.pair_tpw > 1) {        // pairing (kernels_plan.hip): per-step claims, pairing words, accepted pairs
-        d.pair_tpw = plan.pair_tpw; d.pair_stride = B;
+        d.pair_tpw = plan.pair_tpw; d.pair_stride = B; d.pair_gen = c->pair_gen;
         d.partner = c->d_partner + (size_t)i0 * B; d.pslot = c->d_pslot + (size_t)i0 * 2 * plan.list_stride; d.ids4 = c->d_ids4 + (size_t)i0 * B;
     }
     if (staging) {
@@ -729,6 +729,15 @@ static void plan_decide(int64_t kc, int64_t B, bool inline_apply, bool staging, 
 int orx_exact_plan_issue(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,
                          int64_t nU, int64_t nP, int64_t nN, int64_t kc, int64_t B, bool inline_apply, bool staging,
                          const PairPlan& plan, int64_t i0, hipEvent_t counters, const std::function<int()>* after_readback) {
+    if (plan.pair_tpw > 1) {
+        // the pairing records are not initialised per plan: their words carry the plan's generation (orx_internal.h, ORX_PARTNER_*).
+        // The buffer starts all-zero (generation 0 is nobody's) and is zeroed again when the generations wrap.
+        c->pair_gen = c->pair_gen % 63 + 1;
+        if (c->pair_gen == 1 || c->partner_zeroed != c->d_partner || c->partner_zeroed_cap != c->d_partner_cap) {
+            ORX_HIP(hipMemsetAsync(c->d_partner, 0, c->d_partner_cap, c->stream));
+            c->partner_zeroed = c->d_partner; c->partner_zeroed_cap = c->d_partner_cap;
+        }
+    }
     DedupArgs d;
     plan_dedup_args(c, U, V, uid, pid, nid, ds, nU, nP, nN, B, true, inline_apply, staging, plan, i0, &d);
     // bucketed plan; ONE read-back of the per-step counters into pinned memory, and the urgent marks are made while
@@ -740,32 +749,11 @@ int orx_exact_plan_issue(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
         ORX_HIP(hipEventRecord(counters, c->stream));
     }
     if (d.pair_tpw > 1) {
-        // pairing: the fused kernel's input is packed once every flag sits on the rewritten ids (urgent marks included).
-        // MEASURED AND LEFT OFF (profiles/r4_plan_side_stream.txt; ORX_PLAN_SIDE=1 turns it on): step 0 of a chunk needs no urgent
-        // marks, so its record can be packed alone and its launch go out at once while the marks and the records of the other steps
-        // (~25 us of light kernels at K = 20) are made on the plan stream BESIDE step 0 -- 37.8 us/step against 37.1 without: what
-        // runs beside a fused launch takes from it what it gets (the verdict of rounds 2 and 3 on every such overlap).
-        static const bool side = getenv("ORX_PLAN_SIDE") != nullptr && getenv("ORX_PLAN_PIPE") == nullptr;
-        if (side && after_readback && *after_readback && kc > 1 && c->plan_stream && c->stream != c->plan_stream && i0 == 0) {
-            hipStream_t main_stream = c->stream;
-            ORX_HIP(hipEventRecord(c->pipe_cnt[1], main_stream));               // the plan (ranges, pairs) is complete here
-            ORX_HIP(hipStreamWaitEvent(c->plan_stream, c->pipe_cnt[1], 0));
-            c->stream = c->plan_stream;
-            int rc = inline_apply ? orx_launch_plan_urgent(c, d, kc, i0) : ORX_OK;
-            DedupArgs rest = d;                                                 // steps 1 .. kc - 1 (the arrays the pack kernel reads / writes)
-            rest.ids_out += d.flag_stride; rest.partner += d.pair_stride; rest.ids4 += d.pair_stride;
-            if (rc == ORX_OK) rc = orx_launch_plan_pack(c, rest, kc - 1);
-            const hipError_t e = hipEventRecord(c->pipe_done[1], c->plan_stream);
-            c->stream = main_stream;
-            CHECK(rc);
-            ORX_HIP(e);
-            CHECK(orx_launch_plan_pack(c, d, 1));
-            CHECK((*after_readback)());
-            ORX_HIP(hipStreamWaitEvent(main_stream, c->pipe_done[1], 0));
-            return ORX_OK;
-        }
+        // pairing: the ids of the positions an accepted pair moves change places once every flag sits on them (urgent marks included).
+        // (round 4 measured the marks + records of steps 1 .. on a side stream beside step 0: 37.8 against 37.1 us per step --
+        // profiles/r4_plan_side_stream.txt; the switch is gone with the packed copy it scheduled)
         if (inline_apply) CHECK(orx_launch_plan_urgent(c, d, kc, i0));
-        CHECK(orx_launch_plan_pack(c, d, kc));
+        CHECK(orx_launch_plan_swap(c, d, kc));
         if (after_readback && *after_readback) CHECK((*after_readback)());
         return ORX_OK;
     }
@@ -986,7 +974,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     // no read-back (see plan_stats_poll): the previous call of this shape was quiet
     const int64_t stats_key[5] = {B, U->rows, V->rows, (int64_t)model * 16 + opt->kind, (int64_t)U->dim * 4 + (want_censor ? 1 : 0) + (inline_apply ? 2 : 0)};
     CHECK(plan_stats_poll(c));
-    const bool plan_wait = getenv("ORX_PLAN_WAIT") != nullptr || getenv("ORX_PLAN_PIPE") != nullptr || getenv("ORX_PLAN_SIDE") != nullptr;      // (experiments / tests: always read back)
+    const bool plan_wait = getenv("ORX_PLAN_WAIT") != nullptr || getenv("ORX_PLAN_PIPE") != nullptr;      // (experiments / tests: always read back)
     bool nowait = mode == MODE_EXACT && orx_plan_v2(role_bits) && staging && !censor && opt->kind != ORX_ADAM && !plan_wait &&
                   c->plan_stats.valid && c->plan_stats.quiet;
     for (int k = 0; k < 5 && nowait; ++k) nowait = c->plan_stats.key[k] == stats_key[k];
@@ -1007,7 +995,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     if (opt->kind == ORX_ADAM) plan.min_late = 1;
     // pairing (kernels_plan.hip): the two triplets of a row referenced exactly twice share a wavefront and exchange gradients there
     // (SGD / Adagrad on the float4 dims with >= 2 triplets per wavefront; fb bit 4 / ORX_NO_PAIR=1: off)
-    // The pairing plan costs ~1.5 us per step (records, decisions, the packed input); it pays where a good share of the batch pairs
+    // The pairing plan costs ~1.5 us per step (records, decisions, the swaps); it pays where a good share of the batch pairs
     // (uniform ids over tables ~ 10 x the batch: 11 %).  Tables so small that most duplicated rows have three or more references, or
     // ids so skewed that the hot rows take them, pair little: the plan of a call tells (accepted pairs per step), and pairing then
     // pauses for 32 calls before it is tried again.  ORX_PAIR_ALWAYS=1: no pause.

@@ -19,7 +19,8 @@
 //                        counters in LDS), duplicate list with (segment, count), reduction-tree work items
 //   plan_urgent_kernel   bit 28 on the references of step s whose row was duplicated in step s-1 (in-launch apply)
 //   plan_pair_kernel     pairing (below): accepts / refuses the rows referenced exactly twice
-//   plan_pack_kernel     pairing: the fused kernel's input, (user, pos, neg, pairing word) per position in the paired order
+//   plan_swap_kernel     pairing: the input records of the positions an accepted pair moves change places (the records themselves --
+//                        (user, pos, neg, pairing word) per position -- are written by plan_part_kernel and flagged in place)
 //
 // PAIRING (round 4).  A row referenced exactly twice in a step costs the exact step ten row moves (two reads, two gradient
 // deposits, and the apply's three reads + three writes) where a racy kernel pays four.  The order of the triplets inside a
@@ -28,7 +29,7 @@
 // row in place, the other does not write it -- two row moves, no deposit, no apply, no ready flag.  plan_range_kernel tells
 // each of the two references where the other sits; plan_pair_kernel (one thread per entry of the step's list of duplicated rows)
 // accepts a row when it is the first such row of both its triplets and a neighbouring position can be displaced -- a rule on data nothing writes meanwhile: no claims,
-// deterministic -- and sends the refused rows down the deposit / apply path; plan_pack_kernel writes the fused kernel's input in the
+// deterministic -- and sends the refused rows down the deposit / apply path; plan_swap_kernel puts the fused kernel's input into the
 // new order.  Rows with three or more references and rows whose two references sit in one triplet always keep the deposit path.
 // The fused kernel sees a paired reference as a reference to a unique row.
 // The reference's semantics being restated are TF's: every gradient of a step is taken on the pre-step tables and
@@ -69,6 +70,18 @@ __device__ __forceinline__ bool plan_ref(const PlanArgs& a, int64_t s, int64_t j
     else if (j < d.nU + d.nP) { id = d.pid[s * d.id_stride + (j - d.nU)]; is_user = false; pos = (int)(d.role_stride ? d.role_stride + (j - d.nU) : j); }
     else { id = d.nid[s * d.id_stride + (j - d.nU - d.nP)]; is_user = false; pos = (int)(d.role_stride ? 2 * d.role_stride + (j - d.nU - d.nP) : j); }
     return id_ok(id, is_user ? d.NU : d.NI);
+}
+
+// The rewritten id of reference `pos` of step s (pos = slot * role_stride + triplet).  With pairing it lives IN the fused kernel's
+// input record (ids4[s][triplet], words x / y / z): plan_part_kernel writes the records themselves, the later plan kernels put their
+// flags there, and what used to be a whole pass (a packed copy of ids_out in the paired order) is a swap of the few records that move.
+__device__ __forceinline__ int32_t* plan_idword(const DedupArgs& d, int64_t s, int pos) {
+    if (d.pair_tpw > 1) {
+        const int Bp = (int)d.role_stride;
+        const int slot = (pos >= Bp ? 1 : 0) + (pos >= 2 * Bp ? 1 : 0);
+        return reinterpret_cast<int32_t*>(d.ids4 + s * d.pair_stride + (pos - slot * Bp)) + slot;
+    }
+    return d.ids_out + s * d.flag_stride + pos;
 }
 
 // Workgroup barrier that orders LDS traffic only: global loads and returning atomics already in flight stay in flight across it (the
@@ -119,14 +132,23 @@ __global__ __launch_bounds__(PL_THREADS) void plan_part_kernel(PlanArgs a) {
             // the rewritten ids start as a (coalesced) copy; plan_range_kernel then touches only the duplicated references --
             // a scattered 4-byte store costs a memory transaction of its own.  0x7fffffff: out-of-range id, never a valid row
             if (SCATTER) {
-                a.d.ids_out[s * a.d.flag_stride + pos] = ok ? id : 0x7fffffff;
-                // pairing: one 16-byte record per triplet -- no reference has a partner yet (x, y, z = -1), no pairing word and the
-                // triplet is processed where it stands (w = position << 10)
-                // (bit 0 of w: one of the triplet's ids is out of range -- the fused kernel skips such a triplet altogether, so it must
-                // never be the partner a valid triplet relies on: plan_pair_kernel refuses its rows)
-                if (a.d.pair_tpw > 1 && j < a.d.pair_stride) {
-                    const bool tri_ok = ok & id_ok(a.d.pid[s * a.d.id_stride + j], a.d.NI) & id_ok(a.d.nid[s * a.d.id_stride + j], a.d.NI);
-                    a.d.partner[s * a.d.pair_stride + j] = make_int4(-1, -1, -1, (int)(((uint32_t)j << 10) | (tri_ok ? 0u : 1u)));
+                if (a.d.pair_tpw > 1) {
+                    // pairing: the thread of a triplet's USER reference writes the fused kernel's input record -- the three ids (0x7fffffff:
+                    // out of range), no pairing word, processed where it stands (w = position << 10)
+                    if (j < a.d.pair_stride) {
+                        const int p = a.d.pid[s * a.d.id_stride + j], n = a.d.nid[s * a.d.id_stride + j];
+                        const bool okp = id_ok(p, a.d.NI), okn = id_ok(n, a.d.NI);
+                        a.d.ids4[s * a.d.pair_stride + j] = make_int4(ok ? id : 0x7fffffff, okp ? p : 0x7fffffff, okn ? n : 0x7fffffff, (int)((uint32_t)j << 10));
+                        // (the pairing record is NOT initialised: its words count only with this plan's generation, orx_internal.h -- except
+                        // for a triplet with an out-of-range id, which the fused kernel skips altogether: it must never be the partner a valid
+                        // triplet relies on, and says so in every slot; the slot of the invalid id is never overwritten)
+                        if (!(ok & okp & okn)) {
+                            const int poison = (int)(ORX_PARTNER_POISON | ((uint32_t)a.d.pair_gen << 24));
+                            a.d.partner[s * a.d.pair_stride + j] = make_int4(poison, poison, poison, 0);
+                        }
+                    }
+                } else {
+                    a.d.ids_out[s * a.d.flag_stride + pos] = ok ? id : 0x7fffffff;
                 }
             }
         }
@@ -248,7 +270,6 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
         if (dupout) for (int w = threadIdx.x; w < W; w += T) dupout[w] = 0u;
         return;
     }
-    int32_t* ids_out = d.ids_out + s * d.flag_stride;
     int2* refinfo = d.refinfo ? d.refinfo + s * d.flag_stride : nullptr;
     // The usual range (<= PL_UN entries per thread) keeps its entries in registers: they are requested before the LDS is zeroed and
     // serve both passes (one global round trip instead of three: load, role write-back, reload).
@@ -378,7 +399,7 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
             } else if (t3 && refinfo != nullptr) {
                 refinfo[pos] = make_int2(-1, 0);
             }
-            ids_out[pos] = (int32_t)v;
+            *plan_idword(d, s, pos) = (int32_t)v;
         }
     };
     if (small) {
@@ -398,8 +419,9 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
         for (int k = threadIdx.x; k < ndup2; k += T) {
             const int posA = pairpos[2 * k], posB = pairpos[2 * k + 1];
             const int sa = (posA >= Bp ? 1 : 0) + (posA >= 2 * Bp ? 1 : 0), sb = (posB >= Bp ? 1 : 0) + (posB >= 2 * Bp ? 1 : 0);
-            partner[4 * (posA - sa * Bp) + sa] = posB;                           // (bit 30 clear: the row's first reference, which owns the decision)
-            partner[4 * (posB - sb * Bp) + sb] = posA | (1 << 30);
+            const int tag = d.pair_gen << 24;
+            partner[4 * (posA - sa * Bp) + sa] = posB | tag;                     // (bit 30 clear: the row's first reference, which owns the decision)
+            partner[4 * (posB - sb * Bp) + sb] = posA | (1 << 30) | tag;
         }
     }
     PL_STAMP(5);
@@ -492,10 +514,9 @@ __global__ __launch_bounds__(T) void plan_urgent_kernel(PlanArgs a) {
     __syncthreads();
     const int lg = b < a.nru ? a.lgu : a.lgi;
     const int2* ent = a.list + s * a.nref + lo;
-    int32_t* ids_out = a.d.ids_out + s * a.d.flag_stride;
     pl_for_each<T>(ent, n, [&](int, int2 e) {
         const int l = e.x >> lg;
-        if ((pl_lds[l >> 5] >> (l & 31)) & 1u) ids_out[e.y & 0x3fffffff] |= (1 << 28);
+        if ((pl_lds[l >> 5] >> (l & 31)) & 1u) *plan_idword(a.d, s, e.y & 0x3fffffff) |= (1 << 28);
     });
 }
 
@@ -515,15 +536,21 @@ __global__ __launch_bounds__(256) void plan_pair_kernel(PlanArgs a) {
     const int64_t s = blockIdx.y;
     const int B = (int)d.pair_stride, Bp = (int)d.role_stride, tpw = d.pair_tpw;
     const int4* part = d.partner + s * d.pair_stride;      // per triplet: where the partner of slot 0 / 1 / 2 sits (-1: none), w: its pairing word
-    int* pword = reinterpret_cast<int*>(d.partner + s * d.pair_stride) + 3;       // ... which is this kernel's to write (word 4 t + 3)
-    int32_t* ids = d.ids_out + s * d.flag_stride;
+    int* pword = reinterpret_cast<int*>(d.ids4 + s * d.pair_stride) + 3;          // the positions' pairing words: word w of the fused kernel's input records (4 t + 3)
     const int nb = a.nru + a.nri, W = (1 << a.shift) >> 5;
     const int n = d.dcount[s];
     auto slot_of = [&](int pos) { return (pos >= Bp ? 1 : 0) + (pos >= 2 * Bp ? 1 : 0); };
     // the choice of a triplet from its record: its first slot with a partner (-1: none)
-    auto choice = [](int4 r) { return r.x >= 0 ? 0 : (r.y >= 0 ? 1 : (r.z >= 0 ? 2 : -1)); };
+    // a word of a record counts if it carries this plan's generation (the records are not initialised per plan) and is not the poison
+    const uint32_t gen = (uint32_t)d.pair_gen;
+    auto live = [gen](int w) { return (((uint32_t)w >> 24) & 63u) == gen && ((uint32_t)w & ORX_PARTNER_POS) != ORX_PARTNER_POISON; };
+    auto poisoned = [gen](int4 r) {
+        auto p = [gen](int w) { return (((uint32_t)w >> 24) & 63u) == gen && ((uint32_t)w & ORX_PARTNER_POS) == ORX_PARTNER_POISON; };
+        return p(r.x) | p(r.y) | p(r.z);
+    };
+    auto choice = [live](int4 r) { return live(r.x) ? 0 : (live(r.y) ? 1 : (live(r.z) ? 2 : -1)); };
     auto word = [](int4 r, int k) { return k == 0 ? r.x : (k == 1 ? r.y : r.z); };
-    const int4 none = make_int4(-1, -1, -1, 0);
+    const int4 none = make_int4(0, 0, 0, 0);               // (generation 0 is never a plan's)
     int npair = 0;
     // Two dependent levels of 16-byte record loads after the entry's two positions: the records of both triplets and of both buddies
     // (a buddy's record shares its triplet's 32 bytes); then the records of the buddies' partners.
@@ -541,10 +568,10 @@ __global__ __launch_bounds__(256) void plan_pair_kernel(PlanArgs a) {
         const int4 ra = part[ta], rb = part[tb];
         const int4 rl = (needq && bl < B) ? part[bl] : none, rh = (needq && bh < B) ? part[bh] : none;
         // the row is the choice of both its triplets
-        const bool mutual = (ta != tb) & (choice(ra) == sa) & (choice(rb) == sb) & !((ra.w | rb.w) & 1);       // (bit 0: a triplet with an invalid id)
+        const bool mutual = (ta != tb) & (choice(ra) == sa) & (choice(rb) == sb) & !(poisoned(ra) | poisoned(rb));       // (poison: a triplet with an invalid id)
         // is a buddy in a mutual pair of its own?  its choice's partner y must choose it back
         const int cl = choice(rl), ch = choice(rh);
-        const int ppl = word(rl, cl) & 0x3fffffff, pph = word(rh, ch) & 0x3fffffff;
+        const int ppl = (int)((uint32_t)word(rl, cl) & ORX_PARTNER_POS), pph = (int)((uint32_t)word(rh, ch) & ORX_PARTNER_POS);
         const int syl = slot_of(ppl), syh = slot_of(pph);
         const int yl = ppl - syl * Bp, yh = pph - syh * Bp;
         const int4 ryl = (cl >= 0 && yl != bl) ? part[yl] : none, ryh = (ch >= 0 && yh != bh) ? part[yh] : none;
@@ -564,11 +591,15 @@ __global__ __launch_bounds__(256) void plan_pair_kernel(PlanArgs a) {
             pword[4 * stay] = (int)(ORX_PAIR_VALID | ORX_PAIR_WRITER | ((uint32_t)q & m) | (s_stay << 4) | (s_mov << 6) | ((uint32_t)stay << 10));
             pword[4 * q] = (int)(ORX_PAIR_VALID | ((uint32_t)stay & m) | (s_mov << 4) | (s_stay << 6) | ((uint32_t)mover << 10));
             if (q != mover) pword[4 * mover] = (int)((uint32_t)q << 10);
+            // (plan_swap_kernel exchanges the ids of the two positions once every flag sits on them)
+            reinterpret_cast<int2*>(d.pslot)[eg] = q != mover ? make_int2(q, mover) : make_int2(-1, -1);
             npair += 1;
         } else {
-            const uint32_t id = (uint32_t)ids[posA];
-            ids[posA] = (int32_t)(id | (1u << 31));                         // role 0
-            ids[posB] = (int32_t)(id | (1u << 31) | (1u << 29));            // role 1
+            reinterpret_cast<int2*>(d.pslot)[eg] = make_int2(-1, -1);
+            int32_t* wa = plan_idword(d, s, posA);
+            const uint32_t id = (uint32_t)*wa;
+            *wa = (int32_t)(id | (1u << 31));                                      // role 0
+            *plan_idword(d, s, posB) = (int32_t)(id | (1u << 31) | (1u << 29));    // role 1
             d.dlist[eg] = id | (sa ? 0x80000000u : 0u);
             if (a.dupbits != nullptr) {
                 const int bk = sa ? a.nru + (int)(id & (uint32_t)(a.nri - 1)) : (int)(id & (uint32_t)(a.nru - 1));
@@ -586,35 +617,28 @@ __global__ __launch_bounds__(256) void plan_pair_kernel(PlanArgs a) {
     if (threadIdx.x == 0 && sh_np) atomicAdd(d.alloc + 8 * s + 7, sh_np);
 }
 
-// pairing: the fused kernel's input, one 16-byte record per position j of the batch -- the three rewritten ids of the triplet that is
-// processed there (perm: itself, unless a pair moved it) with every flag the plan put on them, the position's pairing word and the
-// triplet's original position (its staging records stay where they were).  Runs after plan_urgent_kernel.
-__global__ __launch_bounds__(256) void plan_pack_kernel(DedupArgs d) {
+// pairing: position q of an accepted pair processes the triplet that stood at `mover` (and the mover's position the triplet that stood
+// at q).  The pairing words already say so (plan_pair_kernel); here the ids of the two records change places -- after every flag of the
+// plan (duplicate flags and roles, urgent marks) has been put on them where the triplets STOOD.  A position is part of at most one such
+// exchange (it can only ever be displaced for its own buddy, and a mover is never anybody's buddy-to-displace): no two threads touch
+// the same record.  One thread per entry of the step's list of duplicated rows.
+__global__ __launch_bounds__(256) void plan_swap_kernel(DedupArgs d) {
     const int64_t s = blockIdx.y;
-    const int32_t* ids = d.ids_out + s * d.flag_stride;
-    const int64_t Bp = d.role_stride;
-    constexpr int R = 4;                                 // positions per thread: four independent chains perm -> ids in flight
-    int src[R]; uint32_t pw[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int64_t j = ((int64_t)blockIdx.x * R + k) * 256 + threadIdx.x;
-        pw[k] = j < d.pair_stride ? (uint32_t)reinterpret_cast<const int*>(d.partner + s * d.pair_stride)[4 * j + 3] : 0u;
-        src[k] = (int)(pw[k] >> 10);
-    }
-    int4 v[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) { v[k].x = ids[src[k]]; v[k].y = ids[Bp + src[k]]; v[k].z = ids[2 * Bp + src[k]]; v[k].w = (int)pw[k]; }
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int64_t j = ((int64_t)blockIdx.x * R + k) * 256 + threadIdx.x;
-        if (j < d.pair_stride) d.ids4[s * d.pair_stride + j] = v[k];
+    const int n = d.dcount[s];
+    int4* rec = d.ids4 + s * d.pair_stride;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const int2 qm = reinterpret_cast<const int2*>(d.pslot)[s * d.list_stride + e];
+        if (qm.x < 0 || qm.y < 0) continue;
+        const int4 a = rec[qm.x], b = rec[qm.y];
+        rec[qm.x] = make_int4(b.x, b.y, b.z, a.w);
+        rec[qm.y] = make_int4(a.x, a.y, a.z, b.w);
     }
 }
 
-int orx_launch_plan_pack(orx_ctx* ctx, const DedupArgs& d, int64_t kc) {
+int orx_launch_plan_swap(orx_ctx* ctx, const DedupArgs& d, int64_t kc) {
     if (d.pair_tpw < 2 || kc <= 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_DEDUP);
-    ORX_LAUNCH(ctx, plan_pack_kernel, dim3((unsigned)((d.pair_stride + 1023) / 1024), (unsigned)kc), dim3(256), 0, d);
+    ORX_LAUNCH(ctx, plan_swap_kernel, dim3((unsigned)std::max<int64_t>(4, (d.pair_stride / 4 + 255) / 256), (unsigned)kc), dim3(256), 0, d);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -753,6 +777,7 @@ int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc, int64_t
     const size_t words = (size_t)nb * ((1u << a.shift) >> 5);
     a.bcnt = ctx->d_pl_cnt + step0 * (3 * nb + 1); a.list = ctx->d_pl_list + step0 * a.nref; a.dupbits = ctx->d_dupbits + step0 * words; a.min_late = -1;
     a.s_first = first;
+    a.tstamp = nullptr;
     const int W = (1 << a.shift) >> 5;
     if (ctx->plan_big) ORX_LAUNCH(ctx, plan_urgent_kernel<1024>, dim3((unsigned)(a.nru + a.nri), (unsigned)(kc - first)), dim3(1024), (size_t)W * 4, a);
     else ORX_LAUNCH(ctx, plan_urgent_kernel<256>, dim3((unsigned)(a.nru + a.nri), (unsigned)(kc - first)), dim3(256), (size_t)W * 4, a);

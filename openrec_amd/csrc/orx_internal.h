@@ -61,11 +61,12 @@ struct orx_ctx {
     const void* pl_cnt_clean = nullptr; size_t pl_cnt_clean_cap = 0; int pl_cnt_nb = -1;      // the buffer (and ranges per step) whose counts and cursors are all zero between plans
     int2* d_pl_list = nullptr; size_t d_pl_list_cap = 0;         // [K][references per step] (id, output position | role << 30)
     bool plan_big = false;                                       // the last plan met a bucket of > 16 k references: 1024-thread workgroups
+    int pair_gen = 0; const void* partner_zeroed = nullptr; size_t partner_zeroed_cap = 0;      // generation of the last pairing plan; the partner buffer (pointer, size) that has been zeroed
     int pair_pause = 0;                                          // pairing: calls left before it is tried again (the last plan that paired accepted too few rows to pay for itself)
     // pairing (kernels_plan.hip, "pairing"): the two references of a row referenced exactly twice are brought into one wavefront
-    int4* d_partner = nullptr; size_t d_partner_cap = 0;         // [K][B] per triplet: where the partner of its slot 0 / 1 / 2 sits if that row is referenced exactly twice (-1: no), pairing word
+    int4* d_partner = nullptr; size_t d_partner_cap = 0;         // [K][B] per triplet: where the partner of its slot 0 / 1 / 2 sits if that row is referenced exactly twice (generation-tagged words, ORX_PARTNER_*)
     int* d_pslot = nullptr;    size_t d_pslot_cap = 0;           // [K][2B] parallel to dlist: position of the FIRST reference of a row referenced exactly twice (-1: another kind of row)
-    int4* d_ids4 = nullptr;    size_t d_ids4_cap = 0;            // [K][B] the fused kernel's input with pairing: (user, pos, neg) rewritten ids of position j, pinfo | origin << 10
+    int4* d_ids4 = nullptr;    size_t d_ids4_cap = 0;            // [K][B] the fused kernel's input with pairing, written by the plan itself: (user, pos, neg) rewritten ids of position j, pairing word | origin << 10
     int* h_plan = nullptr;                                       // pinned host mirror of the per-step plan counters
     size_t h_plan_cap = 0;
     hipEvent_t plan_ev = nullptr;                                // "plan counters have arrived on the host"
@@ -264,9 +265,16 @@ struct DedupArgs {
     // per-step arrays [K][pair_stride] partner (16-byte record per triplet) and ids4, [K][2 list_stride] pslot; the number of accepted pairs
     // of step s is alloc[8 s + 7]
     int pair_tpw; int4* partner; int* pslot; int4* ids4; int64_t pair_stride;
+    int pair_gen;                             // generation tag (1 .. 63) of this plan's partner words: see ORX_PARTNER_* below
 };
 // pairing word of a triplet (PairArgs::pinfo): the triplet shares one row with the triplet of lane group PARTNER of the same wavefront;
 // the WRITER adds the partner's gradient of that row to its own and updates the row in place, the other one does not write it
+// A word of a triplet's pairing record partner[t].{x,y,z}: bits 23:0 the position of the other reference of that slot's row, bit 30
+// "this is the row's second reference", bits 29:24 the GENERATION of the plan that wrote it.  The records are never initialised per
+// plan (16 bytes per triplet and step, a fifth of what plan_part_kernel<true> wrote): a word counts only if it carries the current
+// plan's generation; the buffer is zeroed when it is allocated and whenever the generations wrap (every 63 plans).  Position
+// ORX_PARTNER_POISON marks a triplet with an out-of-range id (written for such triplets only): never paired.
+constexpr uint32_t ORX_PARTNER_POS = 0x00ffffffu, ORX_PARTNER_POISON = 0x00ffffffu;
 constexpr uint32_t ORX_DLIST_DEAD = 0xffffffffu;     // entry of a step's list of duplicated rows whose row was paired after all: nothing to apply
 constexpr uint32_t ORX_PAIR_VALID = 0x200u, ORX_PAIR_WRITER = 0x100u;      // bits 3:0 partner lane group, 5:4 my slot (0 user, 1 pos, 2 neg), 7:6 partner's slot
 constexpr int ORX_SEG_DIRECT = 16;            // the apply sums up to this many staged gradients / partial sums of a row itself
@@ -408,7 +416,7 @@ bool orx_plan_v2(bool role_bits);
 int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t B, int64_t NU, int64_t NI, bool want_dupbits);
 int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupbits, int64_t step0 = 0);
 int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc, int64_t step0 = 0);
-int orx_launch_plan_pack(orx_ctx* ctx, const DedupArgs& d, int64_t kc);      // pairing: permuted (u, p, n, pairing word) records for the fused kernel
+int orx_launch_plan_swap(orx_ctx* ctx, const DedupArgs& d, int64_t kc);      // pairing: the records of the positions an accepted pair moves change places
 int orx_fused_tpw(int D);                        // triplets per wavefront of the float4 fused kernel (0: generic dim)
 int orx_fused_can_inline_apply(int D);
 int orx_dedup_words(void);
