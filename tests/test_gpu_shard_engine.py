@@ -278,3 +278,45 @@ def test_hot_items_shrink_the_exchanged_buckets():
     assert len(res) == 2                                             # (the third share overflowed, above: the buckets ARE sized by it)
     for got in res.values():
         assert rel_err(got[0], Uo) < 1e-5 and rel_err(got[1], Vo) < 1e-5 and rel_err(got[2], bo) < 1e-5
+
+
+@pytest.mark.parametrize("optk", ["adagrad", "adam"])
+def test_hot_replica_state_survives_a_checkpoint_on_the_device(tmp_path, optk):
+    """ADVICE r4 on the device backend: the replicated rows are trained on the replica, so their Adagrad accumulators / Adam moments
+    live in the replica's slots; ShardedPairwise.save writes the replica (tables + slots) beside the shards, load brings it back, and
+    a resumed run continues like the uninterrupted one (library engine, one rank)."""
+    import torch
+    from openrec_amd import sharded
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(21)
+    NU, NI, D, B, K, H = 1500, 2000, 64, 2048, 4, 128
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    w = 1.0 / np.arange(1, NI + 1) ** 1.05
+    cdf = np.cumsum(w / w.sum())
+    draw = lambda: np.minimum(np.searchsorted(cdf, rng.random((K, B))), NI - 1).astype(np.int32)
+    uid = rng.integers(0, NU, (K, B)).astype(np.int32); pid, nid = draw(), draw()
+    lr = 0.002 if optk == "adam" else 0.0005
+    tu, tp, tn = (torch.from_numpy(x).to(dev) for x in (uid, pid, nid))
+
+    def engine():
+        e = sharded.ShardedPairwise("bpr", optk, NU, NI, D, lr=lr, rank=0, world=1, device=dev, slack=3.0, hot_items=H)
+        e.U.write(U); e.V.write(V); e.b.write(b)
+        return e
+    a = engine()
+    a.steps(tu[:2], tp[:2], tn[:2], plan_chunk=2)
+    a.save(str(tmp_path / "ck"))
+    a.steps(tu[2:], tp[2:], tn[2:], plan_chunk=2)
+    a.check(); a.sync_hot()
+    r = engine()
+    r.U.fill(0.0); r.V.fill(0.0); r.b.fill(0.0)
+    r.load(str(tmp_path / "ck"))
+    r.steps(tu[2:], tp[2:], tn[2:], plan_chunk=2)
+    r.check(); r.sync_hot()
+    assert a._fast_hot and r._fast_hot and r._comm is not None
+    tol = 5e-5 if optk == "adam" else 1e-6
+    for x, y, nm in ((a.U.read(), r.U.read(), "U"), (a.V.read(), r.V.read(), "V"), (a.b.read(), r.b.read(), "b"),
+                     (a.Vh.read(), r.Vh.read(), "Vh"), (a.bh.read(), r.bh.read(), "bh")):
+        assert rel_err(y, x) < tol, (nm, rel_err(y, x))
+    with pytest.raises(ValueError):                  # another replica layout cannot take over the replicas' optimizer state
+        sharded.ShardedPairwise("bpr", optk, NU, NI, D, lr=lr, rank=0, world=1, device=dev, slack=3.0, hot_items=64).load(str(tmp_path / "ck"))
