@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_files, rel_err, OPT_KW
+from conftest import GOLDEN, rel_err, OPT_KW
 from oracle import numpy_oracle as orc
 from oracle import metrics_oracle as mo
 
