@@ -141,3 +141,37 @@ def test_maximum_table_sizes(rows):
         assert np.abs(got - want).max() <= TOL * np.abs(want).max(), name
         delta_check(w0, got, want, steps=K, what=f"rows={rows} {name}")
     assert np.array_equal(tU.gather(spare), s0)
+
+
+def test_ids_produced_on_a_busy_torch_stream_are_ordered_before_the_step():
+    """orx_ctx_wait_stream: device ids produced on ANOTHER stream must be complete before the library's stream reads them.  An idle
+    producer stream costs no cross-stream wait (round 5: hipStreamQuery) -- a BUSY one must still be waited for: here the ids are
+    copied behind ~10 ms of matrix products on a side stream, and the step is issued right away."""
+    import torch
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(31)
+    NU, NI, B, D = 5000, 6000, 4096, 64
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32)
+    ids = [rng.integers(0, hi, B).astype(np.int32) for hi in (NU, NI, NI)]
+    ctx = rt.Context(0)
+    tU, tV, tb = (rt.Table(*x.shape, ctx).write(x) for x in (U, V, b))
+    opt = rt.Optimizer.sgd(0.05, ctx=ctx)
+    pinned = [torch.from_numpy(x).pin_memory() for x in ids]
+    bufs = [torch.full((B,), 2 ** 30, dtype=torch.int32, device=dev) for _ in ids]      # (stale contents: out-of-range ids)
+    big = torch.randn((4096, 4096), device=dev)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        acc = big
+        for _ in range(20):
+            acc = (acc @ big) * 1e-3                        # keeps the side stream busy for milliseconds
+        for dst, src in zip(bufs, pinned):
+            dst.copy_(src, non_blocking=True)
+        loss, l2 = rt.pairwise_step("bpr", opt, tU, tV, tb, bufs[0], bufs[1], bufs[2])       # (after_torch: torch's CURRENT stream = side)
+    lo, l2o = orc.bpr_step(U, V, b, ids[0], ids[1], ids[2], orc.SGD(lr=0.05))
+    assert abs(loss[0] - lo) <= 1e-5 * abs(lo)
+    for got, want in ((tU.read(), U), (tV.read(), V), (tb.read(), b)):
+        assert rel_err(got, want) < 1e-5
