@@ -582,23 +582,46 @@ extern "C" int orx_apply_rows_flagged(orx_ctx* ctx, orx_opt* opt, orx_table* t, 
     return orx_apply_rows_flagged_impl(ctx, opt, t, bias, ids, n, grads, g_stride, nullptr, dflag);
 }
 
-// gbias != NULL: the bias gradients come in an array of their own ([n]) instead of column dim of the gradient rows
-int orx_apply_rows_flagged_impl(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
-                                const float* grads, int64_t g_stride, const float* gbias, const unsigned char* dflag) {
+static int flagged_args(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
+                        const float* grads, int64_t g_stride, const float* gbias, const unsigned char* dflag, RowsArgs* out) {
     if (t) CHECK(orx_table_sync(t));
     if (bias) CHECK(orx_table_sync(bias));
     ORX_ARG(ctx && opt && t && (n == 0 || (ids && grads && dflag)), "orx_apply_rows_flagged: NULL argument");
     ORX_ARG(opt->kind == ORX_SGD, "orx_apply_rows_flagged: SGD only (Adagrad / Adam: orx_apply_rows)");
     ORX_ARG(g_stride >= t->dim + ((bias && !gbias) ? 1 : 0), "orx_apply_rows_flagged: g_stride too small");
     ORX_ARG(!bias || (bias->dim == 1 && bias->rows == t->rows), "orx_apply_rows_flagged: bias must be [%lld, 1]", (long long)t->rows);
-    if (n == 0) return ORX_OK;
-    ORX_HIP(hipSetDevice(ctx->device));
     RowsArgs a;
     memset(&a, 0, sizeof(a));
     a.W = t->w; a.bias = bias ? bias->w : nullptr;
     a.ids = ids; a.grads = grads; a.g_stride = g_stride; a.n = n; a.rows = t->rows; a.D = t->dim;
     a.lr = opt->lr; a.err = ctx->d_err; a.dflag = dflag; a.gbias = gbias;
+    *out = a;
+    return ORX_OK;
+}
+
+// gbias != NULL: the bias gradients come in an array of their own ([n]) instead of column dim of the gradient rows
+int orx_apply_rows_flagged_impl(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
+                                const float* grads, int64_t g_stride, const float* gbias, const unsigned char* dflag) {
+    RowsArgs a;
+    CHECK(flagged_args(ctx, opt, t, bias, ids, n, grads, g_stride, gbias, dflag, &a));
+    if (n == 0) return ORX_OK;
+    ORX_HIP(hipSetDevice(ctx->device));
     return orx_launch_apply_rows(ctx, ORX_SGD, true, a);
+}
+
+int orx_apply_rows_flagged_pair(orx_ctx* ctx, orx_opt* opt, orx_table* tA, orx_table* biasA, const int32_t* idsA, int64_t nA, const float* gA, int64_t strideA,
+                                const float* gbiasA, const unsigned char* flagA, orx_table* tB, orx_table* biasB, const int32_t* idsB, int64_t nB, const float* gB,
+                                int64_t strideB, const float* gbiasB, const unsigned char* flagB, bool flags_over_both) {
+    RowsArgs a, b;
+    CHECK(flagged_args(ctx, opt, tA, biasA, idsA, nA, gA, strideA, gbiasA, flagA, &a));
+    CHECK(flagged_args(ctx, opt, tB, biasB, idsB, nB, gB, strideB, gbiasB, flagB, &b));
+    ORX_HIP(hipSetDevice(ctx->device));
+    int rc = ORX_OK;
+    // (two lists of ONE table: only where the caller's flags were made over both lists together -- a row in both is then an atomic add in both)
+    if ((tA != tB || flags_over_both) && orx_launch_apply_rows_pair(ctx, a, b, &rc)) return rc;
+    if (nA) CHECK(orx_launch_apply_rows(ctx, ORX_SGD, true, a));
+    if (nB) CHECK(orx_launch_apply_rows(ctx, ORX_SGD, true, b));
+    return ORX_OK;
 }
 
 // ------------------------------------------------- device-side exchange plan ---

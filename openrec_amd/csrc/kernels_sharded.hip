@@ -177,14 +177,14 @@ __global__ __launch_bounds__(256) void apply_rows_sgd_wave_kernel(RowsArgs a) {
 // once in the list is a plain float4 read-modify-write by its lane group, only duplicated rows take
 // the 64 atomics per reference.  LPR lanes per reference.
 template <int LPR>
-__global__ __launch_bounds__(256) void apply_rows_sgd_flagged_kernel(RowsArgs a) {
+__device__ __forceinline__ void apply_rows_sgd_flagged_body(const RowsArgs a, int block, int nblocks) {      // (by value: through a reference the fields of the kernel argument end up in vector registers -- 34 VGPRs against 24, 35 -> 49 us)
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
-    const int64_t stride = (int64_t)gridDim.x * 4 * TPW;
-    for (int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + grp; k < a.n; k += stride) {
+    const int64_t stride = (int64_t)nblocks * 4 * TPW;
+    for (int64_t k = ((int64_t)block * 4 + (threadIdx.x >> 6)) * TPW + grp; k < a.n; k += stride) {
         const int r = a.ids[k];
         if (r < 0) continue;
         if ((int64_t)r >= a.rows) { if (sub == 0) *a.err = 1; continue; }
@@ -202,6 +202,17 @@ __global__ __launch_bounds__(256) void apply_rows_sgd_flagged_kernel(RowsArgs a)
             else a.bias[r] = a.bias[r] - a.lr * gb;
         }
     }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void apply_rows_sgd_flagged_kernel(RowsArgs a) { apply_rows_sgd_flagged_body<LPR>(a, (int)blockIdx.x, (int)gridDim.x); }
+
+// two lists of two tables in one launch (the sharded step's user rows and item rows: one launch and the gap behind it fewer per step --
+// the user list is short work, 7.5 us as a launch of its own): the first blocks_a workgroups take list a, the others list b
+template <int LPR>
+__global__ __launch_bounds__(256) void apply_rows_sgd_flagged2_kernel(RowsArgs a, RowsArgs b, int blocks_a) {
+    if ((int)blockIdx.x < blocks_a) apply_rows_sgd_flagged_body<LPR>(a, (int)blockIdx.x, blocks_a);
+    else apply_rows_sgd_flagged_body<LPR>(b, (int)blockIdx.x - blocks_a, (int)gridDim.x - blocks_a);
 }
 
 // Planned apply: one lane group per reference.  The row's duplicate status / role comes from the ids rewritten by
@@ -383,6 +394,27 @@ int orx_launch_apply_rows(orx_ctx* ctx, int optkind, bool use_dflag, const RowsA
     }
     ORX_HIP(hipGetLastError());
     return ORX_OK;
+}
+
+// SGD with duplicate flags on two lists (same dim) in one launch; false: not applicable (the caller launches them one by one)
+bool orx_launch_apply_rows_pair(orx_ctx* ctx, const RowsArgs& a, const RowsArgs& b, int* rc) {
+    int lpr = 0;
+    switch (a.D) { case 16: lpr = 4; break; case 32: lpr = 8; break; case 64: lpr = 16; break; case 128: lpr = 32; break; case 256: lpr = 64; break; }
+    static const bool off = getenv("ORX_APPLY_NO_PAIR") != nullptr;
+    if (off || lpr == 0 || a.D != b.D || a.n == 0 || b.n == 0 || a.g_stride % 4 != 0 || b.g_stride % 4 != 0) return false;
+    ProfScope ps(ctx, ORX_K_DUPAPPLY);
+    const unsigned ga = grid_for_rows(lpr, a.n), gb = grid_for_rows(lpr, b.n);
+    const dim3 g(ga + gb);
+    switch (lpr) {
+        case 4: ORX_LAUNCH(ctx, (apply_rows_sgd_flagged2_kernel<4>), g, dim3(256), 0, a, b, (int)ga); break;
+        case 8: ORX_LAUNCH(ctx, (apply_rows_sgd_flagged2_kernel<8>), g, dim3(256), 0, a, b, (int)ga); break;
+        case 16: ORX_LAUNCH(ctx, (apply_rows_sgd_flagged2_kernel<16>), g, dim3(256), 0, a, b, (int)ga); break;
+        case 32: ORX_LAUNCH(ctx, (apply_rows_sgd_flagged2_kernel<32>), g, dim3(256), 0, a, b, (int)ga); break;
+        default: ORX_LAUNCH(ctx, (apply_rows_sgd_flagged2_kernel<64>), g, dim3(256), 0, a, b, (int)ga); break;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { orx_set_error("apply_rows_sgd_flagged2_kernel launch failed: %s", hipGetErrorString(e)); *rc = ORX_ERR_HIP; } else *rc = ORX_OK;
+    return true;
 }
 
 // ---------------------------------------------------------- loss accumulate ---

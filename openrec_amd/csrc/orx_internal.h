@@ -336,6 +336,7 @@ struct GradArgs {
 
 int orx_launch_pair_grads(orx_ctx* ctx, int model, const GradArgs& a, int* nwaves);
 int orx_launch_apply_rows(orx_ctx* ctx, int optkind, bool use_dflag, const RowsArgs& a);
+bool orx_launch_apply_rows_pair(orx_ctx* ctx, const RowsArgs& a, const RowsArgs& b, int* rc);
 int orx_launch_loss_accumulate(orx_ctx* ctx, const float* partial, int64_t nwaves, double* accum);
 int orx_shard_grads_nwaves(int D, int64_t T);
 
@@ -591,6 +592,10 @@ int orx_shard_grads_impl(orx_ctx* ctx, int model, orx_opt* opt, orx_table* user,
                          float* partial_ext = nullptr, int* nwaves_out = nullptr);
 int orx_apply_rows_flagged_impl(orx_ctx* ctx, orx_opt* opt, orx_table* t, orx_table* bias, const int32_t* ids, int64_t n,
                                 const float* grads, int64_t g_stride, const float* gbias, const unsigned char* dflag);
+// two flagged SGD lists (tables of one dim) in one launch where that applies, else one after the other
+int orx_apply_rows_flagged_pair(orx_ctx* ctx, orx_opt* opt, orx_table* tA, orx_table* biasA, const int32_t* idsA, int64_t nA, const float* gA, int64_t strideA,
+                                const float* gbiasA, const unsigned char* flagA, orx_table* tB, orx_table* biasB, const int32_t* idsB, int64_t nB, const float* gB,
+                                int64_t strideB, const float* gbiasB, const unsigned char* flagB, bool flags_over_both = false);
 int orx_launch_shard_segsum(orx_ctx* ctx, const int2* seglist, const int* segcount, const uint2* sorted, int64_t n, const float* gdup, int DSg,
                             float* send_g, int DS, int D, float* gb_out);
 int orx_launch_shard_route(orx_ctx* ctx, const RouteArgs& a, int64_t K = 1);

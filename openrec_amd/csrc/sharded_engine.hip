@@ -563,10 +563,13 @@ static int sharded_pairwise_impl(orx_comm* c, orx_opt* opt, int model, orx_table
                 if (H == 2) ORX_HIP(hipEventRecord(c->ev[6 + h], X));
             }
             if (opt->kind == ORX_ADAM) CHECK(orx_opt_advance(opt, tabs, ntabs));   // Keras `iterations` += 1: after the step's gathers, before its applies
-            if (sgd) {                                     // 5. user rows are local: the duplicated ones, half by half
-                for (int h = 0; h < H; ++h)
-                    CHECK(orx_apply_rows_flagged(ctx, opt, U, nullptr, (int32_t*)c->u_apply.p + (size_t)h * T, T, (float*)c->gu.p + (size_t)h * T * D, D,
-                                                 fu + (size_t)(k * H + h) * T));
+            if (sgd && H == 1) {                           // 5. the duplicated user rows (local) and the item-row gradients at their owners: one launch
+                CHECK(orx_apply_rows_flagged_pair(ctx, opt, U, nullptr, (int32_t*)c->u_apply.p, T, (float*)c->gu.p, D, nullptr, fu + (size_t)k * T,
+                                                  V, b, req_loc + (size_t)k * M, M, (const float*)g_in[0], DS, (const float*)gb_in[0], fv + (size_t)k * M));
+            } else if (sgd) {                              // ... half by half: the user rows, then each half's item rows as its gradients arrive
+                // (both halves' user lists in one launch: their duplicate flags were made over the two lists together)
+                CHECK(orx_apply_rows_flagged_pair(ctx, opt, U, nullptr, (int32_t*)c->u_apply.p, T, (float*)c->gu.p, D, nullptr, fu + (size_t)(k * H) * T,
+                                                  U, nullptr, (int32_t*)c->u_apply.p + (size_t)T, T, (float*)c->gu.p + (size_t)T * D, D, nullptr, fu + (size_t)(k * H + 1) * T, true));
                 for (int h = 0; h < H; ++h) {              // item-row gradients at their owners
                     if (H == 2) ORX_HIP(hipStreamWaitEvent(S, c->ev[6 + h], 0));
                     CHECK(orx_apply_rows_flagged_impl(ctx, opt, V, b, req_loc + (size_t)(k * H + h) * M, M, (const float*)g_in[h], DS, (const float*)gb_in[h],
