@@ -195,10 +195,10 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
         }
         if (model == ORX_GMF) {                  // dense Dense(1) kernel: reduce partials, apply the dense rule
             if (mode == MODE_ACCUM || lazy_adam) {
-                CHECK(orx_launch_dense_reduce(c, c->d_wpart, nw, D, w->w, a.l2w, w->gsum, a.partial + 2 * nw, nullptr, -1, 0.f, 0.f));
+                CHECK(orx_launch_dense_reduce(c, c->d_wpart, orx_point_wparts(D, B), D, w->w, a.l2w, w->gsum, a.partial + 2 * nw, nullptr, -1, 0.f, 0.f));
                 CHECK(orx_launch_adam_sweep(c, w->w, sw.s0, sw.s1, w->gsum, D, lr_t, opt->p0, opt->p1, opt->p2));
             } else {        // reduce + dense SGD / Adagrad rule in one launch
-                CHECK(orx_launch_dense_reduce(c, c->d_wpart, nw, D, w->w, a.l2w, nullptr, a.partial + 2 * nw, sw.s0, opt->kind, opt->lr, a.eps));
+                CHECK(orx_launch_dense_reduce(c, c->d_wpart, orx_point_wparts(D, B), D, w->w, a.l2w, nullptr, a.partial + 2 * nw, sw.s0, opt->kind, opt->lr, a.eps));
             }
         }
     }

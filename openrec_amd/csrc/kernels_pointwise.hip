@@ -157,7 +157,15 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
             gw_acc.x += __shfl_xor(gw_acc.x, off); gw_acc.y += __shfl_xor(gw_acc.y, off);
             gw_acc.z += __shfl_xor(gw_acc.z, off); gw_acc.w += __shfl_xor(gw_acc.w, off);
         }
-        if (grp == 0) *reinterpret_cast<f4*>(a.wpartial + (size_t)wave_global * D + 4 * sub) = gw_acc;
+        // ... and the workgroup's four wavefronts through LDS: one [D] partial per WORKGROUP (1 MB instead of 4 MB per step at B = 65 536 for the
+        // reduce launches to read; every wavefront of a sample block arrives here)
+        __shared__ f4 gwsh[4][LPR];
+        if (grp == 0) gwsh[threadIdx.x >> 6][sub] = gw_acc;
+        __syncthreads();
+        if (threadIdx.x < LPR) {
+            const f4 t = (gwsh[0][sub] + gwsh[1][sub]) + (gwsh[2][sub] + gwsh[3][sub]);
+            *reinterpret_cast<f4*>(a.wpartial + (size_t)(blockIdx.x - nab) * D + 4 * sub) = t;
+        }
     }
 }
 
@@ -346,6 +354,8 @@ static inline int64_t point_grid(int D, int64_t B) {
 }
 
 int orx_point_nwaves(int D, int64_t B) { return (int)(point_grid(D, B) * 4); }
+// rows of GMF's dense-gradient partials: one per workgroup from the float4 kernels, one per wavefront from the generic one
+int orx_point_wparts(int D, int64_t B) { return (int)(point_grid(D, B) * (lpr_for_dim_p(D) ? 1 : 4)); }
 
 template <int LPR, int MODEL, int OPT>
 static void launch_point_mode(int mode, dim3 g, orx_ctx* c, const PointArgs& a) {

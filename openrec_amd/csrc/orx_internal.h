@@ -375,6 +375,7 @@ int orx_launch_dense_apply(orx_ctx* ctx, float* w, float* acc, float* g, int n, 
 int orx_launch_score_all(orx_ctx* ctx, const float* U, const float* V, const float* b, const float* w,
                          const int32_t* uid, int64_t nq, int64_t NU, int64_t NI, int D, int kind, float* out);
 int orx_point_nwaves(int D, int64_t B);
+int orx_point_wparts(int D, int64_t B);
 int orx_launch_score_mfma(orx_ctx* ctx, const float* U, const float* V, const float* b, const float* w, const int32_t* uid,
                           int64_t nq, int64_t NU, int64_t NI, int D, int kind, float* out, bool* launched);
 
