@@ -510,8 +510,20 @@ def main():
                             traffic_src = f"profiles/{tj['tag']}_pmc_summary.csv was measured on another build: not reported"
                 except Exception:
                     traffic = None
+            # second yardstick: the streaming-copy rate of THIS device, measured in this process after the
+            # timed region by a float4 copy kernel over 1 GiB buffers (orx_copy_bandwidth); and the whole step -- algorithmic bytes
+            # over ms_per_step -- against the peak: how much of the step is not the dominant kernel
+            copy_gbs = None
+            if world == 1 and not args.sharded:
+                try:
+                    copy_gbs = ctx.copy_bandwidth(1 << 30, 10)
+                except Exception:
+                    copy_gbs = None
+            step_achieved = args.batch * bpt / (dt / K) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "point_fused_kernel" if args.model in ("gmf", "wrmf") else "fused_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                               "copy_peak_measured": copy_gbs, "frac_of_copy_peak": (achieved / copy_gbs) if copy_gbs else None,
+                               "step_frac": step_achieved / HBM_PEAK_GBS,
                                "bytes_per_triplet": bpt, "kernel_us": dur * 1e6,
                                "other_kernels_us": {k: v["total_ms"] / v["launches"] * 1e3
                                                     for k, v in prof.items() if v.get("launches") and k not in ("fused", "pointwise")}}

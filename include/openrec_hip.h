@@ -484,7 +484,10 @@ int orx_sharded_pairwise_steps(orx_comm* comm, orx_opt* opt, int model, orx_tabl
  * cold_fraction in (0, 1]: the share of a list's item references expected NOT to be hot -- the exchanged buckets (which travel
  * whole: fixed capacities, no size exchange) are sized for that share, which is what takes the hot rows off the wire; a list with
  * more cold references than its buckets hold sets *overflow like any other overflow.  1.0: buckets as without replication.
- * hot_items = 0: orx_sharded_pairwise_steps.  At most 63 ranks. */
+ * hot_items = 0: orx_sharded_pairwise_steps.  At most 63 ranks.  ORX_SHARD_DEDUP is refused together with hot_items > 0
+ * (ORX_ERR_ARG): the plan with the replica as a destination is the one without per-destination dedup.  As with every overflow,
+ * a call that sets *overflow dropped references: the tables AND the replicas (whose summed block the dropped triplets' slots
+ * still entered) are not the result of the steps any more -- restore from a checkpoint, raise `slack` / `cold_fraction`. */
 int orx_sharded_pairwise_steps_hot(orx_comm* comm, orx_opt* opt, int model, orx_table* user, orx_table* item, orx_table* bias,
                                    orx_table* item_hot, orx_table* bias_hot, int64_t hot_items, float cold_fraction,
                                    const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t K, int64_t B, int64_t id_stride,
@@ -515,6 +518,10 @@ int orx_prof_get(orx_ctx* ctx, int kid, double* total_ms, int64_t* launches);
  *        = 2  pairwise calls so far that enqueued every launch without waiting for their plan's counters
  *        = 3  1 if those counters were "quiet" (no range wanted a staging plan, few duplicated rows), else 0 */
 int orx_ctx_stat(orx_ctx* ctx, int what, int64_t* out);
+/* The streaming-copy yardstick of this device (bench.py's `roofline.frac_of_copy_peak`; no reference equivalent): a float4 copy
+ * kernel over two buffers of `bytes` each (allocated and released inside the call; bytes % 16 == 0), three untimed launches, then
+ * `reps` timed ones on the context's stream; *gbps_out = 2 * bytes / mean launch time, in 1e9 bytes per second. */
+int orx_copy_bandwidth(orx_ctx* ctx, int64_t bytes, int32_t reps, double* gbps_out);
 
 #ifdef __cplusplus
 }

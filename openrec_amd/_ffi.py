@@ -121,6 +121,7 @@ SIGNATURES = {
     "orx_prof_reset": (c_int, [_p]),
     "orx_prof_get": (c_int, [_p, c_int, POINTER(c_double), POINTER(c_int64)]),
     "orx_ctx_stat": (c_int, [_p, c_int, POINTER(c_int64)]),
+    "orx_copy_bandwidth": (c_int, [_p, c_int64, c_int32, POINTER(c_double)]),
     "orx_mlp_forward": (c_int, [_p, c_int32, POINTER(_p), POINTER(_p), POINTER(c_int32), _p, c_int64, c_int32, c_int, _p]),
     "orx_interact_forward": (c_int, [_p, _p, c_int64, c_int32, c_int32, c_int, c_int, c_int, _p]),
 }

@@ -745,6 +745,9 @@ int orx_exact_plan_issue(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* 
     d.roles = nullptr; d.dupbits = nullptr;
     CHECK(orx_launch_plan(c, d, kc, inline_apply, i0));
     if (counters != nullptr) {      // (NULL: nobody waits for this plan's counters, see orx_plan_stats_*)
+        // counters a no-read-back pairwise call parked in h_plan are overwritten here (pointwise / row plans share the buffer):
+        // they must not be attributed to that call later -- the next pairwise call plans with the read-back again
+        if (c->stats_pending) { c->stats_pending = false; c->plan_stats.valid = false; }
         ORX_HIP(hipMemcpyAsync(c->h_plan + 8 * i0, c->d_alloc + 8 * i0, (size_t)kc * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // ([5] = duplicated rows)
         ORX_HIP(hipEventRecord(counters, c->stream));
     }
@@ -816,8 +819,9 @@ static int plan_stats_poll(orx_ctx* c) {
         if (++c->stats_age < 8) return ORX_OK;              // (a host far ahead of the device: keep the old answer a little longer)
         e = hipEventSynchronize(c->stats_ev);
     }
-    ORX_HIP(e);
     c->stats_pending = false; c->stats_age = 0;
+    if (e != hipSuccess) c->plan_stats.valid = false;     // (the counters never arrived: later calls read back again instead of failing here)
+    ORX_HIP(e);
     const bool quiet = plan_counters_seen(c, c->stats_kc, c->stats_B, 0, c->h_plan, c->stats_pairing, nullptr);
     c->plan_stats.valid = true; c->plan_stats.quiet = quiet;
     for (int k = 0; k < 5; ++k) c->plan_stats.key[k] = c->stats_key[k];
@@ -994,7 +998,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
     // rows referenced >= 3 times always take staging slots (fixed summation order), never fp32 atomics
     if (opt->kind == ORX_ADAM) plan.min_late = 1;
     // pairing (kernels_plan.hip): the two triplets of a row referenced exactly twice share a wavefront and exchange gradients there
-    // (SGD / Adagrad on the float4 dims with >= 2 triplets per wavefront; fb bit 4 / ORX_NO_PAIR=1: off)
+    // (SGD only -- Adagrad with pairing measured slower, profiles/r5_adagrad_pairing_ab.txt -- on the float4 dims with >= 2 triplets per wavefront; fb bit 4 / ORX_NO_PAIR=1: off)
     // The pairing plan costs ~1.5 us per step (records, decisions, the swaps); it pays where a good share of the batch pairs
     // (uniform ids over tables ~ 10 x the batch: 11 %).  Tables so small that most duplicated rows have three or more references, or
     // ids so skewed that the hot rows take them, pair little: the plan of a call tells (accepted pairs per step), and pairing then

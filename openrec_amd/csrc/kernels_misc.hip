@@ -200,3 +200,45 @@ int orx_launch_adam_flush(orx_ctx* ctx, float* w, float* m, float* v, int* last,
     ORX_HIP(hipGetLastError());
     return orx_launch_fill_int(ctx, last, rows, t_end);
 }
+
+// ---- the streaming-copy yardstick (the fraction of the MEASURED streaming rate beside the fraction of the
+// 8 TB/s peak).  One float4 per thread, whole buffer in one launch: the fastest form scratch/copy_bw.hip found on this part
+// (6.1-6.3 TB/s read + write at 1 GiB; block-contiguous and grid-stride loops reach 5.0-5.8).
+typedef float orx_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy_f4_kernel(const orx_f4* __restrict__ src, orx_f4* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// bytes: size of EACH of the two buffers (allocated and freed here); *gbps_out = 2 * bytes / the mean launch time over `reps`
+// launches (HIP events on the context's stream, three untimed launches first), in GB/s (1e9 bytes per second)
+extern "C" int orx_copy_bandwidth(orx_ctx* c, int64_t bytes, int32_t reps, double* gbps_out) {
+    ORX_ARG(c && gbps_out && bytes >= 4096 && bytes % 16 == 0 && bytes / 16 / 256 < (1LL << 31) && reps > 0 && reps <= 1000, "orx_copy_bandwidth: bad argument");
+    ORX_HIP(hipSetDevice(c->device));
+    orx_f4 *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void**)&a, (size_t)bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&b, (size_t)bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 1, (size_t)bytes, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b, 0, (size_t)bytes, c->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms = 0.f;
+    if (e == hipSuccess) {
+        const size_t n = (size_t)bytes / 16;
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(copy_f4_kernel, dim3(grid), dim3(256), 0, c->stream, a, b, n);
+        e = hipEventRecord(e0, c->stream);
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(copy_f4_kernel, dim3(grid), dim3(256), 0, c->stream, a, b, n);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    hipFree(a); hipFree(b);
+    ORX_HIP(e);
+    *gbps_out = ms > 0.f ? 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9 : 0.0;
+    return ORX_OK;
+}

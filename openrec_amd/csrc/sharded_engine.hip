@@ -395,6 +395,8 @@ static int sharded_pairwise_impl(orx_comm* c, orx_opt* opt, int model, orx_table
     const int N = c->world;
     ORX_ARG(U->rows >= (users_global - c->rank + N - 1) / N && V->rows >= (items_global - c->rank + N - 1) / N,
             "orx_sharded_pairwise_steps: the local shards are smaller than rows r = rank (mod world) of the global tables");
+    ORX_ARG(!(hot && (flags & ORX_SHARD_DEDUP)), "orx_sharded_pairwise_steps_hot: ORX_SHARD_DEDUP cannot be combined with hot_items > 0 "
+            "(the request plan that treats the replica as a destination is the one without per-destination dedup)");
     if (K == 0) return ORX_OK;
     ORX_HIP(hipSetDevice(ctx->device));
     // Overlap: a step is cut into two half-batches, planned as separate lists, whose exchanges run on a second stream beside the

@@ -82,6 +82,12 @@ class Context:
         check(self._lib.orx_ctx_stat(self._h, {"pairs": 0, "max_dup": 1, "nowait_calls": 2, "quiet": 3}[what], byref(v)))
         return int(v.value)
 
+    def copy_bandwidth(self, nbytes=1 << 30, reps=10):
+        """orx_copy_bandwidth: GB/s (read + write) of a float4 streaming copy over two buffers of `nbytes` each"""
+        v = c_double()
+        check(self._lib.orx_copy_bandwidth(self._h, int(nbytes), int(reps), byref(v)))
+        return float(v.value)
+
     def prof_get(self):
         out = {}
         for kid, name in _ffi.KERNEL_NAMES.items():

@@ -60,10 +60,17 @@ class MLP:
         self.build(in_dim)
         x2 = x.reshape(-1, in_dim)
         n = len(self.layers)
+        if n == 0:
+            raise ValueError("MLP.device_forward: the stack has no layers")
+        known = {None: 0, "linear": 0, "relu": 1, "sigmoid": 2}
+        for i, l in enumerate(self.layers):
+            if not (l.activation is None or isinstance(l.activation, str)) or l.activation not in known:
+                raise NotImplementedError("MLP.device_forward: layer %d has activation %r; the device path (orx_mlp_forward) has "
+                                          "None / 'linear' / 'relu' / 'sigmoid'" % (i, l.activation))
         ctx = self.layers[0].kernel.ctx
         kernels = (ctypes.c_void_p * n)(*[l.kernel._h for l in self.layers])
         biases = (ctypes.c_void_p * n)(*[(l.bias._h if l.bias is not None else None) for l in self.layers])
-        acts = (ctypes.c_int32 * n)(*[{None: 0, "linear": 0, "relu": 1, "sigmoid": 2}[l.activation] for l in self.layers])
+        acts = (ctypes.c_int32 * n)(*[known[l.activation] for l in self.layers])
         out = np.empty((x2.shape[0], self.layers[-1].units), np.float32)
         if x2.shape[0]:
             _ffi.check(ctx._lib.orx_mlp_forward(ctx._h, n, kernels, biases, acts, x2.ctypes.data, x2.shape[0], in_dim, 0, out.ctypes.data))

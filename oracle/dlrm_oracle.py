@@ -106,6 +106,9 @@ class DLRMOracle:
                     move = self._flip_move(x, xo, Wo, x_noise)
                 if a == "relu":
                     probe["margin"].append((np.abs(z) / S).min(axis=1))
+                    if "ties" in probe:          # (net, layer, sample, unit) of every relu unit within delta of zero: tie_units
+                        for bi, ji in np.argwhere(np.abs(z) / S < probe["delta"]):
+                            probe["ties"].append((probe["net"], len(outs) - 1, int(bi), int(ji)))
                     if move is not None:
                         probe["risky"] |= (np.abs(z) < move + probe["delta"] * S).any(axis=1)
             x = self._act(z, a)
@@ -133,6 +136,8 @@ class DLRMOracle:
         """emb_rows [B, n_emb, d]: embedding vectors handed in instead of looked up (the hybrid-parallel
         step of openrec_amd/sharded_dlrm.py exchanges them between ranks first)."""
         dense = dense.astype(self.dt)
+        if probe is not None:
+            probe["net"] = "bot"
         bot = self._mlp(dense, self.bot, self.bot_act, probe, None)                     # dlrm.py:87
         if emb_rows is not None:
             vecs = [emb_rows[:, f, :].astype(self.dt) for f in range(emb_rows.shape[1])] + [bot[-1]]
@@ -149,6 +154,8 @@ class DLRMOracle:
             aZ = np.abs(Z)
             Sd = np.einsum("bfd,bgd->bfg", aZ, aZ)[:, self.I, self.J]
             R_noise = np.concatenate([probe["out_noise"] if probe["out_noise"] is not None else np.zeros_like(bot[-1]), probe["kappa"] * Sd], 1)
+        if probe is not None:
+            probe["net"] = "top"
         top = self._mlp(R, self.top, self.top_act, probe, R_noise)
         p = top[-1]
         clip_mask = np.ones_like(p)
@@ -173,10 +180,20 @@ class DLRMOracle:
         m = np.min(np.stack(probe["margin"], 0), axis=0) if probe["margin"] else np.full(dense.shape[0], np.inf)
         return np.where(probe["risky"], -1.0, m)
 
+    def tie_units(self, dense, sparse, emb_rows=None, delta=1e-6):
+        """[(net, layer, sample, unit)]: the relu units whose pre-activation lies within `delta` of zero, relative to the sum of
+        the magnitudes it was added up from -- where two correct fp32 implementations (another order of the same additions) may
+        put the unit on different sides.  The forward value barely notices (|z| ~ 0); the BACKWARD mask `y > 0` is 0 on one side
+        and 1 on the other: `loss_and_grads(flip=...)` gives the gradients with chosen units on the other side."""
+        probe = dict(margin=[], risky=np.zeros(dense.shape[0], bool), kappa=2e-7, delta=delta, out_noise=None, ties=[])
+        self.forward(dense, sparse, emb_rows, probe)
+        return probe["ties"]
+
     # ----------------------------------------------------------- loss + backward
-    def loss_and_grads(self, dense, sparse, label, emb_rows=None, global_batch=None):
+    def loss_and_grads(self, dense, sparse, label, emb_rows=None, global_batch=None, flip=None):
         """global_batch: the loss mean runs over that many samples (this call sees a slice of them);
-        the returned loss is then this slice's share of the global mean."""
+        the returned loss is then this slice's share of the global mean.
+        flip: {(net, layer): bool [B, units]} -- relu units whose backward mask is inverted (tie_units)."""
         c = self.forward(dense, sparse, emb_rows)
         p, y = c["pred"], label.astype(self.dt)
         B = p.shape[0] if global_batch is None else int(global_batch)
@@ -195,7 +212,8 @@ class DLRMOracle:
             while S < B and S < 32768.0:
                 S *= 2.0
         self._gscale = self.dt.type(S)
-        g_top, dR = self._mlp_backward(c["top"], self.top, self.top_act, dp)
+        fl = flip or {}
+        g_top, dR = self._mlp_backward(c["top"], self.top, self.top_act, dp, {l: m for (n, l), m in fl.items() if n == "top"})
         d = self.m_spa
         dZ = np.zeros_like(c["Z"])
         dZ[:, self.F - 1, :] += dR[:, :d]
@@ -211,15 +229,15 @@ class DLRMOracle:
             else:
                 dZ[:, i, :] += g * Z[:, j, :]
                 dZ[:, j, :] += g * Z[:, i, :]
-        g_bot, _ = self._mlp_backward(c["bot"], self.bot, self.bot_act, dZ[:, self.F - 1, :])
+        g_bot, _ = self._mlp_backward(c["bot"], self.bot, self.bot_act, dZ[:, self.F - 1, :], {l: m for (n, l), m in fl.items() if n == "bot"})
         return loss, dict(emb=dZ[:, :self.F - 1, :], bot=g_bot, top=g_top)
 
-    def _mlp_backward(self, outs, layers, acts, dy):
+    def _mlp_backward(self, outs, layers, acts, dy, flip=None):
         grads = [None] * len(layers)
         for l in range(len(layers) - 1, -1, -1):
             y = outs[l + 1]
             if acts[l] == "relu":
-                dz = dy * (y > 0)
+                dz = dy * ((y > 0) ^ flip[l] if flip and l in flip else (y > 0))
             elif acts[l] == "sigmoid":
                 dz = dy * y * (1 - y)
             else:

@@ -161,3 +161,70 @@ def test_c5_shapes_fp16_mode_against_the_fp16_operand_oracle():
     """one step (a second one would start from weights the two sides hold 1e-8 apart, whose fp16 copies can differ by an ulp and
     flip relu units -- see test_gpu_dlrm.py; the K-step sequencing is covered in exact mode above)"""
     _case("c5_fp16_sgd", True, "sgd", 4, 1e-4, DELTA, 1)
+
+
+def test_c5_shapes_exact_mode_with_relu_ties_present():
+    """The other C5 tests draw their batches AWAY from the network's relu ties (tests/dlrm_util.py).  Here the batch is taken as it
+    comes -- the first B candidates, ties and all -- and the comparison is tie-aware instead: a relu unit whose pre-activation lies
+    within DELTA of zero (relative to the magnitudes it was summed from) may come out on the other side on the device; the forward
+    barely notices, the backward mask `y > 0` is 0 or 1, and the parameter gradients then differ by exactly that unit's share of
+    its sample's gradient -- a known quantity P_t (DLRMOracle.loss_and_grads(flip=...) on that one sample).  Every element of
+    every update must lie within
+
+        TOL * max|update of the tensor| + (fp32 storage slack) + lr * sum_t |P_t[element]|
+
+    of the oracle's: each tie is bounded by what it can contribute, nothing is dropped.  (multi_layer_perceptron.py:5-18 under
+    dlrm.py:87-95; tf.nn.relu's gradient is `features > 0`.)"""
+    from oracle import numpy_oracle as orc
+    K, lr, seed = 1, 0.05, 5
+    cand, uniq, rows_of, o, dense_start, spare = _problem(False, seed, DELTA, K)
+    de, sp, la = (x[:B] for x in cand[0])
+    csp = np.stack([np.searchsorted(uniq[f], sp[:, f]) for f in range(NF)], 1).astype(np.int32)
+    ties = o.tie_units(de, csp, delta=DELTA)
+    assert len(ties) > 0, "no relu unit of this batch lies within DELTA of zero: the test would not exercise ties"
+    # the oracle's natural step, and every tie's possible contribution (per element, absolute)
+    e0 = [x.astype(np.float32) for x in o.emb]
+    slack_P = {f"emb{f}": np.zeros_like(o.emb[f]) for f in range(NF)}
+    for nm, layers in (("bot", o.bot), ("top", o.top)):
+        for l, (W, b_) in enumerate(layers):
+            slack_P[f"{nm}_w{l}"] = np.zeros_like(W); slack_P[f"{nm}_b{l}"] = np.zeros_like(b_)
+    by_sample = {}
+    for t in ties:
+        by_sample.setdefault(t[2], []).append(t)
+    for bi, ts in by_sample.items():
+        one = (de[bi:bi + 1], csp[bi:bi + 1], la[bi:bi + 1])
+        _, g0 = o.loss_and_grads(*one, global_batch=B)
+        for net, l, _, j in ts:                                        # (ties are flipped one at a time: |P_t| adds up)
+            m = np.zeros((1, (o.bot if net == "bot" else o.top)[l][0].shape[1]), bool); m[0, j] = True
+            _, g1 = o.loss_and_grads(*one, global_batch=B, flip={(net, l): m})
+            for f in range(NF):
+                slack_P[f"emb{f}"][csp[bi, f]] += np.abs(g1["emb"][0, f] - g0["emb"][0, f])
+            for nm in ("bot", "top"):
+                for ll in range(len(g0[nm])):
+                    slack_P[f"{nm}_w{ll}"] += np.abs(g1[nm][ll][0] - g0[nm][ll][0]); slack_P[f"{nm}_b{ll}"] += np.abs(g1[nm][ll][1] - g0[nm][ll][1])
+    pred_ref = o.inference(de, csp)
+    ref_loss = o.step(de, csp, la, orc.SGD(lr))
+    runs = [_device_run(False, seed, dense_start, [(de, sp, csp, la)], lambda rt: rt.Optimizer.sgd(lr), rows_of, spare) for _ in range(2)]
+    assert_same_bits(runs[0], runs[1])
+    got = runs[0]
+    assert abs(got["loss"][0] - ref_loss) <= TOL * abs(ref_loss) and np.abs(got["pred0"] - pred_ref).max() <= 2e-6
+    want, start = {}, {}
+    for f in range(NF):
+        want[f"emb{f}"], start[f"emb{f}"] = o.emb[f], e0[f]
+    for nm, layers in (("bot", o.bot), ("top", o.top)):
+        for l, (W, b_) in enumerate(layers):
+            want[f"{nm}_w{l}"], start[f"{nm}_w{l}"] = W, dense_start[(nm, l)][0]
+            want[f"{nm}_b{l}"], start[f"{nm}_b{l}"] = b_, dense_start[(nm, l)][1]
+    worst, used = {}, 0
+    for k in want:
+        w0 = np.asarray(start[k], np.float64)
+        d_got, d_want = np.asarray(got[k], np.float64).reshape(w0.shape) - w0, np.asarray(want[k], np.float64) - w0
+        ulp = float(np.spacing(np.float32(max(np.abs(w0).max(), np.abs(want[k]).max()))))
+        base = TOL * np.abs(d_want).max() + (K + 1) * ulp
+        bound = base + lr * slack_P[k]
+        err = np.abs(d_got - d_want)
+        worst[k] = float((err / bound).max())
+        used += int((err > base).sum())                                # elements that needed their tie allowance
+        assert (err <= bound).all(), f"{k}: {int((err > bound).sum())} elements beyond the tie-aware bound, worst {worst[k]:.3g} x"
+    record("c5_exact_sgd_ties_present", ties=len(ties), samples_with_ties=len(by_sample), elements_on_tie_allowance=used,
+           worst=max(worst.values()))

@@ -136,3 +136,56 @@ def test_full_size_lazy_adam_matches_the_c_oracles_dense_rule():
     assert np.abs(opt.slot(tV, 0) - cpu.m[1]).max() <= TOL * np.abs(cpu.m[1]).max()
     untouched_u = np.ones(NU, bool); untouched_u[uid.reshape(-1)] = False      # m = v = 0 there: the rule moves nothing
     assert untouched_u.sum() > 0.5 * NU and np.array_equal(gU[untouched_u], U0[untouched_u])
+
+
+@pytest.mark.parametrize("model,D,censor", [("bpr", 64, False), ("ucml", 128, True)])
+def test_the_form_the_driver_times_matches_the_c_oracle(model, D, censor):
+    """bench.py's protocol at configs[1] / configs[2] sizes, held to the C oracle on EVERY element's update: one context, the
+    per-call buffers reserved, ids resident in HBM, two warm-up calls, then ONE K = 20 call with no loss fetch -- a LATER call
+    of the context, which plans without the read-back (staging off, rows referenced >= 3 times on fp32 atomics), with pairing on.
+    The other full-size tests make one call of a fresh shape each, which takes the read-back form."""
+    import torch
+    from openrec_amd import runtime as rt
+    from oracle import c_oracle
+    NU = NI = 1_000_000
+    B, W, K = 65536, 5, 20
+    U, V, b = _tables(NU, NI, D, 11)
+    if censor:
+        U[::10] *= 0.2; V[::10] *= 0.2
+    rng = np.random.default_rng(12)
+    uid = rng.integers(0, NU, (W + K, B)).astype(np.int32); pid = rng.integers(0, NI, (W + K, B)).astype(np.int32)
+    nid = rng.integers(0, NI, (W + K, B)).astype(np.int32)
+    ctx = rt.Context(0)
+    tU = rt.Table(NU, D, ctx).write(U); tV = rt.Table(NI, D, ctx).write(V); tb = rt.Table(NI, 1, ctx).write(b)
+    opt = rt.Optimizer.sgd(0.05, ctx=ctx)
+    U0, V0, b0 = U.copy(), V.copy(), b.copy()
+    du, dp, dn = (torch.from_numpy(x).cuda().contiguous() for x in (uid, pid, nid))
+    torch.cuda.synchronize()
+    rt.pairwise_reserve(opt, tU, tV, tb, K, B)
+    w1 = W - W // 2
+    losses = []
+    for first, count in ((0, w1), (w1, W // 2)):                                    # bench.py: the warm-up goes in two calls
+        l, l2 = rt.pairwise_step(model, opt, tU, tV, tb, du[first:first + count], dp[first:first + count], dn[first:first + count],
+                                 K=count, B=B, margin=0.5, censor=censor)
+        losses += list(zip(l, l2))
+    nowait_before = ctx.stat("nowait_calls")
+    assert ctx.stat("quiet") == 1, "uniform ids over 1M rows must leave quiet plan counters"
+    r = rt.pairwise_step(model, opt, tU, tV, tb, du[W:], dp[W:], dn[W:], K=K, B=B, margin=0.5, censor=censor, want_loss=False)
+    assert r is None
+    ctx.synchronize()
+    assert ctx.stat("nowait_calls") == nowait_before + 1, "the timed call of the driver's protocol must not wait for its plan's counters"
+    assert ctx.stat("pairs") > 0, "pairing was idle in the timed call"
+    cpu = c_oracle.PairwiseCPU(model, "sgd", U, V, b, lr=0.05)
+    for s in range(W + K):
+        lw, l2w = cpu.step(uid[s], pid[s], nid[s])
+        if s < W:
+            assert abs(losses[s][0] - lw) <= 1e-5 * abs(lw) and abs(losses[s][1] - l2w) <= 1e-5 * abs(l2w)
+        if censor:
+            c_oracle.censor(U, uid[s]); c_oracle.censor(V, pid[s]); c_oracle.censor(V, nid[s])
+    gU, gV, gb = tU.read(), tV.read(), tb.read()
+    for name, w0, got, want in (("user", U0, gU, U), ("item", V0, gV, V), ("item_bias", b0, gb, b)):
+        assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), name
+        coef = delta_check(w0, got, want, steps=(W + K) * (3 if censor else 1), what=f"driver form {model} {name}")
+        assert abs(coef - 1.0) <= 1e-4, (name, coef)
+    untouched_u = np.ones(NU, bool); untouched_u[uid.reshape(-1)] = False
+    assert untouched_u.sum() > 0.1 * NU and np.array_equal(gU[untouched_u], U0[untouched_u])
