@@ -75,6 +75,14 @@ struct orx_dlrm {
     std::vector<void*> bot_y16;         // output of bottom layer l (l < last), [cap][up8(out)]
     float* colpart = nullptr;           // pool of the layers' partial rows
     int32_t* d_idx_all = nullptr; int64_t idx_all_cap = 0;          // combined row ids of a chunk of steps (planned sparse apply)
+    unsigned char* d_single = nullptr; int64_t single_cap = 0;       // [chunk][B F]: lookups whose row nobody else references in their step
+    // set by orx_dlrm_step for the backward of the current step: those rows are updated by the interaction backward itself
+    const unsigned char* fuse_single = nullptr; orx_opt* fuse_opt = nullptr;
+    // the loss folded into the head's backward (orx_dlrm_step, fp16 mode with the 1-unit head kernels): set for the backward of the
+    // current step; `hl_used` says the head branch took it
+    double* d_loss_part = nullptr; int64_t loss_part_cap = 0; const HeadLoss* cur_hl = nullptr; bool hl_used = false;
+    // fp16 copies of the dense features of ALL steps of a call (ids on the device: one cast launch per call instead of one per step)
+    void* dense16_all = nullptr; int64_t dense16_all_cap = 0; const void* dense16_cur = nullptr;
     int32_t* d_sparse_all = nullptr; int64_t sparse_all_cap = 0;
     DenseParam* d_params = nullptr;     // descriptors of the dense parameters for the multi-tensor optimizer launch
     orx_opt* params_opt = nullptr;
@@ -231,6 +239,7 @@ extern "C" int orx_dlrm_destroy(orx_dlrm* m) {
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     free_buffers(m);
+    hipFree(m->d_single); hipFree(m->d_loss_part); hipFree(m->dense16_all);
     hipFree(m->d_offset); hipFree(m->d_colwin); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params); hipFree(m->d_fused); hipFree(m->d_idx_all); hipFree(m->d_sparse_all); hipFree(m->d_tiny_f); hipFree(m->d_is_tiny); hipFree(m->d_flatseg);
     orx_table_destroy(m->emb);
     for (auto& d : m->bot) { orx_table_destroy(d.W); orx_table_destroy(d.b); hipFree(d.w16); hipFree(d.w16t); }
@@ -397,7 +406,8 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
     const float* x = bt.dense; int64_t ldx = m->dense_dim;
     const bool bot16 = m->gen2 && m->dense16 != nullptr;
     const void* bx16 = m->dense16; int64_t ldbx16 = m->ld_dense16;
-    if (bot16) CHECK(orx_launch_cast16(c, bt.dense, m->dense_dim, m->dense16, m->ld_dense16, (int)B, m->dense_dim));
+    if (bot16 && m->dense16_cur != nullptr) bx16 = m->dense16_cur;           // (cast for all steps of the call at once: orx_dlrm_step)
+    else if (bot16) CHECK(orx_launch_cast16(c, bt.dense, m->dense_dim, m->dense16, m->ld_dense16, (int)B, m->dense_dim));
     for (size_t l = 0; l < m->bot.size(); ++l) {
         const DenseLayer& L = m->bot[l];
         const bool last = l + 1 == m->bot.size();
@@ -541,8 +551,10 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
             CHECK(orx_table_scratch(Bl.b));
             const bool below16 = Bl.dw16 && orx_gemm16_nt_ok(Bl.out, Bl.ld16, Bl.in, Bl.out);
             ColPart pW = colpart_of(D.gwpart), pb = colpart_of(D.gbpart), pbb = colpart_of(Bl.gbpart);
+            const HeadLoss* hl = (which == 1 && l == (int)L.size() - 1) ? m->cur_hl : nullptr;
             CHECK(orx_launch_head_bwd(c, (*ins16)[l], (*ld_in16)[l], D.w16t, dy, outs[l], D.act, Bl.act, &pW, &pb,
-                                      m->g16, Bl.out, below16 ? nullptr : other, ld_in[l], &pbb, (int)B, D.in));
+                                      m->g16, Bl.out, below16 ? nullptr : other, ld_in[l], &pbb, (int)B, D.in, hl));
+            if (hl) m->hl_used = true;
             add_job(pW, D.W->gsum, D.in); add_job(pb, D.b->gsum, 1); add_job(pbb, Bl.b->gsum, Bl.out);
             act_done = true; dy16 = m->g16; dy32 = !below16;
             float* t = dy; dy = other; other = t;
@@ -561,8 +573,13 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
             add_job(pb, D.b->gsum, D.out);
         }
         act_done = false;
+        // (round 6) layers whose two backward products cannot fill the chip alone run them in ONE launch (gemm16_group_kernel): both read dZ16
+        const bool nt_here = want_dx && s16 && dy16 != nullptr && m->gen2 && orx_gemm16_nt_ok(D.out, D.ld16, D.in, D.out);
+        const bool grouped = D.dw16 && nt_here && ins16 && (*ins16)[l] && orx_gemm16_group_ok(c, (int)B, D.in, D.out, (*ld_in16)[l], D.ld16);
         // gW [in, out] = X^T * dZ
-        if (D.dw16) {
+        if (grouped) {
+            if (D.slab_S > 1) ++slabs;
+        } else if (D.dw16) {
             ORX_ARG(dy16 != nullptr && ins16 && (*ins16)[l], "dlrm backward: fp16 operands missing for layer %d", l);
             // (tried: these products on a second stream beside the input-gradient chain -- they only feed the optimizer.  The step
             // went from 0.6125 to 0.628 ms: side by side the products slow each other down by more than the overlap gains.)
@@ -588,6 +605,12 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
                         const bool y16 = L[l - 1].lean;
                         ORX_ARG(!y16 || (outs16 && (*outs16)[l - 1]), "dlrm backward: fp16 activation missing for layer %d", l - 1);
                         ColPart pbb = colpart_of(L[l - 1].gbpart);
+                        if (grouped)
+                            CHECK(orx_launch_gemm16_group(c, (*ins16)[l], (*ld_in16)[l], dy16, D.out, D.W->gsum, D.out, D.slab, D.in, D.out, (int)B, inv_scale,
+                                                          D.w16, D.ld16, below16 ? nullptr : other, ld_in[l], next16, L[l - 1].out,
+                                                          y16 ? nullptr : outs[l - 1], y16 ? (*outs16)[l - 1] : nullptr,
+                                                          y16 ? (int64_t)up8(L[l - 1].out) : ld_out[l - 1], L[l - 1].act, &pbb));
+                        else
                         CHECK(orx_launch_gemm16_nt(c, dy16, D.out, D.w16, D.ld16, below16 ? nullptr : other, ld_in[l], next16, L[l - 1].out,
                                                    nullptr, (int)B, D.in, D.out, 0, y16 ? nullptr : outs[l - 1], y16 ? (*outs16)[l - 1] : nullptr,
                                                    y16 ? (int64_t)up8(L[l - 1].out) : ld_out[l - 1], L[l - 1].act, &pbb));
@@ -603,7 +626,10 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
                     }
                     act_done = true;
                 } else {
-                    if (nt) CHECK(orx_launch_gemm16_nt(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, (int)B, D.in, D.out, 0));
+                    if (nt && grouped)
+                        CHECK(orx_launch_gemm16_group(c, (*ins16)[l], (*ld_in16)[l], dy16, D.out, D.W->gsum, D.out, D.slab, D.in, D.out, (int)B, inv_scale,
+                                                      D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, nullptr, 0, 0, nullptr));
+                    else if (nt) CHECK(orx_launch_gemm16_nt(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, (int)B, D.in, D.out, 0));
                     else CHECK(orx_launch_gemm_f16s(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, (int)B, D.in, D.out, 0));
                     dy32 = true;
                 }
@@ -650,9 +676,16 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale, bool 
     CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR, gscale, defer_slabs, m->gen2 ? &ins16 : nullptr, &ldi16, &outs16, &coljobs));
     // ---- interaction backward: dZ for every slot (slot F-1 = d dense_emb)
     // (dR carries the loss scale; dZ -- the embedding rows' gradients -- leaves unscaled)
-    CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B, m->ldR, nullptr, 0, nullptr,
-                              m->direct_idx ? m->direct_base : nullptr, m->direct_idx, m->direct_idx ? m->direct_rows : 0, 1.0f / gscale,
-                              m->ext_rows ? m->ext_gdst : nullptr));
+    {
+        // (round 6) the rows referenced once in the step take their SGD / Adagrad update inside this launch (kernels_dense.hip FusedRows)
+        const bool fuse = m->fuse_single != nullptr && m->direct_idx != nullptr && m->ext_rows == nullptr && m->emb != nullptr && m->direct_base == m->emb->w;
+        float* acc_rows = nullptr;
+        if (fuse && m->fuse_opt->kind == ORX_ADAGRAD) { OptSlots st; CHECK(orx_opt_slots(m->fuse_opt, m->emb, &st)); acc_rows = st.s0; }
+        CHECK(orx_launch_interact(c, false, m->Z, dR, F, d, compat, itself, m->dZ, m->P, B, m->ldR, nullptr, 0, nullptr,
+                                  m->direct_idx ? m->direct_base : nullptr, m->direct_idx, m->direct_idx ? m->direct_rows : 0, 1.0f / gscale,
+                                  m->ext_rows ? m->ext_gdst : nullptr, fuse ? m->fuse_single : nullptr, fuse ? m->fuse_opt->kind : 0,
+                                  fuse ? m->fuse_opt->lr : 0.f, fuse ? m->fuse_opt->p1 : 0.f, acc_rows));
+    }
     // ---- bottom MLP backward from dZ[:, F-1, :]
     float* dy = (dR == m->gA) ? m->gB : m->gA;
     float* other = (dy == m->gA) ? m->gB : m->gA;
@@ -667,7 +700,7 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale, bool 
     const bool bot16 = m->gen2 && m->dense16 != nullptr;
     if (bot16)
         for (size_t l = 0; l < m->bot.size(); ++l) {
-            ins16.push_back(l == 0 ? m->dense16 : m->bot_y16[l - 1]); ldi16.push_back(l == 0 ? m->ld_dense16 : up8(m->bot[l - 1].out));
+            ins16.push_back(l == 0 ? (m->dense16_cur ? m->dense16_cur : m->dense16) : m->bot_y16[l - 1]); ldi16.push_back(l == 0 ? m->ld_dense16 : up8(m->bot[l - 1].out));
             outs16.push_back(l + 1 < m->bot.size() ? m->bot_y16[l] : nullptr);
         }
     // (the bottom MLP's dY = gscale * dZ[:, F-1, :]: its first activation backward reads the slice in place)
@@ -739,12 +772,42 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         }
     }
     if (sorted_apply && !lazy_adam) CHECK(orx_table_sync(m->emb));
+    // (round 6) SGD / Adagrad: a row that a single lookup of the step references is updated by the interaction backward itself
+    // (kernels_dense.hip FusedRows); the sorted list names those lookups for free.  ORX_DLRM_NO_FUSED_SPARSE=1: every row through the sorted apply
+    const bool fuse_rows = sorted_apply && !lazy_adam && (opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD) &&
+                           orx_interact_fuse_ok(F, d, (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0);
+    if (fuse_rows && m->single_cap < PC * B * F) {
+        if (m->d_single) ORX_HIP(hipFree(m->d_single));
+        ORX_HIP(hipMalloc((void**)&m->d_single, (size_t)(PC * B * F))); m->single_cap = PC * B * F;
+    }
+    // (round 6) fewer launches per step: the loss is folded into the head's backward where the 1-unit head kernels run (its value leaves
+    // as per-workgroup partials, summed once per call), and the fp16 copy of the dense features is made for all K steps at once
+    const bool fold_loss = m->gen2 && m->top.size() >= 2 && m->top.back().head && m->g16 != nullptr && getenv("ORX_DLRM_NO_FOLDED_LOSS") == nullptr;
+    const int nb_loss = orx_head_bwd_blocks(c, (int)B);
+    if (fold_loss && m->loss_part_cap < K * nb_loss) {
+        if (m->d_loss_part) ORX_HIP(hipFree(m->d_loss_part));
+        const int64_t cap = std::max<int64_t>(K, 64) * nb_loss;
+        ORX_HIP(hipMalloc((void**)&m->d_loss_part, sizeof(double) * cap)); m->loss_part_cap = cap;
+    }
+    const bool cast_all = m->gen2 && m->dense16 != nullptr && (flags & ORX_IDS_DEVICE) && getenv("ORX_DLRM_CAST_PER_STEP") == nullptr;
+    if (cast_all) {
+        if (m->dense16_all_cap < K * B) {
+            if (m->dense16_all) ORX_HIP(hipFree(m->dense16_all));
+            const int64_t cap = std::max<int64_t>(K, 64) * B;
+            ORX_HIP(hipMalloc(&m->dense16_all, (size_t)cap * m->ld_dense16 * 2)); m->dense16_all_cap = cap;
+        }
+        ORX_ARG(K * B < (1LL << 31), "orx_dlrm_step: K * B must stay below 2^31");
+        CHECK(orx_launch_cast16(c, dense, m->dense_dim, m->dense16_all, m->ld_dense16, (int)(K * B), m->dense_dim));
+    }
+    struct Restore { orx_dlrm* m; ~Restore() { m->dense16_cur = nullptr; m->cur_hl = nullptr; m->fuse_single = nullptr; m->fuse_opt = nullptr; } } restore{m};
     for (int64_t s = 0; s < K; ++s) {
+        m->dense16_cur = cast_all ? (const char*)m->dense16_all + (size_t)s * B * m->ld_dense16 * 2 : nullptr;
         if ((planned || sorted_apply) && s % PC == 0) {
             const int64_t kp = std::min<int64_t>(K - s, PC);
             CHECK(orx_launch_dlrm_ids(c, sparse_dev + s * B * m->n_emb, m->d_offset, m->d_rows, m->n_emb, kp * B, m->d_idx_all));
             if (planned) CHECK(orx_apply_rows_plan(c, m->emb, m->d_idx_all, kp, B * F, B * F, &rp));
             else CHECK(orx_rows_sort(c, m->d_idx_all, kp, B * F, B * F, m->emb->rows, &sorted));
+            if (fuse_rows) CHECK(orx_rows_single_flags(c, sorted, kp, B * F, m->emb->rows, m->d_single));
         }
         const int32_t* idx_s = (planned || sorted_apply) ? m->d_idx_all + (s % PC) * B * F : nullptr;
         const uint2* sorted_s = sorted_apply ? sorted + (s % PC) * B * F : nullptr;
@@ -770,9 +833,16 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         float* pred = m->top_y.back();
         // loss + dLoss/dP  (dlrm.py:72-73, :97-98)
         const float gscale = loss_scale(m, B);
-        CHECK(orx_launch_dlrm_loss(c, pred, bt.label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, m->d_loss + s, 0, 0, gscale));
+        HeadLoss hl{bt.label, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, B, gscale, fold_loss ? m->d_loss_part + s * nb_loss : nullptr};
+        if (!fold_loss) CHECK(orx_launch_dlrm_loss(c, pred, bt.label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, m->d_loss + s, 0, 0, gscale));
+        m->cur_hl = fold_loss ? &hl : nullptr; m->hl_used = false;
         const bool fuse_dense = m->gen2 && getenv("ORX_DLRM_NO_FUSED_DENSE") == nullptr;
-        CHECK(backward(m, bt, B, gscale, fuse_dense));
+        m->fuse_single = fuse_rows ? m->d_single + (s % PC) * B * F : nullptr; m->fuse_opt = opt;
+        const int rc_bwd = backward(m, bt, B, gscale, fuse_dense);
+        const bool rows_fused = m->fuse_single != nullptr && m->direct_idx != nullptr;      // (backward applied them: see there)
+        m->fuse_single = nullptr; m->fuse_opt = nullptr; m->cur_hl = nullptr;
+        CHECK(rc_bwd);
+        ORX_ARG(!fold_loss || m->hl_used, "dlrm step: the loss was to be folded into the head's backward, which did not run");
         // (tried, round 4: the sorted sparse apply on a second stream beside the bottom MLP's backward and the dense apply -- 0.578 against
         // 0.580 ms per step: the launches fill the chip one after the other either way.)
         // ---- optimizer: one step counter for all variables (Keras `iterations`)
@@ -786,7 +856,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         if (sorted_apply) {
             if (lazy_adam) CHECK(orx_adam_rows_sorted(c, opt, m->emb, sorted_s, B * F, m->dZ, d, true));
             else if (opt->kind == ORX_ADAM) CHECK(orx_adam_dense_sorted(c, opt, m->emb, sorted_s, B * F, m->dZ, d));
-            else CHECK(orx_csr_apply(c, opt, m->emb, sorted_s, B * F, m->dZ, d));
+            else CHECK(orx_csr_apply(c, opt, m->emb, sorted_s, B * F, m->dZ, d, rows_fused));
         } else if (planned) {
             CHECK(orx_apply_rows_planned_step(c, opt, m->emb, nullptr, rp, s % PC, idx_s, m->dZ, d));
         } else if (lazy_adam) {
@@ -805,6 +875,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         }
         CHECK(dense_apply_all(m, opt, lr_t, fuse_dense, 1.0f / gscale));
     }
+    if (fold_loss) CHECK(orx_launch_head_loss_finish(c, m->d_loss_part, nb_loss, nb_loss, K, B, m->d_loss));
     if (loss_out) {
         std::vector<double> h((size_t)K);
         ORX_HIP(hipMemcpyAsync(h.data(), m->d_loss, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));

@@ -824,9 +824,21 @@ __global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(RowSrc src, int 
 // (round 4: NSAMP samples per wavefront in turn, the next sample's rows requested before the current sample's products -- 2 samples:
 // no change, 0.5547 against 0.5546 ms per step; 4 / 8 samples: +2 % / +9 %, too few wavefronts.  The launch is not the sum of one
 // wavefront's phases; the random 512-byte rows set its pace.)
-template <int CPL, int SPLIT>
+// FUSE (round 6; north_star's "one pass": dlrm.py:83-85 + second_order_feature_interaction.py:20-32 + tf2_examples/dlrm_criteo.py:45-46):
+// the sparse SGD / Adagrad rule is applied HERE to every embedding row that no other lookup of the step references (`single`, made
+// from the step's sorted id list: orx_rows_single_flags) -- the wavefront that forms the row's gradient is the only reader and
+// the only writer of the row in this step, so w - lr * g goes straight into the table and the gradient never reaches HBM (no dZ row
+// written, none read back by the sorted apply, whose table-row read goes too).  Rows with several references keep the
+// deterministic sorted path (csr_apply_kernel with skip_single).
+struct FusedRows {
+    const unsigned char* single;       // [B][F] flags
+    float* W; float* A;                // the table (= src.emb) and the Adagrad accumulators
+    int kind; float lr, eps;           // ORX_SGD | ORX_ADAGRAD
+};
+
+template <int CPL, int SPLIT, bool FUSE>
 __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, const float* dR, int F, int itself, float* dZ,
-                                                                int64_t B, int ldR, float scale) {
+                                                                int64_t B, int ldR, float scale, FusedRows fr) {
     constexpr int d = 16 * CPL * SPLIT;
     const int lane = threadIdx.x & 63;
     const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -874,6 +886,15 @@ __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, cons
             if (c4 + 2 < CPL) zr[s][c4 + 2] = v.z; if (c4 + 3 < CPL) zr[s][c4 + 3] = v.w;
         }
     }
+    // FUSE: which of the sample's lookups are applied here (bit g of the wavefront-uniform mask) and their rows
+    unsigned fmask = 0u; int myrow = -1;
+    if (FUSE) {
+        if (lane < F - 1) {
+            myrow = src.idx[b * F + lane];
+            if (fr.single[b * F + lane] && (uint32_t)myrow < (uint64_t)src.rows) fmask = 1u;
+        }
+        fmask = (unsigned)__ballot(fmask != 0u);
+    }
     f32x4 acc[2][CPL];
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
@@ -891,6 +912,7 @@ __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, cons
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int g = 16 * ti + q * 4 + r;
+            const int rowg = FUSE ? __shfl(myrow, g) : 0;                // (all lanes still active here: lane g is a valid source)
             if (g >= F) continue;
             float* out = dZ + (b * F + g) * d + coff + CPL * i;
             if (src.gdst != nullptr && g != F - 1) {
@@ -901,6 +923,31 @@ __global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, cons
             float o[CPL];
 #pragma unroll
             for (int t = 0; t < CPL; ++t) o[t] = (acc[ti][t][r] + (g == F - 1 ? rb[coff + CPL * i + t] : 0.0f)) * scale;
+            if (FUSE && CPL >= 4 && ((fmask >> g) & 1u)) {
+                // the row is this wavefront's alone: its CPL columns come back from L2 (the B operand above holds the same row in
+                // another lane), the rule of csr_rule (kernels_rowsort.hip) is applied, the new row is written in place
+                const size_t at = (size_t)rowg * d + coff + CPL * i;
+                float* wp = fr.W + at;
+#pragma unroll
+                for (int t = 0; t < CPL; t += 4) {
+                    f32x4 w = *reinterpret_cast<const f32x4*>(wp + t);
+                    if (fr.kind == ORX_ADAGRAD) {
+                        f32x4 av = *reinterpret_cast<const f32x4*>(fr.A + at + t);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a2 = av[e] + o[t + e] * o[t + e];
+                            av[e] = a2;
+                            w[e] = w[e] - fr.lr * o[t + e] / (sqrtf(a2) + fr.eps);
+                        }
+                        *reinterpret_cast<f32x4*>(fr.A + at + t) = av;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = w[e] - fr.lr * o[t + e];
+                    }
+                    *reinterpret_cast<f32x4*>(wp + t) = w;
+                }
+                continue;
+            }
             if (CPL >= 4) {
 #pragma unroll
                 for (int t = 0; t < CPL; t += 4) { f32x4 v; v.x = o[t]; v.y = o[t + 1]; v.z = o[t + 2]; v.w = o[t + 3]; *reinterpret_cast<f32x4*>(out + t) = v; }
@@ -916,9 +963,15 @@ bool orx_interact_direct_ok(int F, int d, int compat) {
            getenv("ORX_DLRM_NO_DIRECT") == nullptr;
 }
 
+// can orx_launch_interact's backward apply the rows referenced once in place (see FusedRows)?
+bool orx_interact_fuse_ok(int F, int d, int compat) {
+    return orx_interact_direct_ok(F, d, compat) && d >= 64 && getenv("ORX_DLRM_NO_FUSED_SPARSE") == nullptr;
+}
+
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
                         float* out, int P, int64_t B, int ldR, void* R16, int ldR16, bool* wrote16,
-                        const float* emb, const int32_t* idx, int64_t emb_rows, float scale, float* gdst) {
+                        const float* emb, const int32_t* idx, int64_t emb_rows, float scale, float* gdst,
+                        const unsigned char* single, int opt_kind, float lr, float eps, float* acc_rows) {
     if (wrote16) *wrote16 = false;
     if (B == 0) return ORX_OK;
     const bool mfma = !compat && F <= 32 && d % 32 == 0 && ((uintptr_t)Z & 15) == 0 && getenv("ORX_INTERACT_SIMPLE") == nullptr;
@@ -933,10 +986,20 @@ int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR,
             ORX_LAUNCH(ctx, interact_fwd_mfma_kernel, g, dim3(256), (size_t)4 * std::max(ldR, R16 ? ldR16 : 0) * sizeof(float), src, F, d, itself, out, B, ldR, (_Float16*)R16, R16 ? ldR16 : 0);
             if (wrote16 && R16) *wrote16 = true;
         }
-        else if (d == 32) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<2, 1>), g, dim3(256), (size_t)4 * ldR * sizeof(float), src, dR, F, itself, out, B, ldR, scale);
-        else if (d == 64) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4, 1>), g, dim3(256), (size_t)4 * ldR * sizeof(float), src, dR, F, itself, out, B, ldR, scale);
-        else if (d == 128) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8, 1>), g, dim3(256), (size_t)4 * ldR * sizeof(float), src, dR, F, itself, out, B, ldR, scale);
-        else ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<16, 1>), g, dim3(256), (size_t)4 * ldR * sizeof(float), src, dR, F, itself, out, B, ldR, scale);
+        else {
+            FusedRows fr{single, const_cast<float*>(emb), acc_rows, opt_kind, lr, eps};
+            const bool fuse = single != nullptr;
+            ORX_ARG(!fuse || (emb != nullptr && gdst == nullptr && d >= 64 && (opt_kind == ORX_SGD || (opt_kind == ORX_ADAGRAD && acc_rows != nullptr))),
+                    "interact: the in-place apply needs direct table rows, d >= 64 and SGD / Adagrad");
+            const size_t shm = (size_t)4 * ldR * sizeof(float);
+            if (d == 32) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<2, 1, false>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
+            else if (d == 64 && fuse) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4, 1, true>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
+            else if (d == 64) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4, 1, false>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
+            else if (d == 128 && fuse) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8, 1, true>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
+            else if (d == 128) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8, 1, false>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
+            else if (fuse) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<16, 1, true>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
+            else ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<16, 1, false>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
+        }
         ORX_HIP(hipGetLastError());
         return ORX_OK;
     }

@@ -255,8 +255,9 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // and 32-bit per-lane offsets made once -- no vector arithmetic per request.
 // DBG (scratch/exp_dma.hip only): 1 = no epilogue, 2 = no DMA inside the loop, 4 = no fragment reads / MFMA, 16 = nontemporal stores, 32 = write-through stores,
 // 8 = with 1: the main loop's duration in shader cycles and in 100 MHz ticks goes to g.C as [workgroup][2] 64-bit counts
-template <int WM, int WN, int TM, int TN, int MINB, int NS, bool TAIL, int DBG = 0>
-__global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_dma_kernel(Nt16Args g) {
+// (the body is a device function of (workgroup index, number of workgroups of the product): gemm16_group_kernel runs several products in one grid)
+template <int WM, int WN, int TM, int TN, int NS, bool TAIL, int DBG = 0>
+__device__ __forceinline__ void gemm16_nt_dma_body(const Nt16Args& g, const int bid, const int nblk) {
     constexpr int BK = 64, BM = WM * TM * 16, BN = WN * TN * 16, NT = 64 * WM * WN;
     constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT, NL = NA + NB;            // DMA instructions per wavefront and tile
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile / thread mismatch");
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_dma_kernel(Nt16A
     extern __shared__ __attribute__((aligned(16))) _Float16 lds16[];
     constexpr int STAGE = (BM + BN) * BK;                                      // halves
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = xcd_slot(blockIdx.x, gridDim.x);
+    const int t = xcd_slot(bid, nblk);
     const int ntn = (g.N + BN - 1) / BN;
     const int bm = (t / ntn) * BM, bn = (t % ntn) * BN;
     const int wm = (wave / WN) * TM * 16, wn = (wave % WN) * TN * 16;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_dma_kernel(Nt16A
     if (s < nk) step(F(), F(), F(), s);
     if (DBG & 8) {
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();
-        if (threadIdx.x == 0) { unsigned long long* o = reinterpret_cast<unsigned long long*>(g.C) + 2 * blockIdx.x; o[0] = c1 - dbg_c0; o[1] = w1 - dbg_w0; }
+        if (threadIdx.x == 0) { unsigned long long* o = reinterpret_cast<unsigned long long*>(g.C) + 2 * bid; o[0] = c1 - dbg_c0; o[1] = w1 - dbg_w0; }
     }
     if (DBG & 1) {
         float x = 0.0f;
@@ -408,6 +409,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_dma_kernel(Nt16A
     }
     if (g.gb) __syncthreads();                                                 // (the column sums go through the stages' LDS)
     nt_epilogue<WM, WN, TM, TN, (DBG & 32) ? 2 : (DBG & 16) ? 1 : 0>(g, acc, bm, bn, wm, wn, reinterpret_cast<float*>(lds16));
+}
+
+template <int WM, int WN, int TM, int TN, int MINB, int NS, bool TAIL, int DBG = 0>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_nt_dma_kernel(Nt16Args g) {
+    gemm16_nt_dma_body<WM, WN, TM, TN, NS, TAIL, DBG>(g, (int)blockIdx.x, (int)gridDim.x);
 }
 
 template <int WM, int WN, int TM, int TN, int MINB, int NS>
@@ -614,15 +620,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_tn_kernel(Tn16Args 
 // the 16-byte chunk c of its 256 bytes at slot c ^ (2 * (r & 7)) -- chunk PAIRS stay adjacent and the eight rows of a cycle sit on
 // eight different quarters of the banks (what the 288-byte pitch does for the register-staged kernel).
 // TAIL: a tile reaches beyond a leading dimension or the slice ends inside a stage (zero chunk through per-lane addresses).
-template <int MINB, int NS, bool TAIL>
-__global__ __launch_bounds__(256, MINB) void gemm16_tn_dma_kernel(Tn16Args g) {
+template <int NS, bool TAIL>
+__device__ __forceinline__ void gemm16_tn_dma_body(const Tn16Args& g, const int bid, const int nblk) {
     constexpr int BK = 64, BM = 128, BN = 128, NT = 256, TM = 4, TN = 4, WN = 2;
     constexpr int NA = BK * (BM / 8) / NT, NB = BK * (BN / 8) / NT, NL = NA + NB;      // 4 + 4 requests per wavefront and stage
     extern __shared__ __attribute__((aligned(16))) _Float16 lds16[];
     constexpr int STAGE = BK * (BM + BN);                                      // halves
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM, nt = ntn * ntm;
-    const int t = xcd_slot(blockIdx.x, gridDim.x);
+    const int t = xcd_slot(bid, nblk);
     const int bz = t / nt, tile = t - bz * nt;
     const int bm = (tile / ntn) * BM, bn = (tile % ntn) * BN;
     const int wm = (wave / WN) * TM * 16, wn = (wave % WN) * TN * 16;
@@ -735,7 +741,7 @@ __global__ __launch_bounds__(256, MINB) void gemm16_tn_dma_kernel(Tn16Args g) {
         if (s + 1 < nk) { step(F(), T(), F(), s); ++s; }
         if (s < nk) step(F(), F(), F(), s);
     }
-    const int S = gridDim.x / nt;
+    const int S = nblk / nt;
     if (S > 1) {
         float* mine = g.slab + ((size_t)tile * S + bz) * SLAB_STRIDE;
 #pragma unroll
@@ -758,6 +764,24 @@ __global__ __launch_bounds__(256, MINB) void gemm16_tn_dma_kernel(Tn16Args g) {
             for (int e = 0; e < 4; ++e) if (c0 + e < g.N) g.C[(int64_t)row * g.ldc + c0 + e] += v[e] * g.out_scale;
         }
     }
+}
+
+template <int MINB, int NS, bool TAIL>
+__global__ __launch_bounds__(256, MINB) void gemm16_tn_dma_kernel(Tn16Args g) {
+    gemm16_tn_dma_body<NS, TAIL>(g, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---- grouped launch (round 6): the weight gradient X16^T dZ16 (tn) and the input gradient dZ16 W16^T (nt) of ONE layer -- independent
+// given dZ -- in one grid, for the layers whose products cannot fill the chip on their own (a [8192, 256] output is 64 tiles of
+// 256 x 128 on 256 CUs; each of the two launches cost 7-10 us for <= 1 GFLOP).  The weight-gradient workgroups come first (a split-K
+// slice of 128 x 128 is the longer piece), both bodies are the kernels above: same tiles, same summation order, same bits.
+// Two stages of LDS for the tn part (64 KB) and three for the 128 x 64 nt tile (72 KB): two workgroups per CU.
+struct Group16Args { Tn16Args tn; Nt16Args nt; int n_tn, n_nt; };
+template <bool TN_TAIL, bool NT_TAIL, int NTS>
+__global__ __launch_bounds__(256, 2) void gemm16_group_kernel(Group16Args g) {
+    const int b = (int)blockIdx.x;
+    if (b < g.n_tn) gemm16_tn_dma_body<2, TN_TAIL>(g.tn, b, g.n_tn);
+    else gemm16_nt_dma_body<2, 2, 4, 2, 3, NT_TAIL, NTS == 2 ? 32 : NTS == 1 ? 16 : 0>(g.nt, b - g.n_tn, g.n_nt);
 }
 
 // C += sum over the S slices of every tile; one launch serves all layers of an MLP backward.  grid = (max tiles, 8 parts, layers)
@@ -802,7 +826,12 @@ void orx_gemm16_tn_plan(orx_ctx* ctx, int M, int N, int K, int* S_out, int* tile
     // optimizer launch, 146 -> 73 MB each way at the C5 shapes; the products take the same time (0.290 ms), the step 0.558 -> 0.543 ms.
     // ORX_GEMM16_TN_PER_CU=2 with ORX_GEMM16_TN_DMA=2: the two-per-CU form
     static const int per_cu = getenv("ORX_GEMM16_TN_PER_CU") ? atoi(getenv("ORX_GEMM16_TN_PER_CU")) : 1;
-    const int S = std::max(1, std::min(32, (per_cu * cus) / tiles));
+    // (round 6) gradients of <= 16 tiles used to take 32 slices to fill the chip: a 512 x 256 gradient (0.5 MB) left 16.8 MB of slabs for the
+    // optimizer launch to read back.  Their weight-gradient workgroups now share a launch with the layer's input gradient
+    // (gemm16_group_kernel), which fills the chip: ORX_GEMM16_TN_SMALL_S slices (default 8) are enough.  32: the round-5 plan.
+    static const int small_s = getenv("ORX_GEMM16_TN_SMALL_S") ? atoi(getenv("ORX_GEMM16_TN_SMALL_S")) : 8;
+    int S = std::max(1, std::min(32, (per_cu * cus) / tiles));
+    if (tiles <= 16 && small_s >= 1) S = std::min(S, small_s);
     const int kchunk = std::max(64, (((K + S - 1) / S + 63) / 64) * 64);
     *S_out = S; *tiles_out = tiles; *kchunk_out = kchunk;
 }
@@ -840,6 +869,62 @@ int orx_launch_gemm16_tn(orx_ctx* ctx, const void* A16, int64_t lda, const void*
     auto kern = gemm16_tn_kernel<2, 2, 4, 4, 2>;
     ORX_ONCE_PER_DEVICE(ctx, ORX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)));
     ORX_LAUNCH(ctx, kern, dim3((unsigned)(tiles * S)), dim3(256), shm, g);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+// Can the two backward products of a layer [B, out] -> [B, in] share a launch (gemm16_group_kernel)?  Only where the input gradient takes
+// the 128 x 64 tile with three DMA stages and the weight gradient the DMA kernel -- the forms the grouped kernel carries -- i.e. where
+// neither product fills the chip alone.  ORX_GEMM16_NO_GROUP=1: separate launches (A/B measurements, the bit-identity test).
+bool orx_gemm16_group_ok(orx_ctx* ctx, int B, int in, int out, int64_t ldx16, int64_t ldw16) {
+    static const bool off = getenv("ORX_GEMM16_NO_GROUP") != nullptr;
+    static const int dma_nt = getenv("ORX_GEMM16_DMA") ? atoi(getenv("ORX_GEMM16_DMA")) : 3;
+    static const int dma_tn = getenv("ORX_GEMM16_TN_DMA") ? atoi(getenv("ORX_GEMM16_TN_DMA")) : 3;
+    static const bool forced = getenv("ORX_GEMM16_TILE") != nullptr;
+    if (off || forced || dma_nt != 3 || (dma_tn != 2 && dma_tn != 3)) return false;
+    const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+    auto blocks = [&](int bm, int bn) { return (int64_t)((B + bm - 1) / bm) * ((in + bn - 1) / bn); };
+    if (blocks(256, 128) >= cus || blocks(128, 128) >= 2 * cus) return false;                   // (the larger tiles: the product fills the chip)
+    // 32-bit byte offsets of the DMA requests: dZ16 [B][out], W16 [in][ldw16], X16 [B][ldx16]
+    if ((int64_t)B * out >= (1LL << 29) || (int64_t)in * ldw16 >= (1LL << 29) || (int64_t)B * ldx16 >= (1LL << 29)) return false;
+    return orx_gemm16_nt_ok(out, ldw16, in, out) && orx_gemm16_tn_ok(ldx16, out, out);
+}
+
+// dW [in][out] (+)= X16^T dZ16 (slabs when the plan splits K) and dX = dZ16 W16^T with the fused activation backward of the layer below,
+// one launch: the arguments of orx_launch_gemm16_tn followed by those of orx_launch_gemm16_nt
+int orx_launch_gemm16_group(orx_ctx* ctx, const void* X16, int64_t ldx, const void* dZ16, int64_t lddz, float* gW, int64_t ldgw, float* slab,
+                            int in, int out, int B, float out_scale,
+                            const void* W16, int64_t ldw, float* C, int64_t ldc, void* C16, int64_t ldc16,
+                            const float* actY, const void* actY16, int64_t ldy, int act_y, ColPart* gbp) {
+    if (B == 0 || in == 0 || out == 0) return ORX_OK;
+    ORX_ARG(ldx % 8 == 0 && lddz % 8 == 0 && ldw % 8 == 0 && (((uintptr_t)X16 | (uintptr_t)dZ16 | (uintptr_t)W16) & 15) == 0, "gemm16_group: operands need 16-byte rows");
+    ProfScope ps(ctx, ORX_K_GEMM);
+    int S, tiles, kchunk;
+    orx_gemm16_tn_plan(ctx, in, out, B, &S, &tiles, &kchunk);
+    ORX_ARG(S == 1 || slab != nullptr, "gemm16_group: split-K needs a slab workspace");
+    Group16Args g;
+    g.tn = Tn16Args{(const _Float16*)X16, ldx, (const _Float16*)dZ16, lddz, gW, ldgw, slab, in, out, B, kchunk, out_scale};
+    g.nt = Nt16Args{(const _Float16*)dZ16, lddz, (const _Float16*)W16, ldw, C, ldc, (_Float16*)C16, ldc16, nullptr, B, in, out, 0,
+                    actY, (const _Float16*)actY16, ldy, act_y, gbp ? gbp->parts : nullptr};
+    if (gbp) gbp->P = (B + 127) / 128;
+    g.n_tn = tiles * S;
+    g.n_nt = ((B + 127) / 128) * ((in + 63) / 64);
+    const bool tn_tail = (B & 63) != 0 || kchunk % 64 != 0 || (int64_t)((in + 127) / 128) * 128 > ldx || (int64_t)((out + 127) / 128) * 128 > lddz;
+    const bool nt_tail = (lddz & 63) != 0 || (ldw & 63) != 0;
+    static const int nts_env = getenv("ORX_GEMM16_NTS") != nullptr ? atoi(getenv("ORX_GEMM16_NTS")) : 2;
+    const int nts = nts_env >= 0 && nts_env <= 2 ? nts_env : 0;
+    using K = void (*)(Group16Args);
+    static const K kerns[3][2][2] = {
+        {{gemm16_group_kernel<false, false, 0>, gemm16_group_kernel<false, true, 0>}, {gemm16_group_kernel<true, false, 0>, gemm16_group_kernel<true, true, 0>}},
+        {{gemm16_group_kernel<false, false, 1>, gemm16_group_kernel<false, true, 1>}, {gemm16_group_kernel<true, false, 1>, gemm16_group_kernel<true, true, 1>}},
+        {{gemm16_group_kernel<false, false, 2>, gemm16_group_kernel<false, true, 2>}, {gemm16_group_kernel<true, false, 2>, gemm16_group_kernel<true, true, 2>}}};
+    constexpr size_t shm = 3 * (128 + 64) * 64 * 2;                // (>= the tn part's two stages of 64 x 256 halves)
+    static_assert(shm >= 2 * 64 * 256 * 2, "LDS of the grouped launch");
+    ORX_ONCE_PER_DEVICE(ctx, {
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 2; ++b) for (int c2 = 0; c2 < 2; ++c2)
+            ORX_HIP(hipFuncSetAttribute((const void*)kerns[a][b][c2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    });
+    ORX_LAUNCH(ctx, kerns[nts][tn_tail ? 1 : 0][nt_tail ? 1 : 0], dim3((unsigned)(g.n_tn + g.n_nt)), dim3(256), shm, g);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }
@@ -912,11 +997,16 @@ struct HeadBwdArgs {
     float* dZ32; int64_t ld32;           // optional
     float* gb_below;                     // [blocks][K] partial sums
     int B, K, rows_per_block;
+    // round 6: the loss folded in (label != NULL; no dlrm_loss_kernel launch in the step) -- dy is formed here from pred and the label
+    // (dlrm.py:72-73, :97-98; the formulas of dlrm_loss_kernel), the loss terms leave as one fp64 partial per workgroup
+    const float* label; int bce; float thr, invB, gscale; double* loss_part;
 };
 
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     __shared__ float red[8][HEAD_KMAX / 8][8 + 1];             // [half-wave][chunk][e]  (padded), used twice
     __shared__ float red_b[8];
+    __shared__ double red_l[8];
+    double lsum = 0.0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l32 = lane & 31;
     const int hw = wave * 2 + half;                            // 8 half-wavefronts, each takes every 8th row of the block's slab
     const int r0 = blockIdx.x * a.rows_per_block, r1 = min(a.B, r0 + a.rows_per_block);
@@ -931,8 +1021,31 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     }
     float gb = 0.0f;
     for (int row = r0 + hw; row < r1; row += 8) {
-        const float p = a.pred[row];
-        float dz = a.dy[row];
+        float p = a.pred[row];
+        float dz;
+        if (a.label != nullptr) {
+            float mask = 1.0f;
+            if (a.thr > 0.0f && a.thr < 1.0f) {                     // dlrm.py:97-98
+                mask = (p >= a.thr && p <= 1.0f - a.thr) ? 1.0f : 0.0f;
+                p = fminf(fmaxf(p, a.thr), 1.0f - a.thr);
+            }
+            const float t = a.label[row];
+            float g;
+            if (!a.bce) {                                           // keras.losses.MeanSquaredError
+                const float r = t - p;
+                if (l32 == 0) lsum += (double)(r * r);
+                g = 2.0f * (p - t) * a.invB;
+            } else {                                                // keras.losses.BinaryCrossentropy (probabilities)
+                const float eps = 1e-7f;
+                const float pc = fminf(fmaxf(p, eps), 1.0f - eps);
+                if (l32 == 0) lsum += -(double)(t * logf(pc + eps) + (1.0f - t) * logf(1.0f - pc + eps));
+                const float inside = (p >= eps && p <= 1.0f - eps) ? 1.0f : 0.0f;
+                g = -(t / (pc + eps) - (1.0f - t) / (1.0f - pc + eps)) * inside * a.invB;
+            }
+            dz = g * mask * a.gscale;
+        } else {
+            dz = a.dy[row];
+        }
         dz = a.act == 1 ? (p > 0.0f ? dz : 0.0f) : (a.act == 2 ? dz * p * (1.0f - p) : dz);
         if (l32 == 0) gb += dz;
         const float dzh = (float)(_Float16)dz;
@@ -967,7 +1080,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[hw][c][e] = pass == 0 ? gw[j][e] : gbb[j][e];
         }
-        if (pass == 0 && l32 == 0) red_b[hw] = gb;
+        if (pass == 0 && l32 == 0) { red_b[hw] = gb; red_l[hw] = lsum; }
         __syncthreads();
         for (int k = threadIdx.x; k < a.K; k += 256) {
             float s0 = 0.0f;
@@ -979,6 +1092,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
             float s = 0.0f;
             for (int h = 0; h < 8; ++h) s += red_b[h];
             a.gb[blockIdx.x] = s;
+            if (a.loss_part != nullptr) {
+                double t = 0.0;
+                for (int h = 0; h < 8; ++h) t += red_l[h];
+                a.loss_part[blockIdx.x] = t;
+            }
         }
         __syncthreads();
     }
@@ -994,15 +1112,40 @@ int orx_launch_head_fwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* 
     return ORX_OK;
 }
 
+// sum of the loss partials head_bwd_kernel left, for all steps of a call: loss_out[s] = sum_b parts[s][b] / n_mean
+__global__ __launch_bounds__(64) void head_loss_finish_kernel(const double* parts, int64_t stride, int n, double n_mean, double* loss_out) {
+    const double* p = parts + (int64_t)blockIdx.x * stride;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += p[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) loss_out[blockIdx.x] = s / n_mean;
+}
+
+int orx_launch_head_loss_finish(orx_ctx* ctx, const double* parts, int64_t stride, int n, int64_t K, int64_t n_mean, double* loss_out) {
+    if (K == 0) return ORX_OK;
+    ORX_LAUNCH(ctx, head_loss_finish_kernel, dim3((unsigned)K), dim3(64), 0, parts, stride, n, (double)n_mean, loss_out);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
+int orx_head_bwd_blocks(orx_ctx* ctx, int B) {
+    const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+    int rows = std::max(32, (int)((B + cus - 1) / cus));
+    rows = (rows + 7) / 8 * 8;
+    return (B + rows - 1) / rows;
+}
+
 int orx_launch_head_bwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* dy, const float* pred, int act, int act_below,
-                        ColPart* gW, ColPart* gb, void* dZ16, int64_t ld16, float* dZ32, int64_t ld32, ColPart* gb_below, int B, int K) {
+                        ColPart* gW, ColPart* gb, void* dZ16, int64_t ld16, float* dZ32, int64_t ld32, ColPart* gb_below, int B, int K,
+                        const HeadLoss* hl) {
     if (B == 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_GEMM);
     const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
     int rows = std::max(32, (int)((B + cus - 1) / cus));           // <= one workgroup per CU, >= 32 rows each (partial rows = blocks)
     rows = (rows + 7) / 8 * 8;
     gW->P = gb->P = gb_below->P = (B + rows - 1) / rows;
-    HeadBwdArgs a{(const _Float16*)X16, ldx, (const _Float16*)w16, dy, pred, act, act_below, gW->parts, gb->parts, (_Float16*)dZ16, ld16, dZ32, ld32, gb_below->parts, B, K, rows};
+    HeadBwdArgs a{(const _Float16*)X16, ldx, (const _Float16*)w16, dy, pred, act, act_below, gW->parts, gb->parts, (_Float16*)dZ16, ld16, dZ32, ld32, gb_below->parts, B, K, rows,
+                  hl ? hl->label : nullptr, hl ? hl->bce : 0, hl ? hl->thr : 0.f, hl ? 1.0f / (float)hl->n_mean : 0.f, hl ? hl->gscale : 1.f, hl ? hl->loss_part : nullptr};
     ORX_LAUNCH(ctx, head_bwd_kernel, dim3((unsigned)((B + rows - 1) / rows)), dim3(256), 0, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;

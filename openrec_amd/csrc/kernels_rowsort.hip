@@ -143,6 +143,8 @@ struct CsrArgs {
     float lr, eps, b1, b2, lr_T; const float* lrt; int T, newton;
     float* part_lo; float* part_hi;                          // [blocks][Dp]: sums of the runs open at a block's start / end
     int Dp;
+    int skip_single;                                         // rows referenced once are NOT applied here: the kernel that formed their
+                                                             // gradient updated them in place (orx_rows_single_flags, interact_bwd_mfma_kernel)
 };
 
 // the row's state, loaded together with the gradient rows (no dependent round trip when the rule is applied)
@@ -202,49 +204,66 @@ __global__ __launch_bounds__(256) void csr_apply_kernel(CsrArgs a) {
     const int cnt = (int)(a.n - i0 < 64 ? a.n - i0 : 64);
     const uint2 mine = lane < cnt ? a.sorted[i0 + lane] : make_uint2(KEY_NONE, 0u);
     const uint32_t prevk = b > 0 ? a.sorted[i0 - 1].x : KEY_NONE, nextk = i0 + 64 < a.n ? a.sorted[i0 + 64].x : KEY_NONE;
+    // skip_single: an entry whose row differs from both neighbours is left out (its row was updated where its gradient was
+    // formed).  The remaining entries -- whole runs, in order -- are numbered densely: lane l learns the block position of the
+    // l-th of them (runs that cross a block boundary are never single, so the open ends below keep their meaning).
+    int todo_n = cnt, orig = lane;
+    if (a.skip_single) {
+        const uint32_t lk = (uint32_t)__shfl_up((int)mine.x, 1), rk = (uint32_t)__shfl_down((int)mine.x, 1);
+        const uint32_t left = lane == 0 ? prevk : lk, right = lane == cnt - 1 ? nextk : rk;
+        const bool keep = lane < cnt && mine.x < a.rows && !(mine.x != left && mine.x != right);     // (padding ids: nothing to apply)
+        const unsigned long long m = __ballot(keep);
+        todo_n = __popcll(m);
+        if (todo_n == 0) return;
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        orig = __builtin_amdgcn_ds_permute((keep ? rank : 63) * 4, lane);       // (lanes without an entry all write lane 63: only a block
+        if (todo_n == 64) orig = lane;                                           //  of 64 kept entries reads it, and then the map is the identity)
+    }
     float acc[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) acc[e] = 0.0f;
     uint32_t cur = KEY_NONE;
-    int seg0 = 0;
+    int seg_first = 0, seg_last = 0;                         // block positions of the current run's first / latest entry
     RowState<NE, MODE> st_cur;
-    auto flush = [&](int end) {
+    auto flush = [&]() {
         if (cur >= a.rows) return;                           // padding / out-of-range ids (sorted last); nothing before the first entry
-        const bool open_lo = seg0 == 0 && prevk == cur, open_hi = end == 64 && nextk == cur;
+        const bool open_lo = seg_first == 0 && prevk == cur, open_hi = seg_last == 63 && nextk == cur;
         if (!open_lo && !open_hi) { csr_rule<NE, MODE>(a, cur, acc, st_cur, lane); return; }
         float* p = (open_lo ? a.part_lo : a.part_hi) + (size_t)b * a.Dp;
 #pragma unroll
         for (int e = 0; e < NE; ++e) if (lane + 64 * e < a.D) p[lane + 64 * e] = acc[e];
     };
     constexpr int UN = 8;
-    for (int j0 = 0; j0 < cnt; j0 += UN) {
-        uint32_t kj[UN]; float g[UN][NE]; RowState<NE, MODE> st[UN];
+    for (int j0 = 0; j0 < todo_n; j0 += UN) {
+        uint32_t kj[UN]; int oj[UN]; float g[UN][NE]; RowState<NE, MODE> st[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {                       // UN gradient rows and the table rows they belong to in flight
-            const int j = j0 + u < cnt ? j0 + u : cnt - 1;
-            kj[u] = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, j);
-            const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, j);
+            const int j = j0 + u < todo_n ? j0 + u : todo_n - 1;
+            oj[u] = __builtin_amdgcn_readlane(orig, j);
+            kj[u] = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, oj[u]);
+            const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, oj[u]);
             const float* gp = a.grads + (size_t)pj * a.g_stride;
 #pragma unroll
             for (int e = 0; e < NE; ++e) g[u][e] = (kj[u] < a.rows && lane + 64 * e < a.D) ? gp[lane + 64 * e] : 0.0f;
             // (only the entry that starts a run uses its table row; the others re-read a line the run's head just fetched)
-            const uint32_t before = j > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)mine.x, j - 1) : KEY_NONE;
-            if (j0 + u < cnt && kj[u] != before) st[u].load(a, kj[u], lane);
+            const uint32_t before = oj[u] > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)mine.x, oj[u] - 1) : KEY_NONE;
+            if (j0 + u < todo_n && kj[u] != before) st[u].load(a, kj[u], lane);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            if (j0 + u >= cnt) break;
+            if (j0 + u >= todo_n) break;
             if (kj[u] != cur || j0 + u == 0) {
-                if (j0 + u > 0) flush(j0 + u);
-                cur = kj[u]; seg0 = j0 + u; st_cur = st[u];
+                if (j0 + u > 0) flush();
+                cur = kj[u]; seg_first = oj[u]; st_cur = st[u];
 #pragma unroll
                 for (int e = 0; e < NE; ++e) acc[e] = 0.0f;
             }
+            seg_last = oj[u];
 #pragma unroll
             for (int e = 0; e < NE; ++e) acc[e] += g[u][e];
         }
     }
-    flush(cnt);
+    flush();
 }
 
 // runs that cross block boundaries: the wavefront of the block a run STARTS in adds the partial sums in block order
@@ -329,6 +348,27 @@ int launch_csr(orx_ctx* ctx, const CsrArgs& a) {
 
 static inline int bit_width_u64(uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
 
+// flags[k][position] = 1 where the row at that position of list k is referenced by no other position of the list (its sorted
+// neighbours differ), else 0 -- every position of a list appears exactly once in its sorted form, so every flag is written.
+// The kernel that forms the gradient of such a reference may apply it in place: nobody else reads or writes the row in the step.
+__global__ __launch_bounds__(256) void rows_single_flags_kernel(const uint2* sorted, int64_t n, uint32_t rows, unsigned char* flags) {
+    const int64_t k = blockIdx.y;
+    const uint2* s = sorted + k * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint2 e = s[i];
+        const bool single = e.x < rows && (i == 0 || s[i - 1].x != e.x) && (i + 1 >= n || s[i + 1].x != e.x);
+        flags[k * n + e.y] = single ? 1 : 0;
+    }
+}
+
+int orx_rows_single_flags(orx_ctx* ctx, const uint2* sorted, int64_t K, int64_t n, int64_t rows, unsigned char* flags) {
+    if (K == 0 || n == 0) return ORX_OK;
+    ProfScope ps(ctx, ORX_K_DEDUP);
+    ORX_LAUNCH(ctx, rows_single_flags_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048), (unsigned)K), dim3(256), 0, sorted, n, (uint32_t)rows, flags);
+    ORX_HIP(hipGetLastError());
+    return ORX_OK;
+}
+
 // the sort's buffers for K lists of n ids, without sorting: a caller whose calls vary in length reserves for its longest chunk
 // once (growing them inside a longer call costs hipFree + hipMalloc: ~0.5 ms of the DLRM step's first long call)
 int orx_rows_sort_reserve(orx_ctx* ctx, int64_t K, int64_t n, int64_t rows) {
@@ -388,13 +428,13 @@ static int csr_args(orx_ctx* ctx, orx_table* t, const uint2* sorted, int64_t n, 
 }
 
 // SGD / Adagrad on the sorted list (one step)
-int orx_csr_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride) {
+int orx_csr_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride, bool skip_single) {
     if (n == 0) return ORX_OK;
     ORX_ARG(opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD, "csr_apply: SGD / Adagrad (Adam: orx_csr_adam_apply)");
     ProfScope ps(ctx, ORX_K_DUPAPPLY);
     CsrArgs a;
     if (int rc = csr_args(ctx, t, sorted, n, grads, g_stride, &a)) return rc;
-    a.lr = opt->lr;
+    a.lr = opt->lr; a.skip_single = skip_single ? 1 : 0;
     if (opt->kind == ORX_ADAGRAD) {
         OptSlots st;
         if (int rc = orx_opt_slots(opt, t, &st)) return rc;

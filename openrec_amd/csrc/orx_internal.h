@@ -492,11 +492,23 @@ void orx_gemm16_tn_plan(orx_ctx* ctx, int M, int N, int K, int* S_out, int* tile
 int orx_launch_gemm16_tn(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                          float* slab, int M, int N, int K, float out_scale = 1.0f);
 int orx_launch_slab_reduce(orx_ctx* ctx, const void* jobs_dev, int n_jobs, int max_tiles, float out_scale = 1.0f);
+// the weight gradient (arguments of orx_launch_gemm16_tn) and the input gradient (of orx_launch_gemm16_nt) of one layer in ONE launch
+bool orx_gemm16_group_ok(orx_ctx* ctx, int B, int in, int out, int64_t ldx16, int64_t ldw16);
+int orx_launch_gemm16_group(orx_ctx* ctx, const void* X16, int64_t ldx, const void* dZ16, int64_t lddz, float* gW, int64_t ldgw, float* slab,
+                            int in, int out, int B, float out_scale,
+                            const void* W16, int64_t ldw, float* C, int64_t ldc, void* C16, int64_t ldc16,
+                            const float* actY, const void* actY16, int64_t ldy, int act_y, ColPart* gbp);
 int orx_launch_cast16(orx_ctx* ctx, const float* src, int64_t lds_, void* dst16, int64_t ld16, int M, int N);
 bool orx_head16_ok(int K, int64_t ldx);
 int orx_launch_head_fwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* bias, int act, float* pred, int B, int K);
+// hl != NULL: the loss is folded into the head's backward (no dlrm_loss_kernel launch): dy is formed from pred and the label, the loss
+// terms leave as one fp64 partial per workgroup in loss_part[0 .. orx_head_bwd_blocks(B))
+struct HeadLoss { const float* label; int bce; float thr; int64_t n_mean; float gscale; double* loss_part; };
 int orx_launch_head_bwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* dy, const float* pred, int act, int act_below,
-                        ColPart* gW, ColPart* gb, void* dZ16, int64_t ld16, float* dZ32, int64_t ld32, ColPart* gb_below, int B, int K);
+                        ColPart* gW, ColPart* gb, void* dZ16, int64_t ld16, float* dZ32, int64_t ld32, ColPart* gb_below, int B, int K,
+                        const HeadLoss* hl = nullptr);
+int orx_head_bwd_blocks(orx_ctx* ctx, int B);
+int orx_launch_head_loss_finish(orx_ctx* ctx, const double* parts, int64_t stride, int n, int64_t K, int64_t n_mean, double* loss_out);
 struct ShadowParam { const float* w; void* w16; void* w16t; int in, out, ld16, ld16t; };
 int orx_launch_dense_shadow(orx_ctx* ctx, const ShadowParam* ps_dev, int count, int64_t max_n);
 int orx_launch_act_bwd(orx_ctx* ctx, float* dY, const float* Y, int64_t ldy, int M, int N, int act);
@@ -504,8 +516,12 @@ int orx_launch_copy2d(orx_ctx* ctx, float* dst, int64_t ldd, const float* src, i
 int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR, int F, int d, int compat, int itself,
                         float* out, int P, int64_t B, int ldR, void* R16 = nullptr, int ldR16 = 0, bool* wrote16 = nullptr,
                         const float* emb = nullptr, const int32_t* idx = nullptr, int64_t emb_rows = 0, float scale = 1.0f,
-                        float* gdst = nullptr);
+                        float* gdst = nullptr,
+                        // backward with direct rows: flags [B][F] of the lookups whose row nobody else references in the step -- their
+                        // SGD / Adagrad update is applied in place by the kernel (kernels_dense.hip FusedRows), no gradient row is written
+                        const unsigned char* single = nullptr, int opt_kind = 0, float lr = 0.f, float eps = 0.f, float* acc_rows = nullptr);
 bool orx_interact_direct_ok(int F, int d, int compat);
+bool orx_interact_fuse_ok(int F, int d, int compat);
 int orx_launch_dlrm_loss(orx_ctx* ctx, float* P, const float* y, int64_t B, int bce, float thr, float* dP, double* loss_out,
                          int64_t n_mean = 0, int accumulate = 0, float gscale = 1.0f);
 int orx_launch_dlrm_tiny_apply(orx_ctx* ctx, const int32_t* idx, const float* dZ, const int* tiny_f_dev, int n_tiny, int max_rows,
@@ -518,7 +534,9 @@ int orx_launch_rows_accum(orx_ctx* ctx, float* G, const int32_t* ids, const floa
 // kernels_rowsort.hip: deterministic apply of per-occurrence gradient rows (stable sort by row + segmented sums in position order)
 int orx_rows_sort(orx_ctx* ctx, const int32_t* ids, int64_t K, int64_t n, int64_t id_stride, int64_t rows, const uint2** sorted);
 int orx_rows_sort_reserve(orx_ctx* ctx, int64_t K, int64_t n, int64_t rows);
-int orx_csr_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride);
+int orx_csr_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride,
+                  bool skip_single = false);       // skip_single: rows referenced once were updated by the kernel that formed their gradient
+int orx_rows_single_flags(orx_ctx* ctx, const uint2* sorted, int64_t K, int64_t n, int64_t rows, unsigned char* flags);
 int orx_csr_accum(orx_ctx* ctx, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride);
 int orx_csr_adam(orx_ctx* ctx, bool step, const AdamRowsArgs& r, orx_table* t, const uint2* sorted, int64_t n);
 int orx_adam_rows_sorted(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride, bool step);

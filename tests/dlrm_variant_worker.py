@@ -26,10 +26,13 @@ def main():
         label = (rng.uniform(size=Bs) < 0.3).astype(np.float32)
         loss = m.step(opt, dense, sparse, label)
         h.update(np.asarray(loss, np.float32).tobytes())
-    h.update(m.param("emb").read().tobytes())
-    for nm, n in (("bot", 3), ("top", 5)):
-        for l in range(n):
-            h.update(m.param(nm + "_w", l).read().tobytes()); h.update(m.param(nm + "_b", l).read().tobytes())
+    hp = hashlib.sha256()                                     # the parameters alone (a variant that sums the LOSS in another order keeps these)
+    for hh in (h, hp):
+        hh.update(m.param("emb").read().tobytes())
+        for nm, n in (("bot", 3), ("top", 5)):
+            for l in range(n):
+                hh.update(m.param(nm + "_w", l).read().tobytes()); hh.update(m.param(nm + "_b", l).read().tobytes())
+    print("PARAMS", hp.hexdigest())
     print("DIGEST", h.hexdigest())
 
 

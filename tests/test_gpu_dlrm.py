@@ -398,7 +398,8 @@ def test_dlrm_fp16_staging_forms_are_bit_identical():
     import sys as _sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dlrm_variant_worker.py")
     variants = [{}, {"ORX_GEMM16_DMA": "0"}, {"ORX_GEMM16_DMA": "2"}, {"ORX_GEMM16_TN_DMA": "0"}, {"ORX_GEMM16_TN_DMA": "2"},
-                {"ORX_GEMM16_NTS": "0"}, {"ORX_GEMM16_NTS": "1"}]
+                {"ORX_GEMM16_NTS": "0"}, {"ORX_GEMM16_NTS": "1"},
+                {"ORX_GEMM16_NO_GROUP": "1"}]                 # round 6: a layer's dW and dX in one launch (gemm16_group_kernel) vs two
     digests = []
     for v in variants:
         env = dict(os.environ); env.update(v)
@@ -407,4 +408,52 @@ def test_dlrm_fp16_staging_forms_are_bit_identical():
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")]
         assert line, f"{v}: no digest in {r.stdout[-500:]}"
         digests.append(line[-1])
-    assert all(d == digests[0] for d in digests), list(zip([str(v) for v in variants], digests))
+    assert all(d == digests[0] for d in digests), [str(v) for v, d in zip(variants, digests) if d != digests[0]]
+    # round 6: the loss folded into the head's backward (per-workgroup fp64 partials summed once per call) against the dlrm_loss_kernel
+    # launch per step: another order of the loss SUM, the same gradient -- every parameter bit for bit
+    params = []
+    for v in ({}, {"ORX_DLRM_NO_FOLDED_LOSS": "1"}):
+        env = dict(os.environ); env.update(v)
+        r = subprocess.run([_sys.executable, worker], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, f"{v}: {r.stderr[-2000:]}"
+        params.append([ln for ln in r.stdout.splitlines() if ln.startswith("PARAMS ")][-1])
+    assert params[0] == params[1], params
+
+
+@pytest.mark.parametrize("m_spa,optname,K_call", [(128, "sgd", 1), (128, "adagrad", 3), (64, "sgd", 3), (256, "adagrad", 1)])
+def test_dlrm_rows_referenced_once_are_applied_by_the_interaction_backward(m_spa, optname, K_call, monkeypatch):
+    """round 6 (north_star's "one pass"; dlrm.py:83-85 + second_order_feature_interaction.py:20-32 + tf2_examples/dlrm_criteo.py:45-46):
+    an embedding row that a single lookup of the step references takes its SGD / Adagrad update inside interact_bwd_mfma_kernel
+    (its gradient never reaches HBM), rows with several references keep the sorted segmented sums.  Tables of a million rows
+    (every lookup a singleton), of thousands (a mix) and of 3 / 7 rows (hundreds of references per row), against the fp64 oracle;
+    and the same steps with ORX_DLRM_NO_FUSED_SPARSE=1 (everything through the sorted apply): the two paths compute the same
+    expression on the same gradient, every parameter agrees to one fp32 rounding of its update."""
+    from openrec_amd import runtime as rt
+    from oracle import numpy_oracle as orc
+    ln_emb = [1000000, 3, 5000, 7, 200000, 1200, 50]
+    cfg = dict(m_spa=m_spa, ln_emb=ln_emb, ln_bot=[32, m_spa], ln_top=[64, 32, 1], dense_dim=13)
+    kw = dict(reference_compat=False)
+    monkeypatch.delenv("ORX_DLRM_NO_FUSED_SPARSE", raising=False)
+    m, o, batches = _exact_case(f"fusedrows_{m_spa}_{optname}_{K_call}", cfg, kw, kw, optname, 600, 3, seed=21, K_call=K_call)
+    # A/B on the same start, same batches
+    import copy
+    from oracle.dlrm_oracle import DLRMOracle
+    o0 = DLRMOracle(dtype=np.float64, seed=5, **cfg, **kw)
+    round_to_fp32(o0)
+    res = {}
+    for name, env in (("fused", None), ("sorted", "1")):
+        if env is None:
+            monkeypatch.delenv("ORX_DLRM_NO_FUSED_SPARSE", raising=False)
+        else:
+            monkeypatch.setenv("ORX_DLRM_NO_FUSED_SPARSE", env)
+        res[name] = _run_steps(rt, cfg, copy.deepcopy(o0), batches, lambda: _pair(rt, orc, optname)[0], kw, K_call)
+    monkeypatch.delenv("ORX_DLRM_NO_FUSED_SPARSE", raising=False)
+    assert np.array_equal(res["fused"][0], res["sorted"][0]) or np.allclose(res["fused"][0], res["sorted"][0], rtol=1e-6)
+    a, b = res["fused"][1], res["sorted"][1]
+    for k in a:
+        ulp = np.spacing(np.maximum(np.abs(a[k]), np.abs(b[k])).astype(np.float32))
+        assert (np.abs(a[k].astype(np.float64) - b[k]) <= 3 * ulp).all(), (k, float(np.abs(a[k] - b[k]).max()))
+    # the singleton rows DID move (a path that skipped them in both kernels would leave them at their start)
+    start = np.concatenate(o0.emb).astype(np.float32)
+    sp0 = batches[0][1]
+    assert np.abs(a["emb"][sp0[:, 0]] - start[sp0[:, 0]]).max() > 0
