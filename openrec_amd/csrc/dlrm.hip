@@ -89,6 +89,9 @@ struct orx_dlrm {
     DenseFused* d_fused = nullptr;      // ... and for the fused launch of the fp16 mode (slab reduce + rule + fp16 copies)
     orx_opt* fused_opt = nullptr; int fused_tiles = 0; DenseFusedTiles fused_tt;
     bool grads_pending = false;         // orx_dlrm_grads ran, orx_dlrm_dense_apply not yet
+    std::vector<ColJob> pending_coljobs;   // fp16 mode of orx_dlrm_step: the step's partial-row sums, added by the fused optimizer launch
+    std::vector<const float*> fused_out;   // descriptor index -> the gradient array (gsum) that descriptor applies
+    std::vector<const float*> fused_cparts; std::vector<int> fused_cn;      // ... and its partial-row workspace / row length (NULL / 0: none)
     void* d_flatseg = nullptr; const void* flatseg_key = nullptr; int flatseg_n = 0;     // descriptors of dlrm_flat_kernel
     double* d_loss = nullptr;           // [Kcap]
     int64_t loss_cap = 0;
@@ -469,6 +472,8 @@ static int dense_apply_all(orx_dlrm* m, orx_opt* opt, float lr_t = 0.f, bool fus
         if (m->fused_opt != opt) {
             std::vector<DenseFused> h;
             int tiles = 0;
+            m->fused_out.clear(); m->fused_cparts.clear(); m->fused_cn.clear();
+            DenseLayer* bias_of = nullptr;
             auto add = [&](orx_table* t, DenseLayer* D) -> int {
                 OptSlots s;
                 CHECK(orx_opt_slots(opt, t, &s));
@@ -480,12 +485,17 @@ static int dense_apply_all(orx_dlrm* m, orx_opt* opt, float lr_t = 0.f, bool fus
                     if (D->dw16 && D->slab_S > 1) { p.slab = D->slab; p.S = D->slab_S; p.ntn = (D->out + 127) / 128; }
                     p.w16 = D->w16; p.w16t = D->w16t; p.ld16 = D->ld16; p.ld16t = D->ld16t;
                 }
+                if (p.rows == 1 || p.cols == 1) {             // (where its gradient's partial rows live, if it gets any: see below)
+                    p.cN = p.rows * p.cols;
+                    p.cparts = D != nullptr ? D->gwpart : bias_of->gbpart;
+                }
+                m->fused_out.push_back(t->gsum); m->fused_cparts.push_back(p.cparts); m->fused_cn.push_back(p.cN);
                 p.tile0 = tiles; p.tiles_x = (p.cols + 63) / 64;
                 tiles += p.tiles_x * ((p.rows + 15) / 16);        // (16 x 64 tiles: kernels_dense.hip DF_ROWS)
                 h.push_back(p);
                 return ORX_OK;
             };
-            for (int k = 0; k < 2; ++k) for (auto& D : (k == 0 ? m->bot : m->top)) { CHECK(add(D.W, &D)); CHECK(add(D.b, nullptr)); }
+            for (int k = 0; k < 2; ++k) for (auto& D : (k == 0 ? m->bot : m->top)) { CHECK(add(D.W, &D)); bias_of = &D; CHECK(add(D.b, nullptr)); }
             if (!m->d_fused) ORX_HIP(hipMalloc((void**)&m->d_fused, h.size() * sizeof(DenseFused)));
             ORX_HIP(hipMemcpyAsync(m->d_fused, h.data(), h.size() * sizeof(DenseFused), hipMemcpyHostToDevice, c->stream));
             ORX_HIP(hipStreamSynchronize(c->stream));
@@ -494,6 +504,18 @@ static int dense_apply_all(orx_dlrm* m, orx_opt* opt, float lr_t = 0.f, bool fus
             for (size_t i = 0; i < h.size(); ++i) m->fused_tt.tile0[i] = h[i].tile0;
             m->fused_opt = opt; m->fused_tiles = tiles;
         }
+        // the step's partial-row sums (bias gradients, the head's weight gradient): added inside the launch where the descriptor knows the
+        // workspace, by a reduce launch otherwise
+        for (int i = 0; i < m->fused_tt.count; ++i) m->fused_tt.cP[i] = 0;
+        std::vector<ColJob> rest;
+        for (const ColJob& j : m->pending_coljobs) {
+            int idx = -1;
+            for (size_t i = 0; i < m->fused_out.size(); ++i) if (m->fused_out[i] == j.out) { idx = (int)i; break; }
+            if (idx >= 0 && m->fused_cparts[idx] == j.parts && m->fused_cn[idx] == j.N && j.scale == slab_scale && m->fused_tt.cP[idx] == 0 && j.P > 0) m->fused_tt.cP[idx] = j.P;
+            else rest.push_back(j);
+        }
+        m->pending_coljobs.clear();
+        if (!rest.empty()) CHECK(orx_launch_colparts_reduce(c, rest.data(), (int)rest.size()));
         if (opt->kind == ORX_ADAM) CHECK(orx_launch_dense_apply_fused(c, m->d_fused, m->fused_tt, m->fused_tiles, ORX_ADAM, lr_t, opt->p2, opt->p0, opt->p1, slab_scale));
         else CHECK(orx_launch_dense_apply_fused(c, m->d_fused, m->fused_tt, m->fused_tiles, opt->kind, opt->lr, opt->p1, 0.f, 0.f, slab_scale));
         for (int k = 0; k < 2; ++k) for (auto& D : (k == 0 ? m->bot : m->top)) { D.W->version += 1; D.b->version += 1; D.shadow_version = D.W->version; }
@@ -706,7 +728,9 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale, bool 
     // (the bottom MLP's dY = gscale * dZ[:, F-1, :]: its first activation backward reads the slice in place)
     CHECK(mlp_backward(m, m->bot, ins, ldi, outs, ldo, dy, other, B, false, &dx0, gscale, defer_slabs, bot16 ? &ins16 : nullptr, &ldi16, &outs16, &coljobs,
                        m->dZ + (size_t)(F - 1) * d, (int64_t)F * d, gscale));
-    CHECK(orx_launch_colparts_reduce(c, coljobs.data(), (int)coljobs.size()));
+    // (defer_slabs = the fused optimizer launch follows: it adds the partial rows itself, see dense_apply_all)
+    if (defer_slabs && getenv("ORX_DLRM_COLPARTS_LAUNCH") == nullptr) m->pending_coljobs = coljobs;
+    else CHECK(orx_launch_colparts_reduce(c, coljobs.data(), (int)coljobs.size()));
     }
     return ORX_OK;
 }

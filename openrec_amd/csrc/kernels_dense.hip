@@ -836,8 +836,10 @@ struct FusedRows {
     int kind; float lr, eps;           // ORX_SGD | ORX_ADAGRAD
 };
 
-template <int CPL, int SPLIT, bool FUSE>
-__global__ __launch_bounds__(256) void interact_bwd_mfma_kernel(RowSrc src, const float* dR, int F, int itself, float* dZ,
+// OCC: wavefronts per SIMD the register allocation is held to (d = 128: 138 registers and 3 wavefronts without a bound, 118 and 4 with it,
+// no spills; 5 spills).  0: no bound.
+template <int CPL, int SPLIT, bool FUSE, int OCC = 0>
+__global__ __launch_bounds__(256, OCC > 0 ? OCC : 1) void interact_bwd_mfma_kernel(RowSrc src, const float* dR, int F, int itself, float* dZ,
                                                                 int64_t B, int ldR, float scale, FusedRows fr) {
     constexpr int d = 16 * CPL * SPLIT;
     const int lane = threadIdx.x & 63;
@@ -992,9 +994,12 @@ int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR,
             ORX_ARG(!fuse || (emb != nullptr && gdst == nullptr && d >= 64 && (opt_kind == ORX_SGD || (opt_kind == ORX_ADAGRAD && acc_rows != nullptr))),
                     "interact: the in-place apply needs direct table rows, d >= 64 and SGD / Adagrad");
             const size_t shm = (size_t)4 * ldR * sizeof(float);
+            static const bool occ4 = getenv("ORX_INTERACT_BWD_OCC") == nullptr || atoi(getenv("ORX_INTERACT_BWD_OCC")) == 4;
             if (d == 32) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<2, 1, false>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
             else if (d == 64 && fuse) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4, 1, true>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
             else if (d == 64) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<4, 1, false>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
+            else if (d == 128 && fuse && occ4) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8, 1, true, 4>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
+            else if (d == 128 && occ4) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8, 1, false, 4>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
             else if (d == 128 && fuse) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8, 1, true>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
             else if (d == 128) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<8, 1, false>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
             else if (fuse) ORX_LAUNCH(ctx, (interact_bwd_mfma_kernel<16, 1, true>), g, dim3(256), shm, src, dR, F, itself, out, B, ldR, scale, fr);
@@ -1147,11 +1152,35 @@ constexpr int DF_ROWS = 16;
 __global__ __launch_bounds__(256) void dense_apply_fused_kernel(const DenseFused* ps, DenseFusedTiles tt, int optkind, float lr, float eps, float b1, float b2,
                                                                 float slab_scale) {
     __shared__ _Float16 tr[DF_ROWS][64 + 2];
+    __shared__ float cseg[4][64];
     int pi = 0;                                              // (the tile table travels in the kernel arguments: scalar loads, no dependent memory chain)
     while (pi + 1 < tt.count && (int)blockIdx.x >= tt.tile0[pi + 1]) ++pi;
     const DenseFused p = ps[pi];
     const int t = blockIdx.x - p.tile0;
     const int r0 = (t / p.tiles_x) * DF_ROWS, c0 = (t % p.tiles_x) * 64;
+    // a vector parameter's gradient in partial rows (bias gradients, the 1-unit head's weight gradient): the tile's <= 64 elements are
+    // summed exactly as colparts_reduce_kernel does it -- wavefront w takes the w-th quarter of the P rows in order, 8 loads in
+    // flight, the quarters are combined in order -- by all 256 threads of the workgroup, before the (few) owning threads go on
+    const int cP = p.cparts != nullptr ? tt.cP[pi] : 0;
+    const int cbase = p.rows == 1 ? c0 : r0;                // (rows == 1: element = column; cols == 1: element = row)
+    if (cP > 0) {
+        const int k = threadIdx.x & 63, w = threadIdx.x >> 6, c = cbase + k;
+        const int per = (cP + 3) / 4, p0 = w * per, p1 = p0 + per < cP ? p0 + per : cP;
+        float sacc = 0.0f;
+        if (c < p.cN) {
+            int q = p0;
+            for (; q + 8 <= p1; q += 8) {
+                float a[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = p.cparts[(int64_t)(q + u) * p.cN + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sacc += a[u];
+            }
+            for (; q < p1; ++q) sacc += p.cparts[(int64_t)q * p.cN + c];
+        }
+        cseg[w][k] = sacc;
+        __syncthreads();
+    }
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const bool vec = (p.cols & 3) == 0;
     const int row = r0 + ty, col = c0 + 4 * tx;
@@ -1189,6 +1218,12 @@ __global__ __launch_bounds__(256) void dense_apply_fused_kernel(const DenseFused
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) gi[e] += sv[e] * slab_scale;
+        }
+        if (cP > 0) {
+            for (int e = 0; e < nv; ++e) {
+                const int k = (p.rows == 1 ? col + e : row) - cbase;
+                gi[e] += (((cseg[0][k] + cseg[1][k]) + cseg[2][k]) + cseg[3][k]) * slab_scale;
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -473,8 +473,14 @@ int orx_launch_gemm16_nt(orx_ctx* ctx, const void* A16, int64_t lda, const void*
     // ORX_GEMM16_DMA: 0 = the register-staged kernels, 2 / 3 = LDS-DMA staging with that many stages (default 3 for the 256 x 128 tile)
     static const int dma_env = getenv("ORX_GEMM16_DMA") ? atoi(getenv("ORX_GEMM16_DMA")) : 3;
     const int dma = ((int64_t)M * lda < (1LL << 30) && (int64_t)N * ldb < (1LL << 30)) ? dma_env : 0;      // (32-bit byte offsets from A and B)
+    // ORX_GEMM16_WAVE_TILE=128: the 256 x 128 tile on FOUR wavefronts of 128 x 64 instead of eight of 64 x 64.  The main loop of these
+    // products is bound by LDS bandwidth, not by the MFMA pipes (fragment reads 8.7 us + DMA writes 3.3 us of a 13.4 us loop at
+    // 8192 x 1024 x 1024, against ~5 us of products): what a wavefront reads per K step is (rows of A + rows of B) of ITS tile, and
+    // 4 x (128 + 64) rows are 25 % fewer than 8 x (64 + 64).
+    static const int wave_tile = getenv("ORX_GEMM16_WAVE_TILE") ? atoi(getenv("ORX_GEMM16_WAVE_TILE")) : 64;
     if (force == 1 || (force == 0 && blocks(256, 128) >= cus)) {
         if (gbp) gbp->P = (M + 255) / 256;
+        if (dma == 3 && wave_tile == 128) return launch_nt_dma<2, 2, 8, 4, 1, 3>(ctx, g);
         if (dma == 3) return launch_nt_dma<4, 2, 4, 4, 1, 3>(ctx, g);
         if (dma == 2) return launch_nt_dma<4, 2, 4, 4, 1, 2>(ctx, g);
         return launch_nt<4, 2, 4, 4, 1, 16>(ctx, g);
@@ -597,7 +603,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_tn_kernel(Tn16Args 
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                store_sc1(reinterpret_cast<f32x4*>(mine + (wm + mi * 16 + i16) * BN + wn + ni * 16 + q * 4), acc[mi][ni]);
+                if (bm + wm + mi * 16 + i16 < g.M)               // (rows beyond M are never read: a 13 x 512 gradient stores 13 of a tile's 128 rows)
+                    store_sc1(reinterpret_cast<f32x4*>(mine + (wm + mi * 16 + i16) * BN + wn + ni * 16 + q * 4), acc[mi][ni]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // (the write-through stores are acknowledged before the wavefront ends)
         return;
     }
@@ -748,7 +755,8 @@ __device__ __forceinline__ void gemm16_tn_dma_body(const Tn16Args& g, const int 
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                store_sc1(reinterpret_cast<f32x4*>(mine + (wm + mi * 16 + i16) * BN + wn + ni * 16 + q * 4), acc[mi][ni]);
+                if (bm + wm + mi * 16 + i16 < g.M)               // (rows beyond M are never read: a 13 x 512 gradient stores 13 of a tile's 128 rows)
+                    store_sc1(reinterpret_cast<f32x4*>(mine + (wm + mi * 16 + i16) * BN + wn + ni * 16 + q * 4), acc[mi][ni]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // (the write-through stores are acknowledged before the wavefront ends)
         return;
     }
@@ -828,10 +836,13 @@ void orx_gemm16_tn_plan(orx_ctx* ctx, int M, int N, int K, int* S_out, int* tile
     static const int per_cu = getenv("ORX_GEMM16_TN_PER_CU") ? atoi(getenv("ORX_GEMM16_TN_PER_CU")) : 1;
     // (round 6) gradients of <= 16 tiles used to take 32 slices to fill the chip: a 512 x 256 gradient (0.5 MB) left 16.8 MB of slabs for the
     // optimizer launch to read back.  Their weight-gradient workgroups now share a launch with the layer's input gradient
-    // (gemm16_group_kernel), which fills the chip: ORX_GEMM16_TN_SMALL_S slices (default 8) are enough.  32: the round-5 plan.
-    static const int small_s = getenv("ORX_GEMM16_TN_SMALL_S") ? atoi(getenv("ORX_GEMM16_TN_SMALL_S")) : 8;
+    // (gemm16_group_kernel), which fills the chip: fewer slices are enough (ORX_GEMM16_TN_SMALL_S; 32: the round-5 plan).
+    // Measured at the C5 shapes on one box (profiles/r6_tn_slices.txt): 8 slices 499 us per step (the optimizer launch 33 -> 20 us, but the
+    // grouped launches +3-4 us each and the 13 x 512 gradient, which has no input gradient to share a launch with, 8 -> 19 us), 16: 487,
+    // 32: 493.  So: 16 for gradients of 5 .. 16 tiles; smaller ones keep 32 (their slabs are small, and rows beyond M are not stored).
+    static const int small_s = getenv("ORX_GEMM16_TN_SMALL_S") ? atoi(getenv("ORX_GEMM16_TN_SMALL_S")) : 16;
     int S = std::max(1, std::min(32, (per_cu * cus) / tiles));
-    if (tiles <= 16 && small_s >= 1) S = std::min(S, small_s);
+    if (tiles > 4 && tiles <= 16 && small_s >= 1) S = std::min(S, small_s);
     const int kchunk = std::max(64, (((K + S - 1) / S + 63) / 64) * 64);
     *S_out = S; *tiles_out = tiles; *kchunk_out = kchunk;
 }

@@ -463,8 +463,11 @@ struct DenseFused {
     const float* slab; int S, ntn;                 // NULL: the gradient is g alone
     void* w16; void* w16t; int ld16, ld16t;        // NULL: no fp16 copies
     int tile0, tiles_x;                            // first tile of this parameter in the launch's flat tile list; tiles per tile row
+    const float* cparts; int cN;                   // a vector parameter (rows == 1 or cols == 1) whose gradient arrives as partial rows [P][cN]
+                                                   // (ColPart): added here in colparts_reduce_kernel's order -- no reduce launch (round 6)
 };
-struct DenseFusedTiles { int count; int tile0[48]; };       // first tile of every parameter (kernel argument)
+// first tile of every parameter, and how many partial rows its gradient has THIS step (0: none) -- kernel arguments
+struct DenseFusedTiles { int count; int tile0[48]; int cP[48]; };
 int orx_launch_dense_apply_fused(orx_ctx* ctx, const DenseFused* ps_dev, const DenseFusedTiles& tt, int total_tiles, int optkind, float lr, float eps,
                                  float b1, float b2, float slab_scale);
 // Column sums (bias gradients) leave their producers as one partial row per row block -- parts[p * N + c], plain stores --

@@ -399,7 +399,9 @@ def test_dlrm_fp16_staging_forms_are_bit_identical():
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dlrm_variant_worker.py")
     variants = [{}, {"ORX_GEMM16_DMA": "0"}, {"ORX_GEMM16_DMA": "2"}, {"ORX_GEMM16_TN_DMA": "0"}, {"ORX_GEMM16_TN_DMA": "2"},
                 {"ORX_GEMM16_NTS": "0"}, {"ORX_GEMM16_NTS": "1"},
-                {"ORX_GEMM16_NO_GROUP": "1"}]                 # round 6: a layer's dW and dX in one launch (gemm16_group_kernel) vs two
+                {"ORX_GEMM16_NO_GROUP": "1"},                 # round 6: a layer's dW and dX in one launch (gemm16_group_kernel) vs two
+                {"ORX_DLRM_COLPARTS_LAUNCH": "1"},            # ... the partial-row sums added by the optimizer launch vs a reduce launch
+                {"ORX_GEMM16_WAVE_TILE": "128"}]              # ... the 256 x 128 tile on four wavefronts of 128 x 64 (measured slower: off)
     digests = []
     for v in variants:
         env = dict(os.environ); env.update(v)
