@@ -388,7 +388,7 @@ extern "C" int orx_opt_destroy(orx_opt* o) {
         if (kv.first->lazy == o) orx_table_sync(kv.first);       // the table outlives the optimizer: finish its rows
         hipFree(kv.second.s0); hipFree(kv.second.s1); hipFree(kv.second.last);
     }
-    hipFree(o->d_lrt);
+    hipFree(o->d_lrt); hipFree(o->d_lrv);
     auto& live = o->ctx->opts;
     live.erase(std::remove(live.begin(), live.end(), o), live.end());
     delete o;
@@ -401,6 +401,8 @@ extern "C" int orx_opt_set_lr(orx_opt* o, float lr) {
         o->h_lrt.resize((size_t)o->t + 1);
         o->lrt_uploaded = std::min<int64_t>(o->lrt_uploaded, o->t + 1);
     }
+    // (closed-form replay: the moments of the last J steps looked ahead at rates that now change)
+    if (lr != o->lr) o->lrv_done = std::min<int64_t>(o->lrv_done, std::max<int64_t>(0, o->t + 1 - ORX_ADAM_CF_TERMS));
     o->lr = lr;
     return ORX_OK;
 }
@@ -467,6 +469,11 @@ int orx_opt_slots(orx_opt* o, orx_table* t, OptSlots* out) {
     return ORX_OK;
 }
 
+bool orx_adam_cf_ok(const orx_opt* o) {
+    static const bool off = getenv("ORX_ADAM_NO_CF") != nullptr;
+    return !off && o->kind == ORX_ADAM && o->p0 > 0.f && o->p0 <= 0.95f && o->p1 < 1.0f && (1.0f - sqrtf(o->p1)) <= 1e-3f;
+}
+
 // lr_t of steps 1..upto on the device (host mirror keeps every value ever used: a row may replay old steps)
 int orx_adam_lrt(orx_opt* o, int64_t upto) {
     if ((int64_t)o->h_lrt.size() < upto + 1) {
@@ -475,6 +482,40 @@ int orx_adam_lrt(orx_opt* o, int64_t upto) {
         o->h_lrt.resize((size_t)upto + 1);
         for (size_t k = old; k <= (size_t)upto; ++k)
             o->h_lrt[k] = k == 0 ? 0.f : (float)(o->lr * std::sqrt(1.0 - std::pow(b2, (double)k)) / (1.0 - std::pow(b1, (double)k)));
+    }
+    if (orx_adam_cf_ok(o) && o->lrv_done < upto + 1) {
+        // V_q[k] = sum_{j=1..J} b1^j j^q lr_{k+j} in double; lr of steps beyond the table: the rate they WILL have if the learning rate stays
+        // (orx_opt_set_lr takes the entries that looked ahead of a change back)
+        const double b1 = o->p0, b2 = o->p1;
+        auto L = [&](int64_t k) -> double {
+            return k < (int64_t)o->h_lrt.size() ? (double)o->h_lrt[(size_t)k] : o->lr * std::sqrt(1.0 - std::pow(b2, (double)k)) / (1.0 - std::pow(b1, (double)k));
+        };
+        o->h_lrv.resize(4 * ((size_t)upto + 1));
+        std::vector<double> Lw((size_t)ORX_ADAM_CF_TERMS + 1), pw((size_t)ORX_ADAM_CF_TERMS + 1);
+        for (int j = 1; j <= ORX_ADAM_CF_TERMS; ++j) pw[(size_t)j] = std::pow(b1, (double)j);
+        const int64_t k0 = o->lrv_done;
+        // (a sliding window over lr: entry k needs lr_{k+1 .. k+J})
+        std::vector<double> lr_all((size_t)(upto - k0 + 1 + ORX_ADAM_CF_TERMS) + 1);
+        for (size_t i = 0; i < lr_all.size(); ++i) lr_all[i] = L(k0 + (int64_t)i);
+        for (int64_t k = k0; k <= upto; ++k) {
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+            const double* lp = lr_all.data() + (k - k0);
+            for (int j = ORX_ADAM_CF_TERMS; j >= 1; --j) { const double t = pw[(size_t)j] * lp[j]; v0 += t; v1 += t * j; v2 += t * (double)j * j; }
+            float* e = o->h_lrv.data() + 4 * (size_t)k;
+            e[0] = (float)v0; e[1] = (float)v1; e[2] = (float)v2; e[3] = 0.f;
+        }
+        ORX_HIP(hipSetDevice(o->ctx->device));
+        if (o->lrv_cap < (size_t)upto + 1) {
+            const size_t cap = std::max<size_t>(4096, 2 * ((size_t)upto + 1));
+            float* p = nullptr;
+            ORX_HIP(hipMalloc((void**)&p, cap * 4 * sizeof(float)));
+            ORX_HIP(hipStreamSynchronize(o->ctx->stream));
+            if (o->d_lrv) { ORX_HIP(hipMemcpy(p, o->d_lrv, (size_t)k0 * 4 * sizeof(float), hipMemcpyDeviceToDevice)); ORX_HIP(hipFree(o->d_lrv)); }
+            o->d_lrv = p; o->lrv_cap = cap;
+        }
+        ORX_HIP(hipMemcpyAsync(o->d_lrv + 4 * (size_t)k0, o->h_lrv.data() + 4 * (size_t)k0, (size_t)(upto + 1 - k0) * 4 * sizeof(float), hipMemcpyHostToDevice, o->ctx->stream));
+        // entries that looked beyond `upto` used predicted rates: final only while the learning rate stays (set_lr moves lrv_done back)
+        o->lrv_done = upto + 1;
     }
     if (o->lrt_uploaded >= upto + 1) return ORX_OK;
     ORX_HIP(hipSetDevice(o->ctx->device));
@@ -688,6 +729,7 @@ static void plan_dedup_args(orx_ctx* c, orx_table* U, orx_table* V, const int32_
     if (plan.pair_tpw > 1) {        // pairing (kernels_plan.hip): per-step claims, pairing words, accepted pairs
         d.pair_tpw = plan.pair_tpw; d.pair_stride = B; d.pair_gen = c->pair_gen;
         d.partner = c->d_partner + (size_t)i0 * B; d.pslot = c->d_pslot + (size_t)i0 * 2 * plan.list_stride; d.ids4 = c->d_ids4 + (size_t)i0 * B;
+        d.label = nN == 0 ? c->plan_label : nullptr;
     }
     if (staging) {
         d.refinfo = c->d_refinfo + (size_t)i0 * 3 * plan.Bp; d.tricnt = c->d_tricnt + (size_t)i0 * B; d.segstart = c->d_segstart + (size_t)i0 * B;
@@ -906,6 +948,8 @@ void orx_exact_step_views(orx_ctx* c, const PairPlan& plan, int64_t i, int64_t B
 
 // pairing (kernels_plan.hip): SGD on the float4 dims with >= 2 triplets per wavefront, bucketed plan
 // (ORX_FORCE_FALLBACK bit 4 / ORX_NO_PAIR=1: off)
+bool orx_pairing_wanted(int mode, bool role_bits, int optkind, int dim, int64_t B, int fb);
+int orx_pairing_buffers(orx_ctx* c, int64_t B, int dim, PairPlan* plan);
 static bool pairing_wanted(int mode, bool role_bits, int optkind, int dim, int64_t B, int fb) {
     return mode == MODE_EXACT && orx_plan_v2(role_bits) && optkind == ORX_SGD && orx_fused_tpw(dim) > 1 && B >= 2 && B <= (1 << 22) && !(fb & 16) &&
            getenv("ORX_NO_PAIR") == nullptr;
@@ -917,6 +961,9 @@ static int pairing_buffers(orx_ctx* c, int64_t B, int dim, PairPlan* plan) {
     plan->pair_tpw = orx_fused_tpw(dim);
     return ORX_OK;
 }
+
+bool orx_pairing_wanted(int mode, bool role_bits, int optkind, int dim, int64_t B, int fb) { return pairing_wanted(mode, role_bits, optkind, dim, B, fb); }
+int orx_pairing_buffers(orx_ctx* c, int64_t B, int dim, PairPlan* plan) { return pairing_buffers(c, B, dim, plan); }
 
 // TF-2.0 Adam applied lazily (see orx_pairwise_step): float4 dims, role bits available, not hogwild
 static bool lazy_adam_ok(const orx_opt* opt, const orx_table* U, const orx_table* V, int flags) {
@@ -1026,6 +1073,10 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
         CHECK(orx_opt_last(opt, b, !lazy_resume, &a.lastb));
         CHECK(orx_adam_lrt(opt, opt->t + K));
         a.lrt = opt->d_lrt; a.b1 = opt->p0; a.b2 = opt->p1; a.eps = opt->p2;
+        if (orx_adam_cf_ok(opt) && opt->d_lrv != nullptr) {      // closed-form replay (fused_kernel LONGGAP = 2)
+            a.lrv = reinterpret_cast<const float4*>(opt->d_lrv);
+            a.cf_delta = (float)(-0.5 * std::log((double)opt->p1)); a.cf_lb1 = (float)std::log2((double)opt->p0); a.cf_lb2 = (float)std::log2((double)opt->p1);
+        }
         a.newton = (1.0f - sqrtf(opt->p1)) <= 1e-3f && getenv("ORX_ADAM_NO_NEWTON") == nullptr;
         // expected steps between two references of a row = rows / references per step
         a.long_gap = (U->rows / B > 64 || V->rows / (2 * B) > 64) && getenv("ORX_ADAM_NO_LONGGAP") == nullptr;

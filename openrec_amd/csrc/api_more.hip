@@ -98,6 +98,12 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
         const size_t part_cap = c->d_partial_cap;       // orx_exact_buffers sizes d_partial for its own use: keep ours
         CHECK(orx_exact_buffers(c, U, V, K, B, mode, true, inline_apply, staging, nb_total, nslot, &plan));
         if (opt->kind == ORX_ADAM) plan.min_late = 1;      // Adam: fixed summation order for every row referenced >= 3 times (api.hip)
+        // pairing (round 6): as in orx_pairwise_step -- SGD, float4 dims with >= 2 samples per wavefront, paused for 32 calls when a plan
+        // accepts few pairs.  ORX_NO_PAIR=1 / ORX_POINT_NO_PAIR=1 / ORX_FORCE_FALLBACK bit 4: off
+        if (orx_pairing_wanted(mode, true, opt->kind, D, B, fb) && getenv("ORX_POINT_NO_PAIR") == nullptr) {
+            if (c->pair_pause > 0) c->pair_pause -= 1;
+            else CHECK(orx_pairing_buffers(c, B, D, &plan));
+        }
         (void)part_cap;
         ENSURE(c->d_partial, c->d_partial_cap, (size_t)K * nslot * 2 * sizeof(float));
     } else if (mode == MODE_EXACT) {
@@ -153,7 +159,12 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     for (int64_t s0 = 0; s0 < K; s0 += chunk) {
     const int64_t kc = (K - s0 < chunk) ? (K - s0) : chunk;
     ExactChunk ck;
-    if (role_bits) CHECK(orx_exact_plan_chunk(c, U, V, du + s0 * ds, di + s0 * ds, di + s0 * ds, ds, B, B, 0, kc, B, true, inline_apply, staging, plan, &ck));
+    if (role_bits) {
+        c->plan_label = plan.pair_tpw > 1 ? dl + s0 * ds : nullptr;
+        const int rc_plan = orx_exact_plan_chunk(c, U, V, du + s0 * ds, di + s0 * ds, di + s0 * ds, ds, B, B, 0, kc, B, true, inline_apply, staging, plan, &ck);
+        c->plan_label = nullptr;
+        CHECK(rc_plan);
+    }
     const bool inl = inline_apply && !ck.hot && !ck.dense_dups;      // (many duplicated rows / reduction-tree levels: separate launches, api.hip)
     for (int64_t i = 0; i < kc; ++i) {
         const int64_t s = s0 + i;
@@ -161,6 +172,7 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
         a.partial = c->d_partial + (size_t)s * nslot * 2;
         if (role_bits) {
             a.uid = c->d_ids2 + (size_t)i * 3 * plan.Bp; a.iid = a.uid + plan.Bp;
+            a.ids4 = plan.pair_tpw > 1 ? c->d_ids4 + (size_t)i * B : nullptr;      // (with pairing the SoA copy is not written: the records are the input)
             orx_exact_step_views(c, plan, i, B, D, ck.use_stage, &pa);
             a.refinfo = pa.refinfo; a.segstart = pa.segstart; a.stage = pa.stage; a.stageb = pa.stageb;
         } else {

@@ -4,6 +4,7 @@
 // Restates openrec/tf2/recommenders/dlrm.py:8-100 and tf2_examples/dlrm_criteo.py:42-48.
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "orx_internal.h"
@@ -29,6 +30,8 @@ struct DenseLayer {
     float* slab = nullptr;              // split-K slices of this layer's weight gradient, [tiles][S][128 * 128]
     int slab_S = 1, slab_tiles = 0;
     uint64_t shadow_version = ~0ull;    // W->version the fp16 copies were made from
+    void* dz16 = nullptr;               // top MLP, deferred weight gradients (round 6): this layer's dZ16 keeps a buffer of its own until its
+                                        // weight-gradient product has run (g16 / g16b are reused two layers further down)
     float* gbpart = nullptr;            // bias-gradient partial rows [row blocks][out] (ColPart), carved from orx_dlrm::colpart
     float* gwpart = nullptr;            // the head layer: weight-gradient partial rows [row blocks][in]
 };
@@ -89,6 +92,11 @@ struct orx_dlrm {
     DenseFused* d_fused = nullptr;      // ... and for the fused launch of the fp16 mode (slab reduce + rule + fp16 copies)
     orx_opt* fused_opt = nullptr; int fused_tiles = 0; DenseFusedTiles fused_tt;
     bool grads_pending = false;         // orx_dlrm_grads ran, orx_dlrm_dense_apply not yet
+    // (round 6) the weight-gradient products of the top MLP only feed the optimizer: they are collected during the input-gradient chain and
+    // run on a side stream BESIDE the interaction backward (HBM-bound, the matrix pipes idle) -- ORX_DLRM_DEFER_DW=1 | 2; measured SLOWER
+    // than leaving them where they stand (ensure_buffers has the numbers): off by default, kept as the experiment's switch
+    int defer_dw = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool side_pending = false;
+    std::vector<std::function<int()>> deferred;
     std::vector<ColJob> pending_coljobs;   // fp16 mode of orx_dlrm_step: the step's partial-row sums, added by the fused optimizer launch
     std::vector<const float*> fused_out;   // descriptor index -> the gradient array (gsum) that descriptor applies
     std::vector<const float*> fused_cparts; std::vector<int> fused_cn;      // ... and its partial-row workspace / row length (NULL / 0: none)
@@ -217,6 +225,7 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
 
 static void free_buffers(orx_dlrm* m) {
     hipFree(m->R16); hipFree(m->g16); hipFree(m->g16b); m->R16 = m->g16 = m->g16b = nullptr;
+    for (auto& D : m->top) { hipFree(D.dz16); D.dz16 = nullptr; }
     for (auto& D : m->top) { hipFree(D.slab); D.slab = nullptr; }
     for (auto& D : m->bot) { hipFree(D.slab); D.slab = nullptr; }
     for (int k = 0; k < 2; ++k) { hipFree(m->d_slabjobs[k]); m->d_slabjobs[k] = nullptr; m->n_slabjobs[k] = 0; m->slab_max_tiles[k] = 0; }
@@ -243,6 +252,9 @@ extern "C" int orx_dlrm_destroy(orx_dlrm* m) {
     hipStreamSynchronize(m->ctx->stream);
     free_buffers(m);
     hipFree(m->d_single); hipFree(m->d_loss_part); hipFree(m->dense16_all);
+    if (m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); }
+    if (m->ev_fork) hipEventDestroy(m->ev_fork);
+    if (m->ev_join) hipEventDestroy(m->ev_join);
     hipFree(m->d_offset); hipFree(m->d_colwin); hipFree(m->d_rows); hipFree(m->d_loss); hipFree(m->d_params); hipFree(m->d_fused); hipFree(m->d_idx_all); hipFree(m->d_sparse_all); hipFree(m->d_tiny_f); hipFree(m->d_is_tiny); hipFree(m->d_flatseg);
     orx_table_destroy(m->emb);
     for (auto& d : m->bot) { orx_table_destroy(d.W); orx_table_destroy(d.b); hipFree(d.w16); hipFree(d.w16t); }
@@ -309,6 +321,21 @@ static int ensure_buffers(orx_dlrm* m, int64_t B) {
             void* p; const size_t bytes = (size_t)B * up8(m->top[l].out) * 2;
             ORX_HIP(hipMalloc(&p, bytes)); ORX_HIP(hipMemsetAsync(p, 0, bytes, m->ctx->stream));
             m->top_y16.push_back(p);
+        }
+    }
+    if (m->gen2) {
+        // measured (profiles/r6_defer_dw.txt, one box): 0 = 476-477 us per step, 1 = 488-491, 2 = 494-496 -- beside each other the interaction
+        // backward takes 88 us instead of 69, the 1024 x 512 weight gradient 69 instead of 17 (its 256 workgroups get a CU only as the 2048
+        // queued workgroups of the interaction drain), the bottom MLP's first grouped launch 29 instead of 13.  Off.
+        static const int defer_env = getenv("ORX_DLRM_DEFER_DW") ? atoi(getenv("ORX_DLRM_DEFER_DW")) : 0;
+        m->defer_dw = defer_env;
+        if (m->defer_dw > 0) {
+            for (auto& D : m->top) if (D.dw16) ORX_HIP(hipMalloc(&D.dz16, (size_t)B * up8(D.out) * 2));
+            if (!m->side) {
+                ORX_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+                ORX_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+                ORX_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+            }
         }
     }
     if (m->gen2) {          // fp16 copies on the bottom side, weight-gradient split-K workspaces, descriptors of the reduce launches
@@ -561,6 +588,8 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
     std::vector<ColJob> coljobs;        // bias gradients (and the head's weight gradient) leave as partial rows per row block
     auto colpart_of = [&](float* parts) { ColPart cp; cp.parts = parts; return cp; };
     const float inv_scale = 1.0f / gscale;                  // dy and everything derived from it carries the loss scale
+    // deferred weight gradients (top MLP of orx_dlrm_step's backward, see orx_dlrm::defer_dw): every layer's dZ16 in its own buffer
+    const bool own_dz = which == 1 && m->defer_dw > 0 && m->side != nullptr && defer_slabs;
     auto add_job = [&](const ColPart& cp, float* out, int N) { ColJob j; j.parts = cp.parts; j.out = out; j.N = N; j.P = cp.P; j.scale = inv_scale; coljobs.push_back(j); };
     for (int l = (int)L.size() - 1; l >= 0; --l) {
         DenseLayer& D = L[l];
@@ -574,11 +603,12 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
             const bool below16 = Bl.dw16 && orx_gemm16_nt_ok(Bl.out, Bl.ld16, Bl.in, Bl.out);
             ColPart pW = colpart_of(D.gwpart), pb = colpart_of(D.gbpart), pbb = colpart_of(Bl.gbpart);
             const HeadLoss* hl = (which == 1 && l == (int)L.size() - 1) ? m->cur_hl : nullptr;
+            void* dz_below = (own_dz && Bl.dz16 && Bl.out % 8 == 0) ? Bl.dz16 : m->g16;
             CHECK(orx_launch_head_bwd(c, (*ins16)[l], (*ld_in16)[l], D.w16t, dy, outs[l], D.act, Bl.act, &pW, &pb,
-                                      m->g16, Bl.out, below16 ? nullptr : other, ld_in[l], &pbb, (int)B, D.in, hl));
+                                      dz_below, Bl.out, below16 ? nullptr : other, ld_in[l], &pbb, (int)B, D.in, hl));
             if (hl) m->hl_used = true;
             add_job(pW, D.W->gsum, D.in); add_job(pb, D.b->gsum, 1); add_job(pbb, Bl.b->gsum, Bl.out);
-            act_done = true; dy16 = m->g16; dy32 = !below16;
+            act_done = true; dy16 = dz_below; dy32 = !below16;
             float* t = dy; dy = other; other = t;
             continue;
         }
@@ -597,15 +627,23 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
         act_done = false;
         // (round 6) layers whose two backward products cannot fill the chip alone run them in ONE launch (gemm16_group_kernel): both read dZ16
         const bool nt_here = want_dx && s16 && dy16 != nullptr && m->gen2 && orx_gemm16_nt_ok(D.out, D.ld16, D.in, D.out);
-        const bool grouped = D.dw16 && nt_here && ins16 && (*ins16)[l] && orx_gemm16_group_ok(c, (int)B, D.in, D.out, (*ld_in16)[l], D.ld16);
+        const bool can_defer = own_dz && D.dw16 && D.dz16 != nullptr && dy16 == D.dz16 && ins16 && (*ins16)[l];
+        const bool grouped = D.dw16 && nt_here && ins16 && (*ins16)[l] && orx_gemm16_group_ok(c, (int)B, D.in, D.out, (*ld_in16)[l], D.ld16) &&
+                             !(can_defer && m->defer_dw >= 2);          // (ORX_DLRM_DEFER_DW=2: the grouped layers' weight gradients are deferred too)
         // gW [in, out] = X^T * dZ
         if (grouped) {
             if (D.slab_S > 1) ++slabs;
         } else if (D.dw16) {
             ORX_ARG(dy16 != nullptr && ins16 && (*ins16)[l], "dlrm backward: fp16 operands missing for layer %d", l);
-            // (tried: these products on a second stream beside the input-gradient chain -- they only feed the optimizer.  The step
-            // went from 0.6125 to 0.628 ms: side by side the products slow each other down by more than the overlap gains.)
-            CHECK(orx_launch_gemm16_tn(c, (*ins16)[l], (*ld_in16)[l], dy16, D.out, D.W->gsum, D.out, D.slab, D.in, D.out, (int)B, inv_scale));
+            // (tried in round 3: these products on a second stream beside the input-gradient chain -- they only feed the optimizer.  The step
+            // went from 0.6125 to 0.628 ms: side by side the products slow each other down by more than the overlap gains.  Round 6: beside
+            // the INTERACTION backward instead -- HBM-bound, the matrix pipes idle -- see backward())
+            const void* x16 = (*ins16)[l]; const int64_t ldx16 = (*ld_in16)[l]; const void* dz = dy16;
+            DenseLayer* Dp = &D; const int Bi = (int)B;
+            auto go = [c, x16, ldx16, dz, Dp, Bi, inv_scale]() -> int {
+                return orx_launch_gemm16_tn(c, x16, ldx16, dz, Dp->out, Dp->W->gsum, Dp->out, Dp->slab, Dp->in, Dp->out, Bi, inv_scale);
+            };
+            if (can_defer) m->deferred.push_back(go); else CHECK(go());
             if (D.slab_S > 1) ++slabs;
         } else {
             ORX_ARG(dy32, "dlrm backward: fp32 gradient missing for layer %d", l);
@@ -616,7 +654,7 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
             // epilogue also applies that layer's activation backward, sums its bias gradient and writes its dZ16.
             if (s16 && dy16 != nullptr) {
                 const bool fuse = l > 0 && L[l - 1].w16 != nullptr && L[l - 1].out % 8 == 0 && ld_in[l] == L[l - 1].out;
-                void* next16 = (dy16 == m->g16) ? m->g16b : m->g16;
+                void* next16 = (own_dz && l > 0 && L[l - 1].dz16 && L[l - 1].out % 8 == 0) ? L[l - 1].dz16 : ((dy16 == m->g16) ? m->g16b : m->g16);
                 const bool nt = m->gen2 && orx_gemm16_nt_ok(D.out, D.ld16, D.in, D.out);
                 if (fuse) {
                     CHECK(orx_table_scratch(L[l - 1].b));
@@ -678,6 +716,7 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
 // Leaves dZ [B, F, d] (slot F-1 = d dense_emb) and every dense gradient in its table's gsum.
 static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale, bool defer_slabs = false) {
     orx_ctx* c = m->ctx;
+    m->deferred.clear();
     const int F = m->F, d = m->m_spa;
     const int compat = (m->flags & ORX_DLRM_REFERENCE_COMPAT) ? 1 : 0, itself = (m->flags & ORX_DLRM_INTERACT_ITSELF) ? 1 : 0;
     {
@@ -698,6 +737,20 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale, bool 
     CHECK(mlp_backward(m, m->top, ins, ldi, outs, ldo, m->gA, m->gB, B, true, &dR, gscale, defer_slabs, m->gen2 ? &ins16 : nullptr, &ldi16, &outs16, &coljobs));
     // ---- interaction backward: dZ for every slot (slot F-1 = d dense_emb)
     // (dR carries the loss scale; dZ -- the embedding rows' gradients -- leaves unscaled)
+    if (!m->deferred.empty()) {
+        // the top MLP's deferred weight gradients start with the interaction backward, on the side stream
+        ORX_HIP(hipEventRecord(m->ev_fork, c->stream));
+        ORX_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+        hipStream_t main_stream = c->stream;
+        c->stream = m->side;
+        int rc = ORX_OK;
+        for (auto& f : m->deferred) { rc = f(); if (rc != ORX_OK) break; }
+        c->stream = main_stream;
+        m->deferred.clear();
+        CHECK(rc);
+        ORX_HIP(hipEventRecord(m->ev_join, m->side));
+        m->side_pending = true;
+    }
     {
         // (round 6) the rows referenced once in the step take their SGD / Adagrad update inside this launch (kernels_dense.hip FusedRows)
         const bool fuse = m->fuse_single != nullptr && m->direct_idx != nullptr && m->ext_rows == nullptr && m->emb != nullptr && m->direct_base == m->emb->w;
@@ -731,6 +784,10 @@ static int backward(orx_dlrm* m, const Batch& bt, int64_t B, float gscale, bool 
     // (defer_slabs = the fused optimizer launch follows: it adds the partial rows itself, see dense_apply_all)
     if (defer_slabs && getenv("ORX_DLRM_COLPARTS_LAUNCH") == nullptr) m->pending_coljobs = coljobs;
     else CHECK(orx_launch_colparts_reduce(c, coljobs.data(), (int)coljobs.size()));
+    }
+    if (m->side_pending) {                                   // the optimizer launch reads the deferred products' slabs
+        ORX_HIP(hipStreamWaitEvent(c->stream, m->ev_join, 0));
+        m->side_pending = false;
     }
     return ORX_OK;
 }

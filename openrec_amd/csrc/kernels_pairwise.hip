@@ -463,7 +463,8 @@ int orx_launch_loss_reduce(orx_ctx* ctx, const ReduceArgs& a, int64_t K) {
 
 // ------------------------------------------------------------ fused kernel ---
 // LPR lanes own one row (D = 4*LPR).  MODE: see orx_internal.h.
-template <int LPR, int MODEL, int OPT, int MODE, bool CENSOR = false, bool STAGED = false, bool LONGGAP = false>
+// LONGGAP (lazy Adam): 0 = the merged replay loop, 1 = + the bounded per-row replay of rows far behind, 2 = the closed-form replay (orx_device.h AdamCF)
+template <int LPR, int MODEL, int OPT, int MODE, bool CENSOR = false, bool STAGED = false, int LONGGAP = 0>
 __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
@@ -565,7 +566,15 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             mbp = a.ab[p]; vbp = a.a2b[p]; mbn = a.ab[n]; vbn = a.a2b[n];
             // (the bias of an item shares the item row's stamp: the three tables are lazy together, api.hip)
             int lu = a.lastU[u], lp = a.lastV[p], ln = a.lastV[n];
-            if (LONGGAP) {      // large tables: rows that have waited very long take the bounded replay and leave the merged loop
+            if (LONGGAP == 2) {
+                const float4 Vt = a.lrv[T1];                 // (wave-uniform)
+                AdamCF cf;
+                if (lu < T1) { cf.setup(a.lrv, lu, T1, Vt, a.cf_lb1, a.cf_lb2); cf.row4(ru, mu, vu, a.eps, a.cf_delta); }
+                if (lp < T1) { cf.setup(a.lrv, lp, T1, Vt, a.cf_lb1, a.cf_lb2); cf.row4(rp, mp, vp, a.eps, a.cf_delta); cf.elem(bp, mbp, vbp, a.eps, a.cf_delta); }
+                if (ln < T1) { cf.setup(a.lrv, ln, T1, Vt, a.cf_lb1, a.cf_lb2); cf.row4(rn, mn, vn, a.eps, a.cf_delta); cf.elem(bn, mbn, vbn, a.eps, a.cf_delta); }
+                lu = lp = ln = T1;
+            }
+            if (LONGGAP == 1) {      // large tables: rows that have waited very long take the bounded replay and leave the merged loop
                 if (T1 - lu > ORX_ADAM_LONG_GAP) {
                     float z0 = 0.f, z1 = 0.f, z2 = 0.f;
                     adam_replay4_bounded(ru, mu, vu, z0, z1, z2, lu, T1, a.lrt, a.b1, a.b2, a.eps);
@@ -574,7 +583,8 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
                 if (T1 - lp > ORX_ADAM_LONG_GAP) { adam_replay4_bounded(rp, mp, vp, bp, mbp, vbp, lp, T1, a.lrt, a.b1, a.b2, a.eps); lp = T1; }
                 if (T1 - ln > ORX_ADAM_LONG_GAP) { adam_replay4_bounded(rn, mn, vn, bn, mbn, vbn, ln, T1, a.lrt, a.b1, a.b2, a.eps); ln = T1; }
             }
-            if (a.newton) adam_catchup_triplet<true, LPR>(ru, mu, vu, lu, rp, mp, vp, lp, rn, mn, vn, ln, bp, mbp, vbp, bn, mbn, vbn, T1, a.lrt, a.b1, a.b2, a.eps);
+            if (LONGGAP == 2) {}
+            else if (a.newton) adam_catchup_triplet<true, LPR>(ru, mu, vu, lu, rp, mp, vp, lp, rn, mn, vn, ln, bp, mbp, vbp, bn, mbn, vbn, T1, a.lrt, a.b1, a.b2, a.eps);
             else adam_catchup_triplet<false, LPR>(ru, mu, vu, lu, rp, mp, vp, lp, rn, mn, vn, ln, bp, mbp, vbp, bn, mbn, vbn, T1, a.lrt, a.b1, a.b2, a.eps);
         }
 
@@ -1047,8 +1057,21 @@ int orx_fused_tpw(int D) { const int lpr = lpr_for_dim(D); return lpr ? 64 / lpr
 // lazy Adam (exact mode, float4 dims): its own small set of instantiations
 template <int MODEL>
 static void launch_fused_adam(int lpr, dim3 g, orx_ctx* s, const PairArgs& a) {
-#define ORX_FL(L) do { if (a.stage) ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, true, true>), g, dim3(256), 0, a); \
-                       else ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, false, true>), g, dim3(256), 0, a); } while (0)
+#define ORX_FC(L) do { if (a.stage) ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, true, 2>), g, dim3(256), 0, a); \
+                       else ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, false, 2>), g, dim3(256), 0, a); } while (0)
+    if (a.lrv != nullptr && !a.censor) {      // the closed-form replay (orx_device.h AdamCF): no loop over the skipped steps
+        switch (lpr) {
+            case 4: ORX_FC(4); break;
+            case 8: ORX_FC(8); break;
+            case 16: ORX_FC(16); break;
+            case 32: ORX_FC(32); break;
+            default: ORX_FC(64); break;
+        }
+        return;
+    }
+#undef ORX_FC
+#define ORX_FL(L) do { if (a.stage) ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, true, 1>), g, dim3(256), 0, a); \
+                       else ORX_LAUNCH(s, (fused_kernel<L, MODEL, ORX_ADAM, MODE_EXACT, false, false, 1>), g, dim3(256), 0, a); } while (0)
     if (a.long_gap && !a.censor) {      // tables large relative to the batch: the variant with the bounded per-row replay
         switch (lpr) {
             case 4: ORX_FL(4); break;

@@ -136,8 +136,10 @@ __global__ __launch_bounds__(PL_THREADS) void plan_part_kernel(PlanArgs a) {
                     // pairing: the thread of a triplet's USER reference writes the fused kernel's input record -- the three ids (0x7fffffff:
                     // out of range), no pairing word, processed where it stands (w = position << 10)
                     if (j < a.d.pair_stride) {
-                        const int p = a.d.pid[s * a.d.id_stride + j], n = a.d.nid[s * a.d.id_stride + j];
-                        const bool okp = id_ok(p, a.d.NI), okn = id_ok(n, a.d.NI);
+                        const int p = a.d.pid[s * a.d.id_stride + j];
+                        // (a pointwise step: word z is the sample's label, not an id -- DedupArgs::label)
+                        const int n = a.d.label ? __float_as_int(a.d.label[s * a.d.id_stride + j]) : a.d.nid[s * a.d.id_stride + j];
+                        const bool okp = id_ok(p, a.d.NI), okn = a.d.label ? true : id_ok(n, a.d.NI);
                         a.d.ids4[s * a.d.pair_stride + j] = make_int4(ok ? id : 0x7fffffff, okp ? p : 0x7fffffff, okn ? n : 0x7fffffff, (int)((uint32_t)j << 10));
                         // (the pairing record is NOT initialised: its words count only with this plan's generation, orx_internal.h -- except
                         // for a triplet with an out-of-range id, which the fused kernel skips altogether: it must never be the partner a valid

@@ -35,10 +35,20 @@ __device__ __forceinline__ void point_score(float s, float y, float invB, float 
     }
 }
 
-template <int LPR, int MODEL, int OPT, int MODE>
+// PAIR: the instantiation with the pairing tail (97 against 73 VGPRs for GMF at D = 64 -- two wavefronts of occupancy: the host launches it
+// only for steps whose plan paired, a.ids4 != NULL)
+template <int LPR, int MODEL, int OPT, int MODE, bool PAIR = false>
 __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
     constexpr int TPW = 64 / LPR;
     constexpr int D = 4 * LPR;
+    // pairing (round 6; the pairwise step's machinery, kernels_plan.hip + fused_kernel): the two samples of a row referenced exactly
+    // twice in the step meet in a wavefront, leave their gradients of the row in LDS, and ONE of them writes the row -- no deposit,
+    // no apply of that row.  SGD only (as there); a sample has two id slots (0 user, 1 item), its label rides in the record's word z.
+    constexpr bool PAIRS = PAIR && MODE == MODE_EXACT && OPT == ORX_SGD && TPW > 1;
+    __shared__ f4 pair_xg[PAIRS ? 256 : 1];            // gradient exchange, one slot per lane
+    __shared__ float pair_xb[PAIRS ? 256 / LPR : 1];   // ... and per lane group (item bias)
+    __shared__ f4 pair_xw[PAIRS ? 256 : 1];            // the writer's copy of the shared row as read
+    __shared__ float pair_xwb[PAIRS ? 256 / LPR : 1];
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
@@ -55,8 +65,18 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
     if (MODEL == ORX_GMF) wv = *reinterpret_cast<const f4*>(a.w + 4 * sub);
     f4 gw_acc; gw_acc.x = gw_acc.y = gw_acc.z = gw_acc.w = 0.0f;
     for (int64_t t = wave_global * TPW + grp; t < a.B; t += stride) {
-        int u = a.uid[t], i = a.iid[t];
-        const float y = a.label[t];
+        int u, i; float y;
+        uint32_t pinfo = 0u;                    // pairing word of the sample processed at position t
+        int64_t t0 = t;                         // where the sample stood (its staging records are indexed by that)
+        bool packed = false;
+        if (PAIRS) packed = a.ids4 != nullptr;
+        if (packed) {
+            const int4 v = a.ids4[t];
+            u = v.x; i = v.y; y = __int_as_float(v.z);
+            pinfo = (uint32_t)v.w & 0x3ffu; t0 = (int64_t)((uint32_t)v.w >> 10);
+        } else {
+            u = a.uid[t]; i = a.iid[t]; y = a.label[t];
+        }
         int du = 0, di = 0;
         int ku = 2, ki = 2;                     // duplicate role: 0 / 1 = plain store into scratch row 1 / 2, 2 = staged or atomics
         int urgent = 0;
@@ -71,7 +91,17 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
             }
         }
         if (MODE == MODE_ACCUM) { du = di = 1; }
-        if (!(id_ok(u, a.NU) & id_ok(i, a.NI))) { if (sub == 0) *a.err = 1; continue; }
+        if (!(id_ok(u, a.NU) & id_ok(i, a.NI))) {
+            if (sub == 0) *a.err = 1;
+            if (PAIRS) {
+                if (pinfo & ORX_PAIR_VALID) {   // (its partner must not add what an earlier iteration left in LDS)
+                    f4 z; z.x = z.y = z.z = z.w = 0.0f;
+                    pair_xg[threadIdx.x] = z;
+                    if (sub == 0) pair_xb[threadIdx.x / LPR] = 0.0f;
+                }
+            }
+            continue;
+        }
         if (MODE == MODE_EXACT && urgent && nab) {      // a row of this sample is being updated by an apply block of this launch
             if (sub == 0) {
                 if (urgent & 1) wait_ready(a.readyU + u, a.epoch);
@@ -105,6 +135,18 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
         const f4 gu = gs * (ri * wv) + a.l2w * ru;
         const f4 gi = gs * (ru * wv) + a.l2w * ri;
         if (MODEL == ORX_GMF) gw_acc += gs * ui;
+        if (PAIRS) {
+            if (pinfo & ORX_PAIR_VALID) {
+                const int myslot = (pinfo >> 4) & 3;
+                pair_xg[threadIdx.x] = myslot == 0 ? gu : gi;
+                if (pinfo & ORX_PAIR_WRITER) pair_xw[threadIdx.x] = myslot == 0 ? ru : ri;
+                if (sub == 0) {
+                    pair_xb[threadIdx.x / LPR] = gs;
+                    if (pinfo & ORX_PAIR_WRITER) pair_xwb[threadIdx.x / LPR] = bi;
+                }
+                if (myslot == 0) { du = 1; ku = 3; } else { di = 1; ki = 3; }      // the slot is settled: no store below
+            }
+        }
         // staged references: slot = segment start of the row + rank of the reference (refinfo (-1, 0): no plan)
         auto slot_of = [&](int64_t ref) -> int {
             if (MODE != MODE_EXACT || a.stage == nullptr) return -1;
@@ -135,14 +177,28 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
             continue;
         }
         if (du == 0) opt_apply4<OPT>(Up, a.aU + (size_t)u * D + 4 * sub, ru, gu, a.lr, a.eps);
-        else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t) : -1, D, sub);
+        else dup_store4s(a.gU, a.gU2, (size_t)u * D + 4 * sub, gu, ku, a.stage, ku == 2 ? slot_of(t0) : -1, D, sub);
         if (di == 0) {
             opt_apply4<OPT>(Ip, a.aV + (size_t)i * D + 4 * sub, ri, gi, a.lr, a.eps);
             if (sub == 0) opt_apply1<OPT>(a.b + i, a.ab + i, bi, gs, a.lr, a.eps);
         } else {
-            const int si = ki == 2 ? slot_of((a.iid - a.uid) + t) : -1;
+            const int si = ki == 2 ? slot_of((a.iid - a.uid) + t0) : -1;
             dup_store4s(a.gV, a.gV2, (size_t)i * D + 4 * sub, gi, ki, a.stage, si, D, sub);
             if (sub == 0) dup_store1s(a.gb, a.gb2, i, gs, ki, a.stageb, si);
+        }
+        if (PAIRS) {
+            // the writer of a pair: TF sums the gradients of duplicate indices before the sparse apply -- the two gradients
+            // are added and the rule is applied once, to the row as this lane group read it (a wavefront's LDS operations execute in order)
+            if (pinfo & ORX_PAIR_WRITER) {
+                const int myslot = (pinfo >> 4) & 3;
+                const int xsrc = (int)(threadIdx.x & ~63u) + (int)(pinfo & 15u) * LPR + sub;
+                const int id = myslot == 0 ? u : i;
+                const size_t off = (size_t)id * D + 4 * sub;
+                const f4 gsum2 = pair_xg[threadIdx.x] + pair_xg[xsrc];
+                opt_apply4<OPT>((myslot == 0 ? a.U : a.V) + off, (myslot == 0 ? a.aU : a.aV) + off, pair_xw[threadIdx.x], gsum2, a.lr, a.eps);
+                if (myslot != 0 && sub == 0)
+                    opt_apply1<OPT>(a.b + id, a.ab + id, pair_xwb[threadIdx.x / LPR], pair_xb[threadIdx.x / LPR] + pair_xb[xsrc / LPR], a.lr, a.eps);
+            }
         }
     }
     const float ls = wave_sum(loss_acc);
@@ -348,7 +404,10 @@ static inline int64_t point_grid(int D, int64_t B) {
     const int lpr = lpr_for_dim_p(D);
     const int64_t tpb = lpr ? 4 * (64 / lpr) : 4;
     int64_t g = (B + tpb - 1) / tpb;
-    if (g > 16384) g = 16384;
+    // ORX_POINT_GRID_MAX (A/B): workgroups that loop over several sample blocks leave fewer partial rows for GMF's Dense(1) gradient
+    // (<= 1024: dense_reduce_kernel alone, no dense_reduce1_kernel launch)
+    static const int64_t cap = getenv("ORX_POINT_GRID_MAX") ? std::max(64, atoi(getenv("ORX_POINT_GRID_MAX"))) : 16384;
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     return g;
 }
@@ -360,7 +419,10 @@ int orx_point_wparts(int D, int64_t B) { return (int)(point_grid(D, B) * (lpr_fo
 template <int LPR, int MODEL, int OPT>
 static void launch_point_mode(int mode, dim3 g, orx_ctx* c, const PointArgs& a) {
     switch (mode) {
-        case MODE_EXACT: ORX_LAUNCH(c, (point_fused_kernel<LPR, MODEL, OPT, MODE_EXACT>), g, dim3(256), 0, a); break;
+        case MODE_EXACT:
+            if (OPT == ORX_SGD && LPR < 64 && a.ids4 != nullptr) ORX_LAUNCH(c, (point_fused_kernel<LPR, MODEL, OPT, MODE_EXACT, true>), g, dim3(256), 0, a);
+            else ORX_LAUNCH(c, (point_fused_kernel<LPR, MODEL, OPT, MODE_EXACT>), g, dim3(256), 0, a);
+            break;
         case MODE_HOGWILD: ORX_LAUNCH(c, (point_fused_kernel<LPR, MODEL, OPT, MODE_HOGWILD>), g, dim3(256), 0, a); break;
         case MODE_ACCUM: ORX_LAUNCH(c, (point_fused_kernel<LPR, MODEL, ORX_SGD, MODE_ACCUM>), g, dim3(256), 0, a); break;
         default: ORX_LAUNCH(c, (point_fused_kernel<LPR, MODEL, ORX_SGD, MODE_LOSS>), g, dim3(256), 0, a); break;

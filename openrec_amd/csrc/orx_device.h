@@ -308,6 +308,39 @@ __device__ __forceinline__ void adam_replay4_bounded(f4& w, f4& m, f4& v, float&
     }
 }
 
+// ---- closed-form replay (round 6).  The gradient-free steps from+1 .. to of an element are
+//     m_j = m b1^j,   sqrt(v_j) = a0 rho^j  (a0 = sqrt(v), rho = sqrt(b2)),   w -= sum_{j=1..n} lr_{from+j} m b1^j F(j),   F(j) = 1 / (a0 rho^j + eps).
+// b1^j lr_{from+j} decays by ~10 % per step while F moves by at most delta = -ln(rho) = 5e-4 per step: F is expanded to second order at
+// j = 0 -- F(j) ~ F0 (1 + delta x j + delta^2 x (2x - 1) j^2 / 2), x = a0 F0 -- and the sum needs only the three moments
+// W_q = sum_{j=1..n} b1^j j^q lr_{from+j}, which come from the per-step table V_q[k] = sum_{j>=1} b1^j j^q lr_{k+j} (host, double; orx_adam_lrt):
+//     W_0 = V_0[from] - b1^n V_0[to],  W_1 = V_1[from] - b1^n (n V_0[to] + V_1[to]),  W_2 = V_2[from] - b1^n (n^2 V_0[to] + 2 n V_1[to] + V_2[to]).
+// Truncation: the third-order term is delta^3 * sum j^3 b1^j / 6 ~ 1e-6 of the sum; cancellation in W_q costs <= 10 ulp.  No loop, no
+// divergence between the rows of a wavefront (the merged loop ran every wavefront to the LONGEST gap of its twelve rows: ~3x the mean).
+// lr_k itself is not expanded (it moves by per cents per step early in training): the table carries it exactly.
+struct AdamCF {
+    float W0, W1, W2, p1, p2;                   // the row's moments and decay factors b1^n, b2^n
+    __device__ __forceinline__ void setup(const float4* lrv, int from, int to, float4 Vt, float lb1, float lb2) {
+        const float n = (float)(to - from);
+        const float4 Vf = lrv[from];
+        p1 = exp2f(n * lb1); p2 = exp2f(n * lb2);
+        W0 = Vf.x - p1 * Vt.x;
+        W1 = Vf.y - p1 * (n * Vt.x + Vt.y);
+        W2 = Vf.z - p1 * ((n * n) * Vt.x + (2.0f * n) * Vt.y + Vt.z);
+    }
+    __device__ __forceinline__ void elem(float& w, float& m, float& v, float eps, float delta) const {
+        const float a0 = sqrtf(v);
+        const float F0 = __builtin_amdgcn_rcpf(a0 + eps);
+        const float x = a0 * F0;
+        w -= (m * F0) * (W0 + (delta * x) * (W1 + (0.5f * delta) * (2.0f * x - 1.0f) * W2));
+        m *= p1; v *= p2;
+    }
+    __device__ __forceinline__ void row4(f4& w, f4& m, f4& v, float eps, float delta) const {
+        float wx = w.x, wy = w.y, wz = w.z, ww = w.w, mx = m.x, my = m.y, mz = m.z, mw = m.w, vx = v.x, vy = v.y, vz = v.z, vw = v.w;
+        elem(wx, mx, vx, eps, delta); elem(wy, my, vy, eps, delta); elem(wz, mz, vz, eps, delta); elem(ww, mw, vw, eps, delta);
+        w.x = wx; w.y = wy; w.z = wz; w.w = ww; m.x = mx; m.y = my; m.z = mz; m.w = mw; v.x = vx; v.y = vy; v.z = vz; v.w = vw;
+    }
+};
+
 // the three rows (and the two item biases, which share their item row's stamp) of one triplet in ONE loop: its trip
 // count is the longest of the three gaps, not their sum, and the three chains interleave.  A row whose gap is
 // shorter is masked out of the early iterations.

@@ -67,6 +67,7 @@ struct orx_ctx {
     int4* d_partner = nullptr; size_t d_partner_cap = 0;         // [K][B] per triplet: where the partner of its slot 0 / 1 / 2 sits if that row is referenced exactly twice (generation-tagged words, ORX_PARTNER_*)
     int* d_pslot = nullptr;    size_t d_pslot_cap = 0;           // [K][2B] parallel to dlist: position of the FIRST reference of a row referenced exactly twice (-1: another kind of row)
     int4* d_ids4 = nullptr;    size_t d_ids4_cap = 0;            // [K][B] the fused kernel's input with pairing, written by the plan itself: (user, pos, neg) rewritten ids of position j, pairing word | origin << 10
+    const float* plan_label = nullptr;                           // pointwise step with pairing: the labels of the chunk being planned (DedupArgs::label)
     int* h_plan = nullptr;                                       // pinned host mirror of the per-step plan counters
     size_t h_plan_cap = 0;
     hipEvent_t plan_ev = nullptr;                                // "plan counters have arrived on the host"
@@ -146,7 +147,12 @@ struct orx_opt {
     std::map<orx_table*, OptSlots> slots;
     // lazy Adam: lr_t of every step taken so far (index = step), host mirror + device copy
     std::vector<float> h_lrt; float* d_lrt = nullptr; size_t lrt_cap = 0; int64_t lrt_uploaded = 0;
+    // closed-form replay (round 6, orx_device.h adam_cf_*): per step k the three moments V_q[k] = sum_{j=1..J} b1^j j^q lr_{k+j}, q = 0, 1, 2
+    // (float4 per step, w unused); entries [0, lrv_done) are final for the present learning rate
+    std::vector<float> h_lrv; float* d_lrv = nullptr; size_t lrv_cap = 0; int64_t lrv_done = 0;
 };
+constexpr int ORX_ADAM_CF_TERMS = 512;        // J: b1^J is negligible for b1 <= 0.95
+bool orx_adam_cf_ok(const orx_opt* o);        // closed-form replay applicable (b1 <= 0.95, 1 - sqrt(b2) <= 1e-3, ORX_ADAM_NO_CF unset)
 // Lazily-applied TF-2.0 Adam: the dense decay of a row that no triplet touches (m *= b1, v *= b2, w -= lr_t m /
 // (sqrt(v)+eps), every step) is replayed exactly when the row is next needed.  orx_table_sync brings every row of a
 // table up to the optimizer's current step; every entry point that reads or writes a table calls it first.
@@ -206,6 +212,8 @@ struct PairArgs {
     const float* lrt; float b1; float b2; int step_t;   // lr_t per step, betas, index of THIS step (its lr_t = lrt[step_t])
     int newton;                 // lazy Adam: carry 1/(sqrt(v)+eps) by Newton steps (1 - sqrt(beta_2) <= 1e-3)
     int long_gap;               // lazy Adam: tables large relative to the batch (rows wait hundreds of steps): LONGGAP kernel
+    const float4* lrv;          // lazy Adam, closed-form replay: V_q per step (orx_opt::d_lrv), NULL: the replay loops
+    float cf_delta, cf_lb1, cf_lb2;     // -ln sqrt(b2), log2 b1, log2 b2
     const int32_t* uid; const int32_t* pid; const int32_t* nid;
     const int4* ids4;                         // pairing: [B] (user, pos item, neg item) rewritten ids of the triplet processed at position j and, in w, its pairing
                                               // word (ORX_PAIR_*, bits 9:0) and the triplet's original position (bits 31:10); NULL: uid / pid / nid as usual
@@ -266,6 +274,9 @@ struct DedupArgs {
     // of step s is alloc[8 s + 7]
     int pair_tpw; int4* partner; int* pslot; int4* ids4; int64_t pair_stride;
     int pair_gen;                             // generation tag (1 .. 63) of this plan's partner words: see ORX_PARTNER_* below
+    // pointwise steps (two id lists, nN = 0) with pairing: word z of a sample's input record carries its LABEL (the bits of the float)
+    // instead of a third id -- it travels with the ids when plan_swap_kernel moves the sample.  [K][id_stride], NULL: pairwise
+    const float* label;
 };
 // pairing word of a triplet (PairArgs::pinfo): the triplet shares one row with the triplet of lane group PARTNER of the same wavefront;
 // the WRITER adds the partner's gradient of that row to its own and updates the row in place, the other one does not write it
@@ -366,6 +377,8 @@ struct PointArgs {
     // references marked urgent (bit 28 of the rewritten ids) wait for their row's ready flag
     int n_apply_blocks; int epoch; const int* readyU; const int* readyV;
     PairArgs ap;
+    // pairing (round 6; kernels_plan.hip): the step's input records (user id, item id, label bits, pairing word | origin << 10), NULL: off
+    const int4* ids4;
 };
 
 int orx_launch_point_fused(orx_ctx* ctx, int model, int optkind, int mode, const PointArgs& a);
@@ -391,6 +404,9 @@ struct PairPlan { int nw; int64_t chunk; int64_t list_stride; int64_t Bp; int64_
                   int64_t cap = 0; };     // steps the per-step scratch is sized for (>= chunk)
 struct ExactChunk { bool hot = false, use_stage = false, dense_dups = false; int tree_levels = 0;
                     bool quiet = false; };      // the plan's counters were quiet (api.hip, "no read-back")
+// pairing (kernels_plan.hip): is it on for a step of this form, and its per-call buffers (api.hip)
+bool orx_pairing_wanted(int mode, bool role_bits, int optkind, int dim, int64_t B, int fb);
+int orx_pairing_buffers(orx_ctx* c, int64_t B, int dim, PairPlan* plan);
 int orx_exact_buffers(orx_ctx* c, orx_table* U, orx_table* V, int64_t K, int64_t B, int mode, bool role_bits,
                       bool inline_apply, bool staging, int nb_total, int nw, PairPlan* plan);
 int orx_exact_plan_chunk(orx_ctx* c, orx_table* U, orx_table* V, const int32_t* uid, const int32_t* pid, const int32_t* nid, int64_t ds,

@@ -401,6 +401,7 @@ def test_dlrm_fp16_staging_forms_are_bit_identical():
                 {"ORX_GEMM16_NTS": "0"}, {"ORX_GEMM16_NTS": "1"},
                 {"ORX_GEMM16_NO_GROUP": "1"},                 # round 6: a layer's dW and dX in one launch (gemm16_group_kernel) vs two
                 {"ORX_DLRM_COLPARTS_LAUNCH": "1"},            # ... the partial-row sums added by the optimizer launch vs a reduce launch
+                {"ORX_DLRM_DEFER_DW": "1"}, {"ORX_DLRM_DEFER_DW": "2"},   # ... the top MLP's weight gradients beside the interaction backward (side stream; measured slower: off)
                 {"ORX_GEMM16_WAVE_TILE": "128"}]              # ... the 256 x 128 tile on four wavefronts of 128 x 64 (measured slower: off)
     digests = []
     for v in variants:

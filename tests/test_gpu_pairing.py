@@ -195,3 +195,97 @@ def test_an_invalid_id_never_takes_a_partner_down():
     loss_part = (g1["gu"][0] - U[uid[0]]) / B
     want_row = U[uid[0]] - 0.05 * (loss_part + U[uid[0]])
     assert np.abs(got[uid[0]] - want_row).max() < 1e-6, "the valid triplet's update of the shared row was lost"
+
+
+# ---------------------------------------------------------------------------------------------- pointwise steps (round 6)
+def _point_case(seed, NU, NI, B, D, K):
+    rng = np.random.default_rng(seed)
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32); w = rng.uniform(-.3, .3, (D, 1)).astype(np.float32)
+    uid = rng.integers(0, NU, (K, B)).astype(np.int32); iid = rng.integers(0, NI, (K, B)).astype(np.int32)
+    lab = (rng.uniform(size=(K, B)) < 0.4).astype(np.float32)
+    return U, V, b, w, uid, iid, lab
+
+
+def _point_run(model, U, V, b, w, uid, iid, lab, sigmoid=False):
+    rt = _rt()
+    ctx = rt.Context(0)
+    tU, tV, tb = (rt.Table(*x.shape, ctx).write(x) for x in (U, V, b))
+    tw = rt.Table(*w.shape, ctx).write(w) if model == "gmf" else None
+    o = rt.Optimizer.sgd(0.05, ctx=ctx)
+    K, B = uid.shape
+    l, l2 = rt.pointwise_step(model, o, tU, tV, tb, tw, uid.reshape(-1), iid.reshape(-1), lab.reshape(-1), K=K, B=B, a=1.5, b_w=0.7, sigmoid=sigmoid)
+    out = dict(U=tU.read(), V=tV.read(), b=tb.read(), loss=np.asarray(l, np.float64), l2=np.asarray(l2, np.float64),
+               pairs=ctx.stat("pairs"), max_dup=ctx.stat("max_dup"))
+    if model == "gmf":
+        out["w"] = tw.read()
+    return out
+
+
+def _point_oracle(model, U, V, b, w, uid, iid, lab, sigmoid=False):
+    from oracle import numpy_oracle as orc
+    U, V, b, w = U.copy(), V.copy(), b.copy(), w.copy()
+    opt = orc.SGD(lr=0.05)
+    ls = []
+    for k in range(uid.shape[0]):
+        if model == "gmf":
+            ls.append(orc.gmf_step(U, V, b, w, uid[k], iid[k], lab[k], opt))
+        else:
+            ls.append(orc.wrmf_step(U, V, b, uid[k], iid[k], lab[k], opt, a=1.5, b_w=0.7, sigmoid=sigmoid))
+    out = dict(U=U, V=V, b=b, loss=np.array([x[0] for x in ls], np.float64), l2=np.array([x[1] for x in ls], np.float64))
+    if model == "gmf":
+        out["w"] = w
+    return out
+
+
+@pytest.mark.parametrize("D", [16, 32, 64, 128])
+@pytest.mark.parametrize("model,sigmoid", [("gmf", False), ("wrmf", False), ("wrmf", True)])
+@pytest.mark.parametrize("B", [4096, 4095])
+def test_pointwise_paired_step_equals_unpaired_step_and_oracle(D, model, sigmoid, B):
+    """GMF / WRMF (gmf.py:22-34, wrmf.py:21-34, pointwise_mse_loss.py:18-31) with the pairing plan: the two samples of a row referenced
+    exactly twice exchange their gradients in a wavefront and one of them writes the row; a sample's LABEL travels with its ids in the
+    plan's input records (word z) when the plan moves it next to its partner.  Paired = unpaired = oracle, and pairs were accepted."""
+    U, V, b, w, uid, iid, lab = _point_case(31 + D, 30000, 30000, B, D, K=5)
+    with env(ORX_PAIR_ALWAYS=1, ORX_NO_PAIR=None, ORX_POINT_NO_PAIR=None):
+        paired = _point_run(model, U, V, b, w, uid, iid, lab, sigmoid)
+    with env(ORX_POINT_NO_PAIR=1):
+        plain = _point_run(model, U, V, b, w, uid, iid, lab, sigmoid)
+    want = _point_oracle(model, U, V, b, w, uid, iid, lab, sigmoid)
+    assert paired["pairs"] > 5 * 50, "pairing was idle: %d accepted pairs" % paired["pairs"]
+    assert plain["pairs"] == 0
+    assert paired["max_dup"] < plain["max_dup"]
+    keys = ("U", "V", "b", "loss", "l2") + (("w",) if model == "gmf" else ())
+    for what, a, c in (("paired vs oracle", paired, want), ("unpaired vs oracle", plain, want), ("paired vs unpaired", paired, plain)):
+        for k in keys:
+            assert rel_err(a[k], c[k]) < TOL, (what, k, rel_err(a[k], c[k]))
+
+
+def test_pointwise_pairing_in_a_long_call_with_an_invalid_id_and_skew():
+    """K = 40 (the in-launch apply across many steps, dead list entries), one sample with an out-of-range item id (skipped, never
+    anybody's partner), a hot item (hundreds of references: the deposit / staging path beside the pairs)"""
+    rt = _rt()
+    U, V, b, w, uid, iid, lab = _point_case(77, 50000, 60000, 8192, 64, K=40)
+    iid[:, 100:400] = 12345
+    bad = iid.copy(); bad[3, 17] = 60000 + 5
+    with env(ORX_PAIR_ALWAYS=1, ORX_NO_PAIR=None, ORX_POINT_NO_PAIR=None):
+        ctx = rt.Context(0)
+        tU, tV, tb = (rt.Table(*x.shape, ctx).write(x) for x in (U, V, b))
+        o = rt.Optimizer.sgd(0.0005, ctx=ctx)
+        import torch
+        du, di, dl = (torch.from_numpy(x.reshape(-1)).cuda() for x in (uid, bad, lab))     # (device ids: an invalid id is reported, not raised)
+        l, l2 = rt.pointwise_step("wrmf", o, tU, tV, tb, None, du, di, dl, K=40, B=8192, a=1.5, b_w=0.7)
+        assert ctx.stat("pairs") > 40 * 100
+        with pytest.raises(Exception):
+            ctx.check_index_error()
+        got = dict(U=tU.read(), V=tV.read(), b=tb.read())
+    from oracle import numpy_oracle as orc
+    Uo, Vo, bo = U.copy(), V.copy(), b.copy()
+    opt = orc.SGD(lr=0.0005)
+    for k in range(40):
+        keep = np.ones(8192, bool)
+        if k == 3:
+            keep[17] = False                                     # the reference's gather raises on it; the device skips the sample
+        # (WRMF's loss is a SUM over the batch, pointwise_mse_loss.py:31: the other samples' gradients do not notice the missing one)
+        orc.wrmf_step(Uo, Vo, bo, uid[k][keep], iid[k][keep], lab[k][keep], opt, a=1.5, b_w=0.7)
+    for k, want in (("U", Uo), ("V", Vo), ("b", bo)):
+        assert rel_err(got[k], want) < TOL, (k, rel_err(got[k], want))
