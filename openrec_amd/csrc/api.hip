@@ -474,6 +474,15 @@ bool orx_adam_cf_ok(const orx_opt* o) {
     return !off && o->kind == ORX_ADAM && o->p0 > 0.f && o->p0 <= 0.95f && o->p1 < 1.0f && (1.0f - sqrtf(o->p1)) <= 1e-3f;
 }
 
+AdamCFParams orx_adam_cf_params(const orx_opt* o) {
+    AdamCFParams p; p.lrv = nullptr; p.delta = p.lb1 = p.lb2 = 0.f;
+    if (orx_adam_cf_ok(o) && o->d_lrv != nullptr) {
+        p.lrv = reinterpret_cast<const float4*>(o->d_lrv);
+        p.delta = (float)(-0.5 * std::log((double)o->p1)); p.lb1 = (float)std::log2((double)o->p0); p.lb2 = (float)std::log2((double)o->p1);
+    }
+    return p;
+}
+
 // lr_t of steps 1..upto on the device (host mirror keeps every value ever used: a row may replay old steps)
 int orx_adam_lrt(orx_opt* o, int64_t upto) {
     if ((int64_t)o->h_lrt.size() < upto + 1) {
@@ -543,7 +552,7 @@ int orx_table_sync(orx_table* t) {
     ORX_HIP(hipSetDevice(o->ctx->device));
     CHECK(orx_adam_lrt(o, o->t));
     return orx_launch_adam_flush(o->ctx, t->w, it->second.s0, it->second.s1, it->second.last, t->rows, t->dim, (int)o->t, o->d_lrt,
-                                 o->p0, o->p1, o->p2);
+                                 o->p0, o->p1, o->p2, orx_adam_cf_params(o));
 }
 
 // per-row step stamps of the lazy Adam (all rows current at the optimizer's present step)
@@ -1106,6 +1115,7 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             }
             orx_exact_step_views(c, plan, i, B, U->dim, stage_views, &a);
             a.ids4 = plan.pair_tpw > 1 ? c->d_ids4 + (size_t)i * B : nullptr;
+            a.follow_origin = orx_plan_no_swap() ? 1 : 0;
             a.partial = c->d_partial + (size_t)i * nw * 2;
             a.epoch = ++c->epoch;           // one epoch per step: ready flags and censor side marks are tagged with it
             if (lazy_adam) { opt->t += 1; a.step_t = (int)opt->t; }

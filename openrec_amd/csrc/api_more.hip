@@ -152,6 +152,10 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
         pa.lastU = a.lastU; pa.lastV = a.lastV; pa.lastb = a.lastb;
         CHECK(orx_adam_lrt(opt, opt->t + K));
         a.lrt = pa.lrt = opt->d_lrt; a.b1 = pa.b1 = opt->p0; a.b2 = pa.b2 = opt->p1; a.eps = pa.eps = opt->p2;
+        if (orx_adam_cf_ok(opt) && opt->d_lrv != nullptr) {
+            a.lrv = reinterpret_cast<const float4*>(opt->d_lrv);
+            a.cf_delta = (float)(-0.5 * std::log((double)opt->p1)); a.cf_lb1 = (float)std::log2((double)opt->p0); a.cf_lb2 = (float)std::log2((double)opt->p1);
+        }
         a.newton = pa.newton = (1.0f - sqrtf(opt->p1)) <= 1e-3f && getenv("ORX_ADAM_NO_NEWTON") == nullptr;
         U->lazy = opt; V->lazy = opt; b->lazy = opt;
     }
@@ -372,6 +376,7 @@ static int adam_rows_args(orx_ctx* ctx, orx_opt* opt, orx_table* t, int64_t now,
     a->W = t->w; a->M = st.s0; a->V = st.s1; a->rows = t->rows; a->D = t->dim;
     a->lrt = opt->d_lrt; a->b1 = opt->p0; a->b2 = opt->p1; a->eps = opt->p2;
     a->newton = (1.0f - sqrtf(opt->p1)) <= 1e-3f;
+    a->cf = orx_adam_cf_params(opt);
     a->err = ctx->d_err;
     return ORX_OK;
 }

@@ -168,13 +168,13 @@ int orx_launch_adam_sweep(orx_ctx* ctx, float* w, float* m, float* v, float* gsu
 // lazy Adam: bring every row of a table up to optimizer step t_end (replaying its gradient-free steps), then
 // mark the rows current.  Two kernels: all elements of a row read last[row] before it changes.
 __global__ __launch_bounds__(256) void adam_flush_kernel(float* w, float* m, float* v, const int* last, int64_t n, int dim, int t_end,
-                                                         const float* lrt, float b1, float b2, float eps) {
+                                                         const float* lrt, float b1, float b2, float eps, AdamCFParams cf) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int from = last[i / dim];
         if (from >= t_end) continue;
         float wi = w[i], mi = m[i], vi = v[i];
-        adam_replay1<false>(wi, mi, vi, from, t_end, lrt, b1, b2, eps, (1.0f - sqrtf(b2)) <= 1e-3f);     // bounded: see orx_device.h
+        adam_replay1<false>(wi, mi, vi, from, t_end, lrt, b1, b2, eps, (1.0f - sqrtf(b2)) <= 1e-3f, cf);     // closed form, or bounded loop: see orx_device.h
         w[i] = wi; m[i] = mi; v[i] = vi;
     }
 }
@@ -192,11 +192,11 @@ int orx_launch_fill_int(orx_ctx* ctx, int* p, int64_t n, int v) {
 }
 
 int orx_launch_adam_flush(orx_ctx* ctx, float* w, float* m, float* v, int* last, int64_t rows, int dim, int t_end, const float* lrt,
-                          float b1, float b2, float eps) {
+                          float b1, float b2, float eps, AdamCFParams cf) {
     ProfScope ps(ctx, ORX_K_SWEEP);
     const int64_t n = rows * dim;
     if (n == 0) return ORX_OK;
-    ORX_LAUNCH(ctx, adam_flush_kernel, dim3(grid_for(n, 256)), dim3(256), 0, w, m, v, last, n, dim, t_end, lrt, b1, b2, eps);
+    ORX_LAUNCH(ctx, adam_flush_kernel, dim3(grid_for(n, 256)), dim3(256), 0, w, m, v, last, n, dim, t_end, lrt, b1, b2, eps, cf);
     ORX_HIP(hipGetLastError());
     return orx_launch_fill_int(ctx, last, rows, t_end);
 }

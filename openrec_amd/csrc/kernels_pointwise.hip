@@ -122,7 +122,14 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
             mi = *reinterpret_cast<const f4*>(a.aV + (size_t)i * D + 4 * sub); vi = *reinterpret_cast<const f4*>(a.a2V + (size_t)i * D + 4 * sub);
             mbi = a.ab[i]; vbi = a.a2b[i];
             const int lu = a.lastU[u], li = a.lastV[i];
-            if (a.newton) adam_catchup_pair<true, LPR>(ru, mu, vu, lu, ri, mi, vi, li, bi, mbi, vbi, a.step_t - 1, a.lrt, a.b1, a.b2, a.eps);
+            if (a.lrv != nullptr) {                 // closed-form replay (no loop over the skipped steps)
+                const int T1 = a.step_t - 1;
+                const float4 Vt = a.lrv[T1];
+                AdamCF cf;
+                if (lu < T1) { cf.setup(a.lrv, lu, T1, Vt, a.cf_lb1, a.cf_lb2); cf.row4(ru, mu, vu, a.eps, a.cf_delta); }
+                if (li < T1) { cf.setup(a.lrv, li, T1, Vt, a.cf_lb1, a.cf_lb2); cf.row4(ri, mi, vi, a.eps, a.cf_delta); cf.elem(bi, mbi, vbi, a.eps, a.cf_delta); }
+            }
+            else if (a.newton) adam_catchup_pair<true, LPR>(ru, mu, vu, lu, ri, mi, vi, li, bi, mbi, vbi, a.step_t - 1, a.lrt, a.b1, a.b2, a.eps);
             else adam_catchup_pair<false, LPR>(ru, mu, vu, lu, ri, mi, vi, li, bi, mbi, vbi, a.step_t - 1, a.lrt, a.b1, a.b2, a.eps);
         }
         const f4 ui = ru * ri;

@@ -140,7 +140,7 @@ struct CsrArgs {
     const uint2* sorted; int64_t n; uint32_t rows; int D;
     const float* grads; int64_t g_stride;
     float* W; float* A; float* V; int* last; float* G;      // table; Adagrad acc / Adam m; Adam v; lazy stamps; gsum (ACCUM)
-    float lr, eps, b1, b2, lr_T; const float* lrt; int T, newton;
+    float lr, eps, b1, b2, lr_T; const float* lrt; int T, newton; AdamCFParams cf;
     float* part_lo; float* part_hi;                          // [blocks][Dp]: sums of the runs open at a block's start / end
     int Dp;
     int skip_single;                                         // rows referenced once are NOT applied here: the kernel that formed their
@@ -188,7 +188,7 @@ __device__ __forceinline__ void csr_rule(const CsrArgs& a, uint32_t row, const f
         else if (MODE == CSR_ACCUM) a.G[i] = st.w[e] + s[e];
         else {
             float w = st.w[e], m = st.a[e], v = st.v[e];
-            adam_replay1<true>(w, m, v, from, a.T - 1, a.lrt, a.b1, a.b2, a.eps, a.newton != 0);
+            adam_replay1<true>(w, m, v, from, a.T - 1, a.lrt, a.b1, a.b2, a.eps, a.newton != 0, a.cf);
             adam_elem(w, m, v, s[e], a.lr_T, a.b1, a.b2, a.eps);
             a.W[i] = w; a.A[i] = m; a.V[i] = v;
         }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void csr_touch_kernel(CsrArgs a) {
     for (int col = lane; col < a.D; col += 64) {
         const size_t k = (size_t)row * a.D + col;
         float w = a.W[k], m = a.A[k], v = a.V[k];
-        adam_replay1<true>(w, m, v, from, a.T, a.lrt, a.b1, a.b2, a.eps, a.newton != 0);
+        adam_replay1<true>(w, m, v, from, a.T, a.lrt, a.b1, a.b2, a.eps, a.newton != 0, a.cf);
         a.W[k] = w; a.A[k] = m; a.V[k] = v;
     }
     if (lane == 0) a.last[row] = a.T;
@@ -461,7 +461,7 @@ int orx_csr_adam(orx_ctx* ctx, bool step, const AdamRowsArgs& r, orx_table* t, c
     ProfScope ps(ctx, ORX_K_DUPAPPLY);
     CsrArgs a;
     if (int rc = csr_args(ctx, t, sorted, n, r.grads, r.g_stride, &a)) return rc;
-    a.A = r.M; a.V = r.V; a.last = r.last; a.lrt = r.lrt; a.lr_T = r.lr_T; a.b1 = r.b1; a.b2 = r.b2; a.eps = r.eps; a.T = r.T; a.newton = r.newton;
+    a.A = r.M; a.V = r.V; a.last = r.last; a.lrt = r.lrt; a.lr_T = r.lr_T; a.b1 = r.b1; a.b2 = r.b2; a.eps = r.eps; a.T = r.T; a.newton = r.newton; a.cf = r.cf;
     if (step) return launch_csr<CSR_ADAM>(ctx, a);
     ORX_LAUNCH(ctx, csr_touch_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, a);
     ORX_HIP(hipGetLastError());

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(AdamRowsArgs a) {
         for (int e = lane; e < D; e += 64) {
             const size_t i = (size_t)r * D + e;
             float w = a.W[i], m = a.M[i], v = a.V[i];
-            adam_replay1<true>(w, m, v, from, STEP ? a.T - 1 : a.T, a.lrt, a.b1, a.b2, a.eps, a.newton != 0);
+            adam_replay1<true>(w, m, v, from, STEP ? a.T - 1 : a.T, a.lrt, a.b1, a.b2, a.eps, a.newton != 0, a.cf);
             if (STEP) adam_elem(w, m, v, a.grads[k * a.g_stride + e], a.lr_T, a.b1, a.b2, a.eps);
             a.W[i] = w; a.M[i] = m; a.V[i] = v;
         }
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void adam_rows_dup_kernel(AdamRowsArgs a) {
         for (int e = lane; e < D; e += 64) {
             const size_t i = r * D + e;
             float w = a.W[i], m = a.M[i], v = a.V[i];
-            adam_replay1<true>(w, m, v, from, STEP ? a.T - 1 : a.T, a.lrt, a.b1, a.b2, a.eps, a.newton != 0);
+            adam_replay1<true>(w, m, v, from, STEP ? a.T - 1 : a.T, a.lrt, a.b1, a.b2, a.eps, a.newton != 0, a.cf);
             if (STEP) { adam_elem(w, m, v, a.G[i], a.lr_T, a.b1, a.b2, a.eps); a.G[i] = 0.0f; }
             a.W[i] = w; a.M[i] = m; a.V[i] = v;
         }

@@ -341,6 +341,20 @@ struct AdamCF {
     }
 };
 
+// adam_replay1 with the closed form where the caller has the moments table (cf.lrv != NULL)
+template <bool UNIFORM>
+__device__ __forceinline__ void adam_replay1(float& w, float& m, float& v, int from, int to, const float* lrt, float b1, float b2, float eps,
+                                             bool newton, const AdamCFParams& cf) {
+    if (cf.lrv != nullptr) {
+        if (from >= to) return;
+        AdamCF c;
+        c.setup(cf.lrv, from, to, cf.lrv[to], cf.lb1, cf.lb2);
+        c.elem(w, m, v, eps, cf.delta);
+        return;
+    }
+    adam_replay1<UNIFORM>(w, m, v, from, to, lrt, b1, b2, eps, newton);
+}
+
 // the three rows (and the two item biases, which share their item row's stamp) of one triplet in ONE loop: its trip
 // count is the longest of the three gaps, not their sum, and the three chains interleave.  A row whose gap is
 // shorter is masked out of the early iterations.

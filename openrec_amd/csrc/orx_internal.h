@@ -152,6 +152,9 @@ struct orx_opt {
     std::vector<float> h_lrv; float* d_lrv = nullptr; size_t lrv_cap = 0; int64_t lrv_done = 0;
 };
 constexpr int ORX_ADAM_CF_TERMS = 512;        // J: b1^J is negligible for b1 <= 0.95
+// what a kernel needs for the closed-form replay: the moments table and the constants (lrv NULL: the replay loops)
+struct AdamCFParams { const float4* lrv; float delta, lb1, lb2; };
+AdamCFParams orx_adam_cf_params(const orx_opt* o);
 bool orx_adam_cf_ok(const orx_opt* o);        // closed-form replay applicable (b1 <= 0.95, 1 - sqrt(b2) <= 1e-3, ORX_ADAM_NO_CF unset)
 // Lazily-applied TF-2.0 Adam: the dense decay of a row that no triplet touches (m *= b1, v *= b2, w -= lr_t m /
 // (sqrt(v)+eps), every step) is replayed exactly when the row is next needed.  orx_table_sync brings every row of a
@@ -162,7 +165,7 @@ int orx_opt_last(orx_opt* o, orx_table* t, bool restamp, int** out, int64_t stam
 int orx_launch_fill_int(orx_ctx* ctx, int* p, int64_t n, int v);
 int orx_adam_lrt(orx_opt* o, int64_t upto);                      // make lr_t of steps 1..upto available on the device
 int orx_launch_adam_flush(orx_ctx* ctx, float* w, float* m, float* v, int* last, int64_t rows, int dim, int t_end, const float* lrt,
-                          float b1, float b2, float eps);
+                          float b1, float b2, float eps, struct AdamCFParams cf);
 
 // ------------------------------------------------------- helpers (api.hip) ---
 int orx_ensure(void** p, size_t* cap, size_t bytes);           // grow a device buffer
@@ -218,6 +221,7 @@ struct PairArgs {
     const int4* ids4;                         // pairing: [B] (user, pos item, neg item) rewritten ids of the triplet processed at position j and, in w, its pairing
                                               // word (ORX_PAIR_*, bits 9:0) and the triplet's original position (bits 31:10); NULL: uid / pid / nid as usual
     int role_bits;                            // ids carry role (bits 30:29) and urgent (bit 28): tables < 2^28 rows
+    int follow_origin;                        // pairing without plan_swap_kernel (ORX_PLAN_NO_SWAP): a moved position reads the ids at its origin's record
     // in-launch application of the PREVIOUS step's duplicated rows (n_apply_blocks == 0: off)
     int n_apply_blocks; int epoch;
     const uint32_t* prev_dlist; const int* prev_dcount;
@@ -323,6 +327,7 @@ struct AdamRowsArgs {                          // lazy TF-2.0 Adam on gradient r
     const float* lrt; float lr_T; float b1; float b2; float eps;
     int T; int newton;
     int* err;
+    AdamCFParams cf;                          // closed-form replay (orx_device.h AdamCF)
 };
 int orx_launch_adam_rows(orx_ctx* ctx, bool step, const AdamRowsArgs& a, int64_t max_dups);
 // lazy Adam on a table's gradient rows: replay the rows of `ids` to the optimizer's step (touch) / take step opt->t
@@ -372,6 +377,7 @@ struct PointArgs {
     // lazy TF-2.0 Adam: second slots, per-row step stamps (the bias shares its item row's), lr_t table
     float* a2U; float* a2V; float* a2b; int* lastU; int* lastV; int* lastb;
     const float* lrt; float b1; float b2; int step_t; int newton;
+    const float4* lrv; float cf_delta, cf_lb1, cf_lb2;      // closed-form replay (orx_device.h AdamCF; NULL: the replay loops)
     // in-launch application of the PREVIOUS step's duplicated rows, as in the pairwise step (n_apply_blocks == 0: off): the first
     // blocks of the launch run inline_apply on `ap` (the tables seen as a pairwise step sees them, prev_* = step s-1's lists);
     // references marked urgent (bit 28 of the rewritten ids) wait for their row's ready flag
@@ -434,6 +440,7 @@ bool orx_plan_v2(bool role_bits);
 int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t B, int64_t NU, int64_t NI, bool want_dupbits);
 int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupbits, int64_t step0 = 0);
 int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc, int64_t step0 = 0);
+bool orx_plan_no_swap();
 int orx_launch_plan_swap(orx_ctx* ctx, const DedupArgs& d, int64_t kc);      // pairing: the records of the positions an accepted pair moves change places
 int orx_fused_tpw(int D);                        // triplets per wavefront of the float4 fused kernel (0: generic dim)
 int orx_fused_can_inline_apply(int D);
