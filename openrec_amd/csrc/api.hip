@@ -1115,7 +1115,6 @@ extern "C" int orx_pairwise_step(orx_ctx* c, int model, orx_opt* opt,
             }
             orx_exact_step_views(c, plan, i, B, U->dim, stage_views, &a);
             a.ids4 = plan.pair_tpw > 1 ? c->d_ids4 + (size_t)i * B : nullptr;
-            a.follow_origin = orx_plan_no_swap() ? 1 : 0;
             a.partial = c->d_partial + (size_t)i * nw * 2;
             a.epoch = ++c->epoch;           // one epoch per step: ready flags and censor side marks are tagged with it
             if (lazy_adam) { opt->t += 1; a.step_t = (int)opt->t; }

@@ -501,10 +501,9 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
         bool packed = false;
         if (PAIRS) { packed = a.ids4 != nullptr; }
         if (packed) {
-            int4 v = a.ids4[t];
-            pi = (uint32_t)v.w & 0x3ffu; t0 = (int64_t)((uint32_t)v.w >> 10);
-            if (a.follow_origin && t0 != t) { const int4 v2 = a.ids4[t0]; v.x = v2.x; v.y = v2.y; v.z = v2.z; }     // (ORX_PLAN_NO_SWAP: the records did not change places)
+            const int4 v = a.ids4[t];
             uw = (uint32_t)v.x; pw = (uint32_t)v.y; nw = (uint32_t)v.z;
+            pi = (uint32_t)v.w & 0x3ffu; t0 = (int64_t)((uint32_t)v.w >> 10);
         } else {
             uw = (uint32_t)a.uid[t]; pw = (uint32_t)a.pid[t]; nw = (uint32_t)a.nid[t];
         }
@@ -622,7 +621,7 @@ __global__ __launch_bounds__(256) void fused_kernel(PairArgs a) {
             if (!(pi & ORX_PAIR_WRITER)) return;
             const int myslot = (pi >> 4) & 3, oslot = (pi >> 6) & 3;
             const int xsrc = (int)(threadIdx.x & ~63u) + (int)(pi & 15u) * LPR + sub;
-            const int id = reinterpret_cast<const int*>(a.ids4 + (a.follow_origin ? t0 : t))[myslot] & 0x0fffffff;      // (the tail keeps nothing of the triplet alive but t and its pairing word)
+            const int id = reinterpret_cast<const int*>(a.ids4 + t)[myslot] & 0x0fffffff;      // (the tail keeps nothing of the triplet alive but t and its pairing word)
             const size_t off = (size_t)id * D + 4 * sub;
             float* W = myslot == 0 ? a.U : a.V;
             float* A = myslot == 0 ? a.aU : a.aV;

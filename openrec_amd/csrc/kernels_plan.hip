@@ -60,7 +60,6 @@ struct PlanArgs {
     int min_late;              // staging plan in ranges with at least this many third-or-later references (< 0: max(64, n / 512))
     int s_first;               // plan_urgent_kernel: first step to mark (1, or 0 when the plan's step 0 has a predecessor in the same arrays)
     unsigned long long* tstamp; // ORX_PLAN_TIMING: [workgroups][8] wall-clock stamps of plan_range_kernel's phases (NULL: off)
-    int p1_batched;            // plan_range_kernel pass 1: the LDS atomics of a thread's entries issued level by level (round 6, ORX_PLAN_P1_BATCH)
 };
 #define PL_STAMP(i) do { if (a.tstamp != nullptr && threadIdx.x == 0) a.tstamp[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
 
@@ -307,43 +306,7 @@ __global__ __launch_bounds__(T) void plan_range_kernel(PlanArgs a) {
         }
         return role;
     };
-    if (small && a.p1_batched) {
-        // the same decisions level by level: all of the thread's "seen" atomics are issued back to back (one wait instead of one per
-        // entry), then the "twice" atomics of the entries that found their bit set, then the "three times" ones.  Roles stay "by
-        // arrival": which reference of a row comes first is as arbitrary as before.
-        unsigned int o1[PL_UN], o2[PL_UN]; int lk[PL_UN];
-#pragma unroll
-        for (int k = 0; k < PL_UN; ++k) {
-            const int i = threadIdx.x + k * T;
-            lk[k] = i < n ? (er[k].x >> lg) : -1;
-            o1[k] = 0u; o2[k] = 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < PL_UN; ++k) if (lk[k] >= 0) {
-            const unsigned int bit = 1u << (lk[k] & 31);
-            const unsigned int cur = pl_peek(&seen[lk[k] >> 5]);
-            o1[k] = ((cur & bit) ? cur : atomicOr(&seen[lk[k] >> 5], bit)) & bit;
-        }
-#pragma unroll
-        for (int k = 0; k < PL_UN; ++k) if (lk[k] >= 0 && o1[k]) {
-            const unsigned int bit = 1u << (lk[k] & 31);
-            const unsigned int cur2 = pl_peek(&dup[lk[k] >> 5]);
-            o2[k] = ((cur2 & bit) ? cur2 : atomicOr(&dup[lk[k] >> 5], bit)) & bit;
-        }
-#pragma unroll
-        for (int k = 0; k < PL_UN; ++k) if (lk[k] >= 0) {
-            int role = 0;
-            if (o1[k]) {
-                role = 1;
-                if (o2[k]) {
-                    const unsigned int bit = 1u << (lk[k] & 31);
-                    if (!(pl_peek(&tri[lk[k] >> 5]) & bit)) atomicOr(&tri[lk[k] >> 5], bit);
-                    role = 2; ++late;
-                }
-            }
-            er[k].y = (int)((uint32_t)er[k].y | ((uint32_t)role << 30));
-        }
-    } else if (small) {
+    if (small) {
 #pragma unroll
         for (int k = 0; k < PL_UN; ++k) {
             const int i = threadIdx.x + k * T;
@@ -674,12 +637,10 @@ __global__ __launch_bounds__(256) void plan_swap_kernel(DedupArgs d) {
     }
 }
 
-// ORX_PLAN_NO_SWAP=1 (round 6 experiment): no swap launch -- the fused kernel follows the origin index of a moved position to the record
-// where the triplet stands (PairArgs::follow_origin; a dependent 16-byte load for the positions of a moved pair)
-bool orx_plan_no_swap() { static const bool v = getenv("ORX_PLAN_NO_SWAP") != nullptr; return v; }
-
+// (round 6 measured the alternative -- no swap launch, the fused kernel follows the origin index of a moved position: -0.4 us per step at K = 20,
+// below the bar: profiles/r6_plan_levers.txt)
 int orx_launch_plan_swap(orx_ctx* ctx, const DedupArgs& d, int64_t kc) {
-    if (d.pair_tpw < 2 || kc <= 0 || orx_plan_no_swap()) return ORX_OK;
+    if (d.pair_tpw < 2 || kc <= 0) return ORX_OK;
     ProfScope ps(ctx, ORX_K_DEDUP);
     ORX_LAUNCH(ctx, plan_swap_kernel, dim3((unsigned)std::max<int64_t>(4, (d.pair_stride / 4 + 255) / 256), (unsigned)kc), dim3(256), 0, d);
     ORX_HIP(hipGetLastError());
@@ -759,8 +720,6 @@ int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupb
         ORX_HIP(hipMalloc((void**)&a.tstamp, (size_t)nb * kc * 8 * sizeof(unsigned long long)));
         ORX_HIP(hipMemsetAsync(a.tstamp, 0, (size_t)nb * kc * 8 * sizeof(unsigned long long), ctx->stream));
     }
-    static const int p1b = getenv("ORX_PLAN_P1_BATCH") ? atoi(getenv("ORX_PLAN_P1_BATCH")) : 0;
-    a.p1_batched = p1b;
     const char* ml = getenv("ORX_PLAN_MIN_LATE");      // experiments
     a.min_late = ml ? atoi(ml) : d.min_late;
     // The counts and cursors of a step are zeroed again by plan_range_kernel once the scatter has used them: no memset (a launch and
@@ -821,7 +780,7 @@ int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc, int64_t
     const int nb = a.nru + a.nri;
     const size_t words = (size_t)nb * ((1u << a.shift) >> 5);
     a.bcnt = ctx->d_pl_cnt + step0 * (3 * nb + 1); a.list = ctx->d_pl_list + step0 * a.nref; a.dupbits = ctx->d_dupbits + step0 * words; a.min_late = -1;
-    a.s_first = first; a.p1_batched = 0;
+    a.s_first = first;
     a.tstamp = nullptr;
     const int W = (1 << a.shift) >> 5;
     if (ctx->plan_big) ORX_LAUNCH(ctx, plan_urgent_kernel<1024>, dim3((unsigned)(a.nru + a.nri), (unsigned)(kc - first)), dim3(1024), (size_t)W * 4, a);

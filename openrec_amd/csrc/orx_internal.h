@@ -221,7 +221,6 @@ struct PairArgs {
     const int4* ids4;                         // pairing: [B] (user, pos item, neg item) rewritten ids of the triplet processed at position j and, in w, its pairing
                                               // word (ORX_PAIR_*, bits 9:0) and the triplet's original position (bits 31:10); NULL: uid / pid / nid as usual
     int role_bits;                            // ids carry role (bits 30:29) and urgent (bit 28): tables < 2^28 rows
-    int follow_origin;                        // pairing without plan_swap_kernel (ORX_PLAN_NO_SWAP): a moved position reads the ids at its origin's record
     // in-launch application of the PREVIOUS step's duplicated rows (n_apply_blocks == 0: off)
     int n_apply_blocks; int epoch;
     const uint32_t* prev_dlist; const int* prev_dcount;
@@ -440,7 +439,6 @@ bool orx_plan_v2(bool role_bits);
 int orx_plan_buffers(orx_ctx* c, int64_t chunk, int64_t B, int64_t NU, int64_t NI, bool want_dupbits);
 int orx_launch_plan(orx_ctx* ctx, const DedupArgs& d, int64_t kc, bool keep_dupbits, int64_t step0 = 0);
 int orx_launch_plan_urgent(orx_ctx* ctx, const DedupArgs& d, int64_t kc, int64_t step0 = 0);
-bool orx_plan_no_swap();
 int orx_launch_plan_swap(orx_ctx* ctx, const DedupArgs& d, int64_t kc);      // pairing: the records of the positions an accepted pair moves change places
 int orx_fused_tpw(int D);                        // triplets per wavefront of the float4 fused kernel (0: generic dim)
 int orx_fused_can_inline_apply(int D);
