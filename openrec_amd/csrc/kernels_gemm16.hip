@@ -627,20 +627,31 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm16_tn_kernel(Tn16Args 
 // the 16-byte chunk c of its 256 bytes at slot c ^ (2 * (r & 7)) -- chunk PAIRS stay adjacent and the eight rows of a cycle sit on
 // eight different quarters of the banks (what the 288-byte pitch does for the register-staged kernel).
 // TAIL: a tile reaches beyond a leading dimension or the slice ends inside a stage (zero chunk through per-lane addresses).
-template <int NS, bool TAIL>
+// KG = 2 (round 6): a workgroup of EIGHT wavefronts, two K groups of four -- each group runs the schedule below on its own half of the slice's
+// k-rows with its own LDS stages, and at the end group 1 hands its accumulators to group 0 through LDS.  One workgroup per CU then keeps two
+// wavefronts on every SIMD (the four-wavefront form leaves each SIMD one wavefront: nothing to issue while it waits for its fragments) WITHOUT
+// the second set of split-K slices that two four-wavefront workgroups per CU cost (their slabs are written here and read again by the optimizer
+// launch).  The sum of a slice becomes (first half) + (second half): another fixed order.
+template <int NS, bool TAIL, int KG = 1>
 __device__ __forceinline__ void gemm16_tn_dma_body(const Tn16Args& g, const int bid, const int nblk) {
     constexpr int BK = 64, BM = 128, BN = 128, NT = 256, TM = 4, TN = 4, WN = 2;
     constexpr int NA = BK * (BM / 8) / NT, NB = BK * (BN / 8) / NT, NL = NA + NB;      // 4 + 4 requests per wavefront and stage
-    extern __shared__ __attribute__((aligned(16))) _Float16 lds16[];
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds16_all[];
     constexpr int STAGE = BK * (BM + BN);                                      // halves
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kg = KG == 2 ? (wave_all >> 2) : 0, wave = wave_all & 3;          // K group, wavefront inside it
+    _Float16* const lds16 = lds16_all + kg * (NS * STAGE);
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM, nt = ntn * ntm;
     const int t = xcd_slot(bid, nblk);
     const int bz = t / nt, tile = t - bz * nt;
     const int bm = (tile / ntn) * BM, bn = (tile % ntn) * BN;
     const int wm = (wave / WN) * TM * 16, wn = (wave % WN) * TN * 16;
     const int i16 = lane & 15, q = lane >> 4;
-    const int kbeg = bz * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int kbeg_s = bz * g.kchunk, kend = min(g.K, kbeg_s + g.kchunk);
+    // (KG = 2: both groups run the same number of K steps -- the barriers are the workgroup's -- group 1's steps beyond the slice read zeros)
+    const int nk_all = kend > kbeg_s ? (kend - kbeg_s + BK - 1) / BK : 0;
+    const int nk_g = KG == 2 ? (nk_all + 1) / 2 : nk_all;
+    const int kbeg = kbeg_s + kg * nk_g * BK;
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -700,7 +711,7 @@ __device__ __forceinline__ void gemm16_tn_dma_body(const Tn16Args& g, const int 
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) asm volatile("" : "+v"(b[ni]));
     };
-    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int nk = nk_g;
     int cur = 0;
     auto step = [&](auto dma_c, auto more_c, auto inflight_c, int s) {          // (the schedule of gemm16_nt_dma_kernel)
         constexpr bool DMA = decltype(dma_c)::value, MORE = decltype(more_c)::value, INFLIGHT = decltype(inflight_c)::value;
@@ -748,6 +759,27 @@ __device__ __forceinline__ void gemm16_tn_dma_body(const Tn16Args& g, const int 
         if (s + 1 < nk) { step(F(), T(), F(), s); ++s; }
         if (s < nk) step(F(), F(), F(), s);
     }
+    if (KG == 2) {
+        // group 1's accumulators go to group 0 through LDS (the stages are free: 2 x NS x 32 KB >= 128 rows x 132 floats; the 4-float pad
+        // spreads the sixteen rows of a store over the banks)
+        constexpr int XLD = BN + 4;
+        float* xb = reinterpret_cast<float*>(lds16_all);
+        __syncthreads();
+        if (kg == 1) {
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    *reinterpret_cast<f32x4*>(xb + (wm + mi * 16 + i16) * XLD + wn + ni * 16 + q * 4) = acc[mi][ni];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] += *reinterpret_cast<const f32x4*>(xb + (wm + mi * 16 + i16) * XLD + wn + ni * 16 + q * 4);
+    }
     const int S = nblk / nt;
     if (S > 1) {
         float* mine = g.slab + ((size_t)tile * S + bz) * SLAB_STRIDE;
@@ -777,6 +809,12 @@ __device__ __forceinline__ void gemm16_tn_dma_body(const Tn16Args& g, const int 
 template <int MINB, int NS, bool TAIL>
 __global__ __launch_bounds__(256, MINB) void gemm16_tn_dma_kernel(Tn16Args g) {
     gemm16_tn_dma_body<NS, TAIL>(g, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// eight wavefronts, two K groups (see the body): one workgroup per CU, two stages per group = 128 KB of LDS
+template <bool TAIL>
+__global__ __launch_bounds__(512, 1) void gemm16_tn_dma_kg2_kernel(Tn16Args g) {
+    gemm16_tn_dma_body<2, TAIL, 2>(g, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- grouped launch (round 6): the weight gradient X16^T dZ16 (tn) and the input gradient dZ16 W16^T (nt) of ONE layer -- independent
@@ -860,7 +898,24 @@ int orx_launch_gemm16_tn(orx_ctx* ctx, const void* A16, int64_t lda, const void*
     Tn16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, slab, M, N, K, kchunk, out_scale};
     // ORX_GEMM16_TN_DMA: 0 = the register-staged kernel, 2 = LDS-DMA staging with two stages and two workgroups per CU,
     // 3 (default) = three stages, one workgroup per CU
-    static const int dma = getenv("ORX_GEMM16_TN_DMA") ? atoi(getenv("ORX_GEMM16_TN_DMA")) : 3;
+    static const int dma = getenv("ORX_GEMM16_TN_DMA") ? atoi(getenv("ORX_GEMM16_TN_DMA")) : 4;
+    if (dma == 4) {
+        // 4 (default, round 6) = eight wavefronts in two K groups, one workgroup per CU (gemm16_tn_dma_kg2_kernel); a slice whose K steps do not
+        // split evenly, or whose tiles reach beyond a leading dimension, takes the tail form
+        const int nk_all = (std::min(K, kchunk) + 63) / 64;
+        const bool tail = (K & 63) != 0 || kchunk % 64 != 0 || (nk_all & 1) != 0 || (K % kchunk) != 0 ||
+                          (int64_t)((M + 127) / 128) * 128 > lda || (int64_t)((N + 127) / 128) * 128 > ldb;
+        constexpr size_t shm = (size_t)2 * 2 * 64 * 256 * 2;
+        static_assert(shm >= (size_t)128 * 132 * 4, "LDS of the accumulator exchange");
+        auto kern = tail ? gemm16_tn_dma_kg2_kernel<true> : gemm16_tn_dma_kg2_kernel<false>;
+        ORX_ONCE_PER_DEVICE(ctx, {
+            ORX_HIP(hipFuncSetAttribute((const void*)gemm16_tn_dma_kg2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            ORX_HIP(hipFuncSetAttribute((const void*)gemm16_tn_dma_kg2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        });
+        ORX_LAUNCH(ctx, kern, dim3((unsigned)(tiles * S)), dim3(512), shm, g);
+        ORX_HIP(hipGetLastError());
+        return ORX_OK;
+    }
     if (dma == 2 || dma == 3) {
         const bool tail = (K & 63) != 0 || kchunk % 64 != 0 || (int64_t)((M + 127) / 128) * 128 > lda || (int64_t)((N + 127) / 128) * 128 > ldb;
         const size_t shm = (size_t)dma * 64 * 256 * 2;

@@ -397,21 +397,28 @@ def test_dlrm_fp16_staging_forms_are_bit_identical():
     import subprocess
     import sys as _sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dlrm_variant_worker.py")
-    variants = [{}, {"ORX_GEMM16_DMA": "0"}, {"ORX_GEMM16_DMA": "2"}, {"ORX_GEMM16_TN_DMA": "0"}, {"ORX_GEMM16_TN_DMA": "2"},
-                {"ORX_GEMM16_NTS": "0"}, {"ORX_GEMM16_NTS": "1"},
-                {"ORX_GEMM16_NO_GROUP": "1"},                 # round 6: a layer's dW and dX in one launch (gemm16_group_kernel) vs two
-                {"ORX_DLRM_COLPARTS_LAUNCH": "1"},            # ... the partial-row sums added by the optimizer launch vs a reduce launch
-                {"ORX_DLRM_DEFER_DW": "1"}, {"ORX_DLRM_DEFER_DW": "2"},   # ... the top MLP's weight gradients beside the interaction backward (side stream; measured slower: off)
-                {"ORX_GEMM16_WAVE_TILE": "128"}]              # ... the 256 x 128 tile on four wavefronts of 128 x 64 (measured slower: off)
-    digests = []
-    for v in variants:
-        env = dict(os.environ); env.update(v)
-        r = subprocess.run([_sys.executable, worker], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, f"{v}: {r.stderr[-2000:]}"
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")]
-        assert line, f"{v}: no digest in {r.stdout[-500:]}"
-        digests.append(line[-1])
-    assert all(d == digests[0] for d in digests), [str(v) for v, d in zip(variants, digests) if d != digests[0]]
+    # two families: within each, no switch changes which products are summed in which order.  A: the default weight-gradient kernel (round 6: eight
+    # wavefronts in two K groups, a slice = first half + second half); B: the one-group forms of rounds 3-5 (ORX_GEMM16_TN_DMA=3 | 2 | 0), which the
+    # grouped dW + dX launch (gemm16_group_kernel) also carries -- so the grouped and the ungrouped step agree bit for bit there.
+    fam_a = [{}, {"ORX_GEMM16_NTS": "0"}, {"ORX_GEMM16_NTS": "1"},
+             {"ORX_DLRM_COLPARTS_LAUNCH": "1"},            # the partial-row sums added by the optimizer launch vs a reduce launch
+             {"ORX_DLRM_DEFER_DW": "1"},                   # the top MLP's weight gradients beside the interaction backward (side stream; measured slower: off)
+             {"ORX_GEMM16_WAVE_TILE": "128"}]              # the 256 x 128 tile on four wavefronts of 128 x 64 (measured slower: off)
+    # C: no grouped launches (every weight gradient on the two-group kernel): the staging forms of the forward / input-gradient products
+    # (ORX_GEMM16_DMA = 0 | 2 switch the grouped launch off as well)
+    fam_c = [{"ORX_GEMM16_NO_GROUP": "1"}, {"ORX_GEMM16_DMA": "0"}, {"ORX_GEMM16_DMA": "2"}]
+    fam_b = [{"ORX_GEMM16_TN_DMA": "3"}, {"ORX_GEMM16_TN_DMA": "0"}, {"ORX_GEMM16_TN_DMA": "2"},
+             {"ORX_GEMM16_TN_DMA": "3", "ORX_GEMM16_NO_GROUP": "1"}]      # a layer's dW and dX in one launch vs two
+    for variants in (fam_a, fam_b, fam_c):
+        digests = []
+        for v in variants:
+            env = dict(os.environ); env.update(v)
+            r = subprocess.run([_sys.executable, worker], env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, f"{v}: {r.stderr[-2000:]}"
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")]
+            assert line, f"{v}: no digest in {r.stdout[-500:]}"
+            digests.append(line[-1])
+        assert all(d == digests[0] for d in digests), [str(v) for v, d in zip(variants, digests) if d != digests[0]]
     # round 6: the loss folded into the head's backward (per-workgroup fp64 partials summed once per call) against the dlrm_loss_kernel
     # launch per step: another order of the loss SUM, the same gradient -- every parameter bit for bit
     params = []
