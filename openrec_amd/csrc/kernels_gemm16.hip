@@ -43,6 +43,120 @@ __device__ __forceinline__ int xcd_slot(int b, int n) { return (n & 7) ? b : (b 
 // of the file); `red` = LDS that is free once the main loop is over, [WM][BN] floats
 // NTS: how the outputs are stored: 0 = ordinary stores, 1 = nontemporal, 2 = write-through (sc1: past the XCD's L2 as they are issued,
 // nothing left dirty for the end of the kernel)
+// What the epilogue reads -- the bias of the lane's columns and, for the fused activation backward, the layer below's fp16 output at the
+// lane's elements -- requested at the START of the kernel, ahead of the first tiles (round 6).  scratch/exp_k512.hip: with the loads issued inside
+// the epilogue's (row tile, column pair) loop, each of its eight iterations waited for its own round trip: the backward form's epilogue took
+// 11 us of a 20.5 us launch at 8192 x 1024 x 512 (forward form: 5 of 14.5).  Only for tiles that lie inside the matrices and have
+// 16-byte rows (`fast`, uniform over the workgroup); edge tiles take the element-wise path as before.
+// (plain arrays handed on by reference: a struct behind a pointer went to scratch memory -- the "prefetched" operands then came back from HBM)
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ bool nt_epilogue_prefetch(const Nt16Args& g, int bm, int bn, int wm, int wn, h8 (&py)[TM][TN / 2], f32x4 (&pb)[TN / 2][2]) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    const int lane = threadIdx.x & 63;
+    const int r16 = lane & 15, q = lane >> 4;
+    const bool fast = bm + BM <= g.M && bn + BN <= g.N && (g.N & 7) == 0 && (g.actY16 == nullptr || (g.ldy & 7) == 0) && g.actY == nullptr &&
+                      (g.C == nullptr || (g.ldc & 3) == 0) && (g.C16 == nullptr || (g.ldc16 & 7) == 0);
+#pragma unroll
+    for (int np = 0; np < TN / 2; ++np) {
+        const int col = bn + wn + np * 32 + q * 8;
+        f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        pb[np][0] = z4; pb[np][1] = z4;
+        if (fast && g.bias) { pb[np][0] = *reinterpret_cast<const f32x4*>(g.bias + col); pb[np][1] = *reinterpret_cast<const f32x4*>(g.bias + col + 4); }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) py[mi][np][e] = (_Float16)0.0f;
+            if (fast && g.actY16) py[mi][np] = *reinterpret_cast<const h8*>(g.actY16 + (int64_t)(bm + wm + mi * 16 + r16) * g.ldy + col);
+        }
+    }
+    return fast;
+}
+
+// the column sums' second half (shared by both epilogue forms): over the block's WM wavefronts through LDS, one plain store per (workgroup, column)
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void nt_colsums(const Nt16Args& g, float (&cs)[TN / 2][8], int bm, int bn, int wn, float* red) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = 64 * WM * WN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int np = 0; np < TN / 2; ++np)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float s = group_allreduce<16>(cs[np][e]);
+            if (r16 == 0) red[(wave / WN) * BN + wn + np * 32 + q * 8 + e] = s;
+        }
+    __syncthreads();
+    for (int cidx = threadIdx.x; cidx < BN; cidx += NT) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) s += red[w * BN + cidx];
+        if (bn + cidx < g.N) g.gb[(int64_t)(bm / BM) * g.N + bn + cidx] = s;
+    }
+}
+
+// The epilogue of a tile that lies INSIDE the matrices with 16-byte rows everywhere (NtEpiPre::fast, every tile of the C5 shapes): 16-byte
+// accesses only, no bounds checks, no element-wise fallbacks -- a few hundred instructions.  scratch/exp_k512.hip: the general form below,
+// unrolled eight times with its fallbacks, ran the backward form's epilogue 8 us longer than its memory traffic explains (its code alone is
+// most of a 10 000-line kernel: instruction fetch, not data).
+template <int WM, int WN, int TM, int TN, int NTS>
+__device__ __forceinline__ void nt_epilogue_fast(const Nt16Args& g, f32x4 (&acc)[TM][TN], int bm, int bn, int wm, int wn, float* red,
+                                                 const h8 (&py)[TM][TN / 2], const f32x4 (&pb)[TN / 2][2]) {
+    const int lane = threadIdx.x & 63;
+    const int r16 = lane & 15, q = lane >> 4;
+    float cs[TN / 2][8];
+#pragma unroll
+    for (int np = 0; np < TN / 2; ++np)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[np][e] = 0.0f;
+    const bool has_y = g.actY16 != nullptr;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int64_t row = bm + wm + mi * 16 + r16;
+#pragma unroll
+        for (int np = 0; np < TN / 2; ++np) {
+            const int col = bn + wn + np * 32 + q * 8;
+            float v[8] = {acc[mi][2 * np].x, acc[mi][2 * np].y, acc[mi][2 * np].z, acc[mi][2 * np].w,
+                          acc[mi][2 * np + 1].x, acc[mi][2 * np + 1].y, acc[mi][2 * np + 1].z, acc[mi][2 * np + 1].w};
+            if (g.bias) {
+                const f32x4 b0 = pb[np][0], b1 = pb[np][1];
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            if (g.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+            } else if (g.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
+            }
+            if (has_y) {
+                const h8 t8 = py[mi][np];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float y = (float)t8[e];
+                    v[e] = g.act_y == 1 ? (y > 0.0f ? v[e] : 0.0f) : (g.act_y == 2 ? v[e] * y * (1.0f - y) : v[e]);
+                    cs[np][e] += v[e];
+                }
+            }
+            if (g.C) {
+                float* p = g.C + row * g.ldc + col;
+                f32x4 o0, o1; o0.x = v[0]; o0.y = v[1]; o0.z = v[2]; o0.w = v[3]; o1.x = v[4]; o1.y = v[5]; o1.z = v[6]; o1.w = v[7];
+                if (NTS == 2) { store_sc1(reinterpret_cast<f32x4*>(p), o0); store_sc1(reinterpret_cast<f32x4*>(p + 4), o1); }
+                else if (NTS == 1) { __builtin_nontemporal_store(o0, reinterpret_cast<f32x4*>(p)); __builtin_nontemporal_store(o1, reinterpret_cast<f32x4*>(p + 4)); }
+                else { *reinterpret_cast<f32x4*>(p) = o0; *reinterpret_cast<f32x4*>(p + 4) = o1; }
+            }
+            if (g.C16) {
+                _Float16* p = g.C16 + row * g.ldc16 + col;
+                h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+                if (NTS == 2) store_sc1(reinterpret_cast<h8*>(p), o); else if (NTS == 1) __builtin_nontemporal_store(o, reinterpret_cast<h8*>(p)); else *reinterpret_cast<h8*>(p) = o;
+            }
+        }
+    }
+    if (NTS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (g.gb) nt_colsums<WM, WN, TM, TN>(g, cs, bm, bn, wn, red);
+}
+
 template <int WM, int WN, int TM, int TN, int NTS = 0>
 __device__ __forceinline__ void nt_epilogue(const Nt16Args& g, f32x4 (&acc)[TM][TN], int bm, int bn, int wm, int wn, float* red) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = 64 * WM * WN;
@@ -381,6 +495,12 @@ __device__ __forceinline__ void gemm16_nt_dma_body(const Nt16Args& g, const int 
         // pending across the back edge (the compiler's wait counts then let the next half's reads fly under the products above)
         if (MORE) arrived(a0, b0);
     };
+    // The epilogue's operands are requested FIRST, ahead of the first tiles: the memory counter the loop's waits count (vmcnt) retires in
+    // order, so requests OLDER than every tile are long complete wherever the loop waits, while requests issued later -- before the last
+    // K steps, say -- would sit among the newest ones and be waited for with the tiles (measured: no gain that way).
+    h8 pre_y[TM][TN / 2]; f32x4 pre_b[TN / 2][2];
+    bool pre_fast = false;
+    if (!(DBG & 1)) pre_fast = nt_epilogue_prefetch<WM, WN, TM, TN>(g, bm, bn, wm, wn, pre_y, pre_b);
 #pragma unroll
     for (int s = 0; s < NS; ++s) if (s < nk) issue(s * BK, lds16 + s * STAGE);
     if (nk > 2 && NS == 3) wait_vm<2 * NL>(); else if (nk > 1) wait_vm<NL>(); else wait_vm<0>();
@@ -408,7 +528,8 @@ __device__ __forceinline__ void gemm16_nt_dma_body(const Nt16Args& g, const int 
         return;
     }
     if (g.gb) __syncthreads();                                                 // (the column sums go through the stages' LDS)
-    nt_epilogue<WM, WN, TM, TN, (DBG & 32) ? 2 : (DBG & 16) ? 1 : 0>(g, acc, bm, bn, wm, wn, reinterpret_cast<float*>(lds16));
+    if (pre_fast) nt_epilogue_fast<WM, WN, TM, TN, (DBG & 32) ? 2 : (DBG & 16) ? 1 : 0>(g, acc, bm, bn, wm, wn, reinterpret_cast<float*>(lds16), pre_y, pre_b);
+    else nt_epilogue<WM, WN, TM, TN, (DBG & 32) ? 2 : (DBG & 16) ? 1 : 0>(g, acc, bm, bn, wm, wn, reinterpret_cast<float*>(lds16));
 }
 
 template <int WM, int WN, int TM, int TN, int MINB, int NS, bool TAIL, int DBG = 0>
