@@ -30,6 +30,9 @@ struct DenseLayer {
     float* slab = nullptr;              // split-K slices of this layer's weight gradient, [tiles][S][128 * 128]
     int slab_S = 1, slab_tiles = 0;
     uint64_t shadow_version = ~0ull;    // W->version the fp16 copies were made from
+    // relu mask of the layer's fp16 output, one 64-bit word per lane and tile of the forward product (kernels_gemm16.hip Nt16Args::mask_out):
+    // the input-gradient launch of the layer above applies relu' from it instead of fetching the output again
+    unsigned long long* relu_mask = nullptr; int64_t mask_words = 0; int mask_cfg = 0; int64_t mask_B = 0;
     void* dz16 = nullptr;               // top MLP, deferred weight gradients (round 6): this layer's dZ16 keeps a buffer of its own until its
                                         // weight-gradient product has run (g16 / g16b are reused two layers further down)
     float* gbpart = nullptr;            // bias-gradient partial rows [row blocks][out] (ColPart), carved from orx_dlrm::colpart
@@ -226,6 +229,7 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
 static void free_buffers(orx_dlrm* m) {
     hipFree(m->R16); hipFree(m->g16); hipFree(m->g16b); m->R16 = m->g16 = m->g16b = nullptr;
     for (auto& D : m->top) { hipFree(D.dz16); D.dz16 = nullptr; }
+    for (int k = 0; k < 2; ++k) for (auto& D : (k == 0 ? m->bot : m->top)) { hipFree(D.relu_mask); D.relu_mask = nullptr; D.mask_words = 0; D.mask_cfg = 0; }
     for (auto& D : m->top) { hipFree(D.slab); D.slab = nullptr; }
     for (auto& D : m->bot) { hipFree(D.slab); D.slab = nullptr; }
     for (int k = 0; k < 2; ++k) { hipFree(m->d_slabjobs[k]); m->d_slabjobs[k] = nullptr; m->n_slabjobs[k] = 0; m->slab_max_tiles[k] = 0; }
@@ -321,6 +325,18 @@ static int ensure_buffers(orx_dlrm* m, int64_t B) {
             void* p; const size_t bytes = (size_t)B * up8(m->top[l].out) * 2;
             ORX_HIP(hipMalloc(&p, bytes)); ORX_HIP(hipMemsetAsync(p, 0, bytes, m->ctx->stream));
             m->top_y16.push_back(p);
+        }
+    }
+    if (m->gen2) {
+        // relu masks for the layers whose activation backward is fused into the input-gradient product of the layer above (not the last layer of
+        // an MLP, not the layer below the 1-unit head: their dZ comes from other kernels)
+        for (int k = 0; k < 2; ++k) {
+            std::vector<DenseLayer>& L = k == 0 ? m->bot : m->top;
+            for (size_t l = 0; l + 1 < L.size(); ++l) {
+                if (L[l].act != 1 || L[l].w16t == nullptr || L[l + 1].head || L[l].out % 8 != 0) continue;
+                L[l].mask_words = (int64_t)((B + 127) / 128) * ((L[l].out + 63) / 64) * 256 + 1024;      // (the 128 x 64 tiles need the most words)
+                ORX_HIP(hipMalloc((void**)&L[l].relu_mask, (size_t)L[l].mask_words * 8));
+            }
         }
     }
     if (m->gen2) {
@@ -424,6 +440,16 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
         if (!m->direct_idx) CHECK(orx_launch_gather(c, m->emb->w, nullptr, m->emb->rows, d, idx, B * F, m->Z, d, c->d_err, 1));
     }
     const bool f16 = (m->flags & ORX_DLRM_FP16_MLP) != 0;
+    // the relu-mask buffer of a layer for this batch size, or NULL (no buffer, or the product takes a tile form without masks); remembers the form
+    auto mask_for = [&](DenseLayer& D, int64_t Bn) -> unsigned long long* {
+        D.mask_cfg = 0; D.mask_B = Bn;
+        if (D.relu_mask == nullptr) return nullptr;
+        int64_t words = 0;
+        const int cfg = orx_gemm16_nt_config(c, (int)Bn, D.out, &words);
+        if (cfg == 0 || words > D.mask_words) return nullptr;
+        D.mask_cfg = cfg;
+        return D.relu_mask;
+    };
     if (f16) {       // fp16 copies of the dense kernels: written by the fused optimizer launch; refreshed here when something else wrote a kernel
         bool stale = false;
         for (int k = 0; k < 2; ++k) for (auto& D : (k == 0 ? m->bot : m->top)) if (D.w16 != nullptr && D.shadow_version != D.W->version) stale = true;
@@ -445,7 +471,8 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
         const int64_t ldy = last ? (int64_t)F * d : L.out;
         if (bot16 && bx16 != nullptr && orx_gemm16_nt_ok(ldbx16, L.ld16t, L.out, L.in)) {
             void* y16 = last ? nullptr : m->bot_y16[l];
-            CHECK(orx_launch_gemm16_nt(c, bx16, ldbx16, L.w16t, L.ld16t, L.lean ? nullptr : y, ldy, y16, up8(L.out), L.b->w, (int)B, L.out, L.in, L.act));
+            CHECK(orx_launch_gemm16_nt(c, bx16, ldbx16, L.w16t, L.ld16t, L.lean ? nullptr : y, ldy, y16, up8(L.out), L.b->w, (int)B, L.out, L.in, L.act,
+                                       nullptr, nullptr, 0, 0, nullptr, mask_for(m->bot[l], B)));
             bx16 = y16; ldbx16 = up8(L.out);
         } else {
             ORX_ARG(l == 0 || !m->bot[l - 1].lean, "dlrm forward: bottom layer %d has no fp32 input", (int)l);
@@ -477,7 +504,8 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
             if (L.head)
                 CHECK(orx_launch_head_fwd(c, x16, ldx16, L.w16t, L.b->w, L.act, m->top_y[l], (int)B, L.in));
             else if (m->gen2 && orx_gemm16_nt_ok(ldx16, L.ld16t, L.out, L.in))
-                CHECK(orx_launch_gemm16_nt(c, x16, ldx16, L.w16t, L.ld16t, L.lean ? nullptr : m->top_y[l], L.out, y16, up8(L.out), L.b->w, (int)B, L.out, L.in, L.act));
+                CHECK(orx_launch_gemm16_nt(c, x16, ldx16, L.w16t, L.ld16t, L.lean ? nullptr : m->top_y[l], L.out, y16, up8(L.out), L.b->w, (int)B, L.out, L.in, L.act,
+                                           nullptr, nullptr, 0, 0, nullptr, mask_for(m->top[l], B)));
             else
             CHECK(orx_launch_gemm_f16s(c, x16, ldx16, L.w16t, L.ld16t, m->top_y[l], L.out, y16, up8(L.out), L.b->w, (int)B, L.out, L.in, L.act));
             x16 = y16; ldx16 = up8(L.out); have16 = y16 != nullptr;
@@ -665,15 +693,20 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
                         const bool y16 = L[l - 1].lean;
                         ORX_ARG(!y16 || (outs16 && (*outs16)[l - 1]), "dlrm backward: fp16 activation missing for layer %d", l - 1);
                         ColPart pbb = colpart_of(L[l - 1].gbpart);
+                        // the layer below's relu mask, if its forward launch wrote one in the tile form this launch takes
+                        const unsigned long long* mask_in = nullptr;
+                        if (y16 && L[l - 1].act == 1 && L[l - 1].relu_mask != nullptr && L[l - 1].mask_cfg != 0 && L[l - 1].mask_B == B &&
+                            L[l - 1].mask_cfg == (grouped ? 3 : orx_gemm16_nt_config(c, (int)B, D.in, nullptr)))
+                            mask_in = L[l - 1].relu_mask;
                         if (grouped)
                             CHECK(orx_launch_gemm16_group(c, (*ins16)[l], (*ld_in16)[l], dy16, D.out, D.W->gsum, D.out, D.slab, D.in, D.out, (int)B, inv_scale,
                                                           D.w16, D.ld16, below16 ? nullptr : other, ld_in[l], next16, L[l - 1].out,
                                                           y16 ? nullptr : outs[l - 1], y16 ? (*outs16)[l - 1] : nullptr,
-                                                          y16 ? (int64_t)up8(L[l - 1].out) : ld_out[l - 1], L[l - 1].act, &pbb));
+                                                          y16 ? (int64_t)up8(L[l - 1].out) : ld_out[l - 1], L[l - 1].act, &pbb, mask_in));
                         else
                         CHECK(orx_launch_gemm16_nt(c, dy16, D.out, D.w16, D.ld16, below16 ? nullptr : other, ld_in[l], next16, L[l - 1].out,
                                                    nullptr, (int)B, D.in, D.out, 0, y16 ? nullptr : outs[l - 1], y16 ? (*outs16)[l - 1] : nullptr,
-                                                   y16 ? (int64_t)up8(L[l - 1].out) : ld_out[l - 1], L[l - 1].act, &pbb));
+                                                   y16 ? (int64_t)up8(L[l - 1].out) : ld_out[l - 1], L[l - 1].act, &pbb, nullptr, mask_in));
                         add_job(pbb, L[l - 1].b->gsum, L[l - 1].out);
                         dy16 = next16; dy32 = !below16;
                     } else {

@@ -33,6 +33,12 @@ struct Nt16Args {
     const float* bias;
     int M, N, K, act;
     const float* actY; const _Float16* actY16; int64_t ldy; int act_y; float* gb;      // fused activation backward (see above)
+    // relu masks (round 6): ONE 64-bit word per lane and tile -- bit (mi * (TN / 2) + np) * 8 + e says whether the fp16 output of the lane's
+    // element (row tile mi, column pair np, element e) is > 0 -- written by the forward launch of a relu layer (mask_out), read by the input-
+    // gradient launch above it (mask_in) in place of the eight 16-byte requests per lane that fetched the layer's fp16 output for the fused
+    // activation backward (scratch/exp_k512.hip: those requests cost ~5 us of a 18-27 us launch; one request ~1 us).  Word index =
+    // tile * threads + thread: forward and backward launch must use the same tile configuration (the host checks: orx_gemm16_nt_config).
+    unsigned long long* mask_out; const unsigned long long* mask_in;
 };
 
 // XCD-aware tile order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so id b -> slot
@@ -50,8 +56,17 @@ __device__ __forceinline__ int xcd_slot(int b, int n) { return (n & 7) ? b : (b 
 // 16-byte rows (`fast`, uniform over the workgroup); edge tiles take the element-wise path as before.
 // (plain arrays handed on by reference: a struct behind a pointer went to scratch memory -- the "prefetched" operands then came back from HBM)
 template <int WM, int WN, int TM, int TN>
-__device__ __forceinline__ bool nt_epilogue_prefetch(const Nt16Args& g, int bm, int bn, int wm, int wn, h8 (&py)[TM][TN / 2], f32x4 (&pb)[TN / 2][2]) {
+__device__ __forceinline__ size_t nt_mask_index(const Nt16Args& g, int bm, int bn) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = 64 * WM * WN;
+    const int ntn = (g.N + BN - 1) / BN;
+    return ((size_t)(bm / BM) * ntn + (size_t)(bn / BN)) * NT + threadIdx.x;
+}
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ bool nt_epilogue_prefetch(const Nt16Args& g, int bm, int bn, int wm, int wn, h8 (&py)[TM][TN / 2], f32x4 (&pb)[TN / 2][2],
+                                                     unsigned long long& pmask) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    const bool use_mask = g.mask_in != nullptr && g.act_y == 1;
+    pmask = use_mask ? g.mask_in[nt_mask_index<WM, WN, TM, TN>(g, bm, bn)] : 0ull;
     const int lane = threadIdx.x & 63;
     const int r16 = lane & 15, q = lane >> 4;
     const bool fast = bm + BM <= g.M && bn + BN <= g.N && (g.N & 7) == 0 && (g.actY16 == nullptr || (g.ldy & 7) == 0) && g.actY == nullptr &&
@@ -66,7 +81,11 @@ __device__ __forceinline__ bool nt_epilogue_prefetch(const Nt16Args& g, int bm, 
         for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) py[mi][np][e] = (_Float16)0.0f;
-            if (fast && g.actY16) py[mi][np] = *reinterpret_cast<const h8*>(g.actY16 + (int64_t)(bm + wm + mi * 16 + r16) * g.ldy + col);
+#ifdef ORX_EXP_Y1          // (scratch/exp_k512.hip: what ONE request per lane costs instead of eight)
+            if (fast && g.actY16 && mi == 0 && np == 0) py[mi][np] = *reinterpret_cast<const h8*>(g.actY16 + (int64_t)(bm + wm + r16) * g.ldy + col);
+#else
+            if (fast && g.actY16 && !use_mask) py[mi][np] = *reinterpret_cast<const h8*>(g.actY16 + (int64_t)(bm + wm + mi * 16 + r16) * g.ldy + col);
+#endif
         }
     }
     return fast;
@@ -100,7 +119,7 @@ __device__ __forceinline__ void nt_colsums(const Nt16Args& g, float (&cs)[TN / 2
 // most of a 10 000-line kernel: instruction fetch, not data).
 template <int WM, int WN, int TM, int TN, int NTS>
 __device__ __forceinline__ void nt_epilogue_fast(const Nt16Args& g, f32x4 (&acc)[TM][TN], int bm, int bn, int wm, int wn, float* red,
-                                                 const h8 (&py)[TM][TN / 2], const f32x4 (&pb)[TN / 2][2]) {
+                                                 const h8 (&py)[TM][TN / 2], const f32x4 (&pb)[TN / 2][2], unsigned long long pmask) {
     const int lane = threadIdx.x & 63;
     const int r16 = lane & 15, q = lane >> 4;
     float cs[TN / 2][8];
@@ -109,6 +128,8 @@ __device__ __forceinline__ void nt_epilogue_fast(const Nt16Args& g, f32x4 (&acc)
 #pragma unroll
         for (int e = 0; e < 8; ++e) cs[np][e] = 0.0f;
     const bool has_y = g.actY16 != nullptr;
+    const bool use_mask = g.mask_in != nullptr && g.act_y == 1;
+    unsigned long long omask = 0ull;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int64_t row = bm + wm + mi * 16 + r16;
@@ -128,7 +149,14 @@ __device__ __forceinline__ void nt_epilogue_fast(const Nt16Args& g, f32x4 (&acc)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
             }
-            if (has_y) {
+            if (use_mask) {
+                const unsigned bits = (unsigned)(pmask >> ((mi * (TN / 2) + np) * 8)) & 0xffu;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = ((bits >> e) & 1u) ? v[e] : 0.0f;
+                    cs[np][e] += v[e];
+                }
+            } else if (has_y) {
                 const h8 t8 = py[mi][np];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -136,6 +164,11 @@ __device__ __forceinline__ void nt_epilogue_fast(const Nt16Args& g, f32x4 (&acc)
                     v[e] = g.act_y == 1 ? (y > 0.0f ? v[e] : 0.0f) : (g.act_y == 2 ? v[e] * y * (1.0f - y) : v[e]);
                     cs[np][e] += v[e];
                 }
+            }
+            if (g.mask_out) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if ((_Float16)v[e] > (_Float16)0.0f) omask |= 1ull << ((mi * (TN / 2) + np) * 8 + e);
             }
             if (g.C) {
                 float* p = g.C + row * g.ldc + col;
@@ -153,6 +186,7 @@ __device__ __forceinline__ void nt_epilogue_fast(const Nt16Args& g, f32x4 (&acc)
             }
         }
     }
+    if (g.mask_out) g.mask_out[nt_mask_index<WM, WN, TM, TN>(g, bm, bn)] = omask;
     if (NTS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (g.gb) nt_colsums<WM, WN, TM, TN>(g, cs, bm, bn, wn, red);
 }
@@ -166,6 +200,7 @@ __device__ __forceinline__ void nt_epilogue(const Nt16Args& g, f32x4 (&acc)[TM][
     static_assert(TN % 2 == 0, "tile pairs");
     const bool vec = (g.N & 7) == 0;
     float cs[TN / 2][8];
+    unsigned long long gen_mask = 0ull;
 #pragma unroll
     for (int np = 0; np < TN / 2; ++np)
 #pragma unroll
@@ -233,6 +268,11 @@ __device__ __forceinline__ void nt_epilogue(const Nt16Args& g, f32x4 (&acc)[TM][
                     for (int e = 0; e < 8; ++e) if (col + e < g.N) p[e] = v[e];
                 }
             }
+            if (g.mask_out) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (col + e < g.N && (_Float16)v[e] > (_Float16)0.0f) gen_mask |= 1ull << ((mi * (TN / 2) + np) * 8 + e);
+            }
             if (g.C16) {
                 _Float16* p = g.C16 + (int64_t)row * g.ldc16 + col;
                 if (full && (g.ldc16 & 7) == 0) {
@@ -246,6 +286,7 @@ __device__ __forceinline__ void nt_epilogue(const Nt16Args& g, f32x4 (&acc)[TM][
             }
         }
     }
+    if (g.mask_out) g.mask_out[nt_mask_index<WM, WN, TM, TN>(g, bm, bn)] = gen_mask;
     if (NTS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the write-through stores are acknowledged before the wavefront ends)
     if (g.gb) {
         // column sums: over the 16 rows of a lane group (DPP), over the block's WM wavefronts through LDS (the stages are
@@ -499,8 +540,9 @@ __device__ __forceinline__ void gemm16_nt_dma_body(const Nt16Args& g, const int 
     // order, so requests OLDER than every tile are long complete wherever the loop waits, while requests issued later -- before the last
     // K steps, say -- would sit among the newest ones and be waited for with the tiles (measured: no gain that way).
     h8 pre_y[TM][TN / 2]; f32x4 pre_b[TN / 2][2];
+    unsigned long long pre_mask = 0ull;
     bool pre_fast = false;
-    if (!(DBG & 1)) pre_fast = nt_epilogue_prefetch<WM, WN, TM, TN>(g, bm, bn, wm, wn, pre_y, pre_b);
+    if (!(DBG & 1)) pre_fast = nt_epilogue_prefetch<WM, WN, TM, TN>(g, bm, bn, wm, wn, pre_y, pre_b, pre_mask);
 #pragma unroll
     for (int s = 0; s < NS; ++s) if (s < nk) issue(s * BK, lds16 + s * STAGE);
     if (nk > 2 && NS == 3) wait_vm<2 * NL>(); else if (nk > 1) wait_vm<NL>(); else wait_vm<0>();
@@ -528,7 +570,7 @@ __device__ __forceinline__ void gemm16_nt_dma_body(const Nt16Args& g, const int 
         return;
     }
     if (g.gb) __syncthreads();                                                 // (the column sums go through the stages' LDS)
-    if (pre_fast) nt_epilogue_fast<WM, WN, TM, TN, (DBG & 32) ? 2 : (DBG & 16) ? 1 : 0>(g, acc, bm, bn, wm, wn, reinterpret_cast<float*>(lds16), pre_y, pre_b);
+    if (pre_fast) nt_epilogue_fast<WM, WN, TM, TN, (DBG & 32) ? 2 : (DBG & 16) ? 1 : 0>(g, acc, bm, bn, wm, wn, reinterpret_cast<float*>(lds16), pre_y, pre_b, pre_mask);
     else nt_epilogue<WM, WN, TM, TN, (DBG & 32) ? 2 : (DBG & 16) ? 1 : 0>(g, acc, bm, bn, wm, wn, reinterpret_cast<float*>(lds16));
 }
 
@@ -576,15 +618,38 @@ static int launch_nt(orx_ctx* ctx, const Nt16Args& g) {
 
 bool orx_gemm16_nt_ok(int64_t lda, int64_t ldb, int N, int K) { return lda % 8 == 0 && ldb % 8 == 0 && N >= 32 && K >= 8; }
 
+// which tile configuration the [M, N] product takes (the relu-mask words of Nt16Args are laid out per configuration): 1 = 256 x 128 on eight
+// wavefronts, 2 = 128 x 128, 3 = 128 x 64, each in its LDS-DMA form; 0 = any other form (forced tiles, register staging, wave-tile experiment): no masks.
+// words_out: 64-bit words a mask of that product needs
+int orx_gemm16_nt_config(orx_ctx* ctx, int M, int N, int64_t* words_out) {
+    static const bool off = getenv("ORX_GEMM16_NO_MASK") != nullptr;
+    static const int force = getenv("ORX_GEMM16_TILE") ? atoi(getenv("ORX_GEMM16_TILE")) : 0;
+    static const int dma_env = getenv("ORX_GEMM16_DMA") ? atoi(getenv("ORX_GEMM16_DMA")) : 3;
+    static const int wave_tile = getenv("ORX_GEMM16_WAVE_TILE") ? atoi(getenv("ORX_GEMM16_WAVE_TILE")) : 64;
+    if (words_out) *words_out = 0;
+    if (off || force != 0 || dma_env != 3 || wave_tile != 64) return 0;
+    const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+    auto blocks = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    int cfg, bm, bn, nt;
+    if (blocks(256, 128) >= cus) { cfg = 1; bm = 256; bn = 128; nt = 512; }
+    else if (blocks(128, 128) >= 2 * cus) { cfg = 2; bm = 128; bn = 128; nt = 256; }
+    else { cfg = 3; bm = 128; bn = 64; nt = 256; }
+    if (words_out) *words_out = blocks(bm, bn) * nt;
+    return cfg;
+}
+
 int orx_launch_gemm16_nt(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                          void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act,
-                         const float* actY, const void* actY16, int64_t ldy, int act_y, ColPart* gbp) {
+                         const float* actY, const void* actY16, int64_t ldy, int act_y, ColPart* gbp,
+                         unsigned long long* mask_out, const unsigned long long* mask_in) {
     if (M == 0 || N == 0) return ORX_OK;
     float* gb = gbp ? gbp->parts : nullptr;
     ORX_ARG(lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)A16 | (uintptr_t)B16) & 15) == 0, "gemm16_nt: operands need 16-byte rows");
     ProfScope ps(ctx, ORX_K_GEMM);
     Nt16Args g{(const _Float16*)A16, lda, (const _Float16*)B16, ldb, C, ldc, (_Float16*)C16, ldc16, bias, M, N, K, act,
-               actY, (const _Float16*)actY16, ldy, act_y, gb};
+               actY, (const _Float16*)actY16, ldy, act_y, gb, mask_out, mask_in};
+    ORX_ARG((mask_out == nullptr && mask_in == nullptr) || ((int64_t)M * lda < (1LL << 30) && (int64_t)N * ldb < (1LL << 30) && orx_gemm16_nt_config(ctx, M, N, nullptr) != 0),
+            "gemm16_nt: relu masks need the LDS-DMA tile forms");
     // the largest tile that still gives every CU a workgroup (256 CUs)
     auto blocks = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     static const int force = getenv("ORX_GEMM16_TILE") ? atoi(getenv("ORX_GEMM16_TILE")) : 0;
@@ -1082,7 +1147,7 @@ bool orx_gemm16_group_ok(orx_ctx* ctx, int B, int in, int out, int64_t ldx16, in
 int orx_launch_gemm16_group(orx_ctx* ctx, const void* X16, int64_t ldx, const void* dZ16, int64_t lddz, float* gW, int64_t ldgw, float* slab,
                             int in, int out, int B, float out_scale,
                             const void* W16, int64_t ldw, float* C, int64_t ldc, void* C16, int64_t ldc16,
-                            const float* actY, const void* actY16, int64_t ldy, int act_y, ColPart* gbp) {
+                            const float* actY, const void* actY16, int64_t ldy, int act_y, ColPart* gbp, const unsigned long long* mask_in) {
     if (B == 0 || in == 0 || out == 0) return ORX_OK;
     ORX_ARG(ldx % 8 == 0 && lddz % 8 == 0 && ldw % 8 == 0 && (((uintptr_t)X16 | (uintptr_t)dZ16 | (uintptr_t)W16) & 15) == 0, "gemm16_group: operands need 16-byte rows");
     ProfScope ps(ctx, ORX_K_GEMM);
@@ -1092,7 +1157,7 @@ int orx_launch_gemm16_group(orx_ctx* ctx, const void* X16, int64_t ldx, const vo
     Group16Args g;
     g.tn = Tn16Args{(const _Float16*)X16, ldx, (const _Float16*)dZ16, lddz, gW, ldgw, slab, in, out, B, kchunk, out_scale};
     g.nt = Nt16Args{(const _Float16*)dZ16, lddz, (const _Float16*)W16, ldw, C, ldc, (_Float16*)C16, ldc16, nullptr, B, in, out, 0,
-                    actY, (const _Float16*)actY16, ldy, act_y, gbp ? gbp->parts : nullptr};
+                    actY, (const _Float16*)actY16, ldy, act_y, gbp ? gbp->parts : nullptr, nullptr, mask_in};
     if (gbp) gbp->P = (B + 127) / 128;
     g.n_tn = tiles * S;
     g.n_nt = ((B + 127) / 128) * ((in + 63) / 64);

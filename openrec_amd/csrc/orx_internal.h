@@ -508,7 +508,10 @@ int orx_launch_gemm_f16s(orx_ctx* ctx, const void* A16, int64_t lda, const void*
 bool orx_gemm16_nt_ok(int64_t lda, int64_t ldb, int N, int K);
 int orx_launch_gemm16_nt(orx_ctx* ctx, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                          void* C16, int64_t ldc16, const float* bias, int M, int N, int K, int act,
-                         const float* actY = nullptr, const void* actY16 = nullptr, int64_t ldy = 0, int act_y = 0, ColPart* gb = nullptr);
+                         const float* actY = nullptr, const void* actY16 = nullptr, int64_t ldy = 0, int act_y = 0, ColPart* gb = nullptr,
+                         // relu masks (kernels_gemm16.hip Nt16Args): written by a relu layer's forward launch, read by the input-gradient launch above it
+                         unsigned long long* mask_out = nullptr, const unsigned long long* mask_in = nullptr);
+int orx_gemm16_nt_config(orx_ctx* ctx, int M, int N, int64_t* words_out);
 #define ORX_SLAB_STRIDE (128 * 128 + 64)          // floats per (tile, slice) of a split-K workspace (kernels_gemm16.hip)
 struct SlabReduce { const float* slab; float* C; int64_t ldc; int M, N, S, ntn, tiles; };
 bool orx_gemm16_tn_ok(int64_t lda, int64_t ldb, int N);
@@ -521,7 +524,7 @@ bool orx_gemm16_group_ok(orx_ctx* ctx, int B, int in, int out, int64_t ldx16, in
 int orx_launch_gemm16_group(orx_ctx* ctx, const void* X16, int64_t ldx, const void* dZ16, int64_t lddz, float* gW, int64_t ldgw, float* slab,
                             int in, int out, int B, float out_scale,
                             const void* W16, int64_t ldw, float* C, int64_t ldc, void* C16, int64_t ldc16,
-                            const float* actY, const void* actY16, int64_t ldy, int act_y, ColPart* gbp);
+                            const float* actY, const void* actY16, int64_t ldy, int act_y, ColPart* gbp, const unsigned long long* mask_in = nullptr);
 int orx_launch_cast16(orx_ctx* ctx, const float* src, int64_t lds_, void* dst16, int64_t ld16, int M, int N);
 bool orx_head16_ok(int K, int64_t ldx);
 int orx_launch_head_fwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* bias, int act, float* pred, int B, int K);

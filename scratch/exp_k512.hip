@@ -51,6 +51,9 @@ int main() {
         rep("forward form (fp16 out, bias, relu), write-through stores", time_us([&] { launch_dbg<4, 2, 4, 4, 1, 3, 32>(fwd); }));
         rep("backward form (Y16 read, column sums, fp16 out), write-through", time_us([&] { launch_dbg<4, 2, 4, 4, 1, 3, 32>(bwd); }));
         rep("backward form + fp32 copy", time_us([&] { launch_dbg<4, 2, 4, 4, 1, 3, 32>(bwd32); }));
+        { unsigned long long* mk; CK(hipMalloc(&mk, (size_t)M * N / 32 * 8)); CK(hipMemset(mk, 0x5a, (size_t)M * N / 32 * 8));
+          Nt16Args v = bwd; v.mask_in = mk; rep("backward form, relu' from the mask words (one request per lane)", time_us([&] { launch_dbg<4, 2, 4, 4, 1, 3, 32>(v); }));
+          Nt16Args w = fwd; w.mask_out = mk; rep("forward form + mask words written", time_us([&] { launch_dbg<4, 2, 4, 4, 1, 3, 32>(w); })); CK(hipFree(mk)); }
         { Nt16Args v = bwd; v.ldy = 0; rep("backward form, Y16 rows all the same 2 KB (ldy = 0: no HBM read)", time_us([&] { launch_dbg<4, 2, 4, 4, 1, 3, 32>(v); })); }
         { Nt16Args v = bwd; v.act_y = 0; rep("backward form, act_y = 0 (Y loaded, not applied)", time_us([&] { launch_dbg<4, 2, 4, 4, 1, 3, 32>(v); })); }
         { Nt16Args v = bwd; v.act_y = 0; v.gb = nullptr; rep("backward form, act_y = 0, no column sums", time_us([&] { launch_dbg<4, 2, 4, 4, 1, 3, 32>(v); })); }
