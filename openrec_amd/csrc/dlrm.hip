@@ -184,7 +184,9 @@ extern "C" int orx_dlrm_create(orx_ctx* ctx, int32_t m_spa, int32_t n_emb, const
         std::vector<ShadowParam> sp;
         auto add = [&](DenseLayer& D) -> int {
             D.ld16 = up8(D.out); D.ld16t = up_k(D.in);
-            ORX_HIP(hipMalloc(&D.w16, (size_t)D.in * D.ld16 * 2)); ORX_HIP(hipMemset(D.w16, 0, (size_t)D.in * D.ld16 * 2));
+            // (rows up to a multiple of 8, the extra ones zero: the input-gradient product of a 479-wide layer runs as 480 columns -- 16-byte
+            // rows for its epilogue -- and leaves a zero in the padding column of its output)
+            ORX_HIP(hipMalloc(&D.w16, (size_t)up8(D.in) * D.ld16 * 2)); ORX_HIP(hipMemset(D.w16, 0, (size_t)up8(D.in) * D.ld16 * 2));
             ORX_HIP(hipMalloc(&D.w16t, (size_t)D.out * D.ld16t * 2)); ORX_HIP(hipMemset(D.w16t, 0, (size_t)D.out * D.ld16t * 2));
             ShadowParam p; p.w = D.W->w; p.w16 = D.w16; p.w16t = D.w16t; p.in = D.in; p.out = D.out; p.ld16 = D.ld16; p.ld16t = D.ld16t;
             sp.push_back(p); m->shadow_max = std::max<int64_t>(m->shadow_max, (int64_t)D.in * D.out);
@@ -719,10 +721,13 @@ static int mlp_backward(orx_dlrm* m, std::vector<DenseLayer>& L, const std::vect
                     }
                     act_done = true;
                 } else {
+                    // (the output's padding columns are computed too -- zeros, the operand's extra rows are zero -- where that gives the product whole
+                    // 16-byte rows: 479 -> 480 columns of dR)
+                    const int in_cols = (ld_in[l] >= up8(D.in) && getenv("ORX_DLRM_NO_PAD_DX") == nullptr) ? up8(D.in) : D.in;
                     if (nt && grouped)
                         CHECK(orx_launch_gemm16_group(c, (*ins16)[l], (*ld_in16)[l], dy16, D.out, D.W->gsum, D.out, D.slab, D.in, D.out, (int)B, inv_scale,
-                                                      D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, nullptr, 0, 0, nullptr));
-                    else if (nt) CHECK(orx_launch_gemm16_nt(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, (int)B, D.in, D.out, 0));
+                                                      D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, in_cols));
+                    else if (nt) CHECK(orx_launch_gemm16_nt(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, (int)B, in_cols, D.out, 0));
                     else CHECK(orx_launch_gemm_f16s(c, dy16, D.out, D.w16, D.ld16, other, ld_in[l], nullptr, 0, nullptr, (int)B, D.in, D.out, 0));
                     dy32 = true;
                 }

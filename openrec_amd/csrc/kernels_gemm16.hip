@@ -1147,8 +1147,9 @@ bool orx_gemm16_group_ok(orx_ctx* ctx, int B, int in, int out, int64_t ldx16, in
 int orx_launch_gemm16_group(orx_ctx* ctx, const void* X16, int64_t ldx, const void* dZ16, int64_t lddz, float* gW, int64_t ldgw, float* slab,
                             int in, int out, int B, float out_scale,
                             const void* W16, int64_t ldw, float* C, int64_t ldc, void* C16, int64_t ldc16,
-                            const float* actY, const void* actY16, int64_t ldy, int act_y, ColPart* gbp, const unsigned long long* mask_in) {
+                            const float* actY, const void* actY16, int64_t ldy, int act_y, ColPart* gbp, const unsigned long long* mask_in, int nt_cols) {
     if (B == 0 || in == 0 || out == 0) return ORX_OK;
+    const int in_nt = nt_cols > 0 ? nt_cols : in;          // columns of the input-gradient product (>= in: the operand's zero padding rows)
     ORX_ARG(ldx % 8 == 0 && lddz % 8 == 0 && ldw % 8 == 0 && (((uintptr_t)X16 | (uintptr_t)dZ16 | (uintptr_t)W16) & 15) == 0, "gemm16_group: operands need 16-byte rows");
     ProfScope ps(ctx, ORX_K_GEMM);
     int S, tiles, kchunk;
@@ -1156,11 +1157,11 @@ int orx_launch_gemm16_group(orx_ctx* ctx, const void* X16, int64_t ldx, const vo
     ORX_ARG(S == 1 || slab != nullptr, "gemm16_group: split-K needs a slab workspace");
     Group16Args g;
     g.tn = Tn16Args{(const _Float16*)X16, ldx, (const _Float16*)dZ16, lddz, gW, ldgw, slab, in, out, B, kchunk, out_scale};
-    g.nt = Nt16Args{(const _Float16*)dZ16, lddz, (const _Float16*)W16, ldw, C, ldc, (_Float16*)C16, ldc16, nullptr, B, in, out, 0,
+    g.nt = Nt16Args{(const _Float16*)dZ16, lddz, (const _Float16*)W16, ldw, C, ldc, (_Float16*)C16, ldc16, nullptr, B, in_nt, out, 0,
                     actY, (const _Float16*)actY16, ldy, act_y, gbp ? gbp->parts : nullptr, nullptr, mask_in};
     if (gbp) gbp->P = (B + 127) / 128;
     g.n_tn = tiles * S;
-    g.n_nt = ((B + 127) / 128) * ((in + 63) / 64);
+    g.n_nt = ((B + 127) / 128) * ((in_nt + 63) / 64);
     const bool tn_tail = (B & 63) != 0 || kchunk % 64 != 0 || (int64_t)((in + 127) / 128) * 128 > ldx || (int64_t)((out + 127) / 128) * 128 > lddz;
     const bool nt_tail = (lddz & 63) != 0 || (ldw & 63) != 0;
     static const int nts_env = getenv("ORX_GEMM16_NTS") != nullptr ? atoi(getenv("ORX_GEMM16_NTS")) : 2;

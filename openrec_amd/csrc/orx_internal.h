@@ -524,7 +524,8 @@ bool orx_gemm16_group_ok(orx_ctx* ctx, int B, int in, int out, int64_t ldx16, in
 int orx_launch_gemm16_group(orx_ctx* ctx, const void* X16, int64_t ldx, const void* dZ16, int64_t lddz, float* gW, int64_t ldgw, float* slab,
                             int in, int out, int B, float out_scale,
                             const void* W16, int64_t ldw, float* C, int64_t ldc, void* C16, int64_t ldc16,
-                            const float* actY, const void* actY16, int64_t ldy, int act_y, ColPart* gbp, const unsigned long long* mask_in = nullptr);
+                            const float* actY, const void* actY16, int64_t ldy, int act_y, ColPart* gbp, const unsigned long long* mask_in = nullptr,
+                            int nt_cols = 0);     // > 0: the input-gradient product's column count (the weight operand padded with zero rows)
 int orx_launch_cast16(orx_ctx* ctx, const float* src, int64_t lds_, void* dst16, int64_t ld16, int M, int N);
 bool orx_head16_ok(int K, int64_t ldx);
 int orx_launch_head_fwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* bias, int act, float* pred, int B, int K);

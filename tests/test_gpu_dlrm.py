@@ -403,6 +403,7 @@ def test_dlrm_fp16_staging_forms_are_bit_identical():
     fam_a = [{}, {"ORX_GEMM16_NTS": "0"}, {"ORX_GEMM16_NTS": "1"},
              {"ORX_DLRM_COLPARTS_LAUNCH": "1"},            # the partial-row sums added by the optimizer launch vs a reduce launch
              {"ORX_GEMM16_NO_MASK": "1"},                  # relu' from the fp16 output itself instead of the forward launch's mask words
+             {"ORX_DLRM_NO_PAD_DX": "1"},                  # the first top layer's input gradient on its 479 columns instead of 480
              {"ORX_DLRM_DEFER_DW": "1"},                   # the top MLP's weight gradients beside the interaction backward (side stream; measured slower: off)
              {"ORX_GEMM16_WAVE_TILE": "128"}]              # the 256 x 128 tile on four wavefronts of 128 x 64 (measured slower: off)
     # C: no grouped launches (every weight gradient on the two-group kernel): the staging forms of the forward / input-gradient products
