@@ -130,6 +130,16 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
     a.invB = 1.0f / (float)B; a.l2w = (flags & ORX_NO_L2) ? 0.f : 1.f; a.a_w = a_w; a.b_w = b_w;
     a.sigmoid = (model == ORX_WRMF && (flags & ORX_POINT_SIGMOID)) ? 1 : 0;
     a.wpartial = c->d_wpart; a.err = c->d_err;
+    // GMF on the float4 kernels: the Dense(1) gradient is reduced and applied by the last workgroups of the step's own launch
+    const bool dense_tail = model == ORX_GMF && orx_point_dense_tail_ok(D);
+    if (dense_tail) {
+        // the partial rows and the group rows behind them start out EMPTY (all ones); every launch hands them back that way
+        const size_t nrows = (size_t)orx_point_wparts(D, B) + (size_t)orx_point_reducers(D, B) - 1;
+        ORX_HIP(hipMemsetAsync(c->d_wpart, 0xff, nrows * D * sizeof(float), c->stream));
+        a.wt_nred = orx_point_reducers(D, B); a.wt_rows = c->d_wpart + (size_t)orx_point_wparts(D, B) * D;
+        const bool to_gout = mode == MODE_ACCUM || lazy_adam;                        // (Adam: adam_sweep_kernel applies the gradient)
+        a.wt_gout = to_gout ? w->gsum : nullptr; a.wt_acc = to_gout ? nullptr : sw.s0; a.wt_optkind = to_gout ? -1 : opt->kind;
+    }
     if (role_bits) { a.role_bits = 1; a.gU2 = U->gsum2; a.gV2 = V->gsum2; a.gb2 = b->gsum2; a.readyU = U->ready; a.readyV = V->ready; }
     PairArgs pa;                                 // view of the same tables for dup_apply_kernel / hot_reduce_kernel / the in-launch apply
     memset(&pa, 0, sizeof(pa));
@@ -174,6 +184,7 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
         const int64_t s = s0 + i;
         a.label = dl + s * ds;
         a.partial = c->d_partial + (size_t)s * nslot * 2;
+        a.wt_l2slot = a.partial + 2 * nw;
         if (role_bits) {
             a.uid = c->d_ids2 + (size_t)i * 3 * plan.Bp; a.iid = a.uid + plan.Bp;
             a.ids4 = plan.pair_tpw > 1 ? c->d_ids4 + (size_t)i * B : nullptr;      // (with pairing the SoA copy is not written: the records are the input)
@@ -211,9 +222,9 @@ extern "C" int orx_pointwise_step(orx_ctx* c, int model, orx_opt* opt,
         }
         if (model == ORX_GMF) {                  // dense Dense(1) kernel: reduce partials, apply the dense rule
             if (mode == MODE_ACCUM || lazy_adam) {
-                CHECK(orx_launch_dense_reduce(c, c->d_wpart, orx_point_wparts(D, B), D, w->w, a.l2w, w->gsum, a.partial + 2 * nw, nullptr, -1, 0.f, 0.f));
+                if (!dense_tail) CHECK(orx_launch_dense_reduce(c, c->d_wpart, orx_point_wparts(D, B), D, w->w, a.l2w, w->gsum, a.partial + 2 * nw, nullptr, -1, 0.f, 0.f));
                 CHECK(orx_launch_adam_sweep(c, w->w, sw.s0, sw.s1, w->gsum, D, lr_t, opt->p0, opt->p1, opt->p2));
-            } else {        // reduce + dense SGD / Adagrad rule in one launch
+            } else if (!dense_tail) {        // reduce + dense SGD / Adagrad rule in one launch
                 CHECK(orx_launch_dense_reduce(c, c->d_wpart, orx_point_wparts(D, B), D, w->w, a.l2w, nullptr, a.partial + 2 * nw, sw.s0, opt->kind, opt->lr, a.eps));
             }
         }

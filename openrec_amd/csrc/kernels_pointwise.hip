@@ -35,6 +35,101 @@ __device__ __forceinline__ void point_score(float s, float y, float invB, float 
     }
 }
 
+// GMF's Dense(1) gradient INSIDE the launch (round 6).  Until now: one partial row per workgroup, then dense_reduce1_kernel and
+// dense_reduce_kernel between this step's launch and the next one's -- 4.7 + 5.7 us of a 32.8 us step at B = 65 536, on the critical path
+// (the next step reads the updated kernel).  Now the launch carries ceil(workgroups / 64) + 1 REDUCER workgroups behind its sample
+// workgroups (highest block indices: dispatched last, when everything they wait for is resident or done).  Reducer g adds the rows of
+// sample workgroups 64 g .. 64 g + 63 in index order into one group row; the last reducer adds the group rows and applies the dense rule
+// (what dense_reduce_kernel did).  Fixed order of additions: the step stays bit-reproducible.
+// Hand-off without any wait on the producers' side: a slot that holds WT_EMPTY (all ones: a NaN no arithmetic produces) is "not there
+// yet"; a producer stores its row write-through and leaves; a reducer polls the slots with agent-scope loads and hands them back empty.
+// What was tried first, per launch at B = 65 536 (23.8 us without any of it): last-arriver counters with release / acquire fences 580 us
+// (an agent-scope release on gfx950 writes the whole L2 back, and this kernel keeps tens of MB of updated rows there); counters behind
+// s_waitcnt vmcnt(0) 46.7 us (every wavefront then sits on its slot until its scattered row stores are acknowledged).
+constexpr int WT_GROUP = 64;
+constexpr uint32_t WT_EMPTY = 0xffffffffu;
+constexpr int WT_SPIN_MAX = 1 << 22;         // (a value that IS all ones -- only a NaN fed in from outside can be -- is taken after this many polls)
+
+template <int LPR>
+__device__ __forceinline__ void dense_tail_reducer(const PointArgs& a, int red, int nwg) {
+    constexpr int D = 4 * LPR, NSL = 256 / LPR, RB = 4;
+    __shared__ f4 wt_red[256];
+    const int sub = threadIdx.x % LPR, sl = threadIdx.x / LPR;
+    const int ngrp = (nwg + WT_GROUP - 1) / WT_GROUP;
+    // rows first .. first + n - 1 of src are awaited, added in a fixed order (thread slices of every NSL-th row, RB rows in flight, then the
+    // slices in order) and handed back empty; the sum is valid in the threads of slice 0
+    auto take_rows = [&](float* src, int first, int n) -> f4 {
+        f4 s; s.x = s.y = s.z = s.w = 0.0f;
+        for (int r0 = sl; r0 < n; r0 += NSL * RB) {
+            uint32_t v[RB][4];
+#pragma unroll
+            for (int k = 0; k < RB; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[k][e] = WT_EMPTY;
+            for (int spins = 0; spins < WT_SPIN_MAX; ++spins) {
+                bool again = false;
+#pragma unroll
+                for (int k = 0; k < RB; ++k) {
+                    const int r = r0 + k * NSL;
+                    if (r >= n) continue;
+                    uint32_t* q = reinterpret_cast<uint32_t*>(src + (size_t)(first + r) * D + 4 * sub);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (v[k][e] == WT_EMPTY) {
+                            v[k][e] = __hip_atomic_load(q + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            again |= v[k][e] == WT_EMPTY;
+                        }
+                }
+                if (!again) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const int r = r0 + k * NSL;
+                if (r >= n) continue;
+                f4 x, e4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[e] = __uint_as_float(v[k][e]); e4[e] = __uint_as_float(WT_EMPTY); }
+                s += x;
+                store_wt4(src + (size_t)(first + r) * D + 4 * sub, e4);      // (write-through like the producers' stores: rows of 64 bytes share a line)
+            }
+        }
+        wt_red[threadIdx.x] = s;
+        __syncthreads();
+        f4 t; t.x = t.y = t.z = t.w = 0.0f;
+        if (sl == 0) for (int k = 0; k < NSL; ++k) t += wt_red[k * LPR + sub];
+        __syncthreads();
+        return t;
+    };
+    if (red < ngrp) {
+        const int in_grp = nwg - red * WT_GROUP < WT_GROUP ? nwg - red * WT_GROUP : WT_GROUP;
+        const f4 t = take_rows(a.wpartial, red * WT_GROUP, in_grp);
+        if (sl == 0) store_wt4(a.wt_rows + (size_t)red * D + 4 * sub, t);
+        return;
+    }
+    const f4 t = take_rows(a.wt_rows, 0, ngrp);
+    if (threadIdx.x < LPR) {                       // (slice 0 = the first LPR lanes of wavefront 0) the rule of dense_reduce_kernel
+        float* wp = const_cast<float*>(a.w) + 4 * sub;
+        const f4 we = *reinterpret_cast<const f4*>(wp);
+        float wsq = dot4(we, we);
+        const f4 g = t + a.l2w * we;
+        if (a.wt_optkind == ORX_SGD) {
+            *reinterpret_cast<f4*>(wp) = we - a.lr * g;
+        } else if (a.wt_optkind == ORX_ADAGRAD) {
+            f4 a2 = *reinterpret_cast<const f4*>(a.wt_acc + 4 * sub);
+            f4 wn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a2[e] = a2[e] + g[e] * g[e]; wn[e] = we[e] - a.lr * g[e] / (sqrtf(a2[e]) + a.eps); }
+            *reinterpret_cast<f4*>(a.wt_acc + 4 * sub) = a2;
+            *reinterpret_cast<f4*>(wp) = wn;
+        } else if (a.wt_gout != nullptr) {
+            *reinterpret_cast<f4*>(a.wt_gout + 4 * sub) = g;
+        }
+        for (int off = LPR / 2; off > 0; off >>= 1) wsq += __shfl_xor(wsq, off);
+        if (threadIdx.x == 0 && a.wt_l2slot != nullptr) { a.wt_l2slot[0] = 0.0f; a.wt_l2slot[1] = 0.5f * wsq; }
+    }
+}
+
 // PAIR: the instantiation with the pairing tail (97 against 73 VGPRs for GMF at D = 64 -- two wavefronts of occupancy: the host launches it
 // only for steps whose plan paired, a.ids4 != NULL)
 template <int LPR, int MODEL, int OPT, int MODE, bool PAIR = false>
@@ -58,8 +153,13 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
         else inline_apply<LPR, OPT, false, false>(a.ap);
         return;
     }
+    const int nwg = (int)gridDim.x - nab - (MODEL == ORX_GMF ? a.wt_nred : 0);      // sample workgroups
+    if (MODEL == ORX_GMF && MODE != MODE_LOSS && (int)blockIdx.x - nab >= nwg) {        // reducer role (block-uniform): see dense_tail_reducer
+        dense_tail_reducer<LPR>(a, (int)blockIdx.x - nab - nwg, nwg);
+        return;
+    }
     const int64_t wave_global = (int64_t)(blockIdx.x - nab) * 4 + (threadIdx.x >> 6);
-    const int64_t stride = (int64_t)(gridDim.x - nab) * 4 * TPW;
+    const int64_t stride = (int64_t)nwg * 4 * TPW;
     float loss_acc = 0.0f, sq_acc = 0.0f;
     f4 wv; wv.x = wv.y = wv.z = wv.w = 1.0f;
     if (MODEL == ORX_GMF) wv = *reinterpret_cast<const f4*>(a.w + 4 * sub);
@@ -227,7 +327,8 @@ __global__ __launch_bounds__(256) void point_fused_kernel(PointArgs a) {
         __syncthreads();
         if (threadIdx.x < LPR) {
             const f4 t = (gwsh[0][sub] + gwsh[1][sub]) + (gwsh[2][sub] + gwsh[3][sub]);
-            *reinterpret_cast<f4*>(a.wpartial + (size_t)(blockIdx.x - nab) * D + 4 * sub) = t;
+            if (a.wt_nred > 0) store_wt4(a.wpartial + (size_t)(blockIdx.x - nab) * D + 4 * sub, t);      // (a reducer of this launch is waiting for it)
+            else *reinterpret_cast<f4*>(a.wpartial + (size_t)(blockIdx.x - nab) * D + 4 * sub) = t;
         }
     }
 }
@@ -423,6 +524,14 @@ int orx_point_nwaves(int D, int64_t B) { return (int)(point_grid(D, B) * 4); }
 // rows of GMF's dense-gradient partials: one per workgroup from the float4 kernels, one per wavefront from the generic one
 int orx_point_wparts(int D, int64_t B) { return (int)(point_grid(D, B) * (lpr_for_dim_p(D) ? 1 : 4)); }
 
+// does the float4 kernel of this dim reduce and apply GMF's Dense(1) gradient itself (dense_tail)?  ORX_POINT_NO_WTAIL=1: the two
+// reduce launches of rounds 2-5 (A/B)
+// reducer workgroups behind the sample workgroups of a GMF launch: one per 64 partial rows + the one that applies the rule
+int orx_point_reducers(int D, int64_t B) { return (int)((point_grid(D, B) + WT_GROUP - 1) / WT_GROUP) + 1; }
+bool orx_point_dense_tail_ok(int D) {
+    return lpr_for_dim_p(D) != 0 && getenv("ORX_POINT_NO_WTAIL") == nullptr;
+}
+
 template <int LPR, int MODEL, int OPT>
 static void launch_point_mode(int mode, dim3 g, orx_ctx* c, const PointArgs& a) {
     switch (mode) {
@@ -473,7 +582,9 @@ static void launch_point_adam(int lpr, dim3 g, orx_ctx* c, const PointArgs& a) {
 int orx_launch_point_fused(orx_ctx* ctx, int model, int optkind, int mode, const PointArgs& a) {
     ProfScope ps(ctx, ORX_K_POINT);
     const int lpr = lpr_for_dim_p(a.D);
-    const dim3 g((unsigned)(point_grid(a.D, a.B) + (mode == MODE_EXACT && lpr != 0 ? a.n_apply_blocks : 0)));
+    ORX_ARG(a.wt_nred == 0 || (model == ORX_GMF && lpr != 0 && mode != MODE_LOSS && a.wt_nred == orx_point_reducers(a.D, a.B)),
+            "point_fused: reducer workgroups are for GMF's float4 kernels");
+    const dim3 g((unsigned)(point_grid(a.D, a.B) + (mode == MODE_EXACT && lpr != 0 ? a.n_apply_blocks : 0) + a.wt_nred));
     if (optkind == ORX_ADAM && mode == MODE_EXACT) {
         ORX_ARG(lpr != 0 && a.lrt != nullptr && a.role_bits, "point_fused: the lazy Adam path needs a float4 dim and the exact-step plan");
         if (model == ORX_GMF) launch_point_adam<ORX_GMF>(lpr, g, ctx, a);

@@ -384,6 +384,11 @@ struct PointArgs {
     PairArgs ap;
     // pairing (round 6; kernels_plan.hip): the step's input records (user id, item id, label bits, pairing word | origin << 10), NULL: off
     const int4* ids4;
+    // GMF, float4 kernels (round 6): the Dense(1) gradient is summed and its rule applied by wt_nred REDUCER workgroups at the end of the
+    // launch itself (kernels_pointwise.hip dense_tail_reducer) instead of two more launches between this step and the next.  0: off
+    int wt_nred;                              // orx_point_reducers(D, B)
+    float* wt_rows;                           // [wt_nred - 1][D] the sums of 64 consecutive workgroups' partial rows (slots start out WT_EMPTY)
+    float* wt_gout; float* wt_l2slot; float* wt_acc; int wt_optkind;      // as dense_reduce_kernel's arguments
 };
 
 int orx_launch_point_fused(orx_ctx* ctx, int model, int optkind, int mode, const PointArgs& a);
@@ -394,6 +399,8 @@ int orx_launch_score_all(orx_ctx* ctx, const float* U, const float* V, const flo
                          const int32_t* uid, int64_t nq, int64_t NU, int64_t NI, int D, int kind, float* out);
 int orx_point_nwaves(int D, int64_t B);
 int orx_point_wparts(int D, int64_t B);
+bool orx_point_dense_tail_ok(int D);
+int orx_point_reducers(int D, int64_t B);
 int orx_launch_score_mfma(orx_ctx* ctx, const float* U, const float* V, const float* b, const float* w, const int32_t* uid,
                           int64_t nq, int64_t NU, int64_t NI, int D, int kind, float* out, bool* launched);
 

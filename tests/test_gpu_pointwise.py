@@ -180,3 +180,56 @@ def test_lazy_adam_is_the_dense_decay_adam(model, NU, NI, B, K, D, monkeypatch):
     for x, y in zip(got["lazy"], got["dense"]):       # (the same few rows amplify the replay's rounding)
         e = np.abs(x.astype(np.float64) - y).max(axis=1) / np.abs(y).max()
         assert (e > 1e-5).mean() <= 1e-3 and e.max() < 2e-3
+
+
+# ---- GMF's Dense(1) gradient reduced and applied by the last workgroups of the step's own launch (kernels_pointwise.hip dense_tail) ----
+def _gmf_run(optkind, U, V, b, w, uid, iid, lab, K):
+    from openrec_amd import runtime as rt
+    ctx = rt.Context(0)
+    tU, tV, tb, tw = (rt.Table(*x.shape, ctx).write(x) for x in (U, V, b, w))
+    kw = OPT_KW[optkind]
+    opt = {"sgd": lambda: rt.Optimizer.sgd(kw["lr"], ctx=ctx),
+           "adagrad": lambda: rt.Optimizer.adagrad(kw["lr"], kw["initial_accumulator_value"], kw["epsilon"], ctx=ctx),
+           "adam": lambda: rt.Optimizer.adam(kw["lr"], kw["beta_1"], kw["beta_2"], kw["epsilon"], ctx=ctx)}[optkind]()
+    B = uid.shape[1]
+    l, l2 = rt.pointwise_step("gmf", opt, tU, tV, tb, tw, uid.reshape(-1), iid.reshape(-1), lab.reshape(-1), K=K, B=B)
+    return dict(U=tU.read(), V=tV.read(), b=tb.read(), w=tw.read(), loss=np.asarray(l, np.float64), l2=np.asarray(l2, np.float64))
+
+
+@pytest.mark.parametrize("optkind", ["sgd", "adagrad", "adam"])
+@pytest.mark.parametrize("D,B", [(64, 65536), (64, 4095), (16, 70001), (32, 1000), (128, 40000), (256, 9000), (64, 300000), (64, 7)])
+def test_gmf_dense_gradient_inside_the_launch(optkind, D, B, monkeypatch):
+    """gmf.py:26-32: the Dense(1, use_bias=False) kernel is a dense variable -- its gradient is the sum over the WHOLE batch (+ the l2 term)
+    and the next step reads the updated kernel.  The float4 kernels sum it inside the step's launch: the last of 64 consecutive workgroups
+    adds their rows, the last of those adds the group rows and applies the rule.  Held here: (1) to the oracle, (2) to the two reduce
+    launches it replaced (ORX_POINT_NO_WTAIL=1), (3) to ITSELF run again, bit for bit -- which workgroup arrives last differs from run to
+    run, what it adds in which order must not.  Sizes: one workgroup, one group, 64 groups (the benchmark's B), the capped grid of 16 384
+    workgroups = 256 groups, a ragged last group."""
+    from oracle import numpy_oracle as orc
+    rng = np.random.default_rng(D + B)
+    NU, NI, K = B + 1000, B + 777, 4
+    U = rng.uniform(-.05, .05, (NU, D)).astype(np.float32); V = rng.uniform(-.05, .05, (NI, D)).astype(np.float32)
+    b = rng.uniform(-.05, .05, (NI, 1)).astype(np.float32); w = rng.uniform(-.3, .3, (D, 1)).astype(np.float32)
+    # every row referenced at most once per step: nothing but the Dense(1) sum is a sum over samples, so the whole step has to reproduce
+    # bit for bit (rows with many references take atomics on the generic paths; their order is not what this test is about)
+    uid = np.stack([rng.permutation(NU)[:B] for _ in range(K)]).astype(np.int32)
+    iid = np.stack([rng.permutation(NI)[:B] for _ in range(K)]).astype(np.int32)
+    lab = (rng.uniform(size=(K, B)) < 0.4).astype(np.float32)
+    monkeypatch.delenv("ORX_POINT_NO_WTAIL", raising=False)
+    got = _gmf_run(optkind, U, V, b, w, uid, iid, lab, K)
+    again = _gmf_run(optkind, U, V, b, w, uid, iid, lab, K)
+    monkeypatch.setenv("ORX_POINT_NO_WTAIL", "1")
+    launches = _gmf_run(optkind, U, V, b, w, uid, iid, lab, K)
+    monkeypatch.delenv("ORX_POINT_NO_WTAIL")
+    for k in ("w", "U", "V", "b", "loss", "l2"):
+        assert np.array_equal(got[k], again[k]), ("not reproducible", k)
+    oo = {"sgd": orc.SGD, "adagrad": orc.Adagrad, "adam": orc.AdamTFSparse}[optkind](**OPT_KW[optkind])
+    Uo, Vo, bo, wo = U.copy(), V.copy(), b.copy(), w.copy()
+    ls = [orc.gmf_step(Uo, Vo, bo, wo, uid[k], iid[k], lab[k], oo) for k in range(K)]
+    want = dict(U=Uo, V=Vo, b=bo, w=wo, loss=np.array([x[0] for x in ls]), l2=np.array([x[1] for x in ls]))
+    tol = TOL if optkind != "adam" else TOL_ADAM
+    for what, a, c in (("in-launch vs oracle", got, want), ("two launches vs oracle", launches, want), ("in-launch vs two launches", got, launches)):
+        for k in ("w", "U", "V", "b", "loss", "l2"):
+            assert rel_err(a[k], c[k]) < tol, (what, k, rel_err(a[k], c[k]))
+    # the kernel MOVED (the test cannot pass on a gradient that never reached w)
+    assert np.abs(got["w"] - w).max() > 0
