@@ -744,6 +744,13 @@ struct RowSrc {
     const float* Z; const float* emb; const int32_t* idx; int64_t rows; int* err;
     float* gdst;       // backward: the gradient of embedding slot f of sample b goes to row idx[b F + f] of this array instead of dZ
                        // (hybrid-parallel step: straight into the buffer that travels back to the rows' owners); NULL: dZ
+    int xcd;           // workgroup -> samples the way the fp16 products map tiles (orx_device.h xcd_slot): XCD x takes one contiguous eighth of
+                       // the batch, the eighth whose rows of R the top MLP's first product reads on the same XCD (and whose bottom-MLP
+                       // outputs were written there).  Measured (round 6, scripts/gpu_r6_u.sh): the C5 step 0.4364 against 0.4384 ms with the
+                       // round-robin order (ORX_INTERACT_NO_XCD=1), three alternating runs each; no launch of the trace moves by more than 1 %
+    __device__ __forceinline__ int64_t first_sample() const {
+        return (int64_t)(xcd ? xcd_slot((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * 4 + (threadIdx.x >> 6);
+    }
     __device__ __forceinline__ const float* row(int64_t b, int f, int F, int d) const {
         if (emb == nullptr || f == F - 1) return Z + (b * F + f) * d;
         const int r = idx[b * F + f];
@@ -755,7 +762,7 @@ struct RowSrc {
 __global__ __launch_bounds__(256) void interact_fwd_mfma_kernel(RowSrc src, int F, int d, int itself, float* R, int64_t B, int ldR,
                                                                 _Float16* R16, int ldR16) {
     const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t b = src.first_sample();
     if (b >= B) return;
     const int i = lane & 15, q = lane >> 4;
     const float* z0 = i < F ? src.row(b, i, F, d) : nullptr;
@@ -843,7 +850,7 @@ __global__ __launch_bounds__(256, OCC > 0 ? OCC : 1) void interact_bwd_mfma_kern
                                                                 int64_t B, int ldR, float scale, FusedRows fr) {
     constexpr int d = 16 * CPL * SPLIT;
     const int lane = threadIdx.x & 63;
-    const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wv = src.first_sample();
     const int64_t b = wv / SPLIT;
     const int coff = (int)(wv % SPLIT) * 16 * CPL;          // first column of this wavefront's share
     if (b >= B) return;
@@ -979,7 +986,8 @@ int orx_launch_interact(orx_ctx* ctx, bool fwd, const float* Z, const float* dR,
     const bool mfma = !compat && F <= 32 && d % 32 == 0 && ((uintptr_t)Z & 15) == 0 && getenv("ORX_INTERACT_SIMPLE") == nullptr;
     const bool bwd_ok = d == 32 || d == 64 || d == 128 || d == 256;
     ORX_ARG(emb == nullptr || (mfma && bwd_ok), "interact: direct table rows need the MFMA kernels");
-    const RowSrc src{Z, emb, idx, emb_rows, ctx->d_err, fwd ? nullptr : gdst};
+    static const bool no_xcd = getenv("ORX_INTERACT_NO_XCD") != nullptr;
+    const RowSrc src{Z, emb, idx, emb_rows, ctx->d_err, fwd ? nullptr : gdst, (!no_xcd && ((B + 3) / 4) % 8 == 0) ? 1 : 0};
     ORX_ARG(gdst == nullptr || (emb != nullptr && mfma && bwd_ok), "interact: a gradient destination needs the direct rows");
     if (mfma && (fwd || bwd_ok)) {
         const dim3 g((unsigned)((B + 3) / 4));

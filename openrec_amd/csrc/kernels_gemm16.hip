@@ -41,9 +41,7 @@ struct Nt16Args {
     unsigned long long* mask_out; const unsigned long long* mask_in;
 };
 
-// XCD-aware tile order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so id b -> slot
-// (b % 8) * (n / 8) + b / 8 hands every XCD a contiguous run of the row-major tile list
-__device__ __forceinline__ int xcd_slot(int b, int n) { return (n & 7) ? b : (b & 7) * (n >> 3) + (b >> 3); }
+// (XCD-aware tile order: xcd_slot, orx_device.h)
 
 // the products' common epilogue: + bias, activation, stores, or the fused activation backward with its column sums (see the head
 // of the file); `red` = LDS that is free once the main loop is over, [WM][BN] floats

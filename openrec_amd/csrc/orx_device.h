@@ -39,6 +39,10 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
+// XCD-aware tile order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so id b -> slot
+// (b % 8) * (n / 8) + b / 8 hands every XCD a contiguous run of the row-major tile list
+__device__ __forceinline__ int xcd_slot(int b, int n) { return (n & 7) ? b : (b & 7) * (n >> 3) + (b >> 3); }
+
 __device__ __forceinline__ float dot4(f4 a, f4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
 __device__ __forceinline__ void atomic_add_f4(float* p, f4 v) {
