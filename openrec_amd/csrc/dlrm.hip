@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "orx_internal.h"
+#include "orx_csr_device.h"
 
 #define CHECK(call)                                                                    \
     do {                                                                               \
@@ -523,7 +524,7 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
 // SGD / Adagrad / Adam (lr_t of the step) on every dense parameter in one launch (gradients in the tables' gsum).
 // fused (fp16 mode, orx_dlrm_step): the launch also adds the split-K slices of the weight gradients that mlp_backward left in
 // the slab workspaces (no slab_reduce launches) and writes the fp16 copies of the new kernels (no dense_shadow launch).
-static int dense_apply_all(orx_dlrm* m, orx_opt* opt, float lr_t = 0.f, bool fused = false, float slab_scale = 1.0f) {
+static int dense_apply_all(orx_dlrm* m, orx_opt* opt, float lr_t = 0.f, bool fused = false, float slab_scale = 1.0f, const CsrFinish* finish = nullptr) {
     orx_ctx* c = m->ctx;
     if (fused) {
         if (m->fused_opt != opt) {
@@ -573,8 +574,8 @@ static int dense_apply_all(orx_dlrm* m, orx_opt* opt, float lr_t = 0.f, bool fus
         }
         m->pending_coljobs.clear();
         if (!rest.empty()) CHECK(orx_launch_colparts_reduce(c, rest.data(), (int)rest.size()));
-        if (opt->kind == ORX_ADAM) CHECK(orx_launch_dense_apply_fused(c, m->d_fused, m->fused_tt, m->fused_tiles, ORX_ADAM, lr_t, opt->p2, opt->p0, opt->p1, slab_scale));
-        else CHECK(orx_launch_dense_apply_fused(c, m->d_fused, m->fused_tt, m->fused_tiles, opt->kind, opt->lr, opt->p1, 0.f, 0.f, slab_scale));
+        if (opt->kind == ORX_ADAM) CHECK(orx_launch_dense_apply_fused(c, m->d_fused, m->fused_tt, m->fused_tiles, ORX_ADAM, lr_t, opt->p2, opt->p0, opt->p1, slab_scale, finish));
+        else CHECK(orx_launch_dense_apply_fused(c, m->d_fused, m->fused_tt, m->fused_tiles, opt->kind, opt->lr, opt->p1, 0.f, 0.f, slab_scale, finish));
         for (int k = 0; k < 2; ++k) for (auto& D : (k == 0 ? m->bot : m->top)) { D.W->version += 1; D.b->version += 1; D.shadow_version = D.W->version; }
         return ORX_OK;
     }
@@ -919,6 +920,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         CHECK(orx_launch_cast16(c, dense, m->dense_dim, m->dense16_all, m->ld_dense16, (int)(K * B), m->dense_dim));
     }
     struct Restore { orx_dlrm* m; ~Restore() { m->dense16_cur = nullptr; m->cur_hl = nullptr; m->fuse_single = nullptr; m->fuse_opt = nullptr; } } restore{m};
+    static const bool no_carry = getenv("ORX_DLRM_FINISH_LAUNCH") != nullptr;
     for (int64_t s = 0; s < K; ++s) {
         m->dense16_cur = cast_all ? (const char*)m->dense16_all + (size_t)s * B * m->ld_dense16 * 2 : nullptr;
         if ((planned || sorted_apply) && s % PC == 0) {
@@ -956,6 +958,11 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         if (!fold_loss) CHECK(orx_launch_dlrm_loss(c, pred, bt.label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, m->d_loss + s, 0, 0, gscale));
         m->cur_hl = fold_loss ? &hl : nullptr; m->hl_used = false;
         const bool fuse_dense = m->gen2 && getenv("ORX_DLRM_NO_FUSED_DENSE") == nullptr;
+        // (round 6) SGD / Adagrad with the fused dense optimizer launch behind it: the sorted apply's finish pass rides in THAT launch (kernels_dense.hip
+        // dense_apply_fused_kernel) instead of being the step's 24th.  ORX_DLRM_FINISH_LAUNCH=1: its own launch
+        CsrFinish fin;
+        memset(&fin, 0, sizeof(fin));
+        const bool carry_finish = fuse_dense && sorted_apply && !lazy_adam && (opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD) && !no_carry;
         m->fuse_single = fuse_rows ? m->d_single + (s % PC) * B * F : nullptr; m->fuse_opt = opt;
         const int rc_bwd = backward(m, bt, B, gscale, fuse_dense);
         const bool rows_fused = m->fuse_single != nullptr && m->direct_idx != nullptr;      // (backward applied them: see there)
@@ -975,6 +982,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         if (sorted_apply) {
             if (lazy_adam) CHECK(orx_adam_rows_sorted(c, opt, m->emb, sorted_s, B * F, m->dZ, d, true));
             else if (opt->kind == ORX_ADAM) CHECK(orx_adam_dense_sorted(c, opt, m->emb, sorted_s, B * F, m->dZ, d));
+            else if (carry_finish) CHECK(orx_csr_apply_split(c, opt, m->emb, sorted_s, B * F, m->dZ, d, rows_fused, &fin));
             else CHECK(orx_csr_apply(c, opt, m->emb, sorted_s, B * F, m->dZ, d, rows_fused));
         } else if (planned) {
             CHECK(orx_apply_rows_planned_step(c, opt, m->emb, nullptr, rp, s % PC, idx_s, m->dZ, d));
@@ -992,7 +1000,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
         } else {
             CHECK(orx_apply_rows(c, opt, m->emb, nullptr, m->d_idx, B * F, m->dZ, d));
         }
-        CHECK(dense_apply_all(m, opt, lr_t, fuse_dense, 1.0f / gscale));
+        CHECK(dense_apply_all(m, opt, lr_t, fuse_dense, 1.0f / gscale, fin.blocks > 0 ? &fin : nullptr));
     }
     if (fold_loss) CHECK(orx_launch_head_loss_finish(c, m->d_loss_part, nb_loss, nb_loss, K, B, m->d_loss));
     if (loss_out) {

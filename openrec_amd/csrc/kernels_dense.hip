@@ -4,7 +4,8 @@
 // feature interaction (modules/second_order_feature_interaction.py:12-34,
 // forward and backward, with the reference's triangle bug as an option), the
 // loss (MSE / BCE on probabilities, Keras semantics) and index helpers.
-#include "orx_device.h"
+#include <cstring>
+#include "orx_csr_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -1157,14 +1158,35 @@ int orx_launch_dense_apply_multi(orx_ctx* ctx, const DenseParam* ps_dev, int cou
 // order, 8 in flight), the optimizer rule, g re-zeroed, and the fp16 copies of the new weights -- w16 row-major straight from the
 // registers, w16t through an LDS transpose.
 constexpr int DF_ROWS = 16;
+// (round 6) The first `fin.blocks` workgroups of the launch are not tiles of a dense parameter: they finish the embedding table's sorted apply -- the
+// runs of equal rows that cross a 64-entry block, csr_finish_block (orx_csr_device.h), until now a launch of its own between csr_apply_kernel and
+// this one (6.8 us + a launch gap of the C5 step for a few hundred wavefronts with work).  Neither side reads what the other writes; first in the
+// grid, their short dependent chains run under the whole launch.
+template <int MODE>
+__device__ __forceinline__ void csr_finish_any(const CsrArgs& a, int64_t b, int lane) {
+    switch ((a.D + 63) / 64) {
+        case 1: csr_finish_block<1, MODE>(a, b, lane); break;
+        case 2: csr_finish_block<2, MODE>(a, b, lane); break;
+        case 3: csr_finish_block<3, MODE>(a, b, lane); break;
+        default: csr_finish_block<4, MODE>(a, b, lane); break;
+    }
+}
+
 __global__ __launch_bounds__(256) void dense_apply_fused_kernel(const DenseFused* ps, DenseFusedTiles tt, int optkind, float lr, float eps, float b1, float b2,
-                                                                float slab_scale) {
+                                                                float slab_scale, CsrFinish fin) {
+    if ((int)blockIdx.x < fin.blocks) {
+        const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (fin.mode == CSR_SGD) csr_finish_any<CSR_SGD>(fin.a, b, threadIdx.x & 63);
+        else csr_finish_any<CSR_ADAGRAD>(fin.a, b, threadIdx.x & 63);
+        return;
+    }
+    const int bx = (int)blockIdx.x - fin.blocks;
     __shared__ _Float16 tr[DF_ROWS][64 + 2];
     __shared__ float cseg[4][64];
     int pi = 0;                                              // (the tile table travels in the kernel arguments: scalar loads, no dependent memory chain)
-    while (pi + 1 < tt.count && (int)blockIdx.x >= tt.tile0[pi + 1]) ++pi;
+    while (pi + 1 < tt.count && bx >= tt.tile0[pi + 1]) ++pi;
     const DenseFused p = ps[pi];
-    const int t = blockIdx.x - p.tile0;
+    const int t = bx - p.tile0;
     const int r0 = (t / p.tiles_x) * DF_ROWS, c0 = (t % p.tiles_x) * 64;
     // a vector parameter's gradient in partial rows (bias gradients, the 1-unit head's weight gradient): the tile's <= 64 elements are
     // summed exactly as colparts_reduce_kernel does it -- wavefront w takes the w-th quarter of the P rows in order, 8 loads in
@@ -1273,9 +1295,13 @@ __global__ __launch_bounds__(256) void dense_apply_fused_kernel(const DenseFused
 }
 
 int orx_launch_dense_apply_fused(orx_ctx* ctx, const DenseFused* ps_dev, const DenseFusedTiles& tt, int total_tiles, int optkind, float lr, float eps,
-                                 float b1, float b2, float slab_scale) {
-    if (tt.count == 0 || total_tiles == 0) return ORX_OK;
-    ORX_LAUNCH(ctx, dense_apply_fused_kernel, dim3((unsigned)total_tiles), dim3(256), 0, ps_dev, tt, optkind, lr, eps, b1, b2, slab_scale);
+                                 float b1, float b2, float slab_scale, const CsrFinish* finish) {
+    CsrFinish fin;
+    memset(&fin, 0, sizeof(fin));
+    if (finish != nullptr) fin = *finish;
+    if ((tt.count == 0 || total_tiles == 0) && fin.blocks == 0) return ORX_OK;
+    ORX_ARG(fin.blocks == 0 || fin.mode == CSR_SGD || fin.mode == CSR_ADAGRAD, "dense_apply_fused: the finish pass it carries is SGD / Adagrad");
+    ORX_LAUNCH(ctx, dense_apply_fused_kernel, dim3((unsigned)(total_tiles + fin.blocks)), dim3(256), 0, ps_dev, tt, optkind, lr, eps, b1, b2, slab_scale, fin);
     ORX_HIP(hipGetLastError());
     return ORX_OK;
 }

@@ -13,7 +13,7 @@
 // take the same path.  HBM-bound: the gradient rows are read once, every distinct table row is read and written once.
 #include <cstring>
 
-#include "orx_device.h"
+#include "orx_csr_device.h"
 
 namespace {
 
@@ -133,69 +133,6 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(SortArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------ segmented sums + rule
-enum { CSR_SGD = 0, CSR_ADAGRAD = 1, CSR_ADAM = 2, CSR_ACCUM = 3 };
-
-struct CsrArgs {
-    const uint2* sorted; int64_t n; uint32_t rows; int D;
-    const float* grads; int64_t g_stride;
-    float* W; float* A; float* V; int* last; float* G;      // table; Adagrad acc / Adam m; Adam v; lazy stamps; gsum (ACCUM)
-    float lr, eps, b1, b2, lr_T; const float* lrt; int T, newton; AdamCFParams cf;
-    float* part_lo; float* part_hi;                          // [blocks][Dp]: sums of the runs open at a block's start / end
-    int Dp;
-    int skip_single;                                         // rows referenced once are NOT applied here: the kernel that formed their
-                                                             // gradient updated them in place (orx_rows_single_flags, interact_bwd_mfma_kernel)
-};
-
-// the row's state, loaded together with the gradient rows (no dependent round trip when the rule is applied)
-template <int NE, int MODE>
-struct RowState {
-    float w[NE], a[NE], v[NE]; int last;
-    __device__ __forceinline__ void load(const CsrArgs& c, uint32_t row, int lane) {
-        const bool live = row < c.rows;
-        last = 0;
-        if (MODE == CSR_ADAM) last = live ? c.last[row] : 0;
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int col = lane + 64 * e;
-            const size_t i = (size_t)row * c.D + col;
-            const bool ok = live && col < c.D;
-            w[e] = a[e] = v[e] = 0.0f;
-            if (MODE == CSR_ACCUM) { if (ok) w[e] = c.G[i]; continue; }
-            if (ok) w[e] = c.W[i];
-            if (MODE == CSR_ADAGRAD || MODE == CSR_ADAM) { if (ok) a[e] = c.A[i]; }
-            if (MODE == CSR_ADAM) { if (ok) v[e] = c.V[i]; }
-        }
-    }
-};
-
-// the optimizer rule on row `row` with the summed gradient s[e] of column lane + 64 e
-template <int NE, int MODE>
-__device__ __forceinline__ void csr_rule(const CsrArgs& a, uint32_t row, const float (&s)[NE], const RowState<NE, MODE>& st, int lane) {
-    int from = 0;
-    if (MODE == CSR_ADAM) from = __builtin_amdgcn_readfirstlane(st.last);
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const int col = lane + 64 * e;
-        if (col >= a.D) continue;
-        const size_t i = (size_t)row * a.D + col;
-        if (MODE == CSR_SGD) a.W[i] = st.w[e] - a.lr * s[e];
-        else if (MODE == CSR_ADAGRAD) {
-            const float acc = st.a[e] + s[e] * s[e];
-            a.A[i] = acc;
-            a.W[i] = st.w[e] - a.lr * s[e] / (sqrtf(acc) + a.eps);
-        }
-        else if (MODE == CSR_ACCUM) a.G[i] = st.w[e] + s[e];
-        else {
-            float w = st.w[e], m = st.a[e], v = st.v[e];
-            adam_replay1<true>(w, m, v, from, a.T - 1, a.lrt, a.b1, a.b2, a.eps, a.newton != 0, a.cf);
-            adam_elem(w, m, v, s[e], a.lr_T, a.b1, a.b2, a.eps);
-            a.W[i] = w; a.A[i] = m; a.V[i] = v;
-        }
-    }
-    if (MODE == CSR_ADAM && lane == 0) a.last[row] = a.T;
-}
-
 template <int NE, int MODE>
 __global__ __launch_bounds__(256) void csr_apply_kernel(CsrArgs a) {
     const int lane = threadIdx.x & 63;
@@ -266,43 +203,10 @@ __global__ __launch_bounds__(256) void csr_apply_kernel(CsrArgs a) {
     flush();
 }
 
-// runs that cross block boundaries: the wavefront of the block a run STARTS in adds the partial sums in block order
+// runs that cross block boundaries (csr_finish_block, orx_csr_device.h) as a launch of their own
 template <int NE, int MODE>
 __global__ __launch_bounds__(256) void csr_finish_kernel(CsrArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), i0 = b * 64;
-    if (i0 + 64 >= a.n) return;                              // the last block's runs end in it
-    const uint32_t row = a.sorted[i0 + 63].x;
-    if (row >= a.rows || a.sorted[i0 + 64].x != row) return;           // the block's last run ends here
-    if (a.sorted[i0].x == row && b > 0 && a.sorted[i0 - 1].x == row) return;   // ... or started in an earlier block
-    // how many blocks the run continues into: lane l looks at the first key of block b + 2 + l (64 blocks per round)
-    int64_t last = b + 1;                                    // the last block that holds a piece of the run
-    for (;;) {
-        const int64_t nx = (last + 1 + lane) * 64;
-        const bool cont = nx < a.n && a.sorted[nx].x == row;
-        const unsigned long long m = __ballot(cont);
-        const int run = m == ~0ull ? 64 : __builtin_ctzll(~m);         // consecutive continuing blocks
-        last += run;
-        if (run < 64) break;
-    }
-    float s[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) s[e] = lane + 64 * e < a.D ? a.part_hi[(size_t)b * a.Dp + lane + 64 * e] : 0.0f;
-    constexpr int UN = 8;
-    for (int64_t c0 = b + 1; c0 <= last; c0 += UN) {         // UN partial rows in flight, added in block order
-        float q[UN][NE];
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-#pragma unroll
-            for (int e = 0; e < NE; ++e) q[u][e] = (c0 + u <= last && lane + 64 * e < a.D) ? a.part_lo[(size_t)(c0 + u) * a.Dp + lane + 64 * e] : 0.0f;
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-#pragma unroll
-            for (int e = 0; e < NE; ++e) if (c0 + u <= last) s[e] += q[u][e];
-    }
-    RowState<NE, MODE> st;
-    st.load(a, row, lane);
-    csr_rule<NE, MODE>(a, row, s, st, lane);
+    csr_finish_block<NE, MODE>(a, (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 // lazy Adam: every distinct row of the list is replayed to step T before a forward pass reads it
@@ -323,15 +227,16 @@ __global__ __launch_bounds__(256) void csr_touch_kernel(CsrArgs a) {
     if (lane == 0) a.last[row] = a.T;
 }
 
+// finish == false: the first launch only (the caller has the finish pass carried by another launch: orx_csr_apply_split)
 template <int MODE>
-int launch_csr(orx_ctx* ctx, const CsrArgs& a) {
+int launch_csr(orx_ctx* ctx, const CsrArgs& a, bool finish = true) {
     const int64_t nblk = (a.n + 63) / 64;
     const dim3 g((unsigned)((nblk + 3) / 4));
     const int ne = (a.D + 63) / 64;
 #define ORX_CSR_GO(NE)                                                                  \
     do {                                                                                \
         ORX_LAUNCH(ctx, (csr_apply_kernel<NE, MODE>), g, dim3(256), 0, a);              \
-        ORX_LAUNCH(ctx, (csr_finish_kernel<NE, MODE>), g, dim3(256), 0, a);             \
+        if (finish) ORX_LAUNCH(ctx, (csr_finish_kernel<NE, MODE>), g, dim3(256), 0, a); \
     } while (0)
     switch (ne) {
         case 1: ORX_CSR_GO(1); break;
@@ -442,6 +347,28 @@ int orx_csr_apply(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted,
         return launch_csr<CSR_ADAGRAD>(ctx, a);
     }
     return launch_csr<CSR_SGD>(ctx, a);
+}
+
+int orx_csr_apply_split(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride,
+                        bool skip_single, CsrFinish* finish) {
+    memset(finish, 0, sizeof(*finish));
+    if (n == 0) return ORX_OK;
+    ORX_ARG(opt->kind == ORX_SGD || opt->kind == ORX_ADAGRAD, "csr_apply: SGD / Adagrad (Adam: orx_csr_adam_apply)");
+    ProfScope ps(ctx, ORX_K_DUPAPPLY);
+    CsrArgs a;
+    if (int rc = csr_args(ctx, t, sorted, n, grads, g_stride, &a)) return rc;
+    a.lr = opt->lr; a.skip_single = skip_single ? 1 : 0;
+    int rc;
+    if (opt->kind == ORX_ADAGRAD) {
+        OptSlots st;
+        if (int rc2 = orx_opt_slots(opt, t, &st)) return rc2;
+        a.A = st.s0; a.eps = opt->p1;
+        rc = launch_csr<CSR_ADAGRAD>(ctx, a, false);
+    } else rc = launch_csr<CSR_SGD>(ctx, a, false);
+    if (rc != ORX_OK) return rc;
+    finish->a = a; finish->mode = opt->kind == ORX_ADAGRAD ? CSR_ADAGRAD : CSR_SGD;
+    finish->blocks = (int)(((n + 63) / 64 + 3) / 4);
+    return ORX_OK;
 }
 
 // gsum[row] += sum of the row's gradient rows (the whole-table-sweep form of TF-2.0 Adam follows with its sweep)

@@ -496,8 +496,12 @@ struct DenseFused {
 };
 // first tile of every parameter, and how many partial rows its gradient has THIS step (0: none) -- kernel arguments
 struct DenseFusedTiles { int count; int tile0[48]; int cP[48]; };
+struct CsrFinish;       // (orx_csr_device.h) the sorted sparse apply's finish pass, carried by the dense optimizer's launch
 int orx_launch_dense_apply_fused(orx_ctx* ctx, const DenseFused* ps_dev, const DenseFusedTiles& tt, int total_tiles, int optkind, float lr, float eps,
-                                 float b1, float b2, float slab_scale);
+                                 float b1, float b2, float slab_scale, const CsrFinish* finish = nullptr);
+// orx_csr_apply without its second launch: the blocks' sums + rule are launched, the finish pass is DESCRIBED (*finish) for a launch that takes it along
+int orx_csr_apply_split(orx_ctx* ctx, orx_opt* opt, orx_table* t, const uint2* sorted, int64_t n, const float* grads, int64_t g_stride,
+                        bool skip_single, CsrFinish* finish);
 // Column sums (bias gradients) leave their producers as one partial row per row block -- parts[p * N + c], plain stores --
 // and one colparts_reduce launch per MLP backward adds the blocks in order: no fp32 atomics, reproducible sums.
 struct ColPart { float* parts = nullptr; int P = 0; };        // in: the workspace; out: row blocks written
