@@ -87,7 +87,7 @@ struct orx_dlrm {
     const unsigned char* fuse_single = nullptr; orx_opt* fuse_opt = nullptr;
     // the loss folded into the head's backward (orx_dlrm_step, fp16 mode with the 1-unit head kernels): set for the backward of the
     // current step; `hl_used` says the head branch took it
-    double* d_loss_part = nullptr; int64_t loss_part_cap = 0; const HeadLoss* cur_hl = nullptr; bool hl_used = false;
+    double* d_loss_part = nullptr; int64_t loss_part_cap = 0; const HeadLoss* cur_hl = nullptr; bool hl_used = false; bool head_fwd_in_bwd = false;
     // fp16 copies of the dense features of ALL steps of a call (ids on the device: one cast launch per call instead of one per step)
     void* dense16_all = nullptr; int64_t dense16_all_cap = 0; const void* dense16_cur = nullptr;
     int32_t* d_sparse_all = nullptr; int64_t sparse_all_cap = 0;
@@ -504,8 +504,10 @@ static int forward(orx_dlrm* m, const Batch& bt, int64_t B, const float* emb_row
         const bool last = l + 1 == m->top.size();
         if (f16 && have16) {            // X16 * W16T: fp16-resident operands, fp16 copy of the output for the next layer
             void* y16 = last ? nullptr : m->top_y16[l];
-            if (L.head)
-                CHECK(orx_launch_head_fwd(c, x16, ldx16, L.w16t, L.b->w, L.act, m->top_y[l], (int)B, L.in));
+            if (L.head) {
+                // (round 6) inside orx_dlrm_step with the loss folded into the head's backward, that kernel runs the head's forward too: no launch here
+                if (!m->head_fwd_in_bwd) CHECK(orx_launch_head_fwd(c, x16, ldx16, L.w16t, L.b->w, L.act, m->top_y[l], (int)B, L.in));
+            }
             else if (m->gen2 && orx_gemm16_nt_ok(ldx16, L.ld16t, L.out, L.in))
                 CHECK(orx_launch_gemm16_nt(c, x16, ldx16, L.w16t, L.ld16t, L.lean ? nullptr : m->top_y[l], L.out, y16, up8(L.out), L.b->w, (int)B, L.out, L.in, L.act,
                                            nullptr, nullptr, 0, 0, nullptr, mask_for(m->top[l], B)));
@@ -921,6 +923,7 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
     }
     struct Restore { orx_dlrm* m; ~Restore() { m->dense16_cur = nullptr; m->cur_hl = nullptr; m->fuse_single = nullptr; m->fuse_opt = nullptr; } } restore{m};
     static const bool no_carry = getenv("ORX_DLRM_FINISH_LAUNCH") != nullptr;
+    static const bool head_fwd_launch = getenv("ORX_DLRM_HEAD_FWD_LAUNCH") != nullptr;
     for (int64_t s = 0; s < K; ++s) {
         m->dense16_cur = cast_all ? (const char*)m->dense16_all + (size_t)s * B * m->ld_dense16 * 2 : nullptr;
         if ((planned || sorted_apply) && s % PC == 0) {
@@ -950,11 +953,18 @@ extern "C" int orx_dlrm_step(orx_dlrm* m, orx_opt* opt, const float* dense, cons
                 CHECK(orx_table_sync(m->emb));
             }
         }
-        CHECK(forward(m, bt, B, nullptr, idx_s, lazy_adam));
+        // (round 6) with the loss folded into the head's backward, that launch also runs the head's FORWARD (one pass over the layer below's
+        // output instead of two): the forward pass below skips its head launch.  ORX_DLRM_HEAD_FWD_LAUNCH=1: head_fwd_kernel as before
+        const bool head_in_bwd = fold_loss && !head_fwd_launch;
+        m->head_fwd_in_bwd = head_in_bwd;
+        const int rc_fwd = forward(m, bt, B, nullptr, idx_s, lazy_adam);
+        m->head_fwd_in_bwd = false;
+        CHECK(rc_fwd);
         float* pred = m->top_y.back();
         // loss + dLoss/dP  (dlrm.py:72-73, :97-98)
         const float gscale = loss_scale(m, B);
-        HeadLoss hl{bt.label, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, B, gscale, fold_loss ? m->d_loss_part + s * nb_loss : nullptr};
+        HeadLoss hl{bt.label, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, B, gscale, fold_loss ? m->d_loss_part + s * nb_loss : nullptr,
+                    head_in_bwd ? m->top.back().b->w : nullptr, head_in_bwd ? pred : nullptr};
         if (!fold_loss) CHECK(orx_launch_dlrm_loss(c, pred, bt.label, B, (m->flags & ORX_DLRM_LOSS_BCE) ? 1 : 0, m->thr, m->gA, m->d_loss + s, 0, 0, gscale));
         m->cur_hl = fold_loss ? &hl : nullptr; m->hl_used = false;
         const bool fuse_dense = m->gen2 && getenv("ORX_DLRM_NO_FUSED_DENSE") == nullptr;

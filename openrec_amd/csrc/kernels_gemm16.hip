@@ -1251,6 +1251,9 @@ struct HeadBwdArgs {
     // round 6: the loss folded in (label != NULL; no dlrm_loss_kernel launch in the step) -- dy is formed here from pred and the label
     // (dlrm.py:72-73, :97-98; the formulas of dlrm_loss_kernel), the loss terms leave as one fp64 partial per workgroup
     const float* label; int bce; float thr, invB, gscale; double* loss_part;
+    // ... and the head's FORWARD too (fwd_bias != NULL; no head_fwd_kernel launch in the step): the row is read once, pred[b] is formed as
+    // head_fwd_kernel forms it (same lanes, same order of additions) and written to pred_out
+    const float* fwd_bias; float* pred_out;
 };
 
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
@@ -1271,8 +1274,37 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
         if (c * 8 < a.K) wv[j] = *reinterpret_cast<const h8*>(a.w + c * 8);
     }
     float gb = 0.0f;
+    h8 xn[HEAD_J];                                                 // the NEXT row of this half-wavefront, requested one iteration ahead (the forward
+    auto request = [&](int row) {                                  // inside makes a row's chain load -> reduce -> gradients: nothing else hides its load)
+#pragma unroll
+        for (int j = 0; j < HEAD_J; ++j) {
+            const int c = l32 + 32 * j;
+            if (c * 8 < a.K && row < r1) xn[j] = *reinterpret_cast<const h8*>(a.X + (int64_t)row * a.ldx + c * 8);
+        }
+    };
+    request(r0 + hw);
     for (int row = r0 + hw; row < r1; row += 8) {
-        float p = a.pred[row];
+        h8 xr[HEAD_J];                                             // the row: the forward's operand and the backward's
+#pragma unroll
+        for (int j = 0; j < HEAD_J; ++j) xr[j] = xn[j];
+        request(row + 8);
+        float p;
+        if (a.fwd_bias != nullptr) {
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < HEAD_J; ++j) {
+                if ((l32 + 32 * j) * 8 >= a.K) continue;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float)xr[j][e] * (float)wv[j][e];
+            }
+            s = group_allreduce<32>(s);
+            float v = s + a.fwd_bias[0];
+            if (a.act == 1) v = fmaxf(v, 0.0f); else if (a.act == 2) v = 1.0f / (1.0f + __expf(-v));
+            if (l32 == 0) a.pred_out[row] = v;
+            p = v;
+        } else {
+            p = a.pred[row];
+        }
         float dz;
         if (a.label != nullptr) {
             float mask = 1.0f;
@@ -1304,7 +1336,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
         for (int j = 0; j < HEAD_J; ++j) {
             const int c = l32 + 32 * j;
             if (c * 8 >= a.K) continue;
-            const h8 x = *reinterpret_cast<const h8*>(a.X + (int64_t)row * a.ldx + c * 8);
+            const h8 x = xr[j];
             h8 o;
             float o32[8];
 #pragma unroll
@@ -1396,7 +1428,9 @@ int orx_launch_head_bwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* 
     rows = (rows + 7) / 8 * 8;
     gW->P = gb->P = gb_below->P = (B + rows - 1) / rows;
     HeadBwdArgs a{(const _Float16*)X16, ldx, (const _Float16*)w16, dy, pred, act, act_below, gW->parts, gb->parts, (_Float16*)dZ16, ld16, dZ32, ld32, gb_below->parts, B, K, rows,
-                  hl ? hl->label : nullptr, hl ? hl->bce : 0, hl ? hl->thr : 0.f, hl ? 1.0f / (float)hl->n_mean : 0.f, hl ? hl->gscale : 1.f, hl ? hl->loss_part : nullptr};
+                  hl ? hl->label : nullptr, hl ? hl->bce : 0, hl ? hl->thr : 0.f, hl ? 1.0f / (float)hl->n_mean : 0.f, hl ? hl->gscale : 1.f, hl ? hl->loss_part : nullptr,
+                  hl ? hl->fwd_bias : nullptr, hl ? hl->pred_out : nullptr};
+    ORX_ARG(a.fwd_bias == nullptr || a.pred_out != nullptr, "head_bwd: the folded forward needs a place for pred");
     ORX_LAUNCH(ctx, head_bwd_kernel, dim3((unsigned)((B + rows - 1) / rows)), dim3(256), 0, a);
     ORX_HIP(hipGetLastError());
     return ORX_OK;

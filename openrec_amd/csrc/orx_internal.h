@@ -542,7 +542,8 @@ bool orx_head16_ok(int K, int64_t ldx);
 int orx_launch_head_fwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* bias, int act, float* pred, int B, int K);
 // hl != NULL: the loss is folded into the head's backward (no dlrm_loss_kernel launch): dy is formed from pred and the label, the loss
 // terms leave as one fp64 partial per workgroup in loss_part[0 .. orx_head_bwd_blocks(B))
-struct HeadLoss { const float* label; int bce; float thr; int64_t n_mean; float gscale; double* loss_part; };
+struct HeadLoss { const float* label; int bce; float thr; int64_t n_mean; float gscale; double* loss_part;
+                  const float* fwd_bias; float* pred_out; };       // fwd_bias != NULL: head_bwd_kernel runs the head's forward as well (pred -> pred_out)
 int orx_launch_head_bwd(orx_ctx* ctx, const void* X16, int64_t ldx, const void* w16, const float* dy, const float* pred, int act, int act_below,
                         ColPart* gW, ColPart* gb, void* dZ16, int64_t ld16, float* dZ32, int64_t ld32, ColPart* gb_below, int B, int K,
                         const HeadLoss* hl = nullptr);
