@@ -856,6 +856,26 @@ __global__ __launch_bounds__(256, OCC > 0 ? OCC : 1) void interact_bwd_mfma_kern
     const int coff = (int)(wv % SPLIT) * 16 * CPL;          // first column of this wavefront's share
     if (b >= B) return;
     const int i = lane & 15, q = lane >> 4;
+    // (round 6: the sample's rows are requested BEFORE its dR row goes through LDS -- behind the wavefront fence below the compiler could not hoist them, and the
+    // two round trips were taken one after the other: 68.8-69.2 -> 67.2 us at the C5 shapes)
+    // (tried: lane i taking columns (t / 4) * 64 + 4 i + t % 4, so that a 16-byte access of sixteen lanes covers 256 contiguous bytes instead
+    // of every other 16 bytes of 512 -- 72.1 against 68.8 us, no gain)
+    float zr[8][CPL];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int k = 4 * s + q;
+#pragma unroll
+        for (int c4 = 0; c4 < CPL; c4 += 4) {
+            f32x4 v; v.x = v.y = v.z = v.w = 0.0f;
+            const float* zk = k < F ? src.row(b, k, F, d) : nullptr;
+            if (zk) {
+                if (CPL >= 4) v = *reinterpret_cast<const f32x4*>(zk + coff + CPL * i + c4);
+                else { v.x = zk[coff + CPL * i]; v.y = zk[coff + CPL * i + 1]; }
+            }
+            zr[s][c4] = v.x; if (c4 + 1 < CPL) zr[s][c4 + 1] = v.y;
+            if (c4 + 2 < CPL) zr[s][c4 + 2] = v.z; if (c4 + 3 < CPL) zr[s][c4 + 3] = v.w;
+        }
+    }
     // the sample's dR row goes through LDS: two coalesced 16-byte loads per lane instead of the sixteen 4-byte gathers that build
     // the A operand (each a wavefront instruction with 64 different addresses)
     extern __shared__ __attribute__((aligned(16))) float dr_lds[];
@@ -878,24 +898,6 @@ __global__ __launch_bounds__(256, OCC > 0 ? OCC : 1) void interact_bwd_mfma_kern
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int s = 0; s < 8; ++s) sa[ti][s] = sval(16 * ti + i, 4 * s + q);
-    // (tried: lane i taking columns (t / 4) * 64 + 4 i + t % 4, so that a 16-byte access of sixteen lanes covers 256 contiguous bytes instead
-    // of every other 16 bytes of 512 -- 72.1 against 68.8 us, no gain)
-    float zr[8][CPL];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int k = 4 * s + q;
-#pragma unroll
-        for (int c4 = 0; c4 < CPL; c4 += 4) {
-            f32x4 v; v.x = v.y = v.z = v.w = 0.0f;
-            const float* zk = k < F ? src.row(b, k, F, d) : nullptr;
-            if (zk) {
-                if (CPL >= 4) v = *reinterpret_cast<const f32x4*>(zk + coff + CPL * i + c4);
-                else { v.x = zk[coff + CPL * i]; v.y = zk[coff + CPL * i + 1]; }
-            }
-            zr[s][c4] = v.x; if (c4 + 1 < CPL) zr[s][c4 + 1] = v.y;
-            if (c4 + 2 < CPL) zr[s][c4 + 2] = v.z; if (c4 + 3 < CPL) zr[s][c4 + 3] = v.w;
-        }
-    }
     // FUSE: which of the sample's lookups are applied here (bit g of the wavefront-uniform mask) and their rows
     unsigned fmask = 0u; int myrow = -1;
     if (FUSE) {
