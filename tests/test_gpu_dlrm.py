@@ -404,6 +404,7 @@ def test_dlrm_fp16_staging_forms_are_bit_identical():
              {"ORX_DLRM_COLPARTS_LAUNCH": "1"},            # the partial-row sums added by the optimizer launch vs a reduce launch
              {"ORX_DLRM_FINISH_LAUNCH": "1"},              # the sorted apply's finish pass as a launch of its own vs carried by the optimizer launch
              {"ORX_DLRM_HEAD_FWD_LAUNCH": "1"},            # the head's forward as a launch of its own vs inside the head's backward launch
+             {"ORX_INTERACT_NO_XCD": "1"},                 # the interaction kernels' samples dealt round-robin to the XCDs vs in contiguous eighths
              {"ORX_GEMM16_NO_MASK": "1"},                  # relu' from the fp16 output itself instead of the forward launch's mask words
              {"ORX_DLRM_NO_PAD_DX": "1"},                  # the first top layer's input gradient on its 479 columns instead of 480
              {"ORX_DLRM_DEFER_DW": "1"},                   # the top MLP's weight gradients beside the interaction backward (side stream; measured slower: off)
